@@ -1,0 +1,158 @@
+// TEST INFRASTRUCTURE ONLY (oracle).  ctypes-facing C entry points of the CPU
+// restatement; imported by tests/, __graft_entry__.smoke() and bench.py's
+// cpu_baseline leg only.
+#include <chrono>
+#include <cstdio>
+#include <thread>
+
+#include "orb_oracle.hpp"
+
+using namespace oracle;
+
+namespace {
+struct OrbHandle {
+    OrbOracle ex;
+    std::vector<KeyPoint> kps;
+    std::vector<uint8_t> desc;
+    explicit OrbHandle(const OrbParams& p) : ex(p) {}
+};
+Image wrap(const uint8_t* p, int rows, int cols, long step) {
+    Image im(rows, cols);
+    for (int y = 0; y < rows; ++y) std::memcpy(im.row(y), p + (size_t)y * step, cols);
+    return im;
+}
+}  // namespace
+
+extern "C" {
+
+void* oracle_orb_create(unsigned max_kp, float sf, unsigned levels, unsigned ini_thr, unsigned min_thr,
+                        const float* rects, int n_rects) {
+    OrbParams p;
+    p.max_num_keypts = max_kp; p.scale_factor = sf; p.num_levels = levels;
+    p.ini_fast_thr = ini_thr; p.min_fast_thr = min_thr;
+    for (int i = 0; i < n_rects; ++i) p.mask_rects.push_back({rects[4 * i], rects[4 * i + 1], rects[4 * i + 2], rects[4 * i + 3]});
+    return new OrbHandle(p);
+}
+void oracle_orb_destroy(void* h) { delete (OrbHandle*)h; }
+
+// returns number of keypoints (or -1 if cap too small); kps = cap x 28 B, desc = cap x 32 B
+int oracle_orb_extract(void* h, const uint8_t* img, int rows, int cols, long step, const uint8_t* mask,
+                       long mask_step, KeyPoint* kps, uint8_t* desc, int cap) {
+    auto* H = (OrbHandle*)h;
+    Image im = wrap(img, rows, cols, step);
+    Image mk;
+    if (mask) mk = wrap(mask, rows, cols, mask_step);
+    H->ex.extract(im, mask ? &mk : nullptr, H->kps, H->desc);
+    const int n = (int)H->kps.size();
+    if (n > cap) return -1;
+    if (n) {
+        std::memcpy(kps, H->kps.data(), (size_t)n * sizeof(KeyPoint));
+        std::memcpy(desc, H->desc.data(), (size_t)n * 32);
+    }
+    return n;
+}
+void oracle_orb_tables(void* h, float* sf, float* isf, float* s2, float* is2, unsigned* quota, int* umax) {
+    auto& e = ((OrbHandle*)h)->ex;
+    const size_t n = e.scale_factors.size();
+    std::memcpy(sf, e.scale_factors.data(), n * 4);
+    std::memcpy(isf, e.inv_scale_factors.data(), n * 4);
+    std::memcpy(s2, e.level_sigma_sq.data(), n * 4);
+    std::memcpy(is2, e.inv_level_sigma_sq.data(), n * 4);
+    std::memcpy(quota, e.num_keypts_per_level.data(), n * 4);
+    std::memcpy(umax, e.u_max.data(), 16 * 4);
+}
+void oracle_orb_level_size(void* h, int level, int* rows, int* cols) {
+    auto& im = ((OrbHandle*)h)->ex.pyramid.at(level);
+    *rows = im.rows; *cols = im.cols;
+}
+void oracle_orb_level_image(void* h, int level, uint8_t* dst) {
+    auto& im = ((OrbHandle*)h)->ex.pyramid.at(level);
+    std::memcpy(dst, im.data.data(), im.data.size());
+}
+int oracle_orb_level_blurred(void* h, int level, uint8_t* dst) {  // 0 if level was not blurred
+    auto& im = ((OrbHandle*)h)->ex.blurred.at(level);
+    if (im.empty()) return 0;
+    std::memcpy(dst, im.data.data(), im.data.size());
+    return 1;
+}
+int oracle_orb_num_candidates(void* h, int level) { return (int)((OrbHandle*)h)->ex.candidates.at(level).size(); }
+void oracle_orb_candidates(void* h, int level, KeyPoint* dst) {
+    auto& v = ((OrbHandle*)h)->ex.candidates.at(level);
+    if (!v.empty()) std::memcpy(dst, v.data(), v.size() * sizeof(KeyPoint));
+}
+int oracle_orb_num_level_keypts(void* h, int level) { return (int)((OrbHandle*)h)->ex.level_keypts.at(level).size(); }
+void oracle_orb_level_keypts(void* h, int level, KeyPoint* dst) {
+    auto& v = ((OrbHandle*)h)->ex.level_keypts.at(level);
+    if (!v.empty()) std::memcpy(dst, v.data(), v.size() * sizeof(KeyPoint));
+}
+// quadtree alone: in = n candidates (border-relative x,y,response used), out <= n
+int oracle_orb_distribute(void* h, const KeyPoint* in, int n, int min_x, int max_x, int min_y, int max_y,
+                          unsigned num_keypts, KeyPoint* out) {
+    std::vector<KeyPoint> v(in, in + n);
+    auto r = ((OrbHandle*)h)->ex.distribute_via_tree(v, min_x, max_x, min_y, max_y, num_keypts);
+    if (!r.empty()) std::memcpy(out, r.data(), r.size() * sizeof(KeyPoint));
+    return (int)r.size();
+}
+
+// ---- primitives
+void oracle_resize_linear_u8(const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw) {
+    Image s = wrap(src, sh, sw, sw);
+    Image d = resize_linear_u8(s, dw, dh);
+    std::memcpy(dst, d.data.data(), d.data.size());
+}
+void oracle_gaussian_blur_u8(const uint8_t* src, int h, int w, int ksize, double sigma, uint8_t* dst) {
+    Image s = wrap(src, h, w, w);
+    Image d = gaussian_blur_u8(s, ksize, sigma);
+    std::memcpy(dst, d.data.data(), d.data.size());
+}
+void oracle_gaussian_taps_q8(int n, double sigma, int* out) {
+    auto k = gaussian_taps_q8(n, sigma);
+    for (int i = 0; i < n; ++i) out[i] = k[i];
+}
+// FAST on a w x h ROI; out = (x,y,score) int triples; returns count
+int oracle_fast9_16(const uint8_t* base, int step, int w, int h, int threshold, int* out, int cap) {
+    std::vector<FastPoint> v;
+    fast9_16_nms(base, step, w, h, threshold, v);
+    int n = 0;
+    for (auto& p : v) { if (n >= cap) break; out[3 * n] = p.x; out[3 * n + 1] = p.y; out[3 * n + 2] = p.score; ++n; }
+    return (int)v.size();
+}
+float oracle_fast_atan2(float y, float x) { return fast_atan2f_deg(y, x); }
+float oracle_trig_cos(float v) { return trig::cos(v); }
+float oracle_trig_sin(float v) { return trig::sin(v); }
+void oracle_scale_tables(unsigned n, float sf, float* a, float* b, float* c, float* d) {
+    auto v0 = calc_scale_factors(n, sf), v1 = calc_inv_scale_factors(n, sf), v2 = calc_level_sigma_sq(n, sf),
+         v3 = calc_inv_level_sigma_sq(n, sf);
+    std::memcpy(a, v0.data(), n * 4); std::memcpy(b, v1.data(), n * 4);
+    std::memcpy(c, v2.data(), n * 4); std::memcpy(d, v3.data(), n * 4);
+}
+
+// ---- CPU baseline timing helper: extract `n_frames` frames with `n_threads` frame-parallel workers.
+// Returns wall seconds.  (bench.py cpu_baseline leg only.)
+double oracle_orb_time_frames(const uint8_t* frames, int n_frames, int rows, int cols, unsigned max_kp,
+                              int n_threads, long* total_kp) {
+    std::vector<long> counts(n_threads, 0);
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> th;
+    for (int t = 0; t < n_threads; ++t)
+        th.emplace_back([&, t]() {
+            OrbParams p;
+            p.max_num_keypts = max_kp;
+            OrbOracle ex(p);
+            std::vector<KeyPoint> k;
+            std::vector<uint8_t> d;
+            for (int f = t; f < n_frames; f += n_threads) {
+                Image im = wrap(frames + (size_t)f * rows * cols, rows, cols, cols);
+                ex.extract(im, nullptr, k, d);
+                counts[t] += (long)k.size();
+            }
+        });
+    for (auto& x : th) x.join();
+    auto t1 = std::chrono::steady_clock::now();
+    long s = 0;
+    for (auto c : counts) s += c;
+    if (total_kp) *total_kp = s;
+    return std::chrono::duration<double>(t1 - t0).count();
+}
+
+}  // extern "C"
