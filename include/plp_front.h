@@ -1,0 +1,132 @@
+/* plp_front.h — C ABI of libplp_front.so, the MI355X-native feature front-end and matcher
+ * that replaces the per-frame hot path of Structure-PLP-SLAM (src/PLPSLAM/feature,
+ * src/PLPSLAM/match).  Plain pointers and sizes only; no C++/torch types cross this boundary.
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to the
+ * reference repository root).  All functions return a plp_status and never throw.
+ *
+ * Pointer naming: `h_` / unprefixed = host memory, `d_` = device (HBM) memory of the
+ * context's GPU.  Batched `_device` entry points are asynchronous on `hip_stream`
+ * (a hipStream_t passed as void*, NULL = the context's own stream) unless stated otherwise.
+ */
+#ifndef PLP_FRONT_H
+#define PLP_FRONT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum plp_status {
+    PLP_OK = 0,
+    PLP_ERR_INVALID_ARG = 1,   /* what the reference reports via std::runtime_error / assert */
+    PLP_ERR_NO_DEVICE = 2,     /* no usable MI355X / HIP runtime failure at create time */
+    PLP_ERR_HIP = 3,           /* a HIP call failed; see plp_last_error() */
+    PLP_ERR_CAPACITY = 4,      /* caller buffer too small (n_out still holds the needed size) */
+    PLP_ERR_OVERFLOW = 5,      /* an internal per-level candidate buffer overflowed */
+    PLP_ERR_UNSUPPORTED = 6
+} plp_status;
+
+const char* plp_strerror(plp_status s);
+const char* plp_last_error(void);      /* thread-local detail string of the last failure */
+int plp_version(void);                 /* 100*major + minor */
+int plp_device_count(void);            /* number of visible HIP devices (0 on a CPU-only box) */
+
+/* ------------------------------------------------------------------------------------------
+ * Key point record: field-for-field cv::KeyPoint (28 bytes), the element type of
+ * `std::vector<cv::KeyPoint>& keypts` in feature::orb_extractor::extract
+ * (src/PLPSLAM/feature/orb_extractor.h:53-54).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct plp_keypoint {
+    float x, y;        /* pt, in level-0 pixel coordinates                                    */
+    float size;        /* (unsigned)(31 * scale_factor[octave])     orb_extractor.cc:448,457  */
+    float angle;       /* degrees in [0,360), intensity-centroid    orb_extractor.cc:708-735  */
+    float response;    /* FAST-9/16 corner score                                              */
+    int32_t octave;    /* pyramid level                                                        */
+    int32_t class_id;  /* always -1                                                            */
+} plp_keypoint;
+
+/* ------------------------------------------------------------------------------------------
+ * ORB extractor  — replaces feature::orb_extractor (src/PLPSLAM/feature/orb_extractor.h:38-176)
+ * and feature::orb_params (src/PLPSLAM/feature/orb_params.h:34-73).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct plp_orb plp_orb;   /* one per feature::orb_extractor instance; owns a HIP stream */
+
+typedef struct plp_orb_params {   /* orb_params.h:52-60, defaults 2000 / 1.2 / 8 / 20 / 7 */
+    uint32_t max_num_keypts;
+    float scale_factor;
+    uint32_t num_levels;
+    uint32_t ini_fast_thr;
+    uint32_t min_fast_thr;
+    const float* mask_rects;      /* n_mask_rects x [x_min/cols, x_max/cols, y_min/rows, y_max/rows] */
+    int32_t n_mask_rects;
+} plp_orb_params;
+
+void plp_orb_default_params(plp_orb_params* p);
+
+/* orb_extractor::orb_extractor(const orb_params&)  (orb_extractor.cc:66-71).  Validation failures
+ * that make orb_params throw std::runtime_error (orb_params.cc:40-54) return PLP_ERR_INVALID_ARG. */
+plp_status plp_orb_create(const plp_orb_params* params, int device, plp_orb** out);
+void plp_orb_destroy(plp_orb* ctx);
+
+typedef enum plp_orb_param_id {
+    PLP_ORB_MAX_NUM_KEYPOINTS = 0,     /* get/set_max_num_keypoints        orb_extractor.cc:162-171 */
+    PLP_ORB_SCALE_FACTOR = 1,          /* get/set_scale_factor             :173-182 */
+    PLP_ORB_NUM_SCALE_LEVELS = 2,      /* get/set_num_scale_levels         :184-193 */
+    PLP_ORB_INITIAL_FAST_THRESHOLD = 3,/* get/set_initial_fast_threshold   :195-203 */
+    PLP_ORB_MINIMUM_FAST_THRESHOLD = 4 /* get/set_minimum_fast_threshold   :205-213 */
+} plp_orb_param_id;
+plp_status plp_orb_set_param(plp_orb* ctx, plp_orb_param_id id, double value);  /* re-runs initialize() like the setters */
+plp_status plp_orb_get_param(const plp_orb* ctx, plp_orb_param_id id, double* value);
+
+/* get_scale_factors / get_inv_scale_factors / get_level_sigma_sq / get_inv_level_sigma_sq
+ * (orb_extractor.cc:215-233); each output array holds num_levels floats (NULL = skip).
+ * quota = num_keypts_per_level_ (orb_extractor.cc:245-253). */
+plp_status plp_orb_get_tables(const plp_orb* ctx, int32_t* n_levels, float* scale_factors,
+                              float* inv_scale_factors, float* level_sigma_sq, float* inv_level_sigma_sq,
+                              uint32_t* quota);
+
+/* orb_extractor::extract(in_image, in_image_mask, keypts, out_descriptors)  (orb_extractor.cc:73-160).
+ * Host pointers, synchronous.  img: rows x cols CV_8UC1, `step` bytes per row.  mask: NULL or same
+ * size (0 = masked).  kps/desc: caller buffers of `cap` records / cap x 32 bytes; *n_out receives the
+ * number of key points (concatenated by level).  An empty image (rows==0||cols==0) is a no-op that
+ * leaves *n_out untouched, as the reference does (:76-79). */
+plp_status plp_orb_extract(plp_orb* ctx, const uint8_t* img, int32_t rows, int32_t cols, size_t step,
+                           const uint8_t* mask, size_t mask_step,
+                           plp_keypoint* kps, uint8_t* desc, int32_t cap, int32_t* n_out);
+
+/* Batched replay form of extract(): B frames already resident in HBM, results stay in HBM.
+ * d_imgs: B frames, frame b at d_imgs + b*frame_stride, `step` bytes per row.
+ * d_mask: NULL, or masks at d_mask + b*mask_frame_stride (mask_frame_stride==0: one shared mask).
+ * d_kps: B x cap records, d_desc: B x cap x 32 bytes, d_counts: B int32 (key points per frame;
+ * a frame needing more than `cap` slots is truncated and flagged in plp_orb_last_batch_status).
+ * Asynchronous on hip_stream. */
+plp_status plp_orb_extract_batch_device(plp_orb* ctx, const uint8_t* d_imgs, int32_t B, int32_t rows,
+                                        int32_t cols, size_t step, size_t frame_stride,
+                                        const uint8_t* d_mask, size_t mask_step, size_t mask_frame_stride,
+                                        plp_keypoint* d_kps, uint8_t* d_desc, int32_t cap,
+                                        int32_t* d_counts, void* hip_stream);
+/* Synchronises the last batch's stream and reports truncation / overflow (PLP_OK if none). */
+plp_status plp_orb_last_batch_status(plp_orb* ctx);
+
+/* orb_extractor::image_pyramid_ (public member, orb_extractor.h:101; read by match::stereo,
+ * src/PLPSLAM/data/frame.cc:277-281).  Copies level `level` of frame `frame` of the last call to host. */
+plp_status plp_orb_pyramid_level_size(const plp_orb* ctx, int32_t level, int32_t* rows, int32_t* cols);
+plp_status plp_orb_pyramid_host(plp_orb* ctx, int32_t frame, int32_t level, uint8_t* dst, size_t dst_step);
+
+/* Stage read-back for parity tests (synchronous; host destination).
+ *   PLP_ORB_DBG_BLURRED   : the 7x7 sigma-2 blurred level image (orb_extractor.cc:148-149), rows x cols u8 dense
+ *   PLP_ORB_DBG_CANDIDATES: keypts_to_distribute of a level (orb_extractor.cc:359,433) as int32 triples
+ *                           (x, y, score) in border-relative coordinates, reference order
+ *   PLP_ORB_DBG_SELECTED  : per-level quadtree output (orb_extractor.cc:443) as int32 triples (x, y, score)
+ * *n_out = number of bytes (BLURRED) or triples written. */
+typedef enum plp_orb_debug_id { PLP_ORB_DBG_BLURRED = 0, PLP_ORB_DBG_CANDIDATES = 1, PLP_ORB_DBG_SELECTED = 2 } plp_orb_debug_id;
+plp_status plp_orb_debug_read(plp_orb* ctx, plp_orb_debug_id what, int32_t frame, int32_t level,
+                              void* dst, size_t dst_bytes, int64_t* n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLP_FRONT_H */

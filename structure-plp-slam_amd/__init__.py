@@ -1,0 +1,217 @@
+"""structure-plp-slam_amd — MI355X-native feature front-end and matcher for Structure-PLP-SLAM.
+
+The product is ``libplp_front.so`` (hand-written HIP kernels for gfx950 behind the C ABI declared
+in ``include/plp_front.h``).  This package is the thin Python host mirror used by the tests and
+the bench: class and method names follow the reference's C++ interface
+(``feature::orb_extractor`` — src/PLPSLAM/feature/orb_extractor.h:38-176).  There is no CPU
+fallback: if the shared library is missing or no GPU is visible the calls raise.
+"""
+import ctypes as C
+import os
+import pathlib
+import subprocess
+
+import numpy as np
+
+_PKG = pathlib.Path(__file__).resolve().parent
+ROOT = _PKG.parent
+LIB_PATH = _PKG / "libplp_front.so"
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+PLP_OK, PLP_ERR_INVALID_ARG, PLP_ERR_NO_DEVICE, PLP_ERR_HIP, PLP_ERR_CAPACITY, PLP_ERR_OVERFLOW, PLP_ERR_UNSUPPORTED = range(7)
+
+
+class PlpError(RuntimeError):
+    def __init__(self, status, detail):
+        super().__init__(f"plp_front status {status}: {detail}")
+        self.status = status
+
+
+class orb_params_c(C.Structure):
+    _fields_ = [("max_num_keypts", C.c_uint32), ("scale_factor", C.c_float), ("num_levels", C.c_uint32),
+                ("ini_fast_thr", C.c_uint32), ("min_fast_thr", C.c_uint32), ("mask_rects", C.c_void_p),
+                ("n_mask_rects", C.c_int32)]
+
+
+def build(verbose=False):
+    """Compile libplp_front.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    r = subprocess.run(["make", "-C", str(_PKG / "csrc")], capture_output=not verbose, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building libplp_front.so failed:\n" + (r.stdout or "") + (r.stderr or ""))
+    return LIB_PATH
+
+
+_lib = None
+
+# every symbol include/plp_front.h declares: (name, restype, argtypes)
+_VP, _I32, _SZ = C.c_void_p, C.c_int32, C.c_size_t
+_API = [
+    ("plp_strerror", C.c_char_p, [C.c_int]),
+    ("plp_last_error", C.c_char_p, []),
+    ("plp_version", C.c_int, []),
+    ("plp_device_count", C.c_int, []),
+    ("plp_orb_default_params", None, [_VP]),
+    ("plp_orb_create", C.c_int, [_VP, C.c_int, _VP]),
+    ("plp_orb_destroy", None, [_VP]),
+    ("plp_orb_set_param", C.c_int, [_VP, C.c_int, C.c_double]),
+    ("plp_orb_get_param", C.c_int, [_VP, C.c_int, _VP]),
+    ("plp_orb_get_tables", C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    ("plp_orb_extract", C.c_int, [_VP, _VP, _I32, _I32, _SZ, _VP, _SZ, _VP, _VP, _I32, _VP]),
+    ("plp_orb_extract_batch_device", C.c_int, [_VP, _VP, _I32, _I32, _I32, _SZ, _SZ, _VP, _SZ, _SZ, _VP, _VP, _I32, _VP, _VP]),
+    ("plp_orb_last_batch_status", C.c_int, [_VP]),
+    ("plp_orb_pyramid_level_size", C.c_int, [_VP, _I32, _VP, _VP]),
+    ("plp_orb_pyramid_host", C.c_int, [_VP, _I32, _I32, _VP, _SZ]),
+    ("plp_orb_debug_read", C.c_int, [_VP, C.c_int, _I32, _I32, _VP, _SZ, _VP]),
+    ("plp_model_quadtree_host", _I32, [_VP, _I32, _I32, _I32, C.c_uint32, _VP]),
+]
+
+
+def api_symbols():
+    return [n for n, _, _ in _API]
+
+
+def lib():
+    """Load libplp_front.so; raises if it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise FileNotFoundError(f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
+        L = C.CDLL(str(LIB_PATH))
+        for name, res, args in _API:
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _check(status):
+    if status != PLP_OK:
+        raise PlpError(status, lib().plp_last_error().decode())
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def model_quadtree(xys, level_w, level_h, quota):
+    """Host model of the quadtree kernel (no GPU needed).  xys: (n,3) int32 (x, y, score)."""
+    xys = np.ascontiguousarray(xys, np.int32).reshape(-1, 3)
+    out = np.zeros(max(len(xys), 1), np.int32)
+    m = lib().plp_model_quadtree_host(_p(xys), len(xys), level_w, level_h, quota, _p(out))
+    return out[:m].copy()
+
+
+class orb_extractor:
+    """Mirror of feature::orb_extractor (src/PLPSLAM/feature/orb_extractor.h:38-176) over the C ABI."""
+
+    DBG_BLURRED, DBG_CANDIDATES, DBG_SELECTED = 0, 1, 2
+
+    def __init__(self, max_num_keypts=2000, scale_factor=1.2, num_levels=8, ini_fast_thr=20, min_fast_thr=7,
+                 mask_rects=(), device=0):
+        r = np.ascontiguousarray(np.asarray(mask_rects, np.float32).reshape(-1, 4))
+        p = orb_params_c(max_num_keypts, scale_factor, num_levels, ini_fast_thr, min_fast_thr,
+                         r.ctypes.data if len(r) else None, len(r))
+        h = C.c_void_p()
+        st = lib().plp_orb_create(C.byref(p), device, C.byref(h))
+        if st == PLP_ERR_INVALID_ARG:
+            raise ValueError(lib().plp_last_error().decode())   # the reference throws std::runtime_error here
+        _check(st)
+        self._h = h
+        self.device = device
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib().plp_orb_destroy(h)
+            self._h = None
+
+    # ---- getters / setters (orb_extractor.cc:162-233)
+    def _get(self, i):
+        v = C.c_double()
+        _check(lib().plp_orb_get_param(self._h, i, C.byref(v)))
+        return v.value
+
+    def get_max_num_keypoints(self): return int(self._get(0))
+    def set_max_num_keypoints(self, v): _check(lib().plp_orb_set_param(self._h, 0, float(v)))
+    def get_scale_factor(self): return float(np.float32(self._get(1)))
+    def set_scale_factor(self, v): _check(lib().plp_orb_set_param(self._h, 1, float(v)))
+    def get_num_scale_levels(self): return int(self._get(2))
+    def set_num_scale_levels(self, v): _check(lib().plp_orb_set_param(self._h, 2, float(v)))
+    def get_initial_fast_threshold(self): return int(self._get(3))
+    def set_initial_fast_threshold(self, v): _check(lib().plp_orb_set_param(self._h, 3, float(v)))
+    def get_minimum_fast_threshold(self): return int(self._get(4))
+    def set_minimum_fast_threshold(self, v): _check(lib().plp_orb_set_param(self._h, 4, float(v)))
+
+    def _tables(self):
+        n = self.get_num_scale_levels()
+        f = [np.zeros(n, np.float32) for _ in range(4)]
+        q = np.zeros(n, np.uint32)
+        nl = C.c_int32()
+        _check(lib().plp_orb_get_tables(self._h, C.byref(nl), *[_p(a) for a in f], _p(q)))
+        return f, q
+
+    def get_scale_factors(self): return self._tables()[0][0]
+    def get_inv_scale_factors(self): return self._tables()[0][1]
+    def get_level_sigma_sq(self): return self._tables()[0][2]
+    def get_inv_level_sigma_sq(self): return self._tables()[0][3]
+    def get_num_keypts_per_level(self): return self._tables()[1]
+
+    # ---- extract (orb_extractor.cc:73-160): host image in, key points + descriptors out
+    def extract(self, in_image, in_image_mask=None):
+        img = np.ascontiguousarray(in_image, np.uint8)
+        cap = 2 * self.get_max_num_keypoints() + 64
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int32(0)
+        if img.size == 0:
+            _check(lib().plp_orb_extract(self._h, None, 0, 0, 0, None, 0, _p(kps), _p(desc), cap, C.byref(n)))
+            return kps[:0], desc[:0]
+        mask = None if in_image_mask is None else np.ascontiguousarray(in_image_mask, np.uint8)
+        _check(lib().plp_orb_extract(self._h, _p(img), img.shape[0], img.shape[1], img.strides[0],
+                                     _p(mask) if mask is not None else None,
+                                     mask.strides[0] if mask is not None else 0, _p(kps), _p(desc), cap, C.byref(n)))
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    # ---- batched replay on device pointers (torch tensors own the HBM)
+    def extract_batch(self, d_imgs, d_kps, d_desc, d_counts, d_mask=None, stream=None):
+        """d_imgs: torch uint8 [B,H,W] on this device; outputs: d_kps uint8 [B,cap,28], d_desc uint8 [B,cap,32],
+        d_counts int32 [B].  Asynchronous on `stream` (a torch.cuda.Stream; default = the current stream)."""
+        import torch
+        B, H, W = d_imgs.shape
+        cap = d_kps.shape[1]
+        assert d_imgs.is_cuda and d_imgs.dtype == torch.uint8 and d_imgs.stride(2) == 1
+        st = (stream or torch.cuda.current_stream(d_imgs.device)).cuda_stream
+        mptr, mstep, mfs = None, 0, 0
+        if d_mask is not None:
+            mptr, mstep = d_mask.data_ptr(), d_mask.stride(-2)
+            mfs = d_mask.stride(0) if d_mask.dim() == 3 else 0
+        _check(lib().plp_orb_extract_batch_device(self._h, d_imgs.data_ptr(), B, H, W, d_imgs.stride(1), d_imgs.stride(0),
+                                                  mptr, mstep, mfs, d_kps.data_ptr(), d_desc.data_ptr(), cap,
+                                                  d_counts.data_ptr(), st))
+
+    def last_batch_status(self):
+        _check(lib().plp_orb_last_batch_status(self._h))
+
+    # ---- image_pyramid_ (orb_extractor.h:101) and stage read-backs for parity tests
+    def image_pyramid(self, level, frame=0):
+        r, c = C.c_int32(), C.c_int32()
+        _check(lib().plp_orb_pyramid_level_size(self._h, level, C.byref(r), C.byref(c)))
+        a = np.zeros((r.value, c.value), np.uint8)
+        _check(lib().plp_orb_pyramid_host(self._h, frame, level, _p(a), a.strides[0]))
+        return a
+
+    def debug_read(self, what, level, frame=0):
+        r, c = C.c_int32(), C.c_int32()
+        _check(lib().plp_orb_pyramid_level_size(self._h, level, C.byref(r), C.byref(c)))
+        n = C.c_int64()
+        if what == self.DBG_BLURRED:
+            a = np.zeros((r.value, c.value), np.uint8)
+            _check(lib().plp_orb_debug_read(self._h, what, frame, level, _p(a), a.nbytes, C.byref(n)))
+            return a
+        a = np.zeros((r.value * c.value // 4 + 16, 3), np.int32)
+        _check(lib().plp_orb_debug_read(self._h, what, frame, level, _p(a), a.nbytes, C.byref(n)))
+        return a[:n.value].copy()

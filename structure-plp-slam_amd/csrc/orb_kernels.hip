@@ -1,0 +1,440 @@
+// Hand-written HIP kernels (gfx950 / CDNA4, wave64) of the batched ORB front-end.
+// Every kernel carries a leading frame dimension (blockIdx.y or .z) so one launch covers
+// the whole batch; integer stages are bit-exact by construction, the two f32 stages
+// (fastAtan2, rBRIEF rotation) use explicit non-contracted f32 ops.
+//
+//   k_resize_linear   cv::resize(INTER_LINEAR) level l-1 -> l      orb_extractor.cc:315-326
+//   k_fast_cells      per-cell cv::FAST(thr 20 -> 7) + NMS + mask   orb_extractor.cc:365-437
+//   k_blur7           cv::GaussianBlur(7x7, sigma 2, REFLECT_101)   orb_extractor.cc:148-149
+//   k_orient_rbrief   ic_angle + 256-bit rBRIEF + KeyPoint assembly orb_extractor.cc:450-458,708-807
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "orb_device.hpp"
+
+namespace plp {
+
+// ------------------------------------------------------------------------------------------
+// K1  bilinear 11-bit fixed-point down-scale, 4 destination pixels per thread (one u32 store).
+// grid = (ceil(dw/256), ceil(dh/4), B), block = (64, 4)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_resize_linear(const uint8_t* __restrict__ src_base, size_t src_frame_stride,
+                                                       int src_pitch, uint8_t* __restrict__ dst_base,
+                                                       size_t dst_frame_stride, int dst_pitch, int dw, int dh,
+                                                       const int16_t* __restrict__ xofs0, const int16_t* __restrict__ xofs1,
+                                                       const int16_t* __restrict__ a0, const int16_t* __restrict__ a1,
+                                                       const int16_t* __restrict__ yofs0, const int16_t* __restrict__ yofs1,
+                                                       const int16_t* __restrict__ b0, const int16_t* __restrict__ b1) {
+    const int dy = blockIdx.y * 4 + threadIdx.y;
+    const int dx0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    if (dy >= dh || dx0 >= dw) return;
+    const uint8_t* src = src_base + (size_t)blockIdx.z * src_frame_stride;
+    uint8_t* dst = dst_base + (size_t)blockIdx.z * dst_frame_stride;
+    const uint8_t* S0 = src + (size_t)yofs0[dy] * src_pitch;
+    const uint8_t* S1 = src + (size_t)yofs1[dy] * src_pitch;
+    const int wb0 = b0[dy], wb1 = b1[dy];
+    uint32_t packed = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int dx = min(dx0 + i, dw - 1);
+        const int x0 = xofs0[dx], x1 = xofs1[dx], wa0 = a0[dx], wa1 = a1[dx];
+        const int h0 = S0[x0] * wa0 + S0[x1] * wa1;
+        const int h1 = S1[x0] * wa0 + S1[x1] * wa1;
+        const int v = (((wb0 * (h0 >> 4)) >> 16) + ((wb1 * (h1 >> 4)) >> 16) + 2) >> 2;
+        packed |= (uint32_t)(v & 255) << (8 * i);
+    }
+    // rows are padded to a 64-byte pitch, so the 4-byte store never leaves the row
+    *reinterpret_cast<uint32_t*>(dst + (size_t)dy * dst_pitch + dx0) = packed;
+}
+
+// ------------------------------------------------------------------------------------------
+// K2+K3  FAST-9/16 score + 3x3 NMS + threshold fallback + mask, one workgroup per cell ROI.
+//
+// The corner score s(p) = max over the 16 arcs of 9 contiguous circle pixels of
+// min(|I - v|, sign-consistent) - 1 is what cv::cornerScore<16> returns and does not depend
+// on the threshold; cv::FAST(thr) keeps p iff s(p) >= thr and s(p) is strictly greater than
+// the 8 neighbouring scores (non-corners and pixels outside the ROI's tested interior count 0).
+// Hence one score map serves both the thr=ini pass and the thr=min fallback of an empty cell.
+// grid = (n_cells, B), block = 256.
+// ------------------------------------------------------------------------------------------
+constexpr int kTileW = 76;            // LDS row pitch of the u8 ROI tile (>= 70 + 3 alignment slack)
+constexpr int kScoreW = 68;           // 64 tested + 2 zero border, padded
+
+__device__ __forceinline__ int min3(int a, int b, int c) { return min(a, min(b, c)); }
+
+__global__ __launch_bounds__(256) void k_fast_cells(OrbPlanes pl, const CellDesc* __restrict__ cells,
+                                                    const LevelDev* __restrict__ lv, int ini_thr, int min_thr,
+                                                    const uint8_t* __restrict__ mask, size_t mask_step,
+                                                    size_t mask_frame_stride, uint32_t* __restrict__ cell_cand,
+                                                    int32_t* __restrict__ cell_count, int n_cells) {
+    __shared__ uint8_t tile[70 * kTileW];
+    __shared__ uint8_t score[66 * kScoreW];   // score map of the tested interior, +1 zero ring
+    __shared__ uint8_t keep[64 * 64];         // NMS survivors (score or 0)
+    __shared__ uint16_t queue[4096];
+    __shared__ int q_count, n_ini, wave_tot[4], run_base;
+
+    const int tid = threadIdx.x, frame = blockIdx.y, cell = blockIdx.x;
+    const CellDesc cd = cells[cell];
+    const LevelDev L = lv[cd.level];
+    const int out_slot = frame * n_cells + cell;
+    const float sf = L.scale;
+
+    const uint8_t* mk = mask ? mask + (size_t)frame * mask_frame_stride : nullptr;
+    auto masked = [&](int y, int x) -> bool {   // mask.at<uchar>(y * sf, x * sf) == 0
+        return mk[(size_t)(int)((float)y * sf) * mask_step + (int)((float)x * sf)] == 0;
+    };
+    if (mk) {   // skip the cell when one ROI corner is masked (orb_extractor.cc:395-401)
+        const int x0 = cd.min_x, x1 = cd.min_x + cd.w, y0 = cd.min_y, y1 = cd.min_y + cd.h;
+        if (masked(y0, x0) || masked(y1, x0) || masked(y0, x1) || masked(y1, x1)) {
+            if (tid == 0) cell_count[out_slot] = 0;
+            return;
+        }
+    }
+
+    const uint8_t* img = pl.level_ptr(frame, cd.level, L);
+    const int pitch = pl.level_pitch(cd.level, L);
+    const int w = cd.w, h = cd.h;
+    // stage the ROI through LDS: aligned dword loads (pitch and plane bases are 4-byte multiples)
+    {
+        const int ox = cd.min_x & 3;
+        const int ndw = (w + ox + 3) >> 2;
+        const uint8_t* row0 = img + (size_t)cd.min_y * pitch + (cd.min_x - ox);
+        for (int i = tid; i < ndw * h; i += 256) {
+            const int r = i / ndw, c = i - r * ndw;
+            const uint32_t v = *reinterpret_cast<const uint32_t*>(row0 + (size_t)r * pitch + 4 * c);
+            *reinterpret_cast<uint32_t*>(&tile[r * kTileW + 4 * c]) = v;
+        }
+        for (int i = tid; i < 66 * kScoreW; i += 256) score[i] = 0;
+        if (tid == 0) { q_count = 0; n_ini = 0; run_base = 0; }
+    }
+    __syncthreads();
+    const int ox = cd.min_x & 3;
+    const int tw = w - 6, th = h - 6;   // tested interior (ROI x,y in [3, w-3) x [3, h-3))
+
+    // pass 1: 16-bit brighter/darker masks -> "has an arc of 9 at min_thr" -> queue
+    for (int i = tid; i < tw * th; i += 256) {
+        const int ty = i / tw, tx = i - ty * tw;
+        const uint8_t* c = &tile[(ty + 3) * kTileW + tx + 3 + ox];
+        const int v = c[0];
+        const int hi = v + min_thr, lo = v - min_thr;
+        uint32_t B = 0, D = 0;
+#define PLP_T(k, dx, dy) { const int p = c[(dy) * kTileW + (dx)]; B |= (uint32_t)(p > hi) << k; D |= (uint32_t)(p < lo) << k; }
+        PLP_T(0, 0, 3) PLP_T(1, 1, 3) PLP_T(2, 2, 2) PLP_T(3, 3, 1) PLP_T(4, 3, 0) PLP_T(5, 3, -1) PLP_T(6, 2, -2) PLP_T(7, 1, -3)
+        PLP_T(8, 0, -3) PLP_T(9, -1, -3) PLP_T(10, -2, -2) PLP_T(11, -3, -1) PLP_T(12, -3, 0) PLP_T(13, -3, 1) PLP_T(14, -2, 2) PLP_T(15, -1, 3)
+#undef PLP_T
+        auto arc9 = [](uint32_t m) -> bool {
+            m |= m << 16;
+            uint32_t x = m & (m >> 1);
+            x &= x >> 2;
+            x &= x >> 4;
+            x &= m >> 8;
+            return (x & 0xffffu) != 0;
+        };
+        if (arc9(B) || arc9(D)) {
+            const int slot = atomicAdd(&q_count, 1);
+            queue[slot] = (uint16_t)((ty << 6) | tx);
+        }
+    }
+    __syncthreads();
+    // pass 2: exact score of the queued pixels (dense over the queue: no lane idles on non-corners)
+    const int nq = q_count;
+    for (int i = tid; i < nq; i += 256) {
+        const int ty = queue[i] >> 6, tx = queue[i] & 63;
+        const uint8_t* c = &tile[(ty + 3) * kTileW + tx + 3 + ox];
+        const int v = c[0];
+        int d[16];
+        d[0] = c[3 * kTileW] - v;        d[1] = c[3 * kTileW + 1] - v;    d[2] = c[2 * kTileW + 2] - v;   d[3] = c[kTileW + 3] - v;
+        d[4] = c[3] - v;                 d[5] = c[-kTileW + 3] - v;       d[6] = c[-2 * kTileW + 2] - v;  d[7] = c[-3 * kTileW + 1] - v;
+        d[8] = c[-3 * kTileW] - v;       d[9] = c[-3 * kTileW - 1] - v;   d[10] = c[-2 * kTileW - 2] - v; d[11] = c[-kTileW - 3] - v;
+        d[12] = c[-3] - v;               d[13] = c[kTileW - 3] - v;       d[14] = c[2 * kTileW - 2] - v;  d[15] = c[3 * kTileW - 1] - v;
+        // sliding min / max over windows of 9 on the ring, by doubling
+        int mn2[16], mx2[16], mn4[16], mx4[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { mn2[k] = min(d[k], d[(k + 1) & 15]); mx2[k] = max(d[k], d[(k + 1) & 15]); }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { mn4[k] = min(mn2[k], mn2[(k + 2) & 15]); mx4[k] = max(mx2[k], mx2[(k + 2) & 15]); }
+        int bright = -255, dark = 255;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int mn9 = min3(mn4[k], mn4[(k + 4) & 15], d[(k + 8) & 15]);
+            const int mx9 = max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
+            bright = max(bright, mn9);
+            dark = min(dark, mx9);
+        }
+        const int s = max(bright, -dark) - 1;
+        score[(ty + 1) * kScoreW + tx + 1] = (uint8_t)(s >= min_thr ? s : 0);
+    }
+    __syncthreads();
+    // pass 3: 3x3 strict NMS on the score map; count survivors at the initial threshold
+    int my_ini = 0;
+    for (int i = tid; i < tw * th; i += 256) {
+        const int ty = i / tw, tx = i - ty * tw;
+        const uint8_t* s = &score[(ty + 1) * kScoreW + tx + 1];
+        const int v = s[0];
+        const bool ok = v > 0 && v > s[-1] && v > s[1] && v > s[-kScoreW - 1] && v > s[-kScoreW] && v > s[-kScoreW + 1] &&
+                        v > s[kScoreW - 1] && v > s[kScoreW] && v > s[kScoreW + 1];
+        keep[ty * 64 + tx] = ok ? (uint8_t)v : 0;
+        my_ini += (ok && v >= ini_thr);
+    }
+    if (my_ini) atomicAdd(&n_ini, my_ini);
+    __syncthreads();
+    const int thr = n_ini > 0 ? ini_thr : min_thr;   // empty at ini_thr -> redo at min_thr (:408-412)
+
+    // pass 4: ordered (row-major) compaction of the survivors, 256 tested pixels per step
+    uint32_t* out = cell_cand + (size_t)out_slot * kCellCap;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int total = tw * th;
+    for (int base = 0; base < total; base += 256) {
+        const int i = base + tid;
+        bool emit = false;
+        int ty = 0, tx = 0, v = 0;
+        if (i < total) {
+            ty = i / tw; tx = i - ty * tw;
+            v = keep[ty * 64 + tx];
+            emit = v >= thr && v > 0;
+            if (emit && mk) emit = !masked(cd.min_y + ty + 3, cd.min_x + tx + 3);   // (:429)
+        }
+        const unsigned long long bal = __ballot(emit);
+        if (lane == 0) wave_tot[wv] = __popcll(bal);
+        __syncthreads();
+        int off = run_base;
+        for (int k = 0; k < wv; ++k) off += wave_tot[k];
+        if (emit) {
+            off += __popcll(bal & ((1ull << lane) - 1ull));
+            // border-relative position: ROI coordinate + cell index * 64 (orb_extractor.cc:426-427)
+            const uint32_t x = (uint32_t)(tx + 3 + cd.cx * kCellSize), y = (uint32_t)(ty + 3 + cd.cy * kCellSize);
+            out[off] = x | (y << 12) | ((uint32_t)v << 24);
+        }
+        __syncthreads();
+        if (tid == 0) run_base += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+        __syncthreads();
+    }
+    if (tid == 0) cell_count[out_slot] = run_base;
+}
+
+// ------------------------------------------------------------------------------------------
+// K6  7x7 sigma-2 Gaussian, 8.8 fixed-point taps (sum 256), exact separable integer passes:
+// out = (sum_j k[j] * (sum_i k[i] * src) + 32768) >> 16, BORDER_REFLECT_101.
+// One workgroup = 64 x 32 output tile of one level of one frame; all levels in one launch.
+// grid = (tiles of all levels, B), block = 256.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int reflect101(int p, int len) {
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p;
+    return p;
+}
+
+__global__ __launch_bounds__(256) void k_blur7(OrbPlanes pl, uint8_t* __restrict__ blur_base, size_t blur_frame_stride,
+                                               const LevelDev* __restrict__ lv, int n_levels, BlurTaps taps) {
+    constexpr int TW = 64, TH = 32, R = 3;
+    __shared__ uint8_t in[(TH + 2 * R) * (TW + 2 * R + 2)];
+    __shared__ uint16_t hs[(TH + 2 * R) * TW];
+    constexpr int IW = TW + 2 * R + 2;   // 72
+
+    int level = 0, t = blockIdx.x;
+    while (level + 1 < n_levels && t >= lv[level].blur_tiles) { t -= lv[level].blur_tiles; ++level; }
+    const LevelDev L = lv[level];
+    const int tiles_x = (L.w + TW - 1) / TW;
+    const int ty0 = (t / tiles_x) * TH, tx0 = (t % tiles_x) * TW;
+    const int frame = blockIdx.y, tid = threadIdx.x;
+    const uint8_t* img = pl.level_ptr(frame, level, L);
+    const int pitch = pl.level_pitch(level, L);
+
+    for (int i = tid; i < (TH + 2 * R) * (TW + 2 * R); i += 256) {
+        const int r = i / (TW + 2 * R), c = i - r * (TW + 2 * R);
+        const int y = reflect101(ty0 + r - R, L.h), x = reflect101(tx0 + c - R, L.w);
+        in[r * IW + c] = img[(size_t)y * pitch + x];
+    }
+    __syncthreads();
+    for (int i = tid; i < (TH + 2 * R) * TW; i += 256) {
+        const int r = i / TW, c = i - r * TW;
+        const uint8_t* p = &in[r * IW + c];
+        uint32_t a = 0;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) a += (uint32_t)taps.k[k] * p[k];
+        hs[i] = (uint16_t)a;
+    }
+    __syncthreads();
+    uint8_t* out = blur_base + (size_t)frame * blur_frame_stride + L.off;
+    const int cx = (tid & 15) * 4, ry = tid >> 4;   // 16 threads x 4 px across, 16 rows per sweep
+#pragma unroll
+    for (int sweep = 0; sweep < 2; ++sweep) {
+        const int r = ry + sweep * 16;
+        const int y = ty0 + r, x = tx0 + cx;
+        if (y < L.h && x < L.w) {
+            uint32_t packed = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint32_t a = 0;
+#pragma unroll
+                for (int k = 0; k < 7; ++k) a += (uint32_t)taps.k[k] * hs[(r + k) * TW + cx + i];
+                packed |= min((a + 32768u) >> 16, 255u) << (8 * i);
+            }
+            *reinterpret_cast<uint32_t*>(out + (size_t)y * L.pitch + x) = packed;   // pitch is a 64-B multiple
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K5+K7  orientation + rBRIEF + KeyPoint assembly, one wave64 per selected key point.
+// grid = (ceil(total_sel_cap / 4), B), block = 256 (4 waves = 4 key points).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {   // cv::fastAtan2, no FMA
+    const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
+    const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
+    const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
+    const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
+    const float eps = (float)2.2204460492503131e-16;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a;
+    if (ax >= ay) {
+        const float c = __fdiv_rn(ay, __fadd_rn(ax, eps));
+        const float c2 = __fmul_rn(c, c);
+        a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+    } else {
+        const float c = __fdiv_rn(ax, __fadd_rn(ay, eps));
+        const float c2 = __fmul_rn(c, c);
+        a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
+    }
+    if (x < 0) a = __fsub_rn(180.f, a);
+    if (y < 0) a = __fsub_rn(360.f, a);
+    return a;
+}
+
+// util::cos / util::sin of the reference (src/PLPSLAM/util/trigonometric.h:43-78)
+__device__ __forceinline__ float ref_poly_cos(float v) {
+    const float v2 = __fmul_rn(v, v);
+    return __fadd_rn(0.99940307f, __fmul_rn(v2, __fadd_rn(-0.49558072f, __fmul_rn(0.03679168f, v2))));
+}
+__device__ __forceinline__ float ref_cos(float v) {
+    const float PI = 3.14159265358979f, PI_2 = PI / 2.0f, TWO_PI = 2.0f * PI, INV_TWO_PI = 1.0f / TWO_PI, THREE_PI_2 = 3.0f * PI_2;
+    const float q = __fmul_rn(v, INV_TWO_PI);
+    int fl = (int)q;
+    fl -= (fl > q);
+    v = __fsub_rn(v, __fmul_rn((float)fl, TWO_PI));
+    v = (0.0f < v) ? v : -v;
+    if (v < PI_2) return ref_poly_cos(v);
+    if (v < PI) return -ref_poly_cos(__fsub_rn(PI, v));
+    if (v < THREE_PI_2) return -ref_poly_cos(__fsub_rn(v, PI));
+    return ref_poly_cos(__fsub_rn(TWO_PI, v));
+}
+__device__ __forceinline__ float ref_sin(float v) { return ref_cos(__fsub_rn(3.14159265358979f / 2.0f, v)); }
+
+__constant__ int8_t c_pattern[1024] = {
+#include "rbrief_pattern.inc"
+};
+
+__global__ __launch_bounds__(256) void k_orient_rbrief(OrbPlanes pl, const uint8_t* __restrict__ blur_base,
+                                                       size_t blur_frame_stride, const LevelDev* __restrict__ lv,
+                                                       int n_levels, const int32_t* __restrict__ sel,   // [B][total_sel_cap] packed x|y<<12|score<<24
+                                                       const int32_t* __restrict__ sel_count,           // [B][kMaxLevels]
+                                                       int total_sel_cap, UMax um, plp_keypoint* __restrict__ out_kps,
+                                                       uint8_t* __restrict__ out_desc, int cap, int32_t* __restrict__ out_counts,
+                                                       int32_t* __restrict__ status) {
+    const int lane = threadIdx.x & 63, frame = blockIdx.y;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= total_sel_cap) return;
+    int level = 0;
+    while (level + 1 < n_levels && g >= lv[level + 1].sel_base) ++level;
+    const LevelDev L = lv[level];
+    const int i = g - L.sel_base;
+    const int32_t* cnt = sel_count + frame * kMaxLevels;
+    int out_idx = i, total = 0;
+    for (int l = 0; l < n_levels; ++l) { const int c = cnt[l]; if (l < level) out_idx += c; total += c; }
+    if (g == 0 && lane == 0) {
+        out_counts[frame] = min(total, cap);
+        if (total > cap) atomicOr(status, 1);
+    }
+    if (i >= cnt[level] || out_idx >= cap) return;
+
+    const uint32_t pk = (uint32_t)sel[(size_t)frame * total_sel_cap + g];
+    const int cx = (int)(pk & 0xfff) + kOrbBorder, cy = (int)((pk >> 12) & 0xfff) + kOrbBorder;   // level pixel
+    const int resp = (int)(pk >> 24);
+
+    // intensity centroid over the radius-15 disc: two rows per step (lanes 0-31 / 32-63)
+    const uint8_t* img = pl.level_ptr(frame, level, L);
+    const int pitch = pl.level_pitch(level, L);
+    int m10 = 0, m01 = 0;
+    const int u = (lane & 31) - 15;
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int v = -15 + 2 * it + (lane >> 5);
+        if (v <= 15 && (lane & 31) < 31) {
+            const int av = v < 0 ? -v : v;
+            if ((u < 0 ? -u : u) <= um.v[av]) {
+                const int val = img[(size_t)(cy + v) * pitch + cx + u];
+                m10 += u * val;
+                m01 += v * val;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+
+    // rBRIEF on the blurred level: lane handles pair (64*r + lane); ballot packs 64 bits = 8 bytes
+    const float arad = (float)((double)angle * 3.14159265358979323846 / 180.0);
+    const float ca = ref_cos(arad), sa = ref_sin(arad);
+    const uint8_t* bl = blur_base + (size_t)frame * blur_frame_stride + L.off + (size_t)cy * L.pitch + cx;
+    unsigned long long bits[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int p = (64 * r + lane) * 4;
+        const float ax = (float)c_pattern[p], ay = (float)c_pattern[p + 1], bx = (float)c_pattern[p + 2], by = (float)c_pattern[p + 3];
+        const int ar = __float2int_rn(__fadd_rn(__fmul_rn(ax, sa), __fmul_rn(ay, ca)));
+        const int ac = __float2int_rn(__fsub_rn(__fmul_rn(ax, ca), __fmul_rn(ay, sa)));
+        const int br = __float2int_rn(__fadd_rn(__fmul_rn(bx, sa), __fmul_rn(by, ca)));
+        const int bc = __float2int_rn(__fsub_rn(__fmul_rn(bx, ca), __fmul_rn(by, sa)));
+        const int ta = bl[ar * L.pitch + ac], tb = bl[br * L.pitch + bc];
+        bits[r] = __ballot(ta < tb);
+    }
+    if (lane < 4) reinterpret_cast<unsigned long long*>(out_desc + ((size_t)frame * cap + out_idx) * 32)[lane] = bits[lane];
+    if (lane == 0) {
+        plp_keypoint k;
+        const float s = L.scale;
+        k.x = level ? __fmul_rn((float)cx, s) : (float)cx;
+        k.y = level ? __fmul_rn((float)cy, s) : (float)cy;
+        k.size = (float)(unsigned)(__fmul_rn((float)kFastPatch, s));
+        k.angle = angle;
+        k.response = (float)resp;
+        k.octave = level;
+        k.class_id = -1;
+        out_kps[(size_t)frame * cap + out_idx] = k;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ launch wrappers
+void launch_resize(hipStream_t st, const OrbPlanes& pl, const LevelDev* h_lv, int level, int B, const ResizeDev& rs) {
+    const LevelDev& S = h_lv[level - 1];
+    const LevelDev& D = h_lv[level];
+    const uint8_t* src = level - 1 == 0 ? pl.l0 : pl.pyr + S.off;
+    const size_t sstride = level - 1 == 0 ? pl.l0_frame_stride : pl.pyr_frame_stride;
+    const int spitch = level - 1 == 0 ? pl.l0_pitch : S.pitch;
+    dim3 grid((D.w + 255) / 256, (D.h + 3) / 4, B), block(64, 4);
+    hipLaunchKernelGGL(k_resize_linear, grid, block, 0, st, src, sstride, spitch, pl.pyr + D.off, pl.pyr_frame_stride, D.pitch,
+                       D.w, D.h, rs.xofs0 + rs.col_base[level], rs.xofs1 + rs.col_base[level], rs.a0 + rs.col_base[level],
+                       rs.a1 + rs.col_base[level], rs.yofs0 + rs.row_base[level], rs.yofs1 + rs.row_base[level],
+                       rs.b0 + rs.row_base[level], rs.b1 + rs.row_base[level]);
+}
+
+void launch_fast(hipStream_t st, const OrbPlanes& pl, const CellDesc* d_cells, int n_cells, const LevelDev* d_lv, int B,
+                 int ini_thr, int min_thr, const uint8_t* d_mask, size_t mask_step, size_t mask_frame_stride,
+                 uint32_t* cell_cand, int32_t* cell_count) {
+    hipLaunchKernelGGL(k_fast_cells, dim3(n_cells, B), dim3(256), 0, st, pl, d_cells, d_lv, ini_thr, min_thr, d_mask, mask_step,
+                       mask_frame_stride, cell_cand, cell_count, n_cells);
+}
+
+void launch_blur(hipStream_t st, const OrbPlanes& pl, uint8_t* blur, size_t blur_frame_stride, const LevelDev* d_lv,
+                 int n_levels, int total_tiles, int B, const BlurTaps& taps) {
+    hipLaunchKernelGGL(k_blur7, dim3(total_tiles, B), dim3(256), 0, st, pl, blur, blur_frame_stride, d_lv, n_levels, taps);
+}
+
+void launch_orient_rbrief(hipStream_t st, const OrbPlanes& pl, const uint8_t* blur, size_t blur_frame_stride,
+                          const LevelDev* d_lv, int n_levels, const int32_t* sel, const int32_t* sel_count,
+                          int total_sel_cap, const UMax& um, plp_keypoint* kps, uint8_t* desc, int cap, int32_t* counts,
+                          int32_t* status, int B) {
+    hipLaunchKernelGGL(k_orient_rbrief, dim3((total_sel_cap + 3) / 4, B), dim3(256), 0, st, pl, blur, blur_frame_stride, d_lv,
+                       n_levels, sel, sel_count, total_sel_cap, um, kps, desc, cap, counts, status);
+}
+
+}  // namespace plp

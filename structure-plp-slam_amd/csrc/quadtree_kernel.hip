@@ -1,0 +1,372 @@
+// K4  key-point distribution (quadtree) on the GPU: one 256-thread workgroup per (level, frame).
+//
+// Restates distribute_keypoints_via_tree (reference src/PLPSLAM/feature/orb_extractor.cc:468-685)
+// in the sort-based form proven equivalent on the host in quadtree_model.hpp:
+//   1. gather the level's per-cell candidate lists in reference order (cell row, cell col, row-major)
+//   2. one tree key per candidate (initial node + 2 bits per split), LSD radix sort by key
+//   3. every node = a range of the sorted array; whole-list split passes and the "fullest first"
+//      fill phase run data-parallel over node records with prefix sums giving the list order
+//   4. per node: maximum score, ties to the smallest candidate index
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "orb_device.hpp"
+#include "quadtree_model.hpp"
+
+namespace plp {
+
+constexpr int kQtMaxNodes = 2048;
+constexpr int kQtMaxCand = 16384;
+constexpr int kQtSegMax = kQtMaxCand / 64;   // 256 wave-sized segments
+constexpr int kQtKeyCache = 4096;
+
+struct QtShared {
+    uint32_t big[16 * kQtSegMax];   // radix counters, later the sorted-key cache (4096 keys)
+    uint16_t ns[2][kQtMaxNodes], ne[2][kQtMaxNodes];
+    uint8_t nd[2][kQtMaxNodes], nleaf[2][kQtMaxNodes];
+    uint16_t b1[kQtMaxNodes], b2[kQtMaxNodes], b3[kQtMaxNodes];
+    uint32_t pk[kQtMaxNodes];       // packed per-entry counts -> exclusive prefixes (lo16 created, hi16 kept)
+    uint16_t pool_pos[kQtMaxNodes], pool_sorted[kQtMaxNodes];
+    uint32_t partial[256];
+    int misc[8];
+};
+
+// in-place exclusive scan of a[0..M) by the whole workgroup; returns the total
+__device__ uint32_t block_scan_excl(uint32_t* a, int M, uint32_t* partial) {
+    const int tid = threadIdx.x;
+    const int chunk = (M + 255) >> 8;
+    const int lo = min(tid * chunk, M), hi = min(lo + chunk, M);
+    uint32_t sum = 0;
+    for (int i = lo; i < hi; ++i) sum += a[i];
+    partial[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const uint32_t t = tid >= off ? partial[tid - off] : 0;
+        __syncthreads();
+        partial[tid] += t;
+        __syncthreads();
+    }
+    uint32_t run = partial[tid] - sum;
+    const uint32_t total = partial[255];
+    for (int i = lo; i < hi; ++i) { const uint32_t v = a[i]; a[i] = run; run += v; }
+    __syncthreads();
+    return total;
+}
+
+__device__ __forceinline__ uint32_t dev_qt_key(int x, int y, const LevelDev& L) {
+    const unsigned ix = (unsigned)((double)(float)x / L.delta_x);
+    const unsigned iy = (unsigned)((double)(float)y / L.delta_y);
+    const unsigned node = ix + iy * (unsigned)L.n_init_x;
+    int bx = (int)(L.delta_x * ix), ex = (int)(L.delta_x * (ix + 1));
+    int by = (int)(L.delta_y * iy), ey = (int)(L.delta_y * (iy + 1));
+    uint32_t key = node;
+#pragma unroll
+    for (int d = 0; d < kQtDepth; ++d) {
+        const int mx = bx + ((ex - bx + 1) >> 1), my = by + ((ey - by + 1) >> 1);
+        const unsigned xb = mx <= x, yb = my <= y;
+        bx = xb ? mx : bx; ex = xb ? ex : mx;
+        by = yb ? my : by; ey = yb ? ey : my;
+        key = (key << 2) | (xb | (yb << 1));
+    }
+    return key;
+}
+
+// split node [s,e) at `depth`: boundaries of digit values 1,2,3; returns number of non-empty children
+__device__ __forceinline__ int dev_split(const uint32_t* K, int s, int e, int depth, int& o1, int& o2, int& o3) {
+    if (depth >= kQtDepth) { o1 = o2 = o3 = e; return 1; }
+    const int sh = 2 * (kQtDepth - 1 - depth);
+    if (e - s == 1) {
+        const unsigned d = (K[s] >> sh) & 3u;
+        o1 = d >= 1 ? s : e; o2 = d >= 2 ? s : e; o3 = d >= 3 ? s : e;
+        return 1;
+    }
+    int b[3];
+#pragma unroll
+    for (unsigned v = 1; v <= 3; ++v) {
+        int lo = s, hi = e;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (((K[mid] >> sh) & 3u) >= v) hi = mid; else lo = mid + 1;
+        }
+        b[v - 1] = lo;
+    }
+    o1 = b[0]; o2 = b[1]; o3 = b[2];
+    return (o1 > s) + (o2 > o1) + (o3 > o2) + (e > o3);
+}
+
+__global__ __launch_bounds__(256) void k_quadtree(const LevelDev* __restrict__ lv, int n_cells_total,
+                                                  const uint32_t* __restrict__ cell_cand, const int32_t* __restrict__ cell_count,
+                                                  int32_t* __restrict__ sel, int32_t* __restrict__ sel_count, int total_sel_cap,
+                                                  uint8_t* __restrict__ scratch, size_t scratch_frame_stride,
+                                                  int32_t* __restrict__ status) {
+    __shared__ QtShared S;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int level = blockIdx.x, frame = blockIdx.y;
+    const LevelDev L = lv[level];
+    const int N = L.quota;
+    uint32_t* cand = reinterpret_cast<uint32_t*>(scratch + (size_t)frame * scratch_frame_stride + L.qt_off);
+    uint32_t* key = cand + L.qt_cap;
+    uint32_t* idxA = key + L.qt_cap;
+    uint32_t* idxB = idxA + L.qt_cap;
+    int32_t* out_sel = sel + (size_t)frame * total_sel_cap + L.sel_base;
+    int32_t* out_cnt = sel_count + frame * kMaxLevels + level;
+
+    // ---- 1. gather candidates in reference order + keys
+    const int32_t* cc = cell_count + (size_t)frame * n_cells_total + L.cell_base;
+    for (int c = tid; c < L.n_cells; c += 256) S.big[c] = (uint32_t)cc[c];
+    __syncthreads();
+    int n = (int)block_scan_excl(S.big, L.n_cells, S.partial);
+    if (n > L.qt_cap) { if (tid == 0) atomicOr(status, 2); n = L.qt_cap; }
+    for (int c = wv; c < L.n_cells; c += 4) {
+        const int base = (int)S.big[c], cnt = cc[c];
+        const uint32_t* src = cell_cand + ((size_t)frame * n_cells_total + L.cell_base + c) * kCellCap;
+        for (int j = lane; j < cnt; j += 64) {
+            const int dst = base + j;
+            if (dst < n) {
+                const uint32_t pk = src[j];
+                cand[dst] = pk;
+                key[dst] = dev_qt_key((int)(pk & 0xfff), (int)((pk >> 12) & 0xfff), L);
+            }
+        }
+    }
+    __syncthreads();
+    if (n == 0) { if (tid == 0) *out_cnt = 0; return; }
+
+    // ---- 2. LSD radix sort (4 bits per pass) of candidate indices by key bits [sort_lo, sort_hi)
+    const int nseg = (n + 63) >> 6;
+    uint32_t* src = idxA;
+    uint32_t* dst = idxB;
+    bool first = true;
+    for (int shift = L.sort_lo; shift < L.sort_hi; shift += 4) {
+        for (int seg = wv; seg < nseg; seg += 4) {
+            const int i = seg * 64 + lane;
+            unsigned d = 16;
+            if (i < n) d = (key[first ? (uint32_t)i : src[i]] >> shift) & 15u;
+            uint32_t mine = 0;
+#pragma unroll
+            for (unsigned v = 0; v < 16; ++v) {
+                const unsigned long long bal = __ballot(d == v);
+                if ((unsigned)lane == v) mine = (uint32_t)__popcll(bal);
+            }
+            if (lane < 16) S.big[lane * nseg + seg] = mine;
+        }
+        __syncthreads();
+        block_scan_excl(S.big, 16 * nseg, S.partial);
+        for (int seg = wv; seg < nseg; seg += 4) {
+            const int i = seg * 64 + lane;
+            unsigned d = 16;
+            uint32_t id = 0;
+            if (i < n) { id = first ? (uint32_t)i : src[i]; d = (key[id] >> shift) & 15u; }
+            unsigned long long mybal = 0;
+#pragma unroll
+            for (unsigned v = 0; v < 16; ++v) {
+                const unsigned long long bal = __ballot(d == v);
+                if (d == v) mybal = bal;
+            }
+            if (i < n) dst[S.big[d * nseg + seg] + (uint32_t)__popcll(mybal & ((1ull << lane) - 1ull))] = id;
+        }
+        __syncthreads();
+        uint32_t* t = src; src = dst; dst = t;
+        first = false;
+    }
+    // src now holds candidate indices in key order (identity if no pass ran); dst <- sorted keys
+    for (int i = tid; i < n; i += 256) {
+        const uint32_t id = first ? (uint32_t)i : src[i];
+        if (first) src[i] = id;
+        const uint32_t k = key[id];
+        dst[i] = k;
+        if (n <= kQtKeyCache) S.big[i] = k;
+    }
+    __syncthreads();
+    const uint32_t* sidx = src;
+    const uint32_t* K = n <= kQtKeyCache ? S.big : dst;   // flat pointer: LDS cache or HBM scratch
+
+    // ---- 3a. initial nodes = runs of equal initial-node index
+    int cur = 0;
+    if (tid == 0) {
+        int m = 0, s = 0;
+        while (s < n) {   // at most n_init (<= 8) runs; binary search each end
+            const uint32_t node = K[s] >> (2 * kQtDepth);
+            int lo = s, hi = n;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if ((K[mid] >> (2 * kQtDepth)) > node) hi = mid; else lo = mid + 1; }
+            S.ns[0][m] = (uint16_t)s; S.ne[0][m] = (uint16_t)lo; S.nd[0][m] = 0; S.nleaf[0][m] = (lo - s == 1);
+            ++m; s = lo;
+        }
+        S.misc[0] = m;
+    }
+    __syncthreads();
+    int m = S.misc[0];
+    bool filled = false, failed = false;
+
+    // ---- 3b. phase 1: split every non-leaf entry, children to the front in reverse creation order
+    while (true) {
+        const int prev = m;
+        if (tid == 0) S.misc[1] = 0;   // pool size (children with more than one point)
+        __syncthreads();
+        for (int i = tid; i < m; i += 256) {
+            if (S.nleaf[cur][i]) { S.pk[i] = 1u << 16; continue; }
+            int o1, o2, o3;
+            const int s = S.ns[cur][i], e = S.ne[cur][i];
+            const int k = dev_split(K, s, e, S.nd[cur][i], o1, o2, o3);
+            S.b1[i] = (uint16_t)o1; S.b2[i] = (uint16_t)o2; S.b3[i] = (uint16_t)o3;
+            S.pk[i] = (uint32_t)k;
+            const int big = (o1 - s > 1) + (o2 - o1 > 1) + (o3 - o2 > 1) + (e - o3 > 1);
+            if (big) atomicAdd(&S.misc[1], big);
+        }
+        __syncthreads();
+        const uint32_t tot = block_scan_excl(S.pk, m, S.partial);
+        const int T = (int)(tot & 0xffff), kept = (int)(tot >> 16);
+        const int m_new = T + kept;
+        if (m_new > kQtMaxNodes) { failed = true; break; }
+        const int nxt = cur ^ 1;
+        for (int i = tid; i < m; i += 256) {
+            const uint32_t p = S.pk[i];
+            const int s = S.ns[cur][i], e = S.ne[cur][i];
+            if (S.nleaf[cur][i]) {
+                const int pos = T + (int)(p >> 16);
+                S.ns[nxt][pos] = (uint16_t)s; S.ne[nxt][pos] = (uint16_t)e; S.nd[nxt][pos] = S.nd[cur][i]; S.nleaf[nxt][pos] = 1;
+                continue;
+            }
+            int q = (int)(p & 0xffff);
+            const int b[5] = {s, S.b1[i], S.b2[i], S.b3[i], e};
+            const uint8_t dep = (uint8_t)min((int)S.nd[cur][i] + 1, 255);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (b[c + 1] > b[c]) {
+                    const int pos = T - 1 - q;
+                    S.ns[nxt][pos] = (uint16_t)b[c]; S.ne[nxt][pos] = (uint16_t)b[c + 1]; S.nd[nxt][pos] = dep; S.nleaf[nxt][pos] = 0;
+                    ++q;
+                }
+        }
+        __syncthreads();
+        cur = nxt; m = m_new;
+        const int pool = S.misc[1];
+        if (N <= m || m == prev) { filled = true; break; }
+        if (N < m + pool) break;
+        __syncthreads();
+    }
+
+    // ---- 3c. phase 2: split the fullest entries first until the quota is reached
+    while (!filled && !failed) {
+        const int prev = m;
+        // pool = entries with more than one point, in list order (ordered compaction)
+        for (int i = tid; i < m; i += 256) S.pk[i] = (uint32_t)(S.ne[cur][i] - S.ns[cur][i] > 1);
+        __syncthreads();
+        const int p = (int)block_scan_excl(S.pk, m, S.partial);
+        for (int i = tid; i < m; i += 256)
+            if (S.ne[cur][i] - S.ns[cur][i] > 1) S.pool_pos[S.pk[i]] = (uint16_t)i;
+        __syncthreads();
+        if (p == 0) break;   // nothing left to split
+        // order: count descending, then list position ascending (== creation descending)
+        for (int a = tid; a < p; a += 256) {
+            const int ia = S.pool_pos[a];
+            const uint32_t ka = ((uint32_t)(S.ne[cur][ia] - S.ns[cur][ia]) << 12) | (uint32_t)(4095 - min(ia, 4095));
+            int rank = 0;
+            for (int b = 0; b < p; ++b) {
+                const int ib = S.pool_pos[b];
+                const uint32_t kb = ((uint32_t)(S.ne[cur][ib] - S.ns[cur][ib]) << 12) | (uint32_t)(4095 - min(ib, 4095));
+                rank += kb > ka;
+            }
+            S.pool_sorted[rank] = (uint16_t)ia;
+        }
+        __syncthreads();
+        // split in sorted order; inclusive gain prefix decides where the quota is met
+        for (int j = tid; j < p; j += 256) {
+            const int i = S.pool_sorted[j];
+            int o1, o2, o3;
+            const int k = dev_split(K, S.ns[cur][i], S.ne[cur][i], S.nd[cur][i], o1, o2, o3);
+            S.b1[j] = (uint16_t)o1; S.b2[j] = (uint16_t)o2; S.b3[j] = (uint16_t)o3;
+            S.pk[j] = (uint32_t)k;
+        }
+        if (tid == 0) S.misc[2] = p;   // r+1 = number of pool entries actually split
+        __syncthreads();
+        block_scan_excl(S.pk, p, S.partial);   // exclusive prefix of k over sorted order
+        for (int j = tid; j < p; j += 256) {
+            const int i = S.pool_sorted[j];
+            int k = 1;
+            {   // recover k_j from the boundaries
+                const int s = S.ns[cur][i], e = S.ne[cur][i];
+                k = (S.b1[j] > s) + (S.b2[j] > S.b1[j]) + (S.b3[j] > S.b2[j]) + (e > S.b3[j]);
+            }
+            const int size_after = m + (int)S.pk[j] + k - (j + 1);   // m + sum_{t<=j} (k_t - 1)
+            if (N <= size_after) atomicMin(&S.misc[2], j + 1);
+        }
+        __syncthreads();
+        const int nsplit = S.misc[2];
+        // total children created by the first nsplit entries
+        int T;
+        {
+            const int jl = nsplit - 1, il = S.pool_sorted[jl];
+            const int s = S.ns[cur][il], e = S.ne[cur][il];
+            const int kl = (S.b1[jl] > s) + (S.b2[jl] > S.b1[jl]) + (S.b3[jl] > S.b2[jl]) + (e > S.b3[jl]);
+            T = (int)S.pk[jl] + kl;
+        }
+        const int m_new = T + m - nsplit;
+        if (m_new > kQtMaxNodes) { failed = true; break; }
+        const int nxt = cur ^ 1;
+        // erased flags + survivors' new positions
+        __syncthreads();
+        for (int j = tid; j < nsplit; j += 256) {
+            const int i = S.pool_sorted[j];
+            int q = (int)S.pk[j];
+            const int s = S.ns[cur][i], e = S.ne[cur][i];
+            const int b[5] = {s, S.b1[j], S.b2[j], S.b3[j], e};
+            const uint8_t dep = (uint8_t)min((int)S.nd[cur][i] + 1, 255);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (b[c + 1] > b[c]) {
+                    const int pos = T - 1 - q;
+                    S.ns[nxt][pos] = (uint16_t)b[c]; S.ne[nxt][pos] = (uint16_t)b[c + 1]; S.nd[nxt][pos] = dep; S.nleaf[nxt][pos] = 0;
+                    ++q;
+                }
+            S.nleaf[cur][i] |= 2;   // mark erased
+        }
+        __syncthreads();
+        for (int i = tid; i < m; i += 256) S.pk[i] = (S.nleaf[cur][i] & 2) ? 0u : 1u;
+        __syncthreads();
+        block_scan_excl(S.pk, m, S.partial);
+        for (int i = tid; i < m; i += 256)
+            if (!(S.nleaf[cur][i] & 2)) {
+                const int pos = T + (int)S.pk[i];
+                S.ns[nxt][pos] = S.ns[cur][i]; S.ne[nxt][pos] = S.ne[cur][i]; S.nd[nxt][pos] = S.nd[cur][i]; S.nleaf[nxt][pos] = S.nleaf[cur][i];
+            }
+        __syncthreads();
+        cur = nxt; m = m_new;
+        if (N <= m || m == prev) break;
+    }
+
+    if (failed) {
+        if (tid == 0) { atomicOr(status, 2); *out_cnt = 0; }
+        return;
+    }
+    // ---- 4. best candidate per node: max score, then smallest candidate index
+    const int m_out = min(m, L.sel_cap);
+    if (m > L.sel_cap && tid == 0) atomicOr(status, 2);
+    for (int i = tid; i < m_out; i += 256) {
+        const int s = S.ns[cur][i], e = S.ne[cur][i];
+        uint32_t best_id = sidx[s];
+        uint32_t best_pk = cand[best_id];
+        for (int t = s + 1; t < e; ++t) {
+            const uint32_t id = sidx[t], pk = cand[id];
+            const uint32_t sa = pk >> 24, sb = best_pk >> 24;
+            if (sa > sb || (sa == sb && id < best_id)) { best_id = id; best_pk = pk; }
+        }
+        out_sel[i] = (int32_t)best_pk;
+    }
+    if (tid == 0) *out_cnt = m_out;
+}
+
+size_t quadtree_scratch_bytes_per_frame(const LevelDev* h_lv, int n_levels) {
+    size_t end = 0;
+    for (int l = 0; l < n_levels; ++l) end = h_lv[l].qt_off + (size_t)h_lv[l].qt_cap * 16;
+    return (end + 255) / 256 * 256;
+}
+
+void launch_quadtree(hipStream_t st, const LevelDev* d_lv, int n_levels, int n_cells_total, const uint32_t* cell_cand,
+                     const int32_t* cell_count, int32_t* sel, int32_t* sel_count, int total_sel_cap, uint32_t* qt_scratch,
+                     size_t qt_scratch_frame_stride, int32_t* status, int B) {
+    hipLaunchKernelGGL(k_quadtree, dim3(n_levels, B), dim3(256), 0, st, d_lv, n_cells_total, cell_cand, cell_count, sel, sel_count,
+                       total_sel_cap, reinterpret_cast<uint8_t*>(qt_scratch), qt_scratch_frame_stride, status);
+}
+
+}  // namespace plp

@@ -1,0 +1,68 @@
+"""CPU-only checks of the product side: the C-ABI library loads and exports every symbol that
+include/plp_front.h declares, the no-GPU behaviour is loud, and the host model of the quadtree
+kernel agrees with the oracle's std::list restatement."""
+import ctypes as C
+import re
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from plp import plp
+
+
+def test_library_exports_every_declared_symbol():
+    L = plp.lib()
+    header = (plp.ROOT / "include" / "plp_front.h").read_text()
+    declared = set(re.findall(r"\b(plp_[a-z0-9_]+)\s*\(", header))
+    declared -= {"plp_status"}
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(L, name), f"{name} declared in plp_front.h but not exported"
+    for name in plp.api_symbols():
+        assert hasattr(L, name)
+    assert L.plp_version() >= 1
+    assert L.plp_strerror(0) == b"ok"
+
+
+def test_no_gpu_is_loud():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    assert plp.lib().plp_device_count() == 0
+    with pytest.raises(plp.PlpError) as e:
+        plp.orb_extractor()
+    assert e.value.status == plp.PLP_ERR_NO_DEVICE
+
+
+def test_param_validation_matches_orb_params():
+    """orb_params.cc:40-54: bad mask rectangles throw -> PLP_ERR_INVALID_ARG before any device use."""
+    for bad in ([[0.5, 0.2, 0.3, 0.8]], [[0.2, 0.5, 0.8, 0.3]]):
+        with pytest.raises(ValueError):
+            plp.orb_extractor(mask_rects=bad)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_quadtree_model_equals_oracle_list(seed):
+    rng = np.random.default_rng(seed)
+    ex = O.OrbOracle()
+    for trial in range(25):
+        w, h = [(640, 480), (1241, 376), (600, 1200), (int(rng.integers(60, 700)), int(rng.integers(60, 700)))][trial % 4]
+        bw, bh = w - 38, h - 38
+        n = int(rng.integers(0, min(3000, (bw - 6) * (bh - 6) // 4)))
+        quota = int(rng.integers(0, 900))
+        flat = rng.choice((bw - 6) * (bh - 6), size=n, replace=False)
+        pts = np.stack([flat % (bw - 6) + 3, flat // (bw - 6) + 3], 1)
+        if trial % 3 == 0 and n:   # clustered
+            c = pts[rng.integers(0, n, 4)]
+            pts = np.unique(np.clip(c[rng.integers(0, 4, n)] + rng.normal(0, 12, (n, 2)).astype(int), 3, [bw - 4, bh - 4]), axis=0)
+            rng.shuffle(pts)
+            n = len(pts)
+        score = rng.integers(7, 13 if trial % 2 else 255, n)   # narrow range -> many response ties
+        cands = np.zeros(n, O.KP_DTYPE)
+        cands["x"], cands["y"], cands["response"] = pts[:, 0], pts[:, 1], score
+        ref = ex.distribute(cands, 19, w - 19, 19, h - 19, quota)
+        xys = np.stack([pts[:, 0], pts[:, 1], score], 1).astype(np.int32) if n else np.zeros((0, 3), np.int32)
+        pick = plp.model_quadtree(xys, w, h, quota)
+        got = xys[pick]
+        want = np.stack([ref["x"], ref["y"], ref["response"]], 1).astype(np.int32)
+        assert np.array_equal(got, want), (w, h, n, quota)

@@ -1,0 +1,138 @@
+"""GPU parity: the HIP ORB path (through the C ABI) against the CPU oracle on identical frames.
+Bit-exact bar for every integer stage and for positions/octaves/descriptors; angles within 1e-4
+(north_star), in practice identical."""
+import numpy as np
+import pytest
+from PIL import Image
+
+import oracle_lib as O
+from plp import plp, synth
+
+pytestmark = pytest.mark.gpu
+ANGLE_TOL = 1e-4
+
+
+def frames_640(golden_dir):
+    out = [np.asarray(Image.open(golden_dir / n)) for n in
+           ("equirect1_640x480.png", "equirect2_640x480.png", "equirect1_crop_640x480.png", "equirect2_crop_640x480.png")]
+    out.append(synth.canvas(1234, 480, 640))
+    return out
+
+
+def compare_full(img, K=1000, mask=None, mask_rects=(), **kw):
+    ora = O.OrbOracle(K, mask_rects=mask_rects, **kw)
+    ok, od = ora.extract(img, mask)
+    ex = plp.orb_extractor(K, mask_rects=mask_rects, **kw)
+    gk, gd = ex.extract(img, mask)
+    nl = ex.get_num_scale_levels()
+    for l in range(nl):   # stage by stage, so a failure names its stage
+        assert np.array_equal(ex.image_pyramid(l), ora.level_image(l)), f"pyramid level {l}"
+        oc = ora.candidates(l)
+        want = np.stack([oc["x"], oc["y"], oc["response"]], 1).astype(np.int32) if len(oc) else np.zeros((0, 3), np.int32)
+        assert np.array_equal(ex.debug_read(ex.DBG_CANDIDATES, l), want), f"FAST candidates level {l}"
+        ol = ora.level_keypts(l)
+        want = np.stack([ol["x"] - 19, ol["y"] - 19, ol["response"]], 1).astype(np.int32) if len(ol) else np.zeros((0, 3), np.int32)
+        assert np.array_equal(ex.debug_read(ex.DBG_SELECTED, l), want), f"quadtree level {l}"
+        ob = ora.level_blurred(l)
+        if ob is not None:
+            assert np.array_equal(ex.debug_read(ex.DBG_BLURRED, l), ob), f"blur level {l}"
+    assert len(gk) == len(ok)
+    for f in ("x", "y", "size", "response", "octave", "class_id"):
+        assert np.array_equal(gk[f], ok[f]), f
+    assert np.abs(gk["angle"] - ok["angle"]).max(initial=0) <= ANGLE_TOL
+    assert np.array_equal(gk["angle"], ok["angle"])          # same f32 polynomial: exact in practice
+    assert np.array_equal(gd, od)
+    return gk, gd
+
+
+def test_extract_matches_oracle_on_fixture_frames(golden_dir):
+    for img in frames_640(golden_dir):
+        for K in (1000, 2000):
+            compare_full(img, K)
+
+
+@pytest.mark.parametrize("shape", [(376, 1241), (480, 752), (600, 600), (1200, 600), (240, 320), (333, 517)])
+def test_extract_other_geometries(shape):
+    h, w = shape
+    img = synth.canvas(7 + h + w, h, w)
+    compare_full(img, 2000 if w > 1000 else 1000)
+
+
+def test_toy_corners_and_portrait():
+    """reference toy tests (test/PLPSLAM/feature/orb_extractor.cc:27,56,361): HIP path == oracle, and the property holds"""
+    for rows, cols, rect, cx, cy in [(600, 600, (300, 300, 600, 600), 300, 300), (1200, 600, (300, 600, 600, 1200), 300, 600),
+                                     (2000, 2000, (0, 0, 1800, 1800), 1800, 1800)]:
+        img = np.full((rows, cols), 255, np.uint8)
+        img[rect[1]:rect[3] + 1, rect[0]:rect[2] + 1] = 0
+        gk, gd = compare_full(img, 2000)
+        s = plp.orb_extractor().get_scale_factors()
+        assert len(gk) > 0
+        assert (np.abs(gk["x"] - cx) <= 2.0 * s[gk["octave"]]).all() and (np.abs(gk["y"] - cy) <= 2.0 * s[gk["octave"]]).all()
+
+
+def test_masks(golden_dir):
+    img = np.asarray(Image.open(golden_dir / "equirect1_640x480.png"))
+    rows, cols = img.shape
+    m = np.ones_like(img); m[0:rows // 4] = 0; m[3 * rows // 4:rows - 1] = 0
+    gk, _ = compare_full(img, 2000, mask=m)
+    assert (gk["y"] >= rows // 4).all() and (gk["y"] <= 3 * rows // 4).all()
+    m = np.ones_like(img); m[:, 0:cols // 4] = 0; m[:, 3 * cols // 4:cols - 1] = 0
+    gk, _ = compare_full(img, 2000, mask=m)
+    assert (gk["x"] >= cols // 4).all() and (gk["x"] <= 3 * cols // 4).all()
+    gk, _ = compare_full(img, 2000, mask_rects=[[0.0, 1.0, 0.0, 0.2], [0.0, 1.0, 0.8, 1.0]])
+    assert (gk["y"] >= rows // 5).all() and (gk["y"] <= 4 * rows // 5).all()
+
+
+def test_flat_and_noise_images():
+    compare_full(np.full((480, 640), 128, np.uint8), 1000)                       # no corner anywhere
+    rng = np.random.default_rng(3)
+    compare_full(rng.integers(0, 256, (480, 640), dtype=np.uint8), 2000)         # corner-dense: stresses the sort
+    compare_full(rng.integers(100, 112, (240, 320), dtype=np.uint8), 500)        # only the thr-7 fallback fires
+
+
+def test_parameter_variants(golden_dir):
+    img = np.asarray(Image.open(golden_dir / "equirect2_crop_640x480.png"))
+    compare_full(img, 500, num_levels=4, scale_factor=1.5)
+    compare_full(img, 4000)
+    compare_full(img, 300, ini_fast_thr=40, min_fast_thr=15)
+
+
+def test_setters_reinitialize(golden_dir):
+    img = np.asarray(Image.open(golden_dir / "equirect1_crop_640x480.png"))
+    ex = plp.orb_extractor(1000)
+    ex.extract(img)
+    ex.set_max_num_keypoints(2000)      # tracking_module.cc:66-70 builds the init extractor this way
+    gk, gd = ex.extract(img)
+    ok, od = O.OrbOracle(2000).extract(img)
+    assert np.array_equal(gd, od) and np.array_equal(gk["x"], ok["x"])
+    assert ex.get_num_keypts_per_level().sum() == 2000
+
+
+def test_batched_device_path_equals_single_frame():
+    import torch
+    frames = synth.replay(11, 6)
+    dev = torch.device("cuda:0")
+    d = torch.from_numpy(frames).to(dev)
+    K, cap = 1000, 2100
+    ex = plp.orb_extractor(K)
+    d_kps = torch.zeros((len(frames), cap, 28), dtype=torch.uint8, device=dev)
+    d_desc = torch.zeros((len(frames), cap, 32), dtype=torch.uint8, device=dev)
+    d_cnt = torch.zeros(len(frames), dtype=torch.int32, device=dev)
+    ex.extract_batch(d, d_kps, d_desc, d_cnt)
+    torch.cuda.synchronize()
+    ex.last_batch_status()
+    cnt = d_cnt.cpu().numpy()
+    kps = d_kps.cpu().numpy().view(plp.KP_DTYPE).reshape(len(frames), cap)
+    desc = d_desc.cpu().numpy()
+    ora = O.OrbOracle(K)
+    for f in range(len(frames)):
+        ok, od = ora.extract(frames[f])
+        assert cnt[f] == len(ok)
+        assert np.array_equal(kps[f, :cnt[f]], ok)
+        assert np.array_equal(desc[f, :cnt[f]], od)
+
+
+def test_empty_image_is_noop():
+    ex = plp.orb_extractor()
+    k, d = ex.extract(np.zeros((0, 0), np.uint8))
+    assert len(k) == 0 and len(d) == 0
