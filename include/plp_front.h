@@ -111,6 +111,12 @@ plp_status plp_orb_extract_batch_device(plp_orb* ctx, const uint8_t* d_imgs, int
 /* Synchronises the last batch's stream and reports truncation / overflow (PLP_OK if none). */
 plp_status plp_orb_last_batch_status(plp_orb* ctx);
 
+/* Per-stage timing with HIP events recorded on the stream the kernels run on (profiling mode makes
+ * every batch synchronous; leave it off in throughput runs).  ms7 = accumulated milliseconds of
+ * {level-0 copy, pyramid, FAST cells, blur, quadtree, orientation+rBRIEF, whole batch}. */
+plp_status plp_orb_set_profiling(plp_orb* ctx, int32_t enable);
+plp_status plp_orb_get_stage_times(plp_orb* ctx, double* ms7, int64_t* n_batches);
+
 /* orb_extractor::image_pyramid_ (public member, orb_extractor.h:101; read by match::stereo,
  * src/PLPSLAM/data/frame.cc:277-281).  Copies level `level` of frame `frame` of the last call to host. */
 plp_status plp_orb_pyramid_level_size(const plp_orb* ctx, int32_t level, int32_t* rows, int32_t* cols);

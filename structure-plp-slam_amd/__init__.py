@@ -62,6 +62,8 @@ _API = [
     ("plp_orb_extract", C.c_int, [_VP, _VP, _I32, _I32, _SZ, _VP, _SZ, _VP, _VP, _I32, _VP]),
     ("plp_orb_extract_batch_device", C.c_int, [_VP, _VP, _I32, _I32, _I32, _SZ, _SZ, _VP, _SZ, _SZ, _VP, _VP, _I32, _VP, _VP]),
     ("plp_orb_last_batch_status", C.c_int, [_VP]),
+    ("plp_orb_set_profiling", C.c_int, [_VP, _I32]),
+    ("plp_orb_get_stage_times", C.c_int, [_VP, _VP, _VP]),
     ("plp_orb_pyramid_level_size", C.c_int, [_VP, _I32, _VP, _VP]),
     ("plp_orb_pyramid_host", C.c_int, [_VP, _I32, _I32, _VP, _SZ]),
     ("plp_orb_debug_read", C.c_int, [_VP, C.c_int, _I32, _I32, _VP, _SZ, _VP]),
@@ -79,6 +81,12 @@ def lib():
     if _lib is None:
         if not LIB_PATH.exists():
             raise FileNotFoundError(f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
+        try:
+            # PyTorch bundles its own HIP/HSA runtime; a process must hold exactly one.  Loading torch first
+            # makes libplp_front.so (NEEDED libamdhip64.so.7) bind to that copy instead of /opt/rocm's.
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(str(LIB_PATH))
         for name, res, args in _API:
             fn = getattr(L, name)
@@ -195,6 +203,19 @@ class orb_extractor:
 
     def last_batch_status(self):
         _check(lib().plp_orb_last_batch_status(self._h))
+
+    STAGES = ("l0_copy", "pyramid", "fast_cells", "blur7", "quadtree", "orient_rbrief", "batch_total")
+
+    def set_profiling(self, on):
+        _check(lib().plp_orb_set_profiling(self._h, int(bool(on))))
+
+    def stage_times_ms(self):
+        """(dict stage -> mean ms per batch, number of batches) accumulated since set_profiling(True)"""
+        ms = np.zeros(7, np.float64)
+        n = C.c_int64()
+        _check(lib().plp_orb_get_stage_times(self._h, _p(ms), C.byref(n)))
+        nb = max(n.value, 1)
+        return {k: float(v) / nb for k, v in zip(self.STAGES, ms)}, n.value
 
     # ---- image_pyramid_ (orb_extractor.h:101) and stage read-backs for parity tests
     def image_pyramid(self, level, frame=0):

@@ -52,6 +52,11 @@ struct plp_orb {
     OrbPlanes last_planes{};
     hipStream_t last_stream = nullptr;
     bool use_host_quadtree = false;
+    // per-stage HIP-event timing (profiling mode only; makes every batch synchronous)
+    bool profiling = false;
+    hipEvent_t ev[8] = {};
+    double stage_ms[7] = {0, 0, 0, 0, 0, 0, 0};   // l0 copy, pyramid, FAST, blur, quadtree, orient+rBRIEF, total
+    long stage_batches = 0;
     std::mutex mu;
 };
 
@@ -103,7 +108,7 @@ plp_status build_geometry(plp_orb* c, int rows, int cols) {
         L.quota = (int)c->st.quota[l];
         L.n_init_x = G.n_init_x; L.delta_x = G.delta_x; L.delta_y = G.delta_y;
         // quadtree scratch + the key bits that can differ between two candidates of this level
-        L.qt_cap = std::min(std::max(L.n_cells, 1) * 512, 16384);
+        L.qt_cap = std::min(std::max(L.n_cells, 1) * kCellCap, 65535);   // FAST's own bound, capped by the u16 node ranges
         L.qt_off = qt_off;
         qt_off += (size_t)L.qt_cap * 16;
         const int extent = (int)std::ceil(std::max(G.delta_x, G.delta_y)) + 1;
@@ -115,7 +120,7 @@ plp_status build_geometry(plp_orb* c, int rows, int cols) {
         while ((1 << nb) < n_init) ++nb;
         L.sort_lo = 2 * (kQtDepth - d_eff);
         L.sort_hi = 2 * kQtDepth + nb;
-        if (L.n_cells > 4096 || L.sel_cap > 2048 || n_init > 32)
+        if (L.n_cells > 8192 || L.sel_cap > 2048 || n_init > 32)
             return set_error(PLP_ERR_UNSUPPORTED, "frame/keypoint budget exceeds the quadtree kernel limits (quota per level <= 1022)");
     }
     PLP_HIP(c->d_lv.upload(c->h_lv.data(), sizeof(LevelDev) * nl, c->stream));
@@ -220,6 +225,9 @@ plp_status run_batch(plp_orb* c, const uint8_t* d_imgs, int B, int rows, int col
     const OrbGeometry& g = c->geo;
     const int nl = g.n_levels;
 
+    const bool prof = c->profiling;
+    auto mark = [&](int i) { if (prof) (void)hipEventRecord(c->ev[i], st); };
+    mark(0);
     OrbPlanes pl{};
     pl.pyr = (uint8_t*)c->pyr.p; pl.pyr_frame_stride = g.frame_plane_bytes;
     const bool aligned = ((uintptr_t)d_imgs % 4 == 0) && (step % 4 == 0) && (frame_stride % 4 == 0);
@@ -243,20 +251,32 @@ plp_status run_batch(plp_orb* c, const uint8_t* d_imgs, int B, int rows, int col
     }
 
     PLP_HIP(hipMemsetAsync(c->status.p, 0, 16, st));
+    mark(1);
     for (int l = 1; l < nl; ++l) launch_resize(st, pl, c->h_lv.data(), l, B, c->rs);
+    mark(2);
     launch_fast(st, pl, (const CellDesc*)c->d_cells.p, (int)g.cells.size(), (const LevelDev*)c->d_lv.p, B, (int)c->p.ini_fast_thr,
                 (int)c->p.min_fast_thr, d_mask, mask_step, mask_frame_stride, (uint32_t*)c->cell_cand.p, (int32_t*)c->cell_count.p);
+    mark(3);
     BlurTaps taps{{18, 34, 48, 56, 48, 34, 18}};   // 7 taps, sigma 2, 8.8 fixed point, sum 256
     launch_blur(st, pl, (uint8_t*)c->blur.p, g.frame_plane_bytes, (const LevelDev*)c->d_lv.p, nl, c->total_blur_tiles, B, taps);
+    mark(4);
     if (c->use_host_quadtree) PLP_TRY(host_quadtree(c, st, B));
     else launch_quadtree(st, (const LevelDev*)c->d_lv.p, nl, (int)g.cells.size(), (const uint32_t*)c->cell_cand.p,
                          (const int32_t*)c->cell_count.p, (int32_t*)c->sel.p, (int32_t*)c->sel_count.p, g.total_sel_cap,
                          (uint32_t*)c->qt_scratch.p, c->qt_frame_stride, (int32_t*)c->status.p, B);
+    mark(5);
     UMax um;
     for (int v = 0; v <= kHalfPatch; ++v) um.v[v] = c->st.u_max[v];
     launch_orient_rbrief(st, pl, (const uint8_t*)c->blur.p, g.frame_plane_bytes, (const LevelDev*)c->d_lv.p, nl, (const int32_t*)c->sel.p,
                          (const int32_t*)c->sel_count.p, g.total_sel_cap, um, d_kps, d_desc, cap, d_counts, (int32_t*)c->status.p, B);
     PLP_HIP(hipGetLastError());
+    if (prof) {
+        mark(6);
+        PLP_HIP(hipEventSynchronize(c->ev[6]));
+        for (int i = 0; i < 6; ++i) { float ms = 0; PLP_HIP(hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1])); c->stage_ms[i] += ms; }
+        float tot = 0; PLP_HIP(hipEventElapsedTime(&tot, c->ev[0], c->ev[6])); c->stage_ms[6] += tot;
+        ++c->stage_batches;
+    }
     c->last_B = B; c->last_planes = pl; c->last_stream = st;
     return PLP_OK;
 }
@@ -294,8 +314,9 @@ plp_status plp_orb_create(const plp_orb_params* params, int device, plp_orb** ou
 
 void plp_orb_destroy(plp_orb* c) {
     if (!c) return;
-    hipSetDevice(c->device);
-    if (c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); }
+    (void)hipSetDevice(c->device);
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     delete c;
 }
 
@@ -401,6 +422,25 @@ plp_status plp_orb_extract(plp_orb* c, const uint8_t* img, int32_t rows, int32_t
     int32_t s[4];
     PLP_HIP(hipMemcpy(s, c->status.p, 16, hipMemcpyDeviceToHost));
     if (s[0] & 2) return set_error(PLP_ERR_OVERFLOW, "per-level candidate scratch overflow");
+    return PLP_OK;
+}
+
+plp_status plp_orb_set_profiling(plp_orb* c, int32_t enable) {
+    if (!c) return set_error(PLP_ERR_INVALID_ARG, "ctx is NULL");
+    std::lock_guard<std::mutex> lk(c->mu);
+    PLP_HIP(hipSetDevice(c->device));
+    if (enable && !c->ev[0]) for (auto& e : c->ev) PLP_HIP(hipEventCreate(&e));
+    c->profiling = enable != 0;
+    for (auto& v : c->stage_ms) v = 0;
+    c->stage_batches = 0;
+    return PLP_OK;
+}
+
+plp_status plp_orb_get_stage_times(plp_orb* c, double* ms7, int64_t* n_batches) {
+    if (!c || !ms7) return set_error(PLP_ERR_INVALID_ARG, "NULL argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    for (int i = 0; i < 7; ++i) ms7[i] = c->stage_ms[i];
+    if (n_batches) *n_batches = c->stage_batches;
     return PLP_OK;
 }
 

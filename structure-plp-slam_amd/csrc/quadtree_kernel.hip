@@ -16,12 +16,15 @@
 namespace plp {
 
 constexpr int kQtMaxNodes = 2048;
-constexpr int kQtMaxCand = 16384;
-constexpr int kQtSegMax = kQtMaxCand / 64;   // 256 wave-sized segments
-constexpr int kQtKeyCache = 4096;
+constexpr int kQtMaxCand = 65535;            // node ranges are u16; FAST can emit at most tested/4 per level
+constexpr int kQtSegMax = 1024;              // wave-sized (64) segments of the radix passes
+constexpr int kQtKeyCache = 8192;
 
 struct QtShared {
-    uint32_t big[16 * kQtSegMax];   // radix counters, later the sorted-key cache (4096 keys)
+    union {
+        uint16_t cnt[16 * kQtSegMax];   // radix counters [digit][segment] (prefix values < 65536)
+        uint32_t big[kQtKeyCache];      // cell prefix during the gather, later the sorted-key cache
+    };
     uint16_t ns[2][kQtMaxNodes], ne[2][kQtMaxNodes];
     uint8_t nd[2][kQtMaxNodes], nleaf[2][kQtMaxNodes];
     uint16_t b1[kQtMaxNodes], b2[kQtMaxNodes], b3[kQtMaxNodes];
@@ -32,7 +35,8 @@ struct QtShared {
 };
 
 // in-place exclusive scan of a[0..M) by the whole workgroup; returns the total
-__device__ uint32_t block_scan_excl(uint32_t* a, int M, uint32_t* partial) {
+template <typename T>
+__device__ uint32_t block_scan_excl(T* a, int M, uint32_t* partial) {
     const int tid = threadIdx.x;
     const int chunk = (M + 255) >> 8;
     const int lo = min(tid * chunk, M), hi = min(lo + chunk, M);
@@ -48,7 +52,7 @@ __device__ uint32_t block_scan_excl(uint32_t* a, int M, uint32_t* partial) {
     }
     uint32_t run = partial[tid] - sum;
     const uint32_t total = partial[255];
-    for (int i = lo; i < hi; ++i) { const uint32_t v = a[i]; a[i] = run; run += v; }
+    for (int i = lo; i < hi; ++i) { const uint32_t v = a[i]; a[i] = (T)run; run += v; }
     __syncthreads();
     return total;
 }
@@ -148,10 +152,10 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelDev* __restrict__ l
                 const unsigned long long bal = __ballot(d == v);
                 if ((unsigned)lane == v) mine = (uint32_t)__popcll(bal);
             }
-            if (lane < 16) S.big[lane * nseg + seg] = mine;
+            if (lane < 16) S.cnt[lane * nseg + seg] = (uint16_t)mine;
         }
         __syncthreads();
-        block_scan_excl(S.big, 16 * nseg, S.partial);
+        block_scan_excl(S.cnt, 16 * nseg, S.partial);
         for (int seg = wv; seg < nseg; seg += 4) {
             const int i = seg * 64 + lane;
             unsigned d = 16;
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelDev* __restrict__ l
                 const unsigned long long bal = __ballot(d == v);
                 if (d == v) mybal = bal;
             }
-            if (i < n) dst[S.big[d * nseg + seg] + (uint32_t)__popcll(mybal & ((1ull << lane) - 1ull))] = id;
+            if (i < n) dst[(uint32_t)S.cnt[d * nseg + seg] + (uint32_t)__popcll(mybal & ((1ull << lane) - 1ull))] = id;
         }
         __syncthreads();
         uint32_t* t = src; src = dst; dst = t;
