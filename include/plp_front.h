@@ -132,6 +132,75 @@ typedef enum plp_orb_debug_id { PLP_ORB_DBG_BLURRED = 0, PLP_ORB_DBG_CANDIDATES 
 plp_status plp_orb_debug_read(plp_orb* ctx, plp_orb_debug_id what, int32_t frame, int32_t level,
                               void* dst, size_t dst_bytes, int64_t* n_out);
 
+/* ------------------------------------------------------------------------------------------
+ * Hamming matchers, array form — replace the inner loops of the reference's src/PLPSLAM/match directory.
+ *
+ * The reference's matchers walk data::frame / data::landmark objects (match/projection.h,
+ * match/robust.h); the host facade flattens what those loops read into plain arrays, calls one of
+ * the entry points below and writes the returned associations back.  Targets = key points of the
+ * current frame, queries = landmarks / last-frame key points / key-frame key points IN THE
+ * REFERENCE'S ITERATION ORDER (results depend on it: an accepted query blocks its key point for all
+ * later queries).  B independent problems per call; arrays are B x n_cap / B x m_cap, row-major.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct plp_matcher plp_matcher;   /* owns a HIP stream and scratch; one per calling thread */
+plp_status plp_matcher_create(int device, plp_matcher** out);
+void plp_matcher_destroy(plp_matcher* ctx);
+
+typedef enum plp_match_mode {
+    PLP_MATCH_MODE_LANDMARKS = 0,   /* projection::match_frame_and_landmarks          match/projection.cc:37-121  */
+    PLP_MATCH_MODE_LAST_FRAME = 1,  /* projection::match_current_and_last_frames      match/projection.cc:214-358 */
+    PLP_MATCH_MODE_BRUTE_FORCE = 2  /* robust::brute_force_match                      match/robust.cc:257-385     */
+} plp_match_mode;
+
+typedef struct plp_match_grid {     /* camera::base grid (camera/base.h:91) used by data::get_keypoints_in_cell */
+    float min_x, min_y;             /* img_bounds_.min_x_/min_y_ (float, camera/base.h:78-81) */
+    double inv_cell_width, inv_cell_height;   /* double, camera/base.h:158-160 */
+    int32_t cols, rows;             /* 64 x 48 */
+} plp_match_grid;
+
+typedef struct plp_match_args {
+    int32_t mode;                   /* plp_match_mode */
+    int32_t B, n_cap, m_cap;
+    /* targets (current frame): data::frame::undist_keypts_, descriptors_, stereo_x_right_, and
+     * "landmarks_[idx] && landmarks_[idx]->has_observation()" as a byte flag */
+    const plp_keypoint* t_kps;      /* B x n_cap (ignored in brute-force mode) */
+    const uint8_t* t_desc;          /* B x n_cap x 32 */
+    const float* t_x_right;         /* B x n_cap or NULL */
+    const uint8_t* t_occupied;      /* B x n_cap or NULL */
+    const float* t_angle;           /* brute-force mode: B x n_cap key point angles of frame 1 */
+    const int32_t* t_counts;        /* B, or NULL = n_cap everywhere */
+    /* queries */
+    const uint8_t* q_valid;         /* B x m_cap or NULL: the skip tests at the top of the reference loops */
+    const float* q_reproj;          /* B x m_cap x 2: reproj_in_tracking_ / reprojected last-frame landmark */
+    const float* q_x_right;         /* B x m_cap or NULL */
+    const int32_t* q_level;         /* B x m_cap: scale_level_in_tracking_ / last_frm.keypts_[i].octave */
+    const float* q_angle;           /* B x m_cap: needed when check_orientation */
+    const uint8_t* q_desc;          /* B x m_cap x 32 */
+    const uint8_t* q_has_obs;       /* B x m_cap or NULL (= all 1): landmark::has_observation() */
+    const int32_t* q_counts;        /* B, or NULL */
+    float margin, lowe_ratio;       /* match::base(lowe_ratio, check_orientation) */
+    int32_t direction;              /* LAST_FRAME: 0 neither, 1 assume_forward, 2 assume_backward */
+    int32_t check_orientation;
+    int32_t num_levels;
+    const float* scale_factors;     /* HOST pointer, num_levels floats (frame::scale_factors_) */
+    plp_match_grid grid;
+    /* outputs: out_match[b][t] = index of the query associated with key point t (-1 = none),
+     * out_num[b] = the matcher's return value (num_matches) */
+    int32_t* out_match;             /* B x n_cap */
+    int32_t* out_num;               /* B */
+} plp_match_args;
+
+/* All array pointers in `a` are DEVICE pointers (except scale_factors); asynchronous on hip_stream. */
+plp_status plp_match_device(plp_matcher* ctx, const plp_match_args* a, void* hip_stream);
+/* Same with HOST pointers for one call (B problems are staged to HBM and back); synchronous. */
+plp_status plp_match_host(plp_matcher* ctx, const plp_match_args* a);
+
+/* compute_descriptor_distance_32 over all pairs (match/base.h:43-68): dist[q*nt + t], u16.
+ * Device pointers, asynchronous.  (K16: input of brute-force style matchers on the host side.) */
+plp_status plp_hamming_matrix_device(plp_matcher* ctx, const uint8_t* d_q, int32_t nq, const uint8_t* d_t, int32_t nt,
+                                     uint16_t* d_dist, void* hip_stream);
+plp_status plp_hamming_matrix_host(plp_matcher* ctx, const uint8_t* q, int32_t nq, const uint8_t* t, int32_t nt, uint16_t* dist);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,298 @@
+// TEST INFRASTRUCTURE ONLY (oracle).  Not part of the product path.
+//
+// CPU restatement, in array form, of the reference's Hamming matchers
+//   src/PLPSLAM/match/base.h:43-92                 compute_descriptor_distance_32/64
+//   src/PLPSLAM/match/angle_checker.h:38-176       30-bin delta-angle histogram, top-3 bins valid
+//   src/PLPSLAM/data/common.h:104-109, common.cc:205-313   64x48 key-point grid and its window query
+//   src/PLPSLAM/match/projection.cc:37-121         match_frame_and_landmarks
+//   src/PLPSLAM/match/projection.cc:214-358        match_current_and_last_frames
+//   src/PLPSLAM/match/robust.cc:257-385            brute_force_match
+// "Array form": the reference walks data::frame / data::landmark objects; here every quantity those
+// loops read is a plain array prepared by the caller (reprojections, predicted levels, descriptors,
+// occupancy flags), and every quantity they write comes back as an array.  Iteration order, skip
+// rules, thresholds and tie behaviour follow the cited lines.
+//
+// Pinning: test/PLPSLAM/match/base.cc (3 Hamming vectors), test/PLPSLAM/match/angle_checker.cc and
+// test/PLPSLAM/data/common_get_cell_indices.cc are replayed in tests/test_oracle_match.py; the
+// matcher functions themselves have no tests in the reference -> "parity unpinned" for them.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <numeric>
+#include <unordered_set>
+#include <vector>
+
+#include "cv_restated.hpp"
+
+namespace oracle {
+
+constexpr unsigned HAMMING_DIST_THR_LOW = 50, HAMMING_DIST_THR_HIGH = 100, MAX_HAMMING_DIST = 256;
+
+inline unsigned hamming32(const uint8_t* a, const uint8_t* b) {  // base.h:43-68 (SWAR on 8 x u32)
+    uint32_t pa[8], pb[8];
+    std::memcpy(pa, a, 32); std::memcpy(pb, b, 32);
+    unsigned dist = 0;
+    for (int i = 0; i < 8; ++i) {
+        uint32_t v = pa[i] ^ pb[i];
+        v -= ((v >> 1) & 0x55555555U);
+        v = (v & 0x33333333U) + ((v >> 2) & 0x33333333U);
+        dist += (((v + (v >> 4)) & 0x0F0F0F0FU) * 0x01010101U) >> 24;
+    }
+    return dist;
+}
+inline unsigned hamming64(const uint8_t* a, const uint8_t* b) {  // base.h:70-92
+    uint64_t pa[4], pb[4];
+    std::memcpy(pa, a, 32); std::memcpy(pb, b, 32);
+    unsigned dist = 0;
+    for (int i = 0; i < 4; ++i) {
+        uint64_t v = pa[i] ^ pb[i];
+        v -= (v >> 1) & 0x5555555555555555UL;
+        v = (v & 0x3333333333333333UL) + ((v >> 2) & 0x3333333333333333UL);
+        dist += (unsigned)((((v + (v >> 4)) & 0x0F0F0F0F0F0F0F0FUL) * 0x0101010101010101UL) >> 56);
+    }
+    return dist;
+}
+
+// angle_checker<int> (angle_checker.h): bins = cvRound(delta/30) (only 0..12 reachable), invalid =
+// matches outside the 3 fullest bins.  The reference orders bins with std::sort and a size-only
+// comparator (angle_checker.h:165-176), so which of several EQUALLY full bins makes the top 3 is
+// unspecified there.  Deliberate definition (oracle and HIP path alike): equally full bins keep
+// ascending bin order (a stable sort).
+struct AngleChecker {
+    std::vector<std::vector<int>> hist;
+    unsigned len, thr;
+    float inv_len;
+    explicit AngleChecker(unsigned l = 30, unsigned t = 3) : hist(l), len(l), thr(t), inv_len(1.0f / l) {}
+    void append(float delta, int match) {
+        if (delta < 0.0) delta += 360.0;
+        if (360.0 <= delta) delta -= 360.0;
+        const unsigned bin = (unsigned)cv_round(delta * inv_len);
+        hist.at(bin).push_back(match);
+    }
+    std::vector<unsigned> order() const {
+        std::vector<unsigned> idx(hist.size());
+        std::iota(idx.begin(), idx.end(), 0);
+        std::stable_sort(idx.begin(), idx.end(), [&](unsigned a, unsigned b) { return hist.at(a).size() > hist.at(b).size(); });
+        return idx;
+    }
+    std::vector<int> collect(bool valid) const {
+        std::vector<int> out;
+        const auto bins = order();
+        for (unsigned bin = 0; bin < len; ++bin) {
+            const bool is_valid = std::any_of(bins.begin(), bins.begin() + thr, [bin](unsigned i) { return bin == i; });
+            if (is_valid == valid) out.insert(out.end(), hist[bin].begin(), hist[bin].end());
+        }
+        return out;
+    }
+};
+
+// ---- grid (camera/base.h:91 64 x 48 cells over the undistorted image bounds)
+struct Grid {
+    float min_x, min_y;            // image_bounds members are float (camera/base.h:78-81)
+    double inv_cell_w, inv_cell_h;  // inv_cell_width_/height_ are double (camera/base.h:158-160)
+    int cols, rows;
+};
+inline bool cell_of(const Grid& g, float x, float y, int& cx, int& cy) {  // common.h:104-109
+    cx = cv_floor((x - g.min_x) * g.inv_cell_w);
+    cy = cv_floor((y - g.min_y) * g.inv_cell_h);
+    return 0 <= cx && cx < g.cols && 0 <= cy && cy < g.rows;
+}
+struct Features {   // what the matchers read from data::frame
+    int n;
+    const KeyPoint* kps;        // undist_keypts_ (x, y, octave, angle)
+    const uint8_t* desc;        // n x 32
+    const float* x_right;       // stereo_x_right_ (<= 0: none)
+    std::vector<std::vector<std::vector<unsigned>>> cells;   // [col][row] -> indices (ascending)
+};
+inline void assign_to_grid(const Grid& g, Features& f) {  // common.cc:205-231
+    f.cells.assign(g.cols, std::vector<std::vector<unsigned>>(g.rows));
+    for (int i = 0; i < f.n; ++i) {
+        int cx, cy;
+        if (cell_of(g, f.kps[i].x, f.kps[i].y, cx, cy)) f.cells[cx][cy].push_back((unsigned)i);
+    }
+}
+inline std::vector<unsigned> keypoints_in_cell(const Grid& g, const Features& f, float ref_x, float ref_y, float margin,
+                                               int min_level, int max_level) {  // common.cc:241-313
+    std::vector<unsigned> idx;
+    const int min_cx = std::max(0, cv_floor((ref_x - g.min_x - margin) * g.inv_cell_w));
+    if (g.cols <= min_cx) return idx;
+    const int max_cx = std::min(g.cols - 1, cv_ceil((ref_x - g.min_x + margin) * g.inv_cell_w));
+    if (max_cx < 0) return idx;
+    const int min_cy = std::max(0, cv_floor((ref_y - g.min_y - margin) * g.inv_cell_h));
+    if (g.rows <= min_cy) return idx;
+    const int max_cy = std::min(g.rows - 1, cv_ceil((ref_y - g.min_y + margin) * g.inv_cell_h));
+    if (max_cy < 0) return idx;
+    const bool check_level = (0 < min_level) || (0 <= max_level);
+    for (int cx = min_cx; cx <= max_cx; ++cx)
+        for (int cy = min_cy; cy <= max_cy; ++cy)
+            for (unsigned i : f.cells[cx][cy]) {
+                const KeyPoint& k = f.kps[i];
+                if (check_level) {
+                    if (k.octave < min_level) continue;
+                    if (0 <= max_level && max_level < k.octave) continue;
+                }
+                const float dx = k.x - ref_x, dy = k.y - ref_y;
+                if (std::abs(dx) < margin && std::abs(dy) < margin) idx.push_back(i);
+            }
+    return idx;
+}
+
+}  // namespace oracle
+
+using namespace oracle;
+
+extern "C" {
+
+unsigned oracle_hamming32(const uint8_t* a, const uint8_t* b) { return hamming32(a, b); }
+unsigned oracle_hamming64(const uint8_t* a, const uint8_t* b) { return hamming64(a, b); }
+
+// angle_checker: deltas[n] with payload = index; returns the invalid (valid=0) or valid (valid=1) payloads
+int oracle_angle_checker(const float* deltas, int n, int hist_len, int n_bins_thr, int valid, int* out) {
+    AngleChecker ac((unsigned)hist_len, (unsigned)n_bins_thr);
+    for (int i = 0; i < n; ++i) ac.append(deltas[i], i);
+    auto v = ac.collect(valid != 0);
+    for (size_t i = 0; i < v.size(); ++i) out[i] = v[i];
+    return (int)v.size();
+}
+
+int oracle_get_cell_indices(float min_x, float min_y, double inv_w, double inv_h, int cols, int rows, float x, float y, int* cx, int* cy) {
+    Grid g{min_x, min_y, inv_w, inv_h, cols, rows};
+    return cell_of(g, x, y, *cx, *cy) ? 1 : 0;
+}
+
+int oracle_keypoints_in_cell(const double* grid6, const KeyPoint* kps, int n, float ref_x, float ref_y, float margin, int min_level,
+                             int max_level, unsigned* out) {
+    Grid g{(float)grid6[0], (float)grid6[1], grid6[2], grid6[3], (int)grid6[4], (int)grid6[5]};
+    Features f{n, kps, nullptr, nullptr, {}};
+    assign_to_grid(g, f);
+    auto v = keypoints_in_cell(g, f, ref_x, ref_y, margin, min_level, max_level);
+    for (size_t i = 0; i < v.size(); ++i) out[i] = v[i];
+    return (int)v.size();
+}
+
+// projection::match_frame_and_landmarks (projection.cc:37-121), array form.
+//   frame:  kps/desc/x_right[n], occupied[n] (landmarks_[idx] && has_observation()), scale_factors[]
+//   landmarks (in local_landmarks order): valid[m] (is_observable_in_tracking_ && !will_be_erased()),
+//            reproj[m][2], x_right[m], level[m] (scale_level_in_tracking_), desc[m][32],
+//            has_obs[m] (has_observation() of the landmark: whether later landmarks skip its key point)
+//   out: kp_landmark[n] = index of the landmark written into frm.landmarks_[idx] (or -1: untouched)
+unsigned oracle_match_frame_and_landmarks(const double* grid6, const KeyPoint* kps, const uint8_t* desc, const float* x_right,
+                                          const uint8_t* occupied, int n, const float* scale_factors, const uint8_t* lm_valid,
+                                          const float* lm_reproj, const float* lm_x_right, const int* lm_level,
+                                          const uint8_t* lm_desc, const uint8_t* lm_has_obs, int m, float margin, float lowe_ratio,
+                                          int* kp_landmark) {
+    Grid g{(float)grid6[0], (float)grid6[1], grid6[2], grid6[3], (int)grid6[4], (int)grid6[5]};
+    Features f{n, kps, desc, x_right, {}};
+    assign_to_grid(g, f);
+    std::vector<uint8_t> occ(occupied, occupied + n);
+    for (int i = 0; i < n; ++i) kp_landmark[i] = -1;
+    unsigned num_matches = 0;
+    for (int l = 0; l < m; ++l) {
+        if (!lm_valid[l]) continue;
+        const int lvl = lm_level[l];
+        const auto cand = keypoints_in_cell(g, f, lm_reproj[2 * l], lm_reproj[2 * l + 1], margin * scale_factors[lvl], lvl - 1, lvl);
+        if (cand.empty()) continue;
+        unsigned best = MAX_HAMMING_DIST, second = MAX_HAMMING_DIST;
+        int best_level = -1, second_level = -1, best_idx = -1;
+        for (unsigned idx : cand) {
+            if (occ[idx]) continue;
+            if (0 < x_right[idx]) {
+                const auto err = std::abs(lm_x_right[l] - x_right[idx]);
+                if (margin * scale_factors[lvl] < err) continue;
+            }
+            const unsigned d = hamming32(lm_desc + 32 * (size_t)l, desc + 32 * (size_t)idx);
+            if (d < best) { second = best; best = d; second_level = best_level; best_level = kps[idx].octave; best_idx = (int)idx; }
+            else if (d < second) { second_level = kps[idx].octave; second = d; }
+        }
+        if (best <= HAMMING_DIST_THR_HIGH) {
+            if (best_level == second_level && best > lowe_ratio * second) continue;
+            kp_landmark[best_idx] = l;
+            occ[best_idx] = lm_has_obs[l];
+            ++num_matches;
+        }
+    }
+    return num_matches;
+}
+
+// projection::match_current_and_last_frames (projection.cc:214-358), array form.
+//   last frame entries (in idx_last order): valid[m] (landmark && !outlier && reprojects in image),
+//       reproj[m][2], x_right[m], octave[m] (last_frm.keypts_[idx].octave), angle[m] (undist angle), desc (landmark descriptor)
+//   direction: 0 neither (level-1..level+1), 1 forward (level..num_levels-1), 2 backward (0..level)
+//   out: kp_last[n] = idx_last matched to current key point (or -1)
+unsigned oracle_match_current_and_last(const double* grid6, const KeyPoint* kps, const uint8_t* desc, const float* x_right,
+                                       const uint8_t* occupied, int n, const float* scale_factors, int num_levels,
+                                       const uint8_t* valid, const float* reproj, const float* lx_right, const int* loctave,
+                                       const float* langle, const uint8_t* ldesc, const uint8_t* l_has_obs, int m, float margin,
+                                       int direction, int check_orientation, int* kp_last) {
+    Grid g{(float)grid6[0], (float)grid6[1], grid6[2], grid6[3], (int)grid6[4], (int)grid6[5]};
+    Features f{n, kps, desc, x_right, {}};
+    assign_to_grid(g, f);
+    std::vector<uint8_t> occ(occupied, occupied + n);
+    for (int i = 0; i < n; ++i) kp_last[i] = -1;
+    unsigned num_matches = 0;
+    AngleChecker ac;
+    for (int l = 0; l < m; ++l) {
+        if (!valid[l]) continue;
+        const int lvl = loctave[l];
+        const float mg = margin * scale_factors[lvl];
+        std::vector<unsigned> cand;
+        if (direction == 1) cand = keypoints_in_cell(g, f, reproj[2 * l], reproj[2 * l + 1], mg, lvl, num_levels - 1);
+        else if (direction == 2) cand = keypoints_in_cell(g, f, reproj[2 * l], reproj[2 * l + 1], mg, 0, lvl);
+        else cand = keypoints_in_cell(g, f, reproj[2 * l], reproj[2 * l + 1], mg, lvl - 1, lvl + 1);
+        if (cand.empty()) continue;
+        unsigned best = MAX_HAMMING_DIST;
+        int best_idx = -1;
+        for (unsigned idx : cand) {
+            if (occ[idx]) continue;
+            if (x_right[idx] > 0) {
+                const float err = std::fabs(lx_right[l] - x_right[idx]);
+                if (mg < err) continue;
+            }
+            const unsigned d = hamming32(ldesc + 32 * (size_t)l, desc + 32 * (size_t)idx);
+            if (d < best) { best = d; best_idx = (int)idx; }
+        }
+        if (HAMMING_DIST_THR_HIGH < best) continue;
+        kp_last[best_idx] = l;
+        occ[best_idx] = l_has_obs[l];
+        ++num_matches;
+        if (check_orientation) ac.append(langle[l] - kps[best_idx].angle, best_idx);
+    }
+    if (check_orientation)
+        for (int bad : ac.collect(false)) { kp_last[bad] = -1; --num_matches; }
+    return num_matches;
+}
+
+// robust::brute_force_match (robust.cc:257-385), array form.
+//   frame 1 (current): desc1[n1], angle1[n1]; keyframe 2: desc2[n2], angle2[n2], valid2[n2] (landmark && !will_be_erased)
+//   out: match_2_in_1[n1] (idx_2 or -1); returns num_matches.  The reference then lists (idx_1, idx_2) in idx_1 order.
+unsigned oracle_brute_force_match(const uint8_t* desc1, const float* angle1, int n1, const uint8_t* desc2, const float* angle2,
+                                  const uint8_t* valid2, int n2, float lowe_ratio, int check_orientation, int* match_2_in_1) {
+    for (int i = 0; i < n1; ++i) match_2_in_1[i] = -1;
+    std::unordered_set<int> used;
+    unsigned num_matches = 0;
+    AngleChecker ac;
+    for (int i2 = 0; i2 < n2; ++i2) {
+        if (!valid2[i2]) continue;
+        unsigned best = MAX_HAMMING_DIST, second = MAX_HAMMING_DIST;
+        int best_i1 = -1;
+        for (int i1 = 0; i1 < n1; ++i1) {
+            if (used.count(i1)) continue;
+            const unsigned d = hamming32(desc2 + 32 * (size_t)i2, desc1 + 32 * (size_t)i1);
+            if (d < best) { second = best; best = d; best_i1 = i1; }
+            else if (d < second) second = d;
+        }
+        if (HAMMING_DIST_THR_LOW < best) continue;
+        if (best_i1 < 0) continue;
+        if (lowe_ratio * second < static_cast<float>(best)) continue;
+        match_2_in_1[best_i1] = i2;
+        used.insert(best_i1);
+        if (check_orientation) ac.append(angle1[best_i1] - angle2[i2], best_i1);
+        ++num_matches;
+    }
+    if (check_orientation)
+        for (int bad : ac.collect(false)) { match_2_in_1[bad] = -1; --num_matches; }
+    return num_matches;
+}
+
+}  // extern "C"

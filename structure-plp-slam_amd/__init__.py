@@ -68,6 +68,12 @@ _API = [
     ("plp_orb_pyramid_host", C.c_int, [_VP, _I32, _I32, _VP, _SZ]),
     ("plp_orb_debug_read", C.c_int, [_VP, C.c_int, _I32, _I32, _VP, _SZ, _VP]),
     ("plp_model_quadtree_host", _I32, [_VP, _I32, _I32, _I32, C.c_uint32, _VP]),
+    ("plp_matcher_create", C.c_int, [C.c_int, _VP]),
+    ("plp_matcher_destroy", None, [_VP]),
+    ("plp_match_device", C.c_int, [_VP, _VP, _VP]),
+    ("plp_match_host", C.c_int, [_VP, _VP]),
+    ("plp_hamming_matrix_device", C.c_int, [_VP, _VP, _I32, _VP, _I32, _VP, _VP]),
+    ("plp_hamming_matrix_host", C.c_int, [_VP, _VP, _I32, _VP, _I32, _VP]),
 ]
 
 
@@ -236,3 +242,89 @@ class orb_extractor:
         a = np.zeros((r.value * c.value // 4 + 16, 3), np.int32)
         _check(lib().plp_orb_debug_read(self._h, what, frame, level, _p(a), a.nbytes, C.byref(n)))
         return a[:n.value].copy()
+
+
+# ------------------------------------------------------------------------------------------------
+# Hamming matchers, array form (match::projection / match::robust of the reference)
+# ------------------------------------------------------------------------------------------------
+class match_grid_c(C.Structure):
+    _fields_ = [("min_x", C.c_float), ("min_y", C.c_float), ("inv_cell_width", C.c_double), ("inv_cell_height", C.c_double),
+                ("cols", C.c_int32), ("rows", C.c_int32)]
+
+
+class match_args_c(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("B", C.c_int32), ("n_cap", C.c_int32), ("m_cap", C.c_int32),
+                ("t_kps", _VP), ("t_desc", _VP), ("t_x_right", _VP), ("t_occupied", _VP), ("t_angle", _VP), ("t_counts", _VP),
+                ("q_valid", _VP), ("q_reproj", _VP), ("q_x_right", _VP), ("q_level", _VP), ("q_angle", _VP), ("q_desc", _VP),
+                ("q_has_obs", _VP), ("q_counts", _VP),
+                ("margin", C.c_float), ("lowe_ratio", C.c_float), ("direction", C.c_int32), ("check_orientation", C.c_int32),
+                ("num_levels", C.c_int32), ("scale_factors", _VP), ("grid", match_grid_c), ("out_match", _VP), ("out_num", _VP)]
+
+
+MODE_LANDMARKS, MODE_LAST_FRAME, MODE_BRUTE_FORCE = 0, 1, 2
+
+
+def make_grid(cols_px, rows_px, grid_cols=64, grid_rows=48, min_x=0.0, min_y=0.0):
+    """camera::base grid for an undistorted image of cols_px x rows_px (camera/base.h:91, perspective.cc ctor)."""
+    inv_w = np.float64(grid_cols) / np.float64(np.float32(cols_px) - np.float32(min_x))   # perspective.cc:55-56
+    inv_h = np.float64(grid_rows) / np.float64(np.float32(rows_px) - np.float32(min_y))
+    return match_grid_c(min_x, min_y, float(inv_w), float(inv_h), grid_cols, grid_rows)
+
+
+class matcher:
+    """Array-form mirror of match::projection / match::robust (value-constructed with (lowe_ratio, check_orientation)
+    at every call site of the reference, match/base.h:94-110)."""
+
+    def __init__(self, lowe_ratio=0.6, check_orientation=True, device=0):
+        h = C.c_void_p()
+        _check(lib().plp_matcher_create(device, C.byref(h)))
+        self._h = h
+        self.lowe_ratio = lowe_ratio
+        self.check_orientation = check_orientation
+        self._keep = []
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib().plp_matcher_destroy(h)
+            self._h = None
+
+    def _args(self, mode, B, n_cap, m_cap, fields, margin, direction, scale_factors, grid, out_match, out_num, ptr):
+        a = match_args_c()
+        a.mode, a.B, a.n_cap, a.m_cap = mode, B, n_cap, m_cap
+        for k, v in fields.items():
+            setattr(a, k, ptr(v) if v is not None else None)
+        a.margin, a.lowe_ratio = margin, self.lowe_ratio
+        a.direction, a.check_orientation = direction, int(self.check_orientation)
+        if scale_factors is not None:
+            sf = np.ascontiguousarray(scale_factors, np.float32)
+            self._keep = [sf]
+            a.num_levels, a.scale_factors = len(sf), sf.ctypes.data
+        if grid is not None:
+            a.grid = grid
+        a.out_match, a.out_num = ptr(out_match), ptr(out_num)
+        return a
+
+    def match_host(self, mode, n_cap, m_cap, fields, margin=0.0, direction=0, scale_factors=None, grid=None, B=1):
+        """fields: dict of numpy arrays named like plp_match_args members.  Returns (out_match [B,n_cap], out_num [B])."""
+        fields = {k: (None if v is None else np.ascontiguousarray(v)) for k, v in fields.items()}
+        out_match = np.zeros((B, n_cap), np.int32)
+        out_num = np.zeros(B, np.int32)
+        a = self._args(mode, B, n_cap, m_cap, fields, margin, direction, scale_factors, grid, out_match, out_num, lambda v: v.ctypes.data)
+        _check(lib().plp_match_host(self._h, C.byref(a)))
+        return out_match, out_num
+
+    def match_device(self, mode, n_cap, m_cap, fields, out_match, out_num, margin=0.0, direction=0, scale_factors=None, grid=None,
+                     B=1, stream=None):
+        """fields / outputs: torch tensors on the matcher's device.  Asynchronous."""
+        import torch
+        st = (stream or torch.cuda.current_stream(out_match.device)).cuda_stream
+        a = self._args(mode, B, n_cap, m_cap, fields, margin, direction, scale_factors, grid, out_match, out_num, lambda v: v.data_ptr())
+        _check(lib().plp_match_device(self._h, C.byref(a), st))
+
+    def hamming_matrix(self, q, t):
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+        d = np.zeros((len(q), len(t)), np.uint16)
+        _check(lib().plp_hamming_matrix_host(self._h, _p(q), len(q), _p(t), len(t), _p(d)))
+        return d

@@ -1,0 +1,169 @@
+// Host driver + C ABI of the array-form Hamming matchers (include/plp_front.h).
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "match_device.hpp"
+#include "plp_common.hpp"
+
+using namespace plp;
+
+struct plp_matcher {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    DevBuf klist, kcount, claim;             // scratch of the device path
+    DevBuf stage;                            // one slab for the host-pointer path
+    std::mutex mu;
+};
+
+namespace {
+
+plp_status check_args(const plp_match_args* a) {
+    if (!a) return set_error(PLP_ERR_INVALID_ARG, "args is NULL");
+    if (a->B <= 0 || a->n_cap <= 0 || a->m_cap <= 0) return set_error(PLP_ERR_INVALID_ARG, "B, n_cap, m_cap must be positive");
+    if (a->n_cap > 8000) return set_error(PLP_ERR_UNSUPPORTED, "more than 8000 key points per frame");
+    if (!a->t_desc || !a->q_desc || !a->out_match || !a->out_num) return set_error(PLP_ERR_INVALID_ARG, "descriptor / output arrays are required");
+    if (a->mode == PLP_MATCH_MODE_BRUTE_FORCE) {
+        if (a->check_orientation && (!a->t_angle || !a->q_angle)) return set_error(PLP_ERR_INVALID_ARG, "check_orientation needs t_angle and q_angle");
+    } else if (a->mode == PLP_MATCH_MODE_LANDMARKS || a->mode == PLP_MATCH_MODE_LAST_FRAME) {
+        if (!a->t_kps || !a->q_reproj || !a->q_level || !a->scale_factors) return set_error(PLP_ERR_INVALID_ARG, "t_kps, q_reproj, q_level, scale_factors are required");
+        if (a->num_levels <= 0 || a->num_levels > 16) return set_error(PLP_ERR_INVALID_ARG, "num_levels must be in [1,16]");
+        if (a->grid.cols <= 0 || a->grid.rows <= 0 || a->grid.cols * a->grid.rows > 4096) return set_error(PLP_ERR_INVALID_ARG, "grid must have 1..4096 cells");
+        if (a->mode == PLP_MATCH_MODE_LAST_FRAME && a->check_orientation && !a->q_angle) return set_error(PLP_ERR_INVALID_ARG, "check_orientation needs q_angle");
+    } else return set_error(PLP_ERR_INVALID_ARG, "unknown mode");
+    return PLP_OK;
+}
+
+plp_status run_device(plp_matcher* c, const plp_match_args* a, hipStream_t st) {
+    PLP_HIP(hipSetDevice(c->device));
+    const size_t qn = (size_t)a->B * a->m_cap;
+    PLP_HIP(c->klist.reserve(qn * kMatchK * 8));
+    PLP_HIP(c->kcount.reserve(qn * 4));
+    PLP_HIP(c->claim.reserve(qn * 4));
+    MatchProblem P{};
+    P.mode = a->mode; P.n_cap = a->n_cap; P.m_cap = a->m_cap;
+    P.t_kps = a->mode == PLP_MATCH_MODE_BRUTE_FORCE ? nullptr : a->t_kps;
+    P.t_desc = a->t_desc; P.t_x_right = a->t_x_right; P.t_occupied = a->t_occupied; P.t_angle = a->t_angle; P.t_counts = a->t_counts;
+    P.q_valid = a->q_valid; P.q_reproj = a->q_reproj; P.q_x_right = a->q_x_right; P.q_level = a->q_level; P.q_angle = a->q_angle;
+    P.q_desc = a->q_desc; P.q_has_obs = a->q_has_obs; P.q_counts = a->q_counts;
+    P.margin = a->margin; P.lowe_ratio = a->lowe_ratio; P.direction = a->direction; P.check_orientation = a->check_orientation;
+    P.num_levels = a->num_levels;
+    for (int i = 0; i < 16; ++i) P.scale_factors[i] = (a->scale_factors && i < a->num_levels) ? a->scale_factors[i] : 1.0f;
+    P.grid_min_x = a->grid.min_x; P.grid_min_y = a->grid.min_y; P.inv_cell_w = a->grid.inv_cell_width; P.inv_cell_h = a->grid.inv_cell_height;
+    P.grid_cols = a->grid.cols; P.grid_rows = a->grid.rows;
+    P.klist = (unsigned long long*)c->klist.p; P.kcount = (int32_t*)c->kcount.p; P.claim = (int32_t*)c->claim.p;
+    P.out_match = a->out_match; P.out_num = a->out_num;
+    launch_match(st, P, a->B);
+    PLP_HIP(hipGetLastError());
+    return PLP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+plp_status plp_matcher_create(int device, plp_matcher** out) {
+    if (!out) return set_error(PLP_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return set_error(PLP_ERR_NO_DEVICE, "no HIP device visible: the matchers have no CPU fallback");
+    if (device < 0 || device >= n) return set_error(PLP_ERR_INVALID_ARG, "device index out of range");
+    PLP_HIP(hipSetDevice(device));
+    plp_matcher* c = new plp_matcher();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return set_error(PLP_ERR_HIP, "hipStreamCreate failed"); }
+    *out = c;
+    return PLP_OK;
+}
+
+void plp_matcher_destroy(plp_matcher* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    delete c;
+}
+
+plp_status plp_match_device(plp_matcher* c, const plp_match_args* a, void* hip_stream) {
+    if (!c) return set_error(PLP_ERR_INVALID_ARG, "ctx is NULL");
+    PLP_TRY(check_args(a));
+    std::lock_guard<std::mutex> lk(c->mu);
+    return run_device(c, a, hip_stream ? (hipStream_t)hip_stream : c->stream);
+}
+
+plp_status plp_match_host(plp_matcher* c, const plp_match_args* a) {
+    if (!c) return set_error(PLP_ERR_INVALID_ARG, "ctx is NULL");
+    PLP_TRY(check_args(a));
+    std::lock_guard<std::mutex> lk(c->mu);
+    PLP_HIP(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const size_t tn = (size_t)a->B * a->n_cap, qn = (size_t)a->B * a->m_cap;
+    // slab layout (256-byte aligned pieces)
+    struct Piece { const void* src; size_t bytes; size_t off; };
+    std::vector<Piece> in;
+    size_t off = 0;
+    auto add = [&](const void* src, size_t bytes) -> size_t {
+        const size_t o = off;
+        in.push_back({src, bytes, o});
+        off += (bytes + 255) / 256 * 256;
+        return o;
+    };
+    const size_t o_tk = add(a->t_kps, a->t_kps ? tn * sizeof(plp_keypoint) : 0), o_td = add(a->t_desc, tn * 32);
+    const size_t o_tx = add(a->t_x_right, a->t_x_right ? tn * 4 : 0), o_to = add(a->t_occupied, a->t_occupied ? tn : 0);
+    const size_t o_ta = add(a->t_angle, a->t_angle ? tn * 4 : 0), o_tc = add(a->t_counts, a->t_counts ? (size_t)a->B * 4 : 0);
+    const size_t o_qv = add(a->q_valid, a->q_valid ? qn : 0), o_qr = add(a->q_reproj, a->q_reproj ? qn * 8 : 0);
+    const size_t o_qx = add(a->q_x_right, a->q_x_right ? qn * 4 : 0), o_ql = add(a->q_level, a->q_level ? qn * 4 : 0);
+    const size_t o_qa = add(a->q_angle, a->q_angle ? qn * 4 : 0), o_qd = add(a->q_desc, qn * 32);
+    const size_t o_qh = add(a->q_has_obs, a->q_has_obs ? qn : 0), o_qc = add(a->q_counts, a->q_counts ? (size_t)a->B * 4 : 0);
+    const size_t o_om = off; off += (tn * 4 + 255) / 256 * 256;
+    const size_t o_on = off; off += ((size_t)a->B * 4 + 255) / 256 * 256;
+    PLP_HIP(c->stage.reserve(off));
+    uint8_t* base = (uint8_t*)c->stage.p;
+    for (const Piece& p : in)
+        if (p.src && p.bytes) PLP_HIP(hipMemcpyAsync(base + p.off, p.src, p.bytes, hipMemcpyHostToDevice, st));
+    plp_match_args d = *a;
+    auto dp = [&](const void* src, size_t o) -> const void* { return src ? base + o : nullptr; };
+    d.t_kps = (const plp_keypoint*)dp(a->t_kps, o_tk); d.t_desc = (const uint8_t*)dp(a->t_desc, o_td);
+    d.t_x_right = (const float*)dp(a->t_x_right, o_tx); d.t_occupied = (const uint8_t*)dp(a->t_occupied, o_to);
+    d.t_angle = (const float*)dp(a->t_angle, o_ta); d.t_counts = (const int32_t*)dp(a->t_counts, o_tc);
+    d.q_valid = (const uint8_t*)dp(a->q_valid, o_qv); d.q_reproj = (const float*)dp(a->q_reproj, o_qr);
+    d.q_x_right = (const float*)dp(a->q_x_right, o_qx); d.q_level = (const int32_t*)dp(a->q_level, o_ql);
+    d.q_angle = (const float*)dp(a->q_angle, o_qa); d.q_desc = (const uint8_t*)dp(a->q_desc, o_qd);
+    d.q_has_obs = (const uint8_t*)dp(a->q_has_obs, o_qh); d.q_counts = (const int32_t*)dp(a->q_counts, o_qc);
+    d.out_match = (int32_t*)(base + o_om); d.out_num = (int32_t*)(base + o_on);
+    PLP_TRY(run_device(c, &d, st));
+    PLP_HIP(hipMemcpyAsync(a->out_match, base + o_om, tn * 4, hipMemcpyDeviceToHost, st));
+    PLP_HIP(hipMemcpyAsync(a->out_num, base + o_on, (size_t)a->B * 4, hipMemcpyDeviceToHost, st));
+    PLP_HIP(hipStreamSynchronize(st));
+    return PLP_OK;
+}
+
+plp_status plp_hamming_matrix_device(plp_matcher* c, const uint8_t* d_q, int32_t nq, const uint8_t* d_t, int32_t nt, uint16_t* d_dist,
+                                     void* hip_stream) {
+    if (!c || !d_q || !d_t || !d_dist) return set_error(PLP_ERR_INVALID_ARG, "NULL argument");
+    if (nq <= 0 || nt <= 0) return PLP_OK;
+    PLP_HIP(hipSetDevice(c->device));
+    launch_hamming_matrix(hip_stream ? (hipStream_t)hip_stream : c->stream, d_q, nq, d_t, nt, d_dist);
+    PLP_HIP(hipGetLastError());
+    return PLP_OK;
+}
+
+plp_status plp_hamming_matrix_host(plp_matcher* c, const uint8_t* q, int32_t nq, const uint8_t* t, int32_t nt, uint16_t* dist) {
+    if (!c || !q || !t || !dist) return set_error(PLP_ERR_INVALID_ARG, "NULL argument");
+    if (nq <= 0 || nt <= 0) return PLP_OK;
+    std::lock_guard<std::mutex> lk(c->mu);
+    PLP_HIP(hipSetDevice(c->device));
+    const size_t bq = ((size_t)nq * 32 + 255) / 256 * 256, bt = ((size_t)nt * 32 + 255) / 256 * 256;
+    PLP_HIP(c->stage.reserve(bq + bt + (size_t)nq * nt * 2));
+    uint8_t* base = (uint8_t*)c->stage.p;
+    PLP_HIP(hipMemcpyAsync(base, q, (size_t)nq * 32, hipMemcpyHostToDevice, c->stream));
+    PLP_HIP(hipMemcpyAsync(base + bq, t, (size_t)nt * 32, hipMemcpyHostToDevice, c->stream));
+    launch_hamming_matrix(c->stream, base, nq, base + bq, nt, (uint16_t*)(base + bq + bt));
+    PLP_HIP(hipGetLastError());
+    PLP_HIP(hipMemcpyAsync(dist, base + bq + bt, (size_t)nq * nt * 2, hipMemcpyDeviceToHost, c->stream));
+    PLP_HIP(hipStreamSynchronize(c->stream));
+    return PLP_OK;
+}
+
+}  // extern "C"

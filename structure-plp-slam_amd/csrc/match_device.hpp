@@ -1,0 +1,50 @@
+// Problem descriptor shared by the matcher kernels and their host driver (array form of the
+// reference's point matchers; see include/plp_front.h for the field meanings).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/plp_front.h"
+
+namespace plp {
+
+constexpr int kMatchK = 8;          // best candidates kept per query by k_match_topk
+
+struct MatchProblem {
+    int mode;                        // plp_match_mode
+    int n_cap, m_cap;                // per-problem strides of the target / query arrays
+    // targets = key points of the current frame (B x n_cap)
+    const plp_keypoint* t_kps;       // undist_keypts_ (NULL in brute-force mode)
+    const uint8_t* t_desc;           // descriptors_, 32 B rows
+    const float* t_x_right;          // stereo_x_right_ (NULL: none)
+    const uint8_t* t_occupied;       // key point already holds an observed landmark (NULL: none)
+    const float* t_angle;            // brute-force mode: keypts_1[.].angle
+    const int32_t* t_counts;         // per-problem n (NULL: n_cap)
+    // queries = landmarks / last-frame key points / key-frame key points (B x m_cap), reference order
+    const uint8_t* q_valid;          // NULL: all valid
+    const float* q_reproj;           // x, y
+    const float* q_x_right;
+    const int32_t* q_level;
+    const float* q_angle;
+    const uint8_t* q_desc;
+    const uint8_t* q_has_obs;        // NULL: every accepted query blocks its key point
+    const int32_t* q_counts;         // per-problem m (NULL: m_cap)
+    // parameters
+    float margin, lowe_ratio;
+    int direction, check_orientation, num_levels;
+    float scale_factors[16];
+    float grid_min_x, grid_min_y;
+    double inv_cell_w, inv_cell_h;
+    int grid_cols, grid_rows;
+    // scratch + outputs
+    unsigned long long* klist;       // B x m_cap x kMatchK
+    int32_t* kcount;                 // B x m_cap
+    int32_t* claim;                  // B x m_cap
+    int32_t* out_match;              // B x n_cap: query index per key point, -1 = none
+    int32_t* out_num;                // B
+};
+
+void launch_match(hipStream_t st, const MatchProblem& P, int B);
+void launch_hamming_matrix(hipStream_t st, const uint8_t* q, int nq, const uint8_t* t, int nt, uint16_t* dist);
+
+}  // namespace plp

@@ -1,0 +1,339 @@
+// Hand-written HIP kernels (gfx950, wave64) of the Hamming matchers, array form.
+//
+// The reference's point matchers (src/PLPSLAM/match/projection.cc:37-121, :214-358 and
+// robust.cc:257-385) are sequential loops: each query (landmark / last-frame key point /
+// key-frame key point) takes the best still-free key point in its candidate set, and a taken
+// key point is skipped by every later query.  Two kernels reproduce that exactly:
+//
+//   k_match_topk     one wave64 per query: filter all targets (grid-window + level + stereo gate
+//                    of data::get_keypoints_in_cell, common.cc:241-313), 256-bit popcount distance,
+//                    keep the K best by (distance, reference visiting order).
+//   k_match_resolve  one workgroup per problem: fixed-point iteration of "best free candidate given
+//                    the claims of all EARLIER queries" (claims of queries < q are final after q
+//                    rounds, in practice 2-4 rounds), then the accept rules, the delta-angle
+//                    histogram check (match/angle_checker.h) and the scatter of the results.
+//   k_hamming_matrix full nq x nt distance matrix (K16), 64x64 tiles staged through LDS.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "match_device.hpp"
+
+namespace plp {
+
+__device__ __forceinline__ int floor_d(double v) { int i = (int)v; return i - (i > v); }   // cvFloor(double)
+__device__ __forceinline__ int ceil_d(double v) { int i = (int)v; return i + (i < v); }    // cvCeil(double)
+
+__device__ __forceinline__ unsigned hamming256(const uint4& a0, const uint4& a1, const uint4& b0, const uint4& b1) {
+    return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+           __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+}
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned lo = __shfl_xor((unsigned)v, o), hi = __shfl_xor((unsigned)(v >> 32), o);
+        const unsigned long long w = ((unsigned long long)hi << 32) | lo;
+        v = w < v ? w : v;
+    }
+    return v;
+}
+
+// Candidate filter + key of (query q, target t); returns ~0ull when t is not a candidate.
+// key = distance << 32 | visiting order << 4 | octave   (order = grid cell (col-major) then index)
+struct QueryCtx {
+    float rx, ry, mg, xr;
+    int min_level, max_level, min_cx, max_cx, min_cy, max_cy;
+    bool windowed, empty;
+};
+
+__device__ __forceinline__ QueryCtx make_query(const MatchProblem& P, int q, const float* reproj, const float* q_xr, const int32_t* q_level) {
+    QueryCtx c{};
+    c.windowed = P.mode != PLP_MATCH_MODE_BRUTE_FORCE;
+    if (!c.windowed) return c;
+    const int lvl = q_level[q];
+    c.rx = reproj[2 * q]; c.ry = reproj[2 * q + 1];
+    c.mg = __fmul_rn(P.margin, P.scale_factors[lvl]);
+    c.xr = q_xr ? q_xr[q] : -1.f;
+    if (P.mode == PLP_MATCH_MODE_LANDMARKS) { c.min_level = lvl - 1; c.max_level = lvl; }
+    else if (P.direction == 1) { c.min_level = lvl; c.max_level = P.num_levels - 1; }
+    else if (P.direction == 2) { c.min_level = 0; c.max_level = lvl; }
+    else { c.min_level = lvl - 1; c.max_level = lvl + 1; }
+    // cell range of the window (common.cc:249-271)
+    // float window arithmetic, double cell scale (inv_cell_width_ is a double)
+    c.min_cx = max(0, floor_d((double)__fsub_rn(__fsub_rn(c.rx, P.grid_min_x), c.mg) * P.inv_cell_w));
+    c.max_cx = min(P.grid_cols - 1, ceil_d((double)__fadd_rn(__fsub_rn(c.rx, P.grid_min_x), c.mg) * P.inv_cell_w));
+    c.min_cy = max(0, floor_d((double)__fsub_rn(__fsub_rn(c.ry, P.grid_min_y), c.mg) * P.inv_cell_h));
+    c.max_cy = min(P.grid_rows - 1, ceil_d((double)__fadd_rn(__fsub_rn(c.ry, P.grid_min_y), c.mg) * P.inv_cell_h));
+    c.empty = P.grid_cols <= c.min_cx || c.max_cx < 0 || P.grid_rows <= c.min_cy || c.max_cy < 0;
+    return c;
+}
+
+__device__ __forceinline__ unsigned long long candidate_key(const MatchProblem& P, const QueryCtx& c, int t, const plp_keypoint* kps,
+                                                           const uint8_t* t_desc, const float* t_xr, const uint8_t* t_occ,
+                                                           const uint4& q0, const uint4& q1) {
+    unsigned order = (unsigned)t, oct = 0;
+    if (c.windowed) {
+        const plp_keypoint k = kps[t];
+        const int cx = floor_d((double)__fsub_rn(k.x, P.grid_min_x) * P.inv_cell_w);
+        const int cy = floor_d((double)__fsub_rn(k.y, P.grid_min_y) * P.inv_cell_h);
+        if (cx < 0 || cx >= P.grid_cols || cy < 0 || cy >= P.grid_rows) return ~0ull;        // not in the grid at all
+        if (cx < c.min_cx || cx > c.max_cx || cy < c.min_cy || cy > c.max_cy) return ~0ull;
+        const bool check_level = (0 < c.min_level) || (0 <= c.max_level);
+        if (check_level) {
+            if (k.octave < c.min_level) return ~0ull;
+            if (0 <= c.max_level && c.max_level < k.octave) return ~0ull;
+        }
+        if (!(fabsf(__fsub_rn(k.x, c.rx)) < c.mg && fabsf(__fsub_rn(k.y, c.ry)) < c.mg)) return ~0ull;
+        if (t_occ && t_occ[t]) return ~0ull;                                                 // already holds an observed landmark
+        if (t_xr) {
+            const float xr = t_xr[t];
+            if (0 < xr && c.mg < fabsf(__fsub_rn(c.xr, xr))) return ~0ull;                    // stereo gate
+        }
+        order = ((unsigned)(cx * P.grid_rows + cy) << 16) | (unsigned)t;
+        oct = (unsigned)k.octave & 15u;
+    }
+    const uint4* d = reinterpret_cast<const uint4*>(t_desc + 32 * (size_t)t);
+    const unsigned dist = hamming256(q0, q1, d[0], d[1]);
+    return ((unsigned long long)dist << 32) | ((unsigned long long)order << 4) | oct;
+}
+
+// grid = (ceil(m_cap / 4), B), block = 256: one wave per query.
+__global__ __launch_bounds__(256) void k_match_topk(MatchProblem P) {
+    const int lane = threadIdx.x & 63, b = blockIdx.y;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int m = P.q_counts ? P.q_counts[b] : P.m_cap;
+    if (q >= m) return;
+    unsigned long long* klist = P.klist + ((size_t)b * P.m_cap + q) * kMatchK;
+    int32_t* kcount = P.kcount + (size_t)b * P.m_cap + q;
+    const uint8_t* q_valid = P.q_valid ? P.q_valid + (size_t)b * P.m_cap : nullptr;
+    if (q_valid && !q_valid[q]) { if (lane == 0) *kcount = -1; return; }
+    const int n = P.t_counts ? P.t_counts[b] : P.n_cap;
+    const plp_keypoint* kps = P.t_kps ? P.t_kps + (size_t)b * P.n_cap : nullptr;
+    const uint8_t* t_desc = P.t_desc + (size_t)b * P.n_cap * 32;
+    const float* t_xr = P.t_x_right ? P.t_x_right + (size_t)b * P.n_cap : nullptr;
+    const uint8_t* t_occ = P.t_occupied ? P.t_occupied + (size_t)b * P.n_cap : nullptr;
+    const QueryCtx c = make_query(P, q, P.q_reproj ? P.q_reproj + (size_t)b * P.m_cap * 2 : nullptr,
+                                  P.q_x_right ? P.q_x_right + (size_t)b * P.m_cap : nullptr,
+                                  P.q_level ? P.q_level + (size_t)b * P.m_cap : nullptr);
+    const uint4* qd = reinterpret_cast<const uint4*>(P.q_desc + ((size_t)b * P.m_cap + q) * 32);
+    const uint4 q0 = qd[0], q1 = qd[1];
+
+    unsigned long long top[kMatchK];
+#pragma unroll
+    for (int i = 0; i < kMatchK; ++i) top[i] = ~0ull;
+    int passed = 0;
+    if (!(c.windowed && c.empty))
+        for (int t = lane; t < n; t += 64) {
+            const unsigned long long key = candidate_key(P, c, t, kps, t_desc, t_xr, t_occ, q0, q1);
+            if (key == ~0ull) continue;
+            ++passed;
+            if (key < top[kMatchK - 1]) {   // sorted insertion into the lane-local best-K
+                top[kMatchK - 1] = key;
+#pragma unroll
+                for (int i = kMatchK - 1; i > 0; --i)
+                    if (top[i] < top[i - 1]) { const unsigned long long s = top[i]; top[i] = top[i - 1]; top[i - 1] = s; }
+            }
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) passed += __shfl_xor(passed, o);
+    // merge the 64 sorted lane lists: K rounds of wave-min, the owning lane pops its head
+#pragma unroll
+    for (int r = 0; r < kMatchK; ++r) {
+        const unsigned long long mn = wave_min_u64(top[0]);
+        if (lane == 0) klist[r] = mn;
+        if (top[0] == mn && mn != ~0ull) {
+#pragma unroll
+            for (int i = 0; i + 1 < kMatchK; ++i) top[i] = top[i + 1];
+            top[kMatchK - 1] = ~0ull;
+        }
+    }
+    if (lane == 0) *kcount = passed;
+}
+
+// accept rules of the three matchers; best/second are (distance, octave) of the two best free candidates
+__device__ __forceinline__ bool accept(const MatchProblem& P, unsigned best, int best_lvl, unsigned second, int second_lvl) {
+    if (P.mode == PLP_MATCH_MODE_LANDMARKS) {
+        if (!(best <= 100u)) return false;
+        if (best_lvl == second_lvl && (float)best > __fmul_rn(P.lowe_ratio, (float)second)) return false;
+        return true;
+    }
+    if (P.mode == PLP_MATCH_MODE_LAST_FRAME) return best <= 100u;
+    if (50u < best) return false;                                            // brute force: HAMMING_DIST_THR_LOW
+    if (__fmul_rn(P.lowe_ratio, (float)second) < (float)best) return false;
+    return true;
+}
+
+// grid = (B), block = 256.  LDS: owner[2][n_cap] (dynamic).
+__global__ __launch_bounds__(256) void k_match_resolve(MatchProblem P) {
+    extern __shared__ int32_t lds[];
+    __shared__ int s_changed, s_num, s_hist[32], s_valid_bin[32], s_full_n;
+    __shared__ int s_full[256];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.x;
+    const int m = P.q_counts ? P.q_counts[b] : P.m_cap;
+    const int n = P.t_counts ? P.t_counts[b] : P.n_cap;
+    int32_t* owner_prev = lds;
+    int32_t* owner_next = lds + P.n_cap;
+    const unsigned long long* klist = P.klist + (size_t)b * P.m_cap * kMatchK;
+    const int32_t* kcount = P.kcount + (size_t)b * P.m_cap;
+    int32_t* claim = P.claim + (size_t)b * P.m_cap;           // per query: claimed target or -1
+    const uint8_t* has_obs = P.q_has_obs ? P.q_has_obs + (size_t)b * P.m_cap : nullptr;
+    const plp_keypoint* kps = P.t_kps ? P.t_kps + (size_t)b * P.n_cap : nullptr;
+    const uint8_t* t_desc = P.t_desc + (size_t)b * P.n_cap * 32;
+    const float* t_xr = P.t_x_right ? P.t_x_right + (size_t)b * P.n_cap : nullptr;
+    const uint8_t* t_occ = P.t_occupied ? P.t_occupied + (size_t)b * P.n_cap : nullptr;
+    const float* q_reproj = P.q_reproj ? P.q_reproj + (size_t)b * P.m_cap * 2 : nullptr;
+    const float* q_xr = P.q_x_right ? P.q_x_right + (size_t)b * P.m_cap : nullptr;
+    const int32_t* q_level = P.q_level ? P.q_level + (size_t)b * P.m_cap : nullptr;
+    int32_t* out = P.out_match + (size_t)b * P.n_cap;
+
+    for (int t = tid; t < n; t += 256) { owner_prev[t] = 0x7fffffff; out[t] = -1; }
+    for (int q = tid; q < m; q += 256) claim[q] = -1;
+    __syncthreads();
+
+    for (int round = 0; round <= m; ++round) {
+        if (tid == 0) { s_changed = 0; s_full_n = 0; }
+        for (int t = tid; t < n; t += 256) owner_next[t] = 0x7fffffff;
+        __syncthreads();
+        for (int base = 0; base < m; base += 256) {
+            const int q = base + tid;
+            int new_claim = -1;
+            bool need_full = false;
+            if (q < m && kcount[q] > 0) {
+                const int cnt = kcount[q], have = min(cnt, kMatchK);
+                unsigned best = 256, second = 256;
+                int best_lvl = -1, second_lvl = -1, best_t = -1, found = 0;
+                for (int e = 0; e < have && found < 2; ++e) {
+                    const unsigned long long key = klist[(size_t)q * kMatchK + e];
+                    const int t = (int)((key >> 4) & 0xffff);
+                    if (owner_prev[t] < q) continue;   // taken by an earlier query
+                    if (found == 0) { best = (unsigned)(key >> 32); best_lvl = (int)(key & 15); best_t = t; }
+                    else { second = (unsigned)(key >> 32); second_lvl = (int)(key & 15); }
+                    ++found;
+                }
+                if (found < 2 && cnt > kMatchK) need_full = true;   // list truncated and exhausted: exact rescan below
+                else if (found > 0 && accept(P, best, best_lvl, second, second_lvl)) new_claim = best_t;
+            }
+            if (need_full) s_full[atomicAdd(&s_full_n, 1)] = q;   // at most 256 per sweep
+            if (q < m && !need_full) {
+                if (claim[q] != new_claim) { claim[q] = new_claim; s_changed = 1; }
+                if (new_claim >= 0 && (!has_obs || has_obs[q] || P.mode == PLP_MATCH_MODE_BRUTE_FORCE)) atomicMin(&owner_next[new_claim], q);
+            }
+            __syncthreads();
+            // rare: exact two-best over ALL targets with the occupancy filter, one wave per query
+            const int nf = min(s_full_n, 256);
+            for (int f = wv; f < nf; f += 4) {
+                const int fq = s_full[f];
+                const QueryCtx c = make_query(P, fq, q_reproj, q_xr, q_level);
+                const uint4* qd = reinterpret_cast<const uint4*>(P.q_desc + ((size_t)b * P.m_cap + fq) * 32);
+                const uint4 q0 = qd[0], q1 = qd[1];
+                unsigned long long k0 = ~0ull, k1 = ~0ull;
+                for (int t = lane; t < n; t += 64) {
+                    if (owner_prev[t] < fq) continue;
+                    const unsigned long long key = candidate_key(P, c, t, kps, t_desc, t_xr, t_occ, q0, q1);
+                    if (key < k0) { k1 = k0; k0 = key; } else if (key < k1) k1 = key;
+                }
+                const unsigned long long g0 = wave_min_u64(k0);
+                const unsigned long long g1 = wave_min_u64(k0 == g0 ? k1 : k0);
+                if (lane == 0) {
+                    int nc = -1;
+                    if (g0 != ~0ull) {
+                        const unsigned second = g1 != ~0ull ? (unsigned)(g1 >> 32) : 256u;
+                        const int second_lvl = g1 != ~0ull ? (int)(g1 & 15) : -1;
+                        if (accept(P, (unsigned)(g0 >> 32), (int)(g0 & 15), second, second_lvl)) nc = (int)((g0 >> 4) & 0xffff);
+                    }
+                    if (claim[fq] != nc) { claim[fq] = nc; s_changed = 1; }
+                    if (nc >= 0 && (!has_obs || has_obs[fq] || P.mode == PLP_MATCH_MODE_BRUTE_FORCE)) atomicMin(&owner_next[nc], fq);
+                }
+            }
+            __syncthreads();
+            if (tid == 0) s_full_n = 0;
+            __syncthreads();
+        }
+        int32_t* t = owner_prev; owner_prev = owner_next; owner_next = t;
+        const int changed = s_changed;
+        __syncthreads();
+        if (!changed) break;
+    }
+
+    // ---- results: last writer per key point, number of accepted queries, delta-angle histogram check
+    if (tid == 0) s_num = 0;
+    for (int i = tid; i < 32; i += 256) { s_hist[i] = 0; s_valid_bin[i] = 0; }
+    __syncthreads();
+    const bool angle_check = P.check_orientation && P.mode != PLP_MATCH_MODE_LANDMARKS;
+    const float* q_angle = P.q_angle ? P.q_angle + (size_t)b * P.m_cap : nullptr;
+    const float* t_angle = P.t_angle ? P.t_angle + (size_t)b * P.n_cap : nullptr;
+    auto bin_of = [&](int q, int t) -> int {
+        const float ta = kps ? kps[t].angle : t_angle[t];
+        float delta = P.mode == PLP_MATCH_MODE_LAST_FRAME ? __fsub_rn(q_angle[q], ta) : __fsub_rn(ta, q_angle[q]);
+        if (delta < 0.0) delta = (float)((double)delta + 360.0);
+        if (360.0 <= delta) delta = (float)((double)delta - 360.0);
+        return __float2int_rn(__fmul_rn(delta, 1.0f / 30));
+    };
+    int my = 0;
+    for (int q = tid; q < m; q += 256) {
+        const int t = claim[q];
+        if (t < 0) continue;
+        ++my;
+        atomicMax(&out[t], q);
+        if (angle_check) atomicAdd(&s_hist[min(bin_of(q, t), 31)], 1);
+    }
+    if (my) atomicAdd(&s_num, my);
+    __syncthreads();
+    if (angle_check) {
+        if (tid == 0) {   // the 3 fullest of 30 bins; equally full bins keep ascending bin order
+            for (int r = 0; r < 3; ++r) {
+                int bi = -1, bv = -1;
+                for (int i = 0; i < 30; ++i) if (!s_valid_bin[i] && s_hist[i] > bv) { bv = s_hist[i]; bi = i; }
+                s_valid_bin[bi] = 1;
+            }
+        }
+        __syncthreads();
+        int bad = 0;
+        for (int q = tid; q < m; q += 256) {
+            const int t = claim[q];
+            if (t < 0) continue;
+            if (!s_valid_bin[min(bin_of(q, t), 31)]) { out[t] = -1; ++bad; }
+        }
+        if (bad) atomicSub(&s_num, bad);
+        __syncthreads();
+    }
+    if (tid == 0) P.out_num[b] = s_num;
+}
+
+// ------------------------------------------------------------------------------------------
+// K16  full Hamming matrix: dist[q][t] (u16), 64 x 64 tile per workgroup, descriptors staged in LDS.
+// grid = (ceil(nt/64), ceil(nq/64)), block = 256.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_hamming_matrix(const uint8_t* __restrict__ qd, int nq, const uint8_t* __restrict__ td, int nt,
+                                                        uint16_t* __restrict__ dist) {
+    __shared__ uint32_t sq[64 * 9], st[64 * 9];   // 8 dwords per descriptor, +1 pad against bank conflicts
+    const int tid = threadIdx.x;
+    const int q0 = blockIdx.y * 64, t0 = blockIdx.x * 64;
+    for (int i = tid; i < 64 * 8; i += 256) {
+        const int r = i >> 3, w = i & 7;
+        sq[r * 9 + w] = q0 + r < nq ? reinterpret_cast<const uint32_t*>(qd)[(size_t)(q0 + r) * 8 + w] : 0u;
+        st[r * 9 + w] = t0 + r < nt ? reinterpret_cast<const uint32_t*>(td)[(size_t)(t0 + r) * 8 + w] : 0u;
+    }
+    __syncthreads();
+    const int tx = tid & 63, ty = tid >> 6;   // thread: target tx, queries ty, ty+4, ...
+    uint32_t tv[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) tv[w] = st[tx * 9 + w];
+    for (int r = ty; r < 64; r += 4) {
+        unsigned d = 0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) d += __popc(sq[r * 9 + w] ^ tv[w]);
+        if (q0 + r < nq && t0 + tx < nt) dist[(size_t)(q0 + r) * nt + t0 + tx] = (uint16_t)d;
+    }
+}
+
+void launch_match(hipStream_t st, const MatchProblem& P, int B) {
+    hipLaunchKernelGGL(k_match_topk, dim3((P.m_cap + 3) / 4, B), dim3(256), 0, st, P);
+    hipLaunchKernelGGL(k_match_resolve, dim3(B), dim3(256), (size_t)P.n_cap * 8, st, P);
+}
+
+void launch_hamming_matrix(hipStream_t st, const uint8_t* q, int nq, const uint8_t* t, int nt, uint16_t* dist) {
+    hipLaunchKernelGGL(k_hamming_matrix, dim3((nt + 63) / 64, (nq + 63) / 64), dim3(256), 0, st, q, nq, t, nt, dist);
+}
+
+}  // namespace plp

@@ -59,6 +59,22 @@ def lib():
         L.oracle_scale_tables.argtypes = [C.c_uint, C.c_float] + [C.c_void_p] * 4
         L.oracle_orb_time_frames.restype = C.c_double
         L.oracle_orb_time_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_int, C.c_void_p]
+        L.oracle_hamming32.restype = C.c_uint
+        L.oracle_hamming32.argtypes = [C.c_void_p, C.c_void_p]
+        L.oracle_hamming64.restype = C.c_uint
+        L.oracle_hamming64.argtypes = [C.c_void_p, C.c_void_p]
+        L.oracle_angle_checker.restype = C.c_int
+        L.oracle_angle_checker.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.oracle_get_cell_indices.restype = C.c_int
+        L.oracle_get_cell_indices.argtypes = [C.c_float] * 2 + [C.c_double] * 2 + [C.c_int] * 2 + [C.c_float] * 2 + [C.c_void_p] * 2
+        L.oracle_keypoints_in_cell.restype = C.c_int
+        L.oracle_keypoints_in_cell.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p]
+        L.oracle_match_frame_and_landmarks.restype = C.c_uint
+        L.oracle_match_frame_and_landmarks.argtypes = [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 7 + [C.c_int, C.c_float, C.c_float, C.c_void_p]
+        L.oracle_match_current_and_last.restype = C.c_uint
+        L.oracle_match_current_and_last.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 7 + [C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p]
+        L.oracle_brute_force_match.restype = C.c_uint
+        L.oracle_brute_force_match.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p]
         _lib = L
     return _lib
 
@@ -164,3 +180,69 @@ def fast9_16(roi, threshold):
     n = lib().oracle_fast9_16(C.c_void_p(roi.ctypes.data), roi.strides[0], roi.shape[1], roi.shape[0], threshold,
                               _p(out), cap)
     return out[:n].copy()
+
+
+# ---- matchers (oracle/match_oracle.cpp)
+def hamming32(a, b):
+    a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+    return lib().oracle_hamming32(_p(a), _p(b))
+
+
+def hamming64(a, b):
+    a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+    return lib().oracle_hamming64(_p(a), _p(b))
+
+
+def angle_checker(deltas, hist_len=30, n_bins_thr=3, valid=False):
+    d = np.ascontiguousarray(deltas, np.float32)
+    out = np.zeros(max(len(d), 1), np.int32)
+    n = lib().oracle_angle_checker(_p(d), len(d), hist_len, n_bins_thr, int(valid), _p(out))
+    return out[:n].copy()
+
+
+def grid6(g):
+    return np.array([g.min_x, g.min_y, g.inv_cell_width, g.inv_cell_height, g.cols, g.rows], np.float64)
+
+
+def keypoints_in_cell(g6, kps, ref_x, ref_y, margin, min_level=-1, max_level=-1):
+    kps = np.ascontiguousarray(kps, KP_DTYPE)
+    out = np.zeros(max(len(kps), 1), np.uint32)
+    n = lib().oracle_keypoints_in_cell(_p(g6), _p(kps), len(kps), ref_x, ref_y, margin, min_level, max_level, _p(out))
+    return out[:n].copy()
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dt)
+
+
+def match_frame_and_landmarks(g6, kps, desc, x_right, occupied, scale_factors, lm_valid, lm_reproj, lm_x_right, lm_level, lm_desc,
+                              lm_has_obs, margin, lowe_ratio):
+    n, m = len(kps), len(lm_level)
+    out = np.zeros(max(n, 1), np.int32)
+    a = [_c(g6, np.float64), _c(kps, KP_DTYPE), _c(desc, np.uint8), _c(x_right, np.float32), _c(occupied, np.uint8)]
+    b = [_c(scale_factors, np.float32), _c(lm_valid, np.uint8), _c(lm_reproj, np.float32), _c(lm_x_right, np.float32),
+         _c(lm_level, np.int32), _c(lm_desc, np.uint8), _c(lm_has_obs, np.uint8)]
+    num = lib().oracle_match_frame_and_landmarks(*[_p(v) for v in a], n, *[_p(v) for v in b], m, margin, lowe_ratio, _p(out))
+    return out[:n].copy(), num
+
+
+def match_current_and_last(g6, kps, desc, x_right, occupied, scale_factors, valid, reproj, lx_right, loctave, langle, ldesc, l_has_obs,
+                           margin, direction, check_orientation):
+    n, m = len(kps), len(loctave)
+    out = np.zeros(max(n, 1), np.int32)
+    sf = _c(scale_factors, np.float32)
+    a = [_c(g6, np.float64), _c(kps, KP_DTYPE), _c(desc, np.uint8), _c(x_right, np.float32), _c(occupied, np.uint8)]
+    b = [_c(valid, np.uint8), _c(reproj, np.float32), _c(lx_right, np.float32), _c(loctave, np.int32), _c(langle, np.float32),
+         _c(ldesc, np.uint8), _c(l_has_obs, np.uint8)]
+    num = lib().oracle_match_current_and_last(*[_p(v) for v in a], n, _p(sf), len(sf), *[_p(v) for v in b], m, margin, direction,
+                                              int(check_orientation), _p(out))
+    return out[:n].copy(), num
+
+
+def brute_force_match(desc1, angle1, desc2, angle2, valid2, lowe_ratio, check_orientation):
+    n1, n2 = len(desc1), len(desc2)
+    out = np.zeros(max(n1, 1), np.int32)
+    v = [_c(desc1, np.uint8), _c(angle1, np.float32)]
+    w = [_c(desc2, np.uint8), _c(angle2, np.float32), _c(valid2, np.uint8)]
+    num = lib().oracle_brute_force_match(_p(v[0]), _p(v[1]), n1, _p(w[0]), _p(w[1]), _p(w[2]), n2, lowe_ratio, int(check_orientation), _p(out))
+    return out[:n1].copy(), num

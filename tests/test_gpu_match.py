@@ -1,0 +1,120 @@
+"""GPU parity of the array-form Hamming matchers (through the C ABI) against the oracle restatement of
+match::projection / match::robust.  Integer work: the association arrays and num_matches must be identical."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from plp import plp, synth
+import match_cases as MC
+
+pytestmark = pytest.mark.gpu
+SF = (np.float32(1.2) ** np.arange(8)).astype(np.float32)
+
+
+def run_landmarks(t, q, margin, ratio, grid):
+    want, wn = O.match_frame_and_landmarks(O.grid6(grid), t["t_kps"], t["t_desc"], t["t_x_right"], t["t_occupied"], SF, q["q_valid"],
+                                           q["q_reproj"], q["q_x_right"], q["q_level"], q["q_desc"], q["q_has_obs"], margin, ratio)
+    mt = plp.matcher(ratio, True)
+    got, gn = mt.match_host(plp.MODE_LANDMARKS, len(t["t_kps"]), len(q["q_level"]), {**t, **q}, margin=margin, scale_factors=SF, grid=grid)
+    assert gn[0] == wn
+    assert np.array_equal(got[0], want)
+    return wn
+
+
+def run_last(t, q, margin, direction, check, grid):
+    want, wn = O.match_current_and_last(O.grid6(grid), t["t_kps"], t["t_desc"], t["t_x_right"], t["t_occupied"], SF, q["q_valid"],
+                                        q["q_reproj"], q["q_x_right"], q["q_level"], q["q_angle"], q["q_desc"], q["q_has_obs"], margin,
+                                        direction, check)
+    mt = plp.matcher(0.9, check)
+    got, gn = mt.match_host(plp.MODE_LAST_FRAME, len(t["t_kps"]), len(q["q_level"]), {**t, **q}, margin=margin, direction=direction,
+                            scale_factors=SF, grid=grid)
+    assert gn[0] == wn
+    assert np.array_equal(got[0], want)
+    return wn
+
+
+def run_brute(desc1, angle1, desc2, angle2, valid2, ratio, check):
+    want, wn = O.brute_force_match(desc1, angle1, desc2, angle2, valid2, ratio, check)
+    mt = plp.matcher(ratio, check)
+    got, gn = mt.match_host(plp.MODE_BRUTE_FORCE, len(desc1), len(desc2),
+                            dict(t_desc=desc1, t_angle=angle1, q_desc=desc2, q_angle=angle2, q_valid=valid2))
+    assert gn[0] == wn
+    assert np.array_equal(got[0], want)
+    return wn
+
+
+def test_hamming_matrix():
+    rng = np.random.default_rng(0)
+    q = rng.integers(0, 256, (300, 32), dtype=np.uint8); t = rng.integers(0, 256, (517, 32), dtype=np.uint8)
+    d = plp.matcher().hamming_matrix(q, t)
+    want = np.unpackbits(q[:, None, :] ^ t[None, :, :], axis=2).sum(2)
+    assert np.array_equal(d, want)
+    for a, b, w in [(0b01010101, 0b01010101, 0), (0b01010101, 0b10101010, 256), (0b01100110, 0b00111100, 128)]:   # base.cc vectors
+        assert plp.matcher().hamming_matrix(np.full((1, 32), a, np.uint8), np.full((1, 32), b, np.uint8))[0, 0] == w
+
+
+def test_tracking_shaped_problem_from_real_features():
+    frames = synth.replay(21, 3)
+    rng = np.random.default_rng(1)
+    grid = plp.make_grid(640, 480)
+    feats = [MC.features_from_oracle(f, 1000) for f in frames]
+    total = 0
+    for a, b in [(0, 1), (1, 2)]:
+        pk, pd = feats[a]; ck, cd = feats[b]
+        q = MC.make_queries_from_prev(pk, pd, rng, shift=(-3.0, 0.0))
+        t = dict(t_kps=ck, t_desc=cd, t_x_right=np.full(len(ck), -1, np.float32), t_occupied=np.zeros(len(ck), np.uint8))
+        total += run_landmarks(t, q, 10.0, 0.8, grid)
+        total += run_last(t, q, 20.0, 0, True, grid)
+        total += run_last(t, q, 40.0, 1, False, grid)
+        total += run_brute(cd, ck["angle"], pd, pk["angle"], q["q_valid"], 0.75, True)
+    assert total > 500    # the problems are not vacuous
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_problems_with_ties_conflicts_and_stereo(seed):
+    rng = np.random.default_rng(100 + seed)
+    grid = plp.make_grid(640, 480)
+    for trial in range(6):
+        n, m = int(rng.integers(1, 1500)), int(rng.integers(1, 2500))
+        t, q = MC.random_problem(rng, n, m, n_words=(0, 3, 12)[trial % 3], stereo=bool(trial % 2))
+        run_landmarks(t, q, float(rng.uniform(5, 60)), float(rng.choice([0.6, 0.8, 0.9])), grid)
+        run_last(t, q, float(rng.uniform(5, 60)), trial % 3, bool(trial & 1), grid)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_brute_force_heavy_conflicts(seed):
+    rng = np.random.default_rng(7 + seed)
+    for n1, n2, words in [(300, 400, 5), (1200, 900, 40), (2000, 2000, 0), (1, 5, 2), (64, 1, 1)]:
+        t, q = MC.random_problem(rng, n1, n2, n_words=words)
+        run_brute(t["t_desc"], t["t_kps"]["angle"], q["q_desc"], q["q_angle"], q["q_valid"], 0.75, bool(seed & 1))
+
+
+def test_batched_device_matches_per_problem_host():
+    import torch
+    rng = np.random.default_rng(5)
+    grid = plp.make_grid(640, 480)
+    B, n_cap, m_cap = 5, 700, 900
+    ts, qs = zip(*[MC.random_problem(rng, int(rng.integers(200, n_cap)), int(rng.integers(200, m_cap)), n_words=(0, 8)[b % 2]) for b in range(B)])
+    dev = torch.device("cuda:0")
+
+    def pad(arrs, cap, dt):
+        out = np.zeros((B, cap) + arrs[0].shape[1:], dt)
+        for b, a in enumerate(arrs):
+            out[b, :len(a)] = a
+        return out
+    f = {k: pad([t[k] for t in ts], n_cap, ts[0][k].dtype) for k in ts[0]}
+    f.update({k: pad([q[k] for q in qs], m_cap, qs[0][k].dtype) for k in qs[0]})
+    f["t_counts"] = np.array([len(t["t_kps"]) for t in ts], np.int32)
+    f["q_counts"] = np.array([len(q["q_level"]) for q in qs], np.int32)
+    d = {k: torch.from_numpy(v.view(np.uint8) if v.dtype == plp.KP_DTYPE else v).to(dev) for k, v in f.items()}
+    out_match = torch.full((B, n_cap), -7, dtype=torch.int32, device=dev)
+    out_num = torch.zeros(B, dtype=torch.int32, device=dev)
+    mt = plp.matcher(0.8, True)
+    mt.match_device(plp.MODE_LANDMARKS, n_cap, m_cap, d, out_match, out_num, margin=15.0, scale_factors=SF, grid=grid, B=B)
+    torch.cuda.synchronize()
+    om, on = out_match.cpu().numpy(), out_num.cpu().numpy()
+    for b in range(B):
+        t, q = ts[b], qs[b]
+        want, wn = O.match_frame_and_landmarks(O.grid6(grid), t["t_kps"], t["t_desc"], t["t_x_right"], t["t_occupied"], SF, q["q_valid"],
+                                               q["q_reproj"], q["q_x_right"], q["q_level"], q["q_desc"], q["q_has_obs"], 15.0, 0.8)
+        assert on[b] == wn and np.array_equal(om[b, :len(want)], want)
