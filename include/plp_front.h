@@ -133,6 +133,55 @@ plp_status plp_orb_debug_read(plp_orb* ctx, plp_orb_debug_id what, int32_t frame
                               void* dst, size_t dst_bytes, int64_t* n_out);
 
 /* ------------------------------------------------------------------------------------------
+ * Line front-end — replaces feature::LineFeatureTracker (src/PLPSLAM/feature/line_extractor.h:61-104):
+ * LSD detection (LSDDetectorC::detect with the options of line_extractor.cc:113-122, which wraps
+ * cv::createLineSegmentDetector) + LBD description (BinaryDescriptor::compute) + the length filter and
+ * the 2-D line functions of line_extractor.cc:134-159.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct plp_keyline {   /* field-for-field cv::line_descriptor::KeyLine, 68 bytes (descriptor_custom.hpp:139-174) */
+    float angle;
+    int32_t class_id;
+    int32_t octave;
+    float pt_x, pt_y;
+    float response;
+    float size;
+    float startPointX, startPointY, endPointX, endPointY;
+    float sPointInOctaveX, sPointInOctaveY, ePointInOctaveX, ePointInOctaveY;
+    float lineLength;
+    int32_t numOfPixels;
+} plp_keyline;
+
+typedef struct plp_line plp_line;   /* one per LineFeatureTracker instance */
+/* LineFeatureTracker(camera::base*): the camera only feeds the identity "undistortion" remap
+ * (line_extractor.cc:40-86,103), which is elided; no parameter is needed. */
+plp_status plp_line_create(int device, plp_line** out);
+void plp_line_destroy(plp_line* ctx);
+
+/* extract_LSD_LBD(img, frame_keylsd, frame_lbd_descr, keyline_functions)  (line_extractor.cc:88-160).
+ * Host pointers, synchronous.  kl: cap records, lbd: cap x 32 bytes, linefn: cap x 3 doubles
+ * (normalised (sx,sy,1) x (ex,ey,1)); the reference APPENDS to keyline_functions (:158) — the caller's
+ * facade appends these rows.  *n_out = number of kept lines. */
+plp_status plp_line_extract(plp_line* ctx, const uint8_t* img, int32_t rows, int32_t cols, size_t step,
+                            plp_keyline* kl, uint8_t* lbd, double* linefn, int32_t cap, int32_t* n_out);
+/* Batched replay form: B frames resident in HBM, results stay in HBM (B x cap records each). Asynchronous. */
+plp_status plp_line_extract_batch_device(plp_line* ctx, const uint8_t* d_imgs, int32_t B, int32_t rows, int32_t cols,
+                                         size_t step, size_t frame_stride, plp_keyline* d_kl, uint8_t* d_lbd,
+                                         double* d_linefn, int32_t cap, int32_t* d_counts, void* hip_stream);
+plp_status plp_line_last_batch_status(plp_line* ctx);
+
+/* Stage read-back for parity tests (synchronous, host destination, frame of the last call):
+ *   SCALED   u8 sh x sw dense (the 11-tap blur + x0.5 image LSD works on)
+ *   ORDER    int32 seed order (pixel index y*sw + x), (sh-1)*(sw-1) entries
+ *   RAW      float x 4 per LSD segment (x1,y1,x2,y2), in detection order
+ *   ALL_KL   plp_keyline of every segment longer than min_length (before the >= 60 px filter)
+ *   ALL_LBD  32 bytes per ALL_KL record
+ *   SOBEL_DX / SOBEL_DY  int16 rows x cols */
+typedef enum plp_line_debug_id { PLP_LINE_DBG_SCALED = 0, PLP_LINE_DBG_ORDER = 1, PLP_LINE_DBG_RAW = 2, PLP_LINE_DBG_ALL_KL = 3,
+                                 PLP_LINE_DBG_ALL_LBD = 4, PLP_LINE_DBG_SOBEL_DX = 5, PLP_LINE_DBG_SOBEL_DY = 6 } plp_line_debug_id;
+plp_status plp_line_debug_read(plp_line* ctx, plp_line_debug_id what, int32_t frame, void* dst, size_t dst_bytes, int64_t* n_out);
+plp_status plp_line_scaled_size(const plp_line* ctx, int32_t* rows, int32_t* cols);
+
+/* ------------------------------------------------------------------------------------------
  * Hamming matchers, array form — replace the inner loops of the reference's src/PLPSLAM/match directory.
  *
  * The reference's matchers walk data::frame / data::landmark objects (match/projection.h,

@@ -68,6 +68,13 @@ _API = [
     ("plp_orb_pyramid_host", C.c_int, [_VP, _I32, _I32, _VP, _SZ]),
     ("plp_orb_debug_read", C.c_int, [_VP, C.c_int, _I32, _I32, _VP, _SZ, _VP]),
     ("plp_model_quadtree_host", _I32, [_VP, _I32, _I32, _I32, C.c_uint32, _VP]),
+    ("plp_line_create", C.c_int, [C.c_int, _VP]),
+    ("plp_line_destroy", None, [_VP]),
+    ("plp_line_extract", C.c_int, [_VP, _VP, _I32, _I32, _SZ, _VP, _VP, _VP, _I32, _VP]),
+    ("plp_line_extract_batch_device", C.c_int, [_VP, _VP, _I32, _I32, _I32, _SZ, _SZ, _VP, _VP, _VP, _I32, _VP, _VP]),
+    ("plp_line_last_batch_status", C.c_int, [_VP]),
+    ("plp_line_debug_read", C.c_int, [_VP, C.c_int, _I32, _VP, _SZ, _VP]),
+    ("plp_line_scaled_size", C.c_int, [_VP, _VP, _VP]),
     ("plp_matcher_create", C.c_int, [C.c_int, _VP]),
     ("plp_matcher_destroy", None, [_VP]),
     ("plp_match_device", C.c_int, [_VP, _VP, _VP]),
@@ -242,6 +249,78 @@ class orb_extractor:
         a = np.zeros((r.value * c.value // 4 + 16, 3), np.int32)
         _check(lib().plp_orb_debug_read(self._h, what, frame, level, _p(a), a.nbytes, C.byref(n)))
         return a[:n.value].copy()
+
+
+# ------------------------------------------------------------------------------------------------
+# Line front-end (feature::LineFeatureTracker of the reference)
+# ------------------------------------------------------------------------------------------------
+KL_DTYPE = np.dtype([("angle", "<f4"), ("class_id", "<i4"), ("octave", "<i4"), ("pt_x", "<f4"), ("pt_y", "<f4"), ("response", "<f4"),
+                     ("size", "<f4"), ("startPointX", "<f4"), ("startPointY", "<f4"), ("endPointX", "<f4"), ("endPointY", "<f4"),
+                     ("sPointInOctaveX", "<f4"), ("sPointInOctaveY", "<f4"), ("ePointInOctaveX", "<f4"), ("ePointInOctaveY", "<f4"),
+                     ("lineLength", "<f4"), ("numOfPixels", "<i4")])
+assert KL_DTYPE.itemsize == 68
+LINE_CAP = 2048
+
+
+class LineFeatureTracker:
+    """Mirror of feature::LineFeatureTracker (src/PLPSLAM/feature/line_extractor.h:61-104) over the C ABI."""
+
+    DBG_SCALED, DBG_ORDER, DBG_RAW, DBG_ALL_KL, DBG_ALL_LBD, DBG_SOBEL_DX, DBG_SOBEL_DY = range(7)
+
+    def __init__(self, device=0):
+        h = C.c_void_p()
+        _check(lib().plp_line_create(device, C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib().plp_line_destroy(h)
+            self._h = None
+
+    def extract_LSD_LBD(self, img):
+        """returns (frame_keylsd, frame_lbd_descr, keyline_functions) like line_extractor.cc:88-160"""
+        img = np.ascontiguousarray(img, np.uint8)
+        kl = np.zeros(LINE_CAP, KL_DTYPE)
+        lbd = np.zeros((LINE_CAP, 32), np.uint8)
+        fn = np.zeros((LINE_CAP, 3), np.float64)
+        n = C.c_int32(0)
+        _check(lib().plp_line_extract(self._h, _p(img), img.shape[0], img.shape[1], img.strides[0], _p(kl), _p(lbd), _p(fn), LINE_CAP, C.byref(n)))
+        return kl[:n.value].copy(), lbd[:n.value].copy(), fn[:n.value].copy()
+
+    def extract_batch(self, d_imgs, d_kl, d_lbd, d_fn, d_counts, stream=None):
+        """d_imgs torch uint8 [B,H,W]; d_kl uint8 [B,cap,68]; d_lbd uint8 [B,cap,32]; d_fn float64 [B,cap,3]; d_counts int32 [B]"""
+        import torch
+        B, H, W = d_imgs.shape
+        st = (stream or torch.cuda.current_stream(d_imgs.device)).cuda_stream
+        _check(lib().plp_line_extract_batch_device(self._h, d_imgs.data_ptr(), B, H, W, d_imgs.stride(1), d_imgs.stride(0), d_kl.data_ptr(),
+                                                   d_lbd.data_ptr(), d_fn.data_ptr(), d_kl.shape[1], d_counts.data_ptr(), st))
+
+    def last_batch_status(self):
+        _check(lib().plp_line_last_batch_status(self._h))
+
+    def debug_read(self, what, frame=0):
+        r, c = C.c_int32(), C.c_int32()
+        _check(lib().plp_line_scaled_size(self._h, C.byref(r), C.byref(c)))
+        n = C.c_int64()
+        if what == self.DBG_SCALED:
+            a = np.zeros((r.value, c.value), np.uint8)
+        elif what == self.DBG_ORDER:
+            a = np.zeros((r.value - 1) * (c.value - 1), np.int32)
+        elif what == self.DBG_RAW:
+            a = np.zeros((LINE_CAP, 4), np.float32)
+        elif what == self.DBG_ALL_KL:
+            a = np.zeros(LINE_CAP, KL_DTYPE)
+        elif what == self.DBG_ALL_LBD:
+            a = np.zeros((LINE_CAP, 32), np.uint8)
+        else:
+            a = np.zeros(4 * r.value * c.value + 4 * (r.value + c.value) + 8, np.int16)
+        _check(lib().plp_line_debug_read(self._h, what, frame, _p(a), a.nbytes, C.byref(n)))
+        if what in (self.DBG_RAW, self.DBG_ALL_KL, self.DBG_ALL_LBD):
+            return a[:n.value].copy()
+        if what in (self.DBG_SOBEL_DX, self.DBG_SOBEL_DY):
+            return a[:n.value].copy()
+        return a
 
 
 # ------------------------------------------------------------------------------------------------

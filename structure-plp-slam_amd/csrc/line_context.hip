@@ -1,0 +1,274 @@
+// Host driver + C ABI of the line front-end (include/plp_front.h): LSD + LBD, batched over frames.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "line_device.hpp"
+#include "plp_common.hpp"
+
+using namespace plp;
+
+struct plp_line {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int rows = 0, cols = 0, capB = 0;
+    LinePlanes P{};
+    LsdParams lp{};
+    ResizeExactTab rt{};
+    BlurTapsN t11{}, t5{};
+    LbdWeightsDev w{};
+    DevBuf tabs, blur11, scaled, ang, mod, cs, bin, maxgrad, undef, order, reg, raw, n_raw, blur5, dx, dy, all_kl, all_lbd, n_all, status;
+    DevBuf l0copy, s_kl, s_lbd, s_fn, s_cnt;   // host-API staging
+    int s_cap = 0;
+    int last_B = 0;
+    hipStream_t last_stream = nullptr;
+    std::mutex mu;
+};
+
+namespace {
+
+// 8.8 fixed-point Gaussian taps that sum to 256 (edge -> centre error diffusion, centre takes the remainder)
+void gaussian_taps(int n, double sigma, int* out) {
+    std::vector<double> k(n);
+    double sum = 0;
+    for (int i = 0; i < n; ++i) { const double x = i - (n - 1) * 0.5; k[i] = std::exp(-0.5 / (sigma * sigma) * x * x); sum += k[i]; }
+    double err = 0;
+    int acc = 0;
+    for (int i = 0; i < n / 2; ++i) {
+        const double adj = k[i] / sum * 256.0 + err;
+        const int v = (int)std::nearbyint(adj);
+        err = adj - v;
+        out[i] = out[n - 1 - i] = v;
+        acc += v;
+    }
+    out[n / 2] = 256 - 2 * acc;
+}
+
+int floor_d(double v) { int i = (int)v; return i - (i > v); }
+
+void exact_coeffs(int ssize, int dsize, std::vector<int16_t>& ofs, std::vector<int16_t>& c1) {
+    const double scale = 1.0 / ((double)dsize / ssize);
+    for (int d = 0; d < dsize; ++d) {
+        const double val = ((double)d + 0.5) * scale - 0.5;
+        const int iv = floor_d(val);
+        if (iv >= 0 && ssize > 1) {
+            if (iv < ssize - 1) { ofs.push_back((int16_t)iv); c1.push_back((int16_t)std::nearbyint((val - (double)iv) * 256.0)); }
+            else { ofs.push_back((int16_t)(ssize - 1)); c1.push_back(-1); }
+        } else { ofs.push_back(0); c1.push_back(-2); }
+    }
+}
+
+plp_status build(plp_line* c, int rows, int cols) {
+    if (c->rows == rows && c->cols == cols) return PLP_OK;
+    if (rows < 16 || cols < 16 || rows > 16000 || cols > 16000) return set_error(PLP_ERR_INVALID_ARG, "unsupported frame size for the line front-end");
+    LinePlanes& P = c->P;
+    P.W = cols; P.H = rows;
+    P.sw = (int)std::nearbyint(cols * 0.5); P.sh = (int)std::nearbyint(rows * 0.5);   // cvRound(ssize * scale)
+    if (P.sw >= 65536 || P.sh >= 65536 || (size_t)4 * (((size_t)P.sw * P.sh + 31) / 32) * 4 > 65536)
+        return set_error(PLP_ERR_UNSUPPORTED, "frame too large for the LSD region-growing kernel (scaled image must stay below ~131k pixels)");
+    P.pitch = (cols + 63) / 64 * 64; P.spitch = (P.sw + 63) / 64 * 64;
+    // LSD constants (line_extractor.cc:113-122, lsd.cpp flsd)
+    LsdParams& lp = c->lp;
+    const double ang_th = 22.5, quant = 2.0;
+    lp.prec = M_PI * ang_th / 180; lp.p = ang_th / 180; lp.rho = quant / std::sin(lp.prec);
+    lp.density_th = 0.6; lp.scale = 0.5; lp.n_bins = 1024; lp.refine = 1;
+    const double LOG_NT = 5 * (std::log10((double)P.sw) + std::log10((double)P.sh)) / 2 + std::log10(11.0);
+    lp.min_reg_size = (int)(size_t)(-LOG_NT / std::log10(lp.p));
+    lp.min_length = (float)(0.125 * std::min(cols, rows));
+    lp.keep_length = 60.f;
+    const double sigma = 0.6 / 0.5;
+    const unsigned h = (unsigned)std::ceil(sigma * std::sqrt(2 * 3.0 * std::log(10.0)));
+    if (h != 5) return set_error(PLP_ERR_UNSUPPORTED, "unexpected LSD kernel size");
+    gaussian_taps(11, sigma, c->t11.k);
+    for (int i = 0; i < 11; ++i) c->t5.k[i] = 0;
+    gaussian_taps(5, 1.0, c->t5.k);
+    // LBD weights (binary_descriptor_custom.cpp:217-258; integer divisions as in the reference)
+    {
+        double u = (7 * 3 - 1) / 2, sg = (7 * 2 + 1) / 2, inv = -1 / (2 * sg * sg);
+        for (int i = 0; i < 21; ++i) { const double d = i - u; c->w.l[i] = (float)std::exp(d * d * inv); }
+        u = (9 * 7 - 1) / 2; sg = u; inv = -1 / (2 * sg * sg);
+        for (int i = 0; i < 63; ++i) { const double d = i - u; c->w.g[i] = (float)std::exp(d * d * inv); }
+    }
+    std::vector<int16_t> xo, xc, yo, yc;
+    exact_coeffs(cols, P.sw, xo, xc);
+    exact_coeffs(rows, P.sh, yo, yc);
+    std::vector<int16_t> blob;
+    blob.insert(blob.end(), xo.begin(), xo.end()); blob.insert(blob.end(), xc.begin(), xc.end());
+    blob.insert(blob.end(), yo.begin(), yo.end()); blob.insert(blob.end(), yc.begin(), yc.end());
+    PLP_HIP(c->tabs.upload(blob.data(), blob.size() * 2, c->stream));
+    PLP_HIP(hipStreamSynchronize(c->stream));
+    const int16_t* base = (const int16_t*)c->tabs.p;
+    c->rt.xo = base; c->rt.xc = base + P.sw; c->rt.yo = base + 2 * P.sw; c->rt.yc = base + 2 * P.sw + P.sh;
+    c->rows = rows; c->cols = cols; c->capB = 0;
+    return PLP_OK;
+}
+
+plp_status ensure(plp_line* c, int B) {
+    if (B <= c->capB) return PLP_OK;
+    LinePlanes& P = c->P;
+    const size_t n = (size_t)P.sw * P.sh, nv = (size_t)(P.sw - 1) * (P.sh - 1), full = (size_t)P.W * P.H;
+    PLP_HIP(c->blur11.reserve((size_t)P.pitch * P.H * B)); PLP_HIP(c->blur5.reserve((size_t)P.pitch * P.H * B));
+    PLP_HIP(c->scaled.reserve((size_t)P.spitch * P.sh * B));
+    PLP_HIP(c->ang.reserve(n * 8 * B)); PLP_HIP(c->mod.reserve(n * 8 * B)); PLP_HIP(c->cs.reserve(n * 8 * B));
+    PLP_HIP(c->bin.reserve(n * 2 * B)); PLP_HIP(c->maxgrad.reserve(8 * (size_t)B)); PLP_HIP(c->undef.reserve((n + 63) / 64 * 8 * B));
+    PLP_HIP(c->order.reserve(nv * 4 * B)); PLP_HIP(c->reg.reserve(n * 4 * B));
+    PLP_HIP(c->raw.reserve(sizeof(float4) * kLineCap * B)); PLP_HIP(c->n_raw.reserve(4 * (size_t)B));
+    PLP_HIP(c->dx.reserve(full * 2 * B)); PLP_HIP(c->dy.reserve(full * 2 * B));
+    PLP_HIP(c->all_kl.reserve(sizeof(plp_keyline) * kLineCap * B)); PLP_HIP(c->all_lbd.reserve((size_t)32 * kLineCap * B));
+    PLP_HIP(c->n_all.reserve(4 * (size_t)B)); PLP_HIP(c->status.reserve(16));
+    P.blur11 = (uint8_t*)c->blur11.p; P.blur5 = (uint8_t*)c->blur5.p; P.scaled = (uint8_t*)c->scaled.p;
+    P.ang = (double*)c->ang.p; P.mod = (double*)c->mod.p; P.cs = (float2*)c->cs.p; P.bin = (uint16_t*)c->bin.p;
+    P.maxgrad = (unsigned long long*)c->maxgrad.p; P.undef = (unsigned long long*)c->undef.p;
+    P.order = (uint32_t*)c->order.p; P.reg = (uint32_t*)c->reg.p; P.raw = (float4*)c->raw.p; P.n_raw = (int32_t*)c->n_raw.p;
+    P.dx = (int16_t*)c->dx.p; P.dy = (int16_t*)c->dy.p; P.all_kl = (plp_keyline*)c->all_kl.p; P.all_lbd = (uint8_t*)c->all_lbd.p;
+    P.n_all = (int32_t*)c->n_all.p; P.status = (int32_t*)c->status.p;
+    c->capB = B;
+    return PLP_OK;
+}
+
+plp_status run(plp_line* c, const uint8_t* d_imgs, int B, int rows, int cols, size_t step, size_t frame_stride, plp_keyline* d_kl,
+               uint8_t* d_lbd, double* d_fn, int cap, int32_t* d_counts, hipStream_t st) {
+    PLP_HIP(hipSetDevice(c->device));
+    PLP_TRY(build(c, rows, cols));
+    PLP_TRY(ensure(c, B));
+    c->P.img = d_imgs; c->P.img_frame_stride = frame_stride; c->P.img_pitch = (int)step;
+    PLP_HIP(hipMemsetAsync(c->status.p, 0, 16, st));
+    launch_line_front(st, c->P, c->lp, c->rt, c->t11, c->t5, c->w, d_kl, d_lbd, d_fn, cap, d_counts, B);
+    PLP_HIP(hipGetLastError());
+    c->last_B = B; c->last_stream = st;
+    return PLP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+plp_status plp_line_create(int device, plp_line** out) {
+    if (!out) return set_error(PLP_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return set_error(PLP_ERR_NO_DEVICE, "no HIP device visible: the line front-end has no CPU fallback");
+    if (device < 0 || device >= n) return set_error(PLP_ERR_INVALID_ARG, "device index out of range");
+    PLP_HIP(hipSetDevice(device));
+    plp_line* c = new plp_line();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return set_error(PLP_ERR_HIP, "hipStreamCreate failed"); }
+    *out = c;
+    return PLP_OK;
+}
+
+void plp_line_destroy(plp_line* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    delete c;
+}
+
+plp_status plp_line_extract_batch_device(plp_line* c, const uint8_t* d_imgs, int32_t B, int32_t rows, int32_t cols, size_t step,
+                                         size_t frame_stride, plp_keyline* d_kl, uint8_t* d_lbd, double* d_linefn, int32_t cap,
+                                         int32_t* d_counts, void* hip_stream) {
+    if (!c || !d_imgs || !d_kl || !d_lbd || !d_linefn || !d_counts) return set_error(PLP_ERR_INVALID_ARG, "NULL argument");
+    if (B <= 0 || rows <= 0 || cols <= 0 || cap <= 0 || step < (size_t)cols) return set_error(PLP_ERR_INVALID_ARG, "bad batch geometry");
+    std::lock_guard<std::mutex> lk(c->mu);
+    return run(c, d_imgs, B, rows, cols, step, frame_stride, d_kl, d_lbd, d_linefn, cap, d_counts, hip_stream ? (hipStream_t)hip_stream : c->stream);
+}
+
+plp_status plp_line_last_batch_status(plp_line* c) {
+    if (!c) return set_error(PLP_ERR_INVALID_ARG, "ctx is NULL");
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->last_B) return PLP_OK;
+    PLP_HIP(hipSetDevice(c->device));
+    int32_t s[4] = {0, 0, 0, 0};
+    PLP_HIP(hipMemcpyAsync(s, c->status.p, 16, hipMemcpyDeviceToHost, c->last_stream));
+    PLP_HIP(hipStreamSynchronize(c->last_stream));
+    if (s[0] & 1) return set_error(PLP_ERR_CAPACITY, "a frame produced more lines than `cap`; output truncated");
+    if (s[0] & 4) return set_error(PLP_ERR_OVERFLOW, "more LSD segments than the per-frame capacity");
+    return PLP_OK;
+}
+
+plp_status plp_line_extract(plp_line* c, const uint8_t* img, int32_t rows, int32_t cols, size_t step, plp_keyline* kl, uint8_t* lbd,
+                            double* linefn, int32_t cap, int32_t* n_out) {
+    if (!c || !img || !kl || !lbd || !linefn || !n_out) return set_error(PLP_ERR_INVALID_ARG, "NULL argument");
+    if (rows <= 0 || cols <= 0 || cap < 0 || step < (size_t)cols) return set_error(PLP_ERR_INVALID_ARG, "bad image geometry");
+    std::lock_guard<std::mutex> lk(c->mu);
+    PLP_HIP(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const int pitch = (cols + 63) / 64 * 64;
+    PLP_HIP(c->l0copy.reserve((size_t)pitch * rows));
+    if (c->s_cap < kLineCap) {
+        PLP_HIP(c->s_kl.reserve(sizeof(plp_keyline) * kLineCap)); PLP_HIP(c->s_lbd.reserve((size_t)32 * kLineCap));
+        PLP_HIP(c->s_fn.reserve((size_t)24 * kLineCap)); PLP_HIP(c->s_cnt.reserve(16));
+        c->s_cap = kLineCap;
+    }
+    PLP_HIP(hipMemcpy2DAsync(c->l0copy.p, pitch, img, step, cols, rows, hipMemcpyHostToDevice, st));
+    PLP_TRY(run(c, (const uint8_t*)c->l0copy.p, 1, rows, cols, pitch, (size_t)pitch * rows, (plp_keyline*)c->s_kl.p, (uint8_t*)c->s_lbd.p,
+                (double*)c->s_fn.p, kLineCap, (int32_t*)c->s_cnt.p, st));
+    int32_t n = 0;
+    PLP_HIP(hipMemcpyAsync(&n, c->s_cnt.p, 4, hipMemcpyDeviceToHost, st));
+    PLP_HIP(hipStreamSynchronize(st));
+    *n_out = n;
+    if (n > cap) return set_error(PLP_ERR_CAPACITY, "caller buffers too small");
+    if (n > 0) {
+        PLP_HIP(hipMemcpyAsync(kl, c->s_kl.p, sizeof(plp_keyline) * (size_t)n, hipMemcpyDeviceToHost, st));
+        PLP_HIP(hipMemcpyAsync(lbd, c->s_lbd.p, 32 * (size_t)n, hipMemcpyDeviceToHost, st));
+        PLP_HIP(hipMemcpyAsync(linefn, c->s_fn.p, 24 * (size_t)n, hipMemcpyDeviceToHost, st));
+        PLP_HIP(hipStreamSynchronize(st));
+    }
+    int32_t s[4];
+    PLP_HIP(hipMemcpy(s, c->status.p, 16, hipMemcpyDeviceToHost));
+    if (s[0] & 4) return set_error(PLP_ERR_OVERFLOW, "more LSD segments than the per-frame capacity");
+    return PLP_OK;
+}
+
+plp_status plp_line_scaled_size(const plp_line* c, int32_t* rows, int32_t* cols) {
+    if (!c || !rows || !cols || !c->rows) return set_error(PLP_ERR_INVALID_ARG, "no frame processed yet");
+    *rows = c->P.sh; *cols = c->P.sw;
+    return PLP_OK;
+}
+
+plp_status plp_line_debug_read(plp_line* c, plp_line_debug_id what, int32_t frame, void* dst, size_t dst_bytes, int64_t* n_out) {
+    if (!c || !dst || !n_out) return set_error(PLP_ERR_INVALID_ARG, "NULL argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->last_B || frame < 0 || frame >= c->last_B) return set_error(PLP_ERR_INVALID_ARG, "bad frame");
+    PLP_HIP(hipSetDevice(c->device));
+    PLP_HIP(hipStreamSynchronize(c->last_stream));
+    const LinePlanes& P = c->P;
+    const size_t n = (size_t)P.sw * P.sh, nv = (size_t)(P.sw - 1) * (P.sh - 1), full = (size_t)P.W * P.H;
+    int32_t cnt = 0;
+    switch (what) {
+        case PLP_LINE_DBG_SCALED:
+            if (dst_bytes < n) return set_error(PLP_ERR_CAPACITY, "dst too small");
+            PLP_HIP(hipMemcpy2D(dst, P.sw, P.scaled + (size_t)frame * P.spitch * P.sh, P.spitch, P.sw, P.sh, hipMemcpyDeviceToHost));
+            *n_out = (int64_t)n; return PLP_OK;
+        case PLP_LINE_DBG_ORDER:
+            if (dst_bytes < nv * 4) return set_error(PLP_ERR_CAPACITY, "dst too small");
+            PLP_HIP(hipMemcpy(dst, P.order + (size_t)frame * nv, nv * 4, hipMemcpyDeviceToHost));
+            *n_out = (int64_t)nv; return PLP_OK;
+        case PLP_LINE_DBG_RAW:
+            PLP_HIP(hipMemcpy(&cnt, P.n_raw + frame, 4, hipMemcpyDeviceToHost));
+            if (dst_bytes < (size_t)cnt * 16) return set_error(PLP_ERR_CAPACITY, "dst too small");
+            if (cnt) PLP_HIP(hipMemcpy(dst, P.raw + (size_t)frame * kLineCap, (size_t)cnt * 16, hipMemcpyDeviceToHost));
+            *n_out = cnt; return PLP_OK;
+        case PLP_LINE_DBG_ALL_KL:
+        case PLP_LINE_DBG_ALL_LBD: {
+            PLP_HIP(hipMemcpy(&cnt, P.n_all + frame, 4, hipMemcpyDeviceToHost));
+            const size_t rec = what == PLP_LINE_DBG_ALL_KL ? sizeof(plp_keyline) : 32;
+            if (dst_bytes < (size_t)cnt * rec) return set_error(PLP_ERR_CAPACITY, "dst too small");
+            const uint8_t* src = what == PLP_LINE_DBG_ALL_KL ? (const uint8_t*)(P.all_kl + (size_t)frame * kLineCap) : P.all_lbd + (size_t)frame * kLineCap * 32;
+            if (cnt) PLP_HIP(hipMemcpy(dst, src, (size_t)cnt * rec, hipMemcpyDeviceToHost));
+            *n_out = cnt; return PLP_OK;
+        }
+        case PLP_LINE_DBG_SOBEL_DX:
+        case PLP_LINE_DBG_SOBEL_DY:
+            if (dst_bytes < full * 2) return set_error(PLP_ERR_CAPACITY, "dst too small");
+            PLP_HIP(hipMemcpy(dst, (what == PLP_LINE_DBG_SOBEL_DX ? P.dx : P.dy) + (size_t)frame * full, full * 2, hipMemcpyDeviceToHost));
+            *n_out = (int64_t)full; return PLP_OK;
+    }
+    return set_error(PLP_ERR_INVALID_ARG, "unknown debug id");
+}
+
+}  // extern "C"

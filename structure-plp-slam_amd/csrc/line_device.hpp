@@ -1,0 +1,51 @@
+// Structures shared by the line front-end kernels (LSD + LBD) and their host driver.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/plp_front.h"
+
+namespace plp {
+
+constexpr int kLineCap = 2048;        // raw LSD segments / key lines kept per frame (a 640x480 frame yields ~400)
+constexpr double kLsdNotDef = -1024.0;
+
+// Per-frame geometry + HBM planes of the line path.  All planes are B frames back to back.
+struct LinePlanes {
+    int W, H;                 // full-resolution frame
+    int sw, sh;               // LSD working resolution (scale 0.5)
+    int pitch, spitch;        // row pitch of the full-res u8 planes / of the scaled u8 plane (64-B multiples)
+    const uint8_t* img; size_t img_frame_stride; int img_pitch;   // caller's frames
+    uint8_t* blur11;          // 11-tap sigma 1.2 blur (LSD)          [B][H][pitch]
+    uint8_t* scaled;          // INTER_LINEAR_EXACT x0.5              [B][sh][spitch]
+    double* ang;              // level-line angle or NOTDEF           [B][sh*sw]
+    double* mod;              // gradient magnitude                   [B][sh*sw]
+    float2* cs;               // (float)cos / sin of float(angle)     [B][sh*sw]
+    uint16_t* bin;            // pseudo-ordering bin                  [B][sh*sw]
+    unsigned long long* maxgrad;   // per frame, bit pattern of the max defined magnitude  [B]
+    unsigned long long* undef;     // NOTDEF bitmask, 1 bit per scaled pixel          [B][ceil(sh*sw/64)]
+    uint32_t* order;          // seed order (pixel index y*sw+x)      [B][(sh-1)*(sw-1)]
+    uint32_t* reg;            // region point list scratch            [B][sh*sw]
+    float4* raw; int32_t* n_raw;          // LSD segments             [B][kLineCap], [B]
+    uint8_t* blur5;           // 5-tap sigma 1 blur (LBD)             [B][H][pitch]
+    int16_t* dx; int16_t* dy; // Sobel 3x3                            [B][H][W]
+    plp_keyline* all_kl; uint8_t* all_lbd; int32_t* n_all;   // before the length filter  [B][kLineCap]
+    int32_t* status;
+};
+
+struct LsdParams {
+    double prec, p, rho, density_th, scale;
+    int n_bins, refine, min_reg_size;
+    float min_length;         // LSDOptions.min_length (0.125 * min(W,H))
+    float keep_length;        // hard filter of line_extractor.cc:136 (60 px)
+};
+
+struct ResizeExactTab { const int16_t *xo, *xc, *yo, *yc; };   // offsets + 8.8 weights (-1/-2: border sample)
+struct BlurTapsN { int k[11]; };
+struct LbdWeightsDev { float g[63], l[21]; };
+
+void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp, const ResizeExactTab& rt, const BlurTapsN& t11,
+                       const BlurTapsN& t5, const LbdWeightsDev& w, plp_keyline* out_kl, uint8_t* out_lbd, double* out_fn, int cap,
+                       int32_t* out_counts, int B);
+
+}  // namespace plp

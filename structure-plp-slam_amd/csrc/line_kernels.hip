@@ -1,0 +1,741 @@
+// Hand-written HIP kernels (gfx950, wave64) of the batched line front-end: LSD detection + LBD description.
+// Restates LineFeatureTracker::extract_LSD_LBD (reference src/PLPSLAM/feature/line_extractor.cc:88-160),
+// the LSDDetectorC wrapper (line_descriptor/LSDDetector_custom.cpp:216-320), OpenCV's LineSegmentDetector
+// (lsd.cpp, LSD_REFINE_STD; third-party) and BinaryDescriptor::computeLBD
+// (line_descriptor/binary_descriptor_custom.cpp:1018-1364).
+//
+//   k_blur_plane<R>    cv::GaussianBlur u8 fixed point, (2R+1) taps (R=5: LSD sigma 1.2, R=2: LBD sigma 1)
+//   k_resize_exact     cv::resize(x0.5, INTER_LINEAR_EXACT)
+//   k_lsd_gradient     ll_angle: 2x2 gradient, magnitude (f64), level-line angle, max magnitude
+//   k_lsd_bins         pseudo-ordering bins
+//   k_lsd_order        counting sort of the seeds: bin descending, row-major inside a bin
+//   k_lsd_grow         region_grow / region2rect / refine, ONE wave per frame (the algorithm is a
+//                      sequential scan over seeds; frames run in parallel)
+//   k_keylines         KeyLine assembly + min_length filter
+//   k_sobel3           cv::Sobel 3x3 -> s16 dx, dy
+//   k_lbd              63-row band descriptor, one wave per line (lane = row; each row is a strictly
+//                      sequential f32 sum, as in the reference), normalisation, 32-byte binarisation
+//   k_line_finalize    lineLength >= 60 filter, 2-D line function (f64), ordered compaction
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "line_device.hpp"
+
+namespace plp {
+
+__device__ __forceinline__ int reflect101_l(int p, int len) {
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p;
+    return p;
+}
+
+__device__ __forceinline__ float fast_atan2_deg_l(float y, float x) {   // cv::fastAtan2, f32, no FMA
+    const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
+    const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
+    const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
+    const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
+    const float eps = (float)2.2204460492503131e-16;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a;
+    if (ax >= ay) {
+        const float c = __fdiv_rn(ay, __fadd_rn(ax, eps));
+        const float c2 = __fmul_rn(c, c);
+        a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+    } else {
+        const float c = __fdiv_rn(ax, __fadd_rn(ay, eps));
+        const float c2 = __fmul_rn(c, c);
+        a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
+    }
+    if (x < 0) a = __fsub_rn(180.f, a);
+    if (y < 0) a = __fsub_rn(360.f, a);
+    return a;
+}
+
+// ------------------------------------------------------------------------------------------ blur
+// out = (sum_j k[j] * (sum_i k[i] * src) + 32768) >> 16 with REFLECT_101; 64x32 output tile per workgroup.
+template <int R>
+__global__ __launch_bounds__(256) void k_blur_plane(const uint8_t* __restrict__ src, size_t src_fs, int src_pitch,
+                                                    uint8_t* __restrict__ dst, size_t dst_fs, int dst_pitch, int w, int h, BlurTapsN taps) {
+    constexpr int TW = 64, TH = 32, K = 2 * R + 1, IW = TW + 2 * R + 2;
+    __shared__ uint8_t in[(TH + 2 * R) * IW];
+    __shared__ uint16_t hs[(TH + 2 * R) * TW];
+    const int tiles_x = (w + TW - 1) / TW;
+    const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
+    const int tid = threadIdx.x;
+    const uint8_t* img = src + (size_t)blockIdx.y * src_fs;
+    for (int i = tid; i < (TH + 2 * R) * (TW + 2 * R); i += 256) {
+        const int r = i / (TW + 2 * R), c = i - r * (TW + 2 * R);
+        in[r * IW + c] = img[(size_t)reflect101_l(ty0 + r - R, h) * src_pitch + reflect101_l(tx0 + c - R, w)];
+    }
+    __syncthreads();
+    for (int i = tid; i < (TH + 2 * R) * TW; i += 256) {
+        const int r = i / TW, c = i - r * TW;
+        uint32_t a = 0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) a += (uint32_t)taps.k[k] * in[r * IW + c + k];
+        hs[i] = (uint16_t)a;
+    }
+    __syncthreads();
+    uint8_t* out = dst + (size_t)blockIdx.y * dst_fs;
+    const int cx = (tid & 15) * 4, ry = tid >> 4;
+#pragma unroll
+    for (int sweep = 0; sweep < 2; ++sweep) {
+        const int r = ry + sweep * 16, y = ty0 + r, x = tx0 + cx;
+        if (y < h && x < w) {
+            uint32_t packed = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint32_t a = 0;
+#pragma unroll
+                for (int k = 0; k < K; ++k) a += (uint32_t)taps.k[k] * hs[(r + k) * TW + cx + i];
+                packed |= min((a + 32768u) >> 16, 255u) << (8 * i);
+            }
+            *reinterpret_cast<uint32_t*>(out + (size_t)y * dst_pitch + x) = packed;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ x0.5 INTER_LINEAR_EXACT
+__global__ __launch_bounds__(256) void k_resize_exact(const uint8_t* __restrict__ src, size_t src_fs, int src_pitch,
+                                                      uint8_t* __restrict__ dst, size_t dst_fs, int dst_pitch, int dw, int dh,
+                                                      ResizeExactTab t) {
+    const int dy = blockIdx.y * 4 + threadIdx.y, dx0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    if (dy >= dh || dx0 >= dw) return;
+    const uint8_t* s = src + (size_t)blockIdx.z * src_fs;
+    const int yo = t.yo[dy], yc = t.yc[dy];
+    const uint8_t* S0 = s + (size_t)yo * src_pitch;
+    const uint8_t* S1 = yc < 0 ? S0 : S0 + src_pitch;
+    const uint32_t b1 = yc < 0 ? 0u : (uint32_t)yc, b0 = 256u - b1;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int dx = min(dx0 + i, dw - 1);
+        const int xo = t.xo[dx], xc = t.xc[dx];
+        uint32_t h0, h1;
+        if (xc < 0) { h0 = (uint32_t)S0[xo] * 256u; h1 = (uint32_t)S1[xo] * 256u; }
+        else {
+            h0 = (uint32_t)S0[xo] * (uint32_t)(256 - xc) + (uint32_t)S0[xo + 1] * (uint32_t)xc;
+            h1 = (uint32_t)S1[xo] * (uint32_t)(256 - xc) + (uint32_t)S1[xo + 1] * (uint32_t)xc;
+        }
+        const uint32_t v = (b0 * h0 + b1 * h1 + 32768u) >> 16;
+        packed |= min(v, 255u) << (8 * i);
+    }
+    *reinterpret_cast<uint32_t*>(dst + (size_t)blockIdx.z * dst_fs + (size_t)dy * dst_pitch + dx0) = packed;
+}
+
+// ------------------------------------------------------------------------------------------ ll_angle
+__global__ __launch_bounds__(256) void k_lsd_gradient(LinePlanes P, LsdParams lp) {
+    const int b = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int n = P.sw * P.sh;
+    double norm_def = 0.0;
+    if (idx < n) {
+        const int y = idx / P.sw, x = idx - y * P.sw;
+        double ang = kLsdNotDef, norm = 0.0;
+        float2 cs = make_float2(0.f, 0.f);
+        if (x < P.sw - 1 && y < P.sh - 1) {
+            const uint8_t* s = P.scaled + ((size_t)b * P.sh + y) * P.spitch + x;
+            const int DA = (int)s[P.spitch + 1] - (int)s[0];
+            const int BC = (int)s[1] - (int)s[P.spitch];
+            const int gx = DA + BC, gy = DA - BC;
+            norm = sqrt((double)(gx * gx + gy * gy) / 4.0);
+            if (!(norm <= lp.rho)) {
+                ang = (double)fast_atan2_deg_l((float)gx, (float)-gy) * (3.14159265358979323846 / 180);
+                const float fa = (float)ang;
+                cs = make_float2((float)cos((double)fa), (float)sin((double)fa));
+                norm_def = norm;
+            }
+        }
+        const size_t o = (size_t)b * n + idx;
+        P.ang[o] = ang; P.mod[o] = norm; P.cs[o] = cs;
+    }
+    // max over defined pixels: positive doubles order like their bit patterns
+    unsigned long long bits = (unsigned long long)__double_as_longlong(norm_def);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned lo = __shfl_xor((unsigned)bits, o), hi = __shfl_xor((unsigned)(bits >> 32), o);
+        const unsigned long long w = ((unsigned long long)hi << 32) | lo;
+        bits = w > bits ? w : bits;
+    }
+    if ((threadIdx.x & 63) == 0 && bits) atomicMax(&P.maxgrad[b], bits);
+    // one 64-bit word per wave: pixels that can never seed or join a region (angle NOTDEF)
+    const unsigned long long undef = __ballot(!(norm_def > 0.0));
+    if ((threadIdx.x & 63) == 0 && blockIdx.x * 256 + (int)threadIdx.x < ((n + 63) / 64) * 64)
+        P.undef[(size_t)b * ((n + 63) / 64) + (blockIdx.x * 256 + threadIdx.x) / 64] = undef;
+}
+
+__global__ __launch_bounds__(256) void k_lsd_bins(LinePlanes P, LsdParams lp) {
+    const int b = blockIdx.y, idx = blockIdx.x * 256 + threadIdx.x, n = P.sw * P.sh;
+    if (idx >= n) return;
+    const double max_grad = __longlong_as_double((long long)P.maxgrad[b]);
+    const double bin_coef = (max_grad > 0) ? (double)(lp.n_bins - 1) / max_grad : 0;
+    P.bin[(size_t)b * n + idx] = (uint16_t)(int)(P.mod[(size_t)b * n + idx] * bin_coef);
+}
+
+// ------------------------------------------------------------------------------------------ seed ordering
+// One workgroup per frame; wave q owns the q-th quarter of the row-major seed sequence.
+__global__ __launch_bounds__(256) void k_lsd_order(LinePlanes P) {
+    __shared__ uint32_t cnt[4][1024];
+    __shared__ uint32_t base[1024];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
+    const int vw = P.sw - 1, vh = P.sh - 1, nv = vw * vh, n = P.sw * P.sh;
+    const uint16_t* bin = P.bin + (size_t)b * n;
+    uint32_t* order = P.order + (size_t)b * nv;
+    for (int i = tid; i < 4096; i += 256) (&cnt[0][0])[i] = 0;
+    __syncthreads();
+    const int per = (nv + 3) / 4, j0 = q * per, j1 = min(nv, j0 + per);
+    for (int j = j0 + lane; j < j1; j += 64) {
+        const int y = j / vw, x = j - y * vw;
+        atomicAdd(&cnt[q][bin[y * P.sw + x]], 1u);
+    }
+    __syncthreads();
+    // bins in descending order: base[v] = number of seeds with a larger bin
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int v = 1023; v >= 0; --v) { base[v] = run; run += cnt[0][v] + cnt[1][v] + cnt[2][v] + cnt[3][v]; }
+    }
+    __syncthreads();
+    for (int v = tid; v < 1024; v += 256) {   // cnt[q][v] <- first slot of wave q inside bin v
+        uint32_t run = base[v];
+        for (int k = 0; k < 4; ++k) { const uint32_t c = cnt[k][v]; cnt[k][v] = run; run += c; }
+    }
+    __syncthreads();
+    for (int g = j0; g < j1; g += 64) {
+        const int j = g + lane;
+        const bool valid = j < j1;
+        unsigned v = 0;
+        int pix = 0;
+        if (valid) { const int y = j / vw, x = j - y * vw; pix = y * P.sw + x; v = bin[pix]; }
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < 10; ++bit) {
+            const unsigned long long m = __ballot((v >> bit) & 1u);
+            peers &= ((v >> bit) & 1u) ? m : ~m;
+        }
+        if (valid) {
+            const int rank = __popcll(peers & ((1ull << lane) - 1ull));
+            const uint32_t slot = cnt[q][v] + rank;
+            order[slot] = (uint32_t)pix;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (valid && (peers & ((1ull << lane) - 1ull)) == 0) cnt[q][v] += (uint32_t)__popcll(peers);   // one leader per bin
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------------ region growing
+__device__ __forceinline__ double angle_diff_signed(double a, double b) {
+    const double PI = 3.14159265358979323846, TWO_PI = 2 * 3.14159265358979323846;
+    double diff = a - b;
+    while (diff <= -PI) diff += TWO_PI;
+    while (diff > PI) diff -= TWO_PI;
+    return diff;
+}
+__device__ __forceinline__ bool aligned_to(double a, double theta, double prec) {
+    double n_theta = theta - a;
+    if (n_theta < 0) n_theta = -n_theta;
+    if (n_theta > (3 * 3.14159265358979323846) / 2) {
+        n_theta -= 2 * 3.14159265358979323846;
+        if (n_theta < 0) n_theta = -n_theta;
+    }
+    return n_theta <= prec;
+}
+__device__ __forceinline__ double shfl_d(double v, int src) {
+    const long long bits = __double_as_longlong(v);
+    const unsigned lo = __shfl((unsigned)bits, src), hi = __shfl((unsigned)((unsigned long long)bits >> 32), src);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+struct GrowCtx {
+    const double* ang; const double* mod; const float2* cs;
+    uint32_t* reg; uint32_t* used;   // used: LDS bitmap
+    int sw, sh, lane;
+};
+struct Rect { double x1, y1, x2, y2, width; };
+
+__device__ __forceinline__ bool is_used(const GrowCtx& g, int p) { return (g.used[p >> 5] >> (p & 31)) & 1u; }
+__device__ __forceinline__ void set_used(const GrowCtx& g, int p) { g.used[p >> 5] |= 1u << (p & 31); }   // single-lane callers only
+
+// region_grow (lsd.cpp): breadth-first over g.reg; the 3x3 neighbourhood of a region point is evaluated
+// by 9 lanes at once, acceptances are applied strictly in the reference's scan order (row by row) and
+// every acceptance updates reg_angle before the remaining neighbours are tested.
+// Returns the region size; cen[3] = (sum x*w, sum y*w, sum w) accumulated in region order.
+__device__ int region_grow(const GrowCtx& g, int seed, double prec, double& reg_angle, double cen[3]) {
+    const int lane = g.lane;
+    int nreg = 1;
+    const int sx = seed % g.sw, sy = seed / g.sw;
+    reg_angle = g.ang[seed];
+    float sumdx = (float)cos(reg_angle), sumdy = (float)sin(reg_angle);
+    {
+        const double w = g.mod[seed];
+        cen[0] = (double)sx * w; cen[1] = (double)sy * w; cen[2] = w;
+    }
+    if (lane == 0) { g.reg[0] = (uint32_t)sx | ((uint32_t)sy << 16); set_used(g, seed); }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    for (int i = 0; i < nreg; ++i) {
+        uint32_t c = 0;
+        if (lane == 0) c = __hip_atomic_load(&g.reg[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        c = __shfl(c, 0);
+        const int cx = (int)(c & 0xffff), cy = (int)(c >> 16);
+        // lane k < 9: neighbour (cx + k%3 - 1, cy + k/3 - 1)
+        const int nx = cx + (lane % 3) - 1, ny = cy + (lane / 3) - 1;
+        bool cand = lane < 9 && nx >= 0 && ny >= 0 && nx < g.sw && ny < g.sh;
+        const int np = ny * g.sw + nx;
+        double a = kLsdNotDef, w = 0;
+        float2 ncs = make_float2(0.f, 0.f);
+        if (cand) cand = !is_used(g, np);
+        if (cand) { a = g.ang[np]; cand = a != kLsdNotDef; }
+        if (cand) { w = g.mod[np]; ncs = g.cs[np]; }
+        int last = -1;
+        while (true) {
+            const bool ok = cand && lane > last && aligned_to(a, reg_angle, prec);
+            const unsigned long long bal = __ballot(ok);
+            if (!bal) break;
+            const int k = __ffsll((long long)bal) - 1;
+            const int ax = __shfl(nx, k), ay = __shfl(ny, k);
+            const float ccos = __shfl(ncs.x, k), csin = __shfl(ncs.y, k);
+            const double aw = shfl_d(w, k);
+            if (lane == 0) {
+                __hip_atomic_store(&g.reg[nreg], (uint32_t)ax | ((uint32_t)ay << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                set_used(g, ay * g.sw + ax);
+            }
+            ++nreg;
+            sumdx = __fadd_rn(sumdx, ccos);
+            sumdy = __fadd_rn(sumdy, csin);
+            reg_angle = (double)fast_atan2_deg_l(sumdy, sumdx) * (3.14159265358979323846 / 180);
+            cen[0] += (double)ax * aw; cen[1] += (double)ay * aw; cen[2] += aw;
+            last = k;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+    return nreg;
+}
+
+// region2rect (lsd.cpp): centroid given; inertia + extents.  Sequential f64 sums in region order, fed
+// 64 region points at a time (coalesced gathers, then a shuffle-driven serial chain).
+__device__ void region2rect(const GrowCtx& g, int nreg, double reg_angle, double prec, const double cen[3], Rect& rec) {
+    const int lane = g.lane;
+    const double x = cen[0] / cen[2], y = cen[1] / cen[2];
+    double Ixx = 0.0, Iyy = 0.0, Ixy = 0.0;
+    for (int base = 0; base < nreg; base += 64) {
+        const int j = base + lane;
+        double px = 0, py = 0, w = 0;
+        if (j < nreg) {
+            const uint32_t c = g.reg[j];
+            px = (double)(int)(c & 0xffff); py = (double)(int)(c >> 16);
+            w = g.mod[(int)(c >> 16) * g.sw + (int)(c & 0xffff)];
+        }
+        const int cnt = min(64, nreg - base);
+        for (int t = 0; t < cnt; ++t) {
+            const double dx = shfl_d(px, t) - x, dy = shfl_d(py, t) - y, ww = shfl_d(w, t);
+            Ixx += dy * dy * ww;
+            Iyy += dx * dx * ww;
+            Ixy -= dx * dy * ww;
+        }
+    }
+    const double lambda = 0.5 * (Ixx + Iyy - sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
+    double theta = (fabs(Ixx) > fabs(Iyy)) ? (double)fast_atan2_deg_l((float)(lambda - Ixx), (float)Ixy)
+                                           : (double)fast_atan2_deg_l((float)Ixy, (float)(lambda - Iyy));
+    theta *= (3.14159265358979323846 / 180);
+    if (fabs(angle_diff_signed(theta, reg_angle)) > prec) theta += 3.14159265358979323846;
+    const double dx = cos(theta), dy = sin(theta);
+    // extents: min / max are order independent -> lane-parallel
+    double l_min = 0, l_max = 0, w_min = 0, w_max = 0;
+    for (int j = lane; j < nreg; j += 64) {
+        const uint32_t c = g.reg[j];
+        const double rdx = (double)(int)(c & 0xffff) - x, rdy = (double)(int)(c >> 16) - y;
+        const double l = rdx * dx + rdy * dy, w = -rdx * dy + rdy * dx;
+        l_max = fmax(l_max, l); l_min = fmin(l_min, l);
+        w_max = fmax(w_max, w); w_min = fmin(w_min, w);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        l_max = fmax(l_max, shfl_d(l_max, lane ^ o)); l_min = fmin(l_min, shfl_d(l_min, lane ^ o));
+        w_max = fmax(w_max, shfl_d(w_max, lane ^ o)); w_min = fmin(w_min, shfl_d(w_min, lane ^ o));
+    }
+    rec.x1 = x + l_min * dx; rec.y1 = y + l_min * dy;
+    rec.x2 = x + l_max * dx; rec.y2 = y + l_max * dy;
+    rec.width = w_max - w_min;
+    if (rec.width < 1.0) rec.width = 1.0;
+}
+
+__device__ __forceinline__ double rect_density(int nreg, const Rect& r) {
+    const double d = sqrt((r.x2 - r.x1) * (r.x2 - r.x1) + (r.y2 - r.y1) * (r.y2 - r.y1));
+    return (double)nreg / (d * r.width);
+}
+
+// centroid sums in region order (needed after reduce_region_radius reorders the list)
+__device__ void centroid_sums(const GrowCtx& g, int nreg, double cen[3]) {
+    cen[0] = cen[1] = cen[2] = 0;
+    for (int base = 0; base < nreg; base += 64) {
+        const int j = base + g.lane;
+        double px = 0, py = 0, w = 0;
+        if (j < nreg) {
+            const uint32_t c = g.reg[j];
+            px = (double)(int)(c & 0xffff); py = (double)(int)(c >> 16);
+            w = g.mod[(int)(c >> 16) * g.sw + (int)(c & 0xffff)];
+        }
+        const int cnt = min(64, nreg - base);
+        for (int t = 0; t < cnt; ++t) {
+            const double ww = shfl_d(w, t);
+            cen[0] += shfl_d(px, t) * ww; cen[1] += shfl_d(py, t) * ww; cen[2] += ww;
+        }
+    }
+}
+
+// grid = (ceil(B / 4)), block = 256: wave w of a block handles frame 4*blockIdx.x + w.
+// dynamic LDS: 4 x used bitmap.
+__global__ __launch_bounds__(256) void k_lsd_grow(LinePlanes P, LsdParams lp, int B) {
+    extern __shared__ uint32_t s_bits[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + wv;
+    if (b >= B) return;
+    const int n = P.sw * P.sh, nwords = (n + 31) / 32, nv = (P.sw - 1) * (P.sh - 1);
+    GrowCtx g;
+    g.ang = P.ang + (size_t)b * n; g.mod = P.mod + (size_t)b * n; g.cs = P.cs + (size_t)b * n;
+    g.reg = P.reg + (size_t)b * n; g.used = s_bits + (size_t)wv * nwords; g.sw = P.sw; g.sh = P.sh; g.lane = lane;
+    // USED map starts as the NOTDEF mask: an undefined pixel is never a seed and never aligned, so
+    // treating it as used is equivalent and spares a global load per rejected seed
+    {
+        const uint32_t* u32 = reinterpret_cast<const uint32_t*>(P.undef + (size_t)b * ((n + 63) / 64));
+        for (int i = lane; i < nwords; i += 64) g.used[i] = u32[i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t* order = P.order + (size_t)b * nv;
+    float4* raw = P.raw + (size_t)b * kLineCap;
+    int n_lines = 0;
+    for (int base = 0; base < nv; base += 64) {
+        const uint32_t mine = base + lane < nv ? order[base + lane] : 0u;
+        const int cnt = min(64, nv - base);
+        for (int t = 0; t < cnt; ++t) {
+            const int seed = (int)__shfl(mine, t);
+            if (is_used(g, seed)) continue;
+            double reg_angle, cen[3];
+            int nreg = region_grow(g, seed, lp.prec, reg_angle, cen);
+            if (nreg < lp.min_reg_size) continue;
+            Rect rec;
+            region2rect(g, nreg, reg_angle, lp.prec, cen, rec);
+            bool keep = true;
+            if (lp.refine > 0) {
+                double density = rect_density(nreg, rec);
+                if (density < lp.density_th) {
+                    // ---- refine: tighter angle tolerance from the points near the seed
+                    const uint32_t c0 = g.reg[0];
+                    const double xc = (double)(int)(c0 & 0xffff), yc = (double)(int)(c0 >> 16);
+                    const double ang_c = g.ang[(int)(c0 >> 16) * g.sw + (int)(c0 & 0xffff)];
+                    double sum = 0, s_sum = 0;
+                    int nn = 0;
+                    for (int rb = 0; rb < nreg; rb += 64) {
+                        const int j = rb + lane;
+                        double a = 0;
+                        bool near = false;
+                        if (j < nreg) {
+                            const uint32_t c = g.reg[j];
+                            const int px = (int)(c & 0xffff), py = (int)(c >> 16);
+                            atomicAnd(&g.used[(py * g.sw + px) >> 5], ~(1u << ((py * g.sw + px) & 31)));   // *(reg[i].used) = NOTUSED
+                            const double ddx = (double)px - xc, ddy = (double)py - yc;
+                            near = sqrt(ddx * ddx + ddy * ddy) < rec.width;
+                            a = g.ang[py * g.sw + px];
+                        }
+                        const int c64 = min(64, nreg - rb);
+                        const unsigned long long nb = __ballot(near);
+                        for (int u = 0; u < c64; ++u) {
+                            if (!((nb >> u) & 1ull)) continue;
+                            const double ang_d = angle_diff_signed(shfl_d(a, u), ang_c);
+                            sum += ang_d; s_sum += ang_d * ang_d; ++nn;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    const double mean_angle = sum / (double)nn;
+                    const double tau = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / (double)nn + mean_angle * mean_angle);
+                    nreg = region_grow(g, (int)(c0 >> 16) * g.sw + (int)(c0 & 0xffff), tau, reg_angle, cen);
+                    if (nreg < 2) keep = false;
+                    else {
+                        region2rect(g, nreg, reg_angle, lp.prec, cen, rec);
+                        density = rect_density(nreg, rec);
+                        if (density < lp.density_th) {
+                            // ---- reduce_region_radius: shrink around the seed until dense enough
+                            const double r1 = (rec.x1 - xc) * (rec.x1 - xc) + (rec.y1 - yc) * (rec.y1 - yc);
+                            const double r2 = (rec.x2 - xc) * (rec.x2 - xc) + (rec.y2 - yc) * (rec.y2 - yc);
+                            double radSq = r1 > r2 ? r1 : r2;
+                            while (density < lp.density_th) {
+                                radSq *= 0.75 * 0.75;
+                                if (lane == 0) {   // swap-with-last removal is order dependent: one lane, region order
+                                    int m = nreg;
+                                    for (int i = 0; i < m; ++i) {
+                                        const uint32_t c = __hip_atomic_load(&g.reg[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                                        const int px = (int)(c & 0xffff), py = (int)(c >> 16);
+                                        const double ddx = (double)px - xc, ddy = (double)py - yc;
+                                        if (ddx * ddx + ddy * ddy > radSq) {
+                                            g.used[(py * g.sw + px) >> 5] &= ~(1u << ((py * g.sw + px) & 31));
+                                            const uint32_t lastv = __hip_atomic_load(&g.reg[m - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                                            __hip_atomic_store(&g.reg[i], lastv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                                            --m; --i;
+                                        }
+                                    }
+                                    nreg = m;
+                                }
+                                nreg = __shfl(nreg, 0);
+                                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                                __builtin_amdgcn_wave_barrier();
+                                if (nreg < 2) { keep = false; break; }
+                                centroid_sums(g, nreg, cen);
+                                region2rect(g, nreg, reg_angle, lp.prec, cen, rec);
+                                density = rect_density(nreg, rec);
+                            }
+                        }
+                    }
+                }
+            }
+            if (!keep) continue;
+            // +0.5 offset, undo the sub-sampling, cast to f32 (lsd.cpp flsd)
+            rec.x1 += 0.5; rec.y1 += 0.5; rec.x2 += 0.5; rec.y2 += 0.5;
+            if (lp.scale != 1) { rec.x1 /= lp.scale; rec.y1 /= lp.scale; rec.x2 /= lp.scale; rec.y2 /= lp.scale; }
+            if (n_lines < kLineCap) { if (lane == 0) raw[n_lines] = make_float4((float)rec.x1, (float)rec.y1, (float)rec.x2, (float)rec.y2); }
+            else if (lane == 0) atomicOr(P.status, 4);
+            ++n_lines;
+        }
+    }
+    if (lane == 0) P.n_raw[b] = min(n_lines, kLineCap);
+}
+
+// ------------------------------------------------------------------------------------------ KeyLine assembly
+// LSDDetector_custom.cpp:262-303 (octave 0).  One wave per frame; class_id = running index of kept lines.
+__global__ __launch_bounds__(64) void k_keylines(LinePlanes P, LsdParams lp) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int n = P.n_raw[b];
+    const float4* raw = P.raw + (size_t)b * kLineCap;
+    plp_keyline* out = P.all_kl + (size_t)b * kLineCap;
+    int run = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        bool keep = false;
+        plp_keyline kl{};
+        if (i < n) {
+            float4 e = raw[i];
+            const float fw = (float)P.W, fh = (float)P.H;
+            if (e.x < 0) e.x = 0;
+            if (e.x >= fw) e.x = fw - 1.0f;
+            if (e.z < 0) e.z = 0;
+            if (e.z >= fw) e.z = fw - 1.0f;
+            if (e.y < 0) e.y = 0;
+            if (e.y >= fh) e.y = fh - 1.0f;
+            if (e.w < 0) e.w = 0;
+            if (e.w >= fh) e.w = fh - 1.0f;
+            const double ddx = (double)__fsub_rn(e.x, e.z), ddy = (double)__fsub_rn(e.y, e.w);
+            const double length = (double)(float)sqrt(ddx * ddx + ddy * ddy);
+            keep = length > (double)lp.min_length;
+            kl.startPointX = e.x; kl.startPointY = e.y; kl.endPointX = e.z; kl.endPointY = e.w;
+            kl.sPointInOctaveX = e.x; kl.sPointInOctaveY = e.y; kl.ePointInOctaveX = e.z; kl.ePointInOctaveY = e.w;
+            kl.lineLength = (float)length;
+            const int x1 = __float2int_rn(e.x), y1 = __float2int_rn(e.y), x2 = __float2int_rn(e.z), y2 = __float2int_rn(e.w);
+            kl.numOfPixels = max(abs(x2 - x1), abs(y2 - y1)) + 1;
+            kl.angle = (float)atan2((double)__fsub_rn(e.w, e.y), (double)__fsub_rn(e.z, e.x));
+            kl.octave = 0;
+            kl.size = __fmul_rn(__fsub_rn(e.z, e.x), __fsub_rn(e.w, e.y));
+            kl.response = __fdiv_rn(kl.lineLength, (float)max(P.W, P.H));
+            kl.pt_x = __fdiv_rn(__fadd_rn(e.z, e.x), 2.0f);
+            kl.pt_y = __fdiv_rn(__fadd_rn(e.w, e.y), 2.0f);
+        }
+        const unsigned long long bal = __ballot(keep);
+        if (keep) {
+            kl.class_id = run + __popcll(bal & ((1ull << lane) - 1ull));
+            out[kl.class_id] = kl;
+        }
+        run += __popcll(bal);
+    }
+    if (lane == 0) P.n_all[b] = run;
+}
+
+// ------------------------------------------------------------------------------------------ Sobel
+__global__ __launch_bounds__(256) void k_sobel3(const uint8_t* __restrict__ src, size_t src_fs, int pitch, int16_t* __restrict__ dx,
+                                                int16_t* __restrict__ dy, int w, int h) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
+    if (x >= w || y >= h) return;
+    const uint8_t* s = src + (size_t)b * src_fs;
+    const uint8_t* r0 = s + (size_t)reflect101_l(y - 1, h) * pitch;
+    const uint8_t* r1 = s + (size_t)y * pitch;
+    const uint8_t* r2 = s + (size_t)reflect101_l(y + 1, h) * pitch;
+    const int xm = reflect101_l(x - 1, w), xp = reflect101_l(x + 1, w);
+    const size_t o = ((size_t)b * h + y) * w + x;
+    dx[o] = (int16_t)((r0[xp] - r0[xm]) + 2 * (r1[xp] - r1[xm]) + (r2[xp] - r2[xm]));
+    dy[o] = (int16_t)((r2[xm] - r0[xm]) + 2 * (r2[x] - r0[x]) + (r2[xp] - r0[xp]));
+}
+
+// ------------------------------------------------------------------------------------------ LBD
+__constant__ int c_comb[32][2] = {{0, 1}, {0, 2}, {0, 3}, {0, 4}, {0, 5}, {0, 6}, {1, 2}, {1, 3}, {1, 4}, {1, 5}, {1, 6},
+                                  {2, 3}, {2, 4}, {2, 5}, {2, 6}, {2, 7}, {2, 8}, {3, 4}, {3, 5}, {3, 6}, {3, 7}, {3, 8},
+                                  {4, 5}, {4, 6}, {4, 7}, {4, 8}, {5, 6}, {5, 7}, {5, 8}, {6, 7}, {6, 8}, {7, 8}};
+
+// grid = (kLineCap / 4, B), block = 256: one wave per line.
+__global__ __launch_bounds__(256) void k_lbd(LinePlanes P, LbdWeightsDev W) {
+    __shared__ float s_row[4][63][8];   // per row: pgdL, ngdL, pgdL2, ngdL2, pgdO, ngdO, pgdO2, ngdO2 (after the global weight)
+    __shared__ float s_des[4][72];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, b = blockIdx.y;
+    const int li = blockIdx.x * 4 + wv;
+    if (li >= P.n_all[b]) return;
+    const plp_keyline kl = P.all_kl[(size_t)b * kLineCap + li];
+    const int16_t* dxImg = P.dx + (size_t)b * P.W * P.H;
+    const int16_t* dyImg = P.dy + (size_t)b * P.W * P.H;
+    const int realWidth = P.W;
+    const short imageWidth = (short)(P.W - 1), imageHeight = (short)(P.H - 1);
+    const short lengthOfLSP = (short)kl.numOfPixels;
+    const short halfWidth = (short)((lengthOfLSP - 1) / 2), halfHeight = 31;
+    const float midX = (float)(0.5 * (double)__fadd_rn(kl.sPointInOctaveX, kl.ePointInOctaveX));
+    const float midY = (float)(0.5 * (double)__fadd_rn(kl.sPointInOctaveY, kl.ePointInOctaveY));
+    const float dL0 = (float)cos((double)kl.angle), dL1 = (float)sin((double)kl.angle);
+    const float dO0 = -dL1, dO1 = dL0;
+    if (lane < 63) {
+        // start corner of row hID = lane: the reference steps it row by row (sCorX0 -= dL1; sCorY0 += dL0)
+        float sCorX0 = __fadd_rn(__fadd_rn(__fmul_rn(-dL0, (float)halfWidth), __fmul_rn(dL1, (float)halfHeight)), midX);
+        float sCorY0 = __fadd_rn(__fsub_rn(__fmul_rn(-dL1, (float)halfWidth), __fmul_rn(dL0, (float)halfHeight)), midY);
+        for (int r = 0; r < lane; ++r) { sCorX0 = __fsub_rn(sCorX0, dL1); sCorY0 = __fadd_rn(sCorY0, dL0); }
+        float sCorX = sCorX0, sCorY = sCorY0;
+        float pgdL = 0, ngdL = 0, pgdO = 0, ngdO = 0;
+        for (short wID = 0; wID < lengthOfLSP; ++wID) {
+            short t = (short)roundf(sCorX);
+            const short xCor = (t < 0) ? 0 : (t > imageWidth) ? imageWidth : t;
+            t = (short)roundf(sCorY);
+            const short yCor = (t < 0) ? 0 : (t > imageHeight) ? imageHeight : t;
+            const float fx = (float)dxImg[yCor * realWidth + xCor], fy = (float)dyImg[yCor * realWidth + xCor];
+            const float gDL = __fadd_rn(__fmul_rn(fx, dL0), __fmul_rn(fy, dL1));
+            const float gDO = __fadd_rn(__fmul_rn(fx, dO0), __fmul_rn(fy, dO1));
+            if (gDL > 0) pgdL = __fadd_rn(pgdL, gDL); else ngdL = __fsub_rn(ngdL, gDL);
+            if (gDO > 0) pgdO = __fadd_rn(pgdO, gDO); else ngdO = __fsub_rn(ngdO, gDO);
+            sCorX = __fadd_rn(sCorX, dL0);
+            sCorY = __fadd_rn(sCorY, dL1);
+        }
+        const float cg = W.g[lane];
+        pgdL = __fmul_rn(cg, pgdL); ngdL = __fmul_rn(cg, ngdL); pgdO = __fmul_rn(cg, pgdO); ngdO = __fmul_rn(cg, ngdO);
+        float* r = s_row[wv][lane];
+        r[0] = pgdL; r[1] = ngdL; r[2] = __fmul_rn(pgdL, pgdL); r[3] = __fmul_rn(ngdL, ngdL);
+        r[4] = pgdO; r[5] = ngdO; r[6] = __fmul_rn(pgdO, pgdO); r[7] = __fmul_rn(ngdO, ngdO);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    // band sums: lane = (band, component); contributions arrive in row order hID (neighbour-below band first,
+    // own rows, then neighbour-above band), exactly the order of the reference's accumulation
+    for (int item = lane; item < 72; item += 64) {
+        const int band = item >> 3, comp = item & 7;
+        const bool sq = (comp == 2 || comp == 3 || comp == 6 || comp == 7);
+        float acc = 0;
+        for (int hID = max(0, (band - 1) * 7); hID < min(63, (band + 2) * 7); ++hID) {
+            const int rb = hID / 7;
+            const float c = rb == band ? W.l[hID % 7 + 7] : (rb == band + 1 ? W.l[hID % 7 + 14] : W.l[hID % 7]);
+            const float v = s_row[wv][hID][comp];
+            acc = sq ? __fadd_rn(acc, __fmul_rn(__fmul_rn(c, c), v)) : __fadd_rn(acc, __fmul_rn(c, v));
+        }
+        // mean / std per band (components reordered to the descriptor layout below)
+        s_des[wv][item] = acc;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        float des[72];
+        const float invN2 = (float)(1.0 / (7 * 2.0)), invN3 = (float)(1.0 / (7 * 3.0));
+        for (int band = 0; band < 9; ++band) {
+            const float invN = (band == 0 || band == 8) ? invN2 : invN3;
+            const float* s = &s_des[wv][band * 8];   // pgdL, ngdL, pgdL2, ngdL2, pgdO, ngdO, pgdO2, ngdO2
+            const int d = band * 8;
+            float temp = __fmul_rn(s[0], invN);
+            des[d] = temp; des[d + 4] = sqrtf(__fsub_rn(__fmul_rn(s[2], invN), __fmul_rn(temp, temp)));
+            temp = __fmul_rn(s[1], invN);
+            des[d + 1] = temp; des[d + 5] = sqrtf(__fsub_rn(__fmul_rn(s[3], invN), __fmul_rn(temp, temp)));
+            temp = __fmul_rn(s[4], invN);
+            des[d + 2] = temp; des[d + 6] = sqrtf(__fsub_rn(__fmul_rn(s[6], invN), __fmul_rn(temp, temp)));
+            temp = __fmul_rn(s[5], invN);
+            des[d + 3] = temp; des[d + 7] = sqrtf(__fsub_rn(__fmul_rn(s[7], invN), __fmul_rn(temp, temp)));
+        }
+        float tempM = 0, tempS = 0;
+        for (int band = 0; band < 9; ++band) {
+            const float* v = des + 8 * band;
+            for (int k = 0; k < 4; ++k) tempM = __fadd_rn(tempM, __fmul_rn(v[k], v[k]));
+            for (int k = 4; k < 8; ++k) tempS = __fadd_rn(tempS, __fmul_rn(v[k], v[k]));
+        }
+        tempM = __fdiv_rn(1.0f, sqrtf(tempM));
+        tempS = __fdiv_rn(1.0f, sqrtf(tempS));
+        for (int band = 0; band < 9; ++band) {
+            float* v = des + 8 * band;
+            for (int k = 0; k < 4; ++k) v[k] = __fmul_rn(v[k], tempM);
+            for (int k = 4; k < 8; ++k) v[k] = __fmul_rn(v[k], tempS);
+        }
+        for (int i = 0; i < 72; ++i)
+            if ((double)des[i] > 0.4) des[i] = (float)0.4;
+        float temp = 0;
+        for (int i = 0; i < 72; ++i) temp = __fadd_rn(temp, __fmul_rn(des[i], des[i]));
+        temp = __fdiv_rn(1.0f, sqrtf(temp));
+        for (int i = 0; i < 72; ++i) des[i] = __fmul_rn(des[i], temp);
+        uint8_t* out = P.all_lbd + ((size_t)b * kLineCap + li) * 32;
+        for (int c = 0; c < 32; ++c) {
+            const float* f1 = des + 8 * c_comb[c][0];
+            const float* f2 = des + 8 * c_comb[c][1];
+            unsigned r = 0;
+            for (int i = 0; i < 8; ++i) r += (f1[i] > f2[i]) ? (1u << i) : 0u;
+            out[c] = (uint8_t)r;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ finalize
+// line_extractor.cc:134-159: keep octave 0 && lineLength >= 60, 2-D line function (f64).  One wave per frame.
+__global__ __launch_bounds__(64) void k_line_finalize(LinePlanes P, LsdParams lp, plp_keyline* __restrict__ out_kl,
+                                                      uint8_t* __restrict__ out_lbd, double* __restrict__ out_fn, int cap,
+                                                      int32_t* __restrict__ out_counts) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int n = P.n_all[b];
+    int run = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        plp_keyline kl{};
+        bool keep = false;
+        if (i < n) { kl = P.all_kl[(size_t)b * kLineCap + i]; keep = kl.octave == 0 && kl.lineLength >= lp.keep_length; }
+        const unsigned long long bal = __ballot(keep);
+        const int o = run + __popcll(bal & ((1ull << lane) - 1ull));
+        if (keep && o < cap) {
+            out_kl[(size_t)b * cap + o] = kl;
+            const uint4* s = reinterpret_cast<const uint4*>(P.all_lbd + ((size_t)b * kLineCap + i) * 32);
+            uint4* d = reinterpret_cast<uint4*>(out_lbd + ((size_t)b * cap + o) * 32);
+            d[0] = s[0]; d[1] = s[1];
+            const double sx = kl.startPointX, sy = kl.startPointY, ex = kl.endPointX, ey = kl.endPointY;
+            const double a = sy * 1.0 - 1.0 * ey, bb = 1.0 * ex - sx * 1.0, c = sx * ey - sy * ex;
+            const double nrm = sqrt(a * a + bb * bb);
+            double* f = out_fn + ((size_t)b * cap + o) * 3;
+            f[0] = a / nrm; f[1] = bb / nrm; f[2] = c / nrm;
+        }
+        run += __popcll(bal);
+    }
+    if (lane == 0) {
+        out_counts[b] = min(run, cap);
+        if (run > cap) atomicOr(P.status, 1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ launch sequence
+void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp, const ResizeExactTab& rt, const BlurTapsN& t11,
+                       const BlurTapsN& t5, const LbdWeightsDev& w, plp_keyline* out_kl, uint8_t* out_lbd, double* out_fn, int cap,
+                       int32_t* out_counts, int B) {
+    const size_t plane_fs = (size_t)P.pitch * P.H, splane_fs = (size_t)P.spitch * P.sh;
+    const int tiles = ((P.W + 63) / 64) * ((P.H + 31) / 32);
+    (void)hipMemsetAsync(P.maxgrad, 0, sizeof(unsigned long long) * B, st);
+    hipLaunchKernelGGL(k_blur_plane<5>, dim3(tiles, B), dim3(256), 0, st, P.img, P.img_frame_stride, P.img_pitch, P.blur11, plane_fs,
+                       P.pitch, P.W, P.H, t11);
+    hipLaunchKernelGGL(k_resize_exact, dim3((P.sw + 255) / 256, (P.sh + 3) / 4, B), dim3(64, 4), 0, st, P.blur11, plane_fs, P.pitch,
+                       P.scaled, splane_fs, P.spitch, P.sw, P.sh, rt);
+    const int n = P.sw * P.sh;
+    hipLaunchKernelGGL(k_lsd_gradient, dim3((n + 255) / 256, B), dim3(256), 0, st, P, lp);
+    hipLaunchKernelGGL(k_lsd_bins, dim3((n + 255) / 256, B), dim3(256), 0, st, P, lp);
+    hipLaunchKernelGGL(k_lsd_order, dim3(B), dim3(256), 0, st, P);
+    const size_t lds = (size_t)4 * ((n + 31) / 32) * 4;
+    hipLaunchKernelGGL(k_lsd_grow, dim3((B + 3) / 4), dim3(256), lds, st, P, lp, B);
+    hipLaunchKernelGGL(k_keylines, dim3(B), dim3(64), 0, st, P, lp);
+    hipLaunchKernelGGL(k_blur_plane<2>, dim3(tiles, B), dim3(256), 0, st, P.img, P.img_frame_stride, P.img_pitch, P.blur5, plane_fs,
+                       P.pitch, P.W, P.H, t5);
+    hipLaunchKernelGGL(k_sobel3, dim3((P.W + 63) / 64, (P.H + 3) / 4, B), dim3(256), 0, st, P.blur5, plane_fs, P.pitch, P.dx, P.dy, P.W, P.H);
+    hipLaunchKernelGGL(k_lbd, dim3(kLineCap / 4, B), dim3(256), 0, st, P, w);
+    hipLaunchKernelGGL(k_line_finalize, dim3(B), dim3(64), 0, st, P, lp, out_kl, out_lbd, out_fn, cap, out_counts);
+}
+
+}  // namespace plp

@@ -75,6 +75,18 @@ def lib():
         L.oracle_match_current_and_last.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 7 + [C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p]
         L.oracle_brute_force_match.restype = C.c_uint
         L.oracle_brute_force_match.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p]
+        L.oracle_line_extract.restype = C.c_void_p
+        L.oracle_line_extract.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_long, C.c_int]
+        L.oracle_line_free.argtypes = [C.c_void_p]
+        L.oracle_line_count.argtypes = [C.c_void_p, C.c_int]
+        L.oracle_line_get.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 4
+        L.oracle_line_raw.argtypes = [C.c_void_p, C.c_void_p]
+        L.oracle_line_scaled_size.argtypes = [C.c_void_p] * 3
+        L.oracle_line_scaled.argtypes = [C.c_void_p] * 2
+        L.oracle_line_order.argtypes = [C.c_void_p] * 2
+        L.oracle_line_sobel.argtypes = [C.c_void_p] * 3
+        L.oracle_resize_linear_exact_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p]
+        L.oracle_lbd.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -246,3 +258,47 @@ def brute_force_match(desc1, angle1, desc2, angle2, valid2, lowe_ratio, check_or
     w = [_c(desc2, np.uint8), _c(angle2, np.float32), _c(valid2, np.uint8)]
     num = lib().oracle_brute_force_match(_p(v[0]), _p(v[1]), n1, _p(w[0]), _p(w[1]), _p(w[2]), n2, lowe_ratio, int(check_orientation), _p(out))
     return out[:n1].copy(), num
+
+
+# ---- line front-end (oracle/line_oracle.cpp)
+KL_DTYPE = np.dtype([("angle", "<f4"), ("class_id", "<i4"), ("octave", "<i4"), ("pt_x", "<f4"), ("pt_y", "<f4"), ("response", "<f4"),
+                     ("size", "<f4"), ("startPointX", "<f4"), ("startPointY", "<f4"), ("endPointX", "<f4"), ("endPointY", "<f4"),
+                     ("sPointInOctaveX", "<f4"), ("sPointInOctaveY", "<f4"), ("ePointInOctaveX", "<f4"), ("ePointInOctaveY", "<f4"),
+                     ("lineLength", "<f4"), ("numOfPixels", "<i4")])
+
+
+class LineOracle:
+    """one extract_LSD_LBD run of the oracle with its stage outputs"""
+
+    def __init__(self, img, stable_order=True):
+        img = np.ascontiguousarray(img, np.uint8)
+        self.shape = img.shape
+        L = lib()
+        h = L.oracle_line_extract(_p(img), img.shape[0], img.shape[1], img.strides[0], int(stable_order))
+        try:
+            n = L.oracle_line_count(h, 0); na = L.oracle_line_count(h, 1); nr = L.oracle_line_count(h, 2)
+            self.keylsd = np.zeros(n, KL_DTYPE); self.lbd = np.zeros((n, 32), np.uint8); self.linefn = np.zeros((n, 3), np.float64)
+            L.oracle_line_get(h, 0, _p(self.keylsd), _p(self.lbd), _p(self.linefn), None)
+            self.all_kl = np.zeros(na, KL_DTYPE); self.all_lbd = np.zeros((na, 32), np.uint8); self.all_desc_f = np.zeros((na, 72), np.float32)
+            L.oracle_line_get(h, 1, _p(self.all_kl), _p(self.all_lbd), None, _p(self.all_desc_f))
+            self.raw = np.zeros((nr, 4), np.float32)
+            L.oracle_line_raw(h, _p(self.raw))
+            r, c = C.c_int(), C.c_int()
+            L.oracle_line_scaled_size(h, C.byref(r), C.byref(c))
+            self.scaled = np.zeros((r.value, c.value), np.uint8)
+            L.oracle_line_scaled(h, _p(self.scaled))
+            self.order = np.zeros((r.value - 1) * (c.value - 1), np.int32)
+            L.oracle_line_order(h, _p(self.order))
+            self.dx = np.zeros(img.shape, np.int16); self.dy = np.zeros(img.shape, np.int16)
+            if na:
+                L.oracle_line_sobel(h, _p(self.dx), _p(self.dy))
+        finally:
+            L.oracle_line_free(h)
+
+
+def resize_linear_exact_u8(src, fx, fy):
+    src = np.ascontiguousarray(src, np.uint8)
+    dh, dw = int(np.rint(src.shape[0] * fy)), int(np.rint(src.shape[1] * fx))
+    dst = np.zeros((dh, dw), np.uint8)
+    lib().oracle_resize_linear_exact_u8(_p(src), src.shape[0], src.shape[1], fx, fy, _p(dst))
+    return dst

@@ -1,0 +1,78 @@
+"""GPU parity of the line front-end (LSD + LBD through the C ABI) against the oracle restatement, stage by stage."""
+import numpy as np
+import pytest
+from PIL import Image
+
+import oracle_lib as O
+from plp import plp, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def compare(img):
+    ora = O.LineOracle(img)
+    lt = plp.LineFeatureTracker()
+    kl, lbd, fn = lt.extract_LSD_LBD(img)
+    assert np.array_equal(lt.debug_read(lt.DBG_SCALED), ora.scaled), "11-tap blur + x0.5 INTER_LINEAR_EXACT"
+    assert np.array_equal(lt.debug_read(lt.DBG_ORDER), ora.order), "seed order"
+    raw = lt.debug_read(lt.DBG_RAW)
+    assert raw.shape == ora.raw.shape, (raw.shape, ora.raw.shape)
+    assert np.abs(raw - ora.raw).max(initial=0) <= 1e-4, "LSD segment end points"
+    assert np.array_equal(raw, ora.raw), "LSD segments (identical in practice)"
+    akl = lt.debug_read(lt.DBG_ALL_KL)
+    assert np.array_equal(akl, ora.all_kl), "KeyLine records"
+    if len(ora.all_kl):
+        n = img.shape[0] * img.shape[1]
+        assert np.array_equal(lt.debug_read(lt.DBG_SOBEL_DX)[:n].reshape(img.shape), ora.dx), "Sobel dx"
+        assert np.array_equal(lt.debug_read(lt.DBG_SOBEL_DY)[:n].reshape(img.shape), ora.dy), "Sobel dy"
+    albd = lt.debug_read(lt.DBG_ALL_LBD)
+    ham = np.unpackbits(albd ^ ora.all_lbd, axis=1).sum(1) if len(albd) else np.zeros(0)
+    assert ham.sum() == 0, f"LBD bits differ: hamming distances {ham[ham > 0]}"
+    assert np.array_equal(kl, ora.keylsd) and np.array_equal(lbd, ora.lbd)
+    assert np.array_equal(fn, ora.linefn)
+    return kl
+
+
+def test_line_front_matches_oracle_on_fixture_frames(golden_dir):
+    total = 0
+    for name in ("equirect1_640x480.png", "equirect2_640x480.png", "equirect1_crop_640x480.png", "equirect2_crop_640x480.png"):
+        total += len(compare(np.asarray(Image.open(golden_dir / name))))
+    total += len(compare(synth.canvas(1234, 480, 640)))
+    assert total > 50
+
+
+@pytest.mark.parametrize("shape", [(480, 752), (376, 1241), (240, 320), (333, 517)])
+def test_other_geometries(shape):
+    compare(synth.canvas(3 + shape[0], shape[0], shape[1]))
+
+
+def test_degenerate_images():
+    compare(np.full((480, 640), 90, np.uint8))      # no gradient at all: no line, no descriptor
+    img = np.zeros((480, 640), np.uint8); img[:, 320:] = 200
+    compare(img)                                    # one long vertical edge
+    rng = np.random.default_rng(0)
+    compare(rng.integers(0, 256, (240, 320), dtype=np.uint8))   # noise: many tiny regions, refine paths
+
+
+def test_batched_device_path():
+    import torch
+    frames = synth.replay(31, 5)
+    dev = torch.device("cuda:0")
+    d = torch.from_numpy(frames).to(dev)
+    B, cap = len(frames), 512
+    d_kl = torch.zeros((B, cap, 68), dtype=torch.uint8, device=dev)
+    d_lbd = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_fn = torch.zeros((B, cap, 3), dtype=torch.float64, device=dev)
+    d_cnt = torch.zeros(B, dtype=torch.int32, device=dev)
+    lt = plp.LineFeatureTracker()
+    lt.extract_batch(d, d_kl, d_lbd, d_fn, d_cnt)
+    torch.cuda.synchronize()
+    lt.last_batch_status()
+    cnt = d_cnt.cpu().numpy()
+    kl = d_kl.cpu().numpy().view(plp.KL_DTYPE).reshape(B, cap)
+    for f in range(B):
+        ora = O.LineOracle(frames[f])
+        assert cnt[f] == len(ora.keylsd)
+        assert np.array_equal(kl[f, :cnt[f]], ora.keylsd)
+        assert np.array_equal(d_lbd[f, :cnt[f]].cpu().numpy(), ora.lbd)
+        assert np.array_equal(d_fn[f, :cnt[f]].cpu().numpy(), ora.linefn)
