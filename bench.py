@@ -4,12 +4,16 @@
     python bench.py --gpus N --steps K --warmup W          (N=1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one pass of the hot path over one batch of `--batch` frames that are already resident
-in HBM.  Frames shard across ranks with no data-path collective (weak scaling: every rank owns its
-own batch); the timed region is bracketed by a barrier + synchronize and the max over ranks is used.
-Rank 0 prints ONE JSON line.  The `roofline` object is the dominant kernel's algorithmic bytes per
-launch divided by its HIP-event duration (measured live on the launch stream), `cpu_baseline` is the
-oracle restatement timed on this box's host cores on a bounded sample of the same frames.
+One "step" = one pass of the hot path over one batch of `--batch` frames that are already resident in HBM:
+  ORB extract (8-level pyramid, FAST cells, quadtree, orientation, blur, rBRIEF)   stream A
+  LSD + LBD line extract                                                           stream B (concurrent, as the
+                                                                                   reference runs two threads per frame)
+  match_current_and_last_frames  (frame b against frame b-1, margin 20, orientation check)     stream A
+  match_frame_and_landmarks      (frame b against the key points of frames b-1 and b-2 as ~2K local landmarks, margin 10)
+Frames shard across ranks in contiguous blocks with no data-path collective (weak scaling: every rank owns its
+own batch); the timed region is bracketed by a barrier + synchronize and the max over ranks is used.  Rank 0
+prints ONE JSON line.  `roofline` = the dominant kernel's algorithmic bytes per launch / its HIP-event duration
+measured on its launch stream; `cpu_baseline` = the oracle restatement of the same work on this box's host cores.
 """
 import argparse
 import importlib
@@ -28,6 +32,7 @@ import numpy as np
 import torch
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+SHIFT_X = -3.0          # the replay window slides +3 px per frame, so scene points move -3 px
 
 
 def level_pixels(rows, cols, sf, n_levels):
@@ -39,29 +44,38 @@ def level_pixels(rows, cols, sf, n_levels):
     return out
 
 
-def algorithmic_bytes(rows, cols, n_levels, mean_kp, mean_cand):
-    """SURVEY.md §8(d) per-frame figures, split per kernel (bytes the algorithm inherently moves)."""
+def algorithmic_bytes(rows, cols, n_levels, mean_kp, mean_cand, mean_lines, mean_len, mean_raw):
+    """SURVEY.md §8(d) per-frame figures, split per stage (bytes the algorithm inherently moves once)."""
     px = level_pixels(rows, cols, 1.2, n_levels)
-    P = sum(px)
+    P, P0 = sum(px), rows * cols
     return {
         "pyramid": (P - px[-1]) + (P - px[0]),          # read every source level once, write every resized level
         "fast_cells": P + 4 * mean_cand,                 # read each level once, write packed candidates
         "blur7": 2 * P,                                  # read + write every level
         "quadtree": 3 * 4 * mean_cand + 4 * mean_kp,     # candidates in, keys/indices once, selection out
         "orient_rbrief": mean_kp * (749 + 512 + 28 + 32),
+        "lsd_blur11_resize": 2 * P0 + 1.25 * P0,         # 11x11 blur r/w + half-res resize
+        "lsd_gradient_bins": 0.25 * P0 * (1 + 8 + 8),    # read u8, write angle + magnitude
+        "lsd_order": 0.25 * P0 * (2 + 4),                # bins in, seed order out
+        "lsd_grow": 0.25 * P0 * (8 + 1) + 16 * mean_raw, # each pixel's angle once + used flag, segments out
+        "keylines": mean_raw * (16 + 68),
+        "lbd_blur5_sobel": 2 * P0 + P0 * (1 + 4),        # 5x5 blur r/w, Sobel read u8 write 2 x s16
+        "lbd": mean_lines * (63 * mean_len * 4 + 68 + 32),
+        "line_finalize": mean_lines * (68 + 32 + 24) * 2,
     }
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="frames per rank per step")
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=512, help="frames per rank per step")
     ap.add_argument("--keypoints", type=int, default=1000, help="Feature.max_num_keypoints (TUM RGB-D YAML: 1000)")
     ap.add_argument("--rows", type=int, default=480)
     ap.add_argument("--cols", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--orb-only", action="store_true", help="time the ORB extractor alone (config 1 shape)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -80,21 +94,58 @@ def main():
     synth = importlib.import_module("structure-plp-slam_amd.synth")
 
     B, K = args.batch, args.keypoints
-    # every rank replays its own contiguous block of the sequence (frame f -> rank f // B)
-    uniq = min(B, 64)
+    uniq = min(B, 64)   # 64 distinct frames of the pan, repeated to fill the batch (host-side generation is slow)
     frames_np = synth.replay(1234 + rank, uniq, args.rows, args.cols)
     d_frames = torch.from_numpy(frames_np).to(dev)
     if uniq < B:
         d_frames = d_frames.repeat((B + uniq - 1) // uniq, 1, 1)[:B].contiguous()
-    cap = 2 * K + 64
+    cap, lcap = 2 * K + 64, 512
     d_kps = torch.empty((B, cap, 28), dtype=torch.uint8, device=dev)
     d_desc = torch.empty((B, cap, 32), dtype=torch.uint8, device=dev)
     d_cnt = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_kl = torch.empty((B, lcap, 68), dtype=torch.uint8, device=dev)
+    d_lbd = torch.empty((B, lcap, 32), dtype=torch.uint8, device=dev)
+    d_fn = torch.empty((B, lcap, 3), dtype=torch.float64, device=dev)
+    d_lcnt = torch.zeros(B, dtype=torch.int32, device=dev)
+    m1 = torch.empty((B, cap), dtype=torch.int32, device=dev); n1 = torch.zeros(B, dtype=torch.int32, device=dev)
+    m2 = torch.empty((B, cap), dtype=torch.int32, device=dev); n2 = torch.zeros(B, dtype=torch.int32, device=dev)
     ex = plp.orb_extractor(K, device=local_rank)
-    stream = torch.cuda.current_stream(dev)
+    lt = plp.LineFeatureTracker(device=local_rank)
+    mt_last = plp.matcher(0.9, True, device=local_rank)     # motion_based_track: match::projection(0.9, true)
+    mt_lm = plp.matcher(0.8, True, device=local_rank)       # search_local_landmarks: match::projection(0.8)
+    grid = plp.make_grid(args.cols, args.rows)
+    sf = ex.get_scale_factors()
+    cur = torch.cuda.current_stream(dev)
+    sA, sB = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    slot = torch.arange(cap, device=dev, dtype=torch.int32)[None, :]
+
+    def match_stage():
+        kf = d_kps.view(torch.float32).view(B, cap, 7)
+        ki = d_kps.view(torch.int32).view(B, cap, 7)
+        p1k, p2k = torch.roll(kf, 1, 0), torch.roll(kf, 2, 0)
+        p1i, p2i = torch.roll(ki, 1, 0), torch.roll(ki, 2, 0)
+        p1d, p2d = torch.roll(d_desc, 1, 0), torch.roll(d_desc, 2, 0)
+        c1, c2 = torch.roll(d_cnt, 1, 0), torch.roll(d_cnt, 2, 0)
+        shift = torch.tensor([SHIFT_X, 0.0], device=dev)
+        q1 = dict(q_reproj=(p1k[:, :, 0:2] + shift).contiguous(), q_level=p1i[:, :, 5].contiguous(), q_angle=p1k[:, :, 3].contiguous(),
+                  q_desc=p1d, q_counts=c1)
+        t = dict(t_kps=d_kps, t_desc=d_desc, t_counts=d_cnt)
+        mt_last.match_device(plp.MODE_LAST_FRAME, cap, cap, {**t, **q1}, m1, n1, margin=20.0, direction=0, scale_factors=sf, grid=grid, B=B, stream=sA)
+        rp2 = torch.cat([p1k[:, :, 0:2] + shift, p2k[:, :, 0:2] + 2 * shift], 1).contiguous()
+        q2 = dict(q_reproj=rp2, q_level=torch.cat([p1i[:, :, 5], p2i[:, :, 5]], 1).contiguous(), q_desc=torch.cat([p1d, p2d], 1),
+                  q_valid=torch.cat([slot < c1[:, None], slot < c2[:, None]], 1).to(torch.uint8).contiguous())
+        mt_lm.match_device(plp.MODE_LANDMARKS, cap, 2 * cap, {**t, **q2}, m2, n2, margin=10.0, scale_factors=sf, grid=grid, B=B, stream=sA)
 
     def step():
-        ex.extract_batch(d_frames, d_kps, d_desc, d_cnt, stream=stream)
+        sA.wait_stream(cur)
+        sB.wait_stream(cur)
+        ex.extract_batch(d_frames, d_kps, d_desc, d_cnt, stream=sA)
+        if not args.orb_only:
+            lt.extract_batch(d_frames, d_kl, d_lbd, d_fn, d_lcnt, stream=sB)
+            with torch.cuda.stream(sA):
+                match_stage()
+        cur.wait_stream(sA)
+        cur.wait_stream(sB)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -111,6 +162,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     ex.last_batch_status()
+    if not args.orb_only:
+        lt.last_batch_status()
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -118,51 +171,79 @@ def main():
     fps = world * B * args.steps / elapsed
 
     # ---- per-kernel HIP-event timing (separate, synchronous pass) -> roofline of the dominant kernel
-    cnt = d_cnt.cpu().numpy()
-    mean_kp = float(cnt.mean())
-    n_prof = 5
+    mean_kp = float(d_cnt.float().mean().item())
+    n_prof = 3
     ex.set_profiling(True)
     for _ in range(n_prof):
-        step()
-    stage_ms, nb = ex.stage_times_ms()
+        ex.extract_batch(d_frames, d_kps, d_desc, d_cnt, stream=cur)
+    stage_ms, _ = ex.stage_times_ms()
     ex.set_profiling(False)
-    mean_cand = float(np.mean([len(ex.debug_read(ex.DBG_CANDIDATES, l, 0)) for l in range(ex.get_num_scale_levels())]) * ex.get_num_scale_levels())
-    per_frame = algorithmic_bytes(args.rows, args.cols, ex.get_num_scale_levels(), mean_kp, mean_cand)
-    kern = {k: v for k, v in stage_ms.items() if k in per_frame}
+    stage_ms.pop("batch_total"); stage_ms.pop("l0_copy")
+    mean_lines = mean_raw = mean_len = 0.0
+    if not args.orb_only:
+        lt.set_profiling(True)
+        for _ in range(n_prof):
+            lt.extract_batch(d_frames, d_kl, d_lbd, d_fn, d_lcnt, stream=cur)
+        lms, _ = lt.stage_times_ms()
+        lt.set_profiling(False)
+        lms.pop("batch_total")
+        stage_ms.update(lms)
+        mean_lines = float(d_lcnt.float().mean().item())
+        mean_raw = float(np.mean([len(lt.debug_read(lt.DBG_RAW, f)) for f in range(min(B, 8))]))
+        kl0 = d_kl[0, :max(int(d_lcnt[0].item()), 1)].cpu().numpy().view(plp.KL_DTYPE)
+        mean_len = float(kl0["numOfPixels"].mean()) if len(kl0) else 0.0
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(dev)
+        with torch.cuda.stream(sA):
+            e0.record(sA)
+            for _ in range(n_prof):
+                match_stage()
+            e1.record(sA)
+        torch.cuda.synchronize(dev)
+        stage_ms["match_2x"] = e0.elapsed_time(e1) / n_prof
+    nl = ex.get_num_scale_levels()
+    mean_cand = float(sum(len(ex.debug_read(ex.DBG_CANDIDATES, l, 0)) for l in range(nl)))
+    per_frame = algorithmic_bytes(args.rows, args.cols, nl, mean_kp, mean_cand, mean_lines, mean_len, mean_raw)
+    n_match_q = 3 * mean_kp
+    per_frame["match_2x"] = n_match_q * 32 + n_match_q * 15 * (32 + 28)   # 32*M + 60*C, ~15 candidates per query
+    kern = {k: v for k, v in stage_ms.items() if k in per_frame and v > 0}
     dominant = max(kern, key=kern.get)
-    launches = 7 if dominant == "pyramid" else 1
+    launches = {"pyramid": 7, "lsd_blur11_resize": 2, "lsd_gradient_bins": 2, "lbd_blur5_sobel": 2, "match_2x": 4}.get(dominant, 1)
     dom_bytes = per_frame[dominant] * B
     achieved = dom_bytes / (kern[dominant] * 1e-3) / 1e9
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
                 "launch_ms": round(kern[dominant] / launches, 4), "bytes_per_launch": int(dom_bytes / launches),
                 "stage_ms_per_batch": {k: round(v, 4) for k, v in stage_ms.items()},
-                "stage_GBps": {k: round(per_frame[k] * B / (kern[k] * 1e-3) / 1e9, 1) for k in kern if kern[k] > 0}}
+                "stage_GBps": {k: round(per_frame[k] * B / (kern[k] * 1e-3) / 1e9, 1) for k in kern}}
 
+    what = "ORB extract only" if args.orb_only else "ORB extract || LSD+LBD extract, then match_current_and_last_frames + match_frame_and_landmarks (~2K landmarks)"
     out = {
         "metric": "frames/sec ORB+LSD extract+match, 640x480 TUM-RGBD, 1/2/4/8 GPU",
         "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": f"TUM-RGBD-shaped replay {args.cols}x{args.rows}, ORB extract only (K={K}, 8 levels, 1.2); "
-                               "LSD/LBD + matchers not in the timed region yet",
-                   "frames_per_rank_per_step": B, "keypoints_mean": round(mean_kp, 1), "sharding": "frame blocks per rank, no collective"},
+        "config": {"workload": f"TUM-RGBD-shaped replay {args.cols}x{args.rows} (BASELINE configs[1]): {what}; K={K}, 8 levels, 1.2; "
+                               "line matchers / BoW matchers not included",
+                   "frames_per_rank_per_step": B, "keypoints_mean": round(mean_kp, 1), "lines_mean": round(mean_lines, 1),
+                   "matches_mean": [round(float(n1.float().mean().item()), 1), round(float(n2.float().mean().item()), 1)],
+                   "sharding": "contiguous frame blocks per rank, no collective"},
         "roofline": roofline,
     }
     if rank == 0 and not args.no_cpu_baseline:
         import ctypes as C
         import oracle_lib as O
         cores = os.cpu_count() or 1
-        n_cpu = min(uniq, 64)
-        sample = np.ascontiguousarray(frames_np[:n_cpu])
-        reps = max(1, int(8 * cores / n_cpu))     # ~10-20 s of CPU work at ~25 ms/frame/core
-        tot = C.c_long()
-        tiled = np.ascontiguousarray(np.tile(sample, (reps, 1, 1)))
-        sec = O.lib().oracle_orb_time_frames(tiled.ctypes.data_as(C.c_void_p), len(tiled), args.rows, args.cols, K, cores, C.byref(tot))
-        sec1 = O.lib().oracle_orb_time_frames(sample.ctypes.data_as(C.c_void_p), min(n_cpu, 16), args.rows, args.cols, K, 1, C.byref(tot))
-        out["cpu_baseline"] = {"value": round(len(tiled) / sec, 1), "unit": "frames/s", "cores": cores, "kind": "port",
-                               "sample": f"{len(tiled)} frames of the same replay, frame-parallel on {cores} threads, ORB extract only (oracle restatement, -O2 strict FP)",
-                               "single_thread_fps": round(min(n_cpu, 16) / sec1, 2)}
+        n_cpu = max(cores * 3, 24)   # >= 3 frames per worker block so the matchers run; ~15-25 s of CPU work
+        sample = np.ascontiguousarray(np.tile(frames_np, ((n_cpu + uniq - 1) // uniq, 1, 1))[:n_cpu])
+        tot = (C.c_long * 3)()
+        if args.orb_only:
+            sec = O.lib().oracle_orb_time_frames(sample.ctypes.data_as(C.c_void_p), n_cpu, args.rows, args.cols, K, cores, tot)
+        else:
+            sec = O.lib().oracle_front_time_frames(sample.ctypes.data_as(C.c_void_p), n_cpu, args.rows, args.cols, K, cores, SHIFT_X, tot)
+        out["cpu_baseline"] = {"value": round(n_cpu / sec, 1), "unit": "frames/s", "cores": cores, "kind": "port",
+                               "sample": f"{n_cpu} frames of the same replay, contiguous blocks on {cores} threads, same stages "
+                                         "(oracle restatement, g++ -O2 strict FP)"}
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

@@ -168,6 +168,10 @@ plp_status plp_line_extract_batch_device(plp_line* ctx, const uint8_t* d_imgs, i
                                          size_t step, size_t frame_stride, plp_keyline* d_kl, uint8_t* d_lbd,
                                          double* d_linefn, int32_t cap, int32_t* d_counts, void* hip_stream);
 plp_status plp_line_last_batch_status(plp_line* ctx);
+/* HIP-event stage timing (profiling mode makes batches synchronous).  ms9 = accumulated ms of {11-tap blur + x0.5 resize,
+ * gradient + bins, seed order, region growing, key lines, 5-tap blur + Sobel, LBD, finalize, whole batch}. */
+plp_status plp_line_set_profiling(plp_line* ctx, int32_t enable);
+plp_status plp_line_get_stage_times(plp_line* ctx, double* ms9, int64_t* n_batches);
 
 /* Stage read-back for parity tests (synchronous, host destination, frame of the last call):
  *   SCALED   u8 sh x sw dense (the 11-tap blur + x0.5 image LSD works on)

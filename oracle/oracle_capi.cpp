@@ -156,3 +156,83 @@ double oracle_orb_time_frames(const uint8_t* frames, int n_frames, int rows, int
 }
 
 }  // extern "C"
+
+// ---- CPU baseline of the whole front-end (bench.py cpu_baseline leg only): per frame ORB extract + LSD/LBD
+// extract + match_current_and_last_frames + match_frame_and_landmarks against the two previous frames,
+// the same work bench.py times on the GPU.  Frame-parallel over n_threads workers; returns wall seconds.
+namespace oracle { struct LineResult; }
+extern "C" {
+void* oracle_line_extract(const uint8_t* img, int rows, int cols, long step, int stable_order);
+void oracle_line_free(void* h);
+int oracle_line_count(void* h, int which);
+unsigned oracle_match_frame_and_landmarks(const double* grid6, const KeyPoint* kps, const uint8_t* desc, const float* x_right,
+                                          const uint8_t* occupied, int n, const float* scale_factors, const uint8_t* lm_valid,
+                                          const float* lm_reproj, const float* lm_x_right, const int* lm_level,
+                                          const uint8_t* lm_desc, const uint8_t* lm_has_obs, int m, float margin, float lowe_ratio,
+                                          int* kp_landmark);
+unsigned oracle_match_current_and_last(const double* grid6, const KeyPoint* kps, const uint8_t* desc, const float* x_right,
+                                       const uint8_t* occupied, int n, const float* scale_factors, int num_levels,
+                                       const uint8_t* valid, const float* reproj, const float* lx_right, const int* loctave,
+                                       const float* langle, const uint8_t* ldesc, const uint8_t* l_has_obs, int m, float margin,
+                                       int direction, int check_orientation, int* kp_last);
+
+double oracle_front_time_frames(const uint8_t* frames, int n_frames, int rows, int cols, unsigned max_kp, int n_threads,
+                                float shift_x, long* totals3) {
+    std::vector<long> kp(n_threads, 0), ln(n_threads, 0), mt(n_threads, 0);
+    const double grid6[6] = {0.0, 0.0, 64.0 / (double)(float)cols, 48.0 / (double)(float)rows, 64, 48};
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> th;
+    for (int t = 0; t < n_threads; ++t)
+        th.emplace_back([&, t]() {
+            OrbParams p;
+            p.max_num_keypts = max_kp;
+            OrbOracle ex(p);
+            const std::vector<float> sf = ex.scale_factors;
+            // every worker owns a contiguous block of the sequence and matches inside it (as each GPU rank does)
+            const int per = (n_frames + n_threads - 1) / n_threads, f0 = t * per, f1 = std::min(n_frames, f0 + per);
+            std::vector<KeyPoint> k[3];
+            std::vector<uint8_t> d[3];
+            for (int f = f0; f < f1; ++f) {
+                const int cur = f % 3;
+                Image im = wrap(frames + (size_t)f * rows * cols, rows, cols, cols);
+                ex.extract(im, nullptr, k[cur], d[cur]);
+                kp[t] += (long)k[cur].size();
+                void* lh = oracle_line_extract(im.data.data(), rows, cols, cols, 1);
+                ln[t] += oracle_line_count(lh, 0);
+                oracle_line_free(lh);
+                const int n = (int)k[cur].size();
+                if (f - f0 < 2 || n == 0) continue;
+                std::vector<float> xr(n, -1.f);
+                std::vector<uint8_t> occ(n, 0);
+                std::vector<int> out(n);
+                // queries: previous frame (last-frame matcher), previous two frames (local-landmark matcher)
+                std::vector<uint8_t> valid, qd, hobs;
+                std::vector<float> rp, qx, qa;
+                std::vector<int> ql;
+                auto append = [&](int which, float sx) {
+                    for (size_t i = 0; i < k[which].size(); ++i) {
+                        valid.push_back(1); hobs.push_back(1);
+                        rp.push_back(k[which][i].x + sx); rp.push_back(k[which][i].y);
+                        qx.push_back(-1.f); qa.push_back(k[which][i].angle); ql.push_back(k[which][i].octave);
+                    }
+                    qd.insert(qd.end(), d[which].begin(), d[which].end());
+                };
+                append((f + 2) % 3, shift_x);
+                mt[t] += oracle_match_current_and_last(grid6, k[cur].data(), d[cur].data(), xr.data(), occ.data(), n, sf.data(), (int)sf.size(),
+                                                       valid.data(), rp.data(), qx.data(), ql.data(), qa.data(), qd.data(), hobs.data(),
+                                                       (int)ql.size(), 20.f, 0, 1, out.data());
+                append((f + 1) % 3, 2 * shift_x);
+                mt[t] += oracle_match_frame_and_landmarks(grid6, k[cur].data(), d[cur].data(), xr.data(), occ.data(), n, sf.data(), valid.data(),
+                                                          rp.data(), qx.data(), ql.data(), qd.data(), hobs.data(), (int)ql.size(), 10.f, 0.8f,
+                                                          out.data());
+            }
+        });
+    for (auto& x : th) x.join();
+    auto t1 = std::chrono::steady_clock::now();
+    if (totals3) {
+        totals3[0] = totals3[1] = totals3[2] = 0;
+        for (int t = 0; t < n_threads; ++t) { totals3[0] += kp[t]; totals3[1] += ln[t]; totals3[2] += mt[t]; }
+    }
+    return std::chrono::duration<double>(t1 - t0).count();
+}
+}

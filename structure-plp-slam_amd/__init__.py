@@ -73,6 +73,8 @@ _API = [
     ("plp_line_extract", C.c_int, [_VP, _VP, _I32, _I32, _SZ, _VP, _VP, _VP, _I32, _VP]),
     ("plp_line_extract_batch_device", C.c_int, [_VP, _VP, _I32, _I32, _I32, _SZ, _SZ, _VP, _VP, _VP, _I32, _VP, _VP]),
     ("plp_line_last_batch_status", C.c_int, [_VP]),
+    ("plp_line_set_profiling", C.c_int, [_VP, _I32]),
+    ("plp_line_get_stage_times", C.c_int, [_VP, _VP, _VP]),
     ("plp_line_debug_read", C.c_int, [_VP, C.c_int, _I32, _VP, _SZ, _VP]),
     ("plp_line_scaled_size", C.c_int, [_VP, _VP, _VP]),
     ("plp_matcher_create", C.c_int, [C.c_int, _VP]),
@@ -298,6 +300,18 @@ class LineFeatureTracker:
 
     def last_batch_status(self):
         _check(lib().plp_line_last_batch_status(self._h))
+
+    STAGES = ("lsd_blur11_resize", "lsd_gradient_bins", "lsd_order", "lsd_grow", "keylines", "lbd_blur5_sobel", "lbd", "line_finalize", "batch_total")
+
+    def set_profiling(self, on):
+        _check(lib().plp_line_set_profiling(self._h, int(bool(on))))
+
+    def stage_times_ms(self):
+        ms = np.zeros(9, np.float64)
+        n = C.c_int64()
+        _check(lib().plp_line_get_stage_times(self._h, _p(ms), C.byref(n)))
+        nb = max(n.value, 1)
+        return {k: float(v) / nb for k, v in zip(self.STAGES, ms)}, n.value
 
     def debug_read(self, what, frame=0):
         r, c = C.c_int32(), C.c_int32()

@@ -26,6 +26,10 @@ struct plp_line {
     int s_cap = 0;
     int last_B = 0;
     hipStream_t last_stream = nullptr;
+    bool profiling = false;
+    hipEvent_t ev[9] = {};
+    double stage_ms[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // 8 stages + total
+    long stage_batches = 0;
     std::mutex mu;
 };
 
@@ -137,8 +141,14 @@ plp_status run(plp_line* c, const uint8_t* d_imgs, int B, int rows, int cols, si
     PLP_TRY(ensure(c, B));
     c->P.img = d_imgs; c->P.img_frame_stride = frame_stride; c->P.img_pitch = (int)step;
     PLP_HIP(hipMemsetAsync(c->status.p, 0, 16, st));
-    launch_line_front(st, c->P, c->lp, c->rt, c->t11, c->t5, c->w, d_kl, d_lbd, d_fn, cap, d_counts, B);
+    launch_line_front(st, c->P, c->lp, c->rt, c->t11, c->t5, c->w, d_kl, d_lbd, d_fn, cap, d_counts, B, c->profiling ? c->ev : nullptr);
     PLP_HIP(hipGetLastError());
+    if (c->profiling) {
+        PLP_HIP(hipEventSynchronize(c->ev[8]));
+        for (int i = 0; i < 8; ++i) { float ms = 0; PLP_HIP(hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1])); c->stage_ms[i] += ms; }
+        float tot = 0; PLP_HIP(hipEventElapsedTime(&tot, c->ev[0], c->ev[8])); c->stage_ms[8] += tot;
+        ++c->stage_batches;
+    }
     c->last_B = B; c->last_stream = st;
     return PLP_OK;
 }
@@ -165,6 +175,7 @@ void plp_line_destroy(plp_line* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     delete c;
 }
 
@@ -221,6 +232,25 @@ plp_status plp_line_extract(plp_line* c, const uint8_t* img, int32_t rows, int32
     int32_t s[4];
     PLP_HIP(hipMemcpy(s, c->status.p, 16, hipMemcpyDeviceToHost));
     if (s[0] & 4) return set_error(PLP_ERR_OVERFLOW, "more LSD segments than the per-frame capacity");
+    return PLP_OK;
+}
+
+plp_status plp_line_set_profiling(plp_line* c, int32_t enable) {
+    if (!c) return set_error(PLP_ERR_INVALID_ARG, "ctx is NULL");
+    std::lock_guard<std::mutex> lk(c->mu);
+    PLP_HIP(hipSetDevice(c->device));
+    if (enable && !c->ev[0]) for (auto& e : c->ev) PLP_HIP(hipEventCreate(&e));
+    c->profiling = enable != 0;
+    for (auto& v : c->stage_ms) v = 0;
+    c->stage_batches = 0;
+    return PLP_OK;
+}
+
+plp_status plp_line_get_stage_times(plp_line* c, double* ms9, int64_t* n_batches) {
+    if (!c || !ms9) return set_error(PLP_ERR_INVALID_ARG, "NULL argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    for (int i = 0; i < 9; ++i) ms9[i] = c->stage_ms[i];
+    if (n_batches) *n_batches = c->stage_batches;
     return PLP_OK;
 }
 

@@ -716,26 +716,36 @@ __global__ __launch_bounds__(64) void k_line_finalize(LinePlanes P, LsdParams lp
 // ------------------------------------------------------------------------------------------ launch sequence
 void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp, const ResizeExactTab& rt, const BlurTapsN& t11,
                        const BlurTapsN& t5, const LbdWeightsDev& w, plp_keyline* out_kl, uint8_t* out_lbd, double* out_fn, int cap,
-                       int32_t* out_counts, int B) {
+                       int32_t* out_counts, int B, hipEvent_t* ev) {
+    auto mark = [&](int i) { if (ev) (void)hipEventRecord(ev[i], st); };
     const size_t plane_fs = (size_t)P.pitch * P.H, splane_fs = (size_t)P.spitch * P.sh;
     const int tiles = ((P.W + 63) / 64) * ((P.H + 31) / 32);
     (void)hipMemsetAsync(P.maxgrad, 0, sizeof(unsigned long long) * B, st);
+    mark(0);
     hipLaunchKernelGGL(k_blur_plane<5>, dim3(tiles, B), dim3(256), 0, st, P.img, P.img_frame_stride, P.img_pitch, P.blur11, plane_fs,
                        P.pitch, P.W, P.H, t11);
     hipLaunchKernelGGL(k_resize_exact, dim3((P.sw + 255) / 256, (P.sh + 3) / 4, B), dim3(64, 4), 0, st, P.blur11, plane_fs, P.pitch,
                        P.scaled, splane_fs, P.spitch, P.sw, P.sh, rt);
+    mark(1);
     const int n = P.sw * P.sh;
     hipLaunchKernelGGL(k_lsd_gradient, dim3((n + 255) / 256, B), dim3(256), 0, st, P, lp);
     hipLaunchKernelGGL(k_lsd_bins, dim3((n + 255) / 256, B), dim3(256), 0, st, P, lp);
+    mark(2);
     hipLaunchKernelGGL(k_lsd_order, dim3(B), dim3(256), 0, st, P);
+    mark(3);
     const size_t lds = (size_t)4 * ((n + 31) / 32) * 4;
     hipLaunchKernelGGL(k_lsd_grow, dim3((B + 3) / 4), dim3(256), lds, st, P, lp, B);
+    mark(4);
     hipLaunchKernelGGL(k_keylines, dim3(B), dim3(64), 0, st, P, lp);
+    mark(5);
     hipLaunchKernelGGL(k_blur_plane<2>, dim3(tiles, B), dim3(256), 0, st, P.img, P.img_frame_stride, P.img_pitch, P.blur5, plane_fs,
                        P.pitch, P.W, P.H, t5);
     hipLaunchKernelGGL(k_sobel3, dim3((P.W + 63) / 64, (P.H + 3) / 4, B), dim3(256), 0, st, P.blur5, plane_fs, P.pitch, P.dx, P.dy, P.W, P.H);
+    mark(6);
     hipLaunchKernelGGL(k_lbd, dim3(kLineCap / 4, B), dim3(256), 0, st, P, w);
+    mark(7);
     hipLaunchKernelGGL(k_line_finalize, dim3(B), dim3(64), 0, st, P, lp, out_kl, out_lbd, out_fn, cap, out_counts);
+    mark(8);
 }
 
 }  // namespace plp

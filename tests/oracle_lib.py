@@ -75,6 +75,8 @@ def lib():
         L.oracle_match_current_and_last.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 7 + [C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p]
         L.oracle_brute_force_match.restype = C.c_uint
         L.oracle_brute_force_match.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p]
+        L.oracle_front_time_frames.restype = C.c_double
+        L.oracle_front_time_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_int, C.c_float, C.c_void_p]
         L.oracle_line_extract.restype = C.c_void_p
         L.oracle_line_extract.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_long, C.c_int]
         L.oracle_line_free.argtypes = [C.c_void_p]
