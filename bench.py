@@ -119,16 +119,19 @@ def main():
     sA, sB = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
     slot = torch.arange(cap, device=dev, dtype=torch.int32)[None, :]
 
+    replay = importlib.import_module("structure-plp-slam_amd.replay")
+
     def match_stage():
         kf = d_kps.view(torch.float32).view(B, cap, 7)
-        ki = d_kps.view(torch.int32).view(B, cap, 7)
-        p1k, p2k = torch.roll(kf, 1, 0), torch.roll(kf, 2, 0)
-        p1i, p2i = torch.roll(ki, 1, 0), torch.roll(ki, 2, 0)
-        p1d, p2d = torch.roll(d_desc, 1, 0), torch.roll(d_desc, 2, 0)
-        c1, c2 = torch.roll(d_cnt, 1, 0), torch.roll(d_cnt, 2, 0)
+        # the two frames preceding this rank's block come from the previous rank (RCCL all-gather of the tails)
+        hk, hd, hc = replay.exchange_halo([kf, d_desc, d_cnt], halo=2)
+        fk, fd, fc = replay.with_halo(kf, hk), replay.with_halo(d_desc, hd), replay.with_halo(d_cnt, hc)
+        fi = fk.view(torch.int32)
+        p1k, p2k, p1i, p2i = fk[1:B + 1], fk[0:B], fi[1:B + 1], fi[0:B]
+        p1d, p2d, c1, c2 = fd[1:B + 1], fd[0:B], fc[1:B + 1].contiguous(), fc[0:B].contiguous()
         shift = torch.tensor([SHIFT_X, 0.0], device=dev)
         q1 = dict(q_reproj=(p1k[:, :, 0:2] + shift).contiguous(), q_level=p1i[:, :, 5].contiguous(), q_angle=p1k[:, :, 3].contiguous(),
-                  q_desc=p1d, q_counts=c1)
+                  q_desc=p1d.contiguous(), q_counts=c1)
         t = dict(t_kps=d_kps, t_desc=d_desc, t_counts=d_cnt)
         mt_last.match_device(plp.MODE_LAST_FRAME, cap, cap, {**t, **q1}, m1, n1, margin=20.0, direction=0, scale_factors=sf, grid=grid, B=B, stream=sA)
         rp2 = torch.cat([p1k[:, :, 0:2] + shift, p2k[:, :, 0:2] + 2 * shift], 1).contiguous()
@@ -227,7 +230,7 @@ def main():
                                "line matchers / BoW matchers not included",
                    "frames_per_rank_per_step": B, "keypoints_mean": round(mean_kp, 1), "lines_mean": round(mean_lines, 1),
                    "matches_mean": [round(float(n1.float().mean().item()), 1), round(float(n2.float().mean().item()), 1)],
-                   "sharding": "contiguous frame blocks per rank, no collective"},
+                   "sharding": "contiguous frame blocks per rank; RCCL all-gather of the 2-frame feature halo for the matchers"},
         "roofline": roofline,
     }
     if rank == 0 and not args.no_cpu_baseline:
