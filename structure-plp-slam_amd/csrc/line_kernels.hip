@@ -19,6 +19,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "line_device.hpp"
 
 namespace plp {
@@ -249,16 +251,39 @@ __device__ __forceinline__ double shfl_d(double v, int src) {
 struct GrowCtx {
     const double* ang; const double* mod; const float2* cs;
     uint32_t* reg; uint32_t* used;   // used: LDS bitmap
+    uint32_t* ring;                  // LDS: the last kRing region points (the breadth-first frontier lives here)
     int sw, sh, lane;
 };
 struct Rect { double x1, y1, x2, y2, width; };
+constexpr int kRing = 1024;
 
 __device__ __forceinline__ bool is_used(const GrowCtx& g, int p) { return (g.used[p >> 5] >> (p & 31)) & 1u; }
 __device__ __forceinline__ void set_used(const GrowCtx& g, int p) { g.used[p >> 5] |= 1u << (p & 31); }   // single-lane callers only
 
-// region_grow (lsd.cpp): breadth-first over g.reg; the 3x3 neighbourhood of a region point is evaluated
-// by 9 lanes at once, acceptances are applied strictly in the reference's scan order (row by row) and
-// every acceptance updates reg_angle before the remaining neighbours are tested.
+// the 3x3 neighbourhood of one region point, one neighbour per lane (lanes 0..8), data prefetched
+struct Nbhd { int nx, ny, np; bool inb; double a, w; float2 cs; };
+
+__device__ __forceinline__ void fetch_nbhd(const GrowCtx& g, int idx, int nreg, Nbhd& o) {
+    uint32_t c;
+    if (nreg <= idx + kRing) c = g.ring[idx & (kRing - 1)];      // LDS broadcast read
+    else {                                                        // frontier outgrew the ring: read the HBM copy
+        c = 0;
+        if (g.lane == 0) c = __hip_atomic_load(&g.reg[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        c = __shfl(c, 0);
+    }
+    const int cx = (int)(c & 0xffff), cy = (int)(c >> 16);
+    o.nx = cx + (g.lane % 3) - 1; o.ny = cy + (g.lane / 3) - 1;
+    o.inb = g.lane < 9 && o.nx >= 0 && o.ny >= 0 && o.nx < g.sw && o.ny < g.sh;
+    o.np = o.ny * g.sw + o.nx;
+    o.a = 0; o.w = 0; o.cs = make_float2(0.f, 0.f);
+    if (o.inb) { o.a = g.ang[o.np]; o.w = g.mod[o.np]; o.cs = g.cs[o.np]; }   // three independent gathers, one wait
+}
+
+// region_grow (lsd.cpp): breadth-first over the region list; the 3x3 neighbourhood of a region point is
+// evaluated by 9 lanes at once, acceptances are applied strictly in the reference's scan order (row by row)
+// and every acceptance updates reg_angle before the remaining neighbours are tested.  The neighbourhood of
+// the NEXT region point is prefetched while the current one is processed (its pixel data is immutable; only
+// the USED bits, kept in LDS, are read late).  Undefined pixels are pre-marked USED, so no NOTDEF test.
 // Returns the region size; cen[3] = (sum x*w, sum y*w, sum w) accumulated in region order.
 __device__ int region_grow(const GrowCtx& g, int seed, double prec, double& reg_angle, double cen[3]) {
     const int lane = g.lane;
@@ -270,34 +295,32 @@ __device__ int region_grow(const GrowCtx& g, int seed, double prec, double& reg_
         const double w = g.mod[seed];
         cen[0] = (double)sx * w; cen[1] = (double)sy * w; cen[2] = w;
     }
-    if (lane == 0) { g.reg[0] = (uint32_t)sx | ((uint32_t)sy << 16); set_used(g, seed); }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    if (lane == 0) {
+        const uint32_t c = (uint32_t)sx | ((uint32_t)sy << 16);
+        g.reg[0] = c; g.ring[0] = c;
+        set_used(g, seed);
+    }
     __builtin_amdgcn_wave_barrier();
+    Nbhd cur;
+    fetch_nbhd(g, 0, nreg, cur);
     for (int i = 0; i < nreg; ++i) {
-        uint32_t c = 0;
-        if (lane == 0) c = __hip_atomic_load(&g.reg[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        c = __shfl(c, 0);
-        const int cx = (int)(c & 0xffff), cy = (int)(c >> 16);
-        // lane k < 9: neighbour (cx + k%3 - 1, cy + k/3 - 1)
-        const int nx = cx + (lane % 3) - 1, ny = cy + (lane / 3) - 1;
-        bool cand = lane < 9 && nx >= 0 && ny >= 0 && nx < g.sw && ny < g.sh;
-        const int np = ny * g.sw + nx;
-        double a = kLsdNotDef, w = 0;
-        float2 ncs = make_float2(0.f, 0.f);
-        if (cand) cand = !is_used(g, np);
-        if (cand) { a = g.ang[np]; cand = a != kLsdNotDef; }
-        if (cand) { w = g.mod[np]; ncs = g.cs[np]; }
+        Nbhd nxt;
+        const bool have_next = i + 1 < nreg;
+        if (have_next) fetch_nbhd(g, i + 1, nreg, nxt);
+        bool cand = cur.inb && !is_used(g, cur.np);
         int last = -1;
         while (true) {
-            const bool ok = cand && lane > last && aligned_to(a, reg_angle, prec);
+            const bool ok = cand && lane > last && aligned_to(cur.a, reg_angle, prec);
             const unsigned long long bal = __ballot(ok);
             if (!bal) break;
             const int k = __ffsll((long long)bal) - 1;
-            const int ax = __shfl(nx, k), ay = __shfl(ny, k);
-            const float ccos = __shfl(ncs.x, k), csin = __shfl(ncs.y, k);
-            const double aw = shfl_d(w, k);
+            const int ax = __shfl(cur.nx, k), ay = __shfl(cur.ny, k);
+            const float ccos = __shfl(cur.cs.x, k), csin = __shfl(cur.cs.y, k);
+            const double aw = shfl_d(cur.w, k);
             if (lane == 0) {
-                __hip_atomic_store(&g.reg[nreg], (uint32_t)ax | ((uint32_t)ay << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                const uint32_t c = (uint32_t)ax | ((uint32_t)ay << 16);
+                __hip_atomic_store(&g.reg[nreg], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                g.ring[nreg & (kRing - 1)] = c;
                 set_used(g, ay * g.sw + ax);
             }
             ++nreg;
@@ -307,9 +330,12 @@ __device__ int region_grow(const GrowCtx& g, int seed, double prec, double& reg_
             cen[0] += (double)ax * aw; cen[1] += (double)ay * aw; cen[2] += aw;
             last = k;
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
+        if (!have_next && i + 1 < nreg) fetch_nbhd(g, i + 1, nreg, nxt);   // the next point was created just now
+        cur = nxt;
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // region list in HBM is read by all lanes next
+    __builtin_amdgcn_wave_barrier();
     return nreg;
 }
 
@@ -385,17 +411,18 @@ __device__ void centroid_sums(const GrowCtx& g, int nreg, double cen[3]) {
     }
 }
 
-// grid = (ceil(B / 4)), block = 256: wave w of a block handles frame 4*blockIdx.x + w.
-// dynamic LDS: 4 x used bitmap.
-__global__ __launch_bounds__(256) void k_lsd_grow(LinePlanes P, LsdParams lp, int B) {
+// grid = (ceil(B / wpb)), block = 64 * wpb: wave w of a block handles frame wpb*blockIdx.x + w (wpb = waves whose
+// USED bitmap + frontier ring fit 64 KB of LDS together, at most 4).
+__global__ __launch_bounds__(256) void k_lsd_grow(LinePlanes P, LsdParams lp, int B, int wpb) {
     extern __shared__ uint32_t s_bits[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int b = blockIdx.x * 4 + wv;
+    const int b = blockIdx.x * wpb + wv;
     if (b >= B) return;
     const int n = P.sw * P.sh, nwords = (n + 31) / 32, nv = (P.sw - 1) * (P.sh - 1);
     GrowCtx g;
     g.ang = P.ang + (size_t)b * n; g.mod = P.mod + (size_t)b * n; g.cs = P.cs + (size_t)b * n;
-    g.reg = P.reg + (size_t)b * n; g.used = s_bits + (size_t)wv * nwords; g.sw = P.sw; g.sh = P.sh; g.lane = lane;
+    g.reg = P.reg + (size_t)b * n; g.used = s_bits + (size_t)wv * (nwords + kRing); g.ring = g.used + nwords;
+    g.sw = P.sw; g.sh = P.sh; g.lane = lane;
     // USED map starts as the NOTDEF mask: an undefined pixel is never a seed and never aligned, so
     // treating it as used is equivalent and spares a global load per rejected seed
     {
@@ -733,8 +760,9 @@ void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp,
     mark(2);
     hipLaunchKernelGGL(k_lsd_order, dim3(B), dim3(256), 0, st, P);
     mark(3);
-    const size_t lds = (size_t)4 * ((n + 31) / 32) * 4;
-    hipLaunchKernelGGL(k_lsd_grow, dim3((B + 3) / 4), dim3(256), lds, st, P, lp, B);
+    const size_t per_wave = (size_t)((n + 31) / 32 + 1024) * 4;   // USED bitmap + 1024-entry frontier ring
+    const int wpb = (int)std::max<size_t>(1, std::min<size_t>(4, 65536 / per_wave));
+    hipLaunchKernelGGL(k_lsd_grow, dim3((B + wpb - 1) / wpb), dim3(64 * wpb), per_wave * wpb, st, P, lp, B, wpb);
     mark(4);
     hipLaunchKernelGGL(k_keylines, dim3(B), dim3(64), 0, st, P, lp);
     mark(5);
