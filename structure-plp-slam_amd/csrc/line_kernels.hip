@@ -248,6 +248,15 @@ __device__ __forceinline__ double shfl_d(double v, int src) {
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+// broadcasts from a wave-uniform lane index: v_readlane (no LDS round trip, unlike ds_bpermute-based __shfl)
+__device__ __forceinline__ int bcast_i(int v, int src) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src)); }
+__device__ __forceinline__ float bcast_f(float v, int src) { return __int_as_float(bcast_i(__float_as_int(v), src)); }
+__device__ __forceinline__ double bcast_d(double v, int src) {
+    const long long bits = __double_as_longlong(v);
+    const unsigned lo = (unsigned)bcast_i((int)(unsigned)bits, src), hi = (unsigned)bcast_i((int)(unsigned)((unsigned long long)bits >> 32), src);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 struct GrowCtx {
     const double* ang; const double* mod; const float2* cs;
     uint32_t* reg; uint32_t* used;   // used: LDS bitmap
@@ -258,7 +267,7 @@ struct Rect { double x1, y1, x2, y2, width; };
 constexpr int kRing = 1024;
 
 __device__ __forceinline__ bool is_used(const GrowCtx& g, int p) { return (g.used[p >> 5] >> (p & 31)) & 1u; }
-__device__ __forceinline__ void set_used(const GrowCtx& g, int p) { g.used[p >> 5] |= 1u << (p & 31); }   // single-lane callers only
+__device__ __forceinline__ void set_used(const GrowCtx& g, int p) { atomicOr(&g.used[p >> 5], 1u << (p & 31)); }   // fire-and-forget ds_or
 
 // the 3x3 neighbourhood of one region point, one neighbour per lane (lanes 0..8), data prefetched
 struct Nbhd { int nx, ny, np; bool inb; double a, w; float2 cs; };
@@ -314,9 +323,9 @@ __device__ int region_grow(const GrowCtx& g, int seed, double prec, double& reg_
             const unsigned long long bal = __ballot(ok);
             if (!bal) break;
             const int k = __ffsll((long long)bal) - 1;
-            const int ax = __shfl(cur.nx, k), ay = __shfl(cur.ny, k);
-            const float ccos = __shfl(cur.cs.x, k), csin = __shfl(cur.cs.y, k);
-            const double aw = shfl_d(cur.w, k);
+            const int ax = bcast_i(cur.nx, k), ay = bcast_i(cur.ny, k);
+            const float ccos = bcast_f(cur.cs.x, k), csin = bcast_f(cur.cs.y, k);
+            const double aw = bcast_d(cur.w, k);
             if (lane == 0) {
                 const uint32_t c = (uint32_t)ax | ((uint32_t)ay << 16);
                 __hip_atomic_store(&g.reg[nreg], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -347,18 +356,18 @@ __device__ void region2rect(const GrowCtx& g, int nreg, double reg_angle, double
     double Ixx = 0.0, Iyy = 0.0, Ixy = 0.0;
     for (int base = 0; base < nreg; base += 64) {
         const int j = base + lane;
-        double px = 0, py = 0, w = 0;
+        double txx = 0, tyy = 0, txy = 0;   // this lane's addends (same roundings as the reference's per-point products)
         if (j < nreg) {
             const uint32_t c = g.reg[j];
-            px = (double)(int)(c & 0xffff); py = (double)(int)(c >> 16);
-            w = g.mod[(int)(c >> 16) * g.sw + (int)(c & 0xffff)];
+            const double w = g.mod[(int)(c >> 16) * g.sw + (int)(c & 0xffff)];
+            const double dx = (double)(int)(c & 0xffff) - x, dy = (double)(int)(c >> 16) - y;
+            txx = dy * dy * w; tyy = dx * dx * w; txy = dx * dy * w;
         }
         const int cnt = min(64, nreg - base);
-        for (int t = 0; t < cnt; ++t) {
-            const double dx = shfl_d(px, t) - x, dy = shfl_d(py, t) - y, ww = shfl_d(w, t);
-            Ixx += dy * dy * ww;
-            Iyy += dx * dx * ww;
-            Ixy -= dx * dy * ww;
+        for (int t = 0; t < cnt; ++t) {   // strictly sequential adds, region order
+            Ixx += bcast_d(txx, t);
+            Iyy += bcast_d(tyy, t);
+            Ixy -= bcast_d(txy, t);
         }
     }
     const double lambda = 0.5 * (Ixx + Iyy - sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
@@ -397,17 +406,14 @@ __device__ void centroid_sums(const GrowCtx& g, int nreg, double cen[3]) {
     cen[0] = cen[1] = cen[2] = 0;
     for (int base = 0; base < nreg; base += 64) {
         const int j = base + g.lane;
-        double px = 0, py = 0, w = 0;
+        double tx = 0, ty = 0, w = 0;
         if (j < nreg) {
             const uint32_t c = g.reg[j];
-            px = (double)(int)(c & 0xffff); py = (double)(int)(c >> 16);
             w = g.mod[(int)(c >> 16) * g.sw + (int)(c & 0xffff)];
+            tx = (double)(int)(c & 0xffff) * w; ty = (double)(int)(c >> 16) * w;
         }
         const int cnt = min(64, nreg - base);
-        for (int t = 0; t < cnt; ++t) {
-            const double ww = shfl_d(w, t);
-            cen[0] += shfl_d(px, t) * ww; cen[1] += shfl_d(py, t) * ww; cen[2] += ww;
-        }
+        for (int t = 0; t < cnt; ++t) { cen[0] += bcast_d(tx, t); cen[1] += bcast_d(ty, t); cen[2] += bcast_d(w, t); }
     }
 }
 
@@ -435,11 +441,15 @@ __global__ __launch_bounds__(256) void k_lsd_grow(LinePlanes P, LsdParams lp, in
     float4* raw = P.raw + (size_t)b * kLineCap;
     int n_lines = 0;
     for (int base = 0; base < nv; base += 64) {
-        const uint32_t mine = base + lane < nv ? order[base + lane] : 0u;
-        const int cnt = min(64, nv - base);
-        for (int t = 0; t < cnt; ++t) {
-            const int seed = (int)__shfl(mine, t);
-            if (is_used(g, seed)) continue;
+        const bool in_range = base + lane < nv;
+        const uint32_t mine = in_range ? order[base + lane] : 0u;
+        // most seeds are already inside an earlier region: test the 64 USED bits in parallel, visit the rest in order
+        unsigned long long todo = __ballot(in_range && !is_used(g, (int)mine));
+        while (todo) {
+            const int t = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int seed = bcast_i((int)mine, t);
+            if (is_used(g, seed)) continue;   // claimed by a region grown since the ballot
             double reg_angle, cen[3];
             int nreg = region_grow(g, seed, lp.prec, reg_angle, cen);
             if (nreg < lp.min_reg_size) continue;
@@ -467,12 +477,13 @@ __global__ __launch_bounds__(256) void k_lsd_grow(LinePlanes P, LsdParams lp, in
                             near = sqrt(ddx * ddx + ddy * ddy) < rec.width;
                             a = g.ang[py * g.sw + px];
                         }
-                        const int c64 = min(64, nreg - rb);
-                        const unsigned long long nb = __ballot(near);
-                        for (int u = 0; u < c64; ++u) {
-                            if (!((nb >> u) & 1ull)) continue;
-                            const double ang_d = angle_diff_signed(shfl_d(a, u), ang_c);
-                            sum += ang_d; s_sum += ang_d * ang_d; ++nn;
+                        const double my_d = near ? angle_diff_signed(a, ang_c) : 0.0;
+                        const double my_d2 = my_d * my_d;
+                        unsigned long long nb = __ballot(near);
+                        while (nb) {   // near points in region order
+                            const int u = __ffsll((long long)nb) - 1;
+                            nb &= nb - 1;
+                            sum += bcast_d(my_d, u); s_sum += bcast_d(my_d2, u); ++nn;
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
