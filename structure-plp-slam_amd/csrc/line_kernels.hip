@@ -608,13 +608,13 @@ __constant__ int c_comb[32][2] = {{0, 1}, {0, 2}, {0, 3}, {0, 4}, {0, 5}, {0, 6}
                                   {2, 3}, {2, 4}, {2, 5}, {2, 6}, {2, 7}, {2, 8}, {3, 4}, {3, 5}, {3, 6}, {3, 7}, {3, 8},
                                   {4, 5}, {4, 6}, {4, 7}, {4, 8}, {5, 6}, {5, 7}, {5, 8}, {6, 7}, {6, 8}, {7, 8}};
 
-// grid = (kLineCap / 4, B), block = 256: one wave per line.
+// grid = (16, B), block = 256: one wave per line, 64 lines of a frame in flight.
 __global__ __launch_bounds__(256) void k_lbd(LinePlanes P, LbdWeightsDev W) {
     __shared__ float s_row[4][63][8];   // per row: pgdL, ngdL, pgdL2, ngdL2, pgdO, ngdO, pgdO2, ngdO2 (after the global weight)
     __shared__ float s_des[4][72];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, b = blockIdx.y;
-    const int li = blockIdx.x * 4 + wv;
-    if (li >= P.n_all[b]) return;
+    const int n_lines = P.n_all[b];
+    for (int li = blockIdx.x * 4 + wv; li < n_lines; li += gridDim.x * 4) {   // a few resident waves walk the frame's lines
     const plp_keyline kl = P.all_kl[(size_t)b * kLineCap + li];
     const int16_t* dxImg = P.dx + (size_t)b * P.W * P.H;
     const int16_t* dyImg = P.dy + (size_t)b * P.W * P.H;
@@ -715,6 +715,9 @@ __global__ __launch_bounds__(256) void k_lbd(LinePlanes P, LbdWeightsDev W) {
             out[c] = (uint8_t)r;
         }
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    }   // line loop
 }
 
 // ------------------------------------------------------------------------------------------ finalize
@@ -781,7 +784,7 @@ void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp,
                        P.pitch, P.W, P.H, t5);
     hipLaunchKernelGGL(k_sobel3, dim3((P.W + 63) / 64, (P.H + 3) / 4, B), dim3(256), 0, st, P.blur5, plane_fs, P.pitch, P.dx, P.dy, P.W, P.H);
     mark(6);
-    hipLaunchKernelGGL(k_lbd, dim3(kLineCap / 4, B), dim3(256), 0, st, P, w);
+    hipLaunchKernelGGL(k_lbd, dim3(16, B), dim3(256), 0, st, P, w);
     mark(7);
     hipLaunchKernelGGL(k_line_finalize, dim3(B), dim3(64), 0, st, P, lp, out_kl, out_lbd, out_fn, cap, out_counts);
     mark(8);

@@ -97,7 +97,30 @@ __device__ __forceinline__ unsigned long long candidate_key(const MatchProblem& 
     return ((unsigned long long)dist << 32) | ((unsigned long long)order << 4) | oct;
 }
 
-// grid = (ceil(m_cap / 4), B), block = 256: one wave per query.
+// lane-local sorted insertion + wave merge of the K best keys of one query
+__device__ __forceinline__ void topk_insert(unsigned long long (&top)[kMatchK], unsigned long long key) {
+    if (key < top[kMatchK - 1]) {
+        top[kMatchK - 1] = key;
+#pragma unroll
+        for (int i = kMatchK - 1; i > 0; --i)
+            if (top[i] < top[i - 1]) { const unsigned long long s = top[i]; top[i] = top[i - 1]; top[i - 1] = s; }
+    }
+}
+__device__ __forceinline__ void topk_merge_store(unsigned long long (&top)[kMatchK], int lane, unsigned long long* klist) {
+#pragma unroll
+    for (int r = 0; r < kMatchK; ++r) {
+        const unsigned long long mn = wave_min_u64(top[0]);
+        if (lane == 0) klist[r] = mn;
+        if (top[0] == mn && mn != ~0ull) {
+#pragma unroll
+            for (int i = 0; i + 1 < kMatchK; ++i) top[i] = top[i + 1];
+            top[kMatchK - 1] = ~0ull;
+        }
+    }
+}
+
+// Fallback for frames with more key points than the LDS staging of k_match_topk_lds holds:
+// grid = (ceil(m_cap / 4), B), block = 256: one wave per query, targets read from HBM/L2.
 __global__ __launch_bounds__(256) void k_match_topk(MatchProblem P) {
     const int lane = threadIdx.x & 63, b = blockIdx.y;
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -117,7 +140,6 @@ __global__ __launch_bounds__(256) void k_match_topk(MatchProblem P) {
                                   P.q_level ? P.q_level + (size_t)b * P.m_cap : nullptr);
     const uint4* qd = reinterpret_cast<const uint4*>(P.q_desc + ((size_t)b * P.m_cap + q) * 32);
     const uint4 q0 = qd[0], q1 = qd[1];
-
     unsigned long long top[kMatchK];
 #pragma unroll
     for (int i = 0; i < kMatchK; ++i) top[i] = ~0ull;
@@ -127,27 +149,104 @@ __global__ __launch_bounds__(256) void k_match_topk(MatchProblem P) {
             const unsigned long long key = candidate_key(P, c, t, kps, t_desc, t_xr, t_occ, q0, q1);
             if (key == ~0ull) continue;
             ++passed;
-            if (key < top[kMatchK - 1]) {   // sorted insertion into the lane-local best-K
-                top[kMatchK - 1] = key;
-#pragma unroll
-                for (int i = kMatchK - 1; i > 0; --i)
-                    if (top[i] < top[i - 1]) { const unsigned long long s = top[i]; top[i] = top[i - 1]; top[i - 1] = s; }
-            }
+            topk_insert(top, key);
         }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) passed += __shfl_xor(passed, o);
-    // merge the 64 sorted lane lists: K rounds of wave-min, the owning lane pops its head
-#pragma unroll
-    for (int r = 0; r < kMatchK; ++r) {
-        const unsigned long long mn = wave_min_u64(top[0]);
-        if (lane == 0) klist[r] = mn;
-        if (top[0] == mn && mn != ~0ull) {
-#pragma unroll
-            for (int i = 0; i + 1 < kMatchK; ++i) top[i] = top[i + 1];
-            top[kMatchK - 1] = ~0ull;
-        }
-    }
+    topk_merge_store(top, lane, klist);
     if (lane == 0) *kcount = passed;
+}
+
+// Main path: the frame's targets are staged ONCE per workgroup in LDS and reused by kQueriesPerBlock queries
+// (a wave scanning 1000 key points from L2 for each of ~3000 queries made the kernel L2-bandwidth bound).
+//   windowed modes: 12 B per target {x, y, octave | cell col | cell row | flags} (+4 B stereo x_right)
+//   brute force:    the 32-byte descriptors themselves
+// grid = (ceil(m_cap / kQueriesPerBlock), B), block = 256, dynamic LDS = staged bytes.
+constexpr int kQueriesPerBlock = 64;
+struct StagedTarget { float x, y; uint32_t packed; };   // packed = octave | cx << 8 | cy << 16 | flags << 24 (1: in grid, 2: occupied)
+
+__global__ __launch_bounds__(256) void k_match_topk_lds(MatchProblem P) {
+    extern __shared__ uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.y;
+    const int m = P.q_counts ? P.q_counts[b] : P.m_cap;
+    const int q_begin = blockIdx.x * kQueriesPerBlock;
+    if (q_begin >= m) return;
+    const int n = P.t_counts ? P.t_counts[b] : P.n_cap;
+    const bool windowed = P.mode != PLP_MATCH_MODE_BRUTE_FORCE;
+    const uint8_t* t_desc = P.t_desc + (size_t)b * P.n_cap * 32;
+    StagedTarget* st = reinterpret_cast<StagedTarget*>(smem);
+    float* sxr = reinterpret_cast<float*>(smem + (size_t)P.n_cap * sizeof(StagedTarget));
+    uint4* sdesc = reinterpret_cast<uint4*>(smem);
+    const bool has_xr = P.t_x_right != nullptr;
+    if (windowed) {
+        const plp_keypoint* kps = P.t_kps + (size_t)b * P.n_cap;
+        const float* t_xr = has_xr ? P.t_x_right + (size_t)b * P.n_cap : nullptr;
+        const uint8_t* t_occ = P.t_occupied ? P.t_occupied + (size_t)b * P.n_cap : nullptr;
+        for (int t = tid; t < n; t += 256) {
+            const plp_keypoint k = kps[t];
+            const int cx = floor_d((double)__fsub_rn(k.x, P.grid_min_x) * P.inv_cell_w);
+            const int cy = floor_d((double)__fsub_rn(k.y, P.grid_min_y) * P.inv_cell_h);
+            const bool in_grid = cx >= 0 && cx < P.grid_cols && cy >= 0 && cy < P.grid_rows;
+            uint32_t flags = in_grid ? 1u : 0u;
+            if (t_occ && t_occ[t]) flags |= 2u;
+            st[t].x = k.x; st[t].y = k.y;
+            st[t].packed = ((uint32_t)k.octave & 0xffu) | ((uint32_t)(cx & 0xff) << 8) | ((uint32_t)(cy & 0xff) << 16) | (flags << 24);
+            if (has_xr) sxr[t] = t_xr[t];
+        }
+    } else {
+        const uint4* src = reinterpret_cast<const uint4*>(t_desc);
+        for (int i = tid; i < 2 * n; i += 256) sdesc[i] = src[i];
+    }
+    __syncthreads();
+    const uint8_t* q_valid = P.q_valid ? P.q_valid + (size_t)b * P.m_cap : nullptr;
+    for (int q = q_begin + wv; q < min(m, q_begin + kQueriesPerBlock); q += 4) {
+        unsigned long long* klist = P.klist + ((size_t)b * P.m_cap + q) * kMatchK;
+        int32_t* kcount = P.kcount + (size_t)b * P.m_cap + q;
+        if (q_valid && !q_valid[q]) { if (lane == 0) *kcount = -1; continue; }
+        const QueryCtx c = make_query(P, q, P.q_reproj ? P.q_reproj + (size_t)b * P.m_cap * 2 : nullptr,
+                                      P.q_x_right ? P.q_x_right + (size_t)b * P.m_cap : nullptr,
+                                      P.q_level ? P.q_level + (size_t)b * P.m_cap : nullptr);
+        const uint4* qd = reinterpret_cast<const uint4*>(P.q_desc + ((size_t)b * P.m_cap + q) * 32);
+        const uint4 q0 = qd[0], q1 = qd[1];
+        unsigned long long top[kMatchK];
+#pragma unroll
+        for (int i = 0; i < kMatchK; ++i) top[i] = ~0ull;
+        int passed = 0;
+        if (!windowed) {
+            for (int t = lane; t < n; t += 64) {
+                const unsigned dist = hamming256(q0, q1, sdesc[2 * t], sdesc[2 * t + 1]);
+                ++passed;
+                topk_insert(top, ((unsigned long long)dist << 32) | ((unsigned long long)(unsigned)t << 4));
+            }
+        } else if (!c.empty) {
+            const bool check_level = (0 < c.min_level) || (0 <= c.max_level);
+            for (int t = lane; t < n; t += 64) {
+                const StagedTarget s = st[t];
+                const int oct = (int)(s.packed & 0xff), cx = (int)((s.packed >> 8) & 0xff), cy = (int)((s.packed >> 16) & 0xff);
+                const uint32_t flags = s.packed >> 24;
+                if (flags != 1u) continue;                                   // outside the grid, or already holds an observed landmark
+                if (cx < c.min_cx || cx > c.max_cx || cy < c.min_cy || cy > c.max_cy) continue;
+                if (check_level) {
+                    if (oct < c.min_level) continue;
+                    if (0 <= c.max_level && c.max_level < oct) continue;
+                }
+                if (!(fabsf(__fsub_rn(s.x, c.rx)) < c.mg && fabsf(__fsub_rn(s.y, c.ry)) < c.mg)) continue;
+                if (has_xr) {
+                    const float xr = sxr[t];
+                    if (0 < xr && c.mg < fabsf(__fsub_rn(c.xr, xr))) continue;
+                }
+                const uint4* d = reinterpret_cast<const uint4*>(t_desc + 32 * (size_t)t);
+                const unsigned dist = hamming256(q0, q1, d[0], d[1]);
+                const unsigned order = ((unsigned)(cx * P.grid_rows + cy) << 16) | (unsigned)t;
+                ++passed;
+                topk_insert(top, ((unsigned long long)dist << 32) | ((unsigned long long)order << 4) | (unsigned)(oct & 15));
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) passed += __shfl_xor(passed, o);
+        topk_merge_store(top, lane, klist);
+        if (lane == 0) *kcount = passed;
+    }
 }
 
 // accept rules of the three matchers; best/second are (distance, octave) of the two best free candidates
@@ -328,7 +427,12 @@ __global__ __launch_bounds__(256) void k_hamming_matrix(const uint8_t* __restric
 }
 
 void launch_match(hipStream_t st, const MatchProblem& P, int B) {
-    hipLaunchKernelGGL(k_match_topk, dim3((P.m_cap + 3) / 4, B), dim3(256), 0, st, P);
+    const bool windowed = P.mode != PLP_MATCH_MODE_BRUTE_FORCE;
+    const size_t staged = windowed ? (size_t)P.n_cap * (sizeof(StagedTarget) + (P.t_x_right ? 4 : 0)) : (size_t)P.n_cap * 32;
+    if (staged <= 64 * 1024 && (!windowed || (P.grid_cols <= 255 && P.grid_rows <= 255)))
+        hipLaunchKernelGGL(k_match_topk_lds, dim3((P.m_cap + kQueriesPerBlock - 1) / kQueriesPerBlock, B), dim3(256), staged, st, P);
+    else
+        hipLaunchKernelGGL(k_match_topk, dim3((P.m_cap + 3) / 4, B), dim3(256), 0, st, P);
     hipLaunchKernelGGL(k_match_resolve, dim3(B), dim3(256), (size_t)P.n_cap * 8, st, P);
 }
 
