@@ -23,6 +23,7 @@ struct plp_line {
     LbdWeightsDev w{};
     DevBuf tabs, blur11, scaled, ang, mod, cs, bin, maxgrad, undef, order, reg, raw, n_raw, blur5, dx, dy, all_kl, all_lbd, n_all, status;
     DevBuf l0copy, s_kl, s_lbd, s_fn, s_cnt;   // host-API staging
+    DevBuf aligned;                             // aligned copy of odd-pitch device frames
     int s_cap = 0;
     int last_B = 0;
     hipStream_t last_stream = nullptr;
@@ -139,7 +140,15 @@ plp_status run(plp_line* c, const uint8_t* d_imgs, int B, int rows, int cols, si
     PLP_HIP(hipSetDevice(c->device));
     PLP_TRY(build(c, rows, cols));
     PLP_TRY(ensure(c, B));
-    c->P.img = d_imgs; c->P.img_frame_stride = frame_stride; c->P.img_pitch = (int)step;
+    if (((uintptr_t)d_imgs % 4 == 0) && (step % 4 == 0) && (frame_stride % 4 == 0)) {
+        c->P.img = d_imgs; c->P.img_frame_stride = frame_stride; c->P.img_pitch = (int)step;
+    } else {   // the tile loaders read aligned dwords: one aligned copy of odd-pitch frames
+        const size_t fs = (size_t)c->P.pitch * rows;
+        PLP_HIP(c->aligned.reserve(fs * B));
+        for (int f = 0; f < B; ++f)
+            PLP_HIP(hipMemcpy2DAsync((uint8_t*)c->aligned.p + f * fs, c->P.pitch, d_imgs + f * frame_stride, step, cols, rows, hipMemcpyDeviceToDevice, st));
+        c->P.img = (const uint8_t*)c->aligned.p; c->P.img_frame_stride = fs; c->P.img_pitch = c->P.pitch;
+    }
     PLP_HIP(hipMemsetAsync(c->status.p, 0, 16, st));
     launch_line_front(st, c->P, c->lp, c->rt, c->t11, c->t5, c->w, d_kl, d_lbd, d_fn, cap, d_counts, B, c->profiling ? c->ev : nullptr);
     PLP_HIP(hipGetLastError());

@@ -21,6 +21,7 @@
 
 #include <algorithm>
 
+#include "blur_tile.hpp"
 #include "line_device.hpp"
 
 namespace plp {
@@ -54,47 +55,14 @@ __device__ __forceinline__ float fast_atan2_deg_l(float y, float x) {   // cv::f
 }
 
 // ------------------------------------------------------------------------------------------ blur
-// out = (sum_j k[j] * (sum_i k[i] * src) + 32768) >> 16 with REFLECT_101; 64x32 output tile per workgroup.
+// (2R+1)-tap fixed-point Gaussian of one plane per frame (blur_tile.hpp); 128 x 64 output tile per workgroup.
 template <int R>
 __global__ __launch_bounds__(256) void k_blur_plane(const uint8_t* __restrict__ src, size_t src_fs, int src_pitch,
                                                     uint8_t* __restrict__ dst, size_t dst_fs, int dst_pitch, int w, int h, BlurTapsN taps) {
-    constexpr int TW = 64, TH = 32, K = 2 * R + 1, IW = TW + 2 * R + 2;
-    __shared__ uint8_t in[(TH + 2 * R) * IW];
-    __shared__ uint16_t hs[(TH + 2 * R) * TW];
-    const int tiles_x = (w + TW - 1) / TW;
-    const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
-    const int tid = threadIdx.x;
-    const uint8_t* img = src + (size_t)blockIdx.y * src_fs;
-    for (int i = tid; i < (TH + 2 * R) * (TW + 2 * R); i += 256) {
-        const int r = i / (TW + 2 * R), c = i - r * (TW + 2 * R);
-        in[r * IW + c] = img[(size_t)reflect101_l(ty0 + r - R, h) * src_pitch + reflect101_l(tx0 + c - R, w)];
-    }
-    __syncthreads();
-    for (int i = tid; i < (TH + 2 * R) * TW; i += 256) {
-        const int r = i / TW, c = i - r * TW;
-        uint32_t a = 0;
-#pragma unroll
-        for (int k = 0; k < K; ++k) a += (uint32_t)taps.k[k] * in[r * IW + c + k];
-        hs[i] = (uint16_t)a;
-    }
-    __syncthreads();
-    uint8_t* out = dst + (size_t)blockIdx.y * dst_fs;
-    const int cx = (tid & 15) * 4, ry = tid >> 4;
-#pragma unroll
-    for (int sweep = 0; sweep < 2; ++sweep) {
-        const int r = ry + sweep * 16, y = ty0 + r, x = tx0 + cx;
-        if (y < h && x < w) {
-            uint32_t packed = 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                uint32_t a = 0;
-#pragma unroll
-                for (int k = 0; k < K; ++k) a += (uint32_t)taps.k[k] * hs[(r + k) * TW + cx + i];
-                packed |= min((a + 32768u) >> 16, 255u) << (8 * i);
-            }
-            *reinterpret_cast<uint32_t*>(out + (size_t)y * dst_pitch + x) = packed;
-        }
-    }
+    __shared__ BlurTileLds<R> S;
+    const int tiles_x = (w + kBlurTW - 1) / kBlurTW;
+    blur_tile<R>(S, src + (size_t)blockIdx.y * src_fs, src_pitch, dst + (size_t)blockIdx.y * dst_fs, dst_pitch, w, h,
+                 (blockIdx.x % tiles_x) * kBlurTW, (blockIdx.x / tiles_x) * kBlurTH, taps.k);
 }
 
 // ------------------------------------------------------------------------------------------ x0.5 INTER_LINEAR_EXACT
@@ -760,7 +728,7 @@ void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp,
                        int32_t* out_counts, int B, hipEvent_t* ev) {
     auto mark = [&](int i) { if (ev) (void)hipEventRecord(ev[i], st); };
     const size_t plane_fs = (size_t)P.pitch * P.H, splane_fs = (size_t)P.spitch * P.sh;
-    const int tiles = ((P.W + 63) / 64) * ((P.H + 31) / 32);
+    const int tiles = ((P.W + 127) / 128) * ((P.H + 63) / 64);
     (void)hipMemsetAsync(P.maxgrad, 0, sizeof(unsigned long long) * B, st);
     mark(0);
     hipLaunchKernelGGL(k_blur_plane<5>, dim3(tiles, B), dim3(256), 0, st, P.img, P.img_frame_stride, P.img_pitch, P.blur11, plane_fs,

@@ -100,7 +100,7 @@ plp_status build_geometry(plp_orb* c, int rows, int cols) {
         const LevelGeom& G = c->geo.lv[l];
         LevelDev& L = c->h_lv[l];
         L.w = G.w; L.h = G.h; L.pitch = G.pitch; L.off = G.off;
-        L.blur_tiles = ((G.w + 63) / 64) * ((G.h + 31) / 32);
+        L.blur_tiles = ((G.w + 127) / 128) * ((G.h + 63) / 64);
         c->total_blur_tiles += L.blur_tiles;
         L.scale = c->st.sf[l];
         L.sel_base = G.sel_base; L.sel_cap = G.sel_cap;

@@ -11,7 +11,7 @@ namespace plp {
 // Per-level constants as seen by the kernels (array of n_levels in HBM + a host copy).
 struct LevelDev {
     int w, h, pitch;        // level size, row pitch in the pyramid / blur planes
-    int blur_tiles;         // number of 64x32 blur tiles of this level
+    int blur_tiles;         // number of 128x64 blur tiles of this level
     size_t off;             // byte offset of the level inside one frame's plane set
     float scale;            // scale_factors_[level]
     int sel_base, sel_cap;  // slot range of this level in the per-frame selected list

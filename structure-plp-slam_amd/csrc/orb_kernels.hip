@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "blur_tile.hpp"
 #include "orb_device.hpp"
 
 namespace plp {
@@ -213,66 +214,20 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbPlanes pl, const CellDesc
 }
 
 // ------------------------------------------------------------------------------------------
-// K6  7x7 sigma-2 Gaussian, 8.8 fixed-point taps (sum 256), exact separable integer passes:
-// out = (sum_j k[j] * (sum_i k[i] * src) + 32768) >> 16, BORDER_REFLECT_101.
-// One workgroup = 64 x 32 output tile of one level of one frame; all levels in one launch.
+// K6  7x7 sigma-2 Gaussian, 8.8 fixed-point taps (sum 256), exact separable integer passes (blur_tile.hpp).
+// One workgroup = 128 x 64 output tile of one level of one frame; all levels in one launch.
 // grid = (tiles of all levels, B), block = 256.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ int reflect101(int p, int len) {
-    if (len == 1) return 0;
-    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p;
-    return p;
-}
-
 __global__ __launch_bounds__(256) void k_blur7(OrbPlanes pl, uint8_t* __restrict__ blur_base, size_t blur_frame_stride,
                                                const LevelDev* __restrict__ lv, int n_levels, BlurTaps taps) {
-    constexpr int TW = 64, TH = 32, R = 3;
-    __shared__ uint8_t in[(TH + 2 * R) * (TW + 2 * R + 2)];
-    __shared__ uint16_t hs[(TH + 2 * R) * TW];
-    constexpr int IW = TW + 2 * R + 2;   // 72
-
+    __shared__ BlurTileLds<3> S;
     int level = 0, t = blockIdx.x;
     while (level + 1 < n_levels && t >= lv[level].blur_tiles) { t -= lv[level].blur_tiles; ++level; }
     const LevelDev L = lv[level];
-    const int tiles_x = (L.w + TW - 1) / TW;
-    const int ty0 = (t / tiles_x) * TH, tx0 = (t % tiles_x) * TW;
-    const int frame = blockIdx.y, tid = threadIdx.x;
-    const uint8_t* img = pl.level_ptr(frame, level, L);
-    const int pitch = pl.level_pitch(level, L);
-
-    for (int i = tid; i < (TH + 2 * R) * (TW + 2 * R); i += 256) {
-        const int r = i / (TW + 2 * R), c = i - r * (TW + 2 * R);
-        const int y = reflect101(ty0 + r - R, L.h), x = reflect101(tx0 + c - R, L.w);
-        in[r * IW + c] = img[(size_t)y * pitch + x];
-    }
-    __syncthreads();
-    for (int i = tid; i < (TH + 2 * R) * TW; i += 256) {
-        const int r = i / TW, c = i - r * TW;
-        const uint8_t* p = &in[r * IW + c];
-        uint32_t a = 0;
-#pragma unroll
-        for (int k = 0; k < 7; ++k) a += (uint32_t)taps.k[k] * p[k];
-        hs[i] = (uint16_t)a;
-    }
-    __syncthreads();
-    uint8_t* out = blur_base + (size_t)frame * blur_frame_stride + L.off;
-    const int cx = (tid & 15) * 4, ry = tid >> 4;   // 16 threads x 4 px across, 16 rows per sweep
-#pragma unroll
-    for (int sweep = 0; sweep < 2; ++sweep) {
-        const int r = ry + sweep * 16;
-        const int y = ty0 + r, x = tx0 + cx;
-        if (y < L.h && x < L.w) {
-            uint32_t packed = 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                uint32_t a = 0;
-#pragma unroll
-                for (int k = 0; k < 7; ++k) a += (uint32_t)taps.k[k] * hs[(r + k) * TW + cx + i];
-                packed |= min((a + 32768u) >> 16, 255u) << (8 * i);
-            }
-            *reinterpret_cast<uint32_t*>(out + (size_t)y * L.pitch + x) = packed;   // pitch is a 64-B multiple
-        }
-    }
+    const int tiles_x = (L.w + kBlurTW - 1) / kBlurTW;
+    const int frame = blockIdx.y;
+    blur_tile<3>(S, pl.level_ptr(frame, level, L), pl.level_pitch(level, L), blur_base + (size_t)frame * blur_frame_stride + L.off, L.pitch,
+                 L.w, L.h, (t % tiles_x) * kBlurTW, (t / tiles_x) * kBlurTH, taps.k);
 }
 
 // ------------------------------------------------------------------------------------------
