@@ -13,7 +13,7 @@ using namespace plp;
 struct plp_matcher {
     int device = 0;
     hipStream_t stream = nullptr;
-    DevBuf klist, kcount, claim;             // scratch of the device path
+    DevBuf klist, kcount, claim, full_list;  // scratch of the device path
     DevBuf stage;                            // one slab for the host-pointer path
     std::mutex mu;
 };
@@ -42,6 +42,7 @@ plp_status run_device(plp_matcher* c, const plp_match_args* a, hipStream_t st) {
     PLP_HIP(c->klist.reserve(qn * kMatchK * 8));
     PLP_HIP(c->kcount.reserve(qn * 4));
     PLP_HIP(c->claim.reserve(qn * 4));
+    PLP_HIP(c->full_list.reserve(qn * 4));
     MatchProblem P{};
     P.mode = a->mode; P.n_cap = a->n_cap; P.m_cap = a->m_cap;
     P.t_kps = a->mode == PLP_MATCH_MODE_BRUTE_FORCE ? nullptr : a->t_kps;
@@ -53,7 +54,7 @@ plp_status run_device(plp_matcher* c, const plp_match_args* a, hipStream_t st) {
     for (int i = 0; i < 16; ++i) P.scale_factors[i] = (a->scale_factors && i < a->num_levels) ? a->scale_factors[i] : 1.0f;
     P.grid_min_x = a->grid.min_x; P.grid_min_y = a->grid.min_y; P.inv_cell_w = a->grid.inv_cell_width; P.inv_cell_h = a->grid.inv_cell_height;
     P.grid_cols = a->grid.cols; P.grid_rows = a->grid.rows;
-    P.klist = (unsigned long long*)c->klist.p; P.kcount = (int32_t*)c->kcount.p; P.claim = (int32_t*)c->claim.p;
+    P.klist = (unsigned long long*)c->klist.p; P.kcount = (int32_t*)c->kcount.p; P.claim = (int32_t*)c->claim.p; P.full_list = (int32_t*)c->full_list.p;
     P.out_match = a->out_match; P.out_num = a->out_num;
     launch_match(st, P, a->B);
     PLP_HIP(hipGetLastError());

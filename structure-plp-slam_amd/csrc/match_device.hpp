@@ -40,6 +40,7 @@ struct MatchProblem {
     unsigned long long* klist;       // B x m_cap x kMatchK
     int32_t* kcount;                 // B x m_cap
     int32_t* claim;                  // B x m_cap
+    int32_t* full_list;              // B x m_cap
     int32_t* out_match;              // B x n_cap: query index per key point, -1 = none
     int32_t* out_num;                // B
 };

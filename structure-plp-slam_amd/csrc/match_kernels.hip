@@ -159,14 +159,18 @@ __global__ __launch_bounds__(256) void k_match_topk(MatchProblem P) {
 
 // Main path: the frame's targets are staged ONCE per workgroup in LDS and reused by kQueriesPerBlock queries
 // (a wave scanning 1000 key points from L2 for each of ~3000 queries made the kernel L2-bandwidth bound).
-//   windowed modes: 12 B per target {x, y, octave | cell col | cell row | flags} (+4 B stereo x_right)
+//   windowed modes: 16 B per free in-grid target {x, y, octave | cell col | cell row, index}, bucketed by grid ROW
+//                   (counting sort with LDS atomics; the order inside a bucket is irrelevant because every
+//                   candidate key carries the reference's visiting order), so a query only walks the rows its
+//                   window overlaps; (+4 B stereo x_right)
 //   brute force:    the 32-byte descriptors themselves
 // grid = (ceil(m_cap / kQueriesPerBlock), B), block = 256, dynamic LDS = staged bytes.
 constexpr int kQueriesPerBlock = 64;
-struct StagedTarget { float x, y; uint32_t packed; };   // packed = octave | cx << 8 | cy << 16 | flags << 24 (1: in grid, 2: occupied)
+struct StagedTarget { float x, y; uint32_t packed; uint32_t t; };   // packed = octave | cx << 8 | cy << 16
 
 __global__ __launch_bounds__(256) void k_match_topk_lds(MatchProblem P) {
     extern __shared__ uint8_t smem[];
+    __shared__ int row_start[257], row_fill[256];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.y;
     const int m = P.q_counts ? P.q_counts[b] : P.m_cap;
     const int q_begin = blockIdx.x * kQueriesPerBlock;
@@ -182,16 +186,30 @@ __global__ __launch_bounds__(256) void k_match_topk_lds(MatchProblem P) {
         const plp_keypoint* kps = P.t_kps + (size_t)b * P.n_cap;
         const float* t_xr = has_xr ? P.t_x_right + (size_t)b * P.n_cap : nullptr;
         const uint8_t* t_occ = P.t_occupied ? P.t_occupied + (size_t)b * P.n_cap : nullptr;
-        for (int t = tid; t < n; t += 256) {
+        for (int i = tid; i < 257; i += 256) row_start[i] = 0;
+        if (tid < 256) row_fill[tid] = 0;
+        __syncthreads();
+        auto cell_of = [&](const plp_keypoint& k, int t, int& cx, int& cy) -> bool {
+            cx = floor_d((double)__fsub_rn(k.x, P.grid_min_x) * P.inv_cell_w);
+            cy = floor_d((double)__fsub_rn(k.y, P.grid_min_y) * P.inv_cell_h);
+            return cx >= 0 && cx < P.grid_cols && cy >= 0 && cy < P.grid_rows && !(t_occ && t_occ[t]);
+        };
+        for (int t = tid; t < n; t += 256) {   // pass 1: bucket sizes
+            int cx, cy;
+            if (cell_of(kps[t], t, cx, cy)) atomicAdd(&row_start[cy + 1], 1);
+        }
+        __syncthreads();
+        if (tid == 0) for (int r = 0; r < P.grid_rows; ++r) row_start[r + 1] += row_start[r];
+        __syncthreads();
+        for (int t = tid; t < n; t += 256) {   // pass 2: scatter
             const plp_keypoint k = kps[t];
-            const int cx = floor_d((double)__fsub_rn(k.x, P.grid_min_x) * P.inv_cell_w);
-            const int cy = floor_d((double)__fsub_rn(k.y, P.grid_min_y) * P.inv_cell_h);
-            const bool in_grid = cx >= 0 && cx < P.grid_cols && cy >= 0 && cy < P.grid_rows;
-            uint32_t flags = in_grid ? 1u : 0u;
-            if (t_occ && t_occ[t]) flags |= 2u;
-            st[t].x = k.x; st[t].y = k.y;
-            st[t].packed = ((uint32_t)k.octave & 0xffu) | ((uint32_t)(cx & 0xff) << 8) | ((uint32_t)(cy & 0xff) << 16) | (flags << 24);
-            if (has_xr) sxr[t] = t_xr[t];
+            int cx, cy;
+            if (!cell_of(k, t, cx, cy)) continue;
+            const int pos = row_start[cy] + atomicAdd(&row_fill[cy], 1);
+            st[pos].x = k.x; st[pos].y = k.y;
+            st[pos].packed = ((uint32_t)k.octave & 0xffu) | ((uint32_t)cx << 8) | ((uint32_t)cy << 16);
+            st[pos].t = (uint32_t)t;
+            if (has_xr) sxr[pos] = t_xr[t];
         }
     } else {
         const uint4* src = reinterpret_cast<const uint4*>(t_desc);
@@ -220,24 +238,23 @@ __global__ __launch_bounds__(256) void k_match_topk_lds(MatchProblem P) {
             }
         } else if (!c.empty) {
             const bool check_level = (0 < c.min_level) || (0 <= c.max_level);
-            for (int t = lane; t < n; t += 64) {
-                const StagedTarget s = st[t];
-                const int oct = (int)(s.packed & 0xff), cx = (int)((s.packed >> 8) & 0xff), cy = (int)((s.packed >> 16) & 0xff);
-                const uint32_t flags = s.packed >> 24;
-                if (flags != 1u) continue;                                   // outside the grid, or already holds an observed landmark
-                if (cx < c.min_cx || cx > c.max_cx || cy < c.min_cy || cy > c.max_cy) continue;
+            const int i0 = row_start[c.min_cy], i1 = row_start[c.max_cy + 1];   // only the grid rows the window overlaps
+            for (int i = i0 + lane; i < i1; i += 64) {
+                const StagedTarget s = st[i];
+                const int oct = (int)(s.packed & 0xff), cx = (int)((s.packed >> 8) & 0xff), cy = (int)(s.packed >> 16);
+                if (cx < c.min_cx || cx > c.max_cx) continue;
                 if (check_level) {
                     if (oct < c.min_level) continue;
                     if (0 <= c.max_level && c.max_level < oct) continue;
                 }
                 if (!(fabsf(__fsub_rn(s.x, c.rx)) < c.mg && fabsf(__fsub_rn(s.y, c.ry)) < c.mg)) continue;
                 if (has_xr) {
-                    const float xr = sxr[t];
+                    const float xr = sxr[i];
                     if (0 < xr && c.mg < fabsf(__fsub_rn(c.xr, xr))) continue;
                 }
-                const uint4* d = reinterpret_cast<const uint4*>(t_desc + 32 * (size_t)t);
+                const uint4* d = reinterpret_cast<const uint4*>(t_desc + 32 * (size_t)s.t);
                 const unsigned dist = hamming256(q0, q1, d[0], d[1]);
-                const unsigned order = ((unsigned)(cx * P.grid_rows + cy) << 16) | (unsigned)t;
+                const unsigned order = ((unsigned)(cx * P.grid_rows + cy) << 16) | s.t;
                 ++passed;
                 topk_insert(top, ((unsigned long long)dist << 32) | ((unsigned long long)order << 4) | (unsigned)(oct & 15));
             }
@@ -266,7 +283,6 @@ __device__ __forceinline__ bool accept(const MatchProblem& P, unsigned best, int
 __global__ __launch_bounds__(256) void k_match_resolve(MatchProblem P) {
     extern __shared__ int32_t lds[];
     __shared__ int s_changed, s_num, s_hist[32], s_valid_bin[32], s_full_n;
-    __shared__ int s_full[256];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.x;
     const int m = P.q_counts ? P.q_counts[b] : P.m_cap;
     const int n = P.t_counts ? P.t_counts[b] : P.n_cap;
@@ -289,65 +305,59 @@ __global__ __launch_bounds__(256) void k_match_resolve(MatchProblem P) {
     for (int q = tid; q < m; q += 256) claim[q] = -1;
     __syncthreads();
 
+    int32_t* full_list = P.full_list + (size_t)b * P.m_cap;   // queries whose truncated best-K list ran dry this round
     for (int round = 0; round <= m; ++round) {
         if (tid == 0) { s_changed = 0; s_full_n = 0; }
         for (int t = tid; t < n; t += 256) owner_next[t] = 0x7fffffff;
         __syncthreads();
-        for (int base = 0; base < m; base += 256) {
-            const int q = base + tid;
-            int new_claim = -1;
-            bool need_full = false;
-            if (q < m && kcount[q] > 0) {
-                const int cnt = kcount[q], have = min(cnt, kMatchK);
-                unsigned best = 256, second = 256;
-                int best_lvl = -1, second_lvl = -1, best_t = -1, found = 0;
-                for (int e = 0; e < have && found < 2; ++e) {
-                    const unsigned long long key = klist[(size_t)q * kMatchK + e];
-                    const int t = (int)((key >> 4) & 0xffff);
-                    if (owner_prev[t] < q) continue;   // taken by an earlier query
-                    if (found == 0) { best = (unsigned)(key >> 32); best_lvl = (int)(key & 15); best_t = t; }
-                    else { second = (unsigned)(key >> 32); second_lvl = (int)(key & 15); }
-                    ++found;
-                }
-                if (found < 2 && cnt > kMatchK) need_full = true;   // list truncated and exhausted: exact rescan below
-                else if (found > 0 && accept(P, best, best_lvl, second, second_lvl)) new_claim = best_t;
+        for (int q = tid; q < m; q += 256) {
+            const int cnt = kcount[q];
+            if (cnt <= 0) continue;
+            const int have = min(cnt, kMatchK);
+            unsigned best = 256, second = 256;
+            int best_lvl = -1, second_lvl = -1, best_t = -1, found = 0;
+            for (int e = 0; e < have && found < 2; ++e) {
+                const unsigned long long key = klist[(size_t)q * kMatchK + e];
+                const int t = (int)((key >> 4) & 0xffff);
+                if (owner_prev[t] < q) continue;   // taken by an earlier query
+                if (found == 0) { best = (unsigned)(key >> 32); best_lvl = (int)(key & 15); best_t = t; }
+                else { second = (unsigned)(key >> 32); second_lvl = (int)(key & 15); }
+                ++found;
             }
-            if (need_full) s_full[atomicAdd(&s_full_n, 1)] = q;   // at most 256 per sweep
-            if (q < m && !need_full) {
-                if (claim[q] != new_claim) { claim[q] = new_claim; s_changed = 1; }
-                if (new_claim >= 0 && (!has_obs || has_obs[q] || P.mode == PLP_MATCH_MODE_BRUTE_FORCE)) atomicMin(&owner_next[new_claim], q);
-            }
-            __syncthreads();
-            // rare: exact two-best over ALL targets with the occupancy filter, one wave per query
-            const int nf = min(s_full_n, 256);
-            for (int f = wv; f < nf; f += 4) {
-                const int fq = s_full[f];
-                const QueryCtx c = make_query(P, fq, q_reproj, q_xr, q_level);
-                const uint4* qd = reinterpret_cast<const uint4*>(P.q_desc + ((size_t)b * P.m_cap + fq) * 32);
-                const uint4 q0 = qd[0], q1 = qd[1];
-                unsigned long long k0 = ~0ull, k1 = ~0ull;
+            if (found < 2 && cnt > kMatchK) { full_list[atomicAdd(&s_full_n, 1)] = q; continue; }   // exact rescan below
+            const int new_claim = (found > 0 && accept(P, best, best_lvl, second, second_lvl)) ? best_t : -1;
+            if (claim[q] != new_claim) { claim[q] = new_claim; s_changed = 1; }
+            if (new_claim >= 0 && (!has_obs || has_obs[q] || P.mode == PLP_MATCH_MODE_BRUTE_FORCE)) atomicMin(&owner_next[new_claim], q);
+        }
+        __syncthreads();
+        // rare: exact two-best over ALL targets with the occupancy filter, one wave per query
+        const int nf = s_full_n;
+        for (int f = wv; f < nf; f += 4) {
+            const int fq = full_list[f];
+            const QueryCtx c = make_query(P, fq, q_reproj, q_xr, q_level);
+            const uint4* qd = reinterpret_cast<const uint4*>(P.q_desc + ((size_t)b * P.m_cap + fq) * 32);
+            const uint4 q0 = qd[0], q1 = qd[1];
+            unsigned long long k0 = ~0ull, k1 = ~0ull;
+            if (!(c.windowed && c.empty))
                 for (int t = lane; t < n; t += 64) {
                     if (owner_prev[t] < fq) continue;
                     const unsigned long long key = candidate_key(P, c, t, kps, t_desc, t_xr, t_occ, q0, q1);
                     if (key < k0) { k1 = k0; k0 = key; } else if (key < k1) k1 = key;
                 }
-                const unsigned long long g0 = wave_min_u64(k0);
-                const unsigned long long g1 = wave_min_u64(k0 == g0 ? k1 : k0);
-                if (lane == 0) {
-                    int nc = -1;
-                    if (g0 != ~0ull) {
-                        const unsigned second = g1 != ~0ull ? (unsigned)(g1 >> 32) : 256u;
-                        const int second_lvl = g1 != ~0ull ? (int)(g1 & 15) : -1;
-                        if (accept(P, (unsigned)(g0 >> 32), (int)(g0 & 15), second, second_lvl)) nc = (int)((g0 >> 4) & 0xffff);
-                    }
-                    if (claim[fq] != nc) { claim[fq] = nc; s_changed = 1; }
-                    if (nc >= 0 && (!has_obs || has_obs[fq] || P.mode == PLP_MATCH_MODE_BRUTE_FORCE)) atomicMin(&owner_next[nc], fq);
+            const unsigned long long g0 = wave_min_u64(k0);
+            const unsigned long long g1 = wave_min_u64(k0 == g0 ? k1 : k0);
+            if (lane == 0) {
+                int nc = -1;
+                if (g0 != ~0ull) {
+                    const unsigned second = g1 != ~0ull ? (unsigned)(g1 >> 32) : 256u;
+                    const int second_lvl = g1 != ~0ull ? (int)(g1 & 15) : -1;
+                    if (accept(P, (unsigned)(g0 >> 32), (int)(g0 & 15), second, second_lvl)) nc = (int)((g0 >> 4) & 0xffff);
                 }
+                if (claim[fq] != nc) { claim[fq] = nc; s_changed = 1; }
+                if (nc >= 0 && (!has_obs || has_obs[fq] || P.mode == PLP_MATCH_MODE_BRUTE_FORCE)) atomicMin(&owner_next[nc], fq);
             }
-            __syncthreads();
-            if (tid == 0) s_full_n = 0;
-            __syncthreads();
         }
+        __syncthreads();
         int32_t* t = owner_prev; owner_prev = owner_next; owner_next = t;
         const int changed = s_changed;
         __syncthreads();

@@ -17,7 +17,7 @@ namespace plp {
 
 // ------------------------------------------------------------------------------------------
 // K1  bilinear 11-bit fixed-point down-scale, 4 destination pixels per thread (one u32 store).
-// grid = (ceil(dw/256), ceil(dh/4), B), block = (64, 4)
+// grid = (ceil(dw/256), ceil(dh/32), B), block = (64, 4); a thread makes 4 pixels x 8 rows
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_resize_linear(const uint8_t* __restrict__ src_base, size_t src_frame_stride,
                                                        int src_pitch, uint8_t* __restrict__ dst_base,
@@ -26,26 +26,36 @@ __global__ __launch_bounds__(256) void k_resize_linear(const uint8_t* __restrict
                                                        const int16_t* __restrict__ a0, const int16_t* __restrict__ a1,
                                                        const int16_t* __restrict__ yofs0, const int16_t* __restrict__ yofs1,
                                                        const int16_t* __restrict__ b0, const int16_t* __restrict__ b1) {
-    const int dy = blockIdx.y * 4 + threadIdx.y;
+    constexpr int ROWS = 8;   // rows per thread: the 4 column coefficient sets are loaded once and reused
+    const int dy0 = (blockIdx.y * 4 + threadIdx.y) * ROWS;
     const int dx0 = (blockIdx.x * 64 + threadIdx.x) * 4;
-    if (dy >= dh || dx0 >= dw) return;
+    if (dy0 >= dh || dx0 >= dw) return;
     const uint8_t* src = src_base + (size_t)blockIdx.z * src_frame_stride;
     uint8_t* dst = dst_base + (size_t)blockIdx.z * dst_frame_stride;
-    const uint8_t* S0 = src + (size_t)yofs0[dy] * src_pitch;
-    const uint8_t* S1 = src + (size_t)yofs1[dy] * src_pitch;
-    const int wb0 = b0[dy], wb1 = b1[dy];
-    uint32_t packed = 0;
+    int x0[4], x1[4], wa0[4], wa1[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int dx = min(dx0 + i, dw - 1);
-        const int x0 = xofs0[dx], x1 = xofs1[dx], wa0 = a0[dx], wa1 = a1[dx];
-        const int h0 = S0[x0] * wa0 + S0[x1] * wa1;
-        const int h1 = S1[x0] * wa0 + S1[x1] * wa1;
-        const int v = (((wb0 * (h0 >> 4)) >> 16) + ((wb1 * (h1 >> 4)) >> 16) + 2) >> 2;
-        packed |= (uint32_t)(v & 255) << (8 * i);
+        x0[i] = xofs0[dx]; x1[i] = xofs1[dx]; wa0[i] = a0[dx]; wa1[i] = a1[dx];
     }
-    // rows are padded to a 64-byte pitch, so the 4-byte store never leaves the row
-    *reinterpret_cast<uint32_t*>(dst + (size_t)dy * dst_pitch + dx0) = packed;
+#pragma unroll 2
+    for (int r = 0; r < ROWS; ++r) {
+        const int dy = dy0 + r;
+        if (dy >= dh) break;
+        const uint8_t* S0 = src + (size_t)yofs0[dy] * src_pitch;
+        const uint8_t* S1 = src + (size_t)yofs1[dy] * src_pitch;
+        const int wb0 = b0[dy], wb1 = b1[dy];
+        uint32_t packed = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int h0 = S0[x0[i]] * wa0[i] + S0[x1[i]] * wa1[i];
+            const int h1 = S1[x0[i]] * wa0[i] + S1[x1[i]] * wa1[i];
+            const int v = (((wb0 * (h0 >> 4)) >> 16) + ((wb1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            packed |= (uint32_t)(v & 255) << (8 * i);
+        }
+        // rows are padded to a 64-byte pitch, so the 4-byte store never leaves the row
+        *reinterpret_cast<uint32_t*>(dst + (size_t)dy * dst_pitch + dx0) = packed;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -181,35 +191,41 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbPlanes pl, const CellDesc
     __syncthreads();
     const int thr = n_ini > 0 ? ini_thr : min_thr;   // empty at ini_thr -> redo at min_thr (:408-412)
 
-    // pass 4: ordered (row-major) compaction of the survivors, 256 tested pixels per step
+    // pass 4: ordered (row-major) compaction of the survivors.  Wave w owns the w-th quarter of the row-major
+    // sequence: count with ballots, one barrier for the wave bases, then write (no per-step barriers).
     uint32_t* out = cell_cand + (size_t)out_slot * kCellCap;
     const int lane = tid & 63, wv = tid >> 6;
-    const int total = tw * th;
-    for (int base = 0; base < total; base += 256) {
-        const int i = base + tid;
-        bool emit = false;
+    const int total = tw * th, per = (total + 3) / 4, j0 = wv * per, j1 = min(total, j0 + per);
+    auto survivor = [&](int i, int& ty, int& tx, int& v) -> bool {
+        if (i >= j1) return false;
+        ty = i / tw; tx = i - ty * tw;
+        v = keep[ty * 64 + tx];
+        bool emit = v >= thr && v > 0;
+        if (emit && mk) emit = !masked(cd.min_y + ty + 3, cd.min_x + tx + 3);   // (:429)
+        return emit;
+    };
+    int cnt = 0;
+    for (int g = j0; g < j1; g += 64) {
+        int ty, tx, v;
+        cnt += __popcll(__ballot(survivor(g + lane, ty, tx, v)));
+    }
+    if (lane == 0) wave_tot[wv] = cnt;
+    __syncthreads();
+    int off = 0;
+    for (int k = 0; k < wv; ++k) off += wave_tot[k];
+    for (int g = j0; g < j1; g += 64) {
         int ty = 0, tx = 0, v = 0;
-        if (i < total) {
-            ty = i / tw; tx = i - ty * tw;
-            v = keep[ty * 64 + tx];
-            emit = v >= thr && v > 0;
-            if (emit && mk) emit = !masked(cd.min_y + ty + 3, cd.min_x + tx + 3);   // (:429)
-        }
+        const bool emit = survivor(g + lane, ty, tx, v);
         const unsigned long long bal = __ballot(emit);
-        if (lane == 0) wave_tot[wv] = __popcll(bal);
-        __syncthreads();
-        int off = run_base;
-        for (int k = 0; k < wv; ++k) off += wave_tot[k];
         if (emit) {
-            off += __popcll(bal & ((1ull << lane) - 1ull));
             // border-relative position: ROI coordinate + cell index * 64 (orb_extractor.cc:426-427)
             const uint32_t x = (uint32_t)(tx + 3 + cd.cx * kCellSize), y = (uint32_t)(ty + 3 + cd.cy * kCellSize);
-            out[off] = x | (y << 12) | ((uint32_t)v << 24);
+            out[off + __popcll(bal & ((1ull << lane) - 1ull))] = x | (y << 12) | ((uint32_t)v << 24);
         }
-        __syncthreads();
-        if (tid == 0) run_base += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
-        __syncthreads();
+        off += __popcll(bal);
     }
+    if (tid == 0) run_base = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    __syncthreads();
     if (tid == 0) cell_count[out_slot] = run_base;
 }
 
@@ -365,7 +381,7 @@ void launch_resize(hipStream_t st, const OrbPlanes& pl, const LevelDev* h_lv, in
     const uint8_t* src = level - 1 == 0 ? pl.l0 : pl.pyr + S.off;
     const size_t sstride = level - 1 == 0 ? pl.l0_frame_stride : pl.pyr_frame_stride;
     const int spitch = level - 1 == 0 ? pl.l0_pitch : S.pitch;
-    dim3 grid((D.w + 255) / 256, (D.h + 3) / 4, B), block(64, 4);
+    dim3 grid((D.w + 255) / 256, (D.h + 31) / 32, B), block(64, 4);
     hipLaunchKernelGGL(k_resize_linear, grid, block, 0, st, src, sstride, spitch, pl.pyr + D.off, pl.pyr_frame_stride, D.pitch,
                        D.w, D.h, rs.xofs0 + rs.col_base[level], rs.xofs1 + rs.col_base[level], rs.a0 + rs.col_base[level],
                        rs.a1 + rs.col_base[level], rs.yofs0 + rs.row_base[level], rs.yofs1 + rs.row_base[level],
