@@ -13,7 +13,7 @@ using namespace plp;
 struct plp_matcher {
     int device = 0;
     hipStream_t stream = nullptr;
-    DevBuf klist, kcount, claim, full_list;  // scratch of the device path
+    DevBuf klist, kcount, claim, full_list, sorted, sorted_xr, row_start;  // scratch of the device path
     DevBuf stage;                            // one slab for the host-pointer path
     std::mutex mu;
 };
@@ -43,6 +43,10 @@ plp_status run_device(plp_matcher* c, const plp_match_args* a, hipStream_t st) {
     PLP_HIP(c->kcount.reserve(qn * 4));
     PLP_HIP(c->claim.reserve(qn * 4));
     PLP_HIP(c->full_list.reserve(qn * 4));
+    const size_t tn_ = (size_t)a->B * a->n_cap;
+    PLP_HIP(c->sorted.reserve(tn_ * sizeof(StagedTarget)));
+    PLP_HIP(c->sorted_xr.reserve(tn_ * 4));
+    PLP_HIP(c->row_start.reserve((size_t)a->B * 260 * 4));
     MatchProblem P{};
     P.mode = a->mode; P.n_cap = a->n_cap; P.m_cap = a->m_cap;
     P.t_kps = a->mode == PLP_MATCH_MODE_BRUTE_FORCE ? nullptr : a->t_kps;
@@ -55,6 +59,7 @@ plp_status run_device(plp_matcher* c, const plp_match_args* a, hipStream_t st) {
     P.grid_min_x = a->grid.min_x; P.grid_min_y = a->grid.min_y; P.inv_cell_w = a->grid.inv_cell_width; P.inv_cell_h = a->grid.inv_cell_height;
     P.grid_cols = a->grid.cols; P.grid_rows = a->grid.rows;
     P.klist = (unsigned long long*)c->klist.p; P.kcount = (int32_t*)c->kcount.p; P.claim = (int32_t*)c->claim.p; P.full_list = (int32_t*)c->full_list.p;
+    P.sorted = (StagedTarget*)c->sorted.p; P.sorted_xr = (float*)c->sorted_xr.p; P.row_start = (int32_t*)c->row_start.p;
     P.out_match = a->out_match; P.out_num = a->out_num;
     launch_match(st, P, a->B);
     PLP_HIP(hipGetLastError());

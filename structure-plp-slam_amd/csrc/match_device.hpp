@@ -10,6 +10,8 @@ namespace plp {
 
 constexpr int kMatchK = 8;          // best candidates kept per query by k_match_topk
 
+struct StagedTarget { float x, y; uint32_t packed; uint32_t t; };   // packed = octave | cell col << 8 | cell row << 16
+
 struct MatchProblem {
     int mode;                        // plp_match_mode
     int n_cap, m_cap;                // per-problem strides of the target / query arrays
@@ -41,6 +43,9 @@ struct MatchProblem {
     int32_t* kcount;                 // B x m_cap
     int32_t* claim;                  // B x m_cap
     int32_t* full_list;              // B x m_cap
+    StagedTarget* sorted;            // B x n_cap: free in-grid targets bucketed by grid row
+    float* sorted_xr;                // B x n_cap
+    int32_t* row_start;              // B x 260
     int32_t* out_match;              // B x n_cap: query index per key point, -1 = none
     int32_t* out_num;                // B
 };

@@ -157,20 +157,58 @@ __global__ __launch_bounds__(256) void k_match_topk(MatchProblem P) {
     if (lane == 0) *kcount = passed;
 }
 
-// Main path: the frame's targets are staged ONCE per workgroup in LDS and reused by kQueriesPerBlock queries
-// (a wave scanning 1000 key points from L2 for each of ~3000 queries made the kernel L2-bandwidth bound).
-//   windowed modes: 16 B per free in-grid target {x, y, octave | cell col | cell row, index}, bucketed by grid ROW
-//                   (counting sort with LDS atomics; the order inside a bucket is irrelevant because every
-//                   candidate key carries the reference's visiting order), so a query only walks the rows its
-//                   window overlaps; (+4 B stereo x_right)
-//   brute force:    the 32-byte descriptors themselves
-// grid = (ceil(m_cap / kQueriesPerBlock), B), block = 256, dynamic LDS = staged bytes.
-constexpr int kQueriesPerBlock = 64;
-struct StagedTarget { float x, y; uint32_t packed; uint32_t t; };   // packed = octave | cx << 8 | cy << 16
+// Main path.  k_match_prep buckets each frame's free, in-grid targets by grid ROW once (counting sort with LDS
+// atomics; the order inside a bucket is irrelevant because every candidate key carries the reference's visiting
+// order) into 16-byte records in HBM; k_match_topk_lds copies that array into LDS once per workgroup and reuses it
+// for kQueriesPerBlock queries, each of which only walks the rows its window overlaps.  (A wave scanning 1000
+// key points from L2 for each of ~3000 queries had made the first version L2-bandwidth bound.)
+//   windowed modes: {x, y, octave | cell col | cell row, index} (+4 B stereo x_right)
+//   brute force:    the 32-byte descriptors themselves are staged
+constexpr int kQueriesPerBlock = 128;
+constexpr int kRowStride = 260;    // row_start[257] per frame, padded
 
+// grid = (B), block = 256.
+__global__ __launch_bounds__(256) void k_match_prep(MatchProblem P) {
+    __shared__ int row_start[257], row_fill[256];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int n = P.t_counts ? P.t_counts[b] : P.n_cap;
+    const plp_keypoint* kps = P.t_kps + (size_t)b * P.n_cap;
+    const float* t_xr = P.t_x_right ? P.t_x_right + (size_t)b * P.n_cap : nullptr;
+    const uint8_t* t_occ = P.t_occupied ? P.t_occupied + (size_t)b * P.n_cap : nullptr;
+    StagedTarget* st = P.sorted + (size_t)b * P.n_cap;
+    float* sxr = P.sorted_xr + (size_t)b * P.n_cap;
+    for (int i = tid; i < 257; i += 256) row_start[i] = 0;
+    if (tid < 256) row_fill[tid] = 0;
+    __syncthreads();
+    auto cell_of = [&](const plp_keypoint& k, int t, int& cx, int& cy) -> bool {
+        cx = floor_d((double)__fsub_rn(k.x, P.grid_min_x) * P.inv_cell_w);
+        cy = floor_d((double)__fsub_rn(k.y, P.grid_min_y) * P.inv_cell_h);
+        return cx >= 0 && cx < P.grid_cols && cy >= 0 && cy < P.grid_rows && !(t_occ && t_occ[t]);
+    };
+    for (int t = tid; t < n; t += 256) {   // pass 1: bucket sizes
+        int cx, cy;
+        if (cell_of(kps[t], t, cx, cy)) atomicAdd(&row_start[cy + 1], 1);
+    }
+    __syncthreads();
+    if (tid == 0) for (int r = 0; r < P.grid_rows; ++r) row_start[r + 1] += row_start[r];
+    __syncthreads();
+    for (int t = tid; t < n; t += 256) {   // pass 2: scatter
+        const plp_keypoint k = kps[t];
+        int cx, cy;
+        if (!cell_of(k, t, cx, cy)) continue;
+        const int pos = row_start[cy] + atomicAdd(&row_fill[cy], 1);
+        StagedTarget r;
+        r.x = k.x; r.y = k.y; r.packed = ((uint32_t)k.octave & 0xffu) | ((uint32_t)cx << 8) | ((uint32_t)cy << 16); r.t = (uint32_t)t;
+        st[pos] = r;
+        if (t_xr) sxr[pos] = t_xr[t];
+    }
+    for (int i = tid; i < 257; i += 256) P.row_start[(size_t)b * kRowStride + i] = row_start[min(i, P.grid_rows)];
+}
+
+// grid = (ceil(m_cap / kQueriesPerBlock), B), block = 256, dynamic LDS = staged bytes.
 __global__ __launch_bounds__(256) void k_match_topk_lds(MatchProblem P) {
     extern __shared__ uint8_t smem[];
-    __shared__ int row_start[257], row_fill[256];
+    __shared__ int row_start[257];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.y;
     const int m = P.q_counts ? P.q_counts[b] : P.m_cap;
     const int q_begin = blockIdx.x * kQueriesPerBlock;
@@ -183,34 +221,12 @@ __global__ __launch_bounds__(256) void k_match_topk_lds(MatchProblem P) {
     uint4* sdesc = reinterpret_cast<uint4*>(smem);
     const bool has_xr = P.t_x_right != nullptr;
     if (windowed) {
-        const plp_keypoint* kps = P.t_kps + (size_t)b * P.n_cap;
-        const float* t_xr = has_xr ? P.t_x_right + (size_t)b * P.n_cap : nullptr;
-        const uint8_t* t_occ = P.t_occupied ? P.t_occupied + (size_t)b * P.n_cap : nullptr;
-        for (int i = tid; i < 257; i += 256) row_start[i] = 0;
-        if (tid < 256) row_fill[tid] = 0;
+        for (int i = tid; i < 257; i += 256) row_start[i] = P.row_start[(size_t)b * kRowStride + i];
         __syncthreads();
-        auto cell_of = [&](const plp_keypoint& k, int t, int& cx, int& cy) -> bool {
-            cx = floor_d((double)__fsub_rn(k.x, P.grid_min_x) * P.inv_cell_w);
-            cy = floor_d((double)__fsub_rn(k.y, P.grid_min_y) * P.inv_cell_h);
-            return cx >= 0 && cx < P.grid_cols && cy >= 0 && cy < P.grid_rows && !(t_occ && t_occ[t]);
-        };
-        for (int t = tid; t < n; t += 256) {   // pass 1: bucket sizes
-            int cx, cy;
-            if (cell_of(kps[t], t, cx, cy)) atomicAdd(&row_start[cy + 1], 1);
-        }
-        __syncthreads();
-        if (tid == 0) for (int r = 0; r < P.grid_rows; ++r) row_start[r + 1] += row_start[r];
-        __syncthreads();
-        for (int t = tid; t < n; t += 256) {   // pass 2: scatter
-            const plp_keypoint k = kps[t];
-            int cx, cy;
-            if (!cell_of(k, t, cx, cy)) continue;
-            const int pos = row_start[cy] + atomicAdd(&row_fill[cy], 1);
-            st[pos].x = k.x; st[pos].y = k.y;
-            st[pos].packed = ((uint32_t)k.octave & 0xffu) | ((uint32_t)cx << 8) | ((uint32_t)cy << 16);
-            st[pos].t = (uint32_t)t;
-            if (has_xr) sxr[pos] = t_xr[t];
-        }
+        const int used = row_start[P.grid_rows];
+        const uint4* src = reinterpret_cast<const uint4*>(P.sorted + (size_t)b * P.n_cap);
+        for (int i = tid; i < used; i += 256) reinterpret_cast<uint4*>(st)[i] = src[i];
+        if (has_xr) for (int i = tid; i < used; i += 256) sxr[i] = P.sorted_xr[(size_t)b * P.n_cap + i];
     } else {
         const uint4* src = reinterpret_cast<const uint4*>(t_desc);
         for (int i = tid; i < 2 * n; i += 256) sdesc[i] = src[i];
@@ -439,9 +455,10 @@ __global__ __launch_bounds__(256) void k_hamming_matrix(const uint8_t* __restric
 void launch_match(hipStream_t st, const MatchProblem& P, int B) {
     const bool windowed = P.mode != PLP_MATCH_MODE_BRUTE_FORCE;
     const size_t staged = windowed ? (size_t)P.n_cap * (sizeof(StagedTarget) + (P.t_x_right ? 4 : 0)) : (size_t)P.n_cap * 32;
-    if (staged <= 64 * 1024 && (!windowed || (P.grid_cols <= 255 && P.grid_rows <= 255)))
+    if (staged <= 64 * 1024 && (!windowed || (P.grid_cols <= 255 && P.grid_rows <= 255))) {
+        if (windowed) hipLaunchKernelGGL(k_match_prep, dim3(B), dim3(256), 0, st, P);
         hipLaunchKernelGGL(k_match_topk_lds, dim3((P.m_cap + kQueriesPerBlock - 1) / kQueriesPerBlock, B), dim3(256), staged, st, P);
-    else
+    } else
         hipLaunchKernelGGL(k_match_topk, dim3((P.m_cap + 3) / 4, B), dim3(256), 0, st, P);
     hipLaunchKernelGGL(k_match_resolve, dim3(B), dim3(256), (size_t)P.n_cap * 8, st, P);
 }

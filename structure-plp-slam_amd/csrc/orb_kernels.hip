@@ -123,8 +123,9 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbPlanes pl, const CellDesc
     const int tw = w - 6, th = h - 6;   // tested interior (ROI x,y in [3, w-3) x [3, h-3))
 
     // pass 1: 16-bit brighter/darker masks -> "has an arc of 9 at min_thr" -> queue
-    for (int i = tid; i < tw * th; i += 256) {
-        const int ty = i / tw, tx = i - ty * tw;
+    for (int i = tid; i < 4096; i += 256) {   // 64 x 64 positions, shifts instead of divisions; border cells skip the excess
+        const int ty = i >> 6, tx = i & 63;
+        if (tx >= tw || ty >= th) continue;
         const uint8_t* c = &tile[(ty + 3) * kTileW + tx + 3 + ox];
         const int v = c[0];
         const int hi = v + min_thr, lo = v - min_thr;
@@ -178,8 +179,9 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbPlanes pl, const CellDesc
     __syncthreads();
     // pass 3: 3x3 strict NMS on the score map; count survivors at the initial threshold
     int my_ini = 0;
-    for (int i = tid; i < tw * th; i += 256) {
-        const int ty = i / tw, tx = i - ty * tw;
+    for (int i = tid; i < 4096; i += 256) {
+        const int ty = i >> 6, tx = i & 63;
+        if (tx >= tw || ty >= th) continue;
         const uint8_t* s = &score[(ty + 1) * kScoreW + tx + 1];
         const int v = s[0];
         const bool ok = v > 0 && v > s[-1] && v > s[1] && v > s[-kScoreW - 1] && v > s[-kScoreW] && v > s[-kScoreW + 1] &&
@@ -195,10 +197,10 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbPlanes pl, const CellDesc
     // sequence: count with ballots, one barrier for the wave bases, then write (no per-step barriers).
     uint32_t* out = cell_cand + (size_t)out_slot * kCellCap;
     const int lane = tid & 63, wv = tid >> 6;
-    const int total = tw * th, per = (total + 3) / 4, j0 = wv * per, j1 = min(total, j0 + per);
+    const int j0 = wv * 1024, j1 = j0 + 1024;   // 16 rows of the 64 x 64 position grid per wave
     auto survivor = [&](int i, int& ty, int& tx, int& v) -> bool {
-        if (i >= j1) return false;
-        ty = i / tw; tx = i - ty * tw;
+        ty = i >> 6; tx = i & 63;
+        if (tx >= tw || ty >= th) return false;
         v = keep[ty * 64 + tx];
         bool emit = v >= thr && v > 0;
         if (emit && mk) emit = !masked(cd.min_y + ty + 3, cd.min_x + tx + 3);   // (:429)
