@@ -204,6 +204,7 @@ def main():
             e1.record(sA)
         torch.cuda.synchronize(dev)
         stage_ms["match_2x"] = e0.elapsed_time(e1) / n_prof
+        match_dbg = {"last_frame": mt_last.debug_counters()[:2].tolist(), "landmarks": mt_lm.debug_counters()[:2].tolist()}
     nl = ex.get_num_scale_levels()
     mean_cand = float(sum(len(ex.debug_read(ex.DBG_CANDIDATES, l, 0)) for l in range(nl)))
     per_frame = algorithmic_bytes(args.rows, args.cols, nl, mean_kp, mean_cand, mean_lines, mean_len, mean_raw)
@@ -230,6 +231,7 @@ def main():
                                "line matchers / BoW matchers not included",
                    "frames_per_rank_per_step": B, "keypoints_mean": round(mean_kp, 1), "lines_mean": round(mean_lines, 1),
                    "matches_mean": [round(float(n1.float().mean().item()), 1), round(float(n2.float().mean().item()), 1)],
+                   "match_rescans_rounds": (match_dbg if not args.orb_only else None),
                    "sharding": "contiguous frame blocks per rank; RCCL all-gather of the 2-frame feature halo for the matchers"},
         "roofline": roofline,
     }

@@ -248,6 +248,9 @@ plp_status plp_match_device(plp_matcher* ctx, const plp_match_args* a, void* hip
 /* Same with HOST pointers for one call (B problems are staged to HBM and back); synchronous. */
 plp_status plp_match_host(plp_matcher* ctx, const plp_match_args* a);
 
+/* Diagnostics: {exact full rescans, resolve rounds, 0, 0} accumulated over all calls of this context (synchronous). */
+plp_status plp_match_debug_counters(plp_matcher* ctx, int64_t* out4);
+
 /* compute_descriptor_distance_32 over all pairs (match/base.h:43-68): dist[q*nt + t], u16.
  * Device pointers, asynchronous.  (K16: input of brute-force style matchers on the host side.) */
 plp_status plp_hamming_matrix_device(plp_matcher* ctx, const uint8_t* d_q, int32_t nq, const uint8_t* d_t, int32_t nt,

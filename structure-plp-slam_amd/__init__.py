@@ -81,6 +81,7 @@ _API = [
     ("plp_matcher_destroy", None, [_VP]),
     ("plp_match_device", C.c_int, [_VP, _VP, _VP]),
     ("plp_match_host", C.c_int, [_VP, _VP]),
+    ("plp_match_debug_counters", C.c_int, [_VP, _VP]),
     ("plp_hamming_matrix_device", C.c_int, [_VP, _VP, _I32, _VP, _I32, _VP, _VP]),
     ("plp_hamming_matrix_host", C.c_int, [_VP, _VP, _I32, _VP, _I32, _VP]),
 ]
@@ -414,6 +415,11 @@ class matcher:
         st = (stream or torch.cuda.current_stream(out_match.device)).cuda_stream
         a = self._args(mode, B, n_cap, m_cap, fields, margin, direction, scale_factors, grid, out_match, out_num, lambda v: v.data_ptr())
         _check(lib().plp_match_device(self._h, C.byref(a), st))
+
+    def debug_counters(self):
+        v = np.zeros(4, np.int64)
+        _check(lib().plp_match_debug_counters(self._h, _p(v)))
+        return v
 
     def hamming_matrix(self, q, t):
         q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)

@@ -13,7 +13,7 @@ using namespace plp;
 struct plp_matcher {
     int device = 0;
     hipStream_t stream = nullptr;
-    DevBuf klist, kcount, claim, full_list, sorted, sorted_xr, row_start;  // scratch of the device path
+    DevBuf klist, kcount, claim, full_list, sorted, sorted_xr, row_start, dbg;  // scratch of the device path
     DevBuf stage;                            // one slab for the host-pointer path
     std::mutex mu;
 };
@@ -39,7 +39,7 @@ plp_status check_args(const plp_match_args* a) {
 plp_status run_device(plp_matcher* c, const plp_match_args* a, hipStream_t st) {
     PLP_HIP(hipSetDevice(c->device));
     const size_t qn = (size_t)a->B * a->m_cap;
-    PLP_HIP(c->klist.reserve(qn * kMatchK * 8));
+    PLP_HIP(c->klist.reserve(qn * kMatchK * 4));
     PLP_HIP(c->kcount.reserve(qn * 4));
     PLP_HIP(c->claim.reserve(qn * 4));
     PLP_HIP(c->full_list.reserve(qn * 4));
@@ -47,6 +47,7 @@ plp_status run_device(plp_matcher* c, const plp_match_args* a, hipStream_t st) {
     PLP_HIP(c->sorted.reserve(tn_ * sizeof(StagedTarget)));
     PLP_HIP(c->sorted_xr.reserve(tn_ * 4));
     PLP_HIP(c->row_start.reserve((size_t)a->B * 260 * 4));
+    if (!c->dbg.p) { PLP_HIP(c->dbg.reserve(16)); PLP_HIP(hipMemsetAsync(c->dbg.p, 0, 16, st)); }
     MatchProblem P{};
     P.mode = a->mode; P.n_cap = a->n_cap; P.m_cap = a->m_cap;
     P.t_kps = a->mode == PLP_MATCH_MODE_BRUTE_FORCE ? nullptr : a->t_kps;
@@ -58,8 +59,8 @@ plp_status run_device(plp_matcher* c, const plp_match_args* a, hipStream_t st) {
     for (int i = 0; i < 16; ++i) P.scale_factors[i] = (a->scale_factors && i < a->num_levels) ? a->scale_factors[i] : 1.0f;
     P.grid_min_x = a->grid.min_x; P.grid_min_y = a->grid.min_y; P.inv_cell_w = a->grid.inv_cell_width; P.inv_cell_h = a->grid.inv_cell_height;
     P.grid_cols = a->grid.cols; P.grid_rows = a->grid.rows;
-    P.klist = (unsigned long long*)c->klist.p; P.kcount = (int32_t*)c->kcount.p; P.claim = (int32_t*)c->claim.p; P.full_list = (int32_t*)c->full_list.p;
-    P.sorted = (StagedTarget*)c->sorted.p; P.sorted_xr = (float*)c->sorted_xr.p; P.row_start = (int32_t*)c->row_start.p;
+    P.klist = (uint32_t*)c->klist.p; P.kcount = (int32_t*)c->kcount.p; P.claim = (int32_t*)c->claim.p; P.full_list = (int32_t*)c->full_list.p;
+    P.sorted = (StagedTarget*)c->sorted.p; P.sorted_xr = (float*)c->sorted_xr.p; P.row_start = (int32_t*)c->row_start.p; P.dbg = (int32_t*)c->dbg.p;
     P.out_match = a->out_match; P.out_num = a->out_num;
     launch_match(st, P, a->B);
     PLP_HIP(hipGetLastError());
@@ -142,6 +143,16 @@ plp_status plp_match_host(plp_matcher* c, const plp_match_args* a) {
     PLP_HIP(hipMemcpyAsync(a->out_match, base + o_om, tn * 4, hipMemcpyDeviceToHost, st));
     PLP_HIP(hipMemcpyAsync(a->out_num, base + o_on, (size_t)a->B * 4, hipMemcpyDeviceToHost, st));
     PLP_HIP(hipStreamSynchronize(st));
+    return PLP_OK;
+}
+
+plp_status plp_match_debug_counters(plp_matcher* c, int64_t* out4) {
+    if (!c || !out4) return set_error(PLP_ERR_INVALID_ARG, "NULL argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    PLP_HIP(hipSetDevice(c->device));
+    int32_t v[4] = {0, 0, 0, 0};
+    if (c->dbg.p) PLP_HIP(hipMemcpy(v, c->dbg.p, 16, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 4; ++i) out4[i] = v[i];
     return PLP_OK;
 }
 

@@ -39,13 +39,15 @@ struct MatchProblem {
     double inv_cell_w, inv_cell_h;
     int grid_cols, grid_rows;
     // scratch + outputs
-    unsigned long long* klist;       // B x m_cap x kMatchK
+    uint32_t* klist;                 // B x m_cap x kMatchK, packed distance<<20 | octave<<16 | target (sorted)
     int32_t* kcount;                 // B x m_cap
     int32_t* claim;                  // B x m_cap
     int32_t* full_list;              // B x m_cap
     StagedTarget* sorted;            // B x n_cap: free in-grid targets bucketed by grid row
     float* sorted_xr;                // B x n_cap
     int32_t* row_start;              // B x 260
+    int sorted_valid;                // set by launch_match when k_match_prep ran
+    int32_t* dbg;                    // 4 counters: exact rescans, resolve rounds (accumulated)
     int32_t* out_match;              // B x n_cap: query index per key point, -1 = none
     int32_t* out_num;                // B
 };

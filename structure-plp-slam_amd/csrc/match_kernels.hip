@@ -106,11 +106,15 @@ __device__ __forceinline__ void topk_insert(unsigned long long (&top)[kMatchK], 
             if (top[i] < top[i - 1]) { const unsigned long long s = top[i]; top[i] = top[i - 1]; top[i - 1] = s; }
     }
 }
-__device__ __forceinline__ void topk_merge_store(unsigned long long (&top)[kMatchK], int lane, unsigned long long* klist) {
+// the merged list is stored packed: distance << 20 | octave << 16 | target index (0xffffffff = none), 32 B per query
+__device__ __forceinline__ uint32_t pack_key(unsigned long long key) {
+    return key == ~0ull ? 0xffffffffu : ((uint32_t)(key >> 32) << 20) | ((uint32_t)(key & 15) << 16) | (uint32_t)((key >> 4) & 0xffff);
+}
+__device__ __forceinline__ void topk_merge_store(unsigned long long (&top)[kMatchK], int lane, uint32_t* klist) {
 #pragma unroll
     for (int r = 0; r < kMatchK; ++r) {
         const unsigned long long mn = wave_min_u64(top[0]);
-        if (lane == 0) klist[r] = mn;
+        if (lane == 0) klist[r] = pack_key(mn);
         if (top[0] == mn && mn != ~0ull) {
 #pragma unroll
             for (int i = 0; i + 1 < kMatchK; ++i) top[i] = top[i + 1];
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(256) void k_match_topk(MatchProblem P) {
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int m = P.q_counts ? P.q_counts[b] : P.m_cap;
     if (q >= m) return;
-    unsigned long long* klist = P.klist + ((size_t)b * P.m_cap + q) * kMatchK;
+    uint32_t* klist = P.klist + ((size_t)b * P.m_cap + q) * kMatchK;
     int32_t* kcount = P.kcount + (size_t)b * P.m_cap + q;
     const uint8_t* q_valid = P.q_valid ? P.q_valid + (size_t)b * P.m_cap : nullptr;
     if (q_valid && !q_valid[q]) { if (lane == 0) *kcount = -1; return; }
@@ -234,7 +238,7 @@ __global__ __launch_bounds__(256) void k_match_topk_lds(MatchProblem P) {
     __syncthreads();
     const uint8_t* q_valid = P.q_valid ? P.q_valid + (size_t)b * P.m_cap : nullptr;
     for (int q = q_begin + wv; q < min(m, q_begin + kQueriesPerBlock); q += 4) {
-        unsigned long long* klist = P.klist + ((size_t)b * P.m_cap + q) * kMatchK;
+        uint32_t* klist = P.klist + ((size_t)b * P.m_cap + q) * kMatchK;
         int32_t* kcount = P.kcount + (size_t)b * P.m_cap + q;
         if (q_valid && !q_valid[q]) { if (lane == 0) *kcount = -1; continue; }
         const QueryCtx c = make_query(P, q, P.q_reproj ? P.q_reproj + (size_t)b * P.m_cap * 2 : nullptr,
@@ -298,13 +302,13 @@ __device__ __forceinline__ bool accept(const MatchProblem& P, unsigned best, int
 // grid = (B), block = 256.  LDS: owner[2][n_cap] (dynamic).
 __global__ __launch_bounds__(256) void k_match_resolve(MatchProblem P) {
     extern __shared__ int32_t lds[];
-    __shared__ int s_changed, s_num, s_hist[32], s_valid_bin[32], s_full_n;
+    __shared__ int s_changed, s_num, s_hist[32], s_valid_bin[32], s_full_n, s_claim_tmp[256];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.x;
     const int m = P.q_counts ? P.q_counts[b] : P.m_cap;
     const int n = P.t_counts ? P.t_counts[b] : P.n_cap;
     int32_t* owner_prev = lds;
     int32_t* owner_next = lds + P.n_cap;
-    const unsigned long long* klist = P.klist + (size_t)b * P.m_cap * kMatchK;
+    const uint32_t* klist = P.klist + (size_t)b * P.m_cap * kMatchK;
     const int32_t* kcount = P.kcount + (size_t)b * P.m_cap;
     int32_t* claim = P.claim + (size_t)b * P.m_cap;           // per query: claimed target or -1
     const uint8_t* has_obs = P.q_has_obs ? P.q_has_obs + (size_t)b * P.m_cap : nullptr;
@@ -321,59 +325,122 @@ __global__ __launch_bounds__(256) void k_match_resolve(MatchProblem P) {
     for (int q = tid; q < m; q += 256) claim[q] = -1;
     __syncthreads();
 
-    int32_t* full_list = P.full_list + (size_t)b * P.m_cap;   // queries whose truncated best-K list ran dry this round
+    int32_t* full_list = P.full_list + (size_t)b * P.m_cap;   // queries whose truncated best-K list ran dry
+    const int need = P.mode == PLP_MATCH_MODE_LAST_FRAME ? 1 : 2;   // the last-frame matcher has no second-best test
+    const bool blocks_always = !has_obs || P.mode == PLP_MATCH_MODE_BRUTE_FORCE;
+    const bool use_sorted = P.mode != PLP_MATCH_MODE_BRUTE_FORCE && P.sorted_valid;
+    const StagedTarget* sorted = P.sorted + (size_t)b * P.n_cap;
+    const float* sorted_xr = P.sorted_xr + (size_t)b * P.n_cap;
+    const int32_t* g_row_start = P.row_start + (size_t)b * 260;
+    // Rounds of "claim[q] = best free candidate given the claims of the queries before q".  Within a round the
+    // queries are swept in chunks of 256 in index order (Gauss-Seidel): a chunk sees THIS round's claims of all
+    // earlier chunks (owner_next, rebuilt as the sweep advances) and the previous round's claims of the earlier
+    // queries of its own chunk (owner_prev entries that fall inside the chunk).  At a fixed point both tests read
+    // "the smallest claimant of t is < q", i.e. the sequential answer; claims of queries < r are final after r
+    // rounds at the latest, in practice after 2-4.
+    auto taken = [&](int t, int q, int chunk_start) -> bool {
+        const int p = owner_prev[t];
+        return owner_next[t] < q || (p >= chunk_start && p < q);
+    };
     for (int round = 0; round <= m; ++round) {
-        if (tid == 0) { s_changed = 0; s_full_n = 0; }
+        if (tid == 0) s_changed = 0;
         for (int t = tid; t < n; t += 256) owner_next[t] = 0x7fffffff;
         __syncthreads();
-        for (int q = tid; q < m; q += 256) {
-            const int cnt = kcount[q];
-            if (cnt <= 0) continue;
-            const int have = min(cnt, kMatchK);
-            unsigned best = 256, second = 256;
-            int best_lvl = -1, second_lvl = -1, best_t = -1, found = 0;
-            for (int e = 0; e < have && found < 2; ++e) {
-                const unsigned long long key = klist[(size_t)q * kMatchK + e];
-                const int t = (int)((key >> 4) & 0xffff);
-                if (owner_prev[t] < q) continue;   // taken by an earlier query
-                if (found == 0) { best = (unsigned)(key >> 32); best_lvl = (int)(key & 15); best_t = t; }
-                else { second = (unsigned)(key >> 32); second_lvl = (int)(key & 15); }
-                ++found;
-            }
-            if (found < 2 && cnt > kMatchK) { full_list[atomicAdd(&s_full_n, 1)] = q; continue; }   // exact rescan below
-            const int new_claim = (found > 0 && accept(P, best, best_lvl, second, second_lvl)) ? best_t : -1;
-            if (claim[q] != new_claim) { claim[q] = new_claim; s_changed = 1; }
-            if (new_claim >= 0 && (!has_obs || has_obs[q] || P.mode == PLP_MATCH_MODE_BRUTE_FORCE)) atomicMin(&owner_next[new_claim], q);
-        }
-        __syncthreads();
-        // rare: exact two-best over ALL targets with the occupancy filter, one wave per query
-        const int nf = s_full_n;
-        for (int f = wv; f < nf; f += 4) {
-            const int fq = full_list[f];
-            const QueryCtx c = make_query(P, fq, q_reproj, q_xr, q_level);
-            const uint4* qd = reinterpret_cast<const uint4*>(P.q_desc + ((size_t)b * P.m_cap + fq) * 32);
-            const uint4 q0 = qd[0], q1 = qd[1];
-            unsigned long long k0 = ~0ull, k1 = ~0ull;
-            if (!(c.windowed && c.empty))
-                for (int t = lane; t < n; t += 64) {
-                    if (owner_prev[t] < fq) continue;
-                    const unsigned long long key = candidate_key(P, c, t, kps, t_desc, t_xr, t_occ, q0, q1);
-                    if (key < k0) { k1 = k0; k0 = key; } else if (key < k1) k1 = key;
+        for (int chunk_start = 0; chunk_start < m; chunk_start += 256) {
+            if (tid == 0) s_full_n = 0;
+            __syncthreads();
+            const int q = chunk_start + tid;
+            int new_claim = -1;
+            bool decided = false;
+            if (q < m) {
+                const int cnt = kcount[q];
+                if (cnt <= 0) decided = true;
+                else {
+                    const int have = min(cnt, kMatchK);
+                    unsigned best = 256, second = 256;
+                    int best_lvl = -1, second_lvl = -1, best_t = -1, found = 0;
+                    uint32_t e8[kMatchK];
+                    {   // the whole best-K list in two 16-byte loads
+                        const uint4* kp = reinterpret_cast<const uint4*>(klist + (size_t)q * kMatchK);
+                        const uint4 lo = kp[0], hi = kp[1];
+                        e8[0] = lo.x; e8[1] = lo.y; e8[2] = lo.z; e8[3] = lo.w; e8[4] = hi.x; e8[5] = hi.y; e8[6] = hi.z; e8[7] = hi.w;
+                    }
+#pragma unroll
+                    for (int e = 0; e < kMatchK; ++e) {
+                        if (e >= have || found >= need) continue;
+                        const int t = (int)(e8[e] & 0xffff);
+                        if (taken(t, q, chunk_start)) continue;
+                        if (found == 0) { best = e8[e] >> 20; best_lvl = (int)((e8[e] >> 16) & 15); best_t = t; }
+                        else { second = e8[e] >> 20; second_lvl = (int)((e8[e] >> 16) & 15); }
+                        ++found;
+                    }
+                    if (found < need && cnt > kMatchK) full_list[atomicAdd(&s_full_n, 1)] = q;   // exact rescan below
+                    else { decided = true; if (found > 0 && accept(P, best, best_lvl, second, second_lvl)) new_claim = best_t; }
                 }
-            const unsigned long long g0 = wave_min_u64(k0);
-            const unsigned long long g1 = wave_min_u64(k0 == g0 ? k1 : k0);
-            if (lane == 0) {
-                int nc = -1;
-                if (g0 != ~0ull) {
-                    const unsigned second = g1 != ~0ull ? (unsigned)(g1 >> 32) : 256u;
-                    const int second_lvl = g1 != ~0ull ? (int)(g1 & 15) : -1;
-                    if (accept(P, (unsigned)(g0 >> 32), (int)(g0 & 15), second, second_lvl)) nc = (int)((g0 >> 4) & 0xffff);
-                }
-                if (claim[fq] != nc) { claim[fq] = nc; s_changed = 1; }
-                if (nc >= 0 && (!has_obs || has_obs[fq] || P.mode == PLP_MATCH_MODE_BRUTE_FORCE)) atomicMin(&owner_next[nc], fq);
             }
+            __syncthreads();
+            // rare: exact two-best over the query's whole window with the occupancy filter, one wave per query
+            const int nf = s_full_n;
+            if (tid == 0 && P.dbg && nf) atomicAdd(&P.dbg[0], nf);
+            for (int f = wv; f < nf; f += 4) {
+                const int fq = full_list[f];
+                const QueryCtx c = make_query(P, fq, q_reproj, q_xr, q_level);
+                const uint4* qd = reinterpret_cast<const uint4*>(P.q_desc + ((size_t)b * P.m_cap + fq) * 32);
+                const uint4 q0 = qd[0], q1 = qd[1];
+                unsigned long long k0 = ~0ull, k1 = ~0ull;
+                if (use_sorted) {
+                    if (!c.empty) {
+                        const bool check_level = (0 < c.min_level) || (0 <= c.max_level);
+                        const int i0 = g_row_start[c.min_cy], i1 = g_row_start[c.max_cy + 1];
+                        for (int i = i0 + lane; i < i1; i += 64) {
+                            const StagedTarget s = sorted[i];
+                            const int oct = (int)(s.packed & 0xff), cx = (int)((s.packed >> 8) & 0xff), cy = (int)(s.packed >> 16);
+                            if (cx < c.min_cx || cx > c.max_cx) continue;
+                            if (check_level) {
+                                if (oct < c.min_level) continue;
+                                if (0 <= c.max_level && c.max_level < oct) continue;
+                            }
+                            if (!(fabsf(__fsub_rn(s.x, c.rx)) < c.mg && fabsf(__fsub_rn(s.y, c.ry)) < c.mg)) continue;
+                            if (t_xr) {
+                                const float xr = sorted_xr[i];
+                                if (0 < xr && c.mg < fabsf(__fsub_rn(c.xr, xr))) continue;
+                            }
+                            if (taken((int)s.t, fq, chunk_start)) continue;
+                            const uint4* d = reinterpret_cast<const uint4*>(t_desc + 32 * (size_t)s.t);
+                            const unsigned dist = hamming256(q0, q1, d[0], d[1]);
+                            const unsigned order = ((unsigned)(cx * P.grid_rows + cy) << 16) | s.t;
+                            const unsigned long long key = ((unsigned long long)dist << 32) | ((unsigned long long)order << 4) | (unsigned)(oct & 15);
+                            if (key < k0) { k1 = k0; k0 = key; } else if (key < k1) k1 = key;
+                        }
+                    }
+                } else if (!(c.windowed && c.empty)) {
+                    for (int t = lane; t < n; t += 64) {
+                        if (taken(t, fq, chunk_start)) continue;
+                        const unsigned long long key = candidate_key(P, c, t, kps, t_desc, t_xr, t_occ, q0, q1);
+                        if (key < k0) { k1 = k0; k0 = key; } else if (key < k1) k1 = key;
+                    }
+                }
+                const unsigned long long g0 = wave_min_u64(k0);
+                const unsigned long long g1 = wave_min_u64(k0 == g0 ? k1 : k0);
+                if (lane == 0) {
+                    int nc = -1;
+                    if (g0 != ~0ull) {
+                        const unsigned second = g1 != ~0ull ? (unsigned)(g1 >> 32) : 256u;
+                        const int second_lvl = g1 != ~0ull ? (int)(g1 & 15) : -1;
+                        if (accept(P, (unsigned)(g0 >> 32), (int)(g0 & 15), second, second_lvl)) nc = (int)((g0 >> 4) & 0xffff);
+                    }
+                    s_claim_tmp[fq - chunk_start] = nc;
+                }
+            }
+            __syncthreads();
+            if (q < m) {
+                if (!decided) new_claim = s_claim_tmp[tid];
+                if (claim[q] != new_claim) { claim[q] = new_claim; s_changed = 1; }
+                if (new_claim >= 0 && (blocks_always || has_obs[q])) atomicMin(&owner_next[new_claim], q);
+            }
+            __syncthreads();   // this chunk's claims are visible to the next chunk
         }
-        __syncthreads();
+        if (tid == 0 && P.dbg) atomicAdd(&P.dbg[1], 1);
         int32_t* t = owner_prev; owner_prev = owner_next; owner_next = t;
         const int changed = s_changed;
         __syncthreads();
@@ -453,14 +520,17 @@ __global__ __launch_bounds__(256) void k_hamming_matrix(const uint8_t* __restric
 }
 
 void launch_match(hipStream_t st, const MatchProblem& P, int B) {
+    MatchProblem Q = P;
+    Q.sorted_valid = 0;
     const bool windowed = P.mode != PLP_MATCH_MODE_BRUTE_FORCE;
     const size_t staged = windowed ? (size_t)P.n_cap * (sizeof(StagedTarget) + (P.t_x_right ? 4 : 0)) : (size_t)P.n_cap * 32;
     if (staged <= 64 * 1024 && (!windowed || (P.grid_cols <= 255 && P.grid_rows <= 255))) {
         if (windowed) hipLaunchKernelGGL(k_match_prep, dim3(B), dim3(256), 0, st, P);
+        Q.sorted_valid = windowed ? 1 : 0;
         hipLaunchKernelGGL(k_match_topk_lds, dim3((P.m_cap + kQueriesPerBlock - 1) / kQueriesPerBlock, B), dim3(256), staged, st, P);
     } else
         hipLaunchKernelGGL(k_match_topk, dim3((P.m_cap + 3) / 4, B), dim3(256), 0, st, P);
-    hipLaunchKernelGGL(k_match_resolve, dim3(B), dim3(256), (size_t)P.n_cap * 8, st, P);
+    hipLaunchKernelGGL(k_match_resolve, dim3(B), dim3(256), (size_t)P.n_cap * 8, st, Q);
 }
 
 void launch_hamming_matrix(hipStream_t st, const uint8_t* q, int nq, const uint8_t* t, int nt, uint16_t* dist) {
