@@ -68,9 +68,9 @@ def algorithmic_bytes(rows, cols, n_levels, mean_kp, mean_cand, mean_lines, mean
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=512, help="frames per rank per step")
+    ap.add_argument("--batch", type=int, default=2048, help="frames per rank per step (the region-growing kernel is one latency-bound wave per frame: ~2048 frames fill the chip)")
     ap.add_argument("--keypoints", type=int, default=1000, help="Feature.max_num_keypoints (TUM RGB-D YAML: 1000)")
     ap.add_argument("--rows", type=int, default=480)
     ap.add_argument("--cols", type=int, default=640)
@@ -116,7 +116,8 @@ def main():
     grid = plp.make_grid(args.cols, args.rows)
     sf = ex.get_scale_factors()
     cur = torch.cuda.current_stream(dev)
-    sA, sB = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    sA = torch.cuda.Stream(dev)
+    sB = sA if os.environ.get("PLP_BENCH_SERIAL") else torch.cuda.Stream(dev)   # diagnostic: one stream for everything
     slot = torch.arange(cap, device=dev, dtype=torch.int32)[None, :]
 
     replay = importlib.import_module("structure-plp-slam_amd.replay")

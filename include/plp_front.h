@@ -184,6 +184,8 @@ typedef enum plp_line_debug_id { PLP_LINE_DBG_SCALED = 0, PLP_LINE_DBG_ORDER = 1
                                  PLP_LINE_DBG_ALL_LBD = 4, PLP_LINE_DBG_SOBEL_DX = 5, PLP_LINE_DBG_SOBEL_DY = 6 } plp_line_debug_id;
 plp_status plp_line_debug_read(plp_line* ctx, plp_line_debug_id what, int32_t frame, void* dst, size_t dst_bytes, int64_t* n_out);
 plp_status plp_line_scaled_size(const plp_line* ctx, int32_t* rows, int32_t* cols);
+/* Diagnostics of frame 0 of the last batch: shader cycles {whole wave, region_grow, region2rect, refine}, regions grown, pixels grown. */
+plp_status plp_line_debug_grow_profile(plp_line* ctx, int64_t* out6);
 
 /* ------------------------------------------------------------------------------------------
  * Hamming matchers, array form — replace the inner loops of the reference's src/PLPSLAM/match directory.

@@ -77,6 +77,7 @@ _API = [
     ("plp_line_get_stage_times", C.c_int, [_VP, _VP, _VP]),
     ("plp_line_debug_read", C.c_int, [_VP, C.c_int, _I32, _VP, _SZ, _VP]),
     ("plp_line_scaled_size", C.c_int, [_VP, _VP, _VP]),
+    ("plp_line_debug_grow_profile", C.c_int, [_VP, _VP]),
     ("plp_matcher_create", C.c_int, [C.c_int, _VP]),
     ("plp_matcher_destroy", None, [_VP]),
     ("plp_match_device", C.c_int, [_VP, _VP, _VP]),
@@ -313,6 +314,11 @@ class LineFeatureTracker:
         _check(lib().plp_line_get_stage_times(self._h, _p(ms), C.byref(n)))
         nb = max(n.value, 1)
         return {k: float(v) / nb for k, v in zip(self.STAGES, ms)}, n.value
+
+    def grow_profile(self):
+        v = np.zeros(6, np.int64)
+        _check(lib().plp_line_debug_grow_profile(self._h, _p(v)))
+        return dict(zip(("cycles_total", "cycles_grow", "cycles_rect", "cycles_refine", "regions", "pixels"), v.tolist()))
 
     def debug_read(self, what, frame=0):
         r, c = C.c_int32(), C.c_int32()

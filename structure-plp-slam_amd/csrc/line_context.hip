@@ -21,7 +21,7 @@ struct plp_line {
     ResizeExactTab rt{};
     BlurTapsN t11{}, t5{};
     LbdWeightsDev w{};
-    DevBuf tabs, blur11, scaled, ang, mod, cs, bin, maxgrad, undef, order, reg, raw, n_raw, blur5, dx, dy, all_kl, all_lbd, n_all, status;
+    DevBuf tabs, blur11, scaled, pix, bin, maxgrad, undef, order, reg, raw, n_raw, blur5, dx, dy, all_kl, all_lbd, n_all, status, prof;
     DevBuf l0copy, s_kl, s_lbd, s_fn, s_cnt;   // host-API staging
     DevBuf aligned;                             // aligned copy of odd-pitch device frames
     int s_cap = 0;
@@ -73,7 +73,7 @@ plp_status build(plp_line* c, int rows, int cols) {
     LinePlanes& P = c->P;
     P.W = cols; P.H = rows;
     P.sw = (int)std::nearbyint(cols * 0.5); P.sh = (int)std::nearbyint(rows * 0.5);   // cvRound(ssize * scale)
-    if (P.sw >= 65536 || P.sh >= 65536 || (((size_t)P.sw * P.sh + 31) / 32 + 1024) * 4 > 65536)
+    if (P.sw >= 65536 || P.sh >= 65536 || (((size_t)P.sw * P.sh + 31) / 32 + 256) * 4 > 65536)
         return set_error(PLP_ERR_UNSUPPORTED, "frame too large for the LSD region-growing kernel (scaled image must stay below ~131k pixels)");
     P.pitch = (cols + 63) / 64 * 64; P.spitch = (P.sw + 63) / 64 * 64;
     // LSD constants (line_extractor.cc:113-122, lsd.cpp flsd)
@@ -118,19 +118,19 @@ plp_status ensure(plp_line* c, int B) {
     const size_t n = (size_t)P.sw * P.sh, nv = (size_t)(P.sw - 1) * (P.sh - 1), full = (size_t)P.W * P.H;
     PLP_HIP(c->blur11.reserve((size_t)P.pitch * P.H * B)); PLP_HIP(c->blur5.reserve((size_t)P.pitch * P.H * B));
     PLP_HIP(c->scaled.reserve((size_t)P.spitch * P.sh * B));
-    PLP_HIP(c->ang.reserve(n * 8 * B)); PLP_HIP(c->mod.reserve(n * 8 * B)); PLP_HIP(c->cs.reserve(n * 8 * B));
+    PLP_HIP(c->pix.reserve(n * sizeof(LsdPix) * B));
     PLP_HIP(c->bin.reserve(n * 2 * B)); PLP_HIP(c->maxgrad.reserve(8 * (size_t)B)); PLP_HIP(c->undef.reserve((n + 63) / 64 * 8 * B));
     PLP_HIP(c->order.reserve(nv * 4 * B)); PLP_HIP(c->reg.reserve(n * 4 * B));
     PLP_HIP(c->raw.reserve(sizeof(float4) * kLineCap * B)); PLP_HIP(c->n_raw.reserve(4 * (size_t)B));
     PLP_HIP(c->dx.reserve(full * 2 * B)); PLP_HIP(c->dy.reserve(full * 2 * B));
     PLP_HIP(c->all_kl.reserve(sizeof(plp_keyline) * kLineCap * B)); PLP_HIP(c->all_lbd.reserve((size_t)32 * kLineCap * B));
-    PLP_HIP(c->n_all.reserve(4 * (size_t)B)); PLP_HIP(c->status.reserve(16));
+    PLP_HIP(c->n_all.reserve(4 * (size_t)B)); PLP_HIP(c->status.reserve(16)); PLP_HIP(c->prof.reserve(64));
     P.blur11 = (uint8_t*)c->blur11.p; P.blur5 = (uint8_t*)c->blur5.p; P.scaled = (uint8_t*)c->scaled.p;
-    P.ang = (double*)c->ang.p; P.mod = (double*)c->mod.p; P.cs = (float2*)c->cs.p; P.bin = (uint16_t*)c->bin.p;
+    P.pix = (LsdPix*)c->pix.p; P.bin = (uint16_t*)c->bin.p;
     P.maxgrad = (unsigned long long*)c->maxgrad.p; P.undef = (unsigned long long*)c->undef.p;
     P.order = (uint32_t*)c->order.p; P.reg = (uint32_t*)c->reg.p; P.raw = (float4*)c->raw.p; P.n_raw = (int32_t*)c->n_raw.p;
     P.dx = (int16_t*)c->dx.p; P.dy = (int16_t*)c->dy.p; P.all_kl = (plp_keyline*)c->all_kl.p; P.all_lbd = (uint8_t*)c->all_lbd.p;
-    P.n_all = (int32_t*)c->n_all.p; P.status = (int32_t*)c->status.p;
+    P.n_all = (int32_t*)c->n_all.p; P.status = (int32_t*)c->status.p; P.prof = (long long*)c->prof.p;
     c->capB = B;
     return PLP_OK;
 }
@@ -241,6 +241,18 @@ plp_status plp_line_extract(plp_line* c, const uint8_t* img, int32_t rows, int32
     int32_t s[4];
     PLP_HIP(hipMemcpy(s, c->status.p, 16, hipMemcpyDeviceToHost));
     if (s[0] & 4) return set_error(PLP_ERR_OVERFLOW, "more LSD segments than the per-frame capacity");
+    return PLP_OK;
+}
+
+plp_status plp_line_debug_grow_profile(plp_line* c, int64_t* out6) {
+    if (!c || !out6) return set_error(PLP_ERR_INVALID_ARG, "NULL argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->last_B) return set_error(PLP_ERR_INVALID_ARG, "no batch yet");
+    PLP_HIP(hipSetDevice(c->device));
+    PLP_HIP(hipStreamSynchronize(c->last_stream));
+    long long v[8] = {0};
+    PLP_HIP(hipMemcpy(v, c->prof.p, 48, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 6; ++i) out6[i] = v[i];
     return PLP_OK;
 }
 

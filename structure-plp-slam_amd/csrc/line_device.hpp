@@ -10,6 +10,11 @@ namespace plp {
 constexpr int kLineCap = 2048;        // raw LSD segments / key lines kept per frame (a 640x480 frame yields ~400)
 constexpr double kLsdNotDef = -1024.0;
 
+// Everything region growing needs about one pixel of the scaled image, in ONE 32-byte HBM sector (the kernel is
+// bound by random-access sectors, not by bytes): level-line angle (NOTDEF = -1024), gradient magnitude, and
+// (float)cos / (float)sin of float(angle).
+struct alignas(32) LsdPix { double ang; double mod; float2 cs; float2 pad; };
+
 // Per-frame geometry + HBM planes of the line path.  All planes are B frames back to back.
 struct LinePlanes {
     int W, H;                 // full-resolution frame
@@ -18,9 +23,7 @@ struct LinePlanes {
     const uint8_t* img; size_t img_frame_stride; int img_pitch;   // caller's frames
     uint8_t* blur11;          // 11-tap sigma 1.2 blur (LSD)          [B][H][pitch]
     uint8_t* scaled;          // INTER_LINEAR_EXACT x0.5              [B][sh][spitch]
-    double* ang;              // level-line angle or NOTDEF           [B][sh*sw]
-    double* mod;              // gradient magnitude                   [B][sh*sw]
-    float2* cs;               // (float)cos / sin of float(angle)     [B][sh*sw]
+    LsdPix* pix;              // per scaled pixel: angle / magnitude / cos,sin, one 32-byte sector  [B][sh*sw]
     uint16_t* bin;            // pseudo-ordering bin                  [B][sh*sw]
     unsigned long long* maxgrad;   // per frame, bit pattern of the max defined magnitude  [B]
     unsigned long long* undef;     // NOTDEF bitmask, 1 bit per scaled pixel          [B][ceil(sh*sw/64)]
@@ -31,6 +34,7 @@ struct LinePlanes {
     int16_t* dx; int16_t* dy; // Sobel 3x3                            [B][H][W]
     plp_keyline* all_kl; uint8_t* all_lbd; int32_t* n_all;   // before the length filter  [B][kLineCap]
     int32_t* status;
+    long long* prof;          // optional diagnostics of frame 0: cycles {total, grow, rect, refine}, seeds grown, pixels grown
 };
 
 struct LsdParams {

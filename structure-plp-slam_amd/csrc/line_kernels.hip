@@ -20,6 +20,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "blur_tile.hpp"
 #include "line_device.hpp"
@@ -117,7 +118,8 @@ __global__ __launch_bounds__(256) void k_lsd_gradient(LinePlanes P, LsdParams lp
             }
         }
         const size_t o = (size_t)b * n + idx;
-        P.ang[o] = ang; P.mod[o] = norm; P.cs[o] = cs;
+        LsdPix px; px.ang = ang; px.mod = norm; px.cs = cs; px.pad = make_float2(0.f, 0.f);
+        P.pix[o] = px;
     }
     // max over defined pixels: positive doubles order like their bit patterns
     unsigned long long bits = (unsigned long long)__double_as_longlong(norm_def);
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(256) void k_lsd_bins(LinePlanes P, LsdParams lp) {
     if (idx >= n) return;
     const double max_grad = __longlong_as_double((long long)P.maxgrad[b]);
     const double bin_coef = (max_grad > 0) ? (double)(lp.n_bins - 1) / max_grad : 0;
-    P.bin[(size_t)b * n + idx] = (uint16_t)(int)(P.mod[(size_t)b * n + idx] * bin_coef);
+    P.bin[(size_t)b * n + idx] = (uint16_t)(int)(P.pix[(size_t)b * n + idx].mod * bin_coef);
 }
 
 // ------------------------------------------------------------------------------------------ seed ordering
@@ -226,50 +228,34 @@ __device__ __forceinline__ double bcast_d(double v, int src) {
 }
 
 struct GrowCtx {
-    const double* ang; const double* mod; const float2* cs;
+    const LsdPix* pix;
     uint32_t* reg; uint32_t* used;   // used: LDS bitmap
     uint32_t* ring;                  // LDS: the last kRing region points (the breadth-first frontier lives here)
-    int sw, sh, lane;
+    int sw, sh, lane, ring_mask;
 };
 struct Rect { double x1, y1, x2, y2, width; };
-constexpr int kRing = 1024;
 
 __device__ __forceinline__ bool is_used(const GrowCtx& g, int p) { return (g.used[p >> 5] >> (p & 31)) & 1u; }
 __device__ __forceinline__ void set_used(const GrowCtx& g, int p) { atomicOr(&g.used[p >> 5], 1u << (p & 31)); }   // fire-and-forget ds_or
 
-// the 3x3 neighbourhood of one region point, one neighbour per lane (lanes 0..8), data prefetched
-struct Nbhd { int nx, ny, np; bool inb; double a, w; float2 cs; };
-
-__device__ __forceinline__ void fetch_nbhd(const GrowCtx& g, int idx, int nreg, Nbhd& o) {
-    uint32_t c;
-    if (nreg <= idx + kRing) c = g.ring[idx & (kRing - 1)];      // LDS broadcast read
-    else {                                                        // frontier outgrew the ring: read the HBM copy
-        c = 0;
-        if (g.lane == 0) c = __hip_atomic_load(&g.reg[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        c = __shfl(c, 0);
-    }
-    const int cx = (int)(c & 0xffff), cy = (int)(c >> 16);
-    o.nx = cx + (g.lane % 3) - 1; o.ny = cy + (g.lane / 3) - 1;
-    o.inb = g.lane < 9 && o.nx >= 0 && o.ny >= 0 && o.nx < g.sw && o.ny < g.sh;
-    o.np = o.ny * g.sw + o.nx;
-    o.a = 0; o.w = 0; o.cs = make_float2(0.f, 0.f);
-    if (o.inb) { o.a = g.ang[o.np]; o.w = g.mod[o.np]; o.cs = g.cs[o.np]; }   // three independent gathers, one wait
-}
-
-// region_grow (lsd.cpp): breadth-first over the region list; the 3x3 neighbourhood of a region point is
-// evaluated by 9 lanes at once, acceptances are applied strictly in the reference's scan order (row by row)
-// and every acceptance updates reg_angle before the remaining neighbours are tested.  The neighbourhood of
-// the NEXT region point is prefetched while the current one is processed (its pixel data is immutable; only
-// the USED bits, kept in LDS, are read late).  Undefined pixels are pre-marked USED, so no NOTDEF test.
+// region_grow (lsd.cpp).  The region list is processed breadth-first, SEVEN region points at a time: lanes
+// 9c..9c+8 hold the 3x3 neighbourhood of the c-th point of the batch (63 lanes), so one round of gathers serves
+// seven points and its HBM latency is paid once.  Acceptances are applied strictly in the reference's order
+// (point by point, row by row inside a neighbourhood = ascending lane): the lowest passing lane is accepted,
+// reg_angle is updated, and only HIGHER lanes are re-tested with the new angle; a pixel that sits in two
+// neighbourhoods of the batch is invalidated in the later one once accepted.  Undefined pixels are pre-marked
+// USED, so no NOTDEF test; a pixel that is USED when the batch is fetched needs no data at all (USED bits are
+// only ever set while a region grows), so a region interior costs almost no HBM sectors.
 // Returns the region size; cen[3] = (sum x*w, sum y*w, sum w) accumulated in region order.
 __device__ int region_grow(const GrowCtx& g, int seed, double prec, double& reg_angle, double cen[3]) {
     const int lane = g.lane;
     int nreg = 1;
     const int sx = seed % g.sw, sy = seed / g.sw;
-    reg_angle = g.ang[seed];
+    const LsdPix seed_px = g.pix[seed];
+    reg_angle = seed_px.ang;
     float sumdx = (float)cos(reg_angle), sumdy = (float)sin(reg_angle);
     {
-        const double w = g.mod[seed];
+        const double w = seed_px.mod;
         cen[0] = (double)sx * w; cen[1] = (double)sy * w; cen[2] = w;
     }
     if (lane == 0) {
@@ -278,27 +264,43 @@ __device__ int region_grow(const GrowCtx& g, int seed, double prec, double& reg_
         set_used(g, seed);
     }
     __builtin_amdgcn_wave_barrier();
-    Nbhd cur;
-    fetch_nbhd(g, 0, nreg, cur);
-    for (int i = 0; i < nreg; ++i) {
-        Nbhd nxt;
-        const bool have_next = i + 1 < nreg;
-        if (have_next) fetch_nbhd(g, i + 1, nreg, nxt);
-        bool cand = cur.inb && !is_used(g, cur.np);
+    const int slot = lane / 9, k9 = lane - slot * 9;   // slot 0..6 (lane 63: slot 7, idle)
+    const int ddx = k9 % 3 - 1, ddy = k9 / 3 - 1;
+    for (int i = 0; i < nreg;) {
+        const int nb = min(7, nreg - i);
+        // ---- fetch the batch: region point i + slot
+        bool cand = slot < nb;
+        int nx = 0, ny = 0, np = 0;
+        if (nreg > i + g.ring_mask + 1) {   // frontier outgrew the LDS ring: read the HBM copy (uniform branch)
+            uint32_t c = 0;
+            if (cand) c = __hip_atomic_load(&g.reg[i + slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            nx = (int)(c & 0xffff) + ddx; ny = (int)(c >> 16) + ddy;
+        } else {
+            const uint32_t c = g.ring[(i + min(slot, 6)) & g.ring_mask];
+            nx = (int)(c & 0xffff) + ddx; ny = (int)(c >> 16) + ddy;
+        }
+        cand = cand && nx >= 0 && ny >= 0 && nx < g.sw && ny < g.sh;
+        np = ny * g.sw + nx;
+        if (cand) cand = !is_used(g, np);
+        double a = 0, w = 0;
+        float2 ncs = make_float2(0.f, 0.f);
+        if (cand) { const LsdPix px = g.pix[np]; a = px.ang; w = px.mod; ncs = px.cs; }   // one 32-byte sector per live neighbour
+        // ---- acceptances in order
         int last = -1;
         while (true) {
-            const bool ok = cand && lane > last && aligned_to(cur.a, reg_angle, prec);
+            const bool ok = cand && lane > last && aligned_to(a, reg_angle, prec);
             const unsigned long long bal = __ballot(ok);
             if (!bal) break;
             const int k = __ffsll((long long)bal) - 1;
-            const int ax = bcast_i(cur.nx, k), ay = bcast_i(cur.ny, k);
-            const float ccos = bcast_f(cur.cs.x, k), csin = bcast_f(cur.cs.y, k);
-            const double aw = bcast_d(cur.w, k);
+            const int ax = bcast_i(nx, k), ay = bcast_i(ny, k);
+            const float ccos = bcast_f(ncs.x, k), csin = bcast_f(ncs.y, k);
+            const double aw = bcast_d(w, k);
+            const int ap = ay * g.sw + ax;
             if (lane == 0) {
                 const uint32_t c = (uint32_t)ax | ((uint32_t)ay << 16);
                 __hip_atomic_store(&g.reg[nreg], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                g.ring[nreg & (kRing - 1)] = c;
-                set_used(g, ay * g.sw + ax);
+                g.ring[nreg & g.ring_mask] = c;
+                set_used(g, ap);
             }
             ++nreg;
             sumdx = __fadd_rn(sumdx, ccos);
@@ -306,10 +308,10 @@ __device__ int region_grow(const GrowCtx& g, int seed, double prec, double& reg_
             reg_angle = (double)fast_atan2_deg_l(sumdy, sumdx) * (3.14159265358979323846 / 180);
             cen[0] += (double)ax * aw; cen[1] += (double)ay * aw; cen[2] += aw;
             last = k;
+            if (np == ap) cand = false;   // the same pixel seen from a later point of the batch
         }
         __builtin_amdgcn_wave_barrier();
-        if (!have_next && i + 1 < nreg) fetch_nbhd(g, i + 1, nreg, nxt);   // the next point was created just now
-        cur = nxt;
+        i += nb;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // region list in HBM is read by all lanes next
     __builtin_amdgcn_wave_barrier();
@@ -327,7 +329,7 @@ __device__ void region2rect(const GrowCtx& g, int nreg, double reg_angle, double
         double txx = 0, tyy = 0, txy = 0;   // this lane's addends (same roundings as the reference's per-point products)
         if (j < nreg) {
             const uint32_t c = g.reg[j];
-            const double w = g.mod[(int)(c >> 16) * g.sw + (int)(c & 0xffff)];
+            const double w = g.pix[(int)(c >> 16) * g.sw + (int)(c & 0xffff)].mod;
             const double dx = (double)(int)(c & 0xffff) - x, dy = (double)(int)(c >> 16) - y;
             txx = dy * dy * w; tyy = dx * dx * w; txy = dx * dy * w;
         }
@@ -377,7 +379,7 @@ __device__ void centroid_sums(const GrowCtx& g, int nreg, double cen[3]) {
         double tx = 0, ty = 0, w = 0;
         if (j < nreg) {
             const uint32_t c = g.reg[j];
-            w = g.mod[(int)(c >> 16) * g.sw + (int)(c & 0xffff)];
+            w = g.pix[(int)(c >> 16) * g.sw + (int)(c & 0xffff)].mod;
             tx = (double)(int)(c & 0xffff) * w; ty = (double)(int)(c >> 16) * w;
         }
         const int cnt = min(64, nreg - base);
@@ -387,15 +389,15 @@ __device__ void centroid_sums(const GrowCtx& g, int nreg, double cen[3]) {
 
 // grid = (ceil(B / wpb)), block = 64 * wpb: wave w of a block handles frame wpb*blockIdx.x + w (wpb = waves whose
 // USED bitmap + frontier ring fit 64 KB of LDS together, at most 4).
-__global__ __launch_bounds__(256) void k_lsd_grow(LinePlanes P, LsdParams lp, int B, int wpb) {
+__global__ __launch_bounds__(256) void k_lsd_grow(LinePlanes P, LsdParams lp, int B, int wpb, int ring) {
     extern __shared__ uint32_t s_bits[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int b = blockIdx.x * wpb + wv;
     if (b >= B) return;
     const int n = P.sw * P.sh, nwords = (n + 31) / 32, nv = (P.sw - 1) * (P.sh - 1);
     GrowCtx g;
-    g.ang = P.ang + (size_t)b * n; g.mod = P.mod + (size_t)b * n; g.cs = P.cs + (size_t)b * n;
-    g.reg = P.reg + (size_t)b * n; g.used = s_bits + (size_t)wv * (nwords + kRing); g.ring = g.used + nwords;
+    g.pix = P.pix + (size_t)b * n;
+    g.reg = P.reg + (size_t)b * n; g.used = s_bits + (size_t)wv * (nwords + ring); g.ring = g.used + nwords; g.ring_mask = ring - 1;
     g.sw = P.sw; g.sh = P.sh; g.lane = lane;
     // USED map starts as the NOTDEF mask: an undefined pixel is never a seed and never aligned, so
     // treating it as used is equivalent and spares a global load per rejected seed
@@ -408,6 +410,8 @@ __global__ __launch_bounds__(256) void k_lsd_grow(LinePlanes P, LsdParams lp, in
     const uint32_t* order = P.order + (size_t)b * nv;
     float4* raw = P.raw + (size_t)b * kLineCap;
     int n_lines = 0;
+    long long t_grow = 0, t_rect = 0, t_refine = 0, n_seed = 0, n_pix = 0;
+    const long long t_begin = clock64();
     for (int base = 0; base < nv; base += 64) {
         const bool in_range = base + lane < nv;
         const uint32_t mine = in_range ? order[base + lane] : 0u;
@@ -419,10 +423,15 @@ __global__ __launch_bounds__(256) void k_lsd_grow(LinePlanes P, LsdParams lp, in
             const int seed = bcast_i((int)mine, t);
             if (is_used(g, seed)) continue;   // claimed by a region grown since the ballot
             double reg_angle, cen[3];
+            long long t0 = clock64();
             int nreg = region_grow(g, seed, lp.prec, reg_angle, cen);
+            t_grow += clock64() - t0; ++n_seed; n_pix += nreg;
             if (nreg < lp.min_reg_size) continue;
             Rect rec;
+            t0 = clock64();
             region2rect(g, nreg, reg_angle, lp.prec, cen, rec);
+            t_rect += clock64() - t0;
+            t0 = clock64();
             bool keep = true;
             if (lp.refine > 0) {
                 double density = rect_density(nreg, rec);
@@ -430,7 +439,7 @@ __global__ __launch_bounds__(256) void k_lsd_grow(LinePlanes P, LsdParams lp, in
                     // ---- refine: tighter angle tolerance from the points near the seed
                     const uint32_t c0 = g.reg[0];
                     const double xc = (double)(int)(c0 & 0xffff), yc = (double)(int)(c0 >> 16);
-                    const double ang_c = g.ang[(int)(c0 >> 16) * g.sw + (int)(c0 & 0xffff)];
+                    const double ang_c = g.pix[(int)(c0 >> 16) * g.sw + (int)(c0 & 0xffff)].ang;
                     double sum = 0, s_sum = 0;
                     int nn = 0;
                     for (int rb = 0; rb < nreg; rb += 64) {
@@ -443,7 +452,7 @@ __global__ __launch_bounds__(256) void k_lsd_grow(LinePlanes P, LsdParams lp, in
                             atomicAnd(&g.used[(py * g.sw + px) >> 5], ~(1u << ((py * g.sw + px) & 31)));   // *(reg[i].used) = NOTUSED
                             const double ddx = (double)px - xc, ddy = (double)py - yc;
                             near = sqrt(ddx * ddx + ddy * ddy) < rec.width;
-                            a = g.ang[py * g.sw + px];
+                            a = g.pix[py * g.sw + px].ang;
                         }
                         const double my_d = near ? angle_diff_signed(a, ang_c) : 0.0;
                         const double my_d2 = my_d * my_d;
@@ -496,6 +505,7 @@ __global__ __launch_bounds__(256) void k_lsd_grow(LinePlanes P, LsdParams lp, in
                     }
                 }
             }
+            t_refine += clock64() - t0;
             if (!keep) continue;
             // +0.5 offset, undo the sub-sampling, cast to f32 (lsd.cpp flsd)
             rec.x1 += 0.5; rec.y1 += 0.5; rec.x2 += 0.5; rec.y2 += 0.5;
@@ -506,6 +516,9 @@ __global__ __launch_bounds__(256) void k_lsd_grow(LinePlanes P, LsdParams lp, in
         }
     }
     if (lane == 0) P.n_raw[b] = min(n_lines, kLineCap);
+    if (lane == 0 && b == 0 && P.prof) {   // diagnostics of frame 0: cycles per phase
+        P.prof[0] = clock64() - t_begin; P.prof[1] = t_grow; P.prof[2] = t_rect; P.prof[3] = t_refine; P.prof[4] = n_seed; P.prof[5] = n_pix;
+    }
 }
 
 // ------------------------------------------------------------------------------------------ KeyLine assembly
@@ -742,9 +755,14 @@ void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp,
     mark(2);
     hipLaunchKernelGGL(k_lsd_order, dim3(B), dim3(256), 0, st, P);
     mark(3);
-    const size_t per_wave = (size_t)((n + 31) / 32 + 1024) * 4;   // USED bitmap + 1024-entry frontier ring
-    const int wpb = (int)std::max<size_t>(1, std::min<size_t>(4, 65536 / per_wave));
-    hipLaunchKernelGGL(k_lsd_grow, dim3((B + wpb - 1) / wpb), dim3(64 * wpb), per_wave * wpb, st, P, lp, B, wpb);
+    // per wave: USED bitmap + frontier ring (a power of two; the HBM copy of the region list backs larger frontiers).
+    // One wave per workgroup keeps the LDS footprint small so that ~15 frames per CU are in flight: the kernel is
+    // latency bound (one dependent HBM gather per region point), occupancy is what buys throughput.
+    static const int ring = [] { const char* e = getenv("PLP_LSD_RING"); int r = e ? atoi(e) : 256; return (r >= 64 && (r & (r - 1)) == 0) ? r : 256; }();
+    static const int wpb_env = [] { const char* e = getenv("PLP_LSD_WPB"); return e ? atoi(e) : 1; }();
+    const size_t per_wave = (size_t)((n + 31) / 32 + ring) * 4;
+    const int wpb = (int)std::max<size_t>(1, std::min<size_t>(std::min(4, std::max(1, wpb_env)), 65536 / per_wave));
+    hipLaunchKernelGGL(k_lsd_grow, dim3((B + wpb - 1) / wpb), dim3(64 * wpb), per_wave * wpb, st, P, lp, B, wpb, ring);
     mark(4);
     hipLaunchKernelGGL(k_keylines, dim3(B), dim3(64), 0, st, P, lp);
     mark(5);
