@@ -197,6 +197,7 @@ plp_status plp_line_debug_grow_profile(plp_line* ctx, int64_t* out6);
  * REFERENCE'S ITERATION ORDER (results depend on it: an accepted query blocks its key point for all
  * later queries).  B independent problems per call; arrays are B x n_cap / B x m_cap, row-major.
  * ---------------------------------------------------------------------------------------- */
+typedef struct plp_keyline plp_keyline_fwd_;
 typedef struct plp_matcher plp_matcher;   /* owns a HIP stream and scratch; one per calling thread */
 plp_status plp_matcher_create(int device, plp_matcher** out);
 void plp_matcher_destroy(plp_matcher* ctx);
@@ -204,7 +205,9 @@ void plp_matcher_destroy(plp_matcher* ctx);
 typedef enum plp_match_mode {
     PLP_MATCH_MODE_LANDMARKS = 0,   /* projection::match_frame_and_landmarks          match/projection.cc:37-121  */
     PLP_MATCH_MODE_LAST_FRAME = 1,  /* projection::match_current_and_last_frames      match/projection.cc:214-358 */
-    PLP_MATCH_MODE_BRUTE_FORCE = 2  /* robust::brute_force_match                      match/robust.cc:257-385     */
+    PLP_MATCH_MODE_BRUTE_FORCE = 2, /* robust::brute_force_match                      match/robust.cc:257-385     */
+    PLP_MATCH_MODE_LANDMARKS_LINE = 3,  /* projection::match_frame_and_landmarks_line      match/projection.cc:124-212 */
+    PLP_MATCH_MODE_LAST_FRAME_LINE = 4  /* projection::match_current_and_last_frames_line  match/projection.cc:361-527 */
 } plp_match_mode;
 
 typedef struct plp_match_grid {     /* camera::base grid (camera/base.h:91) used by data::get_keypoints_in_cell */
@@ -239,6 +242,19 @@ typedef struct plp_match_args {
     int32_t num_levels;
     const float* scale_factors;     /* HOST pointer, num_levels floats (frame::scale_factors_) */
     plp_match_grid grid;
+    /* line modes (targets = key lines of the current frame, candidates by data::get_keylines_in_cell,
+     * data/common.cc:315-363): t_kl replaces t_kps, t_desc = _lbd_descr, q_reproj/q_reproj2 = reprojected start /
+     * end point, q_desc = Line::get_descriptor().  t_kp_octave[i] = undist_keypts_.at(i).octave, the key POINT
+     * octave the reference reads with a LINE index (projection.cc:187,192; LANDMARKS_LINE only).  RGB-D stereo
+     * gate of LAST_FRAME_LINE: t_x_right / t_x_right2 = _stereo_x_right_cooresponding_to_keylines first / second,
+     * q_x_right / q_x_right2 = x_right of the reprojected start / end point, is_rgbd != 0. */
+    const plp_keyline* t_kl;        /* B x n_cap */
+    const int32_t* t_kp_octave;     /* B x n_cap */
+    const float* t_x_right2;        /* B x n_cap or NULL */
+    const float* q_reproj2;         /* B x m_cap x 2 */
+    const float* q_x_right2;        /* B x m_cap or NULL */
+    int32_t is_rgbd;
+    int32_t num_levels_lsd;         /* last_frm._num_scale_levels_lsd (upper bound of the assume_forward window) */
     /* outputs: out_match[b][t] = index of the query associated with key point t (-1 = none),
      * out_num[b] = the matcher's return value (num_matches) */
     int32_t* out_match;             /* B x n_cap */

@@ -296,3 +296,114 @@ unsigned oracle_brute_force_match(const uint8_t* desc1, const float* angle1, int
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------- line variants
+// data::get_keylines_in_cell (data/common.cc:315-363): linear scan, both end points within `margin` of the
+// projected line; level filter with the `max_level > 0` quirk (:354).
+struct KeyLineRec {   // cv::line_descriptor::KeyLine, 68 bytes
+    float angle; int class_id, octave; float pt_x, pt_y, response, size;
+    float startPointX, startPointY, endPointX, endPointY, sPointInOctaveX, sPointInOctaveY, ePointInOctaveX, ePointInOctaveY;
+    float lineLength; int numOfPixels;
+};
+static std::vector<unsigned> keylines_in_cell(const KeyLineRec* kl, int n, float x1, float y1, float x2, float y2, float margin,
+                                              int min_level, int max_level) {
+    std::vector<unsigned> idx;
+    const double sp[3] = {x1, y1, 1.0}, ep[3] = {x2, y2, 1.0};
+    const double l0 = sp[1] * ep[2] - sp[2] * ep[1], l1 = sp[2] * ep[0] - sp[0] * ep[2], l2 = sp[0] * ep[1] - sp[1] * ep[0];
+    const bool check_level = (0 < min_level) || (0 <= max_level);
+    for (int i = 0; i < n; ++i) {
+        const float dsp = (float)((kl[i].startPointX * l0 + kl[i].startPointY * l1 + l2) / std::sqrt(l0 * l0 + l1 * l1));
+        const float dep = (float)((kl[i].endPointX * l0 + kl[i].endPointY * l1 + l2) / std::sqrt(l0 * l0 + l1 * l1));
+        if (std::abs(dsp) > margin || std::abs(dep) > margin) continue;
+        if (check_level) {
+            if (kl[i].octave < min_level) continue;
+            if (max_level > 0 && kl[i].octave > max_level) continue;
+        }
+        idx.push_back((unsigned)i);
+    }
+    return idx;
+}
+
+extern "C" {
+
+int oracle_keylines_in_cell(const KeyLineRec* kl, int n, float x1, float y1, float x2, float y2, float margin, int min_level,
+                            int max_level, unsigned* out) {
+    auto v = keylines_in_cell(kl, n, x1, y1, x2, y2, margin, min_level, max_level);
+    for (size_t i = 0; i < v.size(); ++i) out[i] = v[i];
+    return (int)v.size();
+}
+
+// projection::match_frame_and_landmarks_line (projection.cc:124-212), array form.
+//   kp_octave[n]: frm.undist_keypts_.at(idx).octave read with the LINE index (quirk, :187,192)
+unsigned oracle_match_frame_and_landmarks_line(const KeyLineRec* kl, const uint8_t* lbd, const int* kp_octave, const uint8_t* occupied, int n,
+                                               const float* scale_factors_lsd, const uint8_t* lm_valid, const float* lm_sp,
+                                               const float* lm_ep, const int* lm_level, const uint8_t* lm_desc,
+                                               const uint8_t* lm_has_obs, int m, float margin, float lowe_ratio, int* line_landmark) {
+    std::vector<uint8_t> occ(occupied, occupied + n);
+    for (int i = 0; i < n; ++i) line_landmark[i] = -1;
+    unsigned num_matches = 0;
+    if (m == 0) return 0;
+    for (int l = 0; l < m; ++l) {
+        if (!lm_valid[l]) continue;
+        const int lvl = lm_level[l];
+        const auto cand = keylines_in_cell(kl, n, lm_sp[2 * l], lm_sp[2 * l + 1], lm_ep[2 * l], lm_ep[2 * l + 1],
+                                           margin * scale_factors_lsd[lvl], lvl - 1, lvl);
+        if (cand.empty()) continue;
+        unsigned best = MAX_HAMMING_DIST, second = MAX_HAMMING_DIST;
+        int best_level = -1, second_level = -1, best_idx = -1;
+        for (unsigned idx : cand) {
+            if (occ[idx]) continue;
+            const unsigned d = hamming32(lm_desc + 32 * (size_t)l, lbd + 32 * (size_t)idx);
+            if (d < best) { second = best; best = d; second_level = best_level; best_level = kp_octave[idx]; best_idx = (int)idx; }
+            else if (d < second) { second_level = kp_octave[idx]; second = d; }
+        }
+        if (best <= HAMMING_DIST_THR_HIGH) {
+            if (best_level == second_level && best > lowe_ratio * second) continue;
+            line_landmark[best_idx] = l;
+            occ[best_idx] = lm_has_obs[l];
+            ++num_matches;
+        }
+    }
+    return num_matches;
+}
+
+// projection::match_current_and_last_frames_line (projection.cc:361-527), array form.
+//   valid[m]: landmark present && !outlier && the (partial-occlusion) visibility test passed
+//   xr_pair[n][2]: _stereo_x_right_cooresponding_to_keylines; is_rgbd: camera setup RGBD
+unsigned oracle_match_current_and_last_line(const KeyLineRec* kl, const uint8_t* lbd, const float* xr_pair, const uint8_t* occupied, int n,
+                                            const float* scale_factors_lsd, int num_levels_lsd, const uint8_t* valid,
+                                            const float* sp, const float* ep, const float* lxr_sp, const float* lxr_ep,
+                                            const int* loctave, const uint8_t* ldesc, const uint8_t* l_has_obs, int m, float margin,
+                                            int direction, int is_rgbd, int* line_last) {
+    std::vector<uint8_t> occ(occupied, occupied + n);
+    for (int i = 0; i < n; ++i) line_last[i] = -1;
+    unsigned num_matches = 0;
+    for (int l = 0; l < m; ++l) {
+        if (!valid[l]) continue;
+        const int lvl = loctave[l];
+        const float mg = margin * scale_factors_lsd[lvl];
+        std::vector<unsigned> cand;
+        if (direction == 1) cand = keylines_in_cell(kl, n, sp[2 * l], sp[2 * l + 1], ep[2 * l], ep[2 * l + 1], mg, lvl, num_levels_lsd);
+        else if (direction == 2) cand = keylines_in_cell(kl, n, sp[2 * l], sp[2 * l + 1], ep[2 * l], ep[2 * l + 1], mg, 0, lvl + 1);
+        else cand = keylines_in_cell(kl, n, sp[2 * l], sp[2 * l + 1], ep[2 * l], ep[2 * l + 1], mg, lvl - 1, lvl + 1);
+        if (cand.empty()) continue;
+        unsigned best = MAX_HAMMING_DIST;
+        int best_idx = -1;
+        for (unsigned idx : cand) {
+            if (occ[idx]) continue;
+            if (is_rgbd && xr_pair[2 * idx] > 0 && xr_pair[2 * idx + 1] > 0) {
+                const float e_sp = std::fabs(lxr_sp[l] - xr_pair[2 * idx]), e_ep = std::fabs(lxr_ep[l] - xr_pair[2 * idx + 1]);
+                if (mg < e_sp || mg < e_ep) continue;
+            }
+            const unsigned d = hamming32(ldesc + 32 * (size_t)l, lbd + 32 * (size_t)idx);
+            if (d < best) { best = d; best_idx = (int)idx; }
+        }
+        if (HAMMING_DIST_THR_HIGH < best) continue;
+        line_last[best_idx] = l;
+        occ[best_idx] = l_has_obs[l];
+        ++num_matches;
+    }
+    return num_matches;
+}
+
+}  // extern "C"

@@ -358,10 +358,12 @@ class match_args_c(C.Structure):
                 ("q_valid", _VP), ("q_reproj", _VP), ("q_x_right", _VP), ("q_level", _VP), ("q_angle", _VP), ("q_desc", _VP),
                 ("q_has_obs", _VP), ("q_counts", _VP),
                 ("margin", C.c_float), ("lowe_ratio", C.c_float), ("direction", C.c_int32), ("check_orientation", C.c_int32),
-                ("num_levels", C.c_int32), ("scale_factors", _VP), ("grid", match_grid_c), ("out_match", _VP), ("out_num", _VP)]
+                ("num_levels", C.c_int32), ("scale_factors", _VP), ("grid", match_grid_c),
+                ("t_kl", _VP), ("t_kp_octave", _VP), ("t_x_right2", _VP), ("q_reproj2", _VP), ("q_x_right2", _VP),
+                ("is_rgbd", C.c_int32), ("num_levels_lsd", C.c_int32), ("out_match", _VP), ("out_num", _VP)]
 
 
-MODE_LANDMARKS, MODE_LAST_FRAME, MODE_BRUTE_FORCE = 0, 1, 2
+MODE_LANDMARKS, MODE_LAST_FRAME, MODE_BRUTE_FORCE, MODE_LANDMARKS_LINE, MODE_LAST_FRAME_LINE = 0, 1, 2, 3, 4
 
 
 def make_grid(cols_px, rows_px, grid_cols=64, grid_rows=48, min_x=0.0, min_y=0.0):
@@ -393,7 +395,10 @@ class matcher:
         a = match_args_c()
         a.mode, a.B, a.n_cap, a.m_cap = mode, B, n_cap, m_cap
         for k, v in fields.items():
-            setattr(a, k, ptr(v) if v is not None else None)
+            if k in ("is_rgbd", "num_levels_lsd"):
+                setattr(a, k, int(v))
+            else:
+                setattr(a, k, ptr(v) if v is not None else None)
         a.margin, a.lowe_ratio = margin, self.lowe_ratio
         a.direction, a.check_orientation = direction, int(self.check_orientation)
         if scale_factors is not None:
@@ -407,7 +412,7 @@ class matcher:
 
     def match_host(self, mode, n_cap, m_cap, fields, margin=0.0, direction=0, scale_factors=None, grid=None, B=1):
         """fields: dict of numpy arrays named like plp_match_args members.  Returns (out_match [B,n_cap], out_num [B])."""
-        fields = {k: (None if v is None else np.ascontiguousarray(v)) for k, v in fields.items()}
+        fields = {k: (v if (v is None or np.isscalar(v)) else np.ascontiguousarray(v)) for k, v in fields.items()}
         out_match = np.zeros((B, n_cap), np.int32)
         out_num = np.zeros(B, np.int32)
         a = self._args(mode, B, n_cap, m_cap, fields, margin, direction, scale_factors, grid, out_match, out_num, lambda v: v.ctypes.data)

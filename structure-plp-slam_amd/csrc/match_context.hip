@@ -32,6 +32,10 @@ plp_status check_args(const plp_match_args* a) {
         if (a->num_levels <= 0 || a->num_levels > 16) return set_error(PLP_ERR_INVALID_ARG, "num_levels must be in [1,16]");
         if (a->grid.cols <= 0 || a->grid.rows <= 0 || a->grid.cols * a->grid.rows > 4096) return set_error(PLP_ERR_INVALID_ARG, "grid must have 1..4096 cells");
         if (a->mode == PLP_MATCH_MODE_LAST_FRAME && a->check_orientation && !a->q_angle) return set_error(PLP_ERR_INVALID_ARG, "check_orientation needs q_angle");
+    } else if (a->mode == PLP_MATCH_MODE_LANDMARKS_LINE || a->mode == PLP_MATCH_MODE_LAST_FRAME_LINE) {
+        if (!a->t_kl || !a->q_reproj || !a->q_reproj2 || !a->q_level || !a->scale_factors) return set_error(PLP_ERR_INVALID_ARG, "t_kl, q_reproj, q_reproj2, q_level, scale_factors are required");
+        if (a->mode == PLP_MATCH_MODE_LANDMARKS_LINE && !a->t_kp_octave) return set_error(PLP_ERR_INVALID_ARG, "t_kp_octave is required");
+        if (a->num_levels <= 0 || a->num_levels > 16) return set_error(PLP_ERR_INVALID_ARG, "num_levels must be in [1,16]");
     } else return set_error(PLP_ERR_INVALID_ARG, "unknown mode");
     return PLP_OK;
 }
@@ -50,10 +54,12 @@ plp_status run_device(plp_matcher* c, const plp_match_args* a, hipStream_t st) {
     if (!c->dbg.p) { PLP_HIP(c->dbg.reserve(16)); PLP_HIP(hipMemsetAsync(c->dbg.p, 0, 16, st)); }
     MatchProblem P{};
     P.mode = a->mode; P.n_cap = a->n_cap; P.m_cap = a->m_cap;
-    P.t_kps = a->mode == PLP_MATCH_MODE_BRUTE_FORCE ? nullptr : a->t_kps;
+    P.t_kps = (a->mode == PLP_MATCH_MODE_LANDMARKS || a->mode == PLP_MATCH_MODE_LAST_FRAME) ? a->t_kps : nullptr;
     P.t_desc = a->t_desc; P.t_x_right = a->t_x_right; P.t_occupied = a->t_occupied; P.t_angle = a->t_angle; P.t_counts = a->t_counts;
     P.q_valid = a->q_valid; P.q_reproj = a->q_reproj; P.q_x_right = a->q_x_right; P.q_level = a->q_level; P.q_angle = a->q_angle;
     P.q_desc = a->q_desc; P.q_has_obs = a->q_has_obs; P.q_counts = a->q_counts;
+    P.t_kl = a->t_kl; P.t_kp_octave = a->t_kp_octave; P.t_x_right2 = a->t_x_right2; P.q_reproj2 = a->q_reproj2; P.q_x_right2 = a->q_x_right2;
+    P.is_rgbd = a->is_rgbd; P.num_levels_lsd = a->num_levels_lsd;
     P.margin = a->margin; P.lowe_ratio = a->lowe_ratio; P.direction = a->direction; P.check_orientation = a->check_orientation;
     P.num_levels = a->num_levels;
     for (int i = 0; i < 16; ++i) P.scale_factors[i] = (a->scale_factors && i < a->num_levels) ? a->scale_factors[i] : 1.0f;
@@ -123,6 +129,9 @@ plp_status plp_match_host(plp_matcher* c, const plp_match_args* a) {
     const size_t o_qx = add(a->q_x_right, a->q_x_right ? qn * 4 : 0), o_ql = add(a->q_level, a->q_level ? qn * 4 : 0);
     const size_t o_qa = add(a->q_angle, a->q_angle ? qn * 4 : 0), o_qd = add(a->q_desc, qn * 32);
     const size_t o_qh = add(a->q_has_obs, a->q_has_obs ? qn : 0), o_qc = add(a->q_counts, a->q_counts ? (size_t)a->B * 4 : 0);
+    const size_t o_kl = add(a->t_kl, a->t_kl ? tn * sizeof(plp_keyline) : 0), o_ko = add(a->t_kp_octave, a->t_kp_octave ? tn * 4 : 0);
+    const size_t o_tx2 = add(a->t_x_right2, a->t_x_right2 ? tn * 4 : 0), o_qr2 = add(a->q_reproj2, a->q_reproj2 ? qn * 8 : 0);
+    const size_t o_qx2 = add(a->q_x_right2, a->q_x_right2 ? qn * 4 : 0);
     const size_t o_om = off; off += (tn * 4 + 255) / 256 * 256;
     const size_t o_on = off; off += ((size_t)a->B * 4 + 255) / 256 * 256;
     PLP_HIP(c->stage.reserve(off));
@@ -138,6 +147,9 @@ plp_status plp_match_host(plp_matcher* c, const plp_match_args* a) {
     d.q_x_right = (const float*)dp(a->q_x_right, o_qx); d.q_level = (const int32_t*)dp(a->q_level, o_ql);
     d.q_angle = (const float*)dp(a->q_angle, o_qa); d.q_desc = (const uint8_t*)dp(a->q_desc, o_qd);
     d.q_has_obs = (const uint8_t*)dp(a->q_has_obs, o_qh); d.q_counts = (const int32_t*)dp(a->q_counts, o_qc);
+    d.t_kl = (const plp_keyline*)dp(a->t_kl, o_kl); d.t_kp_octave = (const int32_t*)dp(a->t_kp_octave, o_ko);
+    d.t_x_right2 = (const float*)dp(a->t_x_right2, o_tx2); d.q_reproj2 = (const float*)dp(a->q_reproj2, o_qr2);
+    d.q_x_right2 = (const float*)dp(a->q_x_right2, o_qx2);
     d.out_match = (int32_t*)(base + o_om); d.out_num = (int32_t*)(base + o_on);
     PLP_TRY(run_device(c, &d, st));
     PLP_HIP(hipMemcpyAsync(a->out_match, base + o_om, tn * 4, hipMemcpyDeviceToHost, st));

@@ -22,6 +22,12 @@ struct MatchProblem {
     const uint8_t* t_occupied;       // key point already holds an observed landmark (NULL: none)
     const float* t_angle;            // brute-force mode: keypts_1[.].angle
     const int32_t* t_counts;         // per-problem n (NULL: n_cap)
+    const plp_keyline* t_kl;         // line modes: key lines (replaces t_kps)
+    const int32_t* t_kp_octave;      // line modes: the key-point octave read with a line index (reference quirk)
+    const float* t_x_right2;         // line modes: second stereo coordinate
+    const float* q_reproj2;          // line modes: reprojected end point
+    const float* q_x_right2;
+    int is_rgbd, num_levels_lsd;
     // queries = landmarks / last-frame key points / key-frame key points (B x m_cap), reference order
     const uint8_t* q_valid;          // NULL: all valid
     const float* q_reproj;           // x, y

@@ -41,16 +41,34 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 // Candidate filter + key of (query q, target t); returns ~0ull when t is not a candidate.
 // key = distance << 32 | visiting order << 4 | octave   (order = grid cell (col-major) then index)
 struct QueryCtx {
-    float rx, ry, mg, xr;
+    float rx, ry, mg, xr, xr2;
     int min_level, max_level, min_cx, max_cx, min_cy, max_cy;
-    bool windowed, empty;
+    double l0, l1, l2, lden;   // line modes: the projected line (sp x ep) and sqrt(l0^2 + l1^2)
+    bool windowed, empty, line;
 };
+__device__ __forceinline__ bool is_line_mode(int mode) { return mode == PLP_MATCH_MODE_LANDMARKS_LINE || mode == PLP_MATCH_MODE_LAST_FRAME_LINE; }
 
 __device__ __forceinline__ QueryCtx make_query(const MatchProblem& P, int q, const float* reproj, const float* q_xr, const int32_t* q_level) {
     QueryCtx c{};
     c.windowed = P.mode != PLP_MATCH_MODE_BRUTE_FORCE;
+    c.line = is_line_mode(P.mode);
     if (!c.windowed) return c;
     const int lvl = q_level[q];
+    if (c.line) {   // data::get_keylines_in_cell (common.cc:315-363) + the level windows of projection.cc:138-144, :429-450
+        const float* r2 = P.q_reproj2 + ((size_t)(reproj - P.q_reproj) / 2) * 2;   // same per-problem offset as `reproj`
+        c.mg = __fmul_rn(P.margin, P.scale_factors[lvl]);
+        const double x1 = reproj[2 * q], y1 = reproj[2 * q + 1], x2 = r2[2 * q], y2 = r2[2 * q + 1];
+        c.l0 = y1 * 1.0 - 1.0 * y2; c.l1 = 1.0 * x2 - x1 * 1.0; c.l2 = x1 * y2 - y1 * x2;
+        c.lden = sqrt(c.l0 * c.l0 + c.l1 * c.l1);
+        c.xr = q_xr ? q_xr[q] : -1.f;
+        c.xr2 = P.q_x_right2 ? (P.q_x_right2 + (q_xr ? (q_xr - P.q_x_right) : 0))[q] : -1.f;
+        if (P.mode == PLP_MATCH_MODE_LANDMARKS_LINE) { c.min_level = lvl - 1; c.max_level = lvl; }
+        else if (P.direction == 1) { c.min_level = lvl; c.max_level = P.num_levels_lsd; }
+        else if (P.direction == 2) { c.min_level = 0; c.max_level = lvl + 1; }
+        else { c.min_level = lvl - 1; c.max_level = lvl + 1; }
+        c.empty = false;
+        return c;
+    }
     c.rx = reproj[2 * q]; c.ry = reproj[2 * q + 1];
     c.mg = __fmul_rn(P.margin, P.scale_factors[lvl]);
     c.xr = q_xr ? q_xr[q] : -1.f;
@@ -72,7 +90,24 @@ __device__ __forceinline__ unsigned long long candidate_key(const MatchProblem& 
                                                            const uint8_t* t_desc, const float* t_xr, const uint8_t* t_occ,
                                                            const uint4& q0, const uint4& q1) {
     unsigned order = (unsigned)t, oct = 0;
-    if (c.windowed) {
+    if (c.line) {
+        const size_t tb = (size_t)(t_desc - P.t_desc) / 32;   // per-problem target offset
+        const plp_keyline kl = P.t_kl[tb + t];
+        const float dsp = (float)(((double)kl.startPointX * c.l0 + (double)kl.startPointY * c.l1 + c.l2) / c.lden);
+        const float dep = (float)(((double)kl.endPointX * c.l0 + (double)kl.endPointY * c.l1 + c.l2) / c.lden);
+        if (fabsf(dsp) > c.mg || fabsf(dep) > c.mg) return ~0ull;
+        const bool check_level = (0 < c.min_level) || (0 <= c.max_level);
+        if (check_level) {
+            if (kl.octave < c.min_level) return ~0ull;
+            if (c.max_level > 0 && kl.octave > c.max_level) return ~0ull;   // `max_level > 0` as the reference (common.cc:354)
+        }
+        if (t_occ && t_occ[t]) return ~0ull;
+        if (P.mode == PLP_MATCH_MODE_LAST_FRAME_LINE && P.is_rgbd && t_xr && P.t_x_right2) {
+            const float a = t_xr[t], b2 = P.t_x_right2[tb + t];
+            if (a > 0 && b2 > 0 && (c.mg < fabsf(__fsub_rn(c.xr, a)) || c.mg < fabsf(__fsub_rn(c.xr2, b2)))) return ~0ull;
+        }
+        oct = P.t_kp_octave ? ((unsigned)P.t_kp_octave[tb + t] & 15u) : 0u;
+    } else if (c.windowed) {
         const plp_keypoint k = kps[t];
         const int cx = floor_d((double)__fsub_rn(k.x, P.grid_min_x) * P.inv_cell_w);
         const int cy = floor_d((double)__fsub_rn(k.y, P.grid_min_y) * P.inv_cell_h);
@@ -288,12 +323,12 @@ __global__ __launch_bounds__(256) void k_match_topk_lds(MatchProblem P) {
 
 // accept rules of the three matchers; best/second are (distance, octave) of the two best free candidates
 __device__ __forceinline__ bool accept(const MatchProblem& P, unsigned best, int best_lvl, unsigned second, int second_lvl) {
-    if (P.mode == PLP_MATCH_MODE_LANDMARKS) {
+    if (P.mode == PLP_MATCH_MODE_LANDMARKS || P.mode == PLP_MATCH_MODE_LANDMARKS_LINE) {
         if (!(best <= 100u)) return false;
         if (best_lvl == second_lvl && (float)best > __fmul_rn(P.lowe_ratio, (float)second)) return false;
         return true;
     }
-    if (P.mode == PLP_MATCH_MODE_LAST_FRAME) return best <= 100u;
+    if (P.mode == PLP_MATCH_MODE_LAST_FRAME || P.mode == PLP_MATCH_MODE_LAST_FRAME_LINE) return best <= 100u;
     if (50u < best) return false;                                            // brute force: HAMMING_DIST_THR_LOW
     if (__fmul_rn(P.lowe_ratio, (float)second) < (float)best) return false;
     return true;
@@ -326,9 +361,9 @@ __global__ __launch_bounds__(256) void k_match_resolve(MatchProblem P) {
     __syncthreads();
 
     int32_t* full_list = P.full_list + (size_t)b * P.m_cap;   // queries whose truncated best-K list ran dry
-    const int need = P.mode == PLP_MATCH_MODE_LAST_FRAME ? 1 : 2;   // the last-frame matcher has no second-best test
+    const int need = (P.mode == PLP_MATCH_MODE_LAST_FRAME || P.mode == PLP_MATCH_MODE_LAST_FRAME_LINE) ? 1 : 2;   // the last-frame matcher has no second-best test
     const bool blocks_always = !has_obs || P.mode == PLP_MATCH_MODE_BRUTE_FORCE;
-    const bool use_sorted = P.mode != PLP_MATCH_MODE_BRUTE_FORCE && P.sorted_valid;
+    const bool use_sorted = P.sorted_valid != 0;
     const StagedTarget* sorted = P.sorted + (size_t)b * P.n_cap;
     const float* sorted_xr = P.sorted_xr + (size_t)b * P.n_cap;
     const int32_t* g_row_start = P.row_start + (size_t)b * 260;
@@ -451,7 +486,7 @@ __global__ __launch_bounds__(256) void k_match_resolve(MatchProblem P) {
     if (tid == 0) s_num = 0;
     for (int i = tid; i < 32; i += 256) { s_hist[i] = 0; s_valid_bin[i] = 0; }
     __syncthreads();
-    const bool angle_check = P.check_orientation && P.mode != PLP_MATCH_MODE_LANDMARKS;
+    const bool angle_check = P.check_orientation && (P.mode == PLP_MATCH_MODE_LAST_FRAME || P.mode == PLP_MATCH_MODE_BRUTE_FORCE);
     const float* q_angle = P.q_angle ? P.q_angle + (size_t)b * P.m_cap : nullptr;
     const float* t_angle = P.t_angle ? P.t_angle + (size_t)b * P.n_cap : nullptr;
     auto bin_of = [&](int q, int t) -> int {
@@ -522,9 +557,10 @@ __global__ __launch_bounds__(256) void k_hamming_matrix(const uint8_t* __restric
 void launch_match(hipStream_t st, const MatchProblem& P, int B) {
     MatchProblem Q = P;
     Q.sorted_valid = 0;
-    const bool windowed = P.mode != PLP_MATCH_MODE_BRUTE_FORCE;
+    const bool windowed = P.mode == PLP_MATCH_MODE_LANDMARKS || P.mode == PLP_MATCH_MODE_LAST_FRAME;
+    const bool line = P.mode == PLP_MATCH_MODE_LANDMARKS_LINE || P.mode == PLP_MATCH_MODE_LAST_FRAME_LINE;
     const size_t staged = windowed ? (size_t)P.n_cap * (sizeof(StagedTarget) + (P.t_x_right ? 4 : 0)) : (size_t)P.n_cap * 32;
-    if (staged <= 64 * 1024 && (!windowed || (P.grid_cols <= 255 && P.grid_rows <= 255))) {
+    if (!line && staged <= 64 * 1024 && (!windowed || (P.grid_cols <= 255 && P.grid_rows <= 255))) {
         if (windowed) hipLaunchKernelGGL(k_match_prep, dim3(B), dim3(256), 0, st, P);
         Q.sorted_valid = windowed ? 1 : 0;
         hipLaunchKernelGGL(k_match_topk_lds, dim3((P.m_cap + kQueriesPerBlock - 1) / kQueriesPerBlock, B), dim3(256), staged, st, P);

@@ -75,6 +75,12 @@ def lib():
         L.oracle_match_current_and_last.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 7 + [C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p]
         L.oracle_brute_force_match.restype = C.c_uint
         L.oracle_brute_force_match.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p]
+        L.oracle_keylines_in_cell.restype = C.c_int
+        L.oracle_keylines_in_cell.argtypes = [C.c_void_p, C.c_int] + [C.c_float] * 5 + [C.c_int, C.c_int, C.c_void_p]
+        L.oracle_match_frame_and_landmarks_line.restype = C.c_uint
+        L.oracle_match_frame_and_landmarks_line.argtypes = [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 7 + [C.c_int, C.c_float, C.c_float, C.c_void_p]
+        L.oracle_match_current_and_last_line.restype = C.c_uint
+        L.oracle_match_current_and_last_line.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p]
         L.oracle_front_time_frames.restype = C.c_double
         L.oracle_front_time_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_int, C.c_float, C.c_void_p]
         L.oracle_line_extract.restype = C.c_void_p
@@ -304,3 +310,26 @@ def resize_linear_exact_u8(src, fx, fy):
     dst = np.zeros((dh, dw), np.uint8)
     lib().oracle_resize_linear_exact_u8(_p(src), src.shape[0], src.shape[1], fx, fy, _p(dst))
     return dst
+
+
+def match_frame_and_landmarks_line(kl, lbd, kp_octave, occupied, sf_lsd, lm_valid, lm_sp, lm_ep, lm_level, lm_desc, lm_has_obs, margin, ratio):
+    n, m = len(kl), len(lm_level)
+    out = np.zeros(max(n, 1), np.int32)
+    a = [_c(kl, KL_DTYPE), _c(lbd, np.uint8), _c(kp_octave, np.int32), _c(occupied, np.uint8)]
+    b = [_c(sf_lsd, np.float32), _c(lm_valid, np.uint8), _c(lm_sp, np.float32), _c(lm_ep, np.float32), _c(lm_level, np.int32),
+         _c(lm_desc, np.uint8), _c(lm_has_obs, np.uint8)]
+    num = lib().oracle_match_frame_and_landmarks_line(*[_p(v) for v in a], n, *[_p(v) for v in b], m, margin, ratio, _p(out))
+    return out[:n].copy(), num
+
+
+def match_current_and_last_line(kl, lbd, xr_pair, occupied, sf_lsd, num_levels_lsd, valid, sp, ep, lxr_sp, lxr_ep, loctave, ldesc, l_has_obs,
+                                margin, direction, is_rgbd):
+    n, m = len(kl), len(loctave)
+    out = np.zeros(max(n, 1), np.int32)
+    a = [_c(kl, KL_DTYPE), _c(lbd, np.uint8), _c(xr_pair, np.float32), _c(occupied, np.uint8)]
+    sf = _c(sf_lsd, np.float32)
+    b = [_c(valid, np.uint8), _c(sp, np.float32), _c(ep, np.float32), _c(lxr_sp, np.float32), _c(lxr_ep, np.float32), _c(loctave, np.int32),
+         _c(ldesc, np.uint8), _c(l_has_obs, np.uint8)]
+    num = lib().oracle_match_current_and_last_line(*[_p(v) for v in a], n, _p(sf), num_levels_lsd, *[_p(v) for v in b], m, margin, direction,
+                                                   int(is_rgbd), _p(out))
+    return out[:n].copy(), num

@@ -118,3 +118,48 @@ def test_batched_device_matches_per_problem_host():
         want, wn = O.match_frame_and_landmarks(O.grid6(grid), t["t_kps"], t["t_desc"], t["t_x_right"], t["t_occupied"], SF, q["q_valid"],
                                                q["q_reproj"], q["q_x_right"], q["q_level"], q["q_desc"], q["q_has_obs"], 15.0, 0.8)
         assert on[b] == wn and np.array_equal(om[b, :len(want)], want)
+
+
+# ---------------------------------------------------------------------------------------- line variants
+def random_line_problem(rng, n, m, words=0):
+    kl = np.zeros(n, O.KL_DTYPE)
+    x1 = rng.uniform(0, 640, n); y1 = rng.uniform(0, 480, n); ang = rng.uniform(0, np.pi, n); ln = rng.uniform(60, 250, n)
+    kl["startPointX"], kl["startPointY"] = x1, y1
+    kl["endPointX"], kl["endPointY"] = x1 + ln * np.cos(ang), y1 + ln * np.sin(ang)
+    kl["octave"] = rng.integers(0, 2, n)
+    vocab = rng.integers(0, 256, (max(words, 1), 32), dtype=np.uint8)
+    lbd = vocab[rng.integers(0, len(vocab), n)].copy() if words else rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    src = rng.integers(0, n, m)
+    sp = np.stack([kl["startPointX"][src], kl["startPointY"][src]], 1) + rng.normal(0, 3, (m, 2))
+    ep = np.stack([kl["endPointX"][src], kl["endPointY"][src]], 1) + rng.normal(0, 3, (m, 2))
+    qd = lbd[src].copy()
+    flip = rng.integers(0, 32, m); qd[np.arange(m), flip] ^= np.uint8(1) << rng.integers(0, 8, m).astype(np.uint8)
+    t = dict(t_kl=kl, t_desc=lbd, t_kp_octave=rng.integers(0, 8, n).astype(np.int32), t_occupied=(rng.uniform(size=n) < 0.1).astype(np.uint8),
+             t_x_right=(rng.uniform(5, 600, n) * (rng.uniform(size=n) < 0.7) - 1).astype(np.float32),
+             t_x_right2=(rng.uniform(5, 600, n) * (rng.uniform(size=n) < 0.7) - 1).astype(np.float32))
+    q = dict(q_valid=(rng.uniform(size=m) > 0.1).astype(np.uint8), q_reproj=sp.astype(np.float32), q_reproj2=ep.astype(np.float32),
+             q_level=rng.integers(0, 2, m).astype(np.int32), q_desc=qd, q_has_obs=(rng.uniform(size=m) > 0.05).astype(np.uint8),
+             q_x_right=(sp[:, 0] - rng.uniform(0, 40, m)).astype(np.float32), q_x_right2=(ep[:, 0] - rng.uniform(0, 40, m)).astype(np.float32))
+    return t, q
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_line_projection_matchers(seed):
+    rng = np.random.default_rng(40 + seed)
+    sf_lsd = np.array([1.0, 2.0], np.float32)
+    for n, m, words in [(60, 80, 0), (300, 500, 4), (1, 3, 1), (150, 40, 2)]:
+        t, q = random_line_problem(rng, n, m, words)
+        margin, ratio = float(rng.uniform(3, 30)), 0.8
+        want, wn = O.match_frame_and_landmarks_line(t["t_kl"], t["t_desc"], t["t_kp_octave"], t["t_occupied"], sf_lsd, q["q_valid"], q["q_reproj"],
+                                                    q["q_reproj2"], q["q_level"], q["q_desc"], q["q_has_obs"], margin, ratio)
+        got, gn = plp.matcher(ratio, False).match_host(plp.MODE_LANDMARKS_LINE, n, m, {**t, **q}, margin=margin, scale_factors=sf_lsd)
+        assert gn[0] == wn and np.array_equal(got[0], want)
+        for direction in (0, 1, 2):
+            for rgbd in (0, 1):
+                xr_pair = np.stack([t["t_x_right"], t["t_x_right2"]], 1)
+                want, wn = O.match_current_and_last_line(t["t_kl"], t["t_desc"], xr_pair, t["t_occupied"], sf_lsd, 1, q["q_valid"], q["q_reproj"],
+                                                         q["q_reproj2"], q["q_x_right"], q["q_x_right2"], q["q_level"], q["q_desc"], q["q_has_obs"],
+                                                         margin, direction, rgbd)
+                got, gn = plp.matcher(0.9, True).match_host(plp.MODE_LAST_FRAME_LINE, n, m, {**t, **q, "is_rgbd": rgbd, "num_levels_lsd": 1},
+                                                            margin=margin, direction=direction, scale_factors=sf_lsd)
+                assert gn[0] == wn and np.array_equal(got[0], want), (n, m, direction, rgbd)
