@@ -122,6 +122,20 @@ plp_status plp_orb_get_stage_times(plp_orb* ctx, double* ms7, int64_t* n_batches
 plp_status plp_orb_pyramid_level_size(const plp_orb* ctx, int32_t level, int32_t* rows, int32_t* cols);
 plp_status plp_orb_pyramid_host(plp_orb* ctx, int32_t frame, int32_t level, uint8_t* dst, size_t dst_step);
 
+/* match::stereo(...).compute(stereo_x_right, depths)  (src/PLPSLAM/match/stereo.cc:30-150, built in data/frame.cc:277-281):
+ * per left key point the best right key point in its row band (Hamming < 75, octave +-1, disparity in [0, fx*b/b)),
+ * 11x11 L1 patch slide on the pyramid level + parabola, 2x-median correlation rejection.  The image pyramids are the
+ * ones `left` / `right` built in their last extract call (the reference passes orb_extractor::image_pyramid_).
+ * Outputs: n_l floats each, -1 where no stereo match. */
+plp_status plp_stereo_compute(plp_orb* left, plp_orb* right, const plp_keypoint* kps_l, int32_t n_l, const plp_keypoint* kps_r, int32_t n_r,
+                              const uint8_t* desc_l, const uint8_t* desc_r, float focal_x_baseline, float true_baseline,
+                              float* stereo_x_right, float* depths);
+/* Batched: key points / descriptors / counts as produced by plp_orb_extract_batch_device of the two extractors. */
+plp_status plp_stereo_compute_batch_device(plp_orb* left, plp_orb* right, const plp_keypoint* d_kps_l, const int32_t* d_cnt_l,
+                                           const plp_keypoint* d_kps_r, const int32_t* d_cnt_r, const uint8_t* d_desc_l,
+                                           const uint8_t* d_desc_r, int32_t cap, int32_t B, float focal_x_baseline, float true_baseline,
+                                           float* d_x_right, float* d_depths, void* hip_stream);
+
 /* Stage read-back for parity tests (synchronous; host destination).
  *   PLP_ORB_DBG_BLURRED   : the 7x7 sigma-2 blurred level image (orb_extractor.cc:148-149), rows x cols u8 dense
  *   PLP_ORB_DBG_CANDIDATES: keypts_to_distribute of a level (orb_extractor.cc:359,433) as int32 triples
@@ -265,6 +279,16 @@ typedef struct plp_match_args {
 plp_status plp_match_device(plp_matcher* ctx, const plp_match_args* a, void* hip_stream);
 /* Same with HOST pointers for one call (B problems are staged to HBM and back); synchronous. */
 plp_status plp_match_host(plp_matcher* ctx, const plp_match_args* a);
+
+/* cv::line_descriptor::BinaryDescriptorMatcher::match(query, train, matches) — exact 1-NN over LBD descriptors by
+ * multi-index hashing (src/PLPSLAM/feature/line_descriptor/binary_descriptor_matcher.cpp:197-255, 597-818), used for the
+ * stereo line association (data/frame.cc:496-533) and two-key-frame line triangulation (mapping_module.cc:481-531).
+ * train_idx[q] = DMatch.trainIdx (among equally near train lines: the one MIH discovers first), dist[q] = DMatch.distance.
+ * Nothing within Hamming distance 128 -> (-1, 256) (the reference reads uninitialised memory there). */
+plp_status plp_lbd_match_1nn_host(plp_matcher* ctx, const uint8_t* q, int32_t nq, const uint8_t* t, int32_t nt, int32_t* train_idx, int32_t* dist);
+/* B problems: q is B x nq_cap x 32, t is B x nt_cap x 32, counts per problem (NULL = cap); asynchronous. */
+plp_status plp_lbd_match_1nn_device(plp_matcher* ctx, const uint8_t* d_q, const int32_t* d_q_counts, int32_t nq_cap, const uint8_t* d_t,
+                                    const int32_t* d_t_counts, int32_t nt_cap, int32_t B, int32_t* d_train_idx, int32_t* d_dist, void* hip_stream);
 
 /* Diagnostics: {exact full rescans, resolve rounds, 0, 0} accumulated over all calls of this context (synchronous). */
 plp_status plp_match_debug_counters(plp_matcher* ctx, int64_t* out4);

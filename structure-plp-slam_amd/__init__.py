@@ -83,6 +83,10 @@ _API = [
     ("plp_match_device", C.c_int, [_VP, _VP, _VP]),
     ("plp_match_host", C.c_int, [_VP, _VP]),
     ("plp_match_debug_counters", C.c_int, [_VP, _VP]),
+    ("plp_lbd_match_1nn_host", C.c_int, [_VP, _VP, _I32, _VP, _I32, _VP, _VP]),
+    ("plp_lbd_match_1nn_device", C.c_int, [_VP, _VP, _VP, _I32, _VP, _VP, _I32, _I32, _VP, _VP, _VP]),
+    ("plp_stereo_compute", C.c_int, [_VP, _VP, _VP, _I32, _VP, _I32, _VP, _VP, C.c_float, C.c_float, _VP, _VP]),
+    ("plp_stereo_compute_batch_device", C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, C.c_float, C.c_float, _VP, _VP, _VP]),
     ("plp_hamming_matrix_device", C.c_int, [_VP, _VP, _I32, _VP, _I32, _VP, _VP]),
     ("plp_hamming_matrix_host", C.c_int, [_VP, _VP, _I32, _VP, _I32, _VP]),
 ]
@@ -233,6 +237,16 @@ class orb_extractor:
         _check(lib().plp_orb_get_stage_times(self._h, _p(ms), C.byref(n)))
         nb = max(n.value, 1)
         return {k: float(v) / nb for k, v in zip(self.STAGES, ms)}, n.value
+
+    # ---- match::stereo(left pyramid, right pyramid, ...).compute (match/stereo.cc:45-150)
+    def stereo_compute(self, right_extractor, keypts_left, keypts_right, descs_left, descs_right, focal_x_baseline, true_baseline):
+        """self = left extractor; both extractors must have just extracted their image.  Returns (stereo_x_right, depths)."""
+        kl = np.ascontiguousarray(keypts_left, KP_DTYPE); kr = np.ascontiguousarray(keypts_right, KP_DTYPE)
+        dl = np.ascontiguousarray(descs_left, np.uint8); dr = np.ascontiguousarray(descs_right, np.uint8)
+        xr = np.full(len(kl), -1, np.float32); dp = np.full(len(kl), -1, np.float32)
+        _check(lib().plp_stereo_compute(self._h, right_extractor._h, _p(kl), len(kl), _p(kr), len(kr), _p(dl), _p(dr),
+                                        float(focal_x_baseline), float(true_baseline), _p(xr), _p(dp)))
+        return xr, dp
 
     # ---- image_pyramid_ (orb_extractor.h:101) and stage read-backs for parity tests
     def image_pyramid(self, level, frame=0):
@@ -426,6 +440,15 @@ class matcher:
         st = (stream or torch.cuda.current_stream(out_match.device)).cuda_stream
         a = self._args(mode, B, n_cap, m_cap, fields, margin, direction, scale_factors, grid, out_match, out_num, lambda v: v.data_ptr())
         _check(lib().plp_match_device(self._h, C.byref(a), st))
+
+    def lbd_match_1nn(self, query_lbd, train_lbd):
+        """BinaryDescriptorMatcher::match: (trainIdx, distance) per query row"""
+        q = np.ascontiguousarray(query_lbd, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(train_lbd, np.uint8).reshape(-1, 32)
+        idx = np.full(len(q), -1, np.int32)
+        dist = np.full(len(q), 256, np.int32)
+        _check(lib().plp_lbd_match_1nn_host(self._h, _p(q), len(q), _p(t), len(t), _p(idx), _p(dist)))
+        return idx, dist
 
     def debug_counters(self):
         v = np.zeros(4, np.int64)

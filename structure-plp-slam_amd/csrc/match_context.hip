@@ -1,6 +1,7 @@
 // Host driver + C ABI of the array-form Hamming matchers (include/plp_front.h).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -155,6 +156,67 @@ plp_status plp_match_host(plp_matcher* c, const plp_match_args* a) {
     PLP_HIP(hipMemcpyAsync(a->out_match, base + o_om, tn * 4, hipMemcpyDeviceToHost, st));
     PLP_HIP(hipMemcpyAsync(a->out_num, base + o_on, (size_t)a->B * 4, hipMemcpyDeviceToHost, st));
     PLP_HIP(hipStreamSynchronize(st));
+    return PLP_OK;
+}
+
+// order in which Mihasher::query enumerates the bit-flip patterns with s ones inside a b-bit substring
+// (binary_descriptor_matcher.cpp:671-735): rank[pattern] = position inside its popcount class
+static MihRanks mih_ranks() {
+    MihRanks R;
+    for (int i = 0; i < 256; ++i) R.rank[i] = 255;
+    const int curb = 8;
+    for (int s = 0; s <= 8; ++s) {
+        int power[16];
+        unsigned long long bitstr = 0;
+        for (int i = 0; i < s; ++i) power[i] = i;
+        power[s] = curb + 1;
+        int bit = s - 1, pos = 0;
+        while (true) {
+            if (bit != -1) {
+                bitstr ^= (power[bit] == bit) ? 1ull << power[bit] : 3ull << (power[bit] - 1);
+                power[bit]++;
+                bit--;
+            } else {
+                if (bitstr < 256 && R.rank[bitstr] == 255) R.rank[bitstr] = (uint8_t)std::min(pos, 254);
+                ++pos;
+                while (++bit < s && power[bit] == power[bit + 1] - 1) {
+                    bitstr ^= 1ull << (power[bit] - 1);
+                    power[bit] = bit;
+                }
+                if (bit == s) break;
+            }
+        }
+    }
+    return R;
+}
+
+plp_status plp_lbd_match_1nn_device(plp_matcher* c, const uint8_t* d_q, const int32_t* d_q_counts, int32_t nq_cap, const uint8_t* d_t,
+                                    const int32_t* d_t_counts, int32_t nt_cap, int32_t B, int32_t* d_train_idx, int32_t* d_dist, void* hip_stream) {
+    if (!c || !d_q || !d_t || !d_train_idx || !d_dist) return set_error(PLP_ERR_INVALID_ARG, "NULL argument");
+    if (nq_cap <= 0 || nt_cap <= 0 || B <= 0 || nt_cap > 65535) return set_error(PLP_ERR_INVALID_ARG, "bad sizes");
+    PLP_HIP(hipSetDevice(c->device));
+    static const MihRanks R = mih_ranks();
+    launch_lbd_match_1nn(hip_stream ? (hipStream_t)hip_stream : c->stream, d_q, d_q_counts, nq_cap, d_t, d_t_counts, nt_cap, R, d_train_idx, d_dist, B);
+    PLP_HIP(hipGetLastError());
+    return PLP_OK;
+}
+
+plp_status plp_lbd_match_1nn_host(plp_matcher* c, const uint8_t* q, int32_t nq, const uint8_t* t, int32_t nt, int32_t* train_idx, int32_t* dist) {
+    if (!c || !q || !t || !train_idx || !dist) return set_error(PLP_ERR_INVALID_ARG, "NULL argument");
+    if (nq <= 0 || nt <= 0) return PLP_OK;   // the reference prints an error and returns with `matches` untouched (:201-205)
+    std::lock_guard<std::mutex> lk(c->mu);
+    PLP_HIP(hipSetDevice(c->device));
+    const size_t bq = ((size_t)nq * 32 + 255) / 256 * 256, bt = ((size_t)nt * 32 + 255) / 256 * 256, bo = ((size_t)nq * 4 + 255) / 256 * 256;
+    PLP_HIP(c->stage.reserve(bq + bt + 2 * bo));
+    uint8_t* base = (uint8_t*)c->stage.p;
+    PLP_HIP(hipMemcpyAsync(base, q, (size_t)nq * 32, hipMemcpyHostToDevice, c->stream));
+    PLP_HIP(hipMemcpyAsync(base + bq, t, (size_t)nt * 32, hipMemcpyHostToDevice, c->stream));
+    static const MihRanks R = mih_ranks();
+    launch_lbd_match_1nn(c->stream, base, nullptr, nq, base + bq, nullptr, nt, R, (int32_t*)(base + bq + bt), (int32_t*)(base + bq + bt + bo), 1);
+    PLP_HIP(hipGetLastError());
+    PLP_HIP(hipMemcpyAsync(train_idx, base + bq + bt, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
+    PLP_HIP(hipMemcpyAsync(dist, base + bq + bt + bo, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
+    PLP_HIP(hipStreamSynchronize(c->stream));
     return PLP_OK;
 }
 

@@ -58,6 +58,9 @@ struct MatchProblem {
     int32_t* out_num;                // B
 };
 
+struct MihRanks { uint8_t rank[256]; };   // enumeration rank of an 8-bit flip pattern inside its popcount class (Mihasher::query)
+void launch_lbd_match_1nn(hipStream_t st, const uint8_t* q, const int32_t* q_counts, int nq_cap, const uint8_t* t, const int32_t* t_counts,
+                          int nt_cap, const MihRanks& R, int32_t* out_idx, int32_t* out_dist, int B);
 void launch_match(hipStream_t st, const MatchProblem& P, int B);
 void launch_hamming_matrix(hipStream_t st, const uint8_t* q, int nq, const uint8_t* t, int nt, uint16_t* dist);
 

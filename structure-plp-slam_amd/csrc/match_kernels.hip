@@ -573,4 +573,57 @@ void launch_hamming_matrix(hipStream_t st, const uint8_t* q, int nq, const uint8
     hipLaunchKernelGGL(k_hamming_matrix, dim3((nt + 63) / 64, (nq + 63) / 64), dim3(256), 0, st, q, nq, t, nt, dist);
 }
 
+// ------------------------------------------------------------------------------------------
+// BinaryDescriptorMatcher::match — exact 1-NN over LBD descriptors (reference
+// src/PLPSLAM/feature/line_descriptor/binary_descriptor_matcher.cpp:197-255; Mihasher(256, 32) :597-818).
+// Multi-index hashing returns, among the train descriptors at the minimum Hamming distance, the one it DISCOVERS
+// first: search radius s ascending, substring (byte) k ascending, then the order in which the s-bit flip patterns
+// are enumerated, then ascending train index inside a bucket.  A descriptor is first discovered at
+// (s, k) = lexicographic minimum over k of (popcount(q_k ^ t_k), k).  The kernel brute-forces the distances and
+// breaks ties with exactly that key; `rank` = position of an 8-bit flip pattern in the enumeration of its
+// popcount class (restated on the host).  Nothing within distance 128 -> (-1, 256): the reference reads
+// uninitialised memory there.
+// grid = (ceil(nq_cap / 4), B), block = 256: one wave per query line.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lbd_match_1nn(const uint8_t* __restrict__ q, const int32_t* __restrict__ q_counts, int nq_cap,
+                                                       const uint8_t* __restrict__ t, const int32_t* __restrict__ t_counts, int nt_cap,
+                                                       MihRanks R, int32_t* __restrict__ out_idx, int32_t* __restrict__ out_dist) {
+    const int lane = threadIdx.x & 63, b = blockIdx.y, qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nq = q_counts ? q_counts[b] : nq_cap, nt = t_counts ? t_counts[b] : nt_cap;
+    if (qi >= nq) return;
+    const uint8_t* Q = q + ((size_t)b * nq_cap + qi) * 32;
+    const uint8_t* T = t + (size_t)b * nt_cap * 32;
+    const uint4 q0 = reinterpret_cast<const uint4*>(Q)[0], q1 = reinterpret_cast<const uint4*>(Q)[1];
+    unsigned long long best = ~0ull;
+    for (int i = lane; i < nt; i += 64) {
+        const uint4 d0 = reinterpret_cast<const uint4*>(T + 32 * (size_t)i)[0], d1 = reinterpret_cast<const uint4*>(T + 32 * (size_t)i)[1];
+        const uint32_t x[8] = {q0.x ^ d0.x, q0.y ^ d0.y, q0.z ^ d0.z, q0.w ^ d0.w, q1.x ^ d1.x, q1.y ^ d1.y, q1.z ^ d1.z, q1.w ^ d1.w};
+        unsigned dist = 0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) dist += __popc(x[w]);
+        // discovery key: smallest (byte distance, byte index), then the flip pattern's enumeration rank
+        unsigned disc = 0xffffffffu;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            const unsigned pat = (x[k >> 2] >> (8 * (k & 3))) & 0xffu;
+            const unsigned key = ((unsigned)__popc(pat) << 16) | ((unsigned)k << 8) | R.rank[pat];
+            disc = min(disc, key);
+        }
+        const unsigned long long key = ((unsigned long long)dist << 40) | ((unsigned long long)disc << 16) | (unsigned)i;
+        best = key < best ? key : best;
+    }
+    best = wave_min_u64(best);
+    if (lane == 0) {
+        const size_t o = (size_t)b * nq_cap + qi;
+        const unsigned dist = (unsigned)(best >> 40);
+        if (best == ~0ull || dist > 128u) { out_idx[o] = -1; out_dist[o] = 256; }
+        else { out_idx[o] = (int32_t)(best & 0xffff); out_dist[o] = (int32_t)dist; }
+    }
+}
+
+void launch_lbd_match_1nn(hipStream_t st, const uint8_t* q, const int32_t* q_counts, int nq_cap, const uint8_t* t, const int32_t* t_counts,
+                          int nt_cap, const MihRanks& R, int32_t* out_idx, int32_t* out_dist, int B) {
+    hipLaunchKernelGGL(k_lbd_match_1nn, dim3((nq_cap + 3) / 4, B), dim3(256), 0, st, q, q_counts, nq_cap, t, t_counts, nt_cap, R, out_idx, out_dist);
+}
+
 }  // namespace plp

@@ -3,6 +3,7 @@
 // image geometry and the HBM work planes sized for the largest batch seen so far.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -40,6 +41,7 @@ struct plp_orb {
     size_t l0copy_frame_stride = 0, qt_frame_stride = 0;
     // single-frame host API staging
     DevBuf s_kps, s_desc, s_counts;
+    DevBuf stereo_corr, stereo_stage;
     int s_cap = 0;
     // reference state: rectangle mask is created once, at the first frame's size
     bool mask_is_initialized = false;
@@ -504,6 +506,69 @@ plp_status plp_orb_debug_read(plp_orb* c, plp_orb_debug_id what, int32_t frame, 
         }
     } else return set_error(PLP_ERR_INVALID_ARG, "unknown debug id");
     *n_out = (int64_t)n;
+    return PLP_OK;
+}
+
+// match::stereo(left pyramid, right pyramid, keypts, descriptors, scale tables, fx*baseline, baseline).compute(...)
+// (reference src/PLPSLAM/match/stereo.cc:30-150; constructed in data/frame.cc:277-281).  The pyramids are the ones the
+// two extractors built in their LAST extract / extract_batch call (the reference reads orb_extractor::image_pyramid_).
+static plp_status stereo_run(plp_orb* l, plp_orb* r, const StereoArgs& A0, int B, hipStream_t st) {
+    if (!l->last_B || !r->last_B || B > l->last_B || B > r->last_B) return set_error(PLP_ERR_INVALID_ARG, "both extractors must have processed the frames first");
+    if (l->geo.rows != r->geo.rows || l->geo.cols != r->geo.cols || l->geo.n_levels != r->geo.n_levels) return set_error(PLP_ERR_INVALID_ARG, "left/right geometry differs");
+    StereoArgs A = A0;
+    for (int i = 0; i < kMaxLevels; ++i) A.inv_scale[i] = i < (int)l->st.isf.size() ? l->st.isf[i] : 1.0f;
+    PLP_HIP(l->stereo_corr.reserve((size_t)B * A.cap * 4));
+    A.corr = (int32_t*)l->stereo_corr.p;
+    launch_stereo(st, l->last_planes, r->last_planes, (const LevelDev*)l->d_lv.p, A, B);
+    PLP_HIP(hipGetLastError());
+    return PLP_OK;
+}
+
+plp_status plp_stereo_compute_batch_device(plp_orb* left, plp_orb* right, const plp_keypoint* d_kps_l, const int32_t* d_cnt_l,
+                                           const plp_keypoint* d_kps_r, const int32_t* d_cnt_r, const uint8_t* d_desc_l, const uint8_t* d_desc_r,
+                                           int32_t cap, int32_t B, float focal_x_baseline, float true_baseline, float* d_x_right, float* d_depths,
+                                           void* hip_stream) {
+    if (!left || !right || !d_kps_l || !d_kps_r || !d_desc_l || !d_desc_r || !d_x_right || !d_depths) return set_error(PLP_ERR_INVALID_ARG, "NULL argument");
+    if (cap <= 0 || cap > 65535 || B <= 0) return set_error(PLP_ERR_INVALID_ARG, "bad sizes");
+    std::lock_guard<std::mutex> lk(left->mu);
+    PLP_HIP(hipSetDevice(left->device));
+    StereoArgs A{};
+    A.kps_l = d_kps_l; A.kps_r = d_kps_r; A.desc_l = d_desc_l; A.desc_r = d_desc_r; A.cnt_l = d_cnt_l; A.cnt_r = d_cnt_r; A.cap = cap;
+    A.fxb = focal_x_baseline; A.tb = true_baseline; A.x_right = d_x_right; A.depth = d_depths;
+    return stereo_run(left, right, A, B, hip_stream ? (hipStream_t)hip_stream : left->stream);
+}
+
+plp_status plp_stereo_compute(plp_orb* left, plp_orb* right, const plp_keypoint* kps_l, int32_t n_l, const plp_keypoint* kps_r, int32_t n_r,
+                              const uint8_t* desc_l, const uint8_t* desc_r, float focal_x_baseline, float true_baseline, float* stereo_x_right,
+                              float* depths) {
+    if (!left || !right || !stereo_x_right || !depths) return set_error(PLP_ERR_INVALID_ARG, "NULL argument");
+    if (n_l <= 0) return PLP_OK;
+    if (n_r < 0 || (n_r > 0 && (!kps_r || !desc_r)) || !kps_l || !desc_l) return set_error(PLP_ERR_INVALID_ARG, "bad argument");
+    std::lock_guard<std::mutex> lk(left->mu);
+    PLP_HIP(hipSetDevice(left->device));
+    hipStream_t st = left->stream;
+    PLP_HIP(hipStreamSynchronize(right->last_stream ? right->last_stream : right->stream));
+    const int cap = std::max(n_l, std::max(n_r, 1));
+    const size_t bk = ((size_t)cap * sizeof(plp_keypoint) + 255) / 256 * 256, bd = ((size_t)cap * 32 + 255) / 256 * 256, bf = ((size_t)cap * 4 + 255) / 256 * 256;
+    PLP_HIP(left->stereo_stage.reserve(2 * bk + 2 * bd + 2 * bf + 512));
+    uint8_t* base = (uint8_t*)left->stereo_stage.p;
+    int32_t cnts[2] = {n_l, n_r};
+    PLP_HIP(hipMemcpyAsync(base, kps_l, (size_t)n_l * sizeof(plp_keypoint), hipMemcpyHostToDevice, st));
+    if (n_r) PLP_HIP(hipMemcpyAsync(base + bk, kps_r, (size_t)n_r * sizeof(plp_keypoint), hipMemcpyHostToDevice, st));
+    PLP_HIP(hipMemcpyAsync(base + 2 * bk, desc_l, (size_t)n_l * 32, hipMemcpyHostToDevice, st));
+    if (n_r) PLP_HIP(hipMemcpyAsync(base + 2 * bk + bd, desc_r, (size_t)n_r * 32, hipMemcpyHostToDevice, st));
+    uint8_t* d_cnt = base + 2 * bk + 2 * bd + 2 * bf;
+    PLP_HIP(hipMemcpyAsync(d_cnt, cnts, 8, hipMemcpyHostToDevice, st));
+    StereoArgs A{};
+    A.kps_l = (const plp_keypoint*)base; A.kps_r = (const plp_keypoint*)(base + bk);
+    A.desc_l = base + 2 * bk; A.desc_r = base + 2 * bk + bd;
+    A.cnt_l = (const int32_t*)d_cnt; A.cnt_r = (const int32_t*)d_cnt + 1; A.cap = cap;
+    A.fxb = focal_x_baseline; A.tb = true_baseline;
+    A.x_right = (float*)(base + 2 * bk + 2 * bd); A.depth = (float*)(base + 2 * bk + 2 * bd + bf);
+    PLP_TRY(stereo_run(left, right, A, 1, st));
+    PLP_HIP(hipMemcpyAsync(stereo_x_right, A.x_right, (size_t)n_l * 4, hipMemcpyDeviceToHost, st));
+    PLP_HIP(hipMemcpyAsync(depths, A.depth, (size_t)n_l * 4, hipMemcpyDeviceToHost, st));
+    PLP_HIP(hipStreamSynchronize(st));
     return PLP_OK;
 }
 

@@ -43,6 +43,18 @@ struct ResizeDev {
     int col_base[kMaxLevels], row_base[kMaxLevels];
 };
 
+struct StereoArgs {
+    const plp_keypoint *kps_l, *kps_r;     // B x cap
+    const uint8_t *desc_l, *desc_r;        // B x cap x 32
+    const int32_t *cnt_l, *cnt_r;          // B (NULL: cap)
+    int cap;
+    float fxb, tb;                         // focal_x_baseline, true_baseline
+    float inv_scale[kMaxLevels];
+    float* x_right; float* depth;          // B x cap outputs
+    int32_t* corr;                         // B x cap scratch: int-truncated best correlation, -1 = no stereo match
+};
+void launch_stereo(hipStream_t st, const OrbPlanes& pl_l, const OrbPlanes& pl_r, const LevelDev* d_lv, const StereoArgs& A, int B);
+
 void launch_resize(hipStream_t st, const OrbPlanes& pl, const LevelDev* h_lv, int level, int B, const ResizeDev& rs);
 void launch_fast(hipStream_t st, const OrbPlanes& pl, const CellDesc* d_cells, int n_cells, const LevelDev* d_lv, int B,
                  int ini_thr, int min_thr, const uint8_t* d_mask, size_t mask_step, size_t mask_frame_stride,

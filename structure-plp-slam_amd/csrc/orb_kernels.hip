@@ -410,4 +410,134 @@ void launch_orient_rbrief(hipStream_t st, const OrbPlanes& pl, const uint8_t* bl
                        n_levels, sel, sel_count, total_sel_cap, um, kps, desc, cap, counts, status);
 }
 
+// ------------------------------------------------------------------------------------------
+// match::stereo::compute (reference src/PLPSLAM/match/stereo.cc:45-301), array form.
+// k_stereo_match: one wave64 per LEFT key point: best right key point in the row band (Hamming < 75, octave +-1,
+// disparity range; first minimum in right-index order), 11x11 L1 patch slide over 11 offsets on the pyramid level
+// of the left key point (integer arithmetic: the reference's float patches hold integers), parabola refinement.
+// k_stereo_median: per frame, the median of the (int-truncated) correlations and the 2x-median rejection.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_stereo_match(OrbPlanes pl_l, OrbPlanes pl_r, const LevelDev* __restrict__ lv, StereoArgs A) {
+    const int lane = threadIdx.x & 63, b = blockIdx.y;
+    const int il = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nl = A.cnt_l ? A.cnt_l[b] : A.cap, nr = A.cnt_r ? A.cnt_r[b] : A.cap;
+    if (il >= A.cap) return;
+    float* xr_out = A.x_right + (size_t)b * A.cap;
+    float* dp_out = A.depth + (size_t)b * A.cap;
+    int32_t* corr_out = A.corr + (size_t)b * A.cap;
+    if (lane == 0) { xr_out[il] = -1.0f; dp_out[il] = -1.0f; corr_out[il] = -1; }
+    if (il >= nl) return;
+    const plp_keypoint kp = A.kps_l[(size_t)b * A.cap + il];
+    const plp_keypoint* kr = A.kps_r + (size_t)b * A.cap;
+    const float max_disp = __fdiv_rn(A.fxb, A.tb), min_disp = 0.0f;
+    const int row = (int)(unsigned long long)kp.y;              // indices_right_in_row.at(y_left): float -> size_t
+    const float min_x = __fsub_rn(kp.x, max_disp), max_x = __fsub_rn(kp.x, min_disp);
+    if (max_x < 0) return;
+    const uint4* ql = reinterpret_cast<const uint4*>(A.desc_l + ((size_t)b * A.cap + il) * 32);
+    const uint4 q0 = ql[0], q1 = ql[1];
+    unsigned best = (75u << 16) | 0xffffu;                      // hamm_dist_thr_ = (100 + 50) / 2; strict < keeps the first minimum
+    for (int ir = lane; ir < nr; ir += 64) {
+        const plp_keypoint k = kr[ir];
+        const float r = __fmul_rn(2.0f, lv[k.octave].scale);
+        const float lo = __fsub_rn(k.y, r), hi = __fadd_rn(k.y, r);
+        int min_r = (int)lo; min_r -= (min_r > lo);
+        int max_r = (int)hi; max_r += (max_r < hi);
+        if (row < min_r || row > max_r) continue;
+        if (k.octave < kp.octave - 1 || k.octave > kp.octave + 1) continue;
+        if (k.x < min_x || max_x < k.x) continue;
+        const uint4* d = reinterpret_cast<const uint4*>(A.desc_r + ((size_t)b * A.cap + ir) * 32);
+        const uint4 d0 = d[0], d1 = d[1];
+        const unsigned dist = __popc(q0.x ^ d0.x) + __popc(q0.y ^ d0.y) + __popc(q0.z ^ d0.z) + __popc(q0.w ^ d0.w) +
+                              __popc(q1.x ^ d1.x) + __popc(q1.y ^ d1.y) + __popc(q1.z ^ d1.z) + __popc(q1.w ^ d1.w);
+        best = min(best, (dist << 16) | (unsigned)ir);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, o));
+    if ((best >> 16) >= 75u) return;
+    const plp_keypoint kpr = kr[best & 0xffffu];
+    // ---- compute_subpixel_disparity (stereo.cc:225-301)
+    const LevelDev L = lv[kp.octave];
+    const float isf = A.inv_scale[kp.octave];
+    const int sxl = __float2int_rn(__fmul_rn(kp.x, isf)), syl = __float2int_rn(__fmul_rn(kp.y, isf)), sxr = __float2int_rn(__fmul_rn(kpr.x, isf));
+    constexpr int win = 5, slide = 5;
+    if (sxr - slide - win < 0 || L.w <= sxr + slide + win) return;
+    const uint8_t* IL = pl_l.level_ptr(b, kp.octave, L);
+    const uint8_t* IR = pl_r.level_ptr(b, kp.octave, L);
+    const int pitch_l = pl_l.level_pitch(kp.octave, L), pitch_r = pl_r.level_pitch(kp.octave, L);
+    const int lc = IL[(size_t)syl * pitch_l + sxl];
+    int lv0 = 0, lv1 = 0;                                       // this lane's two pixels of the 11 x 11 left patch, centre removed
+    const int p0 = lane, p1 = lane + 64;
+    const int dy0 = p0 / 11 - win, dx0 = p0 % 11 - win, dy1 = p1 / 11 - win, dx1 = p1 % 11 - win;
+    lv0 = (int)IL[(size_t)(syl + dy0) * pitch_l + sxl + dx0] - lc;
+    if (p1 < 121) lv1 = (int)IL[(size_t)(syl + dy1) * pitch_l + sxl + dx1] - lc;
+    int corr[2 * slide + 1];
+    int best_corr = 0x7fffffff, best_off = 0;
+#pragma unroll
+    for (int off = -slide; off <= slide; ++off) {
+        const int rc = IR[(size_t)syl * pitch_r + sxr + off];
+        int s = abs(lv0 - ((int)IR[(size_t)(syl + dy0) * pitch_r + sxr + off + dx0] - rc));
+        if (p1 < 121) s += abs(lv1 - ((int)IR[(size_t)(syl + dy1) * pitch_r + sxr + off + dx1] - rc));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        corr[off + slide] = s;
+        if (s < best_corr) { best_corr = s; best_off = off; }
+    }
+    if (best_off == -slide || best_off == slide) return;
+    float c1 = 0, c2 = 0, c3 = 0;
+#pragma unroll
+    for (int i = 1; i < 2 * slide; ++i)
+        if (i == best_off + slide) { c1 = (float)corr[i - 1]; c2 = (float)corr[i]; c3 = (float)corr[i + 1]; }
+    const float x_delta = (float)((double)__fsub_rn(c1, c3) / (2.0 * (double)__fadd_rn(c1, c3) - 4.0 * (double)c2));
+    if (x_delta < -1.0 || 1.0 < x_delta) return;
+    float best_x_right = __fmul_rn(L.scale, __fadd_rn((float)(sxr + best_off), x_delta));
+    float best_disp = __fsub_rn(kp.x, best_x_right);
+    if (best_disp < min_disp || max_disp <= best_disp) return;
+    if (best_disp <= 0.0f) { best_disp = 0.01f; best_x_right = __fsub_rn(kp.x, best_disp); }
+    if (lane == 0) { dp_out[il] = __fdiv_rn(A.fxb, best_disp); xr_out[il] = best_x_right; corr_out[il] = best_corr; }
+}
+
+// grid = (B), block = 256: k-th smallest (k = count / 2) of the valid correlations by two 8-bit histogram passes
+__global__ __launch_bounds__(256) void k_stereo_median(StereoArgs A) {
+    __shared__ int hist[256], s_sel[3];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int nl = A.cnt_l ? A.cnt_l[b] : A.cap;
+    int32_t* corr = A.corr + (size_t)b * A.cap;
+    float* xr_out = A.x_right + (size_t)b * A.cap;
+    float* dp_out = A.depth + (size_t)b * A.cap;
+    hist[tid] = 0;
+    __syncthreads();
+    int mine = 0;
+    for (int i = tid; i < nl; i += 256) { const int c = corr[i]; if (c >= 0) { ++mine; atomicAdd(&hist[min(c >> 8, 255)], 1); } }
+    __syncthreads();
+    if (tid == 0) {
+        int total = 0;
+        for (int i = 0; i < 256; ++i) total += hist[i];
+        int k = total / 2, hb = 0;
+        if (total) { while (k >= hist[hb]) { k -= hist[hb]; ++hb; } }
+        s_sel[0] = total; s_sel[1] = hb; s_sel[2] = k;
+    }
+    __syncthreads();
+    const int total = s_sel[0], hb = s_sel[1], k = s_sel[2];
+    if (total == 0) return;
+    __syncthreads();
+    hist[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < nl; i += 256) { const int c = corr[i]; if (c >= 0 && min(c >> 8, 255) == hb) atomicAdd(&hist[c & 255], 1); }
+    __syncthreads();
+    if (tid == 0) {
+        int kk = k, lb = 0;
+        while (kk >= hist[lb]) { kk -= hist[lb]; ++lb; }
+        s_sel[1] = (hb << 8) | lb;
+    }
+    __syncthreads();
+    const float median = (float)s_sel[1];
+    const float thr = (float)(2.0 * (double)median);
+    for (int i = tid; i < nl; i += 256) { const int c = corr[i]; if (c >= 0 && thr < (float)c) { xr_out[i] = -1.0f; dp_out[i] = -1.0f; } }
+}
+
+void launch_stereo(hipStream_t st, const OrbPlanes& pl_l, const OrbPlanes& pl_r, const LevelDev* d_lv, const StereoArgs& A, int B) {
+    hipLaunchKernelGGL(k_stereo_match, dim3((A.cap + 3) / 4, B), dim3(256), 0, st, pl_l, pl_r, d_lv, A);
+    hipLaunchKernelGGL(k_stereo_median, dim3(B), dim3(256), 0, st, A);
+}
+
 }  // namespace plp

@@ -81,6 +81,8 @@ def lib():
         L.oracle_match_frame_and_landmarks_line.argtypes = [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 7 + [C.c_int, C.c_float, C.c_float, C.c_void_p]
         L.oracle_match_current_and_last_line.restype = C.c_uint
         L.oracle_match_current_and_last_line.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p]
+        L.oracle_stereo_compute.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+        L.oracle_lbd_match_1nn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.oracle_front_time_frames.restype = C.c_double
         L.oracle_front_time_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_int, C.c_float, C.c_void_p]
         L.oracle_line_extract.restype = C.c_void_p
@@ -333,3 +335,18 @@ def match_current_and_last_line(kl, lbd, xr_pair, occupied, sf_lsd, num_levels_l
     num = lib().oracle_match_current_and_last_line(*[_p(v) for v in a], n, _p(sf), num_levels_lsd, *[_p(v) for v in b], m, margin, direction,
                                                    int(is_rgbd), _p(out))
     return out[:n].copy(), num
+
+
+def stereo_compute(orb_left, orb_right, kl, kr, dl, dr, fxb, tb):
+    """orb_left / orb_right: OrbOracle objects that just extracted the left / right image"""
+    kl = _c(kl, KP_DTYPE); kr = _c(kr, KP_DTYPE); dl = _c(dl, np.uint8); dr = _c(dr, np.uint8)
+    xr = np.zeros(max(len(kl), 1), np.float32); dp = np.zeros(max(len(kl), 1), np.float32)
+    lib().oracle_stereo_compute(orb_left.h, orb_right.h, _p(kl), len(kl), _p(kr), len(kr), _p(dl), _p(dr), fxb, tb, _p(xr), _p(dp))
+    return xr[:len(kl)].copy(), dp[:len(kl)].copy()
+
+
+def lbd_match_1nn(q, t):
+    q = _c(q, np.uint8).reshape(-1, 32); t = _c(t, np.uint8).reshape(-1, 32)
+    idx = np.zeros(max(len(q), 1), np.int32); dist = np.zeros(max(len(q), 1), np.int32)
+    lib().oracle_lbd_match_1nn(_p(q), len(q), _p(t), len(t), _p(idx), _p(dist))
+    return idx[:len(q)].copy(), dist[:len(q)].copy()
