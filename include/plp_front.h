@@ -221,7 +221,9 @@ typedef enum plp_match_mode {
     PLP_MATCH_MODE_LAST_FRAME = 1,  /* projection::match_current_and_last_frames      match/projection.cc:214-358 */
     PLP_MATCH_MODE_BRUTE_FORCE = 2, /* robust::brute_force_match                      match/robust.cc:257-385     */
     PLP_MATCH_MODE_LANDMARKS_LINE = 3,  /* projection::match_frame_and_landmarks_line      match/projection.cc:124-212 */
-    PLP_MATCH_MODE_LAST_FRAME_LINE = 4  /* projection::match_current_and_last_frames_line  match/projection.cc:361-527 */
+    PLP_MATCH_MODE_LAST_FRAME_LINE = 4, /* projection::match_current_and_last_frames_line  match/projection.cc:361-527 */
+    PLP_MATCH_MODE_BOW = 5,         /* bow_tree::match_frame_and_keyframe / match_keyframes   match/bow_tree.cc:41-165, 167-307 */
+    PLP_MATCH_MODE_FUSE = 6         /* fuse::replace_duplication, the search part              match/fuse.cc:169-298        */
 } plp_match_mode;
 
 typedef struct plp_match_grid {     /* camera::base grid (camera/base.h:91) used by data::get_keypoints_in_cell */
@@ -269,6 +271,20 @@ typedef struct plp_match_args {
     const float* q_x_right2;        /* B x m_cap or NULL */
     int32_t is_rgbd;
     int32_t num_levels_lsd;         /* last_frm._num_scale_levels_lsd (upper bound of the assume_forward window) */
+    /* BOW mode: queries = key-frame features listed in BoW node order (the order the reference walks the feature
+     * vector in), q_group / t_group = node id of every feature (frame features of one node are visited in ascending
+     * index); q_valid = feature has a live landmark; t_occupied = static skip of a target (match_keyframes: key frame 2
+     * feature without a live landmark); q_angle / t_angle when check_orientation.  Accept: best <= 50 and
+     * lowe_ratio * second >= best.
+     * FUSE mode: independent queries (no blocking): window margin * scale_factors[q_level] around q_reproj_d (all
+     * octaves), then octave in [q_level - 1, q_level] WITH THE REFERENCE'S UNSIGNED ARITHMETIC (q_level == 0 rejects
+     * everything, fuse.cc:236), the chi-square gates on the f64 reprojection (5.99146 / 7.81473 with
+     * inv_level_sigma_sq, stereo when t_x_right >= 0), best <= 50.  Result per query in out_query_best. */
+    const int32_t* q_group;         /* B x m_cap */
+    const int32_t* t_group;         /* B x n_cap */
+    const double* q_reproj_d;       /* B x m_cap x 2 (FUSE) */
+    const float* inv_level_sigma_sq;/* HOST pointer, num_levels floats (FUSE) */
+    int32_t* out_query_best;        /* B x m_cap (FUSE): best key point per query, -1 = none */
     /* outputs: out_match[b][t] = index of the query associated with key point t (-1 = none),
      * out_num[b] = the matcher's return value (num_matches) */
     int32_t* out_match;             /* B x n_cap */
@@ -279,6 +295,14 @@ typedef struct plp_match_args {
 plp_status plp_match_device(plp_matcher* ctx, const plp_match_args* a, void* hip_stream);
 /* Same with HOST pointers for one call (B problems are staged to HBM and back); synchronous. */
 plp_status plp_match_host(plp_matcher* ctx, const plp_match_args* a);
+
+/* area::match_in_consistent_area(frm_1, frm_2, prev_matched_pts, matched_indices_2_in_frm_1, margin)
+ * (src/PLPSLAM/match/area.cc:33-153; monocular initialisation, module/initializer.cc:191-192).  Host pointers, one
+ * problem, synchronous.  kps_1/kps_2 = undist_keypts_ of the two frames, prev_matched_pts = n1 x 2 floats (updated in
+ * place for matched key points), matched_2_in_1 = n1 int32 (idx_2 or -1); *num_matches = return value. */
+plp_status plp_match_area_host(plp_matcher* ctx, const plp_keypoint* kps_1, const uint8_t* desc_1, int32_t n1, const plp_keypoint* kps_2,
+                               const uint8_t* desc_2, int32_t n2, const plp_match_grid* grid, float* prev_matched_pts, int32_t margin,
+                               float lowe_ratio, int32_t check_orientation, int32_t* matched_2_in_1, int32_t* num_matches);
 
 /* cv::line_descriptor::BinaryDescriptorMatcher::match(query, train, matches) — exact 1-NN over LBD descriptors by
  * multi-index hashing (src/PLPSLAM/feature/line_descriptor/binary_descriptor_matcher.cpp:197-255, 597-818), used for the

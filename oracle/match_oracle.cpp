@@ -407,3 +407,132 @@ unsigned oracle_match_current_and_last_line(const KeyLineRec* kl, const uint8_t*
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------- BoW-guided, fuse, area
+extern "C" {
+
+// bow_tree::match_frame_and_keyframe (bow_tree.cc:41-165) and ::match_keyframes (:167-307), array form.
+//   The reference walks the two BoW feature vectors (std::map<node id, vector<feature idx>>) in node order; the
+//   caller lists the key-frame features in that order (queries) with their node id; frame features of the same node
+//   are visited in ascending index (DBoW2 / fbow append feature indices in feature order).
+//   q_valid: key-frame feature has a landmark that will not be erased; t_skip: frame-side static skip
+//   (match_keyframes: key frame 2 feature without a valid landmark; frame variant: none).
+//   out: t_match[n] = query index matched to target t (or -1); returns num_matches.
+unsigned oracle_match_bow(const uint8_t* q_desc, const float* q_angle, const int* q_node, const uint8_t* q_valid, int m,
+                          const uint8_t* t_desc, const float* t_angle, const int* t_node, const uint8_t* t_skip, int n, float lowe_ratio,
+                          int check_orientation, int* t_match) {
+    for (int i = 0; i < n; ++i) t_match[i] = -1;
+    std::vector<uint8_t> taken(n, 0);
+    unsigned num_matches = 0;
+    AngleChecker ac;
+    for (int q = 0; q < m; ++q) {
+        if (!q_valid[q]) continue;
+        unsigned best = MAX_HAMMING_DIST, second = MAX_HAMMING_DIST;
+        int best_t = -1;
+        for (int t = 0; t < n; ++t) {
+            if (t_node[t] != q_node[q]) continue;
+            if (t_skip && t_skip[t]) continue;
+            if (taken[t]) continue;
+            const unsigned d = hamming32(q_desc + 32 * (size_t)q, t_desc + 32 * (size_t)t);
+            if (d < best) { second = best; best = d; best_t = t; }
+            else if (d < second) second = d;
+        }
+        if (HAMMING_DIST_THR_LOW < best) continue;
+        if (lowe_ratio * second < static_cast<float>(best)) continue;
+        t_match[best_t] = q;
+        taken[best_t] = 1;
+        if (check_orientation) ac.append(q_angle[q] - t_angle[best_t], best_t);
+        ++num_matches;
+    }
+    if (check_orientation)
+        for (int bad : ac.collect(false)) { t_match[bad] = -1; --num_matches; }
+    return num_matches;
+}
+
+// fuse::replace_duplication (fuse.cc:169-331), the search part in array form: per landmark (that passed the
+// host-side visibility tests) the key point with the smallest Hamming distance inside the window and the
+// chi-square gates; the map mutation (:300-324) stays on the host and runs on best_idx in landmark order.
+//   reproj_d[m][2]: reprojection as f64 (Vec2_t), x_right[m], pred_level[m] (unsigned), inv_level_sigma_sq[]
+//   out: best_idx[m] (-1: none within HAMMING_DIST_THR_LOW)
+void oracle_fuse_search(const double* grid6, const KeyPoint* kps, const uint8_t* desc, const float* x_right, int n,
+                        const float* scale_factors, const float* inv_level_sigma_sq, const uint8_t* lm_valid, const double* reproj_d,
+                        const float* lm_x_right, const unsigned* pred_level, const uint8_t* lm_desc, int m, float margin, int* best_idx) {
+    Grid g{(float)grid6[0], (float)grid6[1], grid6[2], grid6[3], (int)grid6[4], (int)grid6[5]};
+    Features f{n, kps, desc, x_right, {}};
+    assign_to_grid(g, f);
+    for (int l = 0; l < m; ++l) {
+        best_idx[l] = -1;
+        if (!lm_valid[l]) continue;
+        const unsigned pred = pred_level[l];
+        const auto cand = keypoints_in_cell(g, f, (float)reproj_d[2 * l], (float)reproj_d[2 * l + 1], margin * scale_factors[pred], -1, -1);
+        if (cand.empty()) continue;
+        unsigned best = MAX_HAMMING_DIST;
+        int bi = -1;
+        for (unsigned idx : cand) {
+            const KeyPoint& k = kps[idx];
+            const unsigned scale_level = static_cast<unsigned>(k.octave);
+            if (scale_level < pred - 1 || pred < scale_level) continue;   // unsigned arithmetic, as the reference
+            if (x_right[idx] >= 0) {
+                const double e_x = reproj_d[2 * l] - k.x, e_y = reproj_d[2 * l + 1] - k.y;
+                const float e_xr = lm_x_right[l] - x_right[idx];
+                const double err = e_x * e_x + e_y * e_y + e_xr * e_xr;
+                constexpr float chi_sq_3D = 7.81473;
+                if (chi_sq_3D < err * inv_level_sigma_sq[scale_level]) continue;
+            } else {
+                const double e_x = reproj_d[2 * l] - k.x, e_y = reproj_d[2 * l + 1] - k.y;
+                const double err = e_x * e_x + e_y * e_y;
+                constexpr float chi_sq_2D = 5.99146;
+                if (chi_sq_2D < err * inv_level_sigma_sq[scale_level]) continue;
+            }
+            const unsigned d = hamming32(lm_desc + 32 * (size_t)l, desc + 32 * (size_t)idx);
+            if (d < best) { best = d; bi = (int)idx; }
+        }
+        if (HAMMING_DIST_THR_LOW < best) continue;
+        best_idx[l] = bi;
+    }
+}
+
+// area::match_in_consistent_area (area.cc:33-153), array form.  prev_matched_pts is updated in place.
+unsigned oracle_match_area(const double* grid6, const KeyPoint* kps1, const uint8_t* desc1, int n1, const KeyPoint* kps2,
+                           const uint8_t* desc2, int n2, float* prev_pts, int margin, float lowe_ratio, int check_orientation,
+                           int* matched_2_in_1) {
+    Grid g{(float)grid6[0], (float)grid6[1], grid6[2], grid6[3], (int)grid6[4], (int)grid6[5]};
+    Features f2{n2, kps2, desc2, nullptr, {}};
+    assign_to_grid(g, f2);
+    unsigned num_matches = 0;
+    AngleChecker ac;
+    for (int i = 0; i < n1; ++i) matched_2_in_1[i] = -1;
+    std::vector<unsigned> matched_dists_2(n2, MAX_HAMMING_DIST);
+    std::vector<int> matched_1_in_2(n2, -1);
+    for (int i1 = 0; i1 < n1; ++i1) {
+        const int lvl = kps1[i1].octave;
+        if (0 < lvl) continue;
+        const auto cand = keypoints_in_cell(g, f2, prev_pts[2 * i1], prev_pts[2 * i1 + 1], (float)margin, lvl, lvl);
+        if (cand.empty()) continue;
+        unsigned best = MAX_HAMMING_DIST, second = MAX_HAMMING_DIST;
+        int best_i2 = -1;
+        for (unsigned i2 : cand) {
+            const unsigned d = hamming32(desc1 + 32 * (size_t)i1, desc2 + 32 * (size_t)i2);
+            if (matched_dists_2[i2] <= d) continue;
+            if (d < best) { second = best; best = d; best_i2 = (int)i2; }
+            else if (d < second) second = d;
+        }
+        if (HAMMING_DIST_THR_LOW < best) continue;
+        if (second * lowe_ratio < static_cast<float>(best)) continue;
+        const int prev_i1 = matched_1_in_2[best_i2];
+        if (0 <= prev_i1) { matched_2_in_1[prev_i1] = -1; --num_matches; }
+        matched_2_in_1[i1] = best_i2;
+        matched_1_in_2[best_i2] = i1;
+        matched_dists_2[best_i2] = best;
+        ++num_matches;
+        if (check_orientation) ac.append(kps1[i1].angle - kps2[best_i2].angle, i1);
+    }
+    if (check_orientation)
+        for (int bad : ac.collect(false))
+            if (0 <= matched_2_in_1[bad]) { matched_2_in_1[bad] = -1; --num_matches; }
+    for (int i1 = 0; i1 < n1; ++i1)
+        if (0 <= matched_2_in_1[i1]) { prev_pts[2 * i1] = kps2[matched_2_in_1[i1]].x; prev_pts[2 * i1 + 1] = kps2[matched_2_in_1[i1]].y; }
+    return num_matches;
+}
+
+}  // extern "C"

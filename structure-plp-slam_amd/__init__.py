@@ -83,6 +83,7 @@ _API = [
     ("plp_match_device", C.c_int, [_VP, _VP, _VP]),
     ("plp_match_host", C.c_int, [_VP, _VP]),
     ("plp_match_debug_counters", C.c_int, [_VP, _VP]),
+    ("plp_match_area_host", C.c_int, [_VP, _VP, _VP, _I32, _VP, _VP, _I32, _VP, _VP, _I32, C.c_float, _I32, _VP, _VP]),
     ("plp_lbd_match_1nn_host", C.c_int, [_VP, _VP, _I32, _VP, _I32, _VP, _VP]),
     ("plp_lbd_match_1nn_device", C.c_int, [_VP, _VP, _VP, _I32, _VP, _VP, _I32, _I32, _VP, _VP, _VP]),
     ("plp_stereo_compute", C.c_int, [_VP, _VP, _VP, _I32, _VP, _I32, _VP, _VP, C.c_float, C.c_float, _VP, _VP]),
@@ -374,10 +375,12 @@ class match_args_c(C.Structure):
                 ("margin", C.c_float), ("lowe_ratio", C.c_float), ("direction", C.c_int32), ("check_orientation", C.c_int32),
                 ("num_levels", C.c_int32), ("scale_factors", _VP), ("grid", match_grid_c),
                 ("t_kl", _VP), ("t_kp_octave", _VP), ("t_x_right2", _VP), ("q_reproj2", _VP), ("q_x_right2", _VP),
-                ("is_rgbd", C.c_int32), ("num_levels_lsd", C.c_int32), ("out_match", _VP), ("out_num", _VP)]
+                ("is_rgbd", C.c_int32), ("num_levels_lsd", C.c_int32),
+                ("q_group", _VP), ("t_group", _VP), ("q_reproj_d", _VP), ("inv_level_sigma_sq", _VP), ("out_query_best", _VP),
+                ("out_match", _VP), ("out_num", _VP)]
 
 
-MODE_LANDMARKS, MODE_LAST_FRAME, MODE_BRUTE_FORCE, MODE_LANDMARKS_LINE, MODE_LAST_FRAME_LINE = 0, 1, 2, 3, 4
+MODE_LANDMARKS, MODE_LAST_FRAME, MODE_BRUTE_FORCE, MODE_LANDMARKS_LINE, MODE_LAST_FRAME_LINE, MODE_BOW, MODE_FUSE = 0, 1, 2, 3, 4, 5, 6
 
 
 def make_grid(cols_px, rows_px, grid_cols=64, grid_rows=48, min_x=0.0, min_y=0.0):
@@ -411,6 +414,10 @@ class matcher:
         for k, v in fields.items():
             if k in ("is_rgbd", "num_levels_lsd"):
                 setattr(a, k, int(v))
+            elif k == "inv_level_sigma_sq":
+                arr = np.ascontiguousarray(v, np.float32)
+                self._keep2 = arr
+                a.inv_level_sigma_sq = arr.ctypes.data
             else:
                 setattr(a, k, ptr(v) if v is not None else None)
         a.margin, a.lowe_ratio = margin, self.lowe_ratio
@@ -430,6 +437,11 @@ class matcher:
         out_match = np.zeros((B, n_cap), np.int32)
         out_num = np.zeros(B, np.int32)
         a = self._args(mode, B, n_cap, m_cap, fields, margin, direction, scale_factors, grid, out_match, out_num, lambda v: v.ctypes.data)
+        if mode == MODE_FUSE:
+            out_q = np.full((B, m_cap), -1, np.int32)
+            a.out_query_best = out_q.ctypes.data
+            _check(lib().plp_match_host(self._h, C.byref(a)))
+            return out_q
         _check(lib().plp_match_host(self._h, C.byref(a)))
         return out_match, out_num
 
@@ -440,6 +452,17 @@ class matcher:
         st = (stream or torch.cuda.current_stream(out_match.device)).cuda_stream
         a = self._args(mode, B, n_cap, m_cap, fields, margin, direction, scale_factors, grid, out_match, out_num, lambda v: v.data_ptr())
         _check(lib().plp_match_device(self._h, C.byref(a), st))
+
+    def match_in_consistent_area(self, kps_1, desc_1, kps_2, desc_2, prev_matched_pts, margin, grid):
+        """area::match_in_consistent_area: returns (matched_indices_2_in_frm_1, updated prev_matched_pts, num_matches)"""
+        k1 = np.ascontiguousarray(kps_1, KP_DTYPE); k2 = np.ascontiguousarray(kps_2, KP_DTYPE)
+        d1 = np.ascontiguousarray(desc_1, np.uint8); d2 = np.ascontiguousarray(desc_2, np.uint8)
+        pp = np.ascontiguousarray(prev_matched_pts, np.float32).copy()
+        out = np.full(max(len(k1), 1), -1, np.int32)
+        num = C.c_int32(0)
+        _check(lib().plp_match_area_host(self._h, _p(k1), _p(d1), len(k1), _p(k2), _p(d2), len(k2), C.byref(grid), _p(pp), int(margin),
+                                         float(self.lowe_ratio), int(self.check_orientation), _p(out), C.byref(num)))
+        return out[:len(k1)].copy(), pp, num.value
 
     def lbd_match_1nn(self, query_lbd, train_lbd):
         """BinaryDescriptorMatcher::match: (trainIdx, distance) per query row"""

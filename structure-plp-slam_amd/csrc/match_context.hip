@@ -25,7 +25,8 @@ plp_status check_args(const plp_match_args* a) {
     if (!a) return set_error(PLP_ERR_INVALID_ARG, "args is NULL");
     if (a->B <= 0 || a->n_cap <= 0 || a->m_cap <= 0) return set_error(PLP_ERR_INVALID_ARG, "B, n_cap, m_cap must be positive");
     if (a->n_cap > 8000) return set_error(PLP_ERR_UNSUPPORTED, "more than 8000 key points per frame");
-    if (!a->t_desc || !a->q_desc || !a->out_match || !a->out_num) return set_error(PLP_ERR_INVALID_ARG, "descriptor / output arrays are required");
+    if (!a->t_desc || !a->q_desc) return set_error(PLP_ERR_INVALID_ARG, "descriptor arrays are required");
+    if (a->mode != PLP_MATCH_MODE_FUSE && (!a->out_match || !a->out_num)) return set_error(PLP_ERR_INVALID_ARG, "output arrays are required");
     if (a->mode == PLP_MATCH_MODE_BRUTE_FORCE) {
         if (a->check_orientation && (!a->t_angle || !a->q_angle)) return set_error(PLP_ERR_INVALID_ARG, "check_orientation needs t_angle and q_angle");
     } else if (a->mode == PLP_MATCH_MODE_LANDMARKS || a->mode == PLP_MATCH_MODE_LAST_FRAME) {
@@ -37,6 +38,13 @@ plp_status check_args(const plp_match_args* a) {
         if (!a->t_kl || !a->q_reproj || !a->q_reproj2 || !a->q_level || !a->scale_factors) return set_error(PLP_ERR_INVALID_ARG, "t_kl, q_reproj, q_reproj2, q_level, scale_factors are required");
         if (a->mode == PLP_MATCH_MODE_LANDMARKS_LINE && !a->t_kp_octave) return set_error(PLP_ERR_INVALID_ARG, "t_kp_octave is required");
         if (a->num_levels <= 0 || a->num_levels > 16) return set_error(PLP_ERR_INVALID_ARG, "num_levels must be in [1,16]");
+    } else if (a->mode == PLP_MATCH_MODE_BOW) {
+        if (!a->q_group || !a->t_group) return set_error(PLP_ERR_INVALID_ARG, "q_group and t_group are required");
+        if (a->check_orientation && (!a->t_angle || !a->q_angle)) return set_error(PLP_ERR_INVALID_ARG, "check_orientation needs t_angle and q_angle");
+    } else if (a->mode == PLP_MATCH_MODE_FUSE) {
+        if (!a->t_kps || !a->q_reproj_d || !a->q_level || !a->scale_factors || !a->inv_level_sigma_sq || !a->out_query_best) return set_error(PLP_ERR_INVALID_ARG, "t_kps, q_reproj_d, q_level, scale_factors, inv_level_sigma_sq, out_query_best are required");
+        if (a->num_levels <= 0 || a->num_levels > 16) return set_error(PLP_ERR_INVALID_ARG, "num_levels must be in [1,16]");
+        if (a->grid.cols <= 0 || a->grid.rows <= 0 || a->grid.cols * a->grid.rows > 4096) return set_error(PLP_ERR_INVALID_ARG, "grid must have 1..4096 cells");
     } else return set_error(PLP_ERR_INVALID_ARG, "unknown mode");
     return PLP_OK;
 }
@@ -55,7 +63,9 @@ plp_status run_device(plp_matcher* c, const plp_match_args* a, hipStream_t st) {
     if (!c->dbg.p) { PLP_HIP(c->dbg.reserve(16)); PLP_HIP(hipMemsetAsync(c->dbg.p, 0, 16, st)); }
     MatchProblem P{};
     P.mode = a->mode; P.n_cap = a->n_cap; P.m_cap = a->m_cap;
-    P.t_kps = (a->mode == PLP_MATCH_MODE_LANDMARKS || a->mode == PLP_MATCH_MODE_LAST_FRAME) ? a->t_kps : nullptr;
+    P.t_kps = (a->mode == PLP_MATCH_MODE_LANDMARKS || a->mode == PLP_MATCH_MODE_LAST_FRAME || a->mode == PLP_MATCH_MODE_FUSE) ? a->t_kps : nullptr;
+    P.q_group = a->q_group; P.t_group = a->t_group; P.q_reproj_d = a->q_reproj_d; P.out_query_best = a->out_query_best;
+    for (int i = 0; i < 16; ++i) P.inv_level_sigma_sq[i] = (a->inv_level_sigma_sq && i < a->num_levels) ? a->inv_level_sigma_sq[i] : 1.0f;
     P.t_desc = a->t_desc; P.t_x_right = a->t_x_right; P.t_occupied = a->t_occupied; P.t_angle = a->t_angle; P.t_counts = a->t_counts;
     P.q_valid = a->q_valid; P.q_reproj = a->q_reproj; P.q_x_right = a->q_x_right; P.q_level = a->q_level; P.q_angle = a->q_angle;
     P.q_desc = a->q_desc; P.q_has_obs = a->q_has_obs; P.q_counts = a->q_counts;
@@ -133,6 +143,9 @@ plp_status plp_match_host(plp_matcher* c, const plp_match_args* a) {
     const size_t o_kl = add(a->t_kl, a->t_kl ? tn * sizeof(plp_keyline) : 0), o_ko = add(a->t_kp_octave, a->t_kp_octave ? tn * 4 : 0);
     const size_t o_tx2 = add(a->t_x_right2, a->t_x_right2 ? tn * 4 : 0), o_qr2 = add(a->q_reproj2, a->q_reproj2 ? qn * 8 : 0);
     const size_t o_qx2 = add(a->q_x_right2, a->q_x_right2 ? qn * 4 : 0);
+    const size_t o_qg = add(a->q_group, a->q_group ? qn * 4 : 0), o_tg = add(a->t_group, a->t_group ? tn * 4 : 0);
+    const size_t o_qrd = add(a->q_reproj_d, a->q_reproj_d ? qn * 16 : 0);
+    const size_t o_oq = off; off += (qn * 4 + 255) / 256 * 256;
     const size_t o_om = off; off += (tn * 4 + 255) / 256 * 256;
     const size_t o_on = off; off += ((size_t)a->B * 4 + 255) / 256 * 256;
     PLP_HIP(c->stage.reserve(off));
@@ -151,8 +164,16 @@ plp_status plp_match_host(plp_matcher* c, const plp_match_args* a) {
     d.t_kl = (const plp_keyline*)dp(a->t_kl, o_kl); d.t_kp_octave = (const int32_t*)dp(a->t_kp_octave, o_ko);
     d.t_x_right2 = (const float*)dp(a->t_x_right2, o_tx2); d.q_reproj2 = (const float*)dp(a->q_reproj2, o_qr2);
     d.q_x_right2 = (const float*)dp(a->q_x_right2, o_qx2);
+    d.q_group = (const int32_t*)dp(a->q_group, o_qg); d.t_group = (const int32_t*)dp(a->t_group, o_tg);
+    d.q_reproj_d = (const double*)dp(a->q_reproj_d, o_qrd);
+    d.out_query_best = a->out_query_best ? (int32_t*)(base + o_oq) : nullptr;
     d.out_match = (int32_t*)(base + o_om); d.out_num = (int32_t*)(base + o_on);
     PLP_TRY(run_device(c, &d, st));
+    if (a->mode == PLP_MATCH_MODE_FUSE) {
+        PLP_HIP(hipMemcpyAsync(a->out_query_best, base + o_oq, qn * 4, hipMemcpyDeviceToHost, st));
+        PLP_HIP(hipStreamSynchronize(st));
+        return PLP_OK;
+    }
     PLP_HIP(hipMemcpyAsync(a->out_match, base + o_om, tn * 4, hipMemcpyDeviceToHost, st));
     PLP_HIP(hipMemcpyAsync(a->out_num, base + o_on, (size_t)a->B * 4, hipMemcpyDeviceToHost, st));
     PLP_HIP(hipStreamSynchronize(st));
@@ -217,6 +238,45 @@ plp_status plp_lbd_match_1nn_host(plp_matcher* c, const uint8_t* q, int32_t nq, 
     PLP_HIP(hipMemcpyAsync(train_idx, base + bq + bt, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
     PLP_HIP(hipMemcpyAsync(dist, base + bq + bt + bo, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
     PLP_HIP(hipStreamSynchronize(c->stream));
+    return PLP_OK;
+}
+
+plp_status plp_match_area_host(plp_matcher* c, const plp_keypoint* kps_1, const uint8_t* desc_1, int32_t n1, const plp_keypoint* kps_2,
+                               const uint8_t* desc_2, int32_t n2, const plp_match_grid* grid, float* prev_matched_pts, int32_t margin,
+                               float lowe_ratio, int32_t check_orientation, int32_t* matched_2_in_1, int32_t* num_matches) {
+    if (!c || !grid || !matched_2_in_1 || !num_matches) return set_error(PLP_ERR_INVALID_ARG, "NULL argument");
+    *num_matches = 0;
+    if (n1 <= 0) return PLP_OK;
+    if (!kps_1 || !desc_1 || !prev_matched_pts || n2 < 0 || (n2 > 0 && (!kps_2 || !desc_2)) || n2 > 65535) return set_error(PLP_ERR_INVALID_ARG, "bad argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    PLP_HIP(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    auto al = [](size_t v) { return (v + 255) / 256 * 256; };
+    const size_t n2c = std::max(n2, 1);
+    const size_t o_k1 = 0, o_d1 = o_k1 + al((size_t)n1 * sizeof(plp_keypoint)), o_k2 = o_d1 + al((size_t)n1 * 32), o_d2 = o_k2 + al(n2c * sizeof(plp_keypoint));
+    const size_t o_pp = o_d2 + al(n2c * 32), o_m = o_pp + al((size_t)n1 * 8), o_n = o_m + al((size_t)n1 * 4), o_s = o_n + 256, total = o_s + al(n2c * 8);
+    PLP_HIP(c->stage.reserve(total));
+    uint8_t* base = (uint8_t*)c->stage.p;
+    PLP_HIP(hipMemcpyAsync(base + o_k1, kps_1, (size_t)n1 * sizeof(plp_keypoint), hipMemcpyHostToDevice, st));
+    PLP_HIP(hipMemcpyAsync(base + o_d1, desc_1, (size_t)n1 * 32, hipMemcpyHostToDevice, st));
+    if (n2) {
+        PLP_HIP(hipMemcpyAsync(base + o_k2, kps_2, (size_t)n2 * sizeof(plp_keypoint), hipMemcpyHostToDevice, st));
+        PLP_HIP(hipMemcpyAsync(base + o_d2, desc_2, (size_t)n2 * 32, hipMemcpyHostToDevice, st));
+    }
+    PLP_HIP(hipMemcpyAsync(base + o_pp, prev_matched_pts, (size_t)n1 * 8, hipMemcpyHostToDevice, st));
+    AreaArgs A{};
+    A.kps1 = (const plp_keypoint*)(base + o_k1); A.desc1 = base + o_d1; A.kps2 = (const plp_keypoint*)(base + o_k2); A.desc2 = base + o_d2;
+    A.n1 = n1; A.n2 = n2;
+    A.grid_min_x = grid->min_x; A.grid_min_y = grid->min_y; A.inv_cell_w = grid->inv_cell_width; A.inv_cell_h = grid->inv_cell_height;
+    A.grid_cols = grid->cols; A.grid_rows = grid->rows;
+    A.prev_pts = (float*)(base + o_pp); A.margin = (float)margin; A.lowe_ratio = lowe_ratio; A.check_orientation = check_orientation;
+    A.matched_2_in_1 = (int32_t*)(base + o_m); A.num_matches = (int32_t*)(base + o_n); A.scratch = (uint32_t*)(base + o_s);
+    launch_match_area(st, A);
+    PLP_HIP(hipGetLastError());
+    PLP_HIP(hipMemcpyAsync(matched_2_in_1, base + o_m, (size_t)n1 * 4, hipMemcpyDeviceToHost, st));
+    PLP_HIP(hipMemcpyAsync(prev_matched_pts, base + o_pp, (size_t)n1 * 8, hipMemcpyDeviceToHost, st));
+    PLP_HIP(hipMemcpyAsync(num_matches, base + o_n, 4, hipMemcpyDeviceToHost, st));
+    PLP_HIP(hipStreamSynchronize(st));
     return PLP_OK;
 }
 

@@ -28,6 +28,10 @@ struct MatchProblem {
     const float* q_reproj2;          // line modes: reprojected end point
     const float* q_x_right2;
     int is_rgbd, num_levels_lsd;
+    const int32_t* q_group; const int32_t* t_group;   // BOW mode: node id per feature
+    const double* q_reproj_d;        // FUSE mode: f64 reprojection
+    float inv_level_sigma_sq[16];    // FUSE mode
+    int32_t* out_query_best;         // FUSE mode: B x m_cap
     // queries = landmarks / last-frame key points / key-frame key points (B x m_cap), reference order
     const uint8_t* q_valid;          // NULL: all valid
     const float* q_reproj;           // x, y
@@ -62,6 +66,14 @@ struct MihRanks { uint8_t rank[256]; };   // enumeration rank of an 8-bit flip p
 void launch_lbd_match_1nn(hipStream_t st, const uint8_t* q, const int32_t* q_counts, int nq_cap, const uint8_t* t, const int32_t* t_counts,
                           int nt_cap, const MihRanks& R, int32_t* out_idx, int32_t* out_dist, int B);
 void launch_match(hipStream_t st, const MatchProblem& P, int B);
+struct AreaArgs {
+    const plp_keypoint *kps1, *kps2; const uint8_t *desc1, *desc2; int n1, n2;
+    float grid_min_x, grid_min_y; double inv_cell_w, inv_cell_h; int grid_cols, grid_rows;
+    float* prev_pts; float margin, lowe_ratio; int check_orientation;
+    int32_t* matched_2_in_1; int32_t* num_matches;
+    uint32_t* scratch;   // n2 x 2 words: matched distance, matched idx_1
+};
+void launch_match_area(hipStream_t st, const AreaArgs& A);
 void launch_hamming_matrix(hipStream_t st, const uint8_t* q, int nq, const uint8_t* t, int nt, uint16_t* dist);
 
 }  // namespace plp

@@ -44,24 +44,32 @@ struct QueryCtx {
     float rx, ry, mg, xr, xr2;
     int min_level, max_level, min_cx, max_cx, min_cy, max_cy;
     double l0, l1, l2, lden;   // line modes: the projected line (sp x ep) and sqrt(l0^2 + l1^2)
+    double rdx, rdy;           // FUSE: f64 reprojection
+    int group;                 // BOW: node id of the query feature
+    unsigned pred;             // FUSE: predicted scale level (unsigned, as the reference)
     bool windowed, empty, line;
 };
 __device__ __forceinline__ bool is_line_mode(int mode) { return mode == PLP_MATCH_MODE_LANDMARKS_LINE || mode == PLP_MATCH_MODE_LAST_FRAME_LINE; }
 
-__device__ __forceinline__ QueryCtx make_query(const MatchProblem& P, int q, const float* reproj, const float* q_xr, const int32_t* q_level) {
+__device__ __forceinline__ QueryCtx make_query(const MatchProblem& P, int q, int b) {
+    const size_t qoff = (size_t)b * P.m_cap;
+    const float* reproj = P.q_reproj ? P.q_reproj + qoff * 2 : nullptr;
+    const float* q_xr = P.q_x_right ? P.q_x_right + qoff : nullptr;
+    const int32_t* q_level = P.q_level ? P.q_level + qoff : nullptr;
     QueryCtx c{};
-    c.windowed = P.mode != PLP_MATCH_MODE_BRUTE_FORCE;
+    c.windowed = P.mode != PLP_MATCH_MODE_BRUTE_FORCE && P.mode != PLP_MATCH_MODE_BOW;
     c.line = is_line_mode(P.mode);
+    if (P.mode == PLP_MATCH_MODE_BOW) c.group = P.q_group[qoff + q];
     if (!c.windowed) return c;
     const int lvl = q_level[q];
     if (c.line) {   // data::get_keylines_in_cell (common.cc:315-363) + the level windows of projection.cc:138-144, :429-450
-        const float* r2 = P.q_reproj2 + ((size_t)(reproj - P.q_reproj) / 2) * 2;   // same per-problem offset as `reproj`
+        const float* r2 = P.q_reproj2 + qoff * 2;
         c.mg = __fmul_rn(P.margin, P.scale_factors[lvl]);
         const double x1 = reproj[2 * q], y1 = reproj[2 * q + 1], x2 = r2[2 * q], y2 = r2[2 * q + 1];
         c.l0 = y1 * 1.0 - 1.0 * y2; c.l1 = 1.0 * x2 - x1 * 1.0; c.l2 = x1 * y2 - y1 * x2;
         c.lden = sqrt(c.l0 * c.l0 + c.l1 * c.l1);
         c.xr = q_xr ? q_xr[q] : -1.f;
-        c.xr2 = P.q_x_right2 ? (P.q_x_right2 + (q_xr ? (q_xr - P.q_x_right) : 0))[q] : -1.f;
+        c.xr2 = P.q_x_right2 ? P.q_x_right2[qoff + q] : -1.f;
         if (P.mode == PLP_MATCH_MODE_LANDMARKS_LINE) { c.min_level = lvl - 1; c.max_level = lvl; }
         else if (P.direction == 1) { c.min_level = lvl; c.max_level = P.num_levels_lsd; }
         else if (P.direction == 2) { c.min_level = 0; c.max_level = lvl + 1; }
@@ -69,10 +77,16 @@ __device__ __forceinline__ QueryCtx make_query(const MatchProblem& P, int q, con
         c.empty = false;
         return c;
     }
-    c.rx = reproj[2 * q]; c.ry = reproj[2 * q + 1];
+    if (P.mode == PLP_MATCH_MODE_FUSE) {   // get_keypoints_in_cell(reproj(0), reproj(1), margin * scale) takes the f64 reprojection as float
+        const double* rd = P.q_reproj_d + qoff * 2;
+        c.rdx = rd[2 * q]; c.rdy = rd[2 * q + 1];
+        c.rx = (float)c.rdx; c.ry = (float)c.rdy;
+        c.pred = (unsigned)lvl;
+    } else { c.rx = reproj[2 * q]; c.ry = reproj[2 * q + 1]; }
     c.mg = __fmul_rn(P.margin, P.scale_factors[lvl]);
     c.xr = q_xr ? q_xr[q] : -1.f;
     if (P.mode == PLP_MATCH_MODE_LANDMARKS) { c.min_level = lvl - 1; c.max_level = lvl; }
+    else if (P.mode == PLP_MATCH_MODE_FUSE) { c.min_level = -1; c.max_level = -1; }
     else if (P.direction == 1) { c.min_level = lvl; c.max_level = P.num_levels - 1; }
     else if (P.direction == 2) { c.min_level = 0; c.max_level = lvl; }
     else { c.min_level = lvl - 1; c.max_level = lvl + 1; }
@@ -90,7 +104,11 @@ __device__ __forceinline__ unsigned long long candidate_key(const MatchProblem& 
                                                            const uint8_t* t_desc, const float* t_xr, const uint8_t* t_occ,
                                                            const uint4& q0, const uint4& q1) {
     unsigned order = (unsigned)t, oct = 0;
-    if (c.line) {
+    if (P.mode == PLP_MATCH_MODE_BOW) {
+        const size_t tb = (size_t)(t_desc - P.t_desc) / 32;
+        if (P.t_group[tb + t] != c.group) return ~0ull;
+        if (t_occ && t_occ[t]) return ~0ull;
+    } else if (c.line) {
         const size_t tb = (size_t)(t_desc - P.t_desc) / 32;   // per-problem target offset
         const plp_keyline kl = P.t_kl[tb + t];
         const float dsp = (float)(((double)kl.startPointX * c.l0 + (double)kl.startPointY * c.l1 + c.l2) / c.lden);
@@ -119,10 +137,25 @@ __device__ __forceinline__ unsigned long long candidate_key(const MatchProblem& 
             if (0 <= c.max_level && c.max_level < k.octave) return ~0ull;
         }
         if (!(fabsf(__fsub_rn(k.x, c.rx)) < c.mg && fabsf(__fsub_rn(k.y, c.ry)) < c.mg)) return ~0ull;
+        if (P.mode == PLP_MATCH_MODE_FUSE) {   // fuse.cc:230-262: octave window in unsigned arithmetic + chi-square gates in f64
+            const unsigned sl = (unsigned)k.octave;
+            if (sl < c.pred - 1u || c.pred < sl) return ~0ull;
+            const double e_x = c.rdx - (double)k.x, e_y = c.rdy - (double)k.y;
+            const float xr = t_xr ? t_xr[t] : -1.f;
+            if (xr >= 0) {
+                const float e_xr = __fsub_rn(c.xr, xr);
+                const double err = e_x * e_x + e_y * e_y + (double)__fmul_rn(e_xr, e_xr);
+                if ((double)7.81473f < err * (double)P.inv_level_sigma_sq[sl & 15]) return ~0ull;
+            } else {
+                const double err = e_x * e_x + e_y * e_y;
+                if ((double)5.99146f < err * (double)P.inv_level_sigma_sq[sl & 15]) return ~0ull;
+            }
+        } else {
         if (t_occ && t_occ[t]) return ~0ull;                                                 // already holds an observed landmark
         if (t_xr) {
             const float xr = t_xr[t];
             if (0 < xr && c.mg < fabsf(__fsub_rn(c.xr, xr))) return ~0ull;                    // stereo gate
+        }
         }
         order = ((unsigned)(cx * P.grid_rows + cy) << 16) | (unsigned)t;
         oct = (unsigned)k.octave & 15u;
@@ -174,9 +207,7 @@ __global__ __launch_bounds__(256) void k_match_topk(MatchProblem P) {
     const uint8_t* t_desc = P.t_desc + (size_t)b * P.n_cap * 32;
     const float* t_xr = P.t_x_right ? P.t_x_right + (size_t)b * P.n_cap : nullptr;
     const uint8_t* t_occ = P.t_occupied ? P.t_occupied + (size_t)b * P.n_cap : nullptr;
-    const QueryCtx c = make_query(P, q, P.q_reproj ? P.q_reproj + (size_t)b * P.m_cap * 2 : nullptr,
-                                  P.q_x_right ? P.q_x_right + (size_t)b * P.m_cap : nullptr,
-                                  P.q_level ? P.q_level + (size_t)b * P.m_cap : nullptr);
+    const QueryCtx c = make_query(P, q, b);
     const uint4* qd = reinterpret_cast<const uint4*>(P.q_desc + ((size_t)b * P.m_cap + q) * 32);
     const uint4 q0 = qd[0], q1 = qd[1];
     unsigned long long top[kMatchK];
@@ -276,9 +307,7 @@ __global__ __launch_bounds__(256) void k_match_topk_lds(MatchProblem P) {
         uint32_t* klist = P.klist + ((size_t)b * P.m_cap + q) * kMatchK;
         int32_t* kcount = P.kcount + (size_t)b * P.m_cap + q;
         if (q_valid && !q_valid[q]) { if (lane == 0) *kcount = -1; continue; }
-        const QueryCtx c = make_query(P, q, P.q_reproj ? P.q_reproj + (size_t)b * P.m_cap * 2 : nullptr,
-                                      P.q_x_right ? P.q_x_right + (size_t)b * P.m_cap : nullptr,
-                                      P.q_level ? P.q_level + (size_t)b * P.m_cap : nullptr);
+        const QueryCtx c = make_query(P, q, b);
         const uint4* qd = reinterpret_cast<const uint4*>(P.q_desc + ((size_t)b * P.m_cap + q) * 32);
         const uint4 q0 = qd[0], q1 = qd[1];
         unsigned long long top[kMatchK];
@@ -351,9 +380,6 @@ __global__ __launch_bounds__(256) void k_match_resolve(MatchProblem P) {
     const uint8_t* t_desc = P.t_desc + (size_t)b * P.n_cap * 32;
     const float* t_xr = P.t_x_right ? P.t_x_right + (size_t)b * P.n_cap : nullptr;
     const uint8_t* t_occ = P.t_occupied ? P.t_occupied + (size_t)b * P.n_cap : nullptr;
-    const float* q_reproj = P.q_reproj ? P.q_reproj + (size_t)b * P.m_cap * 2 : nullptr;
-    const float* q_xr = P.q_x_right ? P.q_x_right + (size_t)b * P.m_cap : nullptr;
-    const int32_t* q_level = P.q_level ? P.q_level + (size_t)b * P.m_cap : nullptr;
     int32_t* out = P.out_match + (size_t)b * P.n_cap;
 
     for (int t = tid; t < n; t += 256) { owner_prev[t] = 0x7fffffff; out[t] = -1; }
@@ -362,7 +388,7 @@ __global__ __launch_bounds__(256) void k_match_resolve(MatchProblem P) {
 
     int32_t* full_list = P.full_list + (size_t)b * P.m_cap;   // queries whose truncated best-K list ran dry
     const int need = (P.mode == PLP_MATCH_MODE_LAST_FRAME || P.mode == PLP_MATCH_MODE_LAST_FRAME_LINE) ? 1 : 2;   // the last-frame matcher has no second-best test
-    const bool blocks_always = !has_obs || P.mode == PLP_MATCH_MODE_BRUTE_FORCE;
+    const bool blocks_always = !has_obs || P.mode == PLP_MATCH_MODE_BRUTE_FORCE || P.mode == PLP_MATCH_MODE_BOW;
     const bool use_sorted = P.sorted_valid != 0;
     const StagedTarget* sorted = P.sorted + (size_t)b * P.n_cap;
     const float* sorted_xr = P.sorted_xr + (size_t)b * P.n_cap;
@@ -419,7 +445,7 @@ __global__ __launch_bounds__(256) void k_match_resolve(MatchProblem P) {
             if (tid == 0 && P.dbg && nf) atomicAdd(&P.dbg[0], nf);
             for (int f = wv; f < nf; f += 4) {
                 const int fq = full_list[f];
-                const QueryCtx c = make_query(P, fq, q_reproj, q_xr, q_level);
+                const QueryCtx c = make_query(P, fq, b);
                 const uint4* qd = reinterpret_cast<const uint4*>(P.q_desc + ((size_t)b * P.m_cap + fq) * 32);
                 const uint4 q0 = qd[0], q1 = qd[1];
                 unsigned long long k0 = ~0ull, k1 = ~0ull;
@@ -486,12 +512,12 @@ __global__ __launch_bounds__(256) void k_match_resolve(MatchProblem P) {
     if (tid == 0) s_num = 0;
     for (int i = tid; i < 32; i += 256) { s_hist[i] = 0; s_valid_bin[i] = 0; }
     __syncthreads();
-    const bool angle_check = P.check_orientation && (P.mode == PLP_MATCH_MODE_LAST_FRAME || P.mode == PLP_MATCH_MODE_BRUTE_FORCE);
+    const bool angle_check = P.check_orientation && (P.mode == PLP_MATCH_MODE_LAST_FRAME || P.mode == PLP_MATCH_MODE_BRUTE_FORCE || P.mode == PLP_MATCH_MODE_BOW);
     const float* q_angle = P.q_angle ? P.q_angle + (size_t)b * P.m_cap : nullptr;
     const float* t_angle = P.t_angle ? P.t_angle + (size_t)b * P.n_cap : nullptr;
     auto bin_of = [&](int q, int t) -> int {
         const float ta = kps ? kps[t].angle : t_angle[t];
-        float delta = P.mode == PLP_MATCH_MODE_LAST_FRAME ? __fsub_rn(q_angle[q], ta) : __fsub_rn(ta, q_angle[q]);
+        float delta = (P.mode == PLP_MATCH_MODE_LAST_FRAME || P.mode == PLP_MATCH_MODE_BOW) ? __fsub_rn(q_angle[q], ta) : __fsub_rn(ta, q_angle[q]);
         if (delta < 0.0) delta = (float)((double)delta + 360.0);
         if (360.0 <= delta) delta = (float)((double)delta - 360.0);
         return __float2int_rn(__fmul_rn(delta, 1.0f / 30));
@@ -554,11 +580,129 @@ __global__ __launch_bounds__(256) void k_hamming_matrix(const uint8_t* __restric
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// fuse::replace_duplication, search part (fuse.cc:169-298): independent queries, one wave each.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_match_fuse(MatchProblem P) {
+    const int lane = threadIdx.x & 63, b = blockIdx.y;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int m = P.q_counts ? P.q_counts[b] : P.m_cap;
+    if (q >= m) return;
+    int32_t* out = P.out_query_best + (size_t)b * P.m_cap + q;
+    const uint8_t* q_valid = P.q_valid ? P.q_valid + (size_t)b * P.m_cap : nullptr;
+    if (q_valid && !q_valid[q]) { if (lane == 0) *out = -1; return; }
+    const int n = P.t_counts ? P.t_counts[b] : P.n_cap;
+    const plp_keypoint* kps = P.t_kps + (size_t)b * P.n_cap;
+    const uint8_t* t_desc = P.t_desc + (size_t)b * P.n_cap * 32;
+    const float* t_xr = P.t_x_right ? P.t_x_right + (size_t)b * P.n_cap : nullptr;
+    const QueryCtx c = make_query(P, q, b);
+    const uint4* qd = reinterpret_cast<const uint4*>(P.q_desc + ((size_t)b * P.m_cap + q) * 32);
+    const uint4 q0 = qd[0], q1 = qd[1];
+    unsigned long long best = ~0ull;
+    if (!c.empty)
+        for (int t = lane; t < n; t += 64) {
+            const unsigned long long key = candidate_key(P, c, t, kps, t_desc, t_xr, nullptr, q0, q1);
+            best = key < best ? key : best;
+        }
+    best = wave_min_u64(best);
+    if (lane == 0) *out = (best != ~0ull && (unsigned)(best >> 32) <= 50u) ? (int32_t)((best >> 4) & 0xffff) : -1;
+}
+
+// ------------------------------------------------------------------------------------------
+// area::match_in_consistent_area (area.cc:33-153): the "steal if strictly closer" bookkeeping makes every query depend
+// on the distances recorded by all earlier ones, and the matcher only runs during monocular initialisation, so it is
+// replayed literally: one wave per problem walks frame 1 in order, its 64 lanes scan frame 2.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_match_area(AreaArgs A) {
+    __shared__ int hist[32], valid_bin[32];
+    const int lane = threadIdx.x;
+    uint32_t* mdist = A.scratch;            // matched_dists_in_frm_2
+    int32_t* m1in2 = reinterpret_cast<int32_t*>(A.scratch + A.n2);   // matched_indices_1_in_frm_2
+    for (int i = lane; i < A.n2; i += 64) { mdist[i] = 256u; m1in2[i] = -1; }
+    for (int i = lane; i < A.n1; i += 64) A.matched_2_in_1[i] = -1;
+    if (lane < 32) { hist[lane] = 0; valid_bin[lane] = 0; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    auto bin_of = [&](int i1, int i2) -> int {
+        float delta = __fsub_rn(A.kps1[i1].angle, A.kps2[i2].angle);
+        if (delta < 0.0) delta = (float)((double)delta + 360.0);
+        if (360.0 <= delta) delta = (float)((double)delta - 360.0);
+        return min(__float2int_rn(__fmul_rn(delta, 1.0f / 30)), 31);
+    };
+    for (int i1 = 0; i1 < A.n1; ++i1) {
+        const plp_keypoint k1 = A.kps1[i1];
+        if (0 < k1.octave) continue;
+        const float rx = A.prev_pts[2 * i1], ry = A.prev_pts[2 * i1 + 1], mg = A.margin;
+        const int min_cx = max(0, floor_d((double)__fsub_rn(__fsub_rn(rx, A.grid_min_x), mg) * A.inv_cell_w));
+        const int max_cx = min(A.grid_cols - 1, ceil_d((double)__fadd_rn(__fsub_rn(rx, A.grid_min_x), mg) * A.inv_cell_w));
+        const int min_cy = max(0, floor_d((double)__fsub_rn(__fsub_rn(ry, A.grid_min_y), mg) * A.inv_cell_h));
+        const int max_cy = min(A.grid_rows - 1, ceil_d((double)__fadd_rn(__fsub_rn(ry, A.grid_min_y), mg) * A.inv_cell_h));
+        if (A.grid_cols <= min_cx || max_cx < 0 || A.grid_rows <= min_cy || max_cy < 0) continue;
+        const uint4* qd = reinterpret_cast<const uint4*>(A.desc1 + 32 * (size_t)i1);
+        const uint4 q0 = qd[0], q1 = qd[1];
+        unsigned long long k0 = ~0ull, k1k = ~0ull;
+        for (int t = lane; t < A.n2; t += 64) {
+            const plp_keypoint k = A.kps2[t];
+            const int cx = floor_d((double)__fsub_rn(k.x, A.grid_min_x) * A.inv_cell_w), cy = floor_d((double)__fsub_rn(k.y, A.grid_min_y) * A.inv_cell_h);
+            if (cx < 0 || cx >= A.grid_cols || cy < 0 || cy >= A.grid_rows) continue;
+            if (cx < min_cx || cx > max_cx || cy < min_cy || cy > max_cy) continue;
+            if (k.octave < 0 || 0 < k.octave) continue;                      // min_level = max_level = 0
+            if (!(fabsf(__fsub_rn(k.x, rx)) < mg && fabsf(__fsub_rn(k.y, ry)) < mg)) continue;
+            const uint4* d = reinterpret_cast<const uint4*>(A.desc2 + 32 * (size_t)t);
+            const unsigned dist = hamming256(q0, q1, d[0], d[1]);
+            if (mdist[t] <= dist) continue;                                  // already matched at least as closely (:72)
+            const unsigned long long key = ((unsigned long long)dist << 32) | ((unsigned long long)(((unsigned)(cx * A.grid_rows + cy) << 16) | (unsigned)t));
+            if (key < k0) { k1k = k0; k0 = key; } else if (key < k1k) k1k = key;
+        }
+        const unsigned long long g0 = wave_min_u64(k0);
+        const unsigned long long g1 = wave_min_u64(k0 == g0 ? k1k : k0);
+        if (g0 == ~0ull) continue;
+        const unsigned best = (unsigned)(g0 >> 32), second = g1 != ~0ull ? (unsigned)(g1 >> 32) : 256u;
+        if (50u < best) continue;
+        if (__fmul_rn((float)second, A.lowe_ratio) < (float)best) continue;
+        const int best_i2 = (int)(g0 & 0xffff);
+        if (lane == 0) {
+            const int prev_i1 = m1in2[best_i2];
+            if (0 <= prev_i1) A.matched_2_in_1[prev_i1] = -1;
+            A.matched_2_in_1[i1] = best_i2;
+            m1in2[best_i2] = i1;
+            mdist[best_i2] = best;
+            if (A.check_orientation) hist[bin_of(i1, best_i2)] += 1;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+    // num_matches = matches still standing; the orientation check removes the ones outside the 3 fullest bins
+    if (A.check_orientation && lane == 0) {
+        for (int r = 0; r < 3; ++r) {
+            int bi = -1, bv = -1;
+            for (int i = 0; i < 30; ++i) if (!valid_bin[i] && hist[i] > bv) { bv = hist[i]; bi = i; }
+            valid_bin[bi] = 1;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    int cnt = 0;
+    for (int i1 = lane; i1 < A.n1; i1 += 64) {
+        const int i2 = A.matched_2_in_1[i1];
+        if (i2 < 0) continue;
+        if (A.check_orientation && !valid_bin[bin_of(i1, i2)]) { A.matched_2_in_1[i1] = -1; continue; }
+        ++cnt;
+        A.prev_pts[2 * i1] = A.kps2[i2].x; A.prev_pts[2 * i1 + 1] = A.kps2[i2].y;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if (lane == 0) *A.num_matches = cnt;
+}
+
+void launch_match_area(hipStream_t st, const AreaArgs& A) { hipLaunchKernelGGL(k_match_area, dim3(1), dim3(64), 0, st, A); }
+
 void launch_match(hipStream_t st, const MatchProblem& P, int B) {
+    if (P.mode == PLP_MATCH_MODE_FUSE) { hipLaunchKernelGGL(k_match_fuse, dim3((P.m_cap + 3) / 4, B), dim3(256), 0, st, P); return; }
     MatchProblem Q = P;
     Q.sorted_valid = 0;
     const bool windowed = P.mode == PLP_MATCH_MODE_LANDMARKS || P.mode == PLP_MATCH_MODE_LAST_FRAME;
-    const bool line = P.mode == PLP_MATCH_MODE_LANDMARKS_LINE || P.mode == PLP_MATCH_MODE_LAST_FRAME_LINE;
+    const bool line = P.mode == PLP_MATCH_MODE_LANDMARKS_LINE || P.mode == PLP_MATCH_MODE_LAST_FRAME_LINE || P.mode == PLP_MATCH_MODE_BOW;
     const size_t staged = windowed ? (size_t)P.n_cap * (sizeof(StagedTarget) + (P.t_x_right ? 4 : 0)) : (size_t)P.n_cap * 32;
     if (!line && staged <= 64 * 1024 && (!windowed || (P.grid_cols <= 255 && P.grid_rows <= 255))) {
         if (windowed) hipLaunchKernelGGL(k_match_prep, dim3(B), dim3(256), 0, st, P);

@@ -83,6 +83,11 @@ def lib():
         L.oracle_match_current_and_last_line.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p]
         L.oracle_stereo_compute.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
         L.oracle_lbd_match_1nn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.oracle_match_bow.restype = C.c_uint
+        L.oracle_match_bow.argtypes = [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 4 + [C.c_int, C.c_float, C.c_int, C.c_void_p]
+        L.oracle_fuse_search.argtypes = [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 8 + [C.c_int, C.c_float, C.c_void_p]
+        L.oracle_match_area.restype = C.c_uint
+        L.oracle_match_area.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p]
         L.oracle_front_time_frames.restype = C.c_double
         L.oracle_front_time_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_int, C.c_float, C.c_void_p]
         L.oracle_line_extract.restype = C.c_void_p
@@ -350,3 +355,32 @@ def lbd_match_1nn(q, t):
     idx = np.zeros(max(len(q), 1), np.int32); dist = np.zeros(max(len(q), 1), np.int32)
     lib().oracle_lbd_match_1nn(_p(q), len(q), _p(t), len(t), _p(idx), _p(dist))
     return idx[:len(q)].copy(), dist[:len(q)].copy()
+
+
+def match_bow(q_desc, q_angle, q_node, q_valid, t_desc, t_angle, t_node, t_skip, ratio, check_orientation):
+    m, n = len(q_desc), len(t_desc)
+    out = np.zeros(max(n, 1), np.int32)
+    a = [_c(q_desc, np.uint8), _c(q_angle, np.float32), _c(q_node, np.int32), _c(q_valid, np.uint8)]
+    b = [_c(t_desc, np.uint8), _c(t_angle, np.float32), _c(t_node, np.int32), _c(t_skip, np.uint8)]
+    num = lib().oracle_match_bow(*[_p(v) for v in a], m, *[_p(v) for v in b], n, ratio, int(check_orientation), _p(out))
+    return out[:n].copy(), num
+
+
+def fuse_search(g6, kps, desc, x_right, sf, inv_sigma, lm_valid, reproj_d, lm_x_right, pred_level, lm_desc, margin):
+    n, m = len(kps), len(pred_level)
+    out = np.zeros(max(m, 1), np.int32)
+    a = [_c(g6, np.float64), _c(kps, KP_DTYPE), _c(desc, np.uint8), _c(x_right, np.float32)]
+    b = [_c(sf, np.float32), _c(inv_sigma, np.float32), _c(lm_valid, np.uint8), _c(reproj_d, np.float64), _c(lm_x_right, np.float32),
+         _c(pred_level, np.uint32), _c(lm_desc, np.uint8)]
+    lib().oracle_fuse_search(*[_p(v) for v in a], n, *[_p(v) for v in b], m, margin, _p(out))
+    return out[:m].copy()
+
+
+def match_area(g6, kps1, desc1, kps2, desc2, prev_pts, margin, ratio, check_orientation):
+    n1, n2 = len(kps1), len(kps2)
+    out = np.zeros(max(n1, 1), np.int32)
+    pp = _c(prev_pts, np.float32).copy()
+    v = [_c(g6, np.float64), _c(kps1, KP_DTYPE), _c(desc1, np.uint8)]
+    w = [_c(kps2, KP_DTYPE), _c(desc2, np.uint8)]
+    num = lib().oracle_match_area(_p(v[0]), _p(v[1]), _p(v[2]), n1, _p(w[0]), _p(w[1]), n2, _p(pp), int(margin), ratio, int(check_orientation), _p(out))
+    return out[:n1].copy(), pp, num

@@ -163,3 +163,63 @@ def test_line_projection_matchers(seed):
                 got, gn = plp.matcher(0.9, True).match_host(plp.MODE_LAST_FRAME_LINE, n, m, {**t, **q, "is_rgbd": rgbd, "num_levels_lsd": 1},
                                                             margin=margin, direction=direction, scale_factors=sf_lsd)
                 assert gn[0] == wn and np.array_equal(got[0], want), (n, m, direction, rgbd)
+
+
+# ---------------------------------------------------------------------------------------- BoW-guided, fuse, area
+@pytest.mark.parametrize("seed", range(3))
+def test_bow_guided_matcher(seed):
+    rng = np.random.default_rng(80 + seed)
+    for n, m, nodes, words in [(800, 700, 40, 0), (1500, 1500, 12, 30), (50, 60, 3, 4), (1, 2, 1, 1)]:
+        t, q = MC.random_problem(rng, n, m, n_words=words)
+        # node id = a hash of the descriptor's first byte (as a vocabulary tree would group similar descriptors)
+        t_node = (t["t_desc"][:, 0].astype(np.int32) * 7 + 3) % nodes
+        q_node = (q["q_desc"][:, 0].astype(np.int32) * 7 + 3) % nodes
+        order = np.argsort(q_node, kind="stable")      # the reference walks the key-frame features in node order
+        qd, qa, qn, qv = q["q_desc"][order], q["q_angle"][order], q_node[order], q["q_valid"][order]
+        for skip in (None, t["t_occupied"]):
+            for check in (True, False):
+                tskip = np.zeros(n, np.uint8) if skip is None else skip
+                want, wn = O.match_bow(qd, qa, qn, qv, t["t_desc"], t["t_kps"]["angle"], t_node, tskip, 0.75, check)
+                got, gn = plp.matcher(0.75, check).match_host(plp.MODE_BOW, n, m, dict(t_desc=t["t_desc"], t_angle=t["t_kps"]["angle"], t_group=t_node,
+                                                              t_occupied=skip, q_desc=qd, q_angle=qa, q_group=qn, q_valid=qv))
+                assert gn[0] == wn and np.array_equal(got[0], want), (n, m, nodes, check)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_fuse_search(seed):
+    rng = np.random.default_rng(90 + seed)
+    grid = plp.make_grid(640, 480)
+    inv_sigma = (1.0 / (SF * SF)).astype(np.float32)
+    for n, m in [(900, 1200), (1500, 300), (3, 10)]:
+        t, q = MC.random_problem(rng, n, m, n_words=(0, 6)[seed % 2], stereo=True)
+        reproj_d = q["q_reproj"].astype(np.float64) + rng.normal(0, 0.7, (m, 2))
+        pred = rng.integers(0, 8, m).astype(np.uint32)            # includes 0: the unsigned-wrap quirk rejects everything
+        want = O.fuse_search(O.grid6(grid), t["t_kps"], t["t_desc"], t["t_x_right"], SF, inv_sigma, q["q_valid"], reproj_d, q["q_x_right"], pred,
+                             q["q_desc"], 3.0)
+        got = plp.matcher().match_host(plp.MODE_FUSE, n, m, dict(t_kps=t["t_kps"], t_desc=t["t_desc"], t_x_right=t["t_x_right"], q_valid=q["q_valid"],
+                                       q_reproj_d=reproj_d, q_x_right=q["q_x_right"], q_level=pred.astype(np.int32), q_desc=q["q_desc"],
+                                       inv_level_sigma_sq=inv_sigma), margin=3.0, scale_factors=SF, grid=grid)
+        assert np.array_equal(got[0], want)
+        assert (want[pred == 0] == -1).all()
+    assert (want >= 0).sum() >= 0
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_area_matcher(seed):
+    rng = np.random.default_rng(70 + seed)
+    grid = plp.make_grid(640, 480)
+    frames = synth.replay(50 + seed, 2, step_px=5)
+    f1, f2 = MC.features_from_oracle(frames[0], 2000), MC.features_from_oracle(frames[1], 2000)
+    prev = np.stack([f1[0]["x"], f1[0]["y"]], 1).astype(np.float32)          # initializer: prev_matched_pts = key points of frame 1
+    for check in (True, False):
+        want, wpp, wn = O.match_area(O.grid6(grid), f1[0], f1[1], f2[0], f2[1], prev, 100, 0.9, check)
+        got, gpp, gn = plp.matcher(0.9, check).match_in_consistent_area(f1[0], f1[1], f2[0], f2[1], prev, 100, grid)
+        assert gn == wn and np.array_equal(got, want) and np.array_equal(gpp, wpp)
+        assert wn > 50
+    # synthetic: few distinct descriptors -> many "steal if closer" events
+    t1, _ = MC.random_problem(rng, 600, 5, n_words=5); t2, _ = MC.random_problem(rng, 700, 5, n_words=5)
+    t1["t_kps"]["octave"] = rng.integers(0, 2, 600); t2["t_kps"]["octave"] = rng.integers(0, 2, 700)
+    prev = np.stack([t1["t_kps"]["x"], t1["t_kps"]["y"]], 1).astype(np.float32)
+    want, wpp, wn = O.match_area(O.grid6(grid), t1["t_kps"], t1["t_desc"], t2["t_kps"], t2["t_desc"], prev, 150, 0.9, True)
+    got, gpp, gn = plp.matcher(0.9, True).match_in_consistent_area(t1["t_kps"], t1["t_desc"], t2["t_kps"], t2["t_desc"], prev, 150, grid)
+    assert gn == wn and np.array_equal(got, want) and np.array_equal(gpp, wpp)
