@@ -85,7 +85,7 @@ def lib():
         L.oracle_lbd_match_1nn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.oracle_match_bow.restype = C.c_uint
         L.oracle_match_bow.argtypes = [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 4 + [C.c_int, C.c_float, C.c_int, C.c_void_p]
-        L.oracle_fuse_search.argtypes = [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 8 + [C.c_int, C.c_float, C.c_void_p]
+        L.oracle_fuse_search.argtypes = [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 7 + [C.c_int, C.c_float, C.c_void_p]
         L.oracle_match_area.restype = C.c_uint
         L.oracle_match_area.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p]
         L.oracle_front_time_frames.restype = C.c_double
