@@ -223,8 +223,20 @@ typedef enum plp_match_mode {
     PLP_MATCH_MODE_LANDMARKS_LINE = 3,  /* projection::match_frame_and_landmarks_line      match/projection.cc:124-212 */
     PLP_MATCH_MODE_LAST_FRAME_LINE = 4, /* projection::match_current_and_last_frames_line  match/projection.cc:361-527 */
     PLP_MATCH_MODE_BOW = 5,         /* bow_tree::match_frame_and_keyframe / match_keyframes   match/bow_tree.cc:41-165, 167-307 */
-    PLP_MATCH_MODE_FUSE = 6         /* fuse::replace_duplication, the search part              match/fuse.cc:169-298        */
+    PLP_MATCH_MODE_FUSE = 6,        /* fuse::replace_duplication, the search part              match/fuse.cc:169-298        */
+    PLP_MATCH_MODE_FUSE_LINE = 7,   /* fuse::replace_duplication_line, the search part         match/fuse.cc:335-470        */
+    PLP_MATCH_MODE_TRIANGULATION = 8/* robust::match_for_triangulation                         match/robust.cc:43-216       */
 } plp_match_mode;
+
+/* plp_match_args.flags */
+#define PLP_MATCH_FLAG_NO_CHI2 1        /* FUSE: no chi-square gates (fuse::detect_duplication fuse.cc:40-166,
+                                           projection::match_keyframes_mutually projection.cc:894-1142) */
+#define PLP_MATCH_FLAG_SIGNED_LEVEL 2   /* FUSE: octave window [q_level-1, q_level] in SIGNED arithmetic (detect_duplication
+                                           declares `const int pred_scale_level`, fuse.cc:109,126) */
+#define PLP_MATCH_FLAG_UNSIGNED_LEVEL 4 /* LAST_FRAME with level_window 1: the manual window of match_by_Sim3_transform
+                                           (projection.cc:862) in unsigned arithmetic, q_level == 0 matches nothing */
+/* plp_match_args.level_window (LAST_FRAME / LAST_FRAME_LINE): 0 = from `direction`, 1 = [q_level-1, q_level],
+ * 2 = [q_level-1, q_level+1] */
 
 typedef struct plp_match_grid {     /* camera::base grid (camera/base.h:91) used by data::get_keypoints_in_cell */
     float min_x, min_y;             /* img_bounds_.min_x_/min_y_ (float, camera/base.h:78-81) */
@@ -284,7 +296,33 @@ typedef struct plp_match_args {
     const int32_t* t_group;         /* B x n_cap */
     const double* q_reproj_d;       /* B x m_cap x 2 (FUSE) */
     const float* inv_level_sigma_sq;/* HOST pointer, num_levels floats (FUSE) */
-    int32_t* out_query_best;        /* B x m_cap (FUSE): best key point per query, -1 = none */
+    int32_t* out_query_best;        /* B x m_cap (FUSE, FUSE_LINE): best key point / key line per query, -1 = none */
+    /* Variants of the same loops:
+     *  - projection::match_frame_and_keyframe[_line] (projection.cc:529-645, 648-779) = LAST_FRAME[_LINE] with
+     *    direction 0, t_x_right NULL / is_rgbd 0, t_occupied = "landmarks_[i] != nullptr", q_has_obs NULL and
+     *    hamm_dist_thr = the caller's threshold;
+     *  - projection::match_by_Sim3_transform (:781-892) = LAST_FRAME, level_window 1, PLP_MATCH_FLAG_UNSIGNED_LEVEL,
+     *    hamm_dist_thr 50, check_orientation 0, t_occupied = "matched_lms_in_keyfrm[i] != nullptr";
+     *  - projection::match_keyframes_mutually (:894-1142) = two FUSE calls with PLP_MATCH_FLAG_NO_CHI2 and
+     *    hamm_dist_thr 100, then the cross check (:1124-1139) on the two out_query_best arrays;
+     *  - fuse::detect_duplication (fuse.cc:40-166) = FUSE with NO_CHI2 | SIGNED_LEVEL.
+     * FUSE_LINE: targets t_kl / t_desc (LBD), queries q_reproj_d = reprojected start point, q_reproj2_d = end point
+     *  (f64), window = data::get_keylines_in_cell(margin * scale_factors[q_level]) without octave test, gate
+     *  5.99146 < (e_sp^2 + e_ep^2) * inv_level_sigma_sq[keyline.octave] in f64, best <= 50 (fuse.cc:431-470).
+     * TRIANGULATION: BOW-style node-guided search between two key frames; q = features of key frame 1 in BoW node
+     *  order (q_valid = "has no landmark"), t = features of key frame 2 (t_occupied = "has a landmark"); q_x_right /
+     *  t_x_right >= 0 mark stereo key points; q_level = undist_keypts_[idx_1].octave; gates in f64 on the bearings:
+     *  epipole test (both mono: skip if 0.99862953475 < epipole . bearing_2) and check_epipolar_constraint
+     *  (robust.cc:387-405); Hamming <= 50, equal distances: the LATER candidate wins (`best < dist` skips, :124);
+     *  exclusive on t; angle check on q_angle - t_angle.  `epipolar` = per problem 12 doubles: E_12 row-major, then
+     *  the epipole bearing in key frame 2. */
+    int32_t hamm_dist_thr;          /* 0 = the mode's own threshold */
+    int32_t level_window;
+    int32_t flags;
+    const double* q_reproj2_d;      /* B x m_cap x 2 (FUSE_LINE) */
+    const double* q_bearing;        /* B x m_cap x 3 (TRIANGULATION) */
+    const double* t_bearing;        /* B x n_cap x 3 (TRIANGULATION) */
+    const double* epipolar;         /* B x 12 (TRIANGULATION) */
     /* outputs: out_match[b][t] = index of the query associated with key point t (-1 = none),
      * out_num[b] = the matcher's return value (num_matches) */
     int32_t* out_match;             /* B x n_cap */

@@ -536,3 +536,238 @@ unsigned oracle_match_area(const double* grid6, const KeyPoint* kps1, const uint
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------- relocalisation / loop / mapping variants
+extern "C" {
+
+// projection::match_frame_and_keyframe (projection.cc:529-645), array form.
+//   key-frame landmarks in idx order: valid[m] (present, not erased, not already matched, in image, in the ORB distance
+//   range), reproj[m][2] (Vec2_t narrowed to float by get_keypoints_in_cell), pred_level[m], angle[m] = keyfrm undist angle
+//   occupied[n]: curr_frm.landmarks_[i] != nullptr.  out: kp_lm[n] = idx of the key-frame landmark written to key point i.
+unsigned oracle_match_frame_and_keyframe(const double* grid6, const KeyPoint* kps, const uint8_t* desc, const uint8_t* occupied, int n,
+                                         const float* scale_factors, const uint8_t* valid, const float* reproj, const unsigned* pred_level,
+                                         const float* langle, const uint8_t* ldesc, int m, float margin, unsigned hamm_dist_thr,
+                                         int check_orientation, int* kp_lm) {
+    Grid g{(float)grid6[0], (float)grid6[1], grid6[2], grid6[3], (int)grid6[4], (int)grid6[5]};
+    Features f{n, kps, desc, nullptr, {}};
+    assign_to_grid(g, f);
+    std::vector<uint8_t> occ(occupied, occupied + n);
+    for (int i = 0; i < n; ++i) kp_lm[i] = -1;
+    unsigned num_matches = 0;
+    AngleChecker ac;
+    for (int l = 0; l < m; ++l) {
+        if (!valid[l]) continue;
+        const unsigned pred = pred_level[l];
+        const auto cand = keypoints_in_cell(g, f, reproj[2 * l], reproj[2 * l + 1], margin * scale_factors[pred], (int)(pred - 1), (int)(pred + 1));
+        if (cand.empty()) continue;
+        unsigned best = MAX_HAMMING_DIST;
+        int best_idx = -1;
+        for (unsigned idx : cand) {
+            if (occ[idx]) continue;
+            const unsigned d = hamming32(ldesc + 32 * (size_t)l, desc + 32 * (size_t)idx);
+            if (d < best) { best = d; best_idx = (int)idx; }
+        }
+        if (hamm_dist_thr < best) continue;
+        kp_lm[best_idx] = l;
+        occ[best_idx] = 1;
+        ++num_matches;
+        if (check_orientation) ac.append(langle[l] - kps[best_idx].angle, best_idx);
+    }
+    if (check_orientation)
+        for (int bad : ac.collect(false)) { kp_lm[bad] = -1; --num_matches; }
+    return num_matches;
+}
+
+// projection::match_frame_and_keyframe_line (projection.cc:648-779), array form.
+unsigned oracle_match_frame_and_keyframe_line(const KeyLineRec* kl, const uint8_t* lbd, const uint8_t* occupied, int n,
+                                              const float* scale_factors_lsd, const uint8_t* valid, const float* sp, const float* ep,
+                                              const unsigned* pred_level, const uint8_t* ldesc, int m, float margin,
+                                              unsigned hamm_dist_thr, int* line_lm) {
+    std::vector<uint8_t> occ(occupied, occupied + n);
+    for (int i = 0; i < n; ++i) line_lm[i] = -1;
+    unsigned num_matches = 0;
+    for (int l = 0; l < m; ++l) {
+        if (!valid[l]) continue;
+        const unsigned pred = pred_level[l];
+        const auto cand = keylines_in_cell(kl, n, sp[2 * l], sp[2 * l + 1], ep[2 * l], ep[2 * l + 1], margin * scale_factors_lsd[pred],
+                                           (int)(pred - 1), (int)(pred + 1));
+        if (cand.empty()) continue;
+        unsigned best = MAX_HAMMING_DIST;
+        int best_idx = -1;
+        for (unsigned idx : cand) {
+            if (occ[idx]) continue;
+            const unsigned d = hamming32(ldesc + 32 * (size_t)l, lbd + 32 * (size_t)idx);
+            if (d < best) { best = d; best_idx = (int)idx; }
+        }
+        if (hamm_dist_thr < best) continue;
+        line_lm[best_idx] = l;
+        occ[best_idx] = 1;
+        ++num_matches;
+    }
+    return num_matches;
+}
+
+// projection::match_by_Sim3_transform (projection.cc:781-892), array form.
+//   occupied[n]: matched_lms_in_keyfrm[i] != nullptr; valid[m]: the host-side tests of :797-838.
+unsigned oracle_match_by_sim3(const double* grid6, const KeyPoint* kps, const uint8_t* desc, const uint8_t* occupied, int n,
+                              const float* scale_factors, const uint8_t* valid, const float* reproj, const unsigned* pred_level,
+                              const uint8_t* ldesc, int m, float margin, int* kp_lm) {
+    Grid g{(float)grid6[0], (float)grid6[1], grid6[2], grid6[3], (int)grid6[4], (int)grid6[5]};
+    Features f{n, kps, desc, nullptr, {}};
+    assign_to_grid(g, f);
+    std::vector<uint8_t> occ(occupied, occupied + n);
+    for (int i = 0; i < n; ++i) kp_lm[i] = -1;
+    unsigned num_matches = 0;
+    for (int l = 0; l < m; ++l) {
+        if (!valid[l]) continue;
+        const unsigned pred = pred_level[l];
+        const auto cand = keypoints_in_cell(g, f, reproj[2 * l], reproj[2 * l + 1], margin * scale_factors[pred], -1, -1);
+        if (cand.empty()) continue;
+        unsigned best = MAX_HAMMING_DIST;
+        int best_idx = -1;
+        for (unsigned idx : cand) {
+            if (occ[idx]) continue;
+            const unsigned scale_level = static_cast<unsigned>(kps[idx].octave);
+            if (scale_level < pred - 1 || pred < scale_level) continue;
+            const unsigned d = hamming32(ldesc + 32 * (size_t)l, desc + 32 * (size_t)idx);
+            if (d < best) { best = d; best_idx = (int)idx; }
+        }
+        if (HAMMING_DIST_THR_LOW < best) continue;
+        kp_lm[best_idx] = l;
+        occ[best_idx] = 1;
+        ++num_matches;
+    }
+    return num_matches;
+}
+
+// One direction of projection::match_keyframes_mutually (projection.cc:932-1020 / :1028-1118) and the search of
+// fuse::detect_duplication (fuse.cc:40-140): independent best key point per landmark, no blocking, no chi-square gate.
+//   signed_level != 0: detect_duplication's `const int pred_scale_level`; thr: 100 (mutual) / 50 (detect_duplication)
+void oracle_project_best(const double* grid6, const KeyPoint* kps, const uint8_t* desc, int n, const float* scale_factors,
+                         const uint8_t* valid, const double* reproj_d, const unsigned* pred_level, const uint8_t* ldesc, int m,
+                         float margin, unsigned thr, int signed_level, int* best_idx_out) {
+    Grid g{(float)grid6[0], (float)grid6[1], grid6[2], grid6[3], (int)grid6[4], (int)grid6[5]};
+    Features f{n, kps, desc, nullptr, {}};
+    assign_to_grid(g, f);
+    for (int l = 0; l < m; ++l) {
+        best_idx_out[l] = -1;
+        if (!valid[l]) continue;
+        const unsigned pred = pred_level[l];
+        const auto cand = keypoints_in_cell(g, f, (float)reproj_d[2 * l], (float)reproj_d[2 * l + 1], margin * scale_factors[pred], -1, -1);
+        if (cand.empty()) continue;
+        unsigned best = MAX_HAMMING_DIST;
+        int bi = -1;
+        for (unsigned idx : cand) {
+            if (signed_level) {
+                const int scale_level = kps[idx].octave, p = (int)pred;
+                if (scale_level < p - 1 || p < scale_level) continue;
+            } else {
+                const unsigned scale_level = static_cast<unsigned>(kps[idx].octave);
+                if (scale_level < pred - 1 || pred < scale_level) continue;
+            }
+            const unsigned d = hamming32(ldesc + 32 * (size_t)l, desc + 32 * (size_t)idx);
+            if (d < best) { best = d; bi = (int)idx; }
+        }
+        if (thr < best) continue;
+        best_idx_out[l] = bi;
+    }
+}
+
+// the cross check at the end of match_keyframes_mutually (projection.cc:1124-1139): pairs (idx_1, idx_2) that chose each other
+unsigned oracle_cross_check(const int* idx2_of_1, int n1, const int* idx1_of_2, int* matched_2_in_1) {
+    unsigned num = 0;
+    for (int i = 0; i < n1; ++i) {
+        matched_2_in_1[i] = -1;
+        const int i2 = idx2_of_1[i];
+        if (i2 < 0) continue;
+        if (idx1_of_2[i2] == i) { matched_2_in_1[i] = i2; ++num; }
+    }
+    return num;
+}
+
+// fuse::replace_duplication_line (fuse.cc:335-505), the search part.
+void oracle_fuse_search_line(const KeyLineRec* kl, const uint8_t* lbd, int n, const float* scale_factors_lsd, const float* inv_level_sigma_sq_lsd,
+                             const uint8_t* valid, const double* sp_d, const double* ep_d, const unsigned* pred_level, const uint8_t* ldesc,
+                             int m, float margin, int* best_idx_out) {
+    for (int l = 0; l < m; ++l) {
+        best_idx_out[l] = -1;
+        if (!valid[l]) continue;
+        const unsigned pred = pred_level[l];
+        const auto cand = keylines_in_cell(kl, n, (float)sp_d[2 * l], (float)sp_d[2 * l + 1], (float)ep_d[2 * l], (float)ep_d[2 * l + 1],
+                                           margin * scale_factors_lsd[pred], -1, -1);
+        if (cand.empty()) continue;
+        unsigned best = MAX_HAMMING_DIST;
+        int bi = -1;
+        for (unsigned idx : cand) {
+            const KeyLineRec& k = kl[idx];
+            const unsigned scale_level = static_cast<unsigned>(k.octave);
+            // proj_line = (sp, 1) x (ep, 1) in f64
+            const double x1 = sp_d[2 * l], y1 = sp_d[2 * l + 1], x2 = ep_d[2 * l], y2 = ep_d[2 * l + 1];
+            const double p0 = y1 * 1.0 - 1.0 * y2, p1 = 1.0 * x2 - x1 * 1.0, p2 = x1 * y2 - y1 * x2;
+            const double e_sp = (k.startPointX * p0 + k.startPointY * p1 + p2) / std::sqrt(p0 * p0 + p1 * p1);
+            const double e_ep = (k.endPointX * p0 + k.endPointY * p1 + p2) / std::sqrt(p0 * p0 + p1 * p1);
+            constexpr float chi_sq_2D = 5.99146;
+            if (chi_sq_2D < (e_sp * e_sp + e_ep * e_ep) * inv_level_sigma_sq_lsd[scale_level]) continue;
+            const unsigned d = hamming32(ldesc + 32 * (size_t)l, lbd + 32 * (size_t)idx);
+            if (d < best) { best = d; bi = (int)idx; }
+        }
+        if (HAMMING_DIST_THR_LOW < best) continue;
+        best_idx_out[l] = bi;
+    }
+}
+
+// robust::match_for_triangulation (robust.cc:43-216) + check_epipolar_constraint (:387-405), array form.
+//   Key frame 1 features listed in BoW node order (q_*), key frame 2 features by index (t_*), node ids as in
+//   oracle_match_bow.  q_has_lm / t_has_lm: a landmark is attached (skipped); x_right >= 0 marks stereo key points.
+//   E_12 row-major; epipole = bearing of camera centre 1 in key frame 2.  The f64 products are evaluated left to
+//   right without contraction (this file is built with -ffp-contract=off).
+//   out: match_2_of_q[m] (idx_2 or -1) per listed key frame 1 feature; returns num_matches.
+unsigned oracle_match_for_triangulation(const uint8_t* q_desc, const float* q_angle, const int* q_node, const uint8_t* q_has_lm,
+                                        const float* q_x_right, const int* q_octave, const double* q_bearing, int m,
+                                        const uint8_t* t_desc, const float* t_angle, const int* t_node, const uint8_t* t_has_lm,
+                                        const float* t_x_right, const double* t_bearing, int n, const float* scale_factors,
+                                        const double* E_12, const double* epipole, int check_orientation, int* match_2_of_q) {
+    std::vector<uint8_t> matched2(n, 0);
+    for (int q = 0; q < m; ++q) match_2_of_q[q] = -1;
+    unsigned num_matches = 0;
+    AngleChecker ac;
+    for (int q = 0; q < m; ++q) {
+        if (q_has_lm[q]) continue;
+        const bool stereo1 = 0 <= q_x_right[q];
+        const double* b1 = q_bearing + 3 * (size_t)q;
+        unsigned best = HAMMING_DIST_THR_LOW;
+        int best_i2 = -1;
+        for (int t = 0; t < n; ++t) {   // keyfrm_2_indices of the same node, ascending
+            if (t_node[t] != q_node[q]) continue;
+            if (t_has_lm[t]) continue;
+            if (matched2[t]) continue;
+            const bool stereo2 = 0 <= t_x_right[t];
+            const double* b2 = t_bearing + 3 * (size_t)t;
+            const unsigned d = hamming32(q_desc + 32 * (size_t)q, t_desc + 32 * (size_t)t);
+            if (HAMMING_DIST_THR_LOW < d || best < d) continue;
+            if (!stereo1 && !stereo2) {
+                const double cos_dist = epipole[0] * b2[0] + epipole[1] * b2[1] + epipole[2] * b2[2];
+                constexpr double cos_dist_thr = 0.99862953475;
+                if (cos_dist_thr < cos_dist) continue;
+            }
+            // check_epipolar_constraint
+            const double n0 = E_12[0] * b2[0] + E_12[1] * b2[1] + E_12[2] * b2[2];
+            const double n1 = E_12[3] * b2[0] + E_12[4] * b2[1] + E_12[5] * b2[2];
+            const double n2 = E_12[6] * b2[0] + E_12[7] * b2[1] + E_12[8] * b2[2];
+            const double cos_residual = (n0 * b1[0] + n1 * b1[1] + n2 * b1[2]) / std::sqrt(n0 * n0 + n1 * n1 + n2 * n2);
+            const double residual_rad = M_PI / 2.0 - std::abs(std::acos(cos_residual));
+            constexpr double residual_rad_thr = 0.2 * M_PI / 180.0;
+            if (residual_rad < residual_rad_thr * scale_factors[q_octave[q]]) { best_i2 = t; best = d; }
+        }
+        if (best_i2 < 0) continue;
+        matched2[best_i2] = 1;
+        match_2_of_q[q] = best_i2;
+        ++num_matches;
+        if (check_orientation) ac.append(q_angle[q] - t_angle[best_i2], q);
+    }
+    if (check_orientation)
+        for (int bad : ac.collect(false)) { match_2_of_q[bad] = -1; --num_matches; }
+    return num_matches;
+}
+
+}  // extern "C"

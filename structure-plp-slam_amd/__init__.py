@@ -377,10 +377,13 @@ class match_args_c(C.Structure):
                 ("t_kl", _VP), ("t_kp_octave", _VP), ("t_x_right2", _VP), ("q_reproj2", _VP), ("q_x_right2", _VP),
                 ("is_rgbd", C.c_int32), ("num_levels_lsd", C.c_int32),
                 ("q_group", _VP), ("t_group", _VP), ("q_reproj_d", _VP), ("inv_level_sigma_sq", _VP), ("out_query_best", _VP),
+                ("hamm_dist_thr", C.c_int32), ("level_window", C.c_int32), ("flags", C.c_int32),
+                ("q_reproj2_d", _VP), ("q_bearing", _VP), ("t_bearing", _VP), ("epipolar", _VP),
                 ("out_match", _VP), ("out_num", _VP)]
 
 
-MODE_LANDMARKS, MODE_LAST_FRAME, MODE_BRUTE_FORCE, MODE_LANDMARKS_LINE, MODE_LAST_FRAME_LINE, MODE_BOW, MODE_FUSE = 0, 1, 2, 3, 4, 5, 6
+MODE_LANDMARKS, MODE_LAST_FRAME, MODE_BRUTE_FORCE, MODE_LANDMARKS_LINE, MODE_LAST_FRAME_LINE, MODE_BOW, MODE_FUSE, MODE_FUSE_LINE, MODE_TRIANGULATION = 0, 1, 2, 3, 4, 5, 6, 7, 8
+FLAG_NO_CHI2, FLAG_SIGNED_LEVEL, FLAG_UNSIGNED_LEVEL = 1, 2, 4
 
 
 def make_grid(cols_px, rows_px, grid_cols=64, grid_rows=48, min_x=0.0, min_y=0.0):
@@ -412,7 +415,7 @@ class matcher:
         a = match_args_c()
         a.mode, a.B, a.n_cap, a.m_cap = mode, B, n_cap, m_cap
         for k, v in fields.items():
-            if k in ("is_rgbd", "num_levels_lsd"):
+            if k in ("is_rgbd", "num_levels_lsd", "hamm_dist_thr", "level_window", "flags"):
                 setattr(a, k, int(v))
             elif k == "inv_level_sigma_sq":
                 arr = np.ascontiguousarray(v, np.float32)
@@ -437,7 +440,7 @@ class matcher:
         out_match = np.zeros((B, n_cap), np.int32)
         out_num = np.zeros(B, np.int32)
         a = self._args(mode, B, n_cap, m_cap, fields, margin, direction, scale_factors, grid, out_match, out_num, lambda v: v.ctypes.data)
-        if mode == MODE_FUSE:
+        if mode in (MODE_FUSE, MODE_FUSE_LINE):
             out_q = np.full((B, m_cap), -1, np.int32)
             a.out_query_best = out_q.ctypes.data
             _check(lib().plp_match_host(self._h, C.byref(a)))

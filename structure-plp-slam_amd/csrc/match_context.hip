@@ -26,7 +26,7 @@ plp_status check_args(const plp_match_args* a) {
     if (a->B <= 0 || a->n_cap <= 0 || a->m_cap <= 0) return set_error(PLP_ERR_INVALID_ARG, "B, n_cap, m_cap must be positive");
     if (a->n_cap > 8000) return set_error(PLP_ERR_UNSUPPORTED, "more than 8000 key points per frame");
     if (!a->t_desc || !a->q_desc) return set_error(PLP_ERR_INVALID_ARG, "descriptor arrays are required");
-    if (a->mode != PLP_MATCH_MODE_FUSE && (!a->out_match || !a->out_num)) return set_error(PLP_ERR_INVALID_ARG, "output arrays are required");
+    if (a->mode != PLP_MATCH_MODE_FUSE && a->mode != PLP_MATCH_MODE_FUSE_LINE && (!a->out_match || !a->out_num)) return set_error(PLP_ERR_INVALID_ARG, "output arrays are required");
     if (a->mode == PLP_MATCH_MODE_BRUTE_FORCE) {
         if (a->check_orientation && (!a->t_angle || !a->q_angle)) return set_error(PLP_ERR_INVALID_ARG, "check_orientation needs t_angle and q_angle");
     } else if (a->mode == PLP_MATCH_MODE_LANDMARKS || a->mode == PLP_MATCH_MODE_LAST_FRAME) {
@@ -45,7 +45,15 @@ plp_status check_args(const plp_match_args* a) {
         if (!a->t_kps || !a->q_reproj_d || !a->q_level || !a->scale_factors || !a->inv_level_sigma_sq || !a->out_query_best) return set_error(PLP_ERR_INVALID_ARG, "t_kps, q_reproj_d, q_level, scale_factors, inv_level_sigma_sq, out_query_best are required");
         if (a->num_levels <= 0 || a->num_levels > 16) return set_error(PLP_ERR_INVALID_ARG, "num_levels must be in [1,16]");
         if (a->grid.cols <= 0 || a->grid.rows <= 0 || a->grid.cols * a->grid.rows > 4096) return set_error(PLP_ERR_INVALID_ARG, "grid must have 1..4096 cells");
+    } else if (a->mode == PLP_MATCH_MODE_FUSE_LINE) {
+        if (!a->t_kl || !a->q_reproj_d || !a->q_reproj2_d || !a->q_level || !a->scale_factors || !a->inv_level_sigma_sq || !a->out_query_best) return set_error(PLP_ERR_INVALID_ARG, "t_kl, q_reproj_d, q_reproj2_d, q_level, scale_factors, inv_level_sigma_sq, out_query_best are required");
+        if (a->num_levels <= 0 || a->num_levels > 16) return set_error(PLP_ERR_INVALID_ARG, "num_levels must be in [1,16]");
+    } else if (a->mode == PLP_MATCH_MODE_TRIANGULATION) {
+        if (!a->q_group || !a->t_group || !a->q_bearing || !a->t_bearing || !a->epipolar || !a->q_level || !a->scale_factors) return set_error(PLP_ERR_INVALID_ARG, "q_group, t_group, q_bearing, t_bearing, epipolar, q_level, scale_factors are required");
+        if (a->num_levels <= 0 || a->num_levels > 16) return set_error(PLP_ERR_INVALID_ARG, "num_levels must be in [1,16]");
+        if (a->check_orientation && (!a->t_angle || !a->q_angle)) return set_error(PLP_ERR_INVALID_ARG, "check_orientation needs t_angle and q_angle");
     } else return set_error(PLP_ERR_INVALID_ARG, "unknown mode");
+    if (a->hamm_dist_thr < 0 || a->hamm_dist_thr > 256 || a->level_window < 0 || a->level_window > 2) return set_error(PLP_ERR_INVALID_ARG, "hamm_dist_thr / level_window out of range");
     return PLP_OK;
 }
 
@@ -65,6 +73,8 @@ plp_status run_device(plp_matcher* c, const plp_match_args* a, hipStream_t st) {
     P.mode = a->mode; P.n_cap = a->n_cap; P.m_cap = a->m_cap;
     P.t_kps = (a->mode == PLP_MATCH_MODE_LANDMARKS || a->mode == PLP_MATCH_MODE_LAST_FRAME || a->mode == PLP_MATCH_MODE_FUSE) ? a->t_kps : nullptr;
     P.q_group = a->q_group; P.t_group = a->t_group; P.q_reproj_d = a->q_reproj_d; P.out_query_best = a->out_query_best;
+    P.hamm_dist_thr = a->hamm_dist_thr; P.level_window = a->level_window; P.flags = a->flags;
+    P.q_reproj2_d = a->q_reproj2_d; P.q_bearing = a->q_bearing; P.t_bearing = a->t_bearing; P.epipolar = a->epipolar;
     for (int i = 0; i < 16; ++i) P.inv_level_sigma_sq[i] = (a->inv_level_sigma_sq && i < a->num_levels) ? a->inv_level_sigma_sq[i] : 1.0f;
     P.t_desc = a->t_desc; P.t_x_right = a->t_x_right; P.t_occupied = a->t_occupied; P.t_angle = a->t_angle; P.t_counts = a->t_counts;
     P.q_valid = a->q_valid; P.q_reproj = a->q_reproj; P.q_x_right = a->q_x_right; P.q_level = a->q_level; P.q_angle = a->q_angle;
@@ -145,6 +155,9 @@ plp_status plp_match_host(plp_matcher* c, const plp_match_args* a) {
     const size_t o_qx2 = add(a->q_x_right2, a->q_x_right2 ? qn * 4 : 0);
     const size_t o_qg = add(a->q_group, a->q_group ? qn * 4 : 0), o_tg = add(a->t_group, a->t_group ? tn * 4 : 0);
     const size_t o_qrd = add(a->q_reproj_d, a->q_reproj_d ? qn * 16 : 0);
+    const size_t o_qrd2 = add(a->q_reproj2_d, a->q_reproj2_d ? qn * 16 : 0);
+    const size_t o_qb = add(a->q_bearing, a->q_bearing ? qn * 24 : 0), o_tb = add(a->t_bearing, a->t_bearing ? tn * 24 : 0);
+    const size_t o_ep = add(a->epipolar, a->epipolar ? (size_t)a->B * 96 : 0);
     const size_t o_oq = off; off += (qn * 4 + 255) / 256 * 256;
     const size_t o_om = off; off += (tn * 4 + 255) / 256 * 256;
     const size_t o_on = off; off += ((size_t)a->B * 4 + 255) / 256 * 256;
@@ -166,10 +179,12 @@ plp_status plp_match_host(plp_matcher* c, const plp_match_args* a) {
     d.q_x_right2 = (const float*)dp(a->q_x_right2, o_qx2);
     d.q_group = (const int32_t*)dp(a->q_group, o_qg); d.t_group = (const int32_t*)dp(a->t_group, o_tg);
     d.q_reproj_d = (const double*)dp(a->q_reproj_d, o_qrd);
+    d.q_reproj2_d = (const double*)dp(a->q_reproj2_d, o_qrd2); d.q_bearing = (const double*)dp(a->q_bearing, o_qb);
+    d.t_bearing = (const double*)dp(a->t_bearing, o_tb); d.epipolar = (const double*)dp(a->epipolar, o_ep);
     d.out_query_best = a->out_query_best ? (int32_t*)(base + o_oq) : nullptr;
     d.out_match = (int32_t*)(base + o_om); d.out_num = (int32_t*)(base + o_on);
     PLP_TRY(run_device(c, &d, st));
-    if (a->mode == PLP_MATCH_MODE_FUSE) {
+    if (a->mode == PLP_MATCH_MODE_FUSE || a->mode == PLP_MATCH_MODE_FUSE_LINE) {
         PLP_HIP(hipMemcpyAsync(a->out_query_best, base + o_oq, qn * 4, hipMemcpyDeviceToHost, st));
         PLP_HIP(hipStreamSynchronize(st));
         return PLP_OK;

@@ -32,6 +32,9 @@ struct MatchProblem {
     const double* q_reproj_d;        // FUSE mode: f64 reprojection
     float inv_level_sigma_sq[16];    // FUSE mode
     int32_t* out_query_best;         // FUSE mode: B x m_cap
+    int hamm_dist_thr, level_window, flags;
+    const double* q_reproj2_d;       // FUSE_LINE
+    const double* q_bearing; const double* t_bearing; const double* epipolar;   // TRIANGULATION
     // queries = landmarks / last-frame key points / key-frame key points (B x m_cap), reference order
     const uint8_t* q_valid;          // NULL: all valid
     const float* q_reproj;           // x, y

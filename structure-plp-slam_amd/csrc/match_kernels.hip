@@ -47,9 +47,14 @@ struct QueryCtx {
     double rdx, rdy;           // FUSE: f64 reprojection
     int group;                 // BOW: node id of the query feature
     unsigned pred;             // FUSE: predicted scale level (unsigned, as the reference)
+    double g0, g1, g2, gden;   // FUSE_LINE: the projected line from the f64 reprojections (chi-square gate)
+    double b1x, b1y, b1z, thr; // TRIANGULATION: bearing of the query, residual threshold
+    bool stereo;
     bool windowed, empty, line;
 };
-__device__ __forceinline__ bool is_line_mode(int mode) { return mode == PLP_MATCH_MODE_LANDMARKS_LINE || mode == PLP_MATCH_MODE_LAST_FRAME_LINE; }
+__device__ __forceinline__ bool is_line_mode(int mode) { return mode == PLP_MATCH_MODE_LANDMARKS_LINE || mode == PLP_MATCH_MODE_LAST_FRAME_LINE || mode == PLP_MATCH_MODE_FUSE_LINE; }
+__device__ __forceinline__ bool is_group_mode(int mode) { return mode == PLP_MATCH_MODE_BOW || mode == PLP_MATCH_MODE_TRIANGULATION; }
+__device__ __forceinline__ bool is_last_frame_mode(int mode) { return mode == PLP_MATCH_MODE_LAST_FRAME || mode == PLP_MATCH_MODE_LAST_FRAME_LINE; }
 
 __device__ __forceinline__ QueryCtx make_query(const MatchProblem& P, int q, int b) {
     const size_t qoff = (size_t)b * P.m_cap;
@@ -57,20 +62,37 @@ __device__ __forceinline__ QueryCtx make_query(const MatchProblem& P, int q, int
     const float* q_xr = P.q_x_right ? P.q_x_right + qoff : nullptr;
     const int32_t* q_level = P.q_level ? P.q_level + qoff : nullptr;
     QueryCtx c{};
-    c.windowed = P.mode != PLP_MATCH_MODE_BRUTE_FORCE && P.mode != PLP_MATCH_MODE_BOW;
+    c.windowed = P.mode != PLP_MATCH_MODE_BRUTE_FORCE && !is_group_mode(P.mode);
     c.line = is_line_mode(P.mode);
-    if (P.mode == PLP_MATCH_MODE_BOW) c.group = P.q_group[qoff + q];
+    if (is_group_mode(P.mode)) c.group = P.q_group[qoff + q];
+    if (P.mode == PLP_MATCH_MODE_TRIANGULATION) {
+        const double* bq = P.q_bearing + (qoff + q) * 3;
+        c.b1x = bq[0]; c.b1y = bq[1]; c.b1z = bq[2];
+        c.stereo = q_xr && 0 <= q_xr[q];
+        // residual_rad_thr * bearing_1_scale_factor (robust.cc:399-404)
+        c.thr = (0.2 * 3.14159265358979323846 / 180.0) * (double)P.scale_factors[q_level[q] & 15];
+    }
     if (!c.windowed) return c;
     const int lvl = q_level[q];
     if (c.line) {   // data::get_keylines_in_cell (common.cc:315-363) + the level windows of projection.cc:138-144, :429-450
-        const float* r2 = P.q_reproj2 + qoff * 2;
         c.mg = __fmul_rn(P.margin, P.scale_factors[lvl]);
-        const double x1 = reproj[2 * q], y1 = reproj[2 * q + 1], x2 = r2[2 * q], y2 = r2[2 * q + 1];
+        double x1, y1, x2, y2;
+        if (P.mode == PLP_MATCH_MODE_FUSE_LINE) {   // the f64 reprojections are narrowed to float by the call (fuse.cc:420-422)
+            const double* a = P.q_reproj_d + (qoff + q) * 2; const double* e = P.q_reproj2_d + (qoff + q) * 2;
+            x1 = (float)a[0]; y1 = (float)a[1]; x2 = (float)e[0]; y2 = (float)e[1];
+            c.g0 = a[1] * 1.0 - 1.0 * e[1]; c.g1 = 1.0 * e[0] - a[0] * 1.0; c.g2 = a[0] * e[1] - a[1] * e[0];
+            c.gden = sqrt(c.g0 * c.g0 + c.g1 * c.g1);
+        } else {
+            const float* r2 = P.q_reproj2 + qoff * 2;
+            x1 = reproj[2 * q]; y1 = reproj[2 * q + 1]; x2 = r2[2 * q]; y2 = r2[2 * q + 1];
+        }
         c.l0 = y1 * 1.0 - 1.0 * y2; c.l1 = 1.0 * x2 - x1 * 1.0; c.l2 = x1 * y2 - y1 * x2;
         c.lden = sqrt(c.l0 * c.l0 + c.l1 * c.l1);
         c.xr = q_xr ? q_xr[q] : -1.f;
         c.xr2 = P.q_x_right2 ? P.q_x_right2[qoff + q] : -1.f;
-        if (P.mode == PLP_MATCH_MODE_LANDMARKS_LINE) { c.min_level = lvl - 1; c.max_level = lvl; }
+        if (P.mode == PLP_MATCH_MODE_FUSE_LINE) { c.min_level = -1; c.max_level = -1; }
+        else if (P.mode == PLP_MATCH_MODE_LANDMARKS_LINE || P.level_window == 1) { c.min_level = lvl - 1; c.max_level = lvl; }
+        else if (P.level_window == 2) { c.min_level = lvl - 1; c.max_level = lvl + 1; }
         else if (P.direction == 1) { c.min_level = lvl; c.max_level = P.num_levels_lsd; }
         else if (P.direction == 2) { c.min_level = 0; c.max_level = lvl + 1; }
         else { c.min_level = lvl - 1; c.max_level = lvl + 1; }
@@ -85,8 +107,9 @@ __device__ __forceinline__ QueryCtx make_query(const MatchProblem& P, int q, int
     } else { c.rx = reproj[2 * q]; c.ry = reproj[2 * q + 1]; }
     c.mg = __fmul_rn(P.margin, P.scale_factors[lvl]);
     c.xr = q_xr ? q_xr[q] : -1.f;
-    if (P.mode == PLP_MATCH_MODE_LANDMARKS) { c.min_level = lvl - 1; c.max_level = lvl; }
+    if (P.mode == PLP_MATCH_MODE_LANDMARKS || (P.mode == PLP_MATCH_MODE_LAST_FRAME && P.level_window == 1)) { c.min_level = lvl - 1; c.max_level = lvl; }
     else if (P.mode == PLP_MATCH_MODE_FUSE) { c.min_level = -1; c.max_level = -1; }
+    else if (P.level_window == 2) { c.min_level = lvl - 1; c.max_level = lvl + 1; }
     else if (P.direction == 1) { c.min_level = lvl; c.max_level = P.num_levels - 1; }
     else if (P.direction == 2) { c.min_level = 0; c.max_level = lvl; }
     else { c.min_level = lvl - 1; c.max_level = lvl + 1; }
@@ -97,6 +120,8 @@ __device__ __forceinline__ QueryCtx make_query(const MatchProblem& P, int q, int
     c.min_cy = max(0, floor_d((double)__fsub_rn(__fsub_rn(c.ry, P.grid_min_y), c.mg) * P.inv_cell_h));
     c.max_cy = min(P.grid_rows - 1, ceil_d((double)__fadd_rn(__fsub_rn(c.ry, P.grid_min_y), c.mg) * P.inv_cell_h));
     c.empty = P.grid_cols <= c.min_cx || c.max_cx < 0 || P.grid_rows <= c.min_cy || c.max_cy < 0;
+    // match_by_Sim3_transform tests `scale_level < pred - 1 || pred < scale_level` on unsigned values (projection.cc:862)
+    if (P.mode == PLP_MATCH_MODE_LAST_FRAME && (P.flags & PLP_MATCH_FLAG_UNSIGNED_LEVEL) && lvl == 0) c.empty = true;
     return c;
 }
 
@@ -104,16 +129,42 @@ __device__ __forceinline__ unsigned long long candidate_key(const MatchProblem& 
                                                            const uint8_t* t_desc, const float* t_xr, const uint8_t* t_occ,
                                                            const uint4& q0, const uint4& q1) {
     unsigned order = (unsigned)t, oct = 0;
-    if (P.mode == PLP_MATCH_MODE_BOW) {
+    if (is_group_mode(P.mode)) {
         const size_t tb = (size_t)(t_desc - P.t_desc) / 32;
         if (P.t_group[tb + t] != c.group) return ~0ull;
         if (t_occ && t_occ[t]) return ~0ull;
+        if (P.mode == PLP_MATCH_MODE_TRIANGULATION) {
+            const uint4* d = reinterpret_cast<const uint4*>(t_desc + 32 * (size_t)t);
+            const unsigned dist = hamming256(q0, q1, d[0], d[1]);
+            if (50u < dist) return ~0ull;                                       // HAMMING_DIST_THR_LOW (robust.cc:124)
+            const double* b2 = P.t_bearing + (tb + t) * 3;
+            const double* E = P.epipolar + (tb / P.n_cap) * 12;
+            const bool stereo2 = t_xr && 0 <= t_xr[t];
+            if (!c.stereo && !stereo2) {                                        // not near the epipole (:129-141)
+                const double cos_dist = E[9] * b2[0] + E[10] * b2[1] + E[11] * b2[2];
+                if (0.99862953475 < cos_dist) return ~0ull;
+            }
+            // check_epipolar_constraint (:387-405)
+            const double n0 = E[0] * b2[0] + E[1] * b2[1] + E[2] * b2[2], n1 = E[3] * b2[0] + E[4] * b2[1] + E[5] * b2[2],
+                         n2 = E[6] * b2[0] + E[7] * b2[1] + E[8] * b2[2];
+            const double cos_residual = (n0 * c.b1x + n1 * c.b1y + n2 * c.b1z) / sqrt(n0 * n0 + n1 * n1 + n2 * n2);
+            const double residual_rad = 3.14159265358979323846 / 2.0 - fabs(acos(cos_residual));
+            if (!(residual_rad < c.thr)) return ~0ull;
+            return ((unsigned long long)dist << 32) | ((unsigned long long)(0xffffu - (unsigned)t) << 4);   // ties: the later candidate
+        }
     } else if (c.line) {
         const size_t tb = (size_t)(t_desc - P.t_desc) / 32;   // per-problem target offset
         const plp_keyline kl = P.t_kl[tb + t];
         const float dsp = (float)(((double)kl.startPointX * c.l0 + (double)kl.startPointY * c.l1 + c.l2) / c.lden);
         const float dep = (float)(((double)kl.endPointX * c.l0 + (double)kl.endPointY * c.l1 + c.l2) / c.lden);
         if (fabsf(dsp) > c.mg || fabsf(dep) > c.mg) return ~0ull;
+        if (P.mode == PLP_MATCH_MODE_FUSE_LINE) {   // fuse.cc:440-451, f64
+            const double e_sp = ((double)kl.startPointX * c.g0 + (double)kl.startPointY * c.g1 + c.g2) / c.gden;
+            const double e_ep = ((double)kl.endPointX * c.g0 + (double)kl.endPointY * c.g1 + c.g2) / c.gden;
+            if ((double)5.99146f < (e_sp * e_sp + e_ep * e_ep) * (double)P.inv_level_sigma_sq[(unsigned)kl.octave & 15]) return ~0ull;
+            const uint4* d = reinterpret_cast<const uint4*>(t_desc + 32 * (size_t)t);
+            return ((unsigned long long)hamming256(q0, q1, d[0], d[1]) << 32) | ((unsigned long long)(unsigned)t << 4);
+        }
         const bool check_level = (0 < c.min_level) || (0 <= c.max_level);
         if (check_level) {
             if (kl.octave < c.min_level) return ~0ull;
@@ -139,7 +190,9 @@ __device__ __forceinline__ unsigned long long candidate_key(const MatchProblem& 
         if (!(fabsf(__fsub_rn(k.x, c.rx)) < c.mg && fabsf(__fsub_rn(k.y, c.ry)) < c.mg)) return ~0ull;
         if (P.mode == PLP_MATCH_MODE_FUSE) {   // fuse.cc:230-262: octave window in unsigned arithmetic + chi-square gates in f64
             const unsigned sl = (unsigned)k.octave;
-            if (sl < c.pred - 1u || c.pred < sl) return ~0ull;
+            if (P.flags & PLP_MATCH_FLAG_SIGNED_LEVEL) { if (k.octave < (int)c.pred - 1 || (int)c.pred < k.octave) return ~0ull; }
+            else if (sl < c.pred - 1u || c.pred < sl) return ~0ull;
+            if (!(P.flags & PLP_MATCH_FLAG_NO_CHI2)) {
             const double e_x = c.rdx - (double)k.x, e_y = c.rdy - (double)k.y;
             const float xr = t_xr ? t_xr[t] : -1.f;
             if (xr >= 0) {
@@ -149,6 +202,7 @@ __device__ __forceinline__ unsigned long long candidate_key(const MatchProblem& 
             } else {
                 const double err = e_x * e_x + e_y * e_y;
                 if ((double)5.99146f < err * (double)P.inv_level_sigma_sq[sl & 15]) return ~0ull;
+            }
             }
         } else {
         if (t_occ && t_occ[t]) return ~0ull;                                                 // already holds an observed landmark
@@ -357,7 +411,8 @@ __device__ __forceinline__ bool accept(const MatchProblem& P, unsigned best, int
         if (best_lvl == second_lvl && (float)best > __fmul_rn(P.lowe_ratio, (float)second)) return false;
         return true;
     }
-    if (P.mode == PLP_MATCH_MODE_LAST_FRAME || P.mode == PLP_MATCH_MODE_LAST_FRAME_LINE) return best <= 100u;
+    if (is_last_frame_mode(P.mode)) return best <= (P.hamm_dist_thr > 0 ? (unsigned)P.hamm_dist_thr : 100u);
+    if (P.mode == PLP_MATCH_MODE_TRIANGULATION) return true;                 // every gate is part of the candidate test
     if (50u < best) return false;                                            // brute force: HAMMING_DIST_THR_LOW
     if (__fmul_rn(P.lowe_ratio, (float)second) < (float)best) return false;
     return true;
@@ -387,8 +442,9 @@ __global__ __launch_bounds__(256) void k_match_resolve(MatchProblem P) {
     __syncthreads();
 
     int32_t* full_list = P.full_list + (size_t)b * P.m_cap;   // queries whose truncated best-K list ran dry
-    const int need = (P.mode == PLP_MATCH_MODE_LAST_FRAME || P.mode == PLP_MATCH_MODE_LAST_FRAME_LINE) ? 1 : 2;   // the last-frame matcher has no second-best test
-    const bool blocks_always = !has_obs || P.mode == PLP_MATCH_MODE_BRUTE_FORCE || P.mode == PLP_MATCH_MODE_BOW;
+    const int need = (is_last_frame_mode(P.mode) || P.mode == PLP_MATCH_MODE_TRIANGULATION) ? 1 : 2;   // the last-frame matcher has no second-best test
+    const bool blocks_always = !has_obs || P.mode == PLP_MATCH_MODE_BRUTE_FORCE || is_group_mode(P.mode);
+    const unsigned t_flip = P.mode == PLP_MATCH_MODE_TRIANGULATION ? 0xffffu : 0u;   // that mode orders equal distances by DESCENDING index
     const bool use_sorted = P.sorted_valid != 0;
     const StagedTarget* sorted = P.sorted + (size_t)b * P.n_cap;
     const float* sorted_xr = P.sorted_xr + (size_t)b * P.n_cap;
@@ -429,7 +485,7 @@ __global__ __launch_bounds__(256) void k_match_resolve(MatchProblem P) {
 #pragma unroll
                     for (int e = 0; e < kMatchK; ++e) {
                         if (e >= have || found >= need) continue;
-                        const int t = (int)(e8[e] & 0xffff);
+                        const int t = (int)((e8[e] & 0xffff) ^ t_flip);
                         if (taken(t, q, chunk_start)) continue;
                         if (found == 0) { best = e8[e] >> 20; best_lvl = (int)((e8[e] >> 16) & 15); best_t = t; }
                         else { second = e8[e] >> 20; second_lvl = (int)((e8[e] >> 16) & 15); }
@@ -488,7 +544,7 @@ __global__ __launch_bounds__(256) void k_match_resolve(MatchProblem P) {
                     if (g0 != ~0ull) {
                         const unsigned second = g1 != ~0ull ? (unsigned)(g1 >> 32) : 256u;
                         const int second_lvl = g1 != ~0ull ? (int)(g1 & 15) : -1;
-                        if (accept(P, (unsigned)(g0 >> 32), (int)(g0 & 15), second, second_lvl)) nc = (int)((g0 >> 4) & 0xffff);
+                        if (accept(P, (unsigned)(g0 >> 32), (int)(g0 & 15), second, second_lvl)) nc = (int)(((g0 >> 4) & 0xffff) ^ t_flip);
                     }
                     s_claim_tmp[fq - chunk_start] = nc;
                 }
@@ -512,12 +568,12 @@ __global__ __launch_bounds__(256) void k_match_resolve(MatchProblem P) {
     if (tid == 0) s_num = 0;
     for (int i = tid; i < 32; i += 256) { s_hist[i] = 0; s_valid_bin[i] = 0; }
     __syncthreads();
-    const bool angle_check = P.check_orientation && (P.mode == PLP_MATCH_MODE_LAST_FRAME || P.mode == PLP_MATCH_MODE_BRUTE_FORCE || P.mode == PLP_MATCH_MODE_BOW);
+    const bool angle_check = P.check_orientation && (P.mode == PLP_MATCH_MODE_LAST_FRAME || P.mode == PLP_MATCH_MODE_BRUTE_FORCE || is_group_mode(P.mode));
     const float* q_angle = P.q_angle ? P.q_angle + (size_t)b * P.m_cap : nullptr;
     const float* t_angle = P.t_angle ? P.t_angle + (size_t)b * P.n_cap : nullptr;
     auto bin_of = [&](int q, int t) -> int {
         const float ta = kps ? kps[t].angle : t_angle[t];
-        float delta = (P.mode == PLP_MATCH_MODE_LAST_FRAME || P.mode == PLP_MATCH_MODE_BOW) ? __fsub_rn(q_angle[q], ta) : __fsub_rn(ta, q_angle[q]);
+        float delta = (P.mode == PLP_MATCH_MODE_LAST_FRAME || is_group_mode(P.mode)) ? __fsub_rn(q_angle[q], ta) : __fsub_rn(ta, q_angle[q]);
         if (delta < 0.0) delta = (float)((double)delta + 360.0);
         if (360.0 <= delta) delta = (float)((double)delta - 360.0);
         return __float2int_rn(__fmul_rn(delta, 1.0f / 30));
@@ -605,7 +661,8 @@ __global__ __launch_bounds__(256) void k_match_fuse(MatchProblem P) {
             best = key < best ? key : best;
         }
     best = wave_min_u64(best);
-    if (lane == 0) *out = (best != ~0ull && (unsigned)(best >> 32) <= 50u) ? (int32_t)((best >> 4) & 0xffff) : -1;
+    const unsigned thr = P.hamm_dist_thr > 0 ? (unsigned)P.hamm_dist_thr : 50u;
+    if (lane == 0) *out = (best != ~0ull && (unsigned)(best >> 32) <= thr) ? (int32_t)((best >> 4) & 0xffff) : -1;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -697,12 +754,14 @@ __global__ __launch_bounds__(64) void k_match_area(AreaArgs A) {
 
 void launch_match_area(hipStream_t st, const AreaArgs& A) { hipLaunchKernelGGL(k_match_area, dim3(1), dim3(64), 0, st, A); }
 
+static bool is_line_mode_host(int mode) { return mode == PLP_MATCH_MODE_LANDMARKS_LINE || mode == PLP_MATCH_MODE_LAST_FRAME_LINE || mode == PLP_MATCH_MODE_FUSE_LINE; }
+
 void launch_match(hipStream_t st, const MatchProblem& P, int B) {
-    if (P.mode == PLP_MATCH_MODE_FUSE) { hipLaunchKernelGGL(k_match_fuse, dim3((P.m_cap + 3) / 4, B), dim3(256), 0, st, P); return; }
+    if (P.mode == PLP_MATCH_MODE_FUSE || P.mode == PLP_MATCH_MODE_FUSE_LINE) { hipLaunchKernelGGL(k_match_fuse, dim3((P.m_cap + 3) / 4, B), dim3(256), 0, st, P); return; }
     MatchProblem Q = P;
     Q.sorted_valid = 0;
     const bool windowed = P.mode == PLP_MATCH_MODE_LANDMARKS || P.mode == PLP_MATCH_MODE_LAST_FRAME;
-    const bool line = P.mode == PLP_MATCH_MODE_LANDMARKS_LINE || P.mode == PLP_MATCH_MODE_LAST_FRAME_LINE || P.mode == PLP_MATCH_MODE_BOW;
+    const bool line = is_line_mode_host(P.mode) || P.mode == PLP_MATCH_MODE_BOW || P.mode == PLP_MATCH_MODE_TRIANGULATION;
     const size_t staged = windowed ? (size_t)P.n_cap * (sizeof(StagedTarget) + (P.t_x_right ? 4 : 0)) : (size_t)P.n_cap * 32;
     if (!line && staged <= 64 * 1024 && (!windowed || (P.grid_cols <= 255 && P.grid_rows <= 255))) {
         if (windowed) hipLaunchKernelGGL(k_match_prep, dim3(B), dim3(256), 0, st, P);

@@ -384,3 +384,85 @@ def match_area(g6, kps1, desc1, kps2, desc2, prev_pts, margin, ratio, check_orie
     w = [_c(kps2, KP_DTYPE), _c(desc2, np.uint8)]
     num = lib().oracle_match_area(_p(v[0]), _p(v[1]), _p(v[2]), n1, _p(w[0]), _p(w[1]), n2, _p(pp), int(margin), ratio, int(check_orientation), _p(out))
     return out[:n1].copy(), pp, num
+
+
+def _call(name, args, restype=None):
+    """generic ctypes call: numpy arrays -> pointers, python ints/floats by argtype inference"""
+    fn = getattr(lib(), name)
+    fn.restype = restype
+    conv = []
+    for a in args:
+        if isinstance(a, np.ndarray):
+            conv.append(C.c_void_p(a.ctypes.data))
+        elif isinstance(a, float):
+            conv.append(C.c_float(a))
+        elif isinstance(a, tuple):      # ("u", v): unsigned
+            conv.append(C.c_uint(a[1]))
+        else:
+            conv.append(C.c_int(int(a)))
+    return fn(*conv)
+
+
+def match_frame_and_keyframe(g6, kps, desc, occupied, sf, valid, reproj, pred, langle, ldesc, margin, thr, check):
+    n, m = len(kps), len(pred)
+    out = np.zeros(max(n, 1), np.int32)
+    keep = [_c(g6, np.float64), _c(kps, KP_DTYPE), _c(desc, np.uint8), _c(occupied, np.uint8), _c(sf, np.float32), _c(valid, np.uint8),
+            _c(reproj, np.float32), _c(pred, np.uint32), _c(langle, np.float32), _c(ldesc, np.uint8)]
+    num = _call("oracle_match_frame_and_keyframe", keep[:4] + [n] + keep[4:] + [m, float(margin), ("u", thr), int(check), out], C.c_uint)
+    return out[:n].copy(), num
+
+
+def match_frame_and_keyframe_line(kl, lbd, occupied, sf_lsd, valid, sp, ep, pred, ldesc, margin, thr):
+    n, m = len(kl), len(pred)
+    out = np.zeros(max(n, 1), np.int32)
+    keep = [_c(kl, KL_DTYPE), _c(lbd, np.uint8), _c(occupied, np.uint8), _c(sf_lsd, np.float32), _c(valid, np.uint8), _c(sp, np.float32),
+            _c(ep, np.float32), _c(pred, np.uint32), _c(ldesc, np.uint8)]
+    num = _call("oracle_match_frame_and_keyframe_line", keep[:3] + [n] + keep[3:] + [m, float(margin), ("u", thr), out], C.c_uint)
+    return out[:n].copy(), num
+
+
+def match_by_sim3(g6, kps, desc, occupied, sf, valid, reproj, pred, ldesc, margin):
+    n, m = len(kps), len(pred)
+    out = np.zeros(max(n, 1), np.int32)
+    keep = [_c(g6, np.float64), _c(kps, KP_DTYPE), _c(desc, np.uint8), _c(occupied, np.uint8), _c(sf, np.float32), _c(valid, np.uint8),
+            _c(reproj, np.float32), _c(pred, np.uint32), _c(ldesc, np.uint8)]
+    num = _call("oracle_match_by_sim3", keep[:4] + [n] + keep[4:] + [m, float(margin), out], C.c_uint)
+    return out[:n].copy(), num
+
+
+def project_best(g6, kps, desc, sf, valid, reproj_d, pred, ldesc, margin, thr, signed_level):
+    n, m = len(kps), len(pred)
+    out = np.zeros(max(m, 1), np.int32)
+    keep = [_c(g6, np.float64), _c(kps, KP_DTYPE), _c(desc, np.uint8), _c(sf, np.float32), _c(valid, np.uint8), _c(reproj_d, np.float64),
+            _c(pred, np.uint32), _c(ldesc, np.uint8)]
+    _call("oracle_project_best", keep[:3] + [n] + keep[3:] + [m, float(margin), ("u", thr), int(signed_level), out])
+    return out[:m].copy()
+
+
+def cross_check(idx2_of_1, idx1_of_2):
+    a, b = _c(idx2_of_1, np.int32), _c(idx1_of_2, np.int32)
+    out = np.zeros(max(len(a), 1), np.int32)
+    num = _call("oracle_cross_check", [a, len(a), b, out], C.c_uint)
+    return out[:len(a)].copy(), num
+
+
+def fuse_search_line(kl, lbd, sf_lsd, inv_sigma_lsd, valid, sp_d, ep_d, pred, ldesc, margin):
+    n, m = len(kl), len(pred)
+    out = np.zeros(max(m, 1), np.int32)
+    keep = [_c(kl, KL_DTYPE), _c(lbd, np.uint8), _c(sf_lsd, np.float32), _c(inv_sigma_lsd, np.float32), _c(valid, np.uint8), _c(sp_d, np.float64),
+            _c(ep_d, np.float64), _c(pred, np.uint32), _c(ldesc, np.uint8)]
+    _call("oracle_fuse_search_line", keep[:2] + [n] + keep[2:] + [m, float(margin), out])
+    return out[:m].copy()
+
+
+def match_for_triangulation(q_desc, q_angle, q_node, q_has_lm, q_x_right, q_octave, q_bearing, t_desc, t_angle, t_node, t_has_lm, t_x_right,
+                            t_bearing, sf, E_12, epipole, check):
+    m, n = len(q_desc), len(t_desc)
+    out = np.zeros(max(m, 1), np.int32)
+    a = [_c(q_desc, np.uint8), _c(q_angle, np.float32), _c(q_node, np.int32), _c(q_has_lm, np.uint8), _c(q_x_right, np.float32),
+         _c(q_octave, np.int32), _c(q_bearing, np.float64)]
+    b = [_c(t_desc, np.uint8), _c(t_angle, np.float32), _c(t_node, np.int32), _c(t_has_lm, np.uint8), _c(t_x_right, np.float32),
+         _c(t_bearing, np.float64)]
+    c = [_c(sf, np.float32), _c(E_12, np.float64), _c(epipole, np.float64)]
+    num = _call("oracle_match_for_triangulation", a + [m] + b + [n] + c + [int(check), out], C.c_uint)
+    return out[:m].copy(), num

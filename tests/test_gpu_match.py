@@ -223,3 +223,115 @@ def test_area_matcher(seed):
     want, wpp, wn = O.match_area(O.grid6(grid), t1["t_kps"], t1["t_desc"], t2["t_kps"], t2["t_desc"], prev, 150, 0.9, True)
     got, gpp, gn = plp.matcher(0.9, True).match_in_consistent_area(t1["t_kps"], t1["t_desc"], t2["t_kps"], t2["t_desc"], prev, 150, grid)
     assert gn == wn and np.array_equal(got, want) and np.array_equal(gpp, wpp)
+
+
+# ---------------------------------------------------------------------------------------- relocalisation / loop closing / mapping variants
+@pytest.mark.parametrize("seed", range(3))
+def test_frame_and_keyframe_and_sim3(seed):
+    rng = np.random.default_rng(110 + seed)
+    grid = plp.make_grid(640, 480)
+    for n, m, words in [(1000, 900, 0), (1500, 1500, 8), (40, 70, 2)]:
+        t, q = MC.random_problem(rng, n, m, n_words=words)
+        pred = q["q_level"].astype(np.uint32)                                     # contains 0: (int)(pred - 1) = -1 / the unsigned wrap
+        for thr, check in ((50, True), (100, False)):
+            want, wn = O.match_frame_and_keyframe(O.grid6(grid), t["t_kps"], t["t_desc"], t["t_occupied"], SF, q["q_valid"], q["q_reproj"], pred,
+                                                  q["q_angle"], q["q_desc"], 10.0, thr, check)
+            got, gn = plp.matcher(0.9, check).match_host(plp.MODE_LAST_FRAME, n, m, dict(t_kps=t["t_kps"], t_desc=t["t_desc"], t_occupied=t["t_occupied"],
+                                  q_valid=q["q_valid"], q_reproj=q["q_reproj"], q_level=q["q_level"], q_angle=q["q_angle"], q_desc=q["q_desc"],
+                                  hamm_dist_thr=thr), margin=10.0, direction=0, scale_factors=SF, grid=grid)
+            assert gn[0] == wn and np.array_equal(got[0], want), (n, m, thr)
+        want, wn = O.match_by_sim3(O.grid6(grid), t["t_kps"], t["t_desc"], t["t_occupied"], SF, q["q_valid"], q["q_reproj"], pred, q["q_desc"], 7.5)
+        got, gn = plp.matcher(0.9, False).match_host(plp.MODE_LAST_FRAME, n, m, dict(t_kps=t["t_kps"], t_desc=t["t_desc"], t_occupied=t["t_occupied"],
+                              q_valid=q["q_valid"], q_reproj=q["q_reproj"], q_level=q["q_level"], q_desc=q["q_desc"], hamm_dist_thr=50, level_window=1,
+                              flags=plp.FLAG_UNSIGNED_LEVEL), margin=7.5, scale_factors=SF, grid=grid)
+        assert gn[0] == wn and np.array_equal(got[0], want), (n, m)
+        assert not np.isin(want, np.nonzero(pred == 0)[0]).any()
+
+
+@pytest.mark.parametrize("seed", range(2))
+def test_mutual_and_detect_duplication(seed):
+    rng = np.random.default_rng(120 + seed)
+    grid = plp.make_grid(640, 480)
+    n1, n2 = 1200, 1100
+    a, qa = MC.random_problem(rng, n1, n2, n_words=(0, 10)[seed])     # key frame 1 key points, landmarks of key frame 2 projected into it
+    b, qb = MC.random_problem(rng, n2, n1, n_words=(0, 10)[seed])
+    best = []
+    for t, q in ((b, qb), (a, qa)):          # landmarks of 1 searched in 2, then landmarks of 2 searched in 1
+        rd = q["q_reproj"].astype(np.float64) + rng.normal(0, 0.3, q["q_reproj"].shape)
+        pred = q["q_level"].astype(np.uint32)
+        want = O.project_best(O.grid6(grid), t["t_kps"], t["t_desc"], SF, q["q_valid"], rd, pred, q["q_desc"], 7.5, 100, 0)
+        got = plp.matcher().match_host(plp.MODE_FUSE, len(t["t_kps"]), len(pred), dict(t_kps=t["t_kps"], t_desc=t["t_desc"], q_valid=q["q_valid"],
+                                       q_reproj_d=rd, q_level=q["q_level"], q_desc=q["q_desc"], inv_level_sigma_sq=np.ones(8, np.float32),
+                                       flags=plp.FLAG_NO_CHI2, hamm_dist_thr=100), margin=7.5, scale_factors=SF, grid=grid)
+        assert np.array_equal(got[0], want)
+        best.append(want)
+        # fuse::detect_duplication: signed level window, threshold 50
+        want = O.project_best(O.grid6(grid), t["t_kps"], t["t_desc"], SF, q["q_valid"], rd, pred, q["q_desc"], 4.0, 50, 1)
+        got = plp.matcher().match_host(plp.MODE_FUSE, len(t["t_kps"]), len(pred), dict(t_kps=t["t_kps"], t_desc=t["t_desc"], q_valid=q["q_valid"],
+                                       q_reproj_d=rd, q_level=q["q_level"], q_desc=q["q_desc"], inv_level_sigma_sq=np.ones(8, np.float32),
+                                       flags=plp.FLAG_NO_CHI2 | plp.FLAG_SIGNED_LEVEL), margin=4.0, scale_factors=SF, grid=grid)
+        assert np.array_equal(got[0], want)
+        assert (want[pred == 0] >= 0).any()
+    m21, num = O.cross_check(best[0], best[1])
+    assert num == (m21 >= 0).sum()
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_line_keyframe_and_fuse(seed):
+    rng = np.random.default_rng(130 + seed)
+    sf_lsd = np.array([1.0, 2.0], np.float32)
+    inv_sigma = np.array([1.0, 0.25], np.float32)
+    for n, m, words in [(80, 120, 0), (300, 400, 4), (2, 5, 1)]:
+        t, q = random_line_problem(rng, n, m, words)
+        pred = q["q_level"].astype(np.uint32)
+        want, wn = O.match_frame_and_keyframe_line(t["t_kl"], t["t_desc"], t["t_occupied"], sf_lsd, q["q_valid"], q["q_reproj"], q["q_reproj2"], pred,
+                                                   q["q_desc"], 12.0, 60)
+        got, gn = plp.matcher(0.9, False).match_host(plp.MODE_LAST_FRAME_LINE, n, m, dict(t_kl=t["t_kl"], t_desc=t["t_desc"], t_occupied=t["t_occupied"],
+                              q_valid=q["q_valid"], q_reproj=q["q_reproj"], q_reproj2=q["q_reproj2"], q_level=q["q_level"], q_desc=q["q_desc"],
+                              hamm_dist_thr=60, is_rgbd=0, num_levels_lsd=1), margin=12.0, direction=0, scale_factors=sf_lsd)
+        assert gn[0] == wn and np.array_equal(got[0], want)
+        sp_d = q["q_reproj"].astype(np.float64) + rng.normal(0, 0.2, (m, 2)); ep_d = q["q_reproj2"].astype(np.float64) + rng.normal(0, 0.2, (m, 2))
+        want = O.fuse_search_line(t["t_kl"], t["t_desc"], sf_lsd, inv_sigma, q["q_valid"], sp_d, ep_d, pred, q["q_desc"], 6.0)
+        got = plp.matcher().match_host(plp.MODE_FUSE_LINE, n, m, dict(t_kl=t["t_kl"], t_desc=t["t_desc"], q_valid=q["q_valid"], q_reproj_d=sp_d,
+                                       q_reproj2_d=ep_d, q_level=q["q_level"], q_desc=q["q_desc"], inv_level_sigma_sq=inv_sigma),
+                                       margin=6.0, scale_factors=sf_lsd)
+        assert np.array_equal(got[0], want)
+    assert (want >= 0).any()
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_match_for_triangulation(seed):
+    rng = np.random.default_rng(140 + seed)
+    for n, m, nodes, words in [(900, 800, 30, 0), (1200, 1200, 10, 25), (30, 40, 2, 3)]:
+        t, q = MC.random_problem(rng, n, m, n_words=words)
+        t_node = (t["t_desc"][:, 0].astype(np.int32) * 7 + 3) % nodes
+        q_node = (q["q_desc"][:, 0].astype(np.int32) * 7 + 3) % nodes
+        order = np.argsort(q_node, kind="stable")
+        qd, qa, qn = q["q_desc"][order], q["q_angle"][order], q_node[order]
+        q_has_lm = (rng.uniform(size=m) < 0.3).astype(np.uint8); t_has_lm = (rng.uniform(size=n) < 0.3).astype(np.uint8)
+        q_xr = np.where(rng.uniform(size=m) < 0.3, 100.0, -1.0).astype(np.float32); t_xr = np.where(rng.uniform(size=n) < 0.3, 100.0, -1.0).astype(np.float32)
+        q_oct = rng.integers(0, 8, m).astype(np.int32)
+        # geometry: camera 2 = camera 1 translated by tr (R = I): E_12 = [tr]_x; bearings of common 3-D points + angular noise around the 0.2 deg gate
+        tr = np.array([0.3, 0.02, 0.05])
+        E = np.array([[0, -tr[2], tr[1]], [tr[2], 0, -tr[0]], [-tr[1], tr[0], 0]], np.float64)
+        epipole = -tr / np.linalg.norm(tr)                      # camera centre 1 seen from camera 2 (p2 = p1 - tr)
+        def bearings(k):
+            p1 = np.stack([rng.uniform(-2, 2, k), rng.uniform(-1.5, 1.5, k), rng.uniform(1, 8, k)], 1)
+            return p1
+        pts_t = bearings(n)
+        src = rng.integers(0, n, m)
+        pts_q = pts_t[src] + rng.normal(0, 0.004, (m, 3)) * pts_t[src][:, 2:3]
+        b1 = pts_q / np.linalg.norm(pts_q, axis=1, keepdims=True)                     # key frame 1 bearings (queries)
+        p2 = pts_t - tr
+        p2[rng.uniform(size=n) < 0.05] = epipole * 3.0 + rng.normal(0, 0.01, 3)      # a few targets next to the epipole
+        b2 = p2 / np.linalg.norm(p2, axis=1, keepdims=True)
+        for check in (True, False):
+            want, wn = O.match_for_triangulation(qd, qa, qn, q_has_lm, q_xr, q_oct, b1, t["t_desc"], t["t_kps"]["angle"], t_node, t_has_lm, t_xr, b2,
+                                                 SF, E.ravel(), epipole, check)
+            got, gn = plp.matcher(0.9, check).match_host(plp.MODE_TRIANGULATION, n, m, dict(t_desc=t["t_desc"], t_angle=t["t_kps"]["angle"],
+                                  t_group=t_node, t_occupied=t_has_lm, t_x_right=t_xr, t_bearing=b2, q_desc=qd, q_angle=qa, q_group=qn,
+                                  q_valid=(1 - q_has_lm).astype(np.uint8), q_x_right=q_xr, q_level=q_oct, q_bearing=b1,
+                                  epipolar=np.concatenate([E.ravel(), epipole])), scale_factors=SF)
+            want_t = np.full(n, -1, np.int32); sel = want >= 0; want_t[want[sel]] = np.nonzero(sel)[0]
+            assert gn[0] == wn and np.array_equal(got[0], want_t), (n, m, check)
+    assert wn > 0
