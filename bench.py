@@ -216,8 +216,20 @@ def main():
     launches = {"pyramid": 7, "lsd_blur11_resize": 2, "lsd_gradient_bins": 2, "lbd_blur5_sobel": 2, "match_2x": 4}.get(dominant, 1)
     dom_bytes = per_frame[dominant] * B
     achieved = dom_bytes / (kern[dominant] * 1e-3) / 1e9
+    # HBM-side bytes per launch from the committed rocprofv3 PMC passes (tools/pmc_traffic.py; separate FETCH_SIZE /
+    # WRITE_SIZE runs of this same command at the same batch).  Only quoted when the batch matches.
+    traffic = None
+    stage_kernel = {"lsd_grow": "plp::k_lsd_grow", "fast_cells": "plp::k_fast_cells", "quadtree": "plp::k_quadtree", "lbd": "plp::k_lbd",
+                    "orient_rbrief": "plp::k_orient_rbrief", "blur7": "plp::k_blur7", "pyramid": "plp::k_resize_linear",
+                    "lsd_order": "plp::k_lsd_order", "match_2x": "plp::k_match_topk_lds"}
+    try:
+        pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")))
+        if pmc.get("batch") == B and dominant in stage_kernel:
+            traffic = pmc["traffic_bytes_per_launch"].get(stage_kernel[dominant])
+    except (OSError, ValueError):
+        pass
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                 "launch_ms": round(kern[dominant] / launches, 4), "bytes_per_launch": int(dom_bytes / launches),
                 "stage_ms_per_batch": {k: round(v, 4) for k, v in stage_ms.items()},
                 "stage_GBps": {k: round(per_frame[k] * B / (kern[k] * 1e-3) / 1e9, 1) for k in kern}}
