@@ -100,9 +100,11 @@ def main():
     if uniq < B:
         d_frames = d_frames.repeat((B + uniq - 1) // uniq, 1, 1)[:B].contiguous()
     cap, lcap = 2 * K + 64, 512
-    d_kps = torch.empty((B, cap, 28), dtype=torch.uint8, device=dev)
-    d_desc = torch.empty((B, cap, 32), dtype=torch.uint8, device=dev)
-    d_cnt = torch.zeros(B, dtype=torch.int32, device=dev)
+    # two sets of ORB outputs: the matchers of step n read set n % 2 while the extractor of step n + 1 fills the other
+    kps2 = [torch.empty((B, cap, 28), dtype=torch.uint8, device=dev) for _ in range(2)]
+    desc2 = [torch.empty((B, cap, 32), dtype=torch.uint8, device=dev) for _ in range(2)]
+    cnt2 = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2)]
+    d_kps, d_desc, d_cnt = kps2[0], desc2[0], cnt2[0]
     d_kl = torch.empty((B, lcap, 68), dtype=torch.uint8, device=dev)
     d_lbd = torch.empty((B, lcap, 32), dtype=torch.uint8, device=dev)
     d_fn = torch.empty((B, lcap, 3), dtype=torch.float64, device=dev)
@@ -117,12 +119,14 @@ def main():
     sf = ex.get_scale_factors()
     cur = torch.cuda.current_stream(dev)
     sA = torch.cuda.Stream(dev)
-    sB = sA if os.environ.get("PLP_BENCH_SERIAL") else torch.cuda.Stream(dev)   # diagnostic: one stream for everything
+    serial = bool(os.environ.get("PLP_BENCH_SERIAL"))                            # diagnostic: one stream for everything
+    sB = sA if serial else torch.cuda.Stream(dev)
     slot = torch.arange(cap, device=dev, dtype=torch.int32)[None, :]
 
     replay = importlib.import_module("structure-plp-slam_amd.replay")
 
-    def match_stage():
+    def match_stage(d_kps=d_kps, d_desc=d_desc, d_cnt=d_cnt, st=None):
+        st = st or sA
         kf = d_kps.view(torch.float32).view(B, cap, 7)
         # the two frames preceding this rank's block come from the previous rank (RCCL all-gather of the tails)
         hk, hd, hc = replay.exchange_halo([kf, d_desc, d_cnt], halo=2)
@@ -134,22 +138,33 @@ def main():
         q1 = dict(q_reproj=(p1k[:, :, 0:2] + shift).contiguous(), q_level=p1i[:, :, 5].contiguous(), q_angle=p1k[:, :, 3].contiguous(),
                   q_desc=p1d.contiguous(), q_counts=c1)
         t = dict(t_kps=d_kps, t_desc=d_desc, t_counts=d_cnt)
-        mt_last.match_device(plp.MODE_LAST_FRAME, cap, cap, {**t, **q1}, m1, n1, margin=20.0, direction=0, scale_factors=sf, grid=grid, B=B, stream=sA)
+        mt_last.match_device(plp.MODE_LAST_FRAME, cap, cap, {**t, **q1}, m1, n1, margin=20.0, direction=0, scale_factors=sf, grid=grid, B=B, stream=st)
         rp2 = torch.cat([p1k[:, :, 0:2] + shift, p2k[:, :, 0:2] + 2 * shift], 1).contiguous()
         q2 = dict(q_reproj=rp2, q_level=torch.cat([p1i[:, :, 5], p2i[:, :, 5]], 1).contiguous(), q_desc=torch.cat([p1d, p2d], 1),
                   q_valid=torch.cat([slot < c1[:, None], slot < c2[:, None]], 1).to(torch.uint8).contiguous())
-        mt_lm.match_device(plp.MODE_LANDMARKS, cap, 2 * cap, {**t, **q2}, m2, n2, margin=10.0, scale_factors=sf, grid=grid, B=B, stream=sA)
+        mt_lm.match_device(plp.MODE_LANDMARKS, cap, 2 * cap, {**t, **q2}, m2, n2, margin=10.0, scale_factors=sf, grid=grid, B=B, stream=st)
+
+    # One step = ORB (stream A) || LSD+LBD (stream B), then the halo exchange and the two matchers (stream C) on that
+    # step's features.  Steps are software-pipelined: stream C works on step n while A and B already extract step n + 1
+    # (every stage is latency-bound on its own, see profiles/r01g_sq_counters.md); all K steps' work, matchers
+    # included, is inside the timed region because the closing barrier synchronises the device.
+    sC = sA if serial else torch.cuda.Stream(dev)
+    done_match = [None, None]
+    step_no = [0]
 
     def step():
-        sA.wait_stream(cur)
-        sB.wait_stream(cur)
-        ex.extract_batch(d_frames, d_kps, d_desc, d_cnt, stream=sA)
+        n = step_no[0]; step_no[0] += 1
+        buf = n % 2
+        if done_match[buf] is not None:
+            sA.wait_event(done_match[buf])          # the matchers of step n - 2 have read this set
+        ex.extract_batch(d_frames, kps2[buf], desc2[buf], cnt2[buf], stream=sA)
         if not args.orb_only:
             lt.extract_batch(d_frames, d_kl, d_lbd, d_fn, d_lcnt, stream=sB)
-            with torch.cuda.stream(sA):
-                match_stage()
-        cur.wait_stream(sA)
-        cur.wait_stream(sB)
+            ready = torch.cuda.Event(); ready.record(sA)
+            sC.wait_event(ready)
+            with torch.cuda.stream(sC):
+                match_stage(kps2[buf], desc2[buf], cnt2[buf], sC)
+                done_match[buf] = torch.cuda.Event(); done_match[buf].record(sC)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -157,6 +172,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    sA.wait_stream(cur); sB.wait_stream(cur)
     for _ in range(args.warmup):
         step()
     barrier()

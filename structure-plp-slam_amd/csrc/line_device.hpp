@@ -10,10 +10,14 @@ namespace plp {
 constexpr int kLineCap = 2048;        // raw LSD segments / key lines kept per frame (a 640x480 frame yields ~400)
 constexpr double kLsdNotDef = -1024.0;
 
-// Everything region growing needs about one pixel of the scaled image, in ONE 32-byte HBM sector (the kernel is
-// bound by random-access sectors, not by bytes): level-line angle (NOTDEF = -1024), gradient magnitude, and
-// (float)cos / (float)sin of float(angle).
-struct alignas(32) LsdPix { double ang; double mod; float2 cs; float2 pad; };
+// Everything region growing needs about one pixel of the scaled image in 16 bytes (two pixels per 32-byte HBM sector):
+//   deg  cv::fastAtan2(gx, -gy) in degrees; the level-line angle of lsd.cpp is (double)deg * (pi / 180)
+//   g2   gx^2 + gy^2; the gradient magnitude is sqrt((double)g2 / 4.0)
+//   cs   (float)cos / (float)sin of float(angle)
+// Undefined pixels (magnitude <= rho) are marked in the `undef` bit mask and never read.
+struct alignas(16) LsdPix { float deg; uint32_t g2; float2 cs; };
+__device__ __forceinline__ double pix_ang(const LsdPix& p) { return (double)p.deg * (3.14159265358979323846 / 180); }
+__device__ __forceinline__ double pix_mod(const LsdPix& p) { return sqrt((double)p.g2 / 4.0); }
 
 // Per-frame geometry + HBM planes of the line path.  All planes are B frames back to back.
 struct LinePlanes {
@@ -23,7 +27,7 @@ struct LinePlanes {
     const uint8_t* img; size_t img_frame_stride; int img_pitch;   // caller's frames
     uint8_t* blur11;          // 11-tap sigma 1.2 blur (LSD)          [B][H][pitch]
     uint8_t* scaled;          // INTER_LINEAR_EXACT x0.5              [B][sh][spitch]
-    LsdPix* pix;              // per scaled pixel: angle / magnitude / cos,sin, one 32-byte sector  [B][sh*sw]
+    LsdPix* pix;              // per scaled pixel: angle / magnitude^2 / cos,sin, 16 bytes  [B][sh*sw]
     uint16_t* bin;            // pseudo-ordering bin                  [B][sh*sw]
     unsigned long long* maxgrad;   // per frame, bit pattern of the max defined magnitude  [B]
     unsigned long long* undef;     // NOTDEF bitmask, 1 bit per scaled pixel          [B][ceil(sh*sw/64)]

@@ -102,23 +102,26 @@ __global__ __launch_bounds__(256) void k_lsd_gradient(LinePlanes P, LsdParams lp
     double norm_def = 0.0;
     if (idx < n) {
         const int y = idx / P.sw, x = idx - y * P.sw;
-        double ang = kLsdNotDef, norm = 0.0;
+        double norm = 0.0;
+        float deg = 0.f;
+        uint32_t g2 = 0;
         float2 cs = make_float2(0.f, 0.f);
         if (x < P.sw - 1 && y < P.sh - 1) {
             const uint8_t* s = P.scaled + ((size_t)b * P.sh + y) * P.spitch + x;
             const int DA = (int)s[P.spitch + 1] - (int)s[0];
             const int BC = (int)s[1] - (int)s[P.spitch];
             const int gx = DA + BC, gy = DA - BC;
+            g2 = (uint32_t)(gx * gx + gy * gy);
             norm = sqrt((double)(gx * gx + gy * gy) / 4.0);
             if (!(norm <= lp.rho)) {
-                ang = (double)fast_atan2_deg_l((float)gx, (float)-gy) * (3.14159265358979323846 / 180);
-                const float fa = (float)ang;
+                deg = fast_atan2_deg_l((float)gx, (float)-gy);
+                const float fa = (float)((double)deg * (3.14159265358979323846 / 180));
                 cs = make_float2((float)cos((double)fa), (float)sin((double)fa));
                 norm_def = norm;
             }
         }
         const size_t o = (size_t)b * n + idx;
-        LsdPix px; px.ang = ang; px.mod = norm; px.cs = cs; px.pad = make_float2(0.f, 0.f);
+        LsdPix px; px.deg = deg; px.g2 = g2; px.cs = cs;
         P.pix[o] = px;
     }
     // max over defined pixels: positive doubles order like their bit patterns
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(256) void k_lsd_bins(LinePlanes P, LsdParams lp) {
     if (idx >= n) return;
     const double max_grad = __longlong_as_double((long long)P.maxgrad[b]);
     const double bin_coef = (max_grad > 0) ? (double)(lp.n_bins - 1) / max_grad : 0;
-    P.bin[(size_t)b * n + idx] = (uint16_t)(int)(P.pix[(size_t)b * n + idx].mod * bin_coef);
+    P.bin[(size_t)b * n + idx] = (uint16_t)(int)(pix_mod(P.pix[(size_t)b * n + idx]) * bin_coef);
 }
 
 // ------------------------------------------------------------------------------------------ seed ordering
@@ -246,18 +249,20 @@ __device__ __forceinline__ void set_used(const GrowCtx& g, int p) { atomicOr(&g.
 // neighbourhoods of the batch is invalidated in the later one once accepted.  Undefined pixels are pre-marked
 // USED, so no NOTDEF test; a pixel that is USED when the batch is fetched needs no data at all (USED bits are
 // only ever set while a region grows), so a region interior costs almost no HBM sectors.
-// Returns the region size; cen[3] = (sum x*w, sum y*w, sum w) accumulated in region order.
-__device__ int region_grow(const GrowCtx& g, int seed, double prec, double& reg_angle, double cen[3]) {
+// Latency hiding: (a) the seed's own record and its 8 neighbours arrive with the call (`pre`, fetched for 64 seeds
+// at once by the caller), so a region that never leaves its seed costs no memory round trip; (b) while a full batch
+// is being decided, the records of the NEXT seven region points (when they already exist) are in flight.  A
+// prefetched record is immutable; only its USED bit is re-read when the batch is taken up.
+// The centroid sums of region2rect are not accumulated here any more: most regions are smaller than min_reg_size
+// and are dropped, the others get them from centroid_sums() (same order of additions).
+struct SeedPre { bool use; bool ok; float seed_deg; float deg; float2 cs; };   // ok/deg/cs: lanes 0..8 = the seed's neighbourhood
+
+__device__ int region_grow(const GrowCtx& g, int seed, const SeedPre& pre, double prec, double& reg_angle) {
     const int lane = g.lane;
     int nreg = 1;
     const int sx = seed % g.sw, sy = seed / g.sw;
-    const LsdPix seed_px = g.pix[seed];
-    reg_angle = seed_px.ang;
+    reg_angle = (double)(pre.use ? pre.seed_deg : g.pix[seed].deg) * (3.14159265358979323846 / 180);
     float sumdx = (float)cos(reg_angle), sumdy = (float)sin(reg_angle);
-    {
-        const double w = seed_px.mod;
-        cen[0] = (double)sx * w; cen[1] = (double)sy * w; cen[2] = w;
-    }
     if (lane == 0) {
         const uint32_t c = (uint32_t)sx | ((uint32_t)sy << 16);
         g.reg[0] = c; g.ring[0] = c;
@@ -266,26 +271,54 @@ __device__ int region_grow(const GrowCtx& g, int seed, double prec, double& reg_
     __builtin_amdgcn_wave_barrier();
     const int slot = lane / 9, k9 = lane - slot * 9;   // slot 0..6 (lane 63: slot 7, idle)
     const int ddx = k9 % 3 - 1, ddy = k9 / 3 - 1;
+    // look-ahead state: this lane's record for region point la_idx (valid iff la_have)
+    bool la_have = false, la_cand = false;
+    int la_idx = -1, la_nx = 0, la_ny = 0;
+    float la_deg = 0.f;
+    float2 la_cs = make_float2(0.f, 0.f);
+    auto point_of = [&](int idx, int cur_nreg) -> uint32_t {
+        if (cur_nreg > idx + g.ring_mask + 1) return __hip_atomic_load(&g.reg[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // left the LDS ring
+        return g.ring[idx & g.ring_mask];
+    };
     for (int i = 0; i < nreg;) {
         const int nb = min(7, nreg - i);
-        // ---- fetch the batch: region point i + slot
-        bool cand = slot < nb;
+        const bool active = slot < nb;
+        bool cand = false;
         int nx = 0, ny = 0, np = 0;
-        if (nreg > i + g.ring_mask + 1) {   // frontier outgrew the LDS ring: read the HBM copy (uniform branch)
-            uint32_t c = 0;
-            if (cand) c = __hip_atomic_load(&g.reg[i + slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            nx = (int)(c & 0xffff) + ddx; ny = (int)(c >> 16) + ddy;
-        } else {
-            const uint32_t c = g.ring[(i + min(slot, 6)) & g.ring_mask];
-            nx = (int)(c & 0xffff) + ddx; ny = (int)(c >> 16) + ddy;
-        }
-        cand = cand && nx >= 0 && ny >= 0 && nx < g.sw && ny < g.sh;
-        np = ny * g.sw + nx;
-        if (cand) cand = !is_used(g, np);
-        double a = 0, w = 0;
+        float deg = 0.f;
         float2 ncs = make_float2(0.f, 0.f);
-        if (cand) { const LsdPix px = g.pix[np]; a = px.ang; w = px.mod; ncs = px.cs; }   // one 32-byte sector per live neighbour
-        // ---- acceptances in order
+        if (i == 0 && pre.use) {                       // the seed's neighbourhood came with the call
+            nx = sx + ddx; ny = sy + ddy; np = ny * g.sw + nx;
+            cand = active && pre.ok && !is_used(g, np);
+            deg = pre.deg; ncs = pre.cs;
+        } else if (active) {
+            if (la_have && la_idx == i + slot) {        // fetched while the previous batch was being decided
+                nx = la_nx; ny = la_ny; np = ny * g.sw + nx;
+                cand = la_cand && !is_used(g, np);
+                deg = la_deg; ncs = la_cs;
+            } else {
+                const uint32_t c = point_of(i + slot, nreg);
+                nx = (int)(c & 0xffff) + ddx; ny = (int)(c >> 16) + ddy; np = ny * g.sw + nx;
+                cand = nx >= 0 && ny >= 0 && nx < g.sw && ny < g.sh && !is_used(g, np);
+                if (cand) { const LsdPix px = g.pix[np]; deg = px.deg; ncs = px.cs; }
+            }
+        }
+        // ---- look ahead: region points i+7 .. i+13 that exist already
+        la_have = false;
+        if (nb == 7 && nreg > i + 7) {   // uniform
+            const int idx = i + 7 + slot;
+            if (slot < 7 && idx < nreg) {
+                const uint32_t c = point_of(idx, nreg);
+                la_nx = (int)(c & 0xffff) + ddx; la_ny = (int)(c >> 16) + ddy;
+                const int p2 = la_ny * g.sw + la_nx;
+                la_cand = la_nx >= 0 && la_ny >= 0 && la_nx < g.sw && la_ny < g.sh && !is_used(g, p2);
+                if (la_cand) { const LsdPix px = g.pix[p2]; la_deg = px.deg; la_cs = px.cs; }
+                la_have = true; la_idx = idx;
+            }
+        }
+        const double a = (double)deg * (3.14159265358979323846 / 180);
+        // ---- acceptances in order (no global-memory traffic inside: the look-ahead loads stay in flight)
+        const int n_before = nreg;
         int last = -1;
         while (true) {
             const bool ok = cand && lane > last && aligned_to(a, reg_angle, prec);
@@ -294,28 +327,29 @@ __device__ int region_grow(const GrowCtx& g, int seed, double prec, double& reg_
             const int k = __ffsll((long long)bal) - 1;
             const int ax = bcast_i(nx, k), ay = bcast_i(ny, k);
             const float ccos = bcast_f(ncs.x, k), csin = bcast_f(ncs.y, k);
-            const double aw = bcast_d(w, k);
             const int ap = ay * g.sw + ax;
             if (lane == 0) {
-                const uint32_t c = (uint32_t)ax | ((uint32_t)ay << 16);
-                __hip_atomic_store(&g.reg[nreg], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                g.ring[nreg & g.ring_mask] = c;
+                g.ring[nreg & g.ring_mask] = (uint32_t)ax | ((uint32_t)ay << 16);
                 set_used(g, ap);
             }
             ++nreg;
             sumdx = __fadd_rn(sumdx, ccos);
             sumdy = __fadd_rn(sumdy, csin);
             reg_angle = (double)fast_atan2_deg_l(sumdy, sumdx) * (3.14159265358979323846 / 180);
-            cen[0] += (double)ax * aw; cen[1] += (double)ay * aw; cen[2] += aw;
             last = k;
             if (np == ap) cand = false;   // the same pixel seen from a later point of the batch
         }
         __builtin_amdgcn_wave_barrier();
+        if (n_before + lane < nreg)   // this round's new points (at most 63) go to the HBM copy of the list in one store
+            __hip_atomic_store(&g.reg[n_before + lane], g.ring[(n_before + lane) & g.ring_mask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         i += nb;
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // region list in HBM is read by all lanes next
-    __builtin_amdgcn_wave_barrier();
     return nreg;
+}
+// the region list in HBM is read by all lanes after growing (only regions that are kept get that far)
+__device__ __forceinline__ void region_list_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
 }
 
 // region2rect (lsd.cpp): centroid given; inertia + extents.  Sequential f64 sums in region order, fed
@@ -329,7 +363,7 @@ __device__ void region2rect(const GrowCtx& g, int nreg, double reg_angle, double
         double txx = 0, tyy = 0, txy = 0;   // this lane's addends (same roundings as the reference's per-point products)
         if (j < nreg) {
             const uint32_t c = g.reg[j];
-            const double w = g.pix[(int)(c >> 16) * g.sw + (int)(c & 0xffff)].mod;
+            const double w = pix_mod(g.pix[(int)(c >> 16) * g.sw + (int)(c & 0xffff)]);
             const double dx = (double)(int)(c & 0xffff) - x, dy = (double)(int)(c >> 16) - y;
             txx = dy * dy * w; tyy = dx * dx * w; txy = dx * dy * w;
         }
@@ -379,7 +413,7 @@ __device__ void centroid_sums(const GrowCtx& g, int nreg, double cen[3]) {
         double tx = 0, ty = 0, w = 0;
         if (j < nreg) {
             const uint32_t c = g.reg[j];
-            w = g.pix[(int)(c >> 16) * g.sw + (int)(c & 0xffff)].mod;
+            w = pix_mod(g.pix[(int)(c >> 16) * g.sw + (int)(c & 0xffff)]);
             tx = (double)(int)(c & 0xffff) * w; ty = (double)(int)(c >> 16) * w;
         }
         const int cnt = min(64, nreg - base);
@@ -416,19 +450,54 @@ __global__ __launch_bounds__(256) void k_lsd_grow(LinePlanes P, LsdParams lp, in
         const bool in_range = base + lane < nv;
         const uint32_t mine = in_range ? order[base + lane] : 0u;
         // most seeds are already inside an earlier region: test the 64 USED bits in parallel, visit the rest in order
-        unsigned long long todo = __ballot(in_range && !is_used(g, (int)mine));
+        const bool fresh = in_range && !is_used(g, (int)mine);
+        unsigned long long todo = __ballot(fresh);
+        // every still-unused seed of this group of 64 fetches its own record and its 8 neighbours' now: one memory
+        // round trip for up to 64 regions instead of two per region
+        float s_deg = 0.f, n_deg[9];
+        float2 n_cs[9];
+        unsigned n_ok = 0;
+        if (fresh) {
+            const int sx = (int)mine % g.sw, sy = (int)mine / g.sw;
+            s_deg = g.pix[mine].deg;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                n_deg[k] = 0.f; n_cs[k] = make_float2(0.f, 0.f);
+                if (k == 4) continue;
+                const int nx = sx + k % 3 - 1, ny = sy + k / 3 - 1;
+                if (nx >= 0 && ny >= 0 && nx < g.sw && ny < g.sh && !is_used(g, ny * g.sw + nx)) {
+                    const LsdPix px = g.pix[ny * g.sw + nx];
+                    n_deg[k] = px.deg; n_cs[k] = px.cs; n_ok |= 1u << k;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { n_deg[k] = 0.f; n_cs[k] = make_float2(0.f, 0.f); }
+        }
         while (todo) {
             const int t = __ffsll((long long)todo) - 1;
             todo &= todo - 1;
             const int seed = bcast_i((int)mine, t);
             if (is_used(g, seed)) continue;   // claimed by a region grown since the ballot
+            SeedPre pre;
+            pre.use = true; pre.seed_deg = bcast_f(s_deg, t);
+            pre.ok = lane < 9 && ((unsigned)bcast_i((int)n_ok, t) >> lane) & 1u;
+            pre.deg = 0.f; pre.cs = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {   // lane t's k-th neighbour record -> lane k
+                if (k == 4) continue;
+                const float d = bcast_f(n_deg[k], t), cx = bcast_f(n_cs[k].x, t), cy = bcast_f(n_cs[k].y, t);
+                if (lane == k) { pre.deg = d; pre.cs = make_float2(cx, cy); }
+            }
             double reg_angle, cen[3];
             long long t0 = clock64();
-            int nreg = region_grow(g, seed, lp.prec, reg_angle, cen);
+            int nreg = region_grow(g, seed, pre, lp.prec, reg_angle);
             t_grow += clock64() - t0; ++n_seed; n_pix += nreg;
             if (nreg < lp.min_reg_size) continue;
+            region_list_fence();
             Rect rec;
             t0 = clock64();
+            centroid_sums(g, nreg, cen);
             region2rect(g, nreg, reg_angle, lp.prec, cen, rec);
             t_rect += clock64() - t0;
             t0 = clock64();
@@ -439,7 +508,7 @@ __global__ __launch_bounds__(256) void k_lsd_grow(LinePlanes P, LsdParams lp, in
                     // ---- refine: tighter angle tolerance from the points near the seed
                     const uint32_t c0 = g.reg[0];
                     const double xc = (double)(int)(c0 & 0xffff), yc = (double)(int)(c0 >> 16);
-                    const double ang_c = g.pix[(int)(c0 >> 16) * g.sw + (int)(c0 & 0xffff)].ang;
+                    const double ang_c = pix_ang(g.pix[(int)(c0 >> 16) * g.sw + (int)(c0 & 0xffff)]);
                     double sum = 0, s_sum = 0;
                     int nn = 0;
                     for (int rb = 0; rb < nreg; rb += 64) {
@@ -452,7 +521,7 @@ __global__ __launch_bounds__(256) void k_lsd_grow(LinePlanes P, LsdParams lp, in
                             atomicAnd(&g.used[(py * g.sw + px) >> 5], ~(1u << ((py * g.sw + px) & 31)));   // *(reg[i].used) = NOTUSED
                             const double ddx = (double)px - xc, ddy = (double)py - yc;
                             near = sqrt(ddx * ddx + ddy * ddy) < rec.width;
-                            a = g.pix[py * g.sw + px].ang;
+                            a = pix_ang(g.pix[py * g.sw + px]);
                         }
                         const double my_d = near ? angle_diff_signed(a, ang_c) : 0.0;
                         const double my_d2 = my_d * my_d;
@@ -466,9 +535,12 @@ __global__ __launch_bounds__(256) void k_lsd_grow(LinePlanes P, LsdParams lp, in
                     __builtin_amdgcn_wave_barrier();
                     const double mean_angle = sum / (double)nn;
                     const double tau = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / (double)nn + mean_angle * mean_angle);
-                    nreg = region_grow(g, (int)(c0 >> 16) * g.sw + (int)(c0 & 0xffff), tau, reg_angle, cen);
+                    SeedPre none{};
+                    nreg = region_grow(g, (int)(c0 >> 16) * g.sw + (int)(c0 & 0xffff), none, tau, reg_angle);
+                    region_list_fence();
                     if (nreg < 2) keep = false;
                     else {
+                        centroid_sums(g, nreg, cen);
                         region2rect(g, nreg, reg_angle, lp.prec, cen, rec);
                         density = rect_density(nreg, rec);
                         if (density < lp.density_th) {

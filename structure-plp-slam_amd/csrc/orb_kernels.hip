@@ -16,30 +16,93 @@
 namespace plp {
 
 // ------------------------------------------------------------------------------------------
-// K1  bilinear 11-bit fixed-point down-scale, 4 destination pixels per thread (one u32 store).
-// grid = (ceil(dw/256), ceil(dh/32), B), block = (64, 4); a thread makes 4 pixels x 8 rows
+// K1  bilinear 11-bit fixed-point down-scale.  A workgroup makes a 256 x 32 destination tile: the source rectangle
+// it needs (<= 42 rows x 336 bytes at scale 1.2) is staged in LDS with 16-byte loads, then every thread makes
+// 4 pixels x 8 rows with byte reads from LDS (one u32 store per row).  The first version gathered single bytes
+// from global memory, 16 per output dword, and was bound by the texture addresser (profiles/r01g_sq_counters.md:
+// 50 % issue stalls).  Horizontal sums of a source row are kept for the next destination row (at scale 1.2 five
+// of six destination rows share a source row with their predecessor).
+// grid = (ceil(dw/256), ceil(dh/32), B), block = (64, 4)
 // ------------------------------------------------------------------------------------------
+constexpr int kRsRows = 44, kRsPitch = 352;   // staged source tile (scale factors >= 1.1 fit; larger tiles fall back to global reads)
+
 __global__ __launch_bounds__(256) void k_resize_linear(const uint8_t* __restrict__ src_base, size_t src_frame_stride,
-                                                       int src_pitch, uint8_t* __restrict__ dst_base,
+                                                       int src_pitch, int sw, uint8_t* __restrict__ dst_base,
                                                        size_t dst_frame_stride, int dst_pitch, int dw, int dh,
                                                        const int16_t* __restrict__ xofs0, const int16_t* __restrict__ xofs1,
                                                        const int16_t* __restrict__ a0, const int16_t* __restrict__ a1,
                                                        const int16_t* __restrict__ yofs0, const int16_t* __restrict__ yofs1,
                                                        const int16_t* __restrict__ b0, const int16_t* __restrict__ b1) {
-    constexpr int ROWS = 8;   // rows per thread: the 4 column coefficient sets are loaded once and reused
-    const int dy0 = (blockIdx.y * 4 + threadIdx.y) * ROWS;
-    const int dx0 = (blockIdx.x * 64 + threadIdx.x) * 4;
-    if (dy0 >= dh || dx0 >= dw) return;
+    constexpr int ROWS = 8;
+    __shared__ __attribute__((aligned(16))) uint8_t tile[kRsRows * kRsPitch];
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    const int tile_x0 = blockIdx.x * 256, tile_y0 = blockIdx.y * 32;
+    const int tile_x1 = min(tile_x0 + 256, dw) - 1, tile_y1 = min(tile_y0 + 32, dh) - 1;
     const uint8_t* src = src_base + (size_t)blockIdx.z * src_frame_stride;
     uint8_t* dst = dst_base + (size_t)blockIdx.z * dst_frame_stride;
+    const int xs = (int)xofs0[tile_x0] & ~15, xe = xofs1[tile_x1];
+    const int ys = yofs0[tile_y0], ye = yofs1[tile_y1];
+    const int nrows = ye - ys + 1, nchunks = (xe - xs) / 16 + 1;
+    const bool staged = nrows <= kRsRows && nchunks * 16 <= kRsPitch;   // uniform
+    if (staged) {
+        const bool wide = (((uintptr_t)src | (uintptr_t)src_pitch) & 15) == 0;
+        for (int i = tid; i < nrows * nchunks; i += 256) {
+            const int r = i / nchunks, c = i - r * nchunks;
+            const int x = xs + 16 * c;
+            const uint8_t* g = src + (size_t)(ys + r) * src_pitch + x;
+            uint8_t* t = tile + r * kRsPitch + 16 * c;
+            if (wide && x + 16 <= src_pitch) *reinterpret_cast<uint4*>(t) = *reinterpret_cast<const uint4*>(g);
+            else
+                for (int k = 0; k < 16; ++k) t[k] = x + k < sw ? g[k] : (uint8_t)0;
+        }
+    }
+    __syncthreads();
+    const int dy0 = tile_y0 + threadIdx.y * ROWS;
+    const int dx0 = tile_x0 + threadIdx.x * 4;
+    if (dy0 >= dh || dx0 >= dw) return;
     int x0[4], x1[4], wa0[4], wa1[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int dx = min(dx0 + i, dw - 1);
         x0[i] = xofs0[dx]; x1[i] = xofs1[dx]; wa0[i] = a0[dx]; wa1[i] = a1[dx];
     }
-#pragma unroll 2
-    for (int r = 0; r < ROWS; ++r) {
+    if (staged) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { x0[i] -= xs; x1[i] -= xs; }
+        int cached_row = -1, hc[4] = {0, 0, 0, 0};
+        auto hrow = [&](int y, int (&h)[4]) {
+            const uint8_t* S = tile + (y - ys) * kRsPitch;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) h[i] = S[x0[i]] * wa0[i] + S[x1[i]] * wa1[i];
+        };
+        for (int r = 0; r < ROWS; ++r) {
+            const int dy = dy0 + r;
+            if (dy >= dh) break;
+            const int y0 = yofs0[dy], y1 = yofs1[dy];   // wave-uniform
+            const int wb0 = b0[dy], wb1 = b1[dy];
+            int h0[4], h1[4];
+            if (y0 == cached_row) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) h0[i] = hc[i];
+            } else hrow(y0, h0);
+            if (y1 == y0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) h1[i] = h0[i];
+            } else hrow(y1, h1);
+            uint32_t packed = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int v = (((wb0 * (h0[i] >> 4)) >> 16) + ((wb1 * (h1[i] >> 4)) >> 16) + 2) >> 2;
+                packed |= (uint32_t)(v & 255) << (8 * i);
+                hc[i] = h1[i];
+            }
+            cached_row = y1;
+            // rows are padded to a 64-byte pitch, so the 4-byte store never leaves the row
+            *reinterpret_cast<uint32_t*>(dst + (size_t)dy * dst_pitch + dx0) = packed;
+        }
+        return;
+    }
+    for (int r = 0; r < ROWS; ++r) {   // generic scale factors: gather from global memory
         const int dy = dy0 + r;
         if (dy >= dh) break;
         const uint8_t* S0 = src + (size_t)yofs0[dy] * src_pitch;
@@ -53,7 +116,6 @@ __global__ __launch_bounds__(256) void k_resize_linear(const uint8_t* __restrict
             const int v = (((wb0 * (h0 >> 4)) >> 16) + ((wb1 * (h1 >> 4)) >> 16) + 2) >> 2;
             packed |= (uint32_t)(v & 255) << (8 * i);
         }
-        // rows are padded to a 64-byte pitch, so the 4-byte store never leaves the row
         *reinterpret_cast<uint32_t*>(dst + (size_t)dy * dst_pitch + dx0) = packed;
     }
 }
@@ -78,11 +140,11 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbPlanes pl, const CellDesc
                                                     const uint8_t* __restrict__ mask, size_t mask_step,
                                                     size_t mask_frame_stride, uint32_t* __restrict__ cell_cand,
                                                     int32_t* __restrict__ cell_count, int n_cells) {
-    __shared__ uint8_t tile[70 * kTileW];
-    __shared__ uint8_t score[66 * kScoreW];   // score map of the tested interior, +1 zero ring
-    __shared__ uint8_t keep[64 * 64];         // NMS survivors (score or 0)
-    __shared__ uint16_t queue[4096];
-    __shared__ int q_count, n_ini, wave_tot[4], run_base;
+    __shared__ __attribute__((aligned(16))) uint8_t tile[70 * kTileW];
+    __shared__ __attribute__((aligned(16))) uint8_t score[66 * kScoreW];   // score map of the tested interior, +1 zero ring
+    __shared__ __attribute__((aligned(16))) uint8_t keep[64 * 64];         // NMS survivors (score or 0)
+    __shared__ uint16_t queue[4096], queue2[4096];
+    __shared__ int q_count, q2_count, n_ini, wave_tot[4], run_base;
 
     const int tid = threadIdx.x, frame = blockIdx.y, cell = blockIdx.x;
     const CellDesc cd = cells[cell];
@@ -115,83 +177,101 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbPlanes pl, const CellDesc
             const uint32_t v = *reinterpret_cast<const uint32_t*>(row0 + (size_t)r * pitch + 4 * c);
             *reinterpret_cast<uint32_t*>(&tile[r * kTileW + 4 * c]) = v;
         }
-        for (int i = tid; i < 66 * kScoreW; i += 256) score[i] = 0;
-        if (tid == 0) { q_count = 0; n_ini = 0; run_base = 0; }
     }
-    __syncthreads();
     const int ox = cd.min_x & 3;
     const int tw = w - 6, th = h - 6;   // tested interior (ROI x,y in [3, w-3) x [3, h-3))
-
-    // pass 1: 16-bit brighter/darker masks -> "has an arc of 9 at min_thr" -> queue
-    for (int i = tid; i < 4096; i += 256) {   // 64 x 64 positions, shifts instead of divisions; border cells skip the excess
-        const int ty = i >> 6, tx = i & 63;
-        if (tx >= tw || ty >= th) continue;
-        const uint8_t* c = &tile[(ty + 3) * kTileW + tx + 3 + ox];
-        const int v = c[0];
-        const int hi = v + min_thr, lo = v - min_thr;
-        uint32_t B = 0, D = 0;
+    // cv::FAST(ini_thr), and cv::FAST(min_thr) only when that finds nothing in this cell (:404-412).  A corner at
+    // threshold t has score >= t, and scores below t never win a 3x3 comparison against one >= t, so each attempt may
+    // simply ignore everything below its own threshold.
+    int thr = ini_thr;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        thr = attempt == 0 ? ini_thr : min_thr;
+        for (int i = tid; i < 66 * kScoreW / 4; i += 256) reinterpret_cast<uint32_t*>(score)[i] = 0;
+        for (int i = tid; i < 1024; i += 256) reinterpret_cast<uint32_t*>(keep)[i] = 0;
+        if (tid == 0) { q_count = 0; q2_count = 0; n_ini = 0; run_base = 0; }
+        __syncthreads();
+        // pass 1: every arc of 9 contains two neighbouring compass pixels (0, 4, 8, 12): 5 reads reject most pixels
+        for (int i = tid; i < 4096; i += 256) {   // 64 x 64 positions, shifts instead of divisions; border cells skip the excess
+            const int ty = i >> 6, tx = i & 63;
+            if (tx >= tw || ty >= th) continue;
+            const uint8_t* c = &tile[(ty + 3) * kTileW + tx + 3 + ox];
+            const int v = c[0];
+            const int hi = v + thr, lo = v - thr;
+            const int p0 = c[3 * kTileW], p4 = c[3], p8 = c[-3 * kTileW], p12 = c[-3];
+            const bool b0 = p0 > hi, b4 = p4 > hi, b8 = p8 > hi, b12 = p12 > hi;
+            const bool d0 = p0 < lo, d4 = p4 < lo, d8 = p8 < lo, d12 = p12 < lo;
+            if (((b0 | b8) & (b4 | b12)) | ((d0 | d8) & (d4 | d12))) queue[atomicAdd(&q_count, 1)] = (uint16_t)i;
+        }
+        __syncthreads();
+        // pass 2: 16-bit brighter / darker masks of the survivors -> "has an arc of 9" -> second queue
+        const int nq1 = q_count;
+        for (int j = tid; j < nq1; j += 256) {
+            const int i = queue[j];
+            const int ty = i >> 6, tx = i & 63;
+            const uint8_t* c = &tile[(ty + 3) * kTileW + tx + 3 + ox];
+            const int v = c[0];
+            const int hi = v + thr, lo = v - thr;
+            uint32_t B = 0, D = 0;
 #define PLP_T(k, dx, dy) { const int p = c[(dy) * kTileW + (dx)]; B |= (uint32_t)(p > hi) << k; D |= (uint32_t)(p < lo) << k; }
-        PLP_T(0, 0, 3) PLP_T(1, 1, 3) PLP_T(2, 2, 2) PLP_T(3, 3, 1) PLP_T(4, 3, 0) PLP_T(5, 3, -1) PLP_T(6, 2, -2) PLP_T(7, 1, -3)
-        PLP_T(8, 0, -3) PLP_T(9, -1, -3) PLP_T(10, -2, -2) PLP_T(11, -3, -1) PLP_T(12, -3, 0) PLP_T(13, -3, 1) PLP_T(14, -2, 2) PLP_T(15, -1, 3)
+            PLP_T(0, 0, 3) PLP_T(1, 1, 3) PLP_T(2, 2, 2) PLP_T(3, 3, 1) PLP_T(4, 3, 0) PLP_T(5, 3, -1) PLP_T(6, 2, -2) PLP_T(7, 1, -3)
+            PLP_T(8, 0, -3) PLP_T(9, -1, -3) PLP_T(10, -2, -2) PLP_T(11, -3, -1) PLP_T(12, -3, 0) PLP_T(13, -3, 1) PLP_T(14, -2, 2) PLP_T(15, -1, 3)
 #undef PLP_T
-        auto arc9 = [](uint32_t m) -> bool {
-            m |= m << 16;
-            uint32_t x = m & (m >> 1);
-            x &= x >> 2;
-            x &= x >> 4;
-            x &= m >> 8;
-            return (x & 0xffffu) != 0;
-        };
-        if (arc9(B) || arc9(D)) {
-            const int slot = atomicAdd(&q_count, 1);
-            queue[slot] = (uint16_t)((ty << 6) | tx);
+            auto arc9 = [](uint32_t m) -> bool {
+                m |= m << 16;
+                uint32_t x = m & (m >> 1);
+                x &= x >> 2;
+                x &= x >> 4;
+                x &= m >> 8;
+                return (x & 0xffffu) != 0;
+            };
+            if (arc9(B) || arc9(D)) queue2[atomicAdd(&q2_count, 1)] = (uint16_t)i;
         }
-    }
-    __syncthreads();
-    // pass 2: exact score of the queued pixels (dense over the queue: no lane idles on non-corners)
-    const int nq = q_count;
-    for (int i = tid; i < nq; i += 256) {
-        const int ty = queue[i] >> 6, tx = queue[i] & 63;
-        const uint8_t* c = &tile[(ty + 3) * kTileW + tx + 3 + ox];
-        const int v = c[0];
-        int d[16];
-        d[0] = c[3 * kTileW] - v;        d[1] = c[3 * kTileW + 1] - v;    d[2] = c[2 * kTileW + 2] - v;   d[3] = c[kTileW + 3] - v;
-        d[4] = c[3] - v;                 d[5] = c[-kTileW + 3] - v;       d[6] = c[-2 * kTileW + 2] - v;  d[7] = c[-3 * kTileW + 1] - v;
-        d[8] = c[-3 * kTileW] - v;       d[9] = c[-3 * kTileW - 1] - v;   d[10] = c[-2 * kTileW - 2] - v; d[11] = c[-kTileW - 3] - v;
-        d[12] = c[-3] - v;               d[13] = c[kTileW - 3] - v;       d[14] = c[2 * kTileW - 2] - v;  d[15] = c[3 * kTileW - 1] - v;
-        // sliding min / max over windows of 9 on the ring, by doubling
-        int mn2[16], mx2[16], mn4[16], mx4[16];
+        __syncthreads();
+        // pass 3: exact score of the corners (dense over the queue: no lane idles on non-corners)
+        const int nq = q2_count;
+        for (int j = tid; j < nq; j += 256) {
+            const int ty = queue2[j] >> 6, tx = queue2[j] & 63;
+            const uint8_t* c = &tile[(ty + 3) * kTileW + tx + 3 + ox];
+            const int v = c[0];
+            int d[16];
+            d[0] = c[3 * kTileW] - v;        d[1] = c[3 * kTileW + 1] - v;    d[2] = c[2 * kTileW + 2] - v;   d[3] = c[kTileW + 3] - v;
+            d[4] = c[3] - v;                 d[5] = c[-kTileW + 3] - v;       d[6] = c[-2 * kTileW + 2] - v;  d[7] = c[-3 * kTileW + 1] - v;
+            d[8] = c[-3 * kTileW] - v;       d[9] = c[-3 * kTileW - 1] - v;   d[10] = c[-2 * kTileW - 2] - v; d[11] = c[-kTileW - 3] - v;
+            d[12] = c[-3] - v;               d[13] = c[kTileW - 3] - v;       d[14] = c[2 * kTileW - 2] - v;  d[15] = c[3 * kTileW - 1] - v;
+            // sliding min / max over windows of 9 on the ring, by doubling
+            int mn2[16], mx2[16], mn4[16], mx4[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) { mn2[k] = min(d[k], d[(k + 1) & 15]); mx2[k] = max(d[k], d[(k + 1) & 15]); }
+            for (int k = 0; k < 16; ++k) { mn2[k] = min(d[k], d[(k + 1) & 15]); mx2[k] = max(d[k], d[(k + 1) & 15]); }
 #pragma unroll
-        for (int k = 0; k < 16; ++k) { mn4[k] = min(mn2[k], mn2[(k + 2) & 15]); mx4[k] = max(mx2[k], mx2[(k + 2) & 15]); }
-        int bright = -255, dark = 255;
+            for (int k = 0; k < 16; ++k) { mn4[k] = min(mn2[k], mn2[(k + 2) & 15]); mx4[k] = max(mx2[k], mx2[(k + 2) & 15]); }
+            int bright = -255, dark = 255;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int mn9 = min3(mn4[k], mn4[(k + 4) & 15], d[(k + 8) & 15]);
-            const int mx9 = max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
-            bright = max(bright, mn9);
-            dark = min(dark, mx9);
+            for (int k = 0; k < 16; ++k) {
+                const int mn9 = min3(mn4[k], mn4[(k + 4) & 15], d[(k + 8) & 15]);
+                const int mx9 = max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
+                bright = max(bright, mn9);
+                dark = min(dark, mx9);
+            }
+            const int sc = max(bright, -dark) - 1;
+            score[(ty + 1) * kScoreW + tx + 1] = (uint8_t)(sc >= thr ? sc : 0);
         }
-        const int s = max(bright, -dark) - 1;
-        score[(ty + 1) * kScoreW + tx + 1] = (uint8_t)(s >= min_thr ? s : 0);
+        __syncthreads();
+        // pass 4: 3x3 strict NMS, only around the corners
+        int my_ini = 0;
+        for (int j = tid; j < nq; j += 256) {
+            const int ty = queue2[j] >> 6, tx = queue2[j] & 63;
+            const uint8_t* sp = &score[(ty + 1) * kScoreW + tx + 1];
+            const int v = sp[0];
+            const bool ok = v > 0 && v > sp[-1] && v > sp[1] && v > sp[-kScoreW - 1] && v > sp[-kScoreW] && v > sp[-kScoreW + 1] &&
+                            v > sp[kScoreW - 1] && v > sp[kScoreW] && v > sp[kScoreW + 1];
+            if (ok) { keep[ty * 64 + tx] = (uint8_t)v; ++my_ini; }
+        }
+        if (my_ini) atomicAdd(&n_ini, my_ini);
+        __syncthreads();
+        const int found = n_ini;
+        __syncthreads();
+        if (found > 0 || min_thr >= ini_thr) break;
     }
-    __syncthreads();
-    // pass 3: 3x3 strict NMS on the score map; count survivors at the initial threshold
-    int my_ini = 0;
-    for (int i = tid; i < 4096; i += 256) {
-        const int ty = i >> 6, tx = i & 63;
-        if (tx >= tw || ty >= th) continue;
-        const uint8_t* s = &score[(ty + 1) * kScoreW + tx + 1];
-        const int v = s[0];
-        const bool ok = v > 0 && v > s[-1] && v > s[1] && v > s[-kScoreW - 1] && v > s[-kScoreW] && v > s[-kScoreW + 1] &&
-                        v > s[kScoreW - 1] && v > s[kScoreW] && v > s[kScoreW + 1];
-        keep[ty * 64 + tx] = ok ? (uint8_t)v : 0;
-        my_ini += (ok && v >= ini_thr);
-    }
-    if (my_ini) atomicAdd(&n_ini, my_ini);
-    __syncthreads();
-    const int thr = n_ini > 0 ? ini_thr : min_thr;   // empty at ini_thr -> redo at min_thr (:408-412)
 
     // pass 4: ordered (row-major) compaction of the survivors.  Wave w owns the w-th quarter of the row-major
     // sequence: count with ballots, one barrier for the wave bases, then write (no per-step barriers).
@@ -384,7 +464,7 @@ void launch_resize(hipStream_t st, const OrbPlanes& pl, const LevelDev* h_lv, in
     const size_t sstride = level - 1 == 0 ? pl.l0_frame_stride : pl.pyr_frame_stride;
     const int spitch = level - 1 == 0 ? pl.l0_pitch : S.pitch;
     dim3 grid((D.w + 255) / 256, (D.h + 31) / 32, B), block(64, 4);
-    hipLaunchKernelGGL(k_resize_linear, grid, block, 0, st, src, sstride, spitch, pl.pyr + D.off, pl.pyr_frame_stride, D.pitch,
+    hipLaunchKernelGGL(k_resize_linear, grid, block, 0, st, src, sstride, spitch, S.w, pl.pyr + D.off, pl.pyr_frame_stride, D.pitch,
                        D.w, D.h, rs.xofs0 + rs.col_base[level], rs.xofs1 + rs.col_base[level], rs.a0 + rs.col_base[level],
                        rs.a1 + rs.col_base[level], rs.yofs0 + rs.row_base[level], rs.yofs1 + rs.row_base[level],
                        rs.b0 + rs.row_base[level], rs.b1 + rs.row_base[level]);
