@@ -67,7 +67,7 @@ plp_status run_device(plp_matcher* c, const plp_match_args* a, hipStream_t st) {
     const size_t tn_ = (size_t)a->B * a->n_cap;
     PLP_HIP(c->sorted.reserve(tn_ * sizeof(StagedTarget)));
     PLP_HIP(c->sorted_xr.reserve(tn_ * 4));
-    PLP_HIP(c->row_start.reserve((size_t)a->B * 260 * 4));
+    PLP_HIP(c->row_start.reserve((size_t)a->B * 4104 * 2));
     if (!c->dbg.p) { PLP_HIP(c->dbg.reserve(16)); PLP_HIP(hipMemsetAsync(c->dbg.p, 0, 16, st)); }
     MatchProblem P{};
     P.mode = a->mode; P.n_cap = a->n_cap; P.m_cap = a->m_cap;
@@ -87,7 +87,7 @@ plp_status run_device(plp_matcher* c, const plp_match_args* a, hipStream_t st) {
     P.grid_min_x = a->grid.min_x; P.grid_min_y = a->grid.min_y; P.inv_cell_w = a->grid.inv_cell_width; P.inv_cell_h = a->grid.inv_cell_height;
     P.grid_cols = a->grid.cols; P.grid_rows = a->grid.rows;
     P.klist = (uint32_t*)c->klist.p; P.kcount = (int32_t*)c->kcount.p; P.claim = (int32_t*)c->claim.p; P.full_list = (int32_t*)c->full_list.p;
-    P.sorted = (StagedTarget*)c->sorted.p; P.sorted_xr = (float*)c->sorted_xr.p; P.row_start = (int32_t*)c->row_start.p; P.dbg = (int32_t*)c->dbg.p;
+    P.sorted = (StagedTarget*)c->sorted.p; P.sorted_xr = (float*)c->sorted_xr.p; P.cell_start = (uint16_t*)c->row_start.p; P.dbg = (int32_t*)c->dbg.p;
     P.out_match = a->out_match; P.out_num = a->out_num;
     launch_match(st, P, a->B);
     PLP_HIP(hipGetLastError());

@@ -58,7 +58,7 @@ struct MatchProblem {
     int32_t* full_list;              // B x m_cap
     StagedTarget* sorted;            // B x n_cap: free in-grid targets bucketed by grid row
     float* sorted_xr;                // B x n_cap
-    int32_t* row_start;              // B x 260
+    uint16_t* cell_start;            // B x 4104: first position of every grid cell in `sorted`
     int sorted_valid;                // set by launch_match when k_match_prep ran
     int32_t* dbg;                    // 4 counters: exact rescans, resolve rounds (accumulated)
     int32_t* out_match;              // B x n_cap: query index per key point, -1 = none

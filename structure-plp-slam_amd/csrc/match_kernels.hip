@@ -289,69 +289,198 @@ __global__ __launch_bounds__(256) void k_match_topk(MatchProblem P) {
 //   windowed modes: {x, y, octave | cell col | cell row, index} (+4 B stereo x_right)
 //   brute force:    the 32-byte descriptors themselves are staged
 constexpr int kQueriesPerBlock = 128;
-constexpr int kRowStride = 260;    // row_start[257] per frame, padded
+constexpr int kCellStride = 4104;  // cell_start[cols * rows + 1] per frame (<= 4097 entries), padded
 
+// k_match_prep: the free, in-grid targets of a frame sorted by (grid column, grid row, index) -- the order in which
+// data::get_keypoints_in_cell visits them (common.cc:271-309) -- so that a candidate's rank in the reference's visiting
+// order is simply its position in this array (16 bits), and a window is one contiguous range per grid column.
 // grid = (B), block = 256.
 __global__ __launch_bounds__(256) void k_match_prep(MatchProblem P) {
-    __shared__ int row_start[257], row_fill[256];
+    __shared__ int cnt[4096];
+    __shared__ uint16_t start[4098];
+    __shared__ uint16_t tmp_t[8192];
+    __shared__ int part[256];
     const int tid = threadIdx.x, b = blockIdx.x;
     const int n = P.t_counts ? P.t_counts[b] : P.n_cap;
+    const int ncell = P.grid_cols * P.grid_rows;
     const plp_keypoint* kps = P.t_kps + (size_t)b * P.n_cap;
     const float* t_xr = P.t_x_right ? P.t_x_right + (size_t)b * P.n_cap : nullptr;
     const uint8_t* t_occ = P.t_occupied ? P.t_occupied + (size_t)b * P.n_cap : nullptr;
     StagedTarget* st = P.sorted + (size_t)b * P.n_cap;
     float* sxr = P.sorted_xr + (size_t)b * P.n_cap;
-    for (int i = tid; i < 257; i += 256) row_start[i] = 0;
-    if (tid < 256) row_fill[tid] = 0;
+    for (int i = tid; i < 4096; i += 256) cnt[i] = 0;
     __syncthreads();
     auto cell_of = [&](const plp_keypoint& k, int t, int& cx, int& cy) -> bool {
         cx = floor_d((double)__fsub_rn(k.x, P.grid_min_x) * P.inv_cell_w);
         cy = floor_d((double)__fsub_rn(k.y, P.grid_min_y) * P.inv_cell_h);
         return cx >= 0 && cx < P.grid_cols && cy >= 0 && cy < P.grid_rows && !(t_occ && t_occ[t]);
     };
-    for (int t = tid; t < n; t += 256) {   // pass 1: bucket sizes
+    for (int t = tid; t < n; t += 256) {   // pass 1: cell sizes
         int cx, cy;
-        if (cell_of(kps[t], t, cx, cy)) atomicAdd(&row_start[cy + 1], 1);
+        if (cell_of(kps[t], t, cx, cy)) atomicAdd(&cnt[cx * P.grid_rows + cy], 1);
     }
     __syncthreads();
-    if (tid == 0) for (int r = 0; r < P.grid_rows; ++r) row_start[r + 1] += row_start[r];
+    {   // exclusive scan over the cells: 16 cells per thread + a scan of the 256 partial sums
+        int sum = 0;
+        for (int i = 0; i < 16; ++i) sum += cnt[tid * 16 + i];
+        part[tid] = sum;
+        __syncthreads();
+        int base = 0;
+        for (int i = 0; i < tid; ++i) base += part[i];
+        for (int i = 0; i < 16; ++i) { start[tid * 16 + i] = (uint16_t)base; base += cnt[tid * 16 + i]; }
+        if (tid == 255) { start[4096] = (uint16_t)base; start[4097] = (uint16_t)base; }
+        __syncthreads();
+        for (int i = tid; i < 4096; i += 256) cnt[i] = 0;
+        __syncthreads();
+    }
+    for (int t = tid; t < n; t += 256) {   // pass 2: unordered placement inside the cell
+        int cx, cy;
+        if (!cell_of(kps[t], t, cx, cy)) continue;
+        const int cell = cx * P.grid_rows + cy;
+        tmp_t[start[cell] + atomicAdd(&cnt[cell], 1)] = (uint16_t)t;
+    }
     __syncthreads();
-    for (int t = tid; t < n; t += 256) {   // pass 2: scatter
+    const int used = start[4096];
+    for (int p = tid; p < used; p += 256) {   // pass 3: rank inside the cell by index, final record
+        const int t = tmp_t[p];
         const plp_keypoint k = kps[t];
         int cx, cy;
-        if (!cell_of(k, t, cx, cy)) continue;
-        const int pos = row_start[cy] + atomicAdd(&row_fill[cy], 1);
+        cell_of(k, t, cx, cy);
+        const int cell = cx * P.grid_rows + cy, s0 = start[cell], s1 = start[cell + 1];
+        int rank = 0;
+        for (int j = s0; j < s1; ++j) rank += (int)tmp_t[j] < t;
         StagedTarget r;
         r.x = k.x; r.y = k.y; r.packed = ((uint32_t)k.octave & 0xffu) | ((uint32_t)cx << 8) | ((uint32_t)cy << 16); r.t = (uint32_t)t;
-        st[pos] = r;
-        if (t_xr) sxr[pos] = t_xr[t];
+        st[s0 + rank] = r;
+        if (t_xr) sxr[s0 + rank] = t_xr[t];
     }
-    for (int i = tid; i < 257; i += 256) P.row_start[(size_t)b * kRowStride + i] = row_start[min(i, P.grid_rows)];
+    for (int i = tid; i <= ncell; i += 256) P.cell_start[(size_t)b * kCellStride + i] = start[min(i, 4096)];
 }
 
-// grid = (ceil(m_cap / kQueriesPerBlock), B), block = 256, dynamic LDS = staged bytes.
+// 16-lane (DPP row) reductions: four queries share a wave
+__device__ __forceinline__ uint32_t row16_min_u32(uint32_t v) {
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xf, 0xf, false));   // row_ror:8
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x124, 0xf, 0xf, false));   // row_ror:4
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x122, 0xf, 0xf, false));   // row_ror:2
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x121, 0xf, 0xf, false));   // row_ror:1
+    return v;
+}
+__device__ __forceinline__ int row16_sum_i32(int v) {
+    v += __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(v, v, 0x124, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(v, v, 0x122, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(v, v, 0x121, 0xf, 0xf, false);
+    return v;
+}
+
+// Main path of the point projection matchers.  The workgroup copies the frame's sorted targets (16 B each), their
+// stereo coordinates and the cell index into LDS once and reuses them for kQueriesPerBlock queries.  A query is served
+// by 16 lanes (four queries per wave): lane s walks grid columns min_cx + s, + 16, ... of the window, each column being
+// one contiguous range of the sorted array, so only the window's cells are touched.  Keys are 32 bits
+// (distance << 16 | position in visiting order); the 8 best are merged with DPP row reductions.
+// grid = (ceil(m_cap / kQueriesPerBlock), B), block = 256, dynamic LDS = n_cap * 20 + 2 * kCellStride bytes.
+__global__ __launch_bounds__(256) void k_match_topk_cells(MatchProblem P) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, sub = tid & 15, grp = tid >> 4, b = blockIdx.y;
+    const int m = P.q_counts ? P.q_counts[b] : P.m_cap;
+    const int q_begin = blockIdx.x * kQueriesPerBlock;
+    if (q_begin >= m) return;
+    const int ncell = P.grid_cols * P.grid_rows, rows = P.grid_rows;
+    const uint8_t* t_desc = P.t_desc + (size_t)b * P.n_cap * 32;
+    StagedTarget* st = reinterpret_cast<StagedTarget*>(smem);
+    float* sxr = reinterpret_cast<float*>(smem + (size_t)P.n_cap * sizeof(StagedTarget));
+    uint16_t* cs = reinterpret_cast<uint16_t*>(smem + (size_t)P.n_cap * (sizeof(StagedTarget) + 4));
+    const bool has_xr = P.t_x_right != nullptr;
+    {
+        const uint16_t* gcs = P.cell_start + (size_t)b * kCellStride;
+        const int used = gcs[ncell];
+        const uint4* src = reinterpret_cast<const uint4*>(P.sorted + (size_t)b * P.n_cap);
+        for (int i = tid; i < used; i += 256) reinterpret_cast<uint4*>(st)[i] = src[i];
+        if (has_xr) for (int i = tid; i < used; i += 256) sxr[i] = P.sorted_xr[(size_t)b * P.n_cap + i];
+        const uint32_t* g32 = reinterpret_cast<const uint32_t*>(gcs);
+        for (int i = tid; i < (ncell + 2) / 2; i += 256) reinterpret_cast<uint32_t*>(cs)[i] = g32[i];
+    }
+    __syncthreads();
+    const uint8_t* q_valid = P.q_valid ? P.q_valid + (size_t)b * P.m_cap : nullptr;
+    const int q_end = min(m, q_begin + kQueriesPerBlock);
+    for (int q = q_begin + grp; q < q_begin + kQueriesPerBlock; q += 16) {   // same trip count for every lane of the wave
+        const bool in_range = q < q_end;
+        const bool active = in_range && !(q_valid && !q_valid[q]);
+        uint32_t top[kMatchK];
+#pragma unroll
+        for (int i = 0; i < kMatchK; ++i) top[i] = 0xffffffffu;
+        int passed = 0;
+        if (active) {
+            const QueryCtx c = make_query(P, q, b);
+            if (!c.empty) {
+                const uint4* qd = reinterpret_cast<const uint4*>(P.q_desc + ((size_t)b * P.m_cap + q) * 32);
+                const uint4 q0 = qd[0], q1 = qd[1];
+                const bool check_level = (0 < c.min_level) || (0 <= c.max_level);
+                for (int col = c.min_cx + sub; col <= c.max_cx; col += 16) {
+                    const int i0 = cs[col * rows + c.min_cy], i1 = cs[col * rows + c.max_cy + 1];
+                    for (int i = i0; i < i1; ++i) {
+                        const StagedTarget s = st[i];
+                        const int oct = (int)(s.packed & 0xff);
+                        if (check_level) {
+                            if (oct < c.min_level) continue;
+                            if (0 <= c.max_level && c.max_level < oct) continue;
+                        }
+                        if (!(fabsf(__fsub_rn(s.x, c.rx)) < c.mg && fabsf(__fsub_rn(s.y, c.ry)) < c.mg)) continue;
+                        if (has_xr) {
+                            const float xr = sxr[i];
+                            if (0 < xr && c.mg < fabsf(__fsub_rn(c.xr, xr))) continue;
+                        }
+                        const uint4* d = reinterpret_cast<const uint4*>(t_desc + 32 * (size_t)s.t);
+                        const uint32_t key = (hamming256(q0, q1, d[0], d[1]) << 16) | (uint32_t)i;
+                        ++passed;
+                        if (key < top[kMatchK - 1]) {
+                            top[kMatchK - 1] = key;
+#pragma unroll
+                            for (int k = kMatchK - 1; k > 0; --k)
+                                if (top[k] < top[k - 1]) { const uint32_t w = top[k]; top[k] = top[k - 1]; top[k - 1] = w; }
+                        }
+                    }
+                }
+            }
+        }
+        passed = row16_sum_i32(passed);
+        uint32_t mine = 0xffffffffu;   // lane s of the group ends up with the s-th best key
+#pragma unroll
+        for (int r = 0; r < kMatchK; ++r) {
+            const uint32_t mn = row16_min_u32(top[0]);
+            if (sub == r) mine = mn;
+            if (top[0] == mn && mn != 0xffffffffu) {
+#pragma unroll
+                for (int i = 0; i + 1 < kMatchK; ++i) top[i] = top[i + 1];
+                top[kMatchK - 1] = 0xffffffffu;
+            }
+        }
+        if (in_range) {
+            if (sub < kMatchK) {
+                uint32_t e = 0xffffffffu;
+                if (mine != 0xffffffffu) {
+                    const StagedTarget s = st[mine & 0xffffu];
+                    e = ((mine >> 16) << 20) | ((s.packed & 15u) << 16) | (s.t & 0xffffu);
+                }
+                P.klist[((size_t)b * P.m_cap + q) * kMatchK + sub] = e;
+            }
+            if (sub == 0) P.kcount[(size_t)b * P.m_cap + q] = active ? passed : -1;
+        }
+    }
+}
+
+// Brute-force mode: the frame's 32-byte descriptors are staged in LDS, one wave per query scans them all.
+// grid = (ceil(m_cap / kQueriesPerBlock), B), block = 256, dynamic LDS = n_cap * 32 bytes.
 __global__ __launch_bounds__(256) void k_match_topk_lds(MatchProblem P) {
-    extern __shared__ uint8_t smem[];
-    __shared__ int row_start[257];
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.y;
     const int m = P.q_counts ? P.q_counts[b] : P.m_cap;
     const int q_begin = blockIdx.x * kQueriesPerBlock;
     if (q_begin >= m) return;
     const int n = P.t_counts ? P.t_counts[b] : P.n_cap;
-    const bool windowed = P.mode != PLP_MATCH_MODE_BRUTE_FORCE;
     const uint8_t* t_desc = P.t_desc + (size_t)b * P.n_cap * 32;
-    StagedTarget* st = reinterpret_cast<StagedTarget*>(smem);
-    float* sxr = reinterpret_cast<float*>(smem + (size_t)P.n_cap * sizeof(StagedTarget));
     uint4* sdesc = reinterpret_cast<uint4*>(smem);
-    const bool has_xr = P.t_x_right != nullptr;
-    if (windowed) {
-        for (int i = tid; i < 257; i += 256) row_start[i] = P.row_start[(size_t)b * kRowStride + i];
-        __syncthreads();
-        const int used = row_start[P.grid_rows];
-        const uint4* src = reinterpret_cast<const uint4*>(P.sorted + (size_t)b * P.n_cap);
-        for (int i = tid; i < used; i += 256) reinterpret_cast<uint4*>(st)[i] = src[i];
-        if (has_xr) for (int i = tid; i < used; i += 256) sxr[i] = P.sorted_xr[(size_t)b * P.n_cap + i];
-    } else {
+    {
         const uint4* src = reinterpret_cast<const uint4*>(t_desc);
         for (int i = tid; i < 2 * n; i += 256) sdesc[i] = src[i];
     }
@@ -361,41 +490,16 @@ __global__ __launch_bounds__(256) void k_match_topk_lds(MatchProblem P) {
         uint32_t* klist = P.klist + ((size_t)b * P.m_cap + q) * kMatchK;
         int32_t* kcount = P.kcount + (size_t)b * P.m_cap + q;
         if (q_valid && !q_valid[q]) { if (lane == 0) *kcount = -1; continue; }
-        const QueryCtx c = make_query(P, q, b);
         const uint4* qd = reinterpret_cast<const uint4*>(P.q_desc + ((size_t)b * P.m_cap + q) * 32);
         const uint4 q0 = qd[0], q1 = qd[1];
         unsigned long long top[kMatchK];
 #pragma unroll
         for (int i = 0; i < kMatchK; ++i) top[i] = ~0ull;
         int passed = 0;
-        if (!windowed) {
-            for (int t = lane; t < n; t += 64) {
-                const unsigned dist = hamming256(q0, q1, sdesc[2 * t], sdesc[2 * t + 1]);
-                ++passed;
-                topk_insert(top, ((unsigned long long)dist << 32) | ((unsigned long long)(unsigned)t << 4));
-            }
-        } else if (!c.empty) {
-            const bool check_level = (0 < c.min_level) || (0 <= c.max_level);
-            const int i0 = row_start[c.min_cy], i1 = row_start[c.max_cy + 1];   // only the grid rows the window overlaps
-            for (int i = i0 + lane; i < i1; i += 64) {
-                const StagedTarget s = st[i];
-                const int oct = (int)(s.packed & 0xff), cx = (int)((s.packed >> 8) & 0xff), cy = (int)(s.packed >> 16);
-                if (cx < c.min_cx || cx > c.max_cx) continue;
-                if (check_level) {
-                    if (oct < c.min_level) continue;
-                    if (0 <= c.max_level && c.max_level < oct) continue;
-                }
-                if (!(fabsf(__fsub_rn(s.x, c.rx)) < c.mg && fabsf(__fsub_rn(s.y, c.ry)) < c.mg)) continue;
-                if (has_xr) {
-                    const float xr = sxr[i];
-                    if (0 < xr && c.mg < fabsf(__fsub_rn(c.xr, xr))) continue;
-                }
-                const uint4* d = reinterpret_cast<const uint4*>(t_desc + 32 * (size_t)s.t);
-                const unsigned dist = hamming256(q0, q1, d[0], d[1]);
-                const unsigned order = ((unsigned)(cx * P.grid_rows + cy) << 16) | s.t;
-                ++passed;
-                topk_insert(top, ((unsigned long long)dist << 32) | ((unsigned long long)order << 4) | (unsigned)(oct & 15));
-            }
+        for (int t = lane; t < n; t += 64) {
+            const unsigned dist = hamming256(q0, q1, sdesc[2 * t], sdesc[2 * t + 1]);
+            ++passed;
+            topk_insert(top, ((unsigned long long)dist << 32) | ((unsigned long long)(unsigned)t << 4));
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) passed += __shfl_xor(passed, o);
@@ -448,7 +552,7 @@ __global__ __launch_bounds__(256) void k_match_resolve(MatchProblem P) {
     const bool use_sorted = P.sorted_valid != 0;
     const StagedTarget* sorted = P.sorted + (size_t)b * P.n_cap;
     const float* sorted_xr = P.sorted_xr + (size_t)b * P.n_cap;
-    const int32_t* g_row_start = P.row_start + (size_t)b * 260;
+    const uint16_t* g_cell_start = P.cell_start + (size_t)b * kCellStride;
     // Rounds of "claim[q] = best free candidate given the claims of the queries before q".  Within a round the
     // queries are swept in chunks of 256 in index order (Gauss-Seidel): a chunk sees THIS round's claims of all
     // earlier chunks (owner_next, rebuilt as the sweep advances) and the previous round's claims of the earlier
@@ -508,26 +612,27 @@ __global__ __launch_bounds__(256) void k_match_resolve(MatchProblem P) {
                 if (use_sorted) {
                     if (!c.empty) {
                         const bool check_level = (0 < c.min_level) || (0 <= c.max_level);
-                        const int i0 = g_row_start[c.min_cy], i1 = g_row_start[c.max_cy + 1];
-                        for (int i = i0 + lane; i < i1; i += 64) {
-                            const StagedTarget s = sorted[i];
-                            const int oct = (int)(s.packed & 0xff), cx = (int)((s.packed >> 8) & 0xff), cy = (int)(s.packed >> 16);
-                            if (cx < c.min_cx || cx > c.max_cx) continue;
-                            if (check_level) {
-                                if (oct < c.min_level) continue;
-                                if (0 <= c.max_level && c.max_level < oct) continue;
+                        for (int col = c.min_cx; col <= c.max_cx; ++col) {
+                            const int i0 = g_cell_start[col * P.grid_rows + c.min_cy], i1 = g_cell_start[col * P.grid_rows + c.max_cy + 1];
+                            for (int i = i0 + lane; i < i1; i += 64) {
+                                const StagedTarget s = sorted[i];
+                                const int oct = (int)(s.packed & 0xff);
+                                if (check_level) {
+                                    if (oct < c.min_level) continue;
+                                    if (0 <= c.max_level && c.max_level < oct) continue;
+                                }
+                                if (!(fabsf(__fsub_rn(s.x, c.rx)) < c.mg && fabsf(__fsub_rn(s.y, c.ry)) < c.mg)) continue;
+                                if (t_xr) {
+                                    const float xr = sorted_xr[i];
+                                    if (0 < xr && c.mg < fabsf(__fsub_rn(c.xr, xr))) continue;
+                                }
+                                if (taken((int)s.t, fq, chunk_start)) continue;
+                                const uint4* d = reinterpret_cast<const uint4*>(t_desc + 32 * (size_t)s.t);
+                                const unsigned dist = hamming256(q0, q1, d[0], d[1]);
+                                // visiting order = position in the (column, row, index)-sorted array
+                                const unsigned long long key = ((unsigned long long)dist << 32) | ((unsigned long long)(unsigned)i << 4) | (unsigned)(oct & 15);
+                                if (key < k0) { k1 = k0; k0 = key; } else if (key < k1) k1 = key;
                             }
-                            if (!(fabsf(__fsub_rn(s.x, c.rx)) < c.mg && fabsf(__fsub_rn(s.y, c.ry)) < c.mg)) continue;
-                            if (t_xr) {
-                                const float xr = sorted_xr[i];
-                                if (0 < xr && c.mg < fabsf(__fsub_rn(c.xr, xr))) continue;
-                            }
-                            if (taken((int)s.t, fq, chunk_start)) continue;
-                            const uint4* d = reinterpret_cast<const uint4*>(t_desc + 32 * (size_t)s.t);
-                            const unsigned dist = hamming256(q0, q1, d[0], d[1]);
-                            const unsigned order = ((unsigned)(cx * P.grid_rows + cy) << 16) | s.t;
-                            const unsigned long long key = ((unsigned long long)dist << 32) | ((unsigned long long)order << 4) | (unsigned)(oct & 15);
-                            if (key < k0) { k1 = k0; k0 = key; } else if (key < k1) k1 = key;
                         }
                     }
                 } else if (!(c.windowed && c.empty)) {
@@ -544,7 +649,8 @@ __global__ __launch_bounds__(256) void k_match_resolve(MatchProblem P) {
                     if (g0 != ~0ull) {
                         const unsigned second = g1 != ~0ull ? (unsigned)(g1 >> 32) : 256u;
                         const int second_lvl = g1 != ~0ull ? (int)(g1 & 15) : -1;
-                        if (accept(P, (unsigned)(g0 >> 32), (int)(g0 & 15), second, second_lvl)) nc = (int)(((g0 >> 4) & 0xffff) ^ t_flip);
+                        if (accept(P, (unsigned)(g0 >> 32), (int)(g0 & 15), second, second_lvl))
+                            nc = use_sorted ? (int)sorted[(g0 >> 4) & 0xffff].t : (int)(((g0 >> 4) & 0xffff) ^ t_flip);
                     }
                     s_claim_tmp[fq - chunk_start] = nc;
                 }
@@ -762,11 +868,14 @@ void launch_match(hipStream_t st, const MatchProblem& P, int B) {
     Q.sorted_valid = 0;
     const bool windowed = P.mode == PLP_MATCH_MODE_LANDMARKS || P.mode == PLP_MATCH_MODE_LAST_FRAME;
     const bool line = is_line_mode_host(P.mode) || P.mode == PLP_MATCH_MODE_BOW || P.mode == PLP_MATCH_MODE_TRIANGULATION;
-    const size_t staged = windowed ? (size_t)P.n_cap * (sizeof(StagedTarget) + (P.t_x_right ? 4 : 0)) : (size_t)P.n_cap * 32;
-    if (!line && staged <= 64 * 1024 && (!windowed || (P.grid_cols <= 255 && P.grid_rows <= 255))) {
-        if (windowed) hipLaunchKernelGGL(k_match_prep, dim3(B), dim3(256), 0, st, P);
-        Q.sorted_valid = windowed ? 1 : 0;
-        hipLaunchKernelGGL(k_match_topk_lds, dim3((P.m_cap + kQueriesPerBlock - 1) / kQueriesPerBlock, B), dim3(256), staged, st, P);
+    const size_t staged = windowed ? (size_t)P.n_cap * (sizeof(StagedTarget) + 4) + 2 * kCellStride : (size_t)P.n_cap * 32;
+    const dim3 qgrid((P.m_cap + kQueriesPerBlock - 1) / kQueriesPerBlock, B);
+    if (!line && windowed && staged <= 64 * 1024 && P.grid_cols <= 255 && P.grid_rows <= 255) {
+        hipLaunchKernelGGL(k_match_prep, dim3(B), dim3(256), 0, st, P);
+        Q.sorted_valid = 1;
+        hipLaunchKernelGGL(k_match_topk_cells, qgrid, dim3(256), staged, st, P);
+    } else if (!line && !windowed && staged <= 64 * 1024) {
+        hipLaunchKernelGGL(k_match_topk_lds, qgrid, dim3(256), staged, st, P);
     } else
         hipLaunchKernelGGL(k_match_topk, dim3((P.m_cap + 3) / 4, B), dim3(256), 0, st, P);
     hipLaunchKernelGGL(k_match_resolve, dim3(B), dim3(256), (size_t)P.n_cap * 8, st, Q);
