@@ -1,0 +1,14 @@
+#!/bin/sh
+# TEST INFRASTRUCTURE ONLY.  Builds oracle/_ref/libplpref.so from the reference's own ORB extractor sources, read in
+# place from /root/reference (nothing is copied into this repository), against oracle/ref_shim.  Skipped when the
+# reference is not mounted (GPU box): the prebuilt .so travels with the snapshot.
+set -e
+HERE=$(cd "$(dirname "$0")" && pwd)
+REF=${PLP_REFERENCE:-/root/reference}
+if [ ! -d "$REF/src/PLPSLAM/feature" ]; then echo "ref_build: $REF not present, keeping prebuilt oracle/_ref"; exit 0; fi
+mkdir -p "$HERE/_ref"
+g++ -O2 -std=c++17 -fPIC -shared -Wl,-Bsymbolic -ffp-contract=off -fno-fast-math -DUSE_DBOW2 \
+    -I"$HERE/ref_shim" -I"$REF/src" \
+    "$REF/src/PLPSLAM/feature/orb_extractor.cc" "$REF/src/PLPSLAM/feature/orb_extractor_node.cc" "$REF/src/PLPSLAM/feature/orb_params.cc" \
+    "$HERE/ref_driver.cpp" -o "$HERE/_ref/libplpref.so"
+echo "ref_build: built $HERE/_ref/libplpref.so"
