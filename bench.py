@@ -113,6 +113,12 @@ def main():
     m2 = torch.empty((B, cap), dtype=torch.int32, device=dev); n2 = torch.zeros(B, dtype=torch.int32, device=dev)
     ex = plp.orb_extractor(K, device=local_rank)
     lt = plp.LineFeatureTracker(device=local_rank)
+    # The line path is one long dependent chain per launch (region growing is a single latency-bound wave per frame), so
+    # the batch is cut into n_line contiguous sub-blocks, each with its own context (scratch planes) and HIP stream.
+    n_line = max(1, int(os.environ.get("PLP_BENCH_LINE_SPLIT", "4")))
+    while B % n_line:
+        n_line -= 1
+    lts = [lt] + [plp.LineFeatureTracker(device=local_rank) for _ in range(n_line - 1)]
     mt_last = plp.matcher(0.9, True, device=local_rank)     # motion_based_track: match::projection(0.9, true)
     mt_lm = plp.matcher(0.8, True, device=local_rank)       # search_local_landmarks: match::projection(0.8)
     grid = plp.make_grid(args.cols, args.rows)
@@ -121,6 +127,7 @@ def main():
     sA = torch.cuda.Stream(dev)
     serial = bool(os.environ.get("PLP_BENCH_SERIAL"))                            # diagnostic: one stream for everything
     sB = sA if serial else torch.cuda.Stream(dev)
+    sBs = [sB] + [sA if serial else torch.cuda.Stream(dev) for _ in range(n_line - 1)]
     slot = torch.arange(cap, device=dev, dtype=torch.int32)[None, :]
 
     replay = importlib.import_module("structure-plp-slam_amd.replay")
@@ -159,7 +166,10 @@ def main():
             sA.wait_event(done_match[buf])          # the matchers of step n - 2 have read this set
         ex.extract_batch(d_frames, kps2[buf], desc2[buf], cnt2[buf], stream=sA)
         if not args.orb_only:
-            lt.extract_batch(d_frames, d_kl, d_lbd, d_fn, d_lcnt, stream=sB)
+            bs = B // n_line
+            for i, (lti, sbi) in enumerate(zip(lts, sBs)):
+                sl = slice(i * bs, (i + 1) * bs)
+                lti.extract_batch(d_frames[sl], d_kl[sl], d_lbd[sl], d_fn[sl], d_lcnt[sl], stream=sbi)
             ready = torch.cuda.Event(); ready.record(sA)
             sC.wait_event(ready)
             with torch.cuda.stream(sC):
@@ -172,7 +182,9 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    sA.wait_stream(cur); sB.wait_stream(cur)
+    sA.wait_stream(cur)
+    for sbi in sBs:
+        sbi.wait_stream(cur)
     for _ in range(args.warmup):
         step()
     barrier()
@@ -183,7 +195,8 @@ def main():
     elapsed = time.perf_counter() - t0
     ex.last_batch_status()
     if not args.orb_only:
-        lt.last_batch_status()
+        for lti in lts:
+            lti.last_batch_status()
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -249,20 +249,20 @@ __device__ __forceinline__ void set_used(const GrowCtx& g, int p) { atomicOr(&g.
 // neighbourhoods of the batch is invalidated in the later one once accepted.  Undefined pixels are pre-marked
 // USED, so no NOTDEF test; a pixel that is USED when the batch is fetched needs no data at all (USED bits are
 // only ever set while a region grows), so a region interior costs almost no HBM sectors.
-// Latency hiding: (a) the seed's own record and its 8 neighbours arrive with the call (`pre`, fetched for 64 seeds
-// at once by the caller), so a region that never leaves its seed costs no memory round trip; (b) while a full batch
-// is being decided, the records of the NEXT seven region points (when they already exist) are in flight.  A
-// prefetched record is immutable; only its USED bit is re-read when the batch is taken up.
+// The seed's own record arrives with the call (fetched for 64 seeds at once by the caller).  Neighbour prefetching
+// and a look-ahead over the next batch were tried and removed again: the gathers mostly hit in L2 (~800 cycles per
+// round) while the extra broadcasts cost 16 % more instructions in a kernel that is issue-bound once the other
+// streams fill the SIMDs (profiles/r01g_sq_counters.md).
 // The centroid sums of region2rect are not accumulated here any more: most regions are smaller than min_reg_size
 // and are dropped, the others get them from centroid_sums() (same order of additions).
-struct SeedPre { bool use; bool ok; float seed_deg; float deg; float2 cs; };   // ok/deg/cs: lanes 0..8 = the seed's neighbourhood
-
-__device__ int region_grow(const GrowCtx& g, int seed, const SeedPre& pre, double prec, double& reg_angle) {
+__device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed_deg, double prec, double& reg_angle) {
     const int lane = g.lane;
     int nreg = 1;
     const int sx = seed % g.sw, sy = seed / g.sw;
-    reg_angle = (double)(pre.use ? pre.seed_deg : g.pix[seed].deg) * (3.14159265358979323846 / 180);
-    float sumdx = (float)cos(reg_angle), sumdy = (float)sin(reg_angle);
+    reg_angle = (double)(have_deg ? seed_deg : g.pix[seed].deg) * (3.14159265358979323846 / 180);
+    double s_sin, s_cos;
+    sincos(reg_angle, &s_sin, &s_cos);
+    float sumdx = (float)s_cos, sumdy = (float)s_sin;
     if (lane == 0) {
         const uint32_t c = (uint32_t)sx | ((uint32_t)sy << 16);
         g.reg[0] = c; g.ring[0] = c;
@@ -271,53 +271,25 @@ __device__ int region_grow(const GrowCtx& g, int seed, const SeedPre& pre, doubl
     __builtin_amdgcn_wave_barrier();
     const int slot = lane / 9, k9 = lane - slot * 9;   // slot 0..6 (lane 63: slot 7, idle)
     const int ddx = k9 % 3 - 1, ddy = k9 / 3 - 1;
-    // look-ahead state: this lane's record for region point la_idx (valid iff la_have)
-    bool la_have = false, la_cand = false;
-    int la_idx = -1, la_nx = 0, la_ny = 0;
-    float la_deg = 0.f;
-    float2 la_cs = make_float2(0.f, 0.f);
-    auto point_of = [&](int idx, int cur_nreg) -> uint32_t {
-        if (cur_nreg > idx + g.ring_mask + 1) return __hip_atomic_load(&g.reg[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // left the LDS ring
-        return g.ring[idx & g.ring_mask];
-    };
     for (int i = 0; i < nreg;) {
         const int nb = min(7, nreg - i);
-        const bool active = slot < nb;
-        bool cand = false;
+        bool cand = slot < nb;
         int nx = 0, ny = 0, np = 0;
         float deg = 0.f;
         float2 ncs = make_float2(0.f, 0.f);
-        if (i == 0 && pre.use) {                       // the seed's neighbourhood came with the call
-            nx = sx + ddx; ny = sy + ddy; np = ny * g.sw + nx;
-            cand = active && pre.ok && !is_used(g, np);
-            deg = pre.deg; ncs = pre.cs;
-        } else if (active) {
-            if (la_have && la_idx == i + slot) {        // fetched while the previous batch was being decided
-                nx = la_nx; ny = la_ny; np = ny * g.sw + nx;
-                cand = la_cand && !is_used(g, np);
-                deg = la_deg; ncs = la_cs;
-            } else {
-                const uint32_t c = point_of(i + slot, nreg);
-                nx = (int)(c & 0xffff) + ddx; ny = (int)(c >> 16) + ddy; np = ny * g.sw + nx;
-                cand = nx >= 0 && ny >= 0 && nx < g.sw && ny < g.sh && !is_used(g, np);
-                if (cand) { const LsdPix px = g.pix[np]; deg = px.deg; ncs = px.cs; }
-            }
+        {
+            uint32_t c = 0;
+            if (nreg > i + g.ring_mask + 1) {   // frontier outgrew the LDS ring: read the HBM copy (uniform branch)
+                if (cand) c = __hip_atomic_load(&g.reg[i + slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else c = g.ring[(i + min(slot, 6)) & g.ring_mask];
+            nx = (int)(c & 0xffff) + ddx; ny = (int)(c >> 16) + ddy;
         }
-        // ---- look ahead: region points i+7 .. i+13 that exist already
-        la_have = false;
-        if (nb == 7 && nreg > i + 7) {   // uniform
-            const int idx = i + 7 + slot;
-            if (slot < 7 && idx < nreg) {
-                const uint32_t c = point_of(idx, nreg);
-                la_nx = (int)(c & 0xffff) + ddx; la_ny = (int)(c >> 16) + ddy;
-                const int p2 = la_ny * g.sw + la_nx;
-                la_cand = la_nx >= 0 && la_ny >= 0 && la_nx < g.sw && la_ny < g.sh && !is_used(g, p2);
-                if (la_cand) { const LsdPix px = g.pix[p2]; la_deg = px.deg; la_cs = px.cs; }
-                la_have = true; la_idx = idx;
-            }
-        }
+        cand = cand && nx >= 0 && ny >= 0 && nx < g.sw && ny < g.sh;
+        np = ny * g.sw + nx;
+        if (cand) cand = !is_used(g, np);
+        if (cand) { const LsdPix px = g.pix[np]; deg = px.deg; ncs = px.cs; }   // 16 bytes per live neighbour
         const double a = (double)deg * (3.14159265358979323846 / 180);
-        // ---- acceptances in order (no global-memory traffic inside: the look-ahead loads stay in flight)
+        // ---- acceptances in order (no global-memory traffic inside)
         const int n_before = nreg;
         int last = -1;
         while (true) {
@@ -452,46 +424,16 @@ __global__ __launch_bounds__(256) void k_lsd_grow(LinePlanes P, LsdParams lp, in
         // most seeds are already inside an earlier region: test the 64 USED bits in parallel, visit the rest in order
         const bool fresh = in_range && !is_used(g, (int)mine);
         unsigned long long todo = __ballot(fresh);
-        // every still-unused seed of this group of 64 fetches its own record and its 8 neighbours' now: one memory
-        // round trip for up to 64 regions instead of two per region
-        float s_deg = 0.f, n_deg[9];
-        float2 n_cs[9];
-        unsigned n_ok = 0;
-        if (fresh) {
-            const int sx = (int)mine % g.sw, sy = (int)mine / g.sw;
-            s_deg = g.pix[mine].deg;
-#pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                n_deg[k] = 0.f; n_cs[k] = make_float2(0.f, 0.f);
-                if (k == 4) continue;
-                const int nx = sx + k % 3 - 1, ny = sy + k / 3 - 1;
-                if (nx >= 0 && ny >= 0 && nx < g.sw && ny < g.sh && !is_used(g, ny * g.sw + nx)) {
-                    const LsdPix px = g.pix[ny * g.sw + nx];
-                    n_deg[k] = px.deg; n_cs[k] = px.cs; n_ok |= 1u << k;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 9; ++k) { n_deg[k] = 0.f; n_cs[k] = make_float2(0.f, 0.f); }
-        }
+        // every still-unused seed of this group of 64 fetches its own record now: one round trip for up to 64 regions
+        const float s_deg = fresh ? g.pix[mine].deg : 0.f;
         while (todo) {
             const int t = __ffsll((long long)todo) - 1;
             todo &= todo - 1;
             const int seed = bcast_i((int)mine, t);
             if (is_used(g, seed)) continue;   // claimed by a region grown since the ballot
-            SeedPre pre;
-            pre.use = true; pre.seed_deg = bcast_f(s_deg, t);
-            pre.ok = lane < 9 && ((unsigned)bcast_i((int)n_ok, t) >> lane) & 1u;
-            pre.deg = 0.f; pre.cs = make_float2(0.f, 0.f);
-#pragma unroll
-            for (int k = 0; k < 9; ++k) {   // lane t's k-th neighbour record -> lane k
-                if (k == 4) continue;
-                const float d = bcast_f(n_deg[k], t), cx = bcast_f(n_cs[k].x, t), cy = bcast_f(n_cs[k].y, t);
-                if (lane == k) { pre.deg = d; pre.cs = make_float2(cx, cy); }
-            }
             double reg_angle, cen[3];
             long long t0 = clock64();
-            int nreg = region_grow(g, seed, pre, lp.prec, reg_angle);
+            int nreg = region_grow(g, seed, true, bcast_f(s_deg, t), lp.prec, reg_angle);
             t_grow += clock64() - t0; ++n_seed; n_pix += nreg;
             if (nreg < lp.min_reg_size) continue;
             region_list_fence();
@@ -535,8 +477,7 @@ __global__ __launch_bounds__(256) void k_lsd_grow(LinePlanes P, LsdParams lp, in
                     __builtin_amdgcn_wave_barrier();
                     const double mean_angle = sum / (double)nn;
                     const double tau = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / (double)nn + mean_angle * mean_angle);
-                    SeedPre none{};
-                    nreg = region_grow(g, (int)(c0 >> 16) * g.sw + (int)(c0 & 0xffff), none, tau, reg_angle);
+                    nreg = region_grow(g, (int)(c0 >> 16) * g.sw + (int)(c0 & 0xffff), false, 0.f, tau, reg_angle);
                     region_list_fence();
                     if (nreg < 2) keep = false;
                     else {
