@@ -115,7 +115,7 @@ def main():
     lt = plp.LineFeatureTracker(device=local_rank)
     # The line path is one long dependent chain per launch (region growing is a single latency-bound wave per frame), so
     # the batch is cut into n_line contiguous sub-blocks, each with its own context (scratch planes) and HIP stream.
-    n_line = max(1, int(os.environ.get("PLP_BENCH_LINE_SPLIT", "4")))
+    n_line = max(1, int(os.environ.get("PLP_BENCH_LINE_SPLIT", "2")))
     while B % n_line:
         n_line -= 1
     lts = [lt] + [plp.LineFeatureTracker(device=local_rank) for _ in range(n_line - 1)]

@@ -605,7 +605,7 @@ __constant__ int c_comb[32][2] = {{0, 1}, {0, 2}, {0, 3}, {0, 4}, {0, 5}, {0, 6}
 // grid = (16, B), block = 256: one wave per line, 64 lines of a frame in flight.
 __global__ __launch_bounds__(256) void k_lbd(LinePlanes P, LbdWeightsDev W) {
     __shared__ float s_row[4][63][8];   // per row: pgdL, ngdL, pgdL2, ngdL2, pgdO, ngdO, pgdO2, ngdO2 (after the global weight)
-    __shared__ float s_des[4][72];
+    __shared__ float s_des[4][72], s_des2[4][72], s_norm[4][4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, b = blockIdx.y;
     const int n_lines = P.n_all[b];
     for (int li = blockIdx.x * 4 + wv; li < n_lines; li += gridDim.x * 4) {   // a few resident waves walk the frame's lines
@@ -627,18 +627,33 @@ __global__ __launch_bounds__(256) void k_lbd(LinePlanes P, LbdWeightsDev W) {
         for (int r = 0; r < lane; ++r) { sCorX0 = __fsub_rn(sCorX0, dL1); sCorY0 = __fadd_rn(sCorY0, dL0); }
         float sCorX = sCorX0, sCorY = sCorY0;
         float pgdL = 0, ngdL = 0, pgdO = 0, ngdO = 0;
-        for (short wID = 0; wID < lengthOfLSP; ++wID) {
-            short t = (short)roundf(sCorX);
-            const short xCor = (t < 0) ? 0 : (t > imageWidth) ? imageWidth : t;
-            t = (short)roundf(sCorY);
-            const short yCor = (t < 0) ? 0 : (t > imageHeight) ? imageHeight : t;
-            const float fx = (float)dxImg[yCor * realWidth + xCor], fy = (float)dyImg[yCor * realWidth + xCor];
-            const float gDL = __fadd_rn(__fmul_rn(fx, dL0), __fmul_rn(fy, dL1));
-            const float gDO = __fadd_rn(__fmul_rn(fx, dO0), __fmul_rn(fy, dO1));
-            if (gDL > 0) pgdL = __fadd_rn(pgdL, gDL); else ngdL = __fsub_rn(ngdL, gDL);
-            if (gDO > 0) pgdO = __fadd_rn(pgdO, gDO); else ngdO = __fsub_rn(ngdO, gDO);
-            sCorX = __fadd_rn(sCorX, dL0);
-            sCorY = __fadd_rn(sCorY, dL1);
+        // the gathers do not depend on the running sums: addresses of 8 steps first, 16 loads in flight, then the
+        // strictly ordered accumulation
+        for (int w0 = 0; w0 < lengthOfLSP; w0 += 8) {
+            int off[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                short t = (short)roundf(sCorX);
+                const short xCor = (t < 0) ? 0 : (t > imageWidth) ? imageWidth : t;
+                t = (short)roundf(sCorY);
+                const short yCor = (t < 0) ? 0 : (t > imageHeight) ? imageHeight : t;
+                off[u] = yCor * realWidth + xCor;
+                sCorX = __fadd_rn(sCorX, dL0);
+                sCorY = __fadd_rn(sCorY, dL1);
+            }
+            int16_t vx[8], vy[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { vx[u] = dxImg[off[u]]; vy[u] = dyImg[off[u]]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (w0 + u < lengthOfLSP) {
+                    const float fx = (float)vx[u], fy = (float)vy[u];
+                    const float gDL = __fadd_rn(__fmul_rn(fx, dL0), __fmul_rn(fy, dL1));
+                    const float gDO = __fadd_rn(__fmul_rn(fx, dO0), __fmul_rn(fy, dO1));
+                    if (gDL > 0) pgdL = __fadd_rn(pgdL, gDL); else ngdL = __fsub_rn(ngdL, gDL);
+                    if (gDO > 0) pgdO = __fadd_rn(pgdO, gDO); else ngdO = __fsub_rn(ngdO, gDO);
+                }
+            }
         }
         const float cg = W.g[lane];
         pgdL = __fmul_rn(cg, pgdL); ngdL = __fmul_rn(cg, ngdL); pgdO = __fmul_rn(cg, pgdO); ngdO = __fmul_rn(cg, ngdO);
@@ -665,49 +680,51 @@ __global__ __launch_bounds__(256) void k_lbd(LinePlanes P, LbdWeightsDev W) {
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
+    // mean / std per band, the two-stage normalisation and the binary string.  Element-wise work is spread over the
+    // lanes; the three sums whose order matters (tempM, tempS, temp) are chained by lane 0 over LDS values.
+    float* des = s_des2[wv];
+    auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); };
+    if (lane < 36) {
+        const int band = lane >> 2, k = lane & 3;
+        const float invN = (band == 0 || band == 8) ? (float)(1.0 / (7 * 2.0)) : (float)(1.0 / (7 * 3.0));
+        const float* sb = &s_des[wv][band * 8];   // pgdL, ngdL, pgdL2, ngdL2, pgdO, ngdO, pgdO2, ngdO2
+        const int mi = (k < 2) ? k : k + 2, qi = mi + 2;   // mean from 0,1,4,5; second moment from 2,3,6,7
+        const float temp = __fmul_rn(sb[mi], invN);
+        des[band * 8 + k] = temp;
+        des[band * 8 + 4 + k] = sqrtf(__fsub_rn(__fmul_rn(sb[qi], invN), __fmul_rn(temp, temp)));
+    }
+    wave_sync();
     if (lane == 0) {
-        float des[72];
-        const float invN2 = (float)(1.0 / (7 * 2.0)), invN3 = (float)(1.0 / (7 * 3.0));
-        for (int band = 0; band < 9; ++band) {
-            const float invN = (band == 0 || band == 8) ? invN2 : invN3;
-            const float* s = &s_des[wv][band * 8];   // pgdL, ngdL, pgdL2, ngdL2, pgdO, ngdO, pgdO2, ngdO2
-            const int d = band * 8;
-            float temp = __fmul_rn(s[0], invN);
-            des[d] = temp; des[d + 4] = sqrtf(__fsub_rn(__fmul_rn(s[2], invN), __fmul_rn(temp, temp)));
-            temp = __fmul_rn(s[1], invN);
-            des[d + 1] = temp; des[d + 5] = sqrtf(__fsub_rn(__fmul_rn(s[3], invN), __fmul_rn(temp, temp)));
-            temp = __fmul_rn(s[4], invN);
-            des[d + 2] = temp; des[d + 6] = sqrtf(__fsub_rn(__fmul_rn(s[6], invN), __fmul_rn(temp, temp)));
-            temp = __fmul_rn(s[5], invN);
-            des[d + 3] = temp; des[d + 7] = sqrtf(__fsub_rn(__fmul_rn(s[7], invN), __fmul_rn(temp, temp)));
-        }
         float tempM = 0, tempS = 0;
         for (int band = 0; band < 9; ++band) {
             const float* v = des + 8 * band;
             for (int k = 0; k < 4; ++k) tempM = __fadd_rn(tempM, __fmul_rn(v[k], v[k]));
             for (int k = 4; k < 8; ++k) tempS = __fadd_rn(tempS, __fmul_rn(v[k], v[k]));
         }
-        tempM = __fdiv_rn(1.0f, sqrtf(tempM));
-        tempS = __fdiv_rn(1.0f, sqrtf(tempS));
-        for (int band = 0; band < 9; ++band) {
-            float* v = des + 8 * band;
-            for (int k = 0; k < 4; ++k) v[k] = __fmul_rn(v[k], tempM);
-            for (int k = 4; k < 8; ++k) v[k] = __fmul_rn(v[k], tempS);
-        }
-        for (int i = 0; i < 72; ++i)
-            if ((double)des[i] > 0.4) des[i] = (float)0.4;
+        s_norm[wv][0] = __fdiv_rn(1.0f, sqrtf(tempM));
+        s_norm[wv][1] = __fdiv_rn(1.0f, sqrtf(tempS));
+    }
+    wave_sync();
+    for (int i = lane; i < 72; i += 64) {
+        float v = __fmul_rn(des[i], s_norm[wv][(i >> 2) & 1]);
+        if ((double)v > 0.4) v = (float)0.4;
+        des[i] = v;
+    }
+    wave_sync();
+    if (lane == 0) {
         float temp = 0;
         for (int i = 0; i < 72; ++i) temp = __fadd_rn(temp, __fmul_rn(des[i], des[i]));
-        temp = __fdiv_rn(1.0f, sqrtf(temp));
-        for (int i = 0; i < 72; ++i) des[i] = __fmul_rn(des[i], temp);
-        uint8_t* out = P.all_lbd + ((size_t)b * kLineCap + li) * 32;
-        for (int c = 0; c < 32; ++c) {
-            const float* f1 = des + 8 * c_comb[c][0];
-            const float* f2 = des + 8 * c_comb[c][1];
-            unsigned r = 0;
-            for (int i = 0; i < 8; ++i) r += (f1[i] > f2[i]) ? (1u << i) : 0u;
-            out[c] = (uint8_t)r;
-        }
+        s_norm[wv][2] = __fdiv_rn(1.0f, sqrtf(temp));
+    }
+    wave_sync();
+    for (int i = lane; i < 72; i += 64) des[i] = __fmul_rn(des[i], s_norm[wv][2]);
+    wave_sync();
+    if (lane < 32) {
+        const float* f1 = des + 8 * c_comb[lane][0];
+        const float* f2 = des + 8 * c_comb[lane][1];
+        unsigned r = 0;
+        for (int i = 0; i < 8; ++i) r += (f1[i] > f2[i]) ? (1u << i) : 0u;
+        P.all_lbd[((size_t)b * kLineCap + li) * 32 + lane] = (uint8_t)r;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
