@@ -409,17 +409,20 @@ __global__ __launch_bounds__(256) void k_orient_rbrief(OrbPlanes pl, const uint8
     const int pitch = pl.level_pitch(level, L);
     int m10 = 0, m01 = 0;
     const int u = (lane & 31) - 15;
-#pragma unroll 4
+    // all 16 row loads of a lane are issued before the first is consumed (one memory round trip instead of four)
+    int vals[16];
+#pragma unroll
     for (int it = 0; it < 16; ++it) {
         const int v = -15 + 2 * it + (lane >> 5);
-        if (v <= 15 && (lane & 31) < 31) {
-            const int av = v < 0 ? -v : v;
-            if ((u < 0 ? -u : u) <= um.v[av]) {
-                const int val = img[(size_t)(cy + v) * pitch + cx + u];
-                m10 += u * val;
-                m01 += v * val;
-            }
-        }
+        const int av = v < 0 ? -v : v;
+        const bool in = v <= 15 && (lane & 31) < 31 && (u < 0 ? -u : u) <= um.v[av & 15];
+        vals[it] = in ? (int)img[(size_t)(cy + v) * pitch + cx + u] : 0;
+    }
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int v = -15 + 2 * it + (lane >> 5);
+        m10 += u * vals[it];
+        m01 += v * vals[it];
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
