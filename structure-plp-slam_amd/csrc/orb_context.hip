@@ -17,7 +17,7 @@
 namespace plp {
 void launch_quadtree(hipStream_t st, const LevelDev* d_lv, int n_levels, int n_cells_total, const uint32_t* cell_cand,
                      const int32_t* cell_count, int32_t* sel, int32_t* sel_count, int total_sel_cap, uint32_t* qt_scratch,
-                     size_t qt_scratch_frame_stride, int32_t* status, int B);
+                     size_t qt_scratch_frame_stride, int32_t* status, int B, int max_quota);
 size_t quadtree_scratch_bytes_per_frame(const LevelDev* h_lv, int n_levels);
 }
 
@@ -39,6 +39,7 @@ struct plp_orb {
     int capB = 0;
     DevBuf pyr, blur, l0copy, cell_cand, cell_count, sel, sel_count, status, qt_scratch, d_mask;
     size_t l0copy_frame_stride = 0, qt_frame_stride = 0;
+    int max_quota = 0;
     // single-frame host API staging
     DevBuf s_kps, s_desc, s_counts;
     DevBuf stereo_corr, stereo_stage;
@@ -108,11 +109,12 @@ plp_status build_geometry(plp_orb* c, int rows, int cols) {
         L.sel_base = G.sel_base; L.sel_cap = G.sel_cap;
         L.cell_base = G.cell_base; L.n_cells = G.n_cell_rows * G.n_cell_cols;
         L.quota = (int)c->st.quota[l];
+        c->max_quota = l == 0 ? L.quota : std::max(c->max_quota, L.quota);
         L.n_init_x = G.n_init_x; L.delta_x = G.delta_x; L.delta_y = G.delta_y;
         // quadtree scratch + the key bits that can differ between two candidates of this level
         L.qt_cap = std::min(std::max(L.n_cells, 1) * kCellCap, 65535);   // FAST's own bound, capped by the u16 node ranges
         L.qt_off = qt_off;
-        qt_off += (size_t)L.qt_cap * 16;
+        qt_off += (size_t)L.qt_cap * 20;   // cand, key, two index arrays, radix counters of very large levels
         const int extent = (int)std::ceil(std::max(G.delta_x, G.delta_y)) + 1;
         int t1 = 0;
         while ((1 << t1) < extent) ++t1;
@@ -122,7 +124,7 @@ plp_status build_geometry(plp_orb* c, int rows, int cols) {
         while ((1 << nb) < n_init) ++nb;
         L.sort_lo = 2 * (kQtDepth - d_eff);
         L.sort_hi = 2 * kQtDepth + nb;
-        if (L.n_cells > 8192 || L.sel_cap > 2048 || n_init > 32)
+        if (L.n_cells > 4096 || L.sel_cap > 2048 || n_init > 32)
             return set_error(PLP_ERR_UNSUPPORTED, "frame/keypoint budget exceeds the quadtree kernel limits (quota per level <= 1022)");
     }
     PLP_HIP(c->d_lv.upload(c->h_lv.data(), sizeof(LevelDev) * nl, c->stream));
@@ -265,7 +267,7 @@ plp_status run_batch(plp_orb* c, const uint8_t* d_imgs, int B, int rows, int col
     if (c->use_host_quadtree) PLP_TRY(host_quadtree(c, st, B));
     else launch_quadtree(st, (const LevelDev*)c->d_lv.p, nl, (int)g.cells.size(), (const uint32_t*)c->cell_cand.p,
                          (const int32_t*)c->cell_count.p, (int32_t*)c->sel.p, (int32_t*)c->sel_count.p, g.total_sel_cap,
-                         (uint32_t*)c->qt_scratch.p, c->qt_frame_stride, (int32_t*)c->status.p, B);
+                         (uint32_t*)c->qt_scratch.p, c->qt_frame_stride, (int32_t*)c->status.p, B, c->max_quota);
     mark(5);
     UMax um;
     for (int v = 0; v <= kHalfPatch; ++v) um.v[v] = c->st.u_max[v];

@@ -15,46 +15,68 @@
 
 namespace plp {
 
-constexpr int kQtMaxNodes = 2048;
-constexpr int kQtMaxCand = 65535;            // node ranges are u16; FAST can emit at most tested/4 per level
-constexpr int kQtSegMax = 1024;              // wave-sized (64) segments of the radix passes
-constexpr int kQtKeyCache = 8192;
+constexpr int kQtMaxNodes = 2048;            // hard upper bound of the node arrays (quota up to ~680 per level)
+constexpr int kQtSegLds = 512;               // radix counters for up to 512 wave-sized segments live in LDS (n <= 32768) ...
+constexpr int kQtKeyCache = 4096;            // ... and share it with the sorted-key cache; larger levels use the HBM scratch
 
+// LDS of one workgroup, carved from dynamic shared memory: the node arrays are sized by the largest per-level quota
+// (a list never holds more than 3 * quota + 3 nodes), so that 2-3 workgroups fit a CU for the usual K = 1000..2000
+// (a fixed 85 KB layout had left one workgroup = four waves per CU).
 struct QtShared {
-    union {
-        uint16_t cnt[16 * kQtSegMax];   // radix counters [digit][segment] (prefix values < 65536)
-        uint32_t big[kQtKeyCache];      // cell prefix during the gather, later the sorted-key cache
-    };
-    uint16_t ns[2][kQtMaxNodes], ne[2][kQtMaxNodes];
-    uint8_t nd[2][kQtMaxNodes], nleaf[2][kQtMaxNodes];
-    uint16_t b1[kQtMaxNodes], b2[kQtMaxNodes], b3[kQtMaxNodes];
-    uint32_t pk[kQtMaxNodes];       // packed per-entry counts -> exclusive prefixes (lo16 created, hi16 kept)
-    uint16_t pool_pos[kQtMaxNodes], pool_sorted[kQtMaxNodes];
-    uint32_t partial[256];
-    int misc[8];
+    uint16_t* cnt;                  // [16 * kQtSegLds] radix counters [digit][segment]      } one 16 KB block
+    uint32_t* big;                  // [kQtKeyCache] cell prefix, later the sorted-key cache  }
+    uint16_t *ns[2], *ne[2];
+    uint8_t *nd[2], *nleaf[2];
+    uint16_t *b1, *b2, *b3;
+    uint32_t* pk;                   // packed per-entry counts -> exclusive prefixes (lo16 created, hi16 kept)
+    uint16_t *pool_pos, *pool_sorted;
+    uint32_t* partial;
+    int* misc;
+    int max_nodes;
 };
+__host__ __device__ inline size_t qt_lds_bytes(int max_nodes) {
+    return 16384 + (size_t)max_nodes * (4 * 2 + 4 * 1 + 3 * 2 + 4 + 2 * 2) + 16 + 32;
+}
+__device__ __forceinline__ QtShared qt_carve(uint8_t* base, int mn) {
+    QtShared S;
+    S.cnt = reinterpret_cast<uint16_t*>(base); S.big = reinterpret_cast<uint32_t*>(base);
+    uint8_t* p = base + 16384;
+    S.pk = reinterpret_cast<uint32_t*>(p); p += 4 * (size_t)mn;
+    S.partial = reinterpret_cast<uint32_t*>(p); p += 16;
+    S.misc = reinterpret_cast<int*>(p); p += 32;
+    for (int k = 0; k < 2; ++k) { S.ns[k] = reinterpret_cast<uint16_t*>(p); p += 2 * (size_t)mn; S.ne[k] = reinterpret_cast<uint16_t*>(p); p += 2 * (size_t)mn; }
+    S.b1 = reinterpret_cast<uint16_t*>(p); p += 2 * (size_t)mn; S.b2 = reinterpret_cast<uint16_t*>(p); p += 2 * (size_t)mn;
+    S.b3 = reinterpret_cast<uint16_t*>(p); p += 2 * (size_t)mn;
+    S.pool_pos = reinterpret_cast<uint16_t*>(p); p += 2 * (size_t)mn; S.pool_sorted = reinterpret_cast<uint16_t*>(p); p += 2 * (size_t)mn;
+    for (int k = 0; k < 2; ++k) { S.nd[k] = p; p += mn; S.nleaf[k] = p; p += mn; }
+    S.max_nodes = mn;
+    return S;
+}
 
-// in-place exclusive scan of a[0..M) by the whole workgroup; returns the total
+// in-place exclusive scan of a[0..M) by the whole workgroup; returns the total.  Per-thread chunk sums are scanned
+// inside each wave with shuffles; only the four wave totals cross a barrier (the kernel runs ~50 of these scans per
+// level, and a 16-barrier Hillis-Steele over 256 partials had made barriers its main cost).
 template <typename T>
 __device__ uint32_t block_scan_excl(T* a, int M, uint32_t* partial) {
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int chunk = (M + 255) >> 8;
     const int lo = min(tid * chunk, M), hi = min(lo + chunk, M);
     uint32_t sum = 0;
     for (int i = lo; i < hi; ++i) sum += a[i];
-    partial[tid] = sum;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        const uint32_t t = tid >= off ? partial[tid - off] : 0;
-        __syncthreads();
-        partial[tid] += t;
-        __syncthreads();
+    uint32_t inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(inc, off);
+        if (lane >= off) inc += t;
     }
-    uint32_t run = partial[tid] - sum;
-    const uint32_t total = partial[255];
+    if (lane == 63) partial[wv] = inc;
+    __syncthreads();
+    const uint32_t w0 = partial[0], w1 = partial[1], w2 = partial[2], w3 = partial[3];
+    const uint32_t base = (wv > 0 ? w0 : 0) + (wv > 1 ? w1 : 0) + (wv > 2 ? w2 : 0);
+    uint32_t run = base + inc - sum;
     for (int i = lo; i < hi; ++i) { const uint32_t v = a[i]; a[i] = (T)run; run += v; }
     __syncthreads();
-    return total;
+    return w0 + w1 + w2 + w3;
 }
 
 __device__ __forceinline__ uint32_t dev_qt_key(int x, int y, const LevelDev& L) {
@@ -102,8 +124,9 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelDev* __restrict__ l
                                                   const uint32_t* __restrict__ cell_cand, const int32_t* __restrict__ cell_count,
                                                   int32_t* __restrict__ sel, int32_t* __restrict__ sel_count, int total_sel_cap,
                                                   uint8_t* __restrict__ scratch, size_t scratch_frame_stride,
-                                                  int32_t* __restrict__ status) {
-    __shared__ QtShared S;
+                                                  int32_t* __restrict__ status, int max_nodes) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t qt_smem[];
+    const QtShared S = qt_carve(qt_smem, max_nodes);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int level = blockIdx.x, frame = blockIdx.y;
     const LevelDev L = lv[level];
@@ -112,6 +135,7 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelDev* __restrict__ l
     uint32_t* key = cand + L.qt_cap;
     uint32_t* idxA = key + L.qt_cap;
     uint32_t* idxB = idxA + L.qt_cap;
+    uint16_t* cnt_hbm = reinterpret_cast<uint16_t*>(idxB + L.qt_cap);   // radix counters of levels with more than 32768 candidates
     int32_t* out_sel = sel + (size_t)frame * total_sel_cap + L.sel_base;
     int32_t* out_cnt = sel_count + frame * kMaxLevels + level;
 
@@ -138,6 +162,7 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelDev* __restrict__ l
 
     // ---- 2. LSD radix sort (4 bits per pass) of candidate indices by key bits [sort_lo, sort_hi)
     const int nseg = (n + 63) >> 6;
+    uint16_t* CNT = nseg <= kQtSegLds ? S.cnt : cnt_hbm;   // flat pointer
     uint32_t* src = idxA;
     uint32_t* dst = idxB;
     bool first = true;
@@ -152,10 +177,10 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelDev* __restrict__ l
                 const unsigned long long bal = __ballot(d == v);
                 if ((unsigned)lane == v) mine = (uint32_t)__popcll(bal);
             }
-            if (lane < 16) S.cnt[lane * nseg + seg] = (uint16_t)mine;
+            if (lane < 16) CNT[lane * nseg + seg] = (uint16_t)mine;
         }
         __syncthreads();
-        block_scan_excl(S.cnt, 16 * nseg, S.partial);
+        block_scan_excl(CNT, 16 * nseg, S.partial);
         for (int seg = wv; seg < nseg; seg += 4) {
             const int i = seg * 64 + lane;
             unsigned d = 16;
@@ -167,7 +192,7 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelDev* __restrict__ l
                 const unsigned long long bal = __ballot(d == v);
                 if (d == v) mybal = bal;
             }
-            if (i < n) dst[(uint32_t)S.cnt[d * nseg + seg] + (uint32_t)__popcll(mybal & ((1ull << lane) - 1ull))] = id;
+            if (i < n) dst[(uint32_t)CNT[d * nseg + seg] + (uint32_t)__popcll(mybal & ((1ull << lane) - 1ull))] = id;
         }
         __syncthreads();
         uint32_t* t = src; src = dst; dst = t;
@@ -221,7 +246,7 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelDev* __restrict__ l
         const uint32_t tot = block_scan_excl(S.pk, m, S.partial);
         const int T = (int)(tot & 0xffff), kept = (int)(tot >> 16);
         const int m_new = T + kept;
-        if (m_new > kQtMaxNodes) { failed = true; break; }
+        if (m_new > S.max_nodes) { failed = true; break; }
         const int nxt = cur ^ 1;
         for (int i = tid; i < m; i += 256) {
             const uint32_t p = S.pk[i];
@@ -306,7 +331,7 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelDev* __restrict__ l
             T = (int)S.pk[jl] + kl;
         }
         const int m_new = T + m - nsplit;
-        if (m_new > kQtMaxNodes) { failed = true; break; }
+        if (m_new > S.max_nodes) { failed = true; break; }
         const int nxt = cur ^ 1;
         // erased flags + survivors' new positions
         __syncthreads();
@@ -362,15 +387,19 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelDev* __restrict__ l
 
 size_t quadtree_scratch_bytes_per_frame(const LevelDev* h_lv, int n_levels) {
     size_t end = 0;
-    for (int l = 0; l < n_levels; ++l) end = h_lv[l].qt_off + (size_t)h_lv[l].qt_cap * 16;
+    for (int l = 0; l < n_levels; ++l) end = h_lv[l].qt_off + (size_t)h_lv[l].qt_cap * 20;
     return (end + 255) / 256 * 256;
 }
 
 void launch_quadtree(hipStream_t st, const LevelDev* d_lv, int n_levels, int n_cells_total, const uint32_t* cell_cand,
                      const int32_t* cell_count, int32_t* sel, int32_t* sel_count, int total_sel_cap, uint32_t* qt_scratch,
-                     size_t qt_scratch_frame_stride, int32_t* status, int B) {
-    hipLaunchKernelGGL(k_quadtree, dim3(n_levels, B), dim3(256), 0, st, d_lv, n_cells_total, cell_cand, cell_count, sel, sel_count,
-                       total_sel_cap, reinterpret_cast<uint8_t*>(qt_scratch), qt_scratch_frame_stride, status);
+                     size_t qt_scratch_frame_stride, int32_t* status, int B, int max_quota) {
+    int mn = 256;
+    while (mn < 3 * max_quota + 8 && mn < kQtMaxNodes) mn *= 2;
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)qt_lds_bytes(kQtMaxNodes)); attr_set = true; }
+    hipLaunchKernelGGL(k_quadtree, dim3(n_levels, B), dim3(256), qt_lds_bytes(mn), st, d_lv, n_cells_total, cell_cand, cell_count, sel,
+                       sel_count, total_sel_cap, reinterpret_cast<uint8_t*>(qt_scratch), qt_scratch_frame_stride, status, mn);
 }
 
 }  // namespace plp
