@@ -119,7 +119,7 @@ plp_status ensure(plp_line* c, int B) {
     PLP_HIP(c->blur11.reserve((size_t)P.pitch * P.H * B)); PLP_HIP(c->blur5.reserve((size_t)P.pitch * P.H * B));
     PLP_HIP(c->scaled.reserve((size_t)P.spitch * P.sh * B));
     PLP_HIP(c->pix.reserve(n * sizeof(LsdPix) * B));
-    PLP_HIP(c->bin.reserve(n * 2 * B)); PLP_HIP(c->maxgrad.reserve(8 * (size_t)B)); PLP_HIP(c->undef.reserve((n + 63) / 64 * 8 * B));
+    PLP_HIP(c->bin.reserve(n * 2 * B)); PLP_HIP(c->maxgrad.reserve(4 * ((n + 255) / 256) * (size_t)B)); PLP_HIP(c->undef.reserve((n + 63) / 64 * 8 * B));
     PLP_HIP(c->order.reserve(nv * 4 * B)); PLP_HIP(c->reg.reserve(n * 4 * B));
     PLP_HIP(c->raw.reserve(sizeof(float4) * kLineCap * B)); PLP_HIP(c->n_raw.reserve(4 * (size_t)B));
     PLP_HIP(c->dx.reserve(full * 2 * B)); PLP_HIP(c->dy.reserve(full * 2 * B));
@@ -127,7 +127,7 @@ plp_status ensure(plp_line* c, int B) {
     PLP_HIP(c->n_all.reserve(4 * (size_t)B)); PLP_HIP(c->status.reserve(16)); PLP_HIP(c->prof.reserve(64));
     P.blur11 = (uint8_t*)c->blur11.p; P.blur5 = (uint8_t*)c->blur5.p; P.scaled = (uint8_t*)c->scaled.p;
     P.pix = (LsdPix*)c->pix.p; P.bin = (uint16_t*)c->bin.p;
-    P.maxgrad = (unsigned long long*)c->maxgrad.p; P.undef = (unsigned long long*)c->undef.p;
+    P.blockmax = (uint32_t*)c->maxgrad.p; P.undef = (unsigned long long*)c->undef.p;
     P.order = (uint32_t*)c->order.p; P.reg = (uint32_t*)c->reg.p; P.raw = (float4*)c->raw.p; P.n_raw = (int32_t*)c->n_raw.p;
     P.dx = (int16_t*)c->dx.p; P.dy = (int16_t*)c->dy.p; P.all_kl = (plp_keyline*)c->all_kl.p; P.all_lbd = (uint8_t*)c->all_lbd.p;
     P.n_all = (int32_t*)c->n_all.p; P.status = (int32_t*)c->status.p; P.prof = (long long*)c->prof.p;

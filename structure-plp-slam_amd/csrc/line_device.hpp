@@ -29,7 +29,7 @@ struct LinePlanes {
     uint8_t* scaled;          // INTER_LINEAR_EXACT x0.5              [B][sh][spitch]
     LsdPix* pix;              // per scaled pixel: angle / magnitude^2 / cos,sin, 16 bytes  [B][sh*sw]
     uint16_t* bin;            // pseudo-ordering bin                  [B][sh*sw]
-    unsigned long long* maxgrad;   // per frame, bit pattern of the max defined magnitude  [B]
+    uint32_t* blockmax;       // per gradient workgroup: max g2 over its defined pixels   [B][ceil(sh*sw/256)]
     unsigned long long* undef;     // NOTDEF bitmask, 1 bit per scaled pixel          [B][ceil(sh*sw/64)]
     uint32_t* order;          // seed order (pixel index y*sw+x)      [B][(sh-1)*(sw-1)]
     uint32_t* reg;            // region point list scratch            [B][sh*sw]

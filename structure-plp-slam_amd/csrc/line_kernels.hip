@@ -100,6 +100,7 @@ __global__ __launch_bounds__(256) void k_lsd_gradient(LinePlanes P, LsdParams lp
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int n = P.sw * P.sh;
     double norm_def = 0.0;
+    uint32_t g2_mine = 0;
     if (idx < n) {
         const int y = idx / P.sw, x = idx - y * P.sw;
         double norm = 0.0;
@@ -117,22 +118,23 @@ __global__ __launch_bounds__(256) void k_lsd_gradient(LinePlanes P, LsdParams lp
                 deg = fast_atan2_deg_l((float)gx, (float)-gy);
                 const float fa = (float)((double)deg * (3.14159265358979323846 / 180));
                 cs = make_float2((float)cos((double)fa), (float)sin((double)fa));
-                norm_def = norm;
+                norm_def = norm; g2_mine = g2;
             }
         }
         const size_t o = (size_t)b * n + idx;
         LsdPix px; px.deg = deg; px.g2 = g2; px.cs = cs;
         P.pix[o] = px;
     }
-    // max over defined pixels: positive doubles order like their bit patterns
-    unsigned long long bits = (unsigned long long)__double_as_longlong(norm_def);
+    // max magnitude over the defined pixels = max of g2 (the magnitude is monotone in it).  One plain store per
+    // workgroup; k_lsd_bins reduces the per-workgroup values (2.4 M same-line atomics per launch had made this kernel
+    // wait 86 % of its time).
+    uint32_t g2_def = norm_def > 0.0 ? g2_mine : 0u;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned lo = __shfl_xor((unsigned)bits, o), hi = __shfl_xor((unsigned)(bits >> 32), o);
-        const unsigned long long w = ((unsigned long long)hi << 32) | lo;
-        bits = w > bits ? w : bits;
-    }
-    if ((threadIdx.x & 63) == 0 && bits) atomicMax(&P.maxgrad[b], bits);
+    for (int o = 32; o > 0; o >>= 1) g2_def = max(g2_def, (uint32_t)__shfl_xor((int)g2_def, o));
+    __shared__ uint32_t s_max[4];
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = g2_def;
+    __syncthreads();
+    if (threadIdx.x == 0) P.blockmax[(size_t)b * gridDim.x + blockIdx.x] = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
     // one 64-bit word per wave: pixels that can never seed or join a region (angle NOTDEF)
     const unsigned long long undef = __ballot(!(norm_def > 0.0));
     if ((threadIdx.x & 63) == 0 && blockIdx.x * 256 + (int)threadIdx.x < ((n + 63) / 64) * 64)
@@ -141,8 +143,16 @@ __global__ __launch_bounds__(256) void k_lsd_gradient(LinePlanes P, LsdParams lp
 
 __global__ __launch_bounds__(256) void k_lsd_bins(LinePlanes P, LsdParams lp) {
     const int b = blockIdx.y, idx = blockIdx.x * 256 + threadIdx.x, n = P.sw * P.sh;
+    __shared__ uint32_t s_red[4];
+    uint32_t mx = 0;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) mx = max(mx, P.blockmax[(size_t)b * gridDim.x + i]);   // same grid as k_lsd_gradient
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
     if (idx >= n) return;
-    const double max_grad = __longlong_as_double((long long)P.maxgrad[b]);
+    const double max_grad = sqrt((double)mx / 4.0);
     const double bin_coef = (max_grad > 0) ? (double)(lp.n_bins - 1) / max_grad : 0;
     P.bin[(size_t)b * n + idx] = (uint16_t)(int)(pix_mod(P.pix[(size_t)b * n + idx]) * bin_coef);
 }
@@ -772,7 +782,6 @@ void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp,
     auto mark = [&](int i) { if (ev) (void)hipEventRecord(ev[i], st); };
     const size_t plane_fs = (size_t)P.pitch * P.H, splane_fs = (size_t)P.spitch * P.sh;
     const int tiles = ((P.W + 127) / 128) * ((P.H + 63) / 64);
-    (void)hipMemsetAsync(P.maxgrad, 0, sizeof(unsigned long long) * B, st);
     mark(0);
     hipLaunchKernelGGL(k_blur_plane<5>, dim3(tiles, B), dim3(256), 0, st, P.img, P.img_frame_stride, P.img_pitch, P.blur11, plane_fs,
                        P.pitch, P.W, P.H, t11);
