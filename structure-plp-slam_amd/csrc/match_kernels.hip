@@ -529,8 +529,9 @@ __global__ __launch_bounds__(256) void k_match_resolve(MatchProblem P) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.x;
     const int m = P.q_counts ? P.q_counts[b] : P.m_cap;
     const int n = P.t_counts ? P.t_counts[b] : P.n_cap;
-    int32_t* owner_prev = lds;
-    int32_t* owner_next = lds + P.n_cap;
+    int32_t* owner_final = lds;                 // smallest claimant among the chunks already finished
+    int32_t* owner_prev = lds + P.n_cap;        // claims inside the current chunk, previous / current inner iteration
+    int32_t* owner_next = lds + 2 * P.n_cap;
     const uint32_t* klist = P.klist + (size_t)b * P.m_cap * kMatchK;
     const int32_t* kcount = P.kcount + (size_t)b * P.m_cap;
     int32_t* claim = P.claim + (size_t)b * P.m_cap;           // per query: claimed target or -1
@@ -541,7 +542,7 @@ __global__ __launch_bounds__(256) void k_match_resolve(MatchProblem P) {
     const uint8_t* t_occ = P.t_occupied ? P.t_occupied + (size_t)b * P.n_cap : nullptr;
     int32_t* out = P.out_match + (size_t)b * P.n_cap;
 
-    for (int t = tid; t < n; t += 256) { owner_prev[t] = 0x7fffffff; out[t] = -1; }
+    for (int t = tid; t < n; t += 256) { owner_final[t] = 0x7fffffff; out[t] = -1; }
     for (int q = tid; q < m; q += 256) claim[q] = -1;
     __syncthreads();
 
@@ -553,24 +554,20 @@ __global__ __launch_bounds__(256) void k_match_resolve(MatchProblem P) {
     const StagedTarget* sorted = P.sorted + (size_t)b * P.n_cap;
     const float* sorted_xr = P.sorted_xr + (size_t)b * P.n_cap;
     const uint16_t* g_cell_start = P.cell_start + (size_t)b * kCellStride;
-    // Rounds of "claim[q] = best free candidate given the claims of the queries before q".  Within a round the
-    // queries are swept in chunks of 256 in index order (Gauss-Seidel): a chunk sees THIS round's claims of all
-    // earlier chunks (owner_next, rebuilt as the sweep advances) and the previous round's claims of the earlier
-    // queries of its own chunk (owner_prev entries that fall inside the chunk).  At a fixed point both tests read
-    // "the smallest claimant of t is < q", i.e. the sequential answer; claims of queries < r are final after r
-    // rounds at the latest, in practice after 2-4.
-    auto taken = [&](int t, int q, int chunk_start) -> bool {
-        const int p = owner_prev[t];
-        return owner_next[t] < q || (p >= chunk_start && p < q);
-    };
-    for (int round = 0; round <= m; ++round) {
-        if (tid == 0) s_changed = 0;
-        for (int t = tid; t < n; t += 256) owner_next[t] = 0x7fffffff;
-        __syncthreads();
+    // "claim[q] = best free candidate given the claims of the queries before q", 256 queries (one chunk) at a time in
+    // index order.  Inside a chunk the claims are iterated to their fixed point (claims of its first r queries are
+    // final after r iterations, in practice after 2-3); the chunks before it are final already, so one pass over the
+    // chunks gives the sequential answer.  (The first version iterated whole sweeps over all chunks: ~7 sweeps.)
+    auto taken = [&](int t, int q, int) -> bool { return owner_final[t] != 0x7fffffff || owner_prev[t] < q; };
+    {
         for (int chunk_start = 0; chunk_start < m; chunk_start += 256) {
-            if (tid == 0) s_full_n = 0;
+          const int q = chunk_start + tid;
+          int my_claim = -1;
+          for (int t = tid; t < n; t += 256) owner_prev[t] = 0x7fffffff;
+          for (int inner = 0; inner <= 256; ++inner) {
+            if (tid == 0) { s_full_n = 0; s_changed = 0; }
+            for (int t = tid; t < n; t += 256) owner_next[t] = 0x7fffffff;
             __syncthreads();
-            const int q = chunk_start + tid;
             int new_claim = -1;
             bool decided = false;
             if (q < m) {
@@ -658,16 +655,23 @@ __global__ __launch_bounds__(256) void k_match_resolve(MatchProblem P) {
             __syncthreads();
             if (q < m) {
                 if (!decided) new_claim = s_claim_tmp[tid];
-                if (claim[q] != new_claim) { claim[q] = new_claim; s_changed = 1; }
+                if (my_claim != new_claim) { my_claim = new_claim; s_changed = 1; }
                 if (new_claim >= 0 && (blocks_always || has_obs[q])) atomicMin(&owner_next[new_claim], q);
             }
-            __syncthreads();   // this chunk's claims are visible to the next chunk
+            __syncthreads();
+            { int32_t* t = owner_prev; owner_prev = owner_next; owner_next = t; }
+            const int changed = s_changed;
+            __syncthreads();
+            if (!changed) break;
+          }
+          if (tid == 0 && P.dbg) atomicAdd(&P.dbg[1], 1);
+          // the chunk is final: publish its claims
+          if (q < m) {
+              claim[q] = my_claim;
+              if (my_claim >= 0 && (blocks_always || has_obs[q])) atomicMin(&owner_final[my_claim], q);
+          }
+          __syncthreads();
         }
-        if (tid == 0 && P.dbg) atomicAdd(&P.dbg[1], 1);
-        int32_t* t = owner_prev; owner_prev = owner_next; owner_next = t;
-        const int changed = s_changed;
-        __syncthreads();
-        if (!changed) break;
     }
 
     // ---- results: last writer per key point, number of accepted queries, delta-angle histogram check
@@ -878,7 +882,7 @@ void launch_match(hipStream_t st, const MatchProblem& P, int B) {
         hipLaunchKernelGGL(k_match_topk_lds, qgrid, dim3(256), staged, st, P);
     } else
         hipLaunchKernelGGL(k_match_topk, dim3((P.m_cap + 3) / 4, B), dim3(256), 0, st, P);
-    hipLaunchKernelGGL(k_match_resolve, dim3(B), dim3(256), (size_t)P.n_cap * 8, st, Q);
+    hipLaunchKernelGGL(k_match_resolve, dim3(B), dim3(256), (size_t)P.n_cap * 12, st, Q);
 }
 
 void launch_hamming_matrix(hipStream_t st, const uint8_t* q, int nq, const uint8_t* t, int nt, uint16_t* dist) {
