@@ -48,54 +48,72 @@ __device__ __forceinline__ void blur_tile(BlurTileLds<R>& S, const uint8_t* __re
         *reinterpret_cast<uint32_t*>(&S.in[r * IW + 4 * d]) = v;
     }
     __syncthreads();
-    // ---- horizontal: 4 adjacent sums per work item
+    // ---- horizontal: 4 adjacent sums per work item.  The taps are packed four to a dword and applied with
+    // v_dot4_u32_u8 on byte windows cut from aligned LDS dwords with v_alignbyte (2-3 dot products per output
+    // instead of 2R+1 multiply-adds on single bytes).
+    constexpr int RU = (R + 3) / 4 * 4;           // window start rounded down to a dword: RU - R bytes of slack
+    constexpr int OFF = RU - R;                   // byte offset of tap 0 of output 0 inside the first dword
+    constexpr int ND = (OFF + K + 3 + 3) / 4;     // dwords covering the 4 windows
+    constexpr int NT = (K + 3) / 4;               // packed tap dwords
+    uint32_t tp[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        tp[j] = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (4 * j + k < K) tp[j] |= (uint32_t)taps[4 * j + k] << (8 * k);
+    }
     for (int i = tid; i < IH * (kBlurTW / 4); i += 256) {
         const int r = i / (kBlurTW / 4), c4 = (i - r * (kBlurTW / 4)) * 4;
-        const uint8_t* p = &S.in[r * IW + kBlurPad - R + c4];
-        uint32_t px[K + 3];
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(&S.in[r * IW + kBlurPad - RU + c4]);
+        uint32_t d[ND + 1];
 #pragma unroll
-        for (int k = 0; k < K + 3; ++k) px[k] = p[k];
-        uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        for (int k = 0; k < ND; ++k) d[k] = p[k];
+        d[ND] = 0;
+        uint32_t a[4];
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const uint32_t t = (uint32_t)taps[k];
-            a0 += t * px[k]; a1 += t * px[k + 1]; a2 += t * px[k + 2]; a3 += t * px[k + 3];
+        for (int o = 0; o < 4; ++o) {
+            const int sh = OFF + o;               // first byte of this output's window
+            uint32_t acc = 0;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int q = (sh + 4 * j) >> 2, e = (sh + 4 * j) & 3;
+                const uint32_t wnd = e == 0 ? d[q] : __builtin_amdgcn_alignbyte(d[q + 1], d[q], (uint32_t)e);
+                acc = __builtin_amdgcn_udot4(wnd, tp[j], acc, false);
+            }
+            a[o] = acc;
         }
-        uint32_t* o = reinterpret_cast<uint32_t*>(&S.hs[r * kBlurTW + c4]);
-        o[0] = a0 | (a1 << 16);
-        o[1] = a2 | (a3 << 16);
+        uint32_t* o2 = reinterpret_cast<uint32_t*>(&S.hs[r * kBlurTW + c4]);
+        o2[0] = a[0] | (a[1] << 16);
+        o2[1] = a[2] | (a[3] << 16);
     }
     __syncthreads();
-    // ---- vertical: 4 columns x 8 rows per thread, sliding window of K rows
+    // ---- vertical: 4 columns x 8 rows per thread; the (2R+1)-row window lives unpacked in registers (the loop is
+    // fully unrolled, so sliding it is register renaming)
     const int cg = tid & 31, strip = tid >> 5;
     const int c4 = cg * 4, r0 = strip * 8;
     const int x = tx0 + c4;
     if (x >= w) return;
-    uint32_t win[K][2];
+    uint32_t win[K + 7][4];
 #pragma unroll
-    for (int k = 0; k < K - 1; ++k) {
+    for (int k = 0; k < K + 7; ++k) {
         const uint32_t* q = reinterpret_cast<const uint32_t*>(&S.hs[(r0 + k) * kBlurTW + c4]);
-        win[k][0] = q[0]; win[k][1] = q[1];
+        const uint32_t q0 = q[0], q1 = q[1];
+        win[k][0] = q0 & 0xffffu; win[k][1] = q0 >> 16; win[k][2] = q1 & 0xffffu; win[k][3] = q1 >> 16;
     }
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
-        const uint32_t* q = reinterpret_cast<const uint32_t*>(&S.hs[(r0 + rr + K - 1) * kBlurTW + c4]);
-        win[K - 1][0] = q[0]; win[K - 1][1] = q[1];
-        uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        uint32_t a0 = 32768u, a1 = 32768u, a2 = 32768u, a3 = 32768u;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const uint32_t t = (uint32_t)taps[k];
-            a0 += t * (win[k][0] & 0xffffu); a1 += t * (win[k][0] >> 16);
-            a2 += t * (win[k][1] & 0xffffu); a3 += t * (win[k][1] >> 16);
+            a0 += t * win[rr + k][0]; a1 += t * win[rr + k][1]; a2 += t * win[rr + k][2]; a3 += t * win[rr + k][3];
         }
         const int y = ty0 + r0 + rr;
         if (y < h) {
-            const uint32_t packed = min((a0 + 32768u) >> 16, 255u) | (min((a1 + 32768u) >> 16, 255u) << 8) |
-                                    (min((a2 + 32768u) >> 16, 255u) << 16) | (min((a3 + 32768u) >> 16, 255u) << 24);
+            const uint32_t packed = min(a0 >> 16, 255u) | (min(a1 >> 16, 255u) << 8) | (min(a2 >> 16, 255u) << 16) | (min(a3 >> 16, 255u) << 24);
             *reinterpret_cast<uint32_t*>(dst + (size_t)y * dst_pitch + x) = packed;
         }
-#pragma unroll
-        for (int k = 0; k < K - 1; ++k) { win[k][0] = win[k + 1][0]; win[k][1] = win[k + 1][1]; }
     }
 }
 
