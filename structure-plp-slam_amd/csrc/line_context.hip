@@ -80,6 +80,7 @@ plp_status build(plp_line* c, int rows, int cols) {
     LsdParams& lp = c->lp;
     const double ang_th = 22.5, quant = 2.0;
     lp.prec = M_PI * ang_th / 180; lp.p = ang_th / 180; lp.rho = quant / std::sin(lp.prec);
+    lp.c_pass = (float)std::cos(lp.prec - kLsdAngleBand); lp.c_fail = (float)std::cos(lp.prec + kLsdAngleBand);
     lp.density_th = 0.6; lp.scale = 0.5; lp.n_bins = 1024; lp.refine = 1;
     const double LOG_NT = 5 * (std::log10((double)P.sw) + std::log10((double)P.sh)) / 2 + std::log10(11.0);
     lp.min_reg_size = (int)(size_t)(-LOG_NT / std::log10(lp.p));

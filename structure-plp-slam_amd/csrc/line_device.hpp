@@ -46,7 +46,9 @@ struct LsdParams {
     int n_bins, refine, min_reg_size;
     float min_length;         // LSDOptions.min_length (0.125 * min(W,H))
     float keep_length;        // hard filter of line_extractor.cc:136 (60 px)
+    float c_pass, c_fail;     // cos(prec - eps), cos(prec + eps): the guard band of the angle test (region_grow)
 };
+constexpr double kLsdAngleBand = 3.5e-4;   // rad (0.02 deg) >= 2x the largest error of cv::fastAtan2 (0.0096 deg) + f32 rounding
 
 struct ResizeExactTab { const int16_t *xo, *xc, *yo, *yc; };   // offsets + 8.8 weights (-1/-2: border sample)
 struct BlurTapsN { int k[11]; };

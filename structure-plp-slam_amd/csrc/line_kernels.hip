@@ -265,7 +265,14 @@ __device__ __forceinline__ void set_used(const GrowCtx& g, int p) { atomicOr(&g.
 // streams fill the SIMDs (profiles/r01g_sq_counters.md).
 // The centroid sums of region2rect are not accumulated here any more: most regions are smaller than min_reg_size
 // and are dropped, the others get them from centroid_sums() (same order of additions).
-__device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed_deg, double prec, double& reg_angle) {
+// The angle test `|a - theta| <= prec` with theta = fastAtan2(sum) is decided WITHOUT computing theta whenever the
+// pixel is not within 0.02 deg of the tolerance: cos of the true angle between the pixel's unit vector and the sum
+// vector is compared with cos(prec -+ band); the band covers the polynomial error of cv::fastAtan2 (<= 0.0096 deg) and
+// all f32 roundings with a factor two to spare, so outside it both tests agree by construction.  theta itself (one
+// f32 division + polynomial + two f64 operations on the critical path of EVERY accepted pixel before) is evaluated
+// only for a pixel inside the band that could be the next one accepted, and once when the region is complete.
+__device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed_deg, double prec, float c_pass, float c_fail,
+                           double& reg_angle) {
     const int lane = g.lane;
     int nreg = 1;
     const int sx = seed % g.sw, sy = seed / g.sw;
@@ -273,6 +280,7 @@ __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed
     double s_sin, s_cos;
     sincos(reg_angle, &s_sin, &s_cos);
     float sumdx = (float)s_cos, sumdy = (float)s_sin;
+    bool theta_valid = true;   // reg_angle is the seed's own angle until the first acceptance
     if (lane == 0) {
         const uint32_t c = (uint32_t)sx | ((uint32_t)sy << 16);
         g.reg[0] = c; g.ring[0] = c;
@@ -303,8 +311,20 @@ __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed
         const int n_before = nreg;
         int last = -1;
         while (true) {
-            const bool ok = cand && lane > last && aligned_to(a, reg_angle, prec);
-            const unsigned long long bal = __ballot(ok);
+            const bool elig = cand && lane > last;
+            unsigned long long bal;
+            {
+                const float inv = rsqrtf(sumdx * sumdx + sumdy * sumdy);
+                const float cosang = (ncs.x * sumdx + ncs.y * sumdy) * inv;
+                const bool pass = cosang >= c_pass, fail = cosang < c_fail;
+                const unsigned long long P = __ballot(elig && pass), U = __ballot(elig && !pass && !fail);
+                // a pixel inside the band matters only if it comes before the first certain acceptance
+                const unsigned long long before = P ? ((P & (0ull - P)) - 1ull) : ~0ull;
+                if (U & before) {
+                    if (!theta_valid) { reg_angle = (double)fast_atan2_deg_l(sumdy, sumdx) * (3.14159265358979323846 / 180); theta_valid = true; }
+                    bal = __ballot(elig && aligned_to(a, reg_angle, prec));
+                } else bal = P;
+            }
             if (!bal) break;
             const int k = __ffsll((long long)bal) - 1;
             const int ax = bcast_i(nx, k), ay = bcast_i(ny, k);
@@ -317,7 +337,7 @@ __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed
             ++nreg;
             sumdx = __fadd_rn(sumdx, ccos);
             sumdy = __fadd_rn(sumdy, csin);
-            reg_angle = (double)fast_atan2_deg_l(sumdy, sumdx) * (3.14159265358979323846 / 180);
+            theta_valid = false;
             last = k;
             if (np == ap) cand = false;   // the same pixel seen from a later point of the batch
         }
@@ -326,6 +346,7 @@ __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed
             __hip_atomic_store(&g.reg[n_before + lane], g.ring[(n_before + lane) & g.ring_mask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         i += nb;
     }
+    if (!theta_valid) reg_angle = (double)fast_atan2_deg_l(sumdy, sumdx) * (3.14159265358979323846 / 180);
     return nreg;
 }
 // the region list in HBM is read by all lanes after growing (only regions that are kept get that far)
@@ -443,7 +464,7 @@ __global__ __launch_bounds__(256) void k_lsd_grow(LinePlanes P, LsdParams lp, in
             if (is_used(g, seed)) continue;   // claimed by a region grown since the ballot
             double reg_angle, cen[3];
             long long t0 = clock64();
-            int nreg = region_grow(g, seed, true, bcast_f(s_deg, t), lp.prec, reg_angle);
+            int nreg = region_grow(g, seed, true, bcast_f(s_deg, t), lp.prec, lp.c_pass, lp.c_fail, reg_angle);
             t_grow += clock64() - t0; ++n_seed; n_pix += nreg;
             if (nreg < lp.min_reg_size) continue;
             region_list_fence();
@@ -487,7 +508,10 @@ __global__ __launch_bounds__(256) void k_lsd_grow(LinePlanes P, LsdParams lp, in
                     __builtin_amdgcn_wave_barrier();
                     const double mean_angle = sum / (double)nn;
                     const double tau = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / (double)nn + mean_angle * mean_angle);
-                    nreg = region_grow(g, (int)(c0 >> 16) * g.sw + (int)(c0 & 0xffff), false, 0.f, tau, reg_angle);
+                    // guard band of the angle test for this tolerance (disabled = every test takes the exact path)
+                    float cp = 2.f, cf = -2.f;
+                    if (tau > 2 * kLsdAngleBand && tau < 1.5) { cp = (float)cos(tau - kLsdAngleBand); cf = (float)cos(tau + kLsdAngleBand); }
+                    nreg = region_grow(g, (int)(c0 >> 16) * g.sw + (int)(c0 & 0xffff), false, 0.f, tau, cp, cf, reg_angle);
                     region_list_fence();
                     if (nreg < 2) keep = false;
                     else {

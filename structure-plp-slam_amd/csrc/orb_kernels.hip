@@ -319,11 +319,20 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbPlanes pl, const CellDesc
 __global__ __launch_bounds__(256) void k_blur7(OrbPlanes pl, uint8_t* __restrict__ blur_base, size_t blur_frame_stride,
                                                const LevelDev* __restrict__ lv, int n_levels, BlurTaps taps) {
     __shared__ BlurTileLds<3> S;
-    int level = 0, t = blockIdx.x;
+    // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2: give every XCD whole frames (all tiles of a
+    // frame share halo rows), instead of neighbouring tiles landing on eight different L2s.
+    int t = blockIdx.x, frame = blockIdx.y;
+    {
+        const unsigned total = gridDim.x * gridDim.y, lin = blockIdx.x + gridDim.x * blockIdx.y;
+        if ((total & 7u) == 0) {
+            const unsigned logical = (lin & 7u) * (total >> 3) + (lin >> 3);
+            frame = (int)(logical / gridDim.x); t = (int)(logical - (unsigned)frame * gridDim.x);
+        }
+    }
+    int level = 0;
     while (level + 1 < n_levels && t >= lv[level].blur_tiles) { t -= lv[level].blur_tiles; ++level; }
     const LevelDev L = lv[level];
     const int tiles_x = (L.w + kBlurTW - 1) / kBlurTW;
-    const int frame = blockIdx.y;
     blur_tile<3>(S, pl.level_ptr(frame, level, L), pl.level_pitch(level, L), blur_base + (size_t)frame * blur_frame_stride + L.off, L.pitch,
                  L.w, L.h, (t % tiles_x) * kBlurTW, (t / tiles_x) * kBlurTH, taps.k);
 }
