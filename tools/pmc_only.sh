@@ -1,16 +1,9 @@
-# Round profile: default bench line, kernel trace, PMC traffic passes, SQ counters.  Usage (GPU box): bash tools/run_prof.sh <tag>
-set -x
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-T=${1:-prof}
-O=$R/gpurun_out/$T
-mkdir -p $O
-cd $R && timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
-cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/kt.log 2>&1
-# counter passes: one launch = the whole 2048-frame batch for every kernel (no sub-block split of the line path)
+O=$R/gpurun_out/r01h
 export PLP_BENCH_LINE_SPLIT=1
+mkdir -p $O
+cd /tmp
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o f -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o w -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/pmc_write.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $O/sq -o sq -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/sq.log 2>&1
-cat $O/bench.json
