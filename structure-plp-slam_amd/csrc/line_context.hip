@@ -123,14 +123,14 @@ plp_status ensure(plp_line* c, int B) {
     PLP_HIP(c->bin.reserve(n * 2 * B)); PLP_HIP(c->maxgrad.reserve(4 * ((n + 255) / 256) * (size_t)B)); PLP_HIP(c->undef.reserve((n + 63) / 64 * 8 * B));
     PLP_HIP(c->order.reserve(nv * 4 * B)); PLP_HIP(c->reg.reserve(n * 4 * B));
     PLP_HIP(c->raw.reserve(sizeof(float4) * kLineCap * B)); PLP_HIP(c->n_raw.reserve(4 * (size_t)B));
-    PLP_HIP(c->dx.reserve(full * 2 * B)); PLP_HIP(c->dy.reserve(full * 2 * B));
+    PLP_HIP(c->dx.reserve(full * 4 * B));
     PLP_HIP(c->all_kl.reserve(sizeof(plp_keyline) * kLineCap * B)); PLP_HIP(c->all_lbd.reserve((size_t)32 * kLineCap * B));
     PLP_HIP(c->n_all.reserve(4 * (size_t)B)); PLP_HIP(c->status.reserve(16)); PLP_HIP(c->prof.reserve(64));
     P.blur11 = (uint8_t*)c->blur11.p; P.blur5 = (uint8_t*)c->blur5.p; P.scaled = (uint8_t*)c->scaled.p;
     P.pix = (LsdPix*)c->pix.p; P.bin = (uint16_t*)c->bin.p;
     P.blockmax = (uint32_t*)c->maxgrad.p; P.undef = (unsigned long long*)c->undef.p;
     P.order = (uint32_t*)c->order.p; P.reg = (uint32_t*)c->reg.p; P.raw = (float4*)c->raw.p; P.n_raw = (int32_t*)c->n_raw.p;
-    P.dx = (int16_t*)c->dx.p; P.dy = (int16_t*)c->dy.p; P.all_kl = (plp_keyline*)c->all_kl.p; P.all_lbd = (uint8_t*)c->all_lbd.p;
+    P.dxy = (short2*)c->dx.p; P.all_kl = (plp_keyline*)c->all_kl.p; P.all_lbd = (uint8_t*)c->all_lbd.p;
     P.n_all = (int32_t*)c->n_all.p; P.status = (int32_t*)c->status.p; P.prof = (long long*)c->prof.p;
     c->capB = B;
     return PLP_OK;
@@ -317,7 +317,12 @@ plp_status plp_line_debug_read(plp_line* c, plp_line_debug_id what, int32_t fram
         case PLP_LINE_DBG_SOBEL_DX:
         case PLP_LINE_DBG_SOBEL_DY:
             if (dst_bytes < full * 2) return set_error(PLP_ERR_CAPACITY, "dst too small");
-            PLP_HIP(hipMemcpy(dst, (what == PLP_LINE_DBG_SOBEL_DX ? P.dx : P.dy) + (size_t)frame * full, full * 2, hipMemcpyDeviceToHost));
+            {   // the device plane interleaves (dx, dy)
+                std::vector<int16_t> both(full * 2);
+                PLP_HIP(hipMemcpy(both.data(), P.dxy + (size_t)frame * full, full * 4, hipMemcpyDeviceToHost));
+                int16_t* d16 = (int16_t*)dst;
+                for (size_t i = 0; i < full; ++i) d16[i] = both[2 * i + (what == PLP_LINE_DBG_SOBEL_DY ? 1 : 0)];
+            }
             *n_out = (int64_t)full; return PLP_OK;
     }
     return set_error(PLP_ERR_INVALID_ARG, "unknown debug id");

@@ -35,7 +35,7 @@ struct LinePlanes {
     uint32_t* reg;            // region point list scratch            [B][sh*sw]
     float4* raw; int32_t* n_raw;          // LSD segments             [B][kLineCap], [B]
     uint8_t* blur5;           // 5-tap sigma 1 blur (LBD)             [B][H][pitch]
-    int16_t* dx; int16_t* dy; // Sobel 3x3                            [B][H][W]
+    short2* dxy;              // Sobel 3x3, (dx, dy) per pixel        [B][H][W]
     plp_keyline* all_kl; uint8_t* all_lbd; int32_t* n_all;   // before the length filter  [B][kLineCap]
     int32_t* status;
     long long* prof;          // optional diagnostics of frame 0: cycles {total, grow, rect, refine}, seeds grown, pixels grown

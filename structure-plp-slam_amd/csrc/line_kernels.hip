@@ -617,18 +617,39 @@ __global__ __launch_bounds__(64) void k_keylines(LinePlanes P, LsdParams lp) {
 }
 
 // ------------------------------------------------------------------------------------------ Sobel
-__global__ __launch_bounds__(256) void k_sobel3(const uint8_t* __restrict__ src, size_t src_fs, int pitch, int16_t* __restrict__ dx,
-                                                int16_t* __restrict__ dy, int w, int h) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
+// cv::Sobel 3x3 (dx and dy, CV_16S, BORDER_REFLECT_101).  Four pixels per thread from aligned dword loads; the two
+// derivatives of a pixel are stored side by side (one 4-byte gather per LBD sample instead of two 2-byte ones).
+// grid = (ceil(w / 256), ceil(h / 4), B), block = 256 (64 x 4)
+__global__ __launch_bounds__(256) void k_sobel3(const uint8_t* __restrict__ src, size_t src_fs, int pitch, short2* __restrict__ dxy,
+                                                int w, int h) {
+    const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
     if (x >= w || y >= h) return;
     const uint8_t* s = src + (size_t)b * src_fs;
-    const uint8_t* r0 = s + (size_t)reflect101_l(y - 1, h) * pitch;
-    const uint8_t* r1 = s + (size_t)y * pitch;
-    const uint8_t* r2 = s + (size_t)reflect101_l(y + 1, h) * pitch;
-    const int xm = reflect101_l(x - 1, w), xp = reflect101_l(x + 1, w);
+    const uint8_t* rows[3] = {s + (size_t)reflect101_l(y - 1, h) * pitch, s + (size_t)y * pitch, s + (size_t)reflect101_l(y + 1, h) * pitch};
+    int p[3][6];   // columns x-1 .. x+4 of the three rows
+    const bool interior = x >= 4 && x + 4 <= w - 1 && x + 8 <= pitch;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        if (interior) {
+            const uint32_t* q = reinterpret_cast<const uint32_t*>(rows[r] + x);
+            const uint32_t L = q[-1], M = q[0], R = q[1];
+            p[r][0] = (int)(L >> 24); p[r][1] = (int)(M & 255u); p[r][2] = (int)((M >> 8) & 255u); p[r][3] = (int)((M >> 16) & 255u);
+            p[r][4] = (int)(M >> 24); p[r][5] = (int)(R & 255u);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) p[r][k] = rows[r][reflect101_l(min(x - 1 + k, w), w)];
+        }
+    }
+    short2 out[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {   // pixel x + i: xm = p[.][i], centre = p[.][i+1], xp = p[.][i+2]
+        out[i].x = (short)((p[0][i + 2] - p[0][i]) + 2 * (p[1][i + 2] - p[1][i]) + (p[2][i + 2] - p[2][i]));
+        out[i].y = (short)((p[2][i] - p[0][i]) + 2 * (p[2][i + 1] - p[0][i + 1]) + (p[2][i + 2] - p[0][i + 2]));
+    }
     const size_t o = ((size_t)b * h + y) * w + x;
-    dx[o] = (int16_t)((r0[xp] - r0[xm]) + 2 * (r1[xp] - r1[xm]) + (r2[xp] - r2[xm]));
-    dy[o] = (int16_t)((r2[xm] - r0[xm]) + 2 * (r2[x] - r0[x]) + (r2[xp] - r0[xp]));
+    if (x + 3 < w && (o & 3) == 0) *reinterpret_cast<uint4*>(dxy + o) = *reinterpret_cast<const uint4*>(out);
+    else
+        for (int i = 0; i < 4 && x + i < w; ++i) dxy[o + i] = out[i];
 }
 
 // ------------------------------------------------------------------------------------------ LBD
@@ -636,7 +657,8 @@ __constant__ int c_comb[32][2] = {{0, 1}, {0, 2}, {0, 3}, {0, 4}, {0, 5}, {0, 6}
                                   {2, 3}, {2, 4}, {2, 5}, {2, 6}, {2, 7}, {2, 8}, {3, 4}, {3, 5}, {3, 6}, {3, 7}, {3, 8},
                                   {4, 5}, {4, 6}, {4, 7}, {4, 8}, {5, 6}, {5, 7}, {5, 8}, {6, 7}, {6, 8}, {7, 8}};
 
-// grid = (16, B), block = 256: one wave per line, 64 lines of a frame in flight.
+// grid = (4, B), block = 256: one wave per line, 16 lines of a frame in flight (more waves thrash L1/L2: every wave
+// keeps 63 image rows live).
 __global__ __launch_bounds__(256) void k_lbd(LinePlanes P, LbdWeightsDev W) {
     __shared__ float s_row[4][63][8];   // per row: pgdL, ngdL, pgdL2, ngdL2, pgdO, ngdO, pgdO2, ngdO2 (after the global weight)
     __shared__ float s_des[4][72], s_des2[4][72], s_norm[4][4];
@@ -644,8 +666,7 @@ __global__ __launch_bounds__(256) void k_lbd(LinePlanes P, LbdWeightsDev W) {
     const int n_lines = P.n_all[b];
     for (int li = blockIdx.x * 4 + wv; li < n_lines; li += gridDim.x * 4) {   // a few resident waves walk the frame's lines
     const plp_keyline kl = P.all_kl[(size_t)b * kLineCap + li];
-    const int16_t* dxImg = P.dx + (size_t)b * P.W * P.H;
-    const int16_t* dyImg = P.dy + (size_t)b * P.W * P.H;
+    const short2* dxyImg = P.dxy + (size_t)b * P.W * P.H;
     const int realWidth = P.W;
     const short imageWidth = (short)(P.W - 1), imageHeight = (short)(P.H - 1);
     const short lengthOfLSP = (short)kl.numOfPixels;
@@ -675,13 +696,13 @@ __global__ __launch_bounds__(256) void k_lbd(LinePlanes P, LbdWeightsDev W) {
                 sCorX = __fadd_rn(sCorX, dL0);
                 sCorY = __fadd_rn(sCorY, dL1);
             }
-            int16_t vx[8], vy[8];
+            short2 vxy[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { vx[u] = dxImg[off[u]]; vy[u] = dyImg[off[u]]; }
+            for (int u = 0; u < 8; ++u) vxy[u] = dxyImg[off[u]];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 if (w0 + u < lengthOfLSP) {
-                    const float fx = (float)vx[u], fy = (float)vy[u];
+                    const float fx = (float)vxy[u].x, fy = (float)vxy[u].y;
                     const float gDL = __fadd_rn(__fmul_rn(fx, dL0), __fmul_rn(fy, dL1));
                     const float gDO = __fadd_rn(__fmul_rn(fx, dO0), __fmul_rn(fy, dO1));
                     if (gDL > 0) pgdL = __fadd_rn(pgdL, gDL); else ngdL = __fsub_rn(ngdL, gDL);
@@ -831,9 +852,10 @@ void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp,
     mark(5);
     hipLaunchKernelGGL(k_blur_plane<2>, dim3(tiles, B), dim3(256), 0, st, P.img, P.img_frame_stride, P.img_pitch, P.blur5, plane_fs,
                        P.pitch, P.W, P.H, t5);
-    hipLaunchKernelGGL(k_sobel3, dim3((P.W + 63) / 64, (P.H + 3) / 4, B), dim3(256), 0, st, P.blur5, plane_fs, P.pitch, P.dx, P.dy, P.W, P.H);
+    hipLaunchKernelGGL(k_sobel3, dim3((P.W + 255) / 256, (P.H + 3) / 4, B), dim3(256), 0, st, P.blur5, plane_fs, P.pitch, P.dxy, P.W, P.H);
     mark(6);
-    hipLaunchKernelGGL(k_lbd, dim3(16, B), dim3(256), 0, st, P, w);
+    static const int lbd_blocks = [] { const char* e = getenv("PLP_LBD_BLOCKS"); int r = e ? atoi(e) : 4; return r > 0 ? r : 4; }();   // few resident waves per frame: their 63-row working sets have to stay in L1/L2
+    hipLaunchKernelGGL(k_lbd, dim3(lbd_blocks, B), dim3(256), 0, st, P, w);
     mark(7);
     hipLaunchKernelGGL(k_line_finalize, dim3(B), dim3(64), 0, st, P, lp, out_kl, out_lbd, out_fn, cap, out_counts);
     mark(8);
