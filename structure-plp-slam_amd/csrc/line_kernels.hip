@@ -24,6 +24,7 @@
 
 #include "blur_tile.hpp"
 #include "line_device.hpp"
+#include "xcd_map.hpp"
 
 namespace plp {
 
@@ -62,8 +63,10 @@ __global__ __launch_bounds__(256) void k_blur_plane(const uint8_t* __restrict__ 
                                                     uint8_t* __restrict__ dst, size_t dst_fs, int dst_pitch, int w, int h, BlurTapsN taps) {
     __shared__ BlurTileLds<R> S;
     const int tiles_x = (w + kBlurTW - 1) / kBlurTW;
-    blur_tile<R>(S, src + (size_t)blockIdx.y * src_fs, src_pitch, dst + (size_t)blockIdx.y * dst_fs, dst_pitch, w, h,
-                 (blockIdx.x % tiles_x) * kBlurTW, (blockIdx.x / tiles_x) * kBlurTH, taps.k);
+    unsigned t, f;
+    xcd_frame_major(t, f);
+    blur_tile<R>(S, src + (size_t)f * src_fs, src_pitch, dst + (size_t)f * dst_fs, dst_pitch, w, h,
+                 ((int)t % tiles_x) * kBlurTW, ((int)t / tiles_x) * kBlurTH, taps.k);
 }
 
 // ------------------------------------------------------------------------------------------ x0.5 INTER_LINEAR_EXACT

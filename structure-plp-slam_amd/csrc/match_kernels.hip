@@ -17,6 +17,7 @@
 #include <stdint.h>
 
 #include "match_device.hpp"
+#include "xcd_map.hpp"
 
 namespace plp {
 
@@ -381,9 +382,11 @@ __device__ __forceinline__ int row16_sum_i32(int v) {
 // grid = (ceil(m_cap / kQueriesPerBlock), B), block = 256, dynamic LDS = n_cap * 20 + 2 * kCellStride bytes.
 __global__ __launch_bounds__(256) void k_match_topk_cells(MatchProblem P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int tid = threadIdx.x, sub = tid & 15, grp = tid >> 4, b = blockIdx.y;
+    unsigned uqb, ub;
+    xcd_frame_major(uqb, ub);   // the query blocks of a frame all stage the same sorted target array
+    const int tid = threadIdx.x, sub = tid & 15, grp = tid >> 4, b = (int)ub;
     const int m = P.q_counts ? P.q_counts[b] : P.m_cap;
-    const int q_begin = blockIdx.x * kQueriesPerBlock;
+    const int q_begin = (int)uqb * kQueriesPerBlock;
     if (q_begin >= m) return;
     const int ncell = P.grid_cols * P.grid_rows, rows = P.grid_rows;
     const uint8_t* t_desc = P.t_desc + (size_t)b * P.n_cap * 32;

@@ -12,6 +12,7 @@
 
 #include "blur_tile.hpp"
 #include "orb_device.hpp"
+#include "xcd_map.hpp"
 
 namespace plp {
 
@@ -146,7 +147,9 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbPlanes pl, const CellDesc
     __shared__ uint16_t queue[4096], queue2[4096];
     __shared__ int q_count, q2_count, n_ini, wave_tot[4], run_base;
 
-    const int tid = threadIdx.x, frame = blockIdx.y, cell = blockIdx.x;
+    unsigned ucell, uframe;
+    xcd_frame_major(ucell, uframe);   // neighbouring cell ROIs overlap by 6 pixels and share cache lines
+    const int tid = threadIdx.x, frame = (int)uframe, cell = (int)ucell;
     const CellDesc cd = cells[cell];
     const LevelDev L = lv[cd.level];
     const int out_slot = frame * n_cells + cell;
@@ -319,16 +322,10 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbPlanes pl, const CellDesc
 __global__ __launch_bounds__(256) void k_blur7(OrbPlanes pl, uint8_t* __restrict__ blur_base, size_t blur_frame_stride,
                                                const LevelDev* __restrict__ lv, int n_levels, BlurTaps taps) {
     __shared__ BlurTileLds<3> S;
-    // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2: give every XCD whole frames (all tiles of a
-    // frame share halo rows), instead of neighbouring tiles landing on eight different L2s.
-    int t = blockIdx.x, frame = blockIdx.y;
-    {
-        const unsigned total = gridDim.x * gridDim.y, lin = blockIdx.x + gridDim.x * blockIdx.y;
-        if ((total & 7u) == 0) {
-            const unsigned logical = (lin & 7u) * (total >> 3) + (lin >> 3);
-            frame = (int)(logical / gridDim.x); t = (int)(logical - (unsigned)frame * gridDim.x);
-        }
-    }
+    unsigned ut, uf;
+    xcd_frame_major(ut, uf);   // all tiles of a frame share halo rows: one L2 per frame
+    int t = (int)ut;
+    const int frame = (int)uf;
     int level = 0;
     while (level + 1 < n_levels && t >= lv[level].blur_tiles) { t -= lv[level].blur_tiles; ++level; }
     const LevelDev L = lv[level];
@@ -393,8 +390,10 @@ __global__ __launch_bounds__(256) void k_orient_rbrief(OrbPlanes pl, const uint8
                                                        int total_sel_cap, UMax um, plp_keypoint* __restrict__ out_kps,
                                                        uint8_t* __restrict__ out_desc, int cap, int32_t* __restrict__ out_counts,
                                                        int32_t* __restrict__ status) {
-    const int lane = threadIdx.x & 63, frame = blockIdx.y;
-    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    unsigned ublk, uframe;
+    xcd_frame_major(ublk, uframe);   // a frame's patches (two planes, ~2.6 MB) stay in one L2
+    const int lane = threadIdx.x & 63, frame = (int)uframe;
+    const int g = (int)ublk * 4 + (threadIdx.x >> 6);
     if (g >= total_sel_cap) return;
     int level = 0;
     while (level + 1 < n_levels && g >= lv[level + 1].sel_base) ++level;
