@@ -310,14 +310,18 @@ __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed
         if (cand) cand = !is_used(g, np);
         if (cand) { const LsdPix px = g.pix[np]; deg = px.deg; ncs = px.cs; }   // 16 bytes per live neighbour
         const double a = (double)deg * (3.14159265358979323846 / 180);
-        // ---- acceptances in order (no global-memory traffic inside)
+        // ---- acceptances in order.  Accepted lanes are strictly increasing, so the set of accepted lanes (a bit mask)
+        // already is the order: the list append and the USED bits are written by the accepted lanes themselves after
+        // the loop, in parallel (the loop used to hand every acceptance to lane 0: two more broadcasts and a
+        // predicated block per accepted pixel of a kernel that is instruction-bound).
         const int n_before = nreg;
         int last = -1;
+        unsigned long long acc = 0;
         while (true) {
             const bool elig = cand && lane > last;
             unsigned long long bal;
             {
-                const float inv = rsqrtf(sumdx * sumdx + sumdy * sumdy);
+                const float inv = __builtin_amdgcn_rsqf(sumdx * sumdx + sumdy * sumdy);   // |sum| >= 0.9: no denormal care needed
                 const float cosang = (ncs.x * sumdx + ncs.y * sumdy) * inv;
                 const bool pass = cosang >= c_pass, fail = cosang < c_fail;
                 const unsigned long long P = __ballot(elig && pass), U = __ballot(elig && !pass && !fail);
@@ -330,13 +334,9 @@ __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed
             }
             if (!bal) break;
             const int k = __ffsll((long long)bal) - 1;
-            const int ax = bcast_i(nx, k), ay = bcast_i(ny, k);
             const float ccos = bcast_f(ncs.x, k), csin = bcast_f(ncs.y, k);
-            const int ap = ay * g.sw + ax;
-            if (lane == 0) {
-                g.ring[nreg & g.ring_mask] = (uint32_t)ax | ((uint32_t)ay << 16);
-                set_used(g, ap);
-            }
+            const int ap = bcast_i(np, k);
+            acc |= 1ull << k;
             ++nreg;
             sumdx = __fadd_rn(sumdx, ccos);
             sumdy = __fadd_rn(sumdy, csin);
@@ -344,9 +344,14 @@ __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed
             last = k;
             if (np == ap) cand = false;   // the same pixel seen from a later point of the batch
         }
-        __builtin_amdgcn_wave_barrier();
-        if (n_before + lane < nreg)   // this round's new points (at most 63) go to the HBM copy of the list in one store
-            __hip_atomic_store(&g.reg[n_before + lane], g.ring[(n_before + lane) & g.ring_mask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if ((acc >> lane) & 1ull) {
+            const int pos = n_before + __popcll(acc & ((1ull << lane) - 1ull));
+            const uint32_t c = (uint32_t)nx | ((uint32_t)ny << 16);
+            g.ring[pos & g.ring_mask] = c;
+            set_used(g, np);
+            __hip_atomic_store(&g.reg[pos], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // HBM copy of the list
+        }
+        __builtin_amdgcn_wave_barrier();   // LDS operations of one wave complete in order: the next round's reads see these writes
         i += nb;
     }
     if (!theta_valid) reg_angle = (double)fast_atan2_deg_l(sumdy, sumdx) * (3.14159265358979323846 / 180);
