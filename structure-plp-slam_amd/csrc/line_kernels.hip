@@ -309,7 +309,6 @@ __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed
         np = ny * g.sw + nx;
         if (cand) cand = !is_used(g, np);
         if (cand) { const LsdPix px = g.pix[np]; deg = px.deg; ncs = px.cs; }   // 16 bytes per live neighbour
-        const double a = (double)deg * (3.14159265358979323846 / 180);
         // ---- acceptances in order.  Accepted lanes are strictly increasing, so the set of accepted lanes (a bit mask)
         // already is the order: the list append and the USED bits are written by the accepted lanes themselves after
         // the loop, in parallel (the loop used to hand every acceptance to lane 0: two more broadcasts and a
@@ -329,7 +328,7 @@ __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed
                 const unsigned long long before = P ? ((P & (0ull - P)) - 1ull) : ~0ull;
                 if (U & before) {
                     if (!theta_valid) { reg_angle = (double)fast_atan2_deg_l(sumdy, sumdx) * (3.14159265358979323846 / 180); theta_valid = true; }
-                    bal = __ballot(elig && aligned_to(a, reg_angle, prec));
+                    bal = __ballot(elig && aligned_to((double)deg * (3.14159265358979323846 / 180), reg_angle, prec));
                 } else bal = P;
             }
             if (!bal) break;
