@@ -335,8 +335,13 @@ __global__ __launch_bounds__(256) void k_blur7(OrbPlanes pl, uint8_t* __restrict
 }
 
 // ------------------------------------------------------------------------------------------
-// K5+K7  orientation + rBRIEF + KeyPoint assembly, one wave64 per selected key point.
-// grid = (ceil(total_sel_cap / 4), B), block = 256 (4 waves = 4 key points).
+// K5+K7  orientation + rBRIEF + KeyPoint assembly, 16 lanes per selected key point (4 key points per wave64).
+// The first version spent a whole wave on one key point: 4.2 M waves of ~300 instructions each, three dependent memory
+// round trips per wave, latency-bound at full occupancy.  Now a round trip serves four key points:
+//   ic_angle   lane s owns disc rows s-15 and s+1: eight unaligned dword loads per row, masked moments with
+//              v_dot4_u32_u8 against per-row weight tables (sum of (u+15)*I and of I; m10 = first - 15 * second)
+//   rBRIEF     lane s owns pairs 16s .. 16s+15 = descriptor bytes 2s, 2s+1
+// grid = (ceil(total_sel_cap / 16), B), block = 256.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {   // cv::fastAtan2, no FMA
     const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
@@ -379,9 +384,22 @@ __device__ __forceinline__ float ref_cos(float v) {
 }
 __device__ __forceinline__ float ref_sin(float v) { return ref_cos(__fsub_rn(3.14159265358979f / 2.0f, v)); }
 
-__constant__ int8_t c_pattern[1024] = {
+__constant__ __attribute__((aligned(16))) int8_t c_pattern[1024] = {
 #include "rbrief_pattern.inc"
 };
+
+__device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p) {
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);   // global loads take any byte address on gfx950 (unaligned access mode)
+    return v;
+}
+__device__ __forceinline__ int row16_sum(int v) {
+    v += __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false);   // row_ror:8
+    v += __builtin_amdgcn_update_dpp(v, v, 0x124, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(v, v, 0x122, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(v, v, 0x121, 0xf, 0xf, false);
+    return v;
+}
 
 __global__ __launch_bounds__(256) void k_orient_rbrief(OrbPlanes pl, const uint8_t* __restrict__ blur_base,
                                                        size_t blur_frame_stride, const LevelDev* __restrict__ lv,
@@ -390,10 +408,23 @@ __global__ __launch_bounds__(256) void k_orient_rbrief(OrbPlanes pl, const uint8
                                                        int total_sel_cap, UMax um, plp_keypoint* __restrict__ out_kps,
                                                        uint8_t* __restrict__ out_desc, int cap, int32_t* __restrict__ out_counts,
                                                        int32_t* __restrict__ status) {
+    __shared__ uint32_t s_w0[16][8], s_w1[16][8];   // per |v|: byte weights 1 / (u + 15) inside the disc, 0 outside
+    __shared__ uint32_t s_pat[256];                 // the 256 test pairs (ax, ay, bx, by as int8)
     unsigned ublk, uframe;
     xcd_frame_major(ublk, uframe);   // a frame's patches (two planes, ~2.6 MB) stay in one L2
-    const int lane = threadIdx.x & 63, frame = (int)uframe;
-    const int g = (int)ublk * 4 + (threadIdx.x >> 6);
+    const int tid = threadIdx.x, sub = tid & 15, frame = (int)uframe;
+    if (tid < 128) {
+        const int av = tid >> 3, j = tid & 7, half = um.v[av];
+        uint32_t w0 = 0, w1 = 0;
+        for (int k = 0; k < 4; ++k) {
+            const int u = 4 * j + k - 15;
+            if (u <= 15 && (u < 0 ? -u : u) <= half) { w0 |= 1u << (8 * k); w1 |= (uint32_t)(u + 15) << (8 * k); }
+        }
+        s_w0[av][j] = w0; s_w1[av][j] = w1;
+    }
+    s_pat[tid] = reinterpret_cast<const uint32_t*>(c_pattern)[tid];
+    __syncthreads();
+    const int g = (int)ublk * 16 + (tid >> 4);
     if (g >= total_sel_cap) return;
     int level = 0;
     while (level + 1 < n_levels && g >= lv[level + 1].sel_base) ++level;
@@ -402,58 +433,62 @@ __global__ __launch_bounds__(256) void k_orient_rbrief(OrbPlanes pl, const uint8
     const int32_t* cnt = sel_count + frame * kMaxLevels;
     int out_idx = i, total = 0;
     for (int l = 0; l < n_levels; ++l) { const int c = cnt[l]; if (l < level) out_idx += c; total += c; }
-    if (g == 0 && lane == 0) {
+    if (g == 0 && sub == 0) {
         out_counts[frame] = min(total, cap);
         if (total > cap) atomicOr(status, 1);
     }
-    if (i >= cnt[level] || out_idx >= cap) return;
+    if (i >= cnt[level] || out_idx >= cap) return;   // the 16 lanes of a key point leave together
 
     const uint32_t pk = (uint32_t)sel[(size_t)frame * total_sel_cap + g];
     const int cx = (int)(pk & 0xfff) + kOrbBorder, cy = (int)((pk >> 12) & 0xfff) + kOrbBorder;   // level pixel
     const int resp = (int)(pk >> 24);
 
-    // intensity centroid over the radius-15 disc: two rows per step (lanes 0-31 / 32-63)
+    // intensity centroid over the radius-15 disc (key points keep 19 pixels from the border: every load is inside)
     const uint8_t* img = pl.level_ptr(frame, level, L);
     const int pitch = pl.level_pitch(level, L);
     int m10 = 0, m01 = 0;
-    const int u = (lane & 31) - 15;
-    // all 16 row loads of a lane are issued before the first is consumed (one memory round trip instead of four)
-    int vals[16];
+    {
+        const int vA = sub - 15, vB = sub + 1;   // rows -15..0 and 1..15 (lane 15 has no second row)
+        const uint8_t* pA = img + (size_t)(cy + vA) * pitch + cx - 15;
+        const uint8_t* pB = img + (size_t)(cy + min(vB, 15)) * pitch + cx - 15;
+        uint32_t dA[8], dB[8];
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
-        const int v = -15 + 2 * it + (lane >> 5);
-        const int av = v < 0 ? -v : v;
-        const bool in = v <= 15 && (lane & 31) < 31 && (u < 0 ? -u : u) <= um.v[av & 15];
-        vals[it] = in ? (int)img[(size_t)(cy + v) * pitch + cx + u] : 0;
+        for (int j = 0; j < 8; ++j) { dA[j] = load_u32_unaligned(pA + 4 * j); dB[j] = load_u32_unaligned(pB + 4 * j); }
+        uint32_t sA = 0, tA = 0, sB = 0, tB = 0;   // s = sum I, t = sum (u + 15) I
+        const int aA = -vA, aB = min(vB, 15);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            sA = __builtin_amdgcn_udot4(dA[j], s_w0[aA][j], sA, false); tA = __builtin_amdgcn_udot4(dA[j], s_w1[aA][j], tA, false);
+            sB = __builtin_amdgcn_udot4(dB[j], s_w0[aB][j], sB, false); tB = __builtin_amdgcn_udot4(dB[j], s_w1[aB][j], tB, false);
+        }
+        if (vB > 15) { sB = 0; tB = 0; }
+        m10 = (int)tA - 15 * (int)sA + (int)tB - 15 * (int)sB;
+        m01 = vA * (int)sA + vB * (int)sB;
     }
-#pragma unroll
-    for (int it = 0; it < 16; ++it) {
-        const int v = -15 + 2 * it + (lane >> 5);
-        m10 += u * vals[it];
-        m01 += v * vals[it];
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
+    m10 = row16_sum(m10); m01 = row16_sum(m01);
     const float angle = fast_atan2_deg((float)m01, (float)m10);
 
-    // rBRIEF on the blurred level: lane handles pair (64*r + lane); ballot packs 64 bits = 8 bytes
+    // rBRIEF on the blurred level
     const float arad = (float)((double)angle * 3.14159265358979323846 / 180.0);
     const float ca = ref_cos(arad), sa = ref_sin(arad);
     const uint8_t* bl = blur_base + (size_t)frame * blur_frame_stride + L.off + (size_t)cy * L.pitch + cx;
-    unsigned long long bits[4];
+    uint32_t bits = 0;
+    int ta[16], tb[16];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int p = (64 * r + lane) * 4;
-        const float ax = (float)c_pattern[p], ay = (float)c_pattern[p + 1], bx = (float)c_pattern[p + 2], by = (float)c_pattern[p + 3];
+    for (int r = 0; r < 16; ++r) {
+        const uint32_t pt = s_pat[16 * sub + r];
+        const float ax = (float)(int8_t)(pt & 0xff), ay = (float)(int8_t)((pt >> 8) & 0xff), bx = (float)(int8_t)((pt >> 16) & 0xff),
+                    by = (float)(int8_t)(pt >> 24);
         const int ar = __float2int_rn(__fadd_rn(__fmul_rn(ax, sa), __fmul_rn(ay, ca)));
         const int ac = __float2int_rn(__fsub_rn(__fmul_rn(ax, ca), __fmul_rn(ay, sa)));
         const int br = __float2int_rn(__fadd_rn(__fmul_rn(bx, sa), __fmul_rn(by, ca)));
         const int bc = __float2int_rn(__fsub_rn(__fmul_rn(bx, ca), __fmul_rn(by, sa)));
-        const int ta = bl[ar * L.pitch + ac], tb = bl[br * L.pitch + bc];
-        bits[r] = __ballot(ta < tb);
+        ta[r] = bl[ar * L.pitch + ac]; tb[r] = bl[br * L.pitch + bc];
     }
-    if (lane < 4) reinterpret_cast<unsigned long long*>(out_desc + ((size_t)frame * cap + out_idx) * 32)[lane] = bits[lane];
-    if (lane == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bits |= (uint32_t)(ta[r] < tb[r]) << r;
+    reinterpret_cast<uint16_t*>(out_desc + ((size_t)frame * cap + out_idx) * 32)[sub] = (uint16_t)bits;
+    if (sub == 0) {
         plp_keypoint k;
         const float s = L.scale;
         k.x = level ? __fmul_rn((float)cx, s) : (float)cx;
@@ -497,7 +532,7 @@ void launch_orient_rbrief(hipStream_t st, const OrbPlanes& pl, const uint8_t* bl
                           const LevelDev* d_lv, int n_levels, const int32_t* sel, const int32_t* sel_count,
                           int total_sel_cap, const UMax& um, plp_keypoint* kps, uint8_t* desc, int cap, int32_t* counts,
                           int32_t* status, int B) {
-    hipLaunchKernelGGL(k_orient_rbrief, dim3((total_sel_cap + 3) / 4, B), dim3(256), 0, st, pl, blur, blur_frame_stride, d_lv,
+    hipLaunchKernelGGL(k_orient_rbrief, dim3((total_sel_cap + 15) / 16, B), dim3(256), 0, st, pl, blur, blur_frame_stride, d_lv,
                        n_levels, sel, sel_count, total_sel_cap, um, kps, desc, cap, counts, status);
 }
 
