@@ -358,6 +358,8 @@ __global__ __launch_bounds__(256) void k_match_prep(MatchProblem P) {
     for (int i = tid; i <= ncell; i += 256) P.cell_start[(size_t)b * kCellStride + i] = start[min(i, 4096)];
 }
 
+constexpr int kLaneCand = 6;   // candidate positions a lane collects before it fetches their descriptors
+
 // 16-lane (DPP row) reductions: four queries share a wave
 __device__ __forceinline__ uint32_t row16_min_u32(uint32_t v) {
     v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xf, 0xf, false));   // row_ror:8
@@ -393,6 +395,7 @@ __global__ __launch_bounds__(256) void k_match_topk_cells(MatchProblem P) {
     StagedTarget* st = reinterpret_cast<StagedTarget*>(smem);
     float* sxr = reinterpret_cast<float*>(smem + (size_t)P.n_cap * sizeof(StagedTarget));
     uint16_t* cs = reinterpret_cast<uint16_t*>(smem + (size_t)P.n_cap * (sizeof(StagedTarget) + 4));
+    __shared__ uint16_t s_cand[256 * kLaneCand];
     const bool has_xr = P.t_x_right != nullptr;
     {
         const uint16_t* gcs = P.cell_start + (size_t)b * kCellStride;
@@ -419,6 +422,34 @@ __global__ __launch_bounds__(256) void k_match_topk_cells(MatchProblem P) {
                 const uint4* qd = reinterpret_cast<const uint4*>(P.q_desc + ((size_t)b * P.m_cap + q) * 32);
                 const uint4 q0 = qd[0], q1 = qd[1];
                 const bool check_level = (0 < c.min_level) || (0 <= c.max_level);
+                // Two phases so that the descriptor gathers of a lane are in flight together: (1) walk the column
+                // ranges and note the positions that pass the geometric tests (up to kLaneCand per lane in an LDS
+                // slot of this thread), (2) fetch their descriptors, (3) distances and the best-8 insertion.  A lane that
+                // finds more candidates drains its slot and goes on.
+                uint16_t* my = s_cand + tid * kLaneCand;
+                int nc = 0;
+                auto drain = [&]() {
+                    uint4 d0[kLaneCand], d1[kLaneCand];
+#pragma unroll
+                    for (int k = 0; k < kLaneCand; ++k)
+                        if (k < nc) {
+                            const uint4* d = reinterpret_cast<const uint4*>(t_desc + 32 * (size_t)st[my[k]].t);
+                            d0[k] = d[0]; d1[k] = d[1];
+                        }
+#pragma unroll
+                    for (int k = 0; k < kLaneCand; ++k)
+                        if (k < nc) {
+                            const uint32_t key = (hamming256(q0, q1, d0[k], d1[k]) << 16) | (uint32_t)my[k];
+                            if (key < top[kMatchK - 1]) {
+                                top[kMatchK - 1] = key;
+#pragma unroll
+                                for (int e = kMatchK - 1; e > 0; --e)
+                                    if (top[e] < top[e - 1]) { const uint32_t w = top[e]; top[e] = top[e - 1]; top[e - 1] = w; }
+                            }
+                        }
+                    passed += nc;
+                    nc = 0;
+                };
                 for (int col = c.min_cx + sub; col <= c.max_cx; col += 16) {
                     const int i0 = cs[col * rows + c.min_cy], i1 = cs[col * rows + c.max_cy + 1];
                     for (int i = i0; i < i1; ++i) {
@@ -433,17 +464,11 @@ __global__ __launch_bounds__(256) void k_match_topk_cells(MatchProblem P) {
                             const float xr = sxr[i];
                             if (0 < xr && c.mg < fabsf(__fsub_rn(c.xr, xr))) continue;
                         }
-                        const uint4* d = reinterpret_cast<const uint4*>(t_desc + 32 * (size_t)s.t);
-                        const uint32_t key = (hamming256(q0, q1, d[0], d[1]) << 16) | (uint32_t)i;
-                        ++passed;
-                        if (key < top[kMatchK - 1]) {
-                            top[kMatchK - 1] = key;
-#pragma unroll
-                            for (int k = kMatchK - 1; k > 0; --k)
-                                if (top[k] < top[k - 1]) { const uint32_t w = top[k]; top[k] = top[k - 1]; top[k - 1] = w; }
-                        }
+                        my[nc++] = (uint16_t)i;
+                        if (nc == kLaneCand) drain();
                     }
                 }
+                drain();
             }
         }
         passed = row16_sum_i32(passed);
