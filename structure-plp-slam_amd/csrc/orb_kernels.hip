@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbPlanes pl, const CellDesc
                                                     int32_t* __restrict__ cell_count, int n_cells) {
     __shared__ __attribute__((aligned(16))) uint8_t tile[70 * kTileW];
     __shared__ __attribute__((aligned(16))) uint8_t score[66 * kScoreW];   // score map of the tested interior, +1 zero ring
-    __shared__ __attribute__((aligned(16))) uint8_t keep[64 * 64];         // NMS survivors (score or 0)
+    __shared__ unsigned long long keepbits[64];                            // NMS survivors, one bit per tested position
     __shared__ uint16_t queue[4096], queue2[4096];
     __shared__ int q_count, q2_count, n_ini, wave_tot[4], run_base;
 
@@ -170,18 +170,22 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbPlanes pl, const CellDesc
     const uint8_t* img = pl.level_ptr(frame, cd.level, L);
     const int pitch = pl.level_pitch(cd.level, L);
     const int w = cd.w, h = cd.h;
-    // stage the ROI through LDS: aligned dword loads (pitch and plane bases are 4-byte multiples)
+    // stage the ROI through LDS so that ROI column j sits at tile column j + 1: the tested position tx (ROI column
+    // tx + 3) is then at tile column tx + 4, dword-aligned for tx % 4 == 0 (pass 1 handles 4 positions per thread from
+    // whole dwords).  Global reads are aligned dwords, shifted into place with v_alignbyte.
     {
-        const int ox = cd.min_x & 3;
-        const int ndw = (w + ox + 3) >> 2;
-        const uint8_t* row0 = img + (size_t)cd.min_y * pitch + (cd.min_x - ox);
+        const int a0 = cd.min_x - 1;                 // image column of tile column 0
+        const int sh = a0 & 3;
+        const int ndw = (w + 2 + 3) >> 2;            // tile columns 0 .. w + 1
+        const uint8_t* row0 = img + (size_t)cd.min_y * pitch + (a0 - sh);
         for (int i = tid; i < ndw * h; i += 256) {
             const int r = i / ndw, c = i - r * ndw;
-            const uint32_t v = *reinterpret_cast<const uint32_t*>(row0 + (size_t)r * pitch + 4 * c);
+            const uint32_t* g = reinterpret_cast<const uint32_t*>(row0 + (size_t)r * pitch + 4 * c);
+            const uint32_t lo = g[0];
+            const uint32_t v = sh ? __builtin_amdgcn_alignbyte(g[1], lo, (uint32_t)sh) : lo;
             *reinterpret_cast<uint32_t*>(&tile[r * kTileW + 4 * c]) = v;
         }
     }
-    const int ox = cd.min_x & 3;
     const int tw = w - 6, th = h - 6;   // tested interior (ROI x,y in [3, w-3) x [3, h-3))
     // cv::FAST(ini_thr), and cv::FAST(min_thr) only when that finds nothing in this cell (:404-412).  A corner at
     // threshold t has score >= t, and scores below t never win a 3x3 comparison against one >= t, so each attempt may
@@ -190,20 +194,31 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbPlanes pl, const CellDesc
     for (int attempt = 0; attempt < 2; ++attempt) {
         thr = attempt == 0 ? ini_thr : min_thr;
         for (int i = tid; i < 66 * kScoreW / 4; i += 256) reinterpret_cast<uint32_t*>(score)[i] = 0;
-        for (int i = tid; i < 1024; i += 256) reinterpret_cast<uint32_t*>(keep)[i] = 0;
+        if (tid < 64) keepbits[tid] = 0ull;
         if (tid == 0) { q_count = 0; q2_count = 0; n_ini = 0; run_base = 0; }
         __syncthreads();
-        // pass 1: every arc of 9 contains two neighbouring compass pixels (0, 4, 8, 12): 5 reads reject most pixels
-        for (int i = tid; i < 4096; i += 256) {   // 64 x 64 positions, shifts instead of divisions; border cells skip the excess
-            const int ty = i >> 6, tx = i & 63;
-            if (tx >= tw || ty >= th) continue;
-            const uint8_t* c = &tile[(ty + 3) * kTileW + tx + 3 + ox];
-            const int v = c[0];
-            const int hi = v + thr, lo = v - thr;
-            const int p0 = c[3 * kTileW], p4 = c[3], p8 = c[-3 * kTileW], p12 = c[-3];
-            const bool b0 = p0 > hi, b4 = p4 > hi, b8 = p8 > hi, b12 = p12 > hi;
-            const bool d0 = p0 < lo, d4 = p4 < lo, d8 = p8 < lo, d12 = p12 < lo;
-            if (((b0 | b8) & (b4 | b12)) | ((d0 | d8) & (d4 | d12))) queue[atomicAdd(&q_count, 1)] = (uint16_t)i;
+        // pass 1: every arc of 9 contains two neighbouring compass pixels (0, 4, 8, 12): five dword reads serve four
+        // positions and reject most of them
+        for (int i = tid; i < 1024; i += 256) {   // 64 rows x 16 groups of 4 positions
+            const int ty = i >> 4, tx4 = (i & 15) * 4;
+            if (tx4 >= tw || ty >= th) continue;
+            const uint32_t* rowc = reinterpret_cast<const uint32_t*>(&tile[(ty + 3) * kTileW]) + (tx4 >> 2);
+            const uint32_t C = rowc[1], Lw = rowc[0], Rw = rowc[2];
+            const uint32_t Lq = __builtin_amdgcn_alignbyte(C, Lw, 1u);     // columns -3 of the four positions
+            const uint32_t Rq = __builtin_amdgcn_alignbyte(Rw, C, 3u);     // columns +3
+            const uint32_t U = *(reinterpret_cast<const uint32_t*>(&tile[ty * kTileW]) + (tx4 >> 2) + 1);          // row -3
+            const uint32_t D = *(reinterpret_cast<const uint32_t*>(&tile[(ty + 6) * kTileW]) + (tx4 >> 2) + 1);    // row +3
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (tx4 + k >= tw) break;
+                const int v = (int)((C >> (8 * k)) & 255u);
+                const int hi = v + thr, lo = v - thr;
+                const int p0 = (int)((D >> (8 * k)) & 255u), p4 = (int)((Rq >> (8 * k)) & 255u), p8 = (int)((U >> (8 * k)) & 255u),
+                          p12 = (int)((Lq >> (8 * k)) & 255u);
+                const bool b0 = p0 > hi, b4 = p4 > hi, b8 = p8 > hi, b12 = p12 > hi;
+                const bool d0 = p0 < lo, d4 = p4 < lo, d8 = p8 < lo, d12 = p12 < lo;
+                if (((b0 | b8) & (b4 | b12)) | ((d0 | d8) & (d4 | d12))) queue[atomicAdd(&q_count, 1)] = (uint16_t)((ty << 6) | (tx4 + k));
+            }
         }
         __syncthreads();
         // pass 2: 16-bit brighter / darker masks of the survivors -> "has an arc of 9" -> second queue
@@ -211,7 +226,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbPlanes pl, const CellDesc
         for (int j = tid; j < nq1; j += 256) {
             const int i = queue[j];
             const int ty = i >> 6, tx = i & 63;
-            const uint8_t* c = &tile[(ty + 3) * kTileW + tx + 3 + ox];
+            const uint8_t* c = &tile[(ty + 3) * kTileW + tx + 4];
             const int v = c[0];
             const int hi = v + thr, lo = v - thr;
             uint32_t B = 0, D = 0;
@@ -234,7 +249,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbPlanes pl, const CellDesc
         const int nq = q2_count;
         for (int j = tid; j < nq; j += 256) {
             const int ty = queue2[j] >> 6, tx = queue2[j] & 63;
-            const uint8_t* c = &tile[(ty + 3) * kTileW + tx + 3 + ox];
+            const uint8_t* c = &tile[(ty + 3) * kTileW + tx + 4];
             const int v = c[0];
             int d[16];
             d[0] = c[3 * kTileW] - v;        d[1] = c[3 * kTileW + 1] - v;    d[2] = c[2 * kTileW + 2] - v;   d[3] = c[kTileW + 3] - v;
@@ -267,7 +282,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbPlanes pl, const CellDesc
             const int v = sp[0];
             const bool ok = v > 0 && v > sp[-1] && v > sp[1] && v > sp[-kScoreW - 1] && v > sp[-kScoreW] && v > sp[-kScoreW + 1] &&
                             v > sp[kScoreW - 1] && v > sp[kScoreW] && v > sp[kScoreW + 1];
-            if (ok) { keep[ty * 64 + tx] = (uint8_t)v; ++my_ini; }
+            if (ok) { atomicOr(&keepbits[ty], 1ull << tx); ++my_ini; }
         }
         if (my_ini) atomicAdd(&n_ini, my_ini);
         __syncthreads();
@@ -276,38 +291,30 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbPlanes pl, const CellDesc
         if (found > 0 || min_thr >= ini_thr) break;
     }
 
-    // pass 4: ordered (row-major) compaction of the survivors.  Wave w owns the w-th quarter of the row-major
-    // sequence: count with ballots, one barrier for the wave bases, then write (no per-step barriers).
+    // pass 5: ordered (row-major) compaction of the survivors.  The NMS survivors of a position row are one 64-bit
+    // mask; wave w owns rows 16w .. 16w+15: counts by popcount, one barrier for the wave bases, then the writes.
     uint32_t* out = cell_cand + (size_t)out_slot * kCellCap;
     const int lane = tid & 63, wv = tid >> 6;
-    const int j0 = wv * 1024, j1 = j0 + 1024;   // 16 rows of the 64 x 64 position grid per wave
-    auto survivor = [&](int i, int& ty, int& tx, int& v) -> bool {
-        ty = i >> 6; tx = i & 63;
-        if (tx >= tw || ty >= th) return false;
-        v = keep[ty * 64 + tx];
-        bool emit = v >= thr && v > 0;
-        if (emit && mk) emit = !masked(cd.min_y + ty + 3, cd.min_x + tx + 3);   // (:429)
-        return emit;
+    auto row_mask = [&](int ty) -> unsigned long long {
+        unsigned long long m = keepbits[ty];
+        if (mk) m = __ballot(((m >> lane) & 1ull) && !masked(cd.min_y + ty + 3, cd.min_x + lane + 3));   // (:429)
+        return m;
     };
     int cnt = 0;
-    for (int g = j0; g < j1; g += 64) {
-        int ty, tx, v;
-        cnt += __popcll(__ballot(survivor(g + lane, ty, tx, v)));
-    }
+    for (int ty = 16 * wv; ty < 16 * wv + 16; ++ty) cnt += __popcll(row_mask(ty));
     if (lane == 0) wave_tot[wv] = cnt;
     __syncthreads();
     int off = 0;
     for (int k = 0; k < wv; ++k) off += wave_tot[k];
-    for (int g = j0; g < j1; g += 64) {
-        int ty = 0, tx = 0, v = 0;
-        const bool emit = survivor(g + lane, ty, tx, v);
-        const unsigned long long bal = __ballot(emit);
-        if (emit) {
+    for (int ty = 16 * wv; ty < 16 * wv + 16; ++ty) {
+        const unsigned long long m = row_mask(ty);
+        if ((m >> lane) & 1ull) {
             // border-relative position: ROI coordinate + cell index * 64 (orb_extractor.cc:426-427)
-            const uint32_t x = (uint32_t)(tx + 3 + cd.cx * kCellSize), y = (uint32_t)(ty + 3 + cd.cy * kCellSize);
-            out[off + __popcll(bal & ((1ull << lane) - 1ull))] = x | (y << 12) | ((uint32_t)v << 24);
+            const uint32_t v = score[(ty + 1) * kScoreW + lane + 1];
+            const uint32_t x = (uint32_t)(lane + 3 + cd.cx * kCellSize), y = (uint32_t)(ty + 3 + cd.cy * kCellSize);
+            out[off + __popcll(m & ((1ull << lane) - 1ull))] = x | (y << 12) | (v << 24);
         }
-        off += __popcll(bal);
+        off += __popcll(m);
     }
     if (tid == 0) run_base = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
     __syncthreads();
