@@ -29,6 +29,7 @@ struct plp_line {
     hipStream_t last_stream = nullptr;
     bool profiling = false;
     hipEvent_t ev[9] = {};
+    LineSideStream side{};                      // blur5 + Sobel beside the LSD chain
     double stage_ms[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // 8 stages + total
     long stage_batches = 0;
     std::mutex mu;
@@ -151,7 +152,8 @@ plp_status run(plp_line* c, const uint8_t* d_imgs, int B, int rows, int cols, si
         c->P.img = (const uint8_t*)c->aligned.p; c->P.img_frame_stride = fs; c->P.img_pitch = c->P.pitch;
     }
     PLP_HIP(hipMemsetAsync(c->status.p, 0, 16, st));
-    launch_line_front(st, c->P, c->lp, c->rt, c->t11, c->t5, c->w, d_kl, d_lbd, d_fn, cap, d_counts, B, c->profiling ? c->ev : nullptr);
+    launch_line_front(st, c->P, c->lp, c->rt, c->t11, c->t5, c->w, d_kl, d_lbd, d_fn, cap, d_counts, B, c->profiling ? c->ev : nullptr,
+                      c->side.stream ? &c->side : nullptr);
     PLP_HIP(hipGetLastError());
     if (c->profiling) {
         PLP_HIP(hipEventSynchronize(c->ev[8]));
@@ -177,6 +179,8 @@ plp_status plp_line_create(int device, plp_line** out) {
     plp_line* c = new plp_line();
     c->device = device;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return set_error(PLP_ERR_HIP, "hipStreamCreate failed"); }
+    if (hipStreamCreateWithFlags(&c->side.stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->side.fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->side.join, hipEventDisableTiming) != hipSuccess) { c->side.stream = nullptr; }   // optional: falls back to one stream
     *out = c;
     return PLP_OK;
 }
@@ -185,6 +189,9 @@ void plp_line_destroy(plp_line* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    if (c->side.stream) { (void)hipStreamSynchronize(c->side.stream); (void)hipStreamDestroy(c->side.stream); }
+    if (c->side.fork) (void)hipEventDestroy(c->side.fork);
+    if (c->side.join) (void)hipEventDestroy(c->side.join);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     delete c;
 }

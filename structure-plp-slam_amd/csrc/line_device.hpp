@@ -54,10 +54,12 @@ struct ResizeExactTab { const int16_t *xo, *xc, *yo, *yc; };   // offsets + 8.8 
 struct BlurTapsN { int k[11]; };
 struct LbdWeightsDev { float g[63], l[21]; };
 
+struct LineSideStream { hipStream_t stream; hipEvent_t fork, join; };   // optional second stream of a line context
+
 // ev: NULL or 9 events recorded around the 8 stages {blur11+resize, gradient+bins, seed order, region grow, key lines,
 // blur5+sobel, LBD, finalize}
 void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp, const ResizeExactTab& rt, const BlurTapsN& t11,
                        const BlurTapsN& t5, const LbdWeightsDev& w, plp_keyline* out_kl, uint8_t* out_lbd, double* out_fn, int cap,
-                       int32_t* out_counts, int B, hipEvent_t* ev);
+                       int32_t* out_counts, int B, hipEvent_t* ev, const LineSideStream* side);
 
 }  // namespace plp

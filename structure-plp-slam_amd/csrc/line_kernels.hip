@@ -830,11 +830,23 @@ __global__ __launch_bounds__(64) void k_line_finalize(LinePlanes P, LsdParams lp
 // ------------------------------------------------------------------------------------------ launch sequence
 void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp, const ResizeExactTab& rt, const BlurTapsN& t11,
                        const BlurTapsN& t5, const LbdWeightsDev& w, plp_keyline* out_kl, uint8_t* out_lbd, double* out_fn, int cap,
-                       int32_t* out_counts, int B, hipEvent_t* ev) {
+                       int32_t* out_counts, int B, hipEvent_t* ev, const LineSideStream* side) {
     auto mark = [&](int i) { if (ev) (void)hipEventRecord(ev[i], st); };
+    // The LBD image pass (5-tap blur + Sobel) does not depend on LSD: when a side stream is given (and no per-stage
+    // timing is requested) it runs beside the LSD chain and joins before k_lbd.
+    const bool fork = side && !ev;
+    hipStream_t st2 = fork ? side->stream : st;
     const size_t plane_fs = (size_t)P.pitch * P.H, splane_fs = (size_t)P.spitch * P.sh;
     const int tiles = ((P.W + 127) / 128) * ((P.H + 63) / 64);
     mark(0);
+    if (fork) {
+        (void)hipEventRecord(side->fork, st);
+        (void)hipStreamWaitEvent(st2, side->fork, 0);
+        hipLaunchKernelGGL(k_blur_plane<2>, dim3(tiles, B), dim3(256), 0, st2, P.img, P.img_frame_stride, P.img_pitch, P.blur5, plane_fs,
+                           P.pitch, P.W, P.H, t5);
+        hipLaunchKernelGGL(k_sobel3, dim3((P.W + 255) / 256, (P.H + 3) / 4, B), dim3(256), 0, st2, P.blur5, plane_fs, P.pitch, P.dxy, P.W, P.H);
+        (void)hipEventRecord(side->join, st2);
+    }
     hipLaunchKernelGGL(k_blur_plane<5>, dim3(tiles, B), dim3(256), 0, st, P.img, P.img_frame_stride, P.img_pitch, P.blur11, plane_fs,
                        P.pitch, P.W, P.H, t11);
     hipLaunchKernelGGL(k_resize_exact, dim3((P.sw + 255) / 256, (P.sh + 3) / 4, B), dim3(64, 4), 0, st, P.blur11, plane_fs, P.pitch,
@@ -857,9 +869,12 @@ void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp,
     mark(4);
     hipLaunchKernelGGL(k_keylines, dim3(B), dim3(64), 0, st, P, lp);
     mark(5);
-    hipLaunchKernelGGL(k_blur_plane<2>, dim3(tiles, B), dim3(256), 0, st, P.img, P.img_frame_stride, P.img_pitch, P.blur5, plane_fs,
-                       P.pitch, P.W, P.H, t5);
-    hipLaunchKernelGGL(k_sobel3, dim3((P.W + 255) / 256, (P.H + 3) / 4, B), dim3(256), 0, st, P.blur5, plane_fs, P.pitch, P.dxy, P.W, P.H);
+    if (fork) (void)hipStreamWaitEvent(st, side->join, 0);
+    else {
+        hipLaunchKernelGGL(k_blur_plane<2>, dim3(tiles, B), dim3(256), 0, st, P.img, P.img_frame_stride, P.img_pitch, P.blur5, plane_fs,
+                           P.pitch, P.W, P.H, t5);
+        hipLaunchKernelGGL(k_sobel3, dim3((P.W + 255) / 256, (P.H + 3) / 4, B), dim3(256), 0, st, P.blur5, plane_fs, P.pitch, P.dxy, P.W, P.H);
+    }
     mark(6);
     static const int lbd_blocks = [] { const char* e = getenv("PLP_LBD_BLOCKS"); int r = e ? atoi(e) : 4; return r > 0 ? r : 4; }();   // few resident waves per frame: their 63-row working sets have to stay in L1/L2
     hipLaunchKernelGGL(k_lbd, dim3(lbd_blocks, B), dim3(256), 0, st, P, w);
