@@ -1,0 +1,49 @@
+// TEST INFRASTRUCTURE ONLY.  Drives the shipped C++ facade (structure-plp-slam_amd/facade/PLPSLAM/feature/
+// orb_extractor.h, the header a reference maintainer swaps in for src/PLPSLAM/feature/orb_extractor.h) exactly the way
+// data::frame does (data/frame.cc:1125-1140, :763-772): cv::Mat in, std::vector<cv::KeyPoint> + cv::Mat out, getters,
+// set_max_num_keypoints, image_pyramid_.  Compiled against the reference's own orb_params.{h,cc} and oracle/ref_shim
+// (OpenCV is not in the image) and linked to libplp_front.so; tests/test_gpu_facade.py runs it on the GPU box and
+// compares its output file with the oracle.
+//   facade_orb_check <raw u8 image> <rows> <cols> <max_kp> <out file>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "PLPSLAM/feature/orb_extractor.h"
+
+int main(int argc, char** argv) {
+    if (argc < 6) return 2;
+    const int rows = std::atoi(argv[2]), cols = std::atoi(argv[3]), K = std::atoi(argv[4]);
+    std::vector<unsigned char> buf((size_t)rows * cols);
+    FILE* f = std::fopen(argv[1], "rb");
+    if (!f || std::fread(buf.data(), 1, buf.size(), f) != buf.size()) return 3;
+    std::fclose(f);
+    try {
+        PLPSLAM::feature::orb_extractor ex(2 * K, 1.2f, 8, 20, 7);
+        ex.set_max_num_keypoints(K);                                   // tracking_module.cc:88-97
+        cv::Mat img(rows, cols, CV_8UC1, buf.data());
+        std::vector<cv::KeyPoint> kps;
+        cv::Mat desc;
+        ex.extract(cv::_InputArray(img), cv::_InputArray(), kps, cv::_OutputArray(desc));
+        const std::vector<float> sf = ex.get_scale_factors(), isq = ex.get_inv_level_sigma_sq();
+        FILE* o = std::fopen(argv[5], "wb");
+        if (!o) return 4;
+        const int n = (int)kps.size(), nl = (int)ex.get_num_scale_levels(), mk = (int)ex.get_max_num_keypoints();
+        std::fwrite(&n, 4, 1, o); std::fwrite(&nl, 4, 1, o); std::fwrite(&mk, 4, 1, o);
+        std::fwrite(sf.data(), 4, sf.size(), o); std::fwrite(isq.data(), 4, isq.size(), o);
+        std::fwrite(kps.data(), sizeof(cv::KeyPoint), kps.size(), o);
+        for (int i = 0; i < n; ++i) std::fwrite(desc.ptr<unsigned char>(i), 1, 32, o);
+        for (int l = 0; l < nl; ++l) {                                  // the public pyramid (match::stereo reads it)
+            const cv::Mat& m = ex.image_pyramid_.at(l);
+            std::fwrite(&m.rows, 4, 1, o); std::fwrite(&m.cols, 4, 1, o);
+            unsigned sum = 0;
+            for (int y = 0; y < m.rows; ++y) for (int x = 0; x < m.cols; ++x) sum += m.at<unsigned char>(y, x);
+            std::fwrite(&sum, 4, 1, o);
+        }
+        std::fclose(o);
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "facade_orb_check: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

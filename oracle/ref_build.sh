@@ -12,3 +12,11 @@ g++ -O2 -std=c++17 -fPIC -shared -Wl,-Bsymbolic -ffp-contract=off -fno-fast-math
     "$REF/src/PLPSLAM/feature/orb_extractor.cc" "$REF/src/PLPSLAM/feature/orb_extractor_node.cc" "$REF/src/PLPSLAM/feature/orb_params.cc" \
     "$HERE/ref_driver.cpp" -o "$HERE/_ref/libplpref.so"
 echo "ref_build: built $HERE/_ref/libplpref.so"
+# the shipped C++ facade, compiled like a reference translation unit and linked to the product library
+PKG="$HERE/../structure-plp-slam_amd"
+if [ -f "$PKG/libplp_front.so" ]; then
+    g++ -O2 -std=c++17 -I"$PKG/facade" -I"$HERE/../include" -I"$HERE/ref_shim" -I"$REF/src" \
+        "$HERE/facade_check.cpp" "$REF/src/PLPSLAM/feature/orb_params.cc" -L"$PKG" -lplp_front -Wl,-rpath,'$ORIGIN/../../structure-plp-slam_amd' \
+        -Wl,--allow-shlib-undefined -o "$HERE/_ref/facade_orb_check"
+    echo "ref_build: built $HERE/_ref/facade_orb_check"
+fi

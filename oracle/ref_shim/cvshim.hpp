@@ -13,6 +13,7 @@
 #include <cstdint>
 #include <cstring>
 #include <memory>
+#include <stdexcept>
 #include <vector>
 
 #include "../cv_restated.hpp"
@@ -22,6 +23,7 @@ typedef unsigned char uchar;
 #define CV_8UC1 0
 #define CV_32F 5
 #define CV_PI 3.1415926535897932384626433832795
+#define CV_Assert(expr) do { if (!(expr)) throw std::runtime_error("CV_Assert failed: " #expr); } while (0)
 
 inline int cvRound(double v) { return oracle::cv_round(v); }
 inline int cvRound(float v) { return oracle::cv_round(v); }
@@ -99,6 +101,7 @@ public:
     template <typename T> T* ptr(size_t y) { return ptr<T>((int)y); }
     template <typename T> T* ptr(int y = 0) { return reinterpret_cast<T*>(data + (size_t)y * step); }
     template <typename T> const T* ptr(int y = 0) const { return reinterpret_cast<const T*>(data + (size_t)y * step); }
+    void copyTo(const class _OutputArray& dst) const;
     static MatZeros zeros(int r, int c, int type) { return MatZeros{r, c, type}; }
     // Mat = Mat::zeros(...) evaluates the expression INTO an existing matrix of the same size (cv::MatExpr semantics): a
     // row-range view keeps pointing into its parent
@@ -128,6 +131,11 @@ public:
     void create(int r, int c, int type) const { m_->create(r, c, type); }
     void release() const { m_->release(); }
 };
+inline void Mat::copyTo(const _OutputArray& dst) const {
+    dst.create(rows, cols, 0);
+    Mat d = dst.getMat();
+    for (int y = 0; y < rows; ++y) std::memcpy(d.data + (size_t)y * d.step, data + (size_t)y * step, cols);
+}
 typedef const _InputArray& InputArray;
 typedef const _OutputArray& OutputArray;
 
