@@ -314,25 +314,26 @@ __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed
         // the loop, in parallel (the loop used to hand every acceptance to lane 0: two more broadcasts and a
         // predicated block per accepted pixel of a kernel that is instruction-bound).
         const int n_before = nreg;
-        int last = -1;
         unsigned long long acc = 0;
+        // candidate / "comes after the last accepted lane" sets live in scalar registers: per iteration the vector
+        // unit only evaluates the two compares of the guard-banded test
+        unsigned long long candmask = __builtin_amdgcn_ballot_w64(cand), gt = ~0ull;
         while (true) {
-            const bool elig = cand && lane > last;
-            unsigned long long bal;
-            {
-                const float inv = __builtin_amdgcn_rsqf(sumdx * sumdx + sumdy * sumdy);   // |sum| >= 0.9: no denormal care needed
-                const float cosang = (ncs.x * sumdx + ncs.y * sumdy) * inv;
-                const bool pass = cosang >= c_pass, fail = cosang < c_fail;
-                const unsigned long long P = __ballot(elig && pass), U = __ballot(elig && !pass && !fail);
-                // a pixel inside the band matters only if it comes before the first certain acceptance
-                const unsigned long long before = P ? ((P & (0ull - P)) - 1ull) : ~0ull;
-                if (U & before) {
-                    if (!theta_valid) { reg_angle = (double)fast_atan2_deg_l(sumdy, sumdx) * (3.14159265358979323846 / 180); theta_valid = true; }
-                    bal = __ballot(elig && aligned_to((double)deg * (3.14159265358979323846 / 180), reg_angle, prec));
-                } else bal = P;
+            const unsigned long long elig = candmask & gt;
+            if (!elig) break;
+            const float inv = __builtin_amdgcn_rsqf(sumdx * sumdx + sumdy * sumdy);   // |sum| >= 0.9: no denormal care needed
+            const float cosang = (ncs.x * sumdx + ncs.y * sumdy) * inv;
+            const unsigned long long P = __builtin_amdgcn_ballot_w64(cosang >= c_pass) & elig;
+            const unsigned long long U = elig & ~P & ~__builtin_amdgcn_ballot_w64(cosang < c_fail);
+            // a pixel inside the band matters only if it comes before the first certain acceptance
+            const unsigned long long before = P ? ((P & (0ull - P)) - 1ull) : ~0ull;
+            unsigned long long bal = P;
+            if (U & before) {
+                if (!theta_valid) { reg_angle = (double)fast_atan2_deg_l(sumdy, sumdx) * (3.14159265358979323846 / 180); theta_valid = true; }
+                bal = __builtin_amdgcn_ballot_w64(aligned_to((double)deg * (3.14159265358979323846 / 180), reg_angle, prec)) & elig;
             }
             if (!bal) break;
-            const int k = __ffsll((long long)bal) - 1;
+            const int k = __builtin_ctzll(bal);
             const float ccos = bcast_f(ncs.x, k), csin = bcast_f(ncs.y, k);
             const int ap = bcast_i(np, k);
             acc |= 1ull << k;
@@ -340,8 +341,8 @@ __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed
             sumdx = __fadd_rn(sumdx, ccos);
             sumdy = __fadd_rn(sumdy, csin);
             theta_valid = false;
-            last = k;
-            if (np == ap) cand = false;   // the same pixel seen from a later point of the batch
+            gt = ~((2ull << k) - 1ull);                                       // lanes above k
+            candmask &= ~__builtin_amdgcn_ballot_w64(np == ap);              // the same pixel seen from a later point of the batch
         }
         if ((acc >> lane) & 1ull) {
             const int pos = n_before + __popcll(acc & ((1ull << lane) - 1ull));
