@@ -274,15 +274,21 @@ __device__ __forceinline__ void set_used(const GrowCtx& g, int p) { atomicOr(&g.
 // all f32 roundings with a factor two to spare, so outside it both tests agree by construction.  theta itself (one
 // f32 division + polynomial + two f64 operations on the critical path of EVERY accepted pixel before) is evaluated
 // only for a pixel inside the band that could be the next one accepted, and once when the region is complete.
-__device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed_deg, double prec, float c_pass, float c_fail,
-                           double& reg_angle) {
+// seed_cs: (float)cos / (float)sin of the seed's f64 angle when the caller has them (it evaluates them for 64 seeds in
+// one go: a sincos here runs with 64 lanes computing the same value), else NULL.
+__device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed_deg, const float2* seed_cs, double prec, float c_pass,
+                           float c_fail, double& reg_angle) {
     const int lane = g.lane;
     int nreg = 1;
     const int sx = seed % g.sw, sy = seed / g.sw;
     reg_angle = (double)(have_deg ? seed_deg : g.pix[seed].deg) * (3.14159265358979323846 / 180);
-    double s_sin, s_cos;
-    sincos(reg_angle, &s_sin, &s_cos);
-    float sumdx = (float)s_cos, sumdy = (float)s_sin;
+    float sumdx, sumdy;
+    if (seed_cs) { sumdx = seed_cs->x; sumdy = seed_cs->y; }
+    else {
+        double s_sin, s_cos;
+        sincos(reg_angle, &s_sin, &s_cos);
+        sumdx = (float)s_cos; sumdy = (float)s_sin;
+    }
     bool theta_valid = true;   // reg_angle is the seed's own angle until the first acceptance
     if (lane == 0) {
         const uint32_t c = (uint32_t)sx | ((uint32_t)sy << 16);
@@ -465,6 +471,12 @@ __global__ __launch_bounds__(256) void k_lsd_grow(LinePlanes P, LsdParams lp, in
         unsigned long long todo = __ballot(fresh);
         // every still-unused seed of this group of 64 fetches its own record now: one round trip for up to 64 regions
         const float s_deg = fresh ? g.pix[mine].deg : 0.f;
+        float2 s_cs = make_float2(0.f, 0.f);
+        if (fresh) {   // (float)cos / (float)sin of the f64 seed angle, 64 seeds per evaluation
+            double sn, cs;
+            sincos((double)s_deg * (3.14159265358979323846 / 180), &sn, &cs);
+            s_cs = make_float2((float)cs, (float)sn);
+        }
         while (todo) {
             const int t = __ffsll((long long)todo) - 1;
             todo &= todo - 1;
@@ -472,7 +484,8 @@ __global__ __launch_bounds__(256) void k_lsd_grow(LinePlanes P, LsdParams lp, in
             if (is_used(g, seed)) continue;   // claimed by a region grown since the ballot
             double reg_angle, cen[3];
             long long t0 = clock64();
-            int nreg = region_grow(g, seed, true, bcast_f(s_deg, t), lp.prec, lp.c_pass, lp.c_fail, reg_angle);
+            const float2 seed_cs = make_float2(bcast_f(s_cs.x, t), bcast_f(s_cs.y, t));
+            int nreg = region_grow(g, seed, true, bcast_f(s_deg, t), &seed_cs, lp.prec, lp.c_pass, lp.c_fail, reg_angle);
             t_grow += clock64() - t0; ++n_seed; n_pix += nreg;
             if (nreg < lp.min_reg_size) continue;
             region_list_fence();
@@ -519,7 +532,7 @@ __global__ __launch_bounds__(256) void k_lsd_grow(LinePlanes P, LsdParams lp, in
                     // guard band of the angle test for this tolerance (disabled = every test takes the exact path)
                     float cp = 2.f, cf = -2.f;
                     if (tau > 2 * kLsdAngleBand && tau < 1.5) { cp = (float)cos(tau - kLsdAngleBand); cf = (float)cos(tau + kLsdAngleBand); }
-                    nreg = region_grow(g, (int)(c0 >> 16) * g.sw + (int)(c0 & 0xffff), false, 0.f, tau, cp, cf, reg_angle);
+                    nreg = region_grow(g, (int)(c0 >> 16) * g.sw + (int)(c0 & 0xffff), false, 0.f, nullptr, tau, cp, cf, reg_angle);
                     region_list_fence();
                     if (nreg < 2) keep = false;
                     else {
