@@ -24,7 +24,7 @@ namespace {
 plp_status check_args(const plp_match_args* a) {
     if (!a) return set_error(PLP_ERR_INVALID_ARG, "args is NULL");
     if (a->B <= 0 || a->n_cap <= 0 || a->m_cap <= 0) return set_error(PLP_ERR_INVALID_ARG, "B, n_cap, m_cap must be positive");
-    if (a->n_cap > 8000) return set_error(PLP_ERR_UNSUPPORTED, "more than 8000 key points per frame");
+    if (a->n_cap > 8192) return set_error(PLP_ERR_UNSUPPORTED, "more than 8192 key points per frame");
     if (!a->t_desc || !a->q_desc) return set_error(PLP_ERR_INVALID_ARG, "descriptor arrays are required");
     if (a->mode != PLP_MATCH_MODE_FUSE && a->mode != PLP_MATCH_MODE_FUSE_LINE && (!a->out_match || !a->out_num)) return set_error(PLP_ERR_INVALID_ARG, "output arrays are required");
     if (a->mode == PLP_MATCH_MODE_BRUTE_FORCE) {

@@ -910,6 +910,8 @@ void launch_match(hipStream_t st, const MatchProblem& P, int B) {
         hipLaunchKernelGGL(k_match_topk_lds, qgrid, dim3(256), staged, st, P);
     } else
         hipLaunchKernelGGL(k_match_topk, dim3((P.m_cap + 3) / 4, B), dim3(256), 0, st, P);
+    static bool attr_set = false;   // up to 8192 targets: 96 KB of owner arrays
+    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_match_resolve), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 12); attr_set = true; }
     hipLaunchKernelGGL(k_match_resolve, dim3(B), dim3(256), (size_t)P.n_cap * 12, st, Q);
 }
 

@@ -335,3 +335,17 @@ def test_match_for_triangulation(seed):
             want_t = np.full(n, -1, np.int32); sel = want >= 0; want_t[want[sel]] = np.nonzero(sel)[0]
             assert gn[0] == wn and np.array_equal(got[0], want_t), (n, m, check)
     assert wn > 0
+
+
+def test_large_frames_take_the_global_memory_path():
+    """more targets than the LDS staging holds (KITTI, K = 4000: up to 8064 slots): k_match_topk + unsorted rescans"""
+    rng = np.random.default_rng(150)
+    grid = plp.make_grid(1241, 376)
+    for n, m, words in [(5000, 4000, 0), (8100, 3000, 12)]:
+        t, q = MC.random_problem(rng, n, m, n_words=words, cols=1241, rows=376, stereo=True)
+        run_landmarks(t, q, 12.0, 0.8, grid)
+        for check in (True, False):
+            want, wn = O.match_current_and_last(O.grid6(grid), t["t_kps"], t["t_desc"], t["t_x_right"], t["t_occupied"], SF, q["q_valid"], q["q_reproj"],
+                                                q["q_x_right"], q["q_level"], q["q_angle"], q["q_desc"], q["q_has_obs"], 15.0, 0, check)
+            got, gn = plp.matcher(0.9, check).match_host(plp.MODE_LAST_FRAME, n, m, {**t, **q}, margin=15.0, direction=0, scale_factors=SF, grid=grid)
+            assert gn[0] == wn and np.array_equal(got[0], want), (n, m, check)
