@@ -352,6 +352,33 @@ plp_status plp_lbd_match_1nn_host(plp_matcher* ctx, const uint8_t* q, int32_t nq
 plp_status plp_lbd_match_1nn_device(plp_matcher* ctx, const uint8_t* d_q, const int32_t* d_q_counts, int32_t nq_cap, const uint8_t* d_t,
                                     const int32_t* d_t_counts, int32_t nt_cap, int32_t B, int32_t* d_train_idx, int32_t* d_dist, void* hip_stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Post-extract per-key-point step of every data::frame constructor (src/PLPSLAM/data/frame.cc:68-86, 110-128, ...;
+ * SURVEY.md 8(f) item 1), so that features can stay in HBM between extraction and matching:
+ *   camera::perspective::undistort_keypoints            camera/perspective.cc:130-162 (cv::undistortPoints, EPS|MAX_ITER 20 1e-6,
+ *                                                        float camera matrix / distortion vector as the reference stores them)
+ *   camera::perspective::convert_keypoints_to_bearings  camera/perspective.cc:165-175
+ *   data::frame::compute_stereo_from_depth              data/frame.cc:1169-1219 (key points, and key lines when given)
+ * (data::assign_keypoints_to_grid, data/common.cc:205-231, is what the matcher's preparation kernel builds from undist.)
+ * undist gets pt / angle / size / octave of the distorted key point, response 0 and class_id -1, as the reference's resize()
+ * + field copies do.  depth: B x rows x cols f32 (depth_step = bytes per row) or NULL (then x_right / depths may be NULL);
+ * key-line outputs are written only for lines with both end-point depths >= 0, like the reference (pre-fill them).
+ * Device pointers, asynchronous on hip_stream (NULL = the context's stream). */
+typedef struct plp_camera {
+    double fx, fy, cx, cy;          /* camera::perspective fx_, fy_, cx_, cy_ */
+    double k1, k2, p1, p2, k3;      /* distortion */
+    double focal_x_baseline;        /* camera::base focal_x_baseline_ */
+} plp_camera;
+plp_status plp_post_extract_device(plp_matcher* ctx, const plp_camera* cam, const plp_keypoint* d_kps, const int32_t* d_counts, int32_t cap,
+                                   int32_t B, const float* d_depth, int32_t rows, int32_t cols, size_t depth_step, size_t depth_frame_stride,
+                                   plp_keypoint* d_undist, double* d_bearings, float* d_x_right, float* d_depths,
+                                   const plp_keyline* d_kl, const int32_t* d_kl_counts, int32_t kl_cap, float* d_kl_depths,
+                                   float* d_kl_x_right, void* hip_stream);
+/* One frame, host pointers, synchronous (NULL for the parts that are not wanted, as above). */
+plp_status plp_post_extract_host(plp_matcher* ctx, const plp_camera* cam, const plp_keypoint* kps, int32_t n, const float* depth, int32_t rows,
+                                 int32_t cols, size_t depth_step, plp_keypoint* undist, double* bearings, float* x_right, float* depths,
+                                 const plp_keyline* kl, int32_t n_kl, float* kl_depths, float* kl_x_right);
+
 /* Diagnostics: {exact full rescans, resolve rounds, 0, 0} accumulated over all calls of this context (synchronous). */
 plp_status plp_match_debug_counters(plp_matcher* ctx, int64_t* out4);
 

@@ -1,0 +1,135 @@
+// TEST INFRASTRUCTURE ONLY (oracle).  Not part of the product path.
+//
+// CPU restatement of the per-key-point step that follows extraction in every data::frame constructor
+// (src/PLPSLAM/data/frame.cc:68-86, 110-128, ... SURVEY.md 8(f) item 1):
+//   camera::perspective::undistort_keypoints          camera/perspective.cc:130-162
+//   camera::perspective::convert_keypoints_to_bearings camera/perspective.cc:165-175
+//   data::frame::compute_stereo_from_depth            data/frame.cc:1169-1219 (key points and key lines)
+// (assign_keypoints_to_grid, data/common.cc:205-231, is restated in match_oracle.cpp.)
+//
+// cv::undistortPoints is third-party (OpenCV, not under /root/reference): restated from the plain-C code path of
+// OpenCV 3.4.16 imgproc/undistort.cpp (cvUndistortPointsInternal) = "OpenCV-knowledge", PARITY UNPINNED -- the reference
+// has no test for this step.  Facts taken from the reference: the camera matrix and the distortion vector are stored
+// as cv::Mat_<float> (perspective.cc:47-48), so the solver sees FLOAT-rounded fx, fy, cx, cy, k1, k2, p1, p2, k3; R is
+// empty and P is the same float matrix; TermCriteria(EPS | MAX_ITER, 20, 1e-6); input and output points are CV_32FC2.
+#include <cmath>
+#include <cstdint>
+#include <limits>
+
+namespace {
+
+struct KeyPoint { float x, y, size, angle, response; int octave, class_id; };
+struct KeyLineRec {
+    float angle; int class_id; int octave; float pt_x, pt_y, response, size, startPointX, startPointY, endPointX, endPointY,
+        sPointInOctaveX, sPointInOctaveY, ePointInOctaveX, ePointInOctaveY, lineLength; int numOfPixels;
+};
+
+// cvUndistortPointsInternal for one CV_32FC2 point, distortion (k1, k2, p1, p2, k3), no tilt, R = I, P = A
+void undistort_point(double fx, double fy, double cx, double cy, const double k[5], float u_in, float v_in, float& out_x, float& out_y) {
+    const double ifx = 1. / fx, ify = 1. / fy;
+    double x = u_in, y = v_in;
+    const double u = x, v = y;
+    x = (x - cx) * ifx;
+    y = (y - cy) * ify;
+    // tilt compensation with the identity matrix: x*1 + y*0 + 1*0, invProj = 1/1
+    {
+        const double ux = x * 1.0 + y * 0.0 + 1.0 * 0.0, uy = x * 0.0 + y * 1.0 + 1.0 * 0.0, uz = x * 0.0 + y * 0.0 + 1.0 * 1.0;
+        const double invProj = uz ? 1. / uz : 1;
+        x = invProj * ux; y = invProj * uy;
+    }
+    const double x0 = x, y0 = y;
+    double error = std::numeric_limits<double>::max();
+    for (int j = 0;; j++) {
+        if (j >= 20) break;
+        if (error < 1e-6) break;
+        double r2 = x * x + y * y;
+        const double icdist = (1 + ((0.0 * r2 + 0.0) * r2 + 0.0) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+        if (icdist < 0) {   // test: undistortPoints regression 14583
+            x = (u - cx) * ifx;
+            y = (v - cy) * ify;
+            break;
+        }
+        const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + 0.0 * r2 + 0.0 * r2 * r2;
+        const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + 0.0 * r2 + 0.0 * r2 * r2;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+        {
+            r2 = x * x + y * y;
+            const double r4 = r2 * r2, r6 = r4 * r2;
+            const double a1 = 2 * x * y, a2 = r2 + 2 * x * x, a3 = r2 + 2 * y * y;
+            const double cdist = 1 + k[0] * r2 + k[1] * r4 + k[4] * r6;
+            const double icdist2 = 1. / (1 + 0.0 * r2 + 0.0 * r4 + 0.0 * r6);
+            const double xd0 = x * cdist * icdist2 + k[2] * a1 + k[3] * a2 + 0.0 * r2 + 0.0 * r4;
+            const double yd0 = y * cdist * icdist2 + k[2] * a3 + k[3] * a1 + 0.0 * r2 + 0.0 * r4;
+            const double tx = xd0 * 1.0 + yd0 * 0.0 + 1.0 * 0.0, ty = xd0 * 0.0 + yd0 * 1.0 + 1.0 * 0.0, tz = xd0 * 0.0 + yd0 * 0.0 + 1.0 * 1.0;
+            const double invProj = tz ? 1. / tz : 1;
+            const double xd = invProj * tx, yd = invProj * ty;
+            const double x_proj = xd * fx + cx, y_proj = yd * fy + cy;
+            error = std::sqrt((x_proj - u) * (x_proj - u) + (y_proj - v) * (y_proj - v));   // pow(d, 2) is exact squaring
+        }
+    }
+    // RR = P * I = [fx 0 cx; 0 fy cy; 0 0 1]
+    const double xx = fx * x + 0.0 * y + cx;
+    const double yy = 0.0 * x + fy * y + cy;
+    const double ww = 1. / (0.0 * x + 0.0 * y + 1.0);
+    out_x = (float)(xx * ww);
+    out_y = (float)(yy * ww);
+}
+
+}  // namespace
+
+extern "C" {
+
+// cam = {fx, fy, cx, cy, k1, k2, p1, p2, k3, focal_x_baseline} as the doubles of camera::perspective
+void oracle_undistort_keypoints(const double* cam, const KeyPoint* dist, int n, KeyPoint* undist) {
+    // cv_cam_matrix_ / cv_dist_params_ are float matrices, converted back to double by cvConvert
+    const double fx = (double)(float)cam[0], fy = (double)(float)cam[1], cx = (double)(float)cam[2], cy = (double)(float)cam[3];
+    const double k[5] = {(double)(float)cam[4], (double)(float)cam[5], (double)(float)cam[6], (double)(float)cam[7], (double)(float)cam[8]};
+    for (int i = 0; i < n; ++i) {
+        KeyPoint o{};   // undist_keypts.resize(): default key points, then pt / angle / size / octave are filled (:153-160)
+        o.size = 0; o.angle = -1; o.response = 0; o.octave = 0; o.class_id = -1;
+        undistort_point(fx, fy, cx, cy, k, dist[i].x, dist[i].y, o.x, o.y);
+        o.angle = dist[i].angle; o.size = dist[i].size; o.octave = dist[i].octave;
+        undist[i] = o;
+    }
+}
+
+void oracle_bearings(const double* cam, const KeyPoint* undist, int n, double* bearings) {
+    const double fx = cam[0], fy = cam[1], cx = cam[2], cy = cam[3];
+    for (int i = 0; i < n; ++i) {
+        const double x_normalized = (undist[i].x - cx) / fx;
+        const double y_normalized = (undist[i].y - cy) / fy;
+        const double l2_norm = std::sqrt(x_normalized * x_normalized + y_normalized * y_normalized + 1.0);
+        bearings[3 * i] = x_normalized / l2_norm; bearings[3 * i + 1] = y_normalized / l2_norm; bearings[3 * i + 2] = 1.0 / l2_norm;
+    }
+}
+
+// depth: rows x cols f32 (dense).  x_right / depths as std::vector<float>(n, -1) then overwritten.
+void oracle_stereo_from_depth(const double* cam, const float* depth, int rows, int cols, const KeyPoint* kps, const KeyPoint* undist, int n,
+                              float* x_right, float* depths) {
+    (void)rows;
+    for (int i = 0; i < n; ++i) {
+        x_right[i] = -1; depths[i] = -1;
+        const float x = kps[i].x, y = kps[i].y;
+        const float d = depth[(size_t)(int)y * cols + (int)x];   // cv::Mat::at<float>(float, float): truncation
+        if (d <= 0) continue;
+        depths[i] = d;
+        x_right[i] = (float)(undist[i].x - cam[9] / d);
+    }
+}
+
+// key lines (frame.cc:1196-1217); the two output arrays are left untouched for skipped lines, as in the reference
+void oracle_stereo_from_depth_lines(const double* cam, const float* depth, int rows, int cols, const KeyLineRec* kl, int n, float* depth_pairs,
+                                    float* x_right_pairs) {
+    (void)rows;
+    for (int i = 0; i < n; ++i) {
+        const float spx = kl[i].startPointX, spy = kl[i].startPointY, epx = kl[i].endPointX, epy = kl[i].endPointY;
+        const float depth_sp = depth[(size_t)(int)spy * cols + (int)spx], depth_ep = depth[(size_t)(int)epy * cols + (int)epx];
+        if (depth_sp < 0 || depth_ep < 0) continue;
+        depth_pairs[2 * i] = depth_sp; depth_pairs[2 * i + 1] = depth_ep;
+        x_right_pairs[2 * i] = (float)(spx - cam[9] / depth_sp);
+        x_right_pairs[2 * i + 1] = (float)(epx - cam[9] / depth_ep);
+    }
+}
+
+}  // extern "C"

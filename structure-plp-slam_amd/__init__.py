@@ -84,6 +84,8 @@ _API = [
     ("plp_match_host", C.c_int, [_VP, _VP]),
     ("plp_match_debug_counters", C.c_int, [_VP, _VP]),
     ("plp_match_area_host", C.c_int, [_VP, _VP, _VP, _I32, _VP, _VP, _I32, _VP, _VP, _I32, C.c_float, _I32, _VP, _VP]),
+    ("plp_post_extract_device", C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _VP, _I32, _I32, C.c_size_t, C.c_size_t, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _VP, _VP, _VP]),
+    ("plp_post_extract_host", C.c_int, [_VP, _VP, _VP, _I32, _VP, _I32, _I32, C.c_size_t, _VP, _VP, _VP, _VP, _VP, _I32, _VP, _VP]),
     ("plp_lbd_match_1nn_host", C.c_int, [_VP, _VP, _I32, _VP, _I32, _VP, _VP]),
     ("plp_lbd_match_1nn_device", C.c_int, [_VP, _VP, _VP, _I32, _VP, _VP, _I32, _I32, _VP, _VP, _VP]),
     ("plp_stereo_compute", C.c_int, [_VP, _VP, _VP, _I32, _VP, _I32, _VP, _VP, C.c_float, C.c_float, _VP, _VP]),
@@ -362,6 +364,11 @@ class LineFeatureTracker:
 # ------------------------------------------------------------------------------------------------
 # Hamming matchers, array form (match::projection / match::robust of the reference)
 # ------------------------------------------------------------------------------------------------
+class camera_c(C.Structure):
+    """plp_camera: camera::perspective intrinsics, distortion, focal_x_baseline"""
+    _fields_ = [(k, C.c_double) for k in ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "k3", "focal_x_baseline")]
+
+
 class match_grid_c(C.Structure):
     _fields_ = [("min_x", C.c_float), ("min_y", C.c_float), ("inv_cell_width", C.c_double), ("inv_cell_height", C.c_double),
                 ("cols", C.c_int32), ("rows", C.c_int32)]
@@ -466,6 +473,29 @@ class matcher:
         _check(lib().plp_match_area_host(self._h, _p(k1), _p(d1), len(k1), _p(k2), _p(d2), len(k2), C.byref(grid), _p(pp), int(margin),
                                          float(self.lowe_ratio), int(self.check_orientation), _p(out), C.byref(num)))
         return out[:len(k1)].copy(), pp, num.value
+
+    def post_extract(self, camera, keypts, depth=None, keylines=None, kl_depths=None, kl_x_right=None):
+        """undistort_keypoints + convert_keypoints_to_bearings (+ compute_stereo_from_depth when a depth image is given).
+        Returns dict(undist_keypts, bearings[, stereo_x_right, depths][, kl_depths, kl_x_right])."""
+        k = np.ascontiguousarray(keypts, KP_DTYPE)
+        n = len(k)
+        und = np.zeros(max(n, 1), KP_DTYPE); bear = np.zeros((max(n, 1), 3), np.float64)
+        xr = np.zeros(max(n, 1), np.float32); dep = np.zeros(max(n, 1), np.float32)
+        d = np.ascontiguousarray(depth, np.float32) if depth is not None else None
+        kl = np.ascontiguousarray(keylines, KL_DTYPE) if keylines is not None else None
+        nl = len(kl) if kl is not None else 0
+        kd = np.ascontiguousarray(kl_depths, np.float32).copy() if kl is not None else None
+        kx = np.ascontiguousarray(kl_x_right, np.float32).copy() if kl is not None else None
+        _check(lib().plp_post_extract_host(self._h, C.byref(camera), _p(k) if n else None, n, _p(d) if d is not None else None,
+                                           d.shape[0] if d is not None else 0, d.shape[1] if d is not None else 0, d.strides[0] if d is not None else 0,
+                                           _p(und), _p(bear), _p(xr) if d is not None else None, _p(dep) if d is not None else None,
+                                           _p(kl) if nl else None, nl, _p(kd) if nl else None, _p(kx) if nl else None))
+        out = dict(undist_keypts=und[:n].copy(), bearings=bear[:n].copy())
+        if d is not None:
+            out.update(stereo_x_right=xr[:n].copy(), depths=dep[:n].copy())
+        if kl is not None:
+            out.update(kl_depths=kd, kl_x_right=kx)
+        return out
 
     def lbd_match_1nn(self, query_lbd, train_lbd):
         """BinaryDescriptorMatcher::match: (trainIdx, distance) per query row"""

@@ -295,6 +295,97 @@ plp_status plp_match_area_host(plp_matcher* c, const plp_keypoint* kps_1, const 
     return PLP_OK;
 }
 
+namespace {
+PostArgs post_args(const plp_camera* cam) {
+    PostArgs A{};
+    A.fx = cam->fx; A.fy = cam->fy; A.cx = cam->cx; A.cy = cam->cy;
+    // cv_cam_matrix_ / cv_dist_params_ are cv::Mat_<float> (camera/perspective.cc:47-48)
+    A.fx_f = (double)(float)cam->fx; A.fy_f = (double)(float)cam->fy; A.cx_f = (double)(float)cam->cx; A.cy_f = (double)(float)cam->cy;
+    const double k[5] = {cam->k1, cam->k2, cam->p1, cam->p2, cam->k3};
+    for (int i = 0; i < 5; ++i) A.k[i] = (double)(float)k[i];
+    A.fxb = cam->focal_x_baseline;
+    return A;
+}
+}  // namespace
+
+plp_status plp_post_extract_device(plp_matcher* c, const plp_camera* cam, const plp_keypoint* d_kps, const int32_t* d_counts, int32_t cap,
+                                   int32_t B, const float* d_depth, int32_t rows, int32_t cols, size_t depth_step, size_t depth_frame_stride,
+                                   plp_keypoint* d_undist, double* d_bearings, float* d_x_right, float* d_depths,
+                                   const plp_keyline* d_kl, const int32_t* d_kl_counts, int32_t kl_cap, float* d_kl_depths,
+                                   float* d_kl_x_right, void* hip_stream) {
+    if (!c || !cam) return set_error(PLP_ERR_INVALID_ARG, "NULL argument");
+    if (B <= 0 || (d_kps && cap <= 0) || (d_kl && kl_cap <= 0)) return set_error(PLP_ERR_INVALID_ARG, "bad sizes");
+    if (!d_kps && !d_kl) return PLP_OK;
+    if (d_kps && !d_undist) return set_error(PLP_ERR_INVALID_ARG, "d_undist is required with d_kps");
+    if (d_depth && (rows <= 0 || cols <= 0 || depth_step < (size_t)cols * 4)) return set_error(PLP_ERR_INVALID_ARG, "bad depth geometry");
+    if (d_kl && (!d_depth || !d_kl_depths || !d_kl_x_right)) return set_error(PLP_ERR_INVALID_ARG, "key lines need depth, d_kl_depths, d_kl_x_right");
+    if (!(cam->fx != 0) || !(cam->fy != 0)) return set_error(PLP_ERR_INVALID_ARG, "fx, fy must be non-zero");
+    std::lock_guard<std::mutex> lk(c->mu);
+    PLP_HIP(hipSetDevice(c->device));
+    PostArgs A = post_args(cam);
+    A.kps = d_kps; A.counts = d_counts; A.cap = d_kps ? cap : 0;
+    A.depth = d_depth; A.depth_step = depth_step; A.depth_frame_stride = depth_frame_stride;
+    A.undist = d_undist; A.bearings = d_bearings; A.x_right = d_x_right; A.depths = d_depths;
+    A.kl = d_kl; A.kl_counts = d_kl_counts; A.kl_cap = d_kl ? kl_cap : 0; A.kl_depths = d_kl_depths; A.kl_x_right = d_kl_x_right;
+    launch_post_extract(hip_stream ? (hipStream_t)hip_stream : c->stream, A, B);
+    PLP_HIP(hipGetLastError());
+    return PLP_OK;
+}
+
+plp_status plp_post_extract_host(plp_matcher* c, const plp_camera* cam, const plp_keypoint* kps, int32_t n, const float* depth, int32_t rows,
+                                 int32_t cols, size_t depth_step, plp_keypoint* undist, double* bearings, float* x_right, float* depths,
+                                 const plp_keyline* kl, int32_t n_kl, float* kl_depths, float* kl_x_right) {
+    if (!c || !cam) return set_error(PLP_ERR_INVALID_ARG, "NULL argument");
+    if (n < 0 || n_kl < 0) return set_error(PLP_ERR_INVALID_ARG, "negative count");
+    if (n == 0 && n_kl == 0) return PLP_OK;
+    if (n > 0 && (!kps || !undist)) return set_error(PLP_ERR_INVALID_ARG, "kps and undist are required");
+    if (n_kl > 0 && (!kl || !depth || !kl_depths || !kl_x_right)) return set_error(PLP_ERR_INVALID_ARG, "key lines need depth and both outputs");
+    if (depth && (rows <= 0 || cols <= 0 || depth_step < (size_t)cols * 4)) return set_error(PLP_ERR_INVALID_ARG, "bad depth geometry");
+    hipStream_t st;
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        PLP_HIP(hipSetDevice(c->device));
+        st = c->stream;
+        auto al = [](size_t v) { return (v + 255) / 256 * 256; };
+        const size_t nk = std::max(n, 1), nl = std::max(n_kl, 1);
+        const size_t o_k = 0, o_u = o_k + al(nk * sizeof(plp_keypoint)), o_b = o_u + al(nk * sizeof(plp_keypoint)), o_x = o_b + al(nk * 24),
+                     o_d = o_x + al(nk * 4), o_l = o_d + al(nk * 4), o_ld = o_l + al(nl * sizeof(plp_keyline)), o_lx = o_ld + al(nl * 8),
+                     o_img = o_lx + al(nl * 8), total = o_img + (depth ? al((size_t)rows * cols * 4) : 0);
+        PLP_HIP(c->stage.reserve(total));
+        uint8_t* base = (uint8_t*)c->stage.p;
+        if (n) PLP_HIP(hipMemcpyAsync(base + o_k, kps, (size_t)n * sizeof(plp_keypoint), hipMemcpyHostToDevice, st));
+        if (n_kl) {
+            PLP_HIP(hipMemcpyAsync(base + o_l, kl, (size_t)n_kl * sizeof(plp_keyline), hipMemcpyHostToDevice, st));
+            PLP_HIP(hipMemcpyAsync(base + o_ld, kl_depths, (size_t)n_kl * 8, hipMemcpyHostToDevice, st));     // skipped lines keep the caller's values
+            PLP_HIP(hipMemcpyAsync(base + o_lx, kl_x_right, (size_t)n_kl * 8, hipMemcpyHostToDevice, st));
+        }
+        if (depth) PLP_HIP(hipMemcpy2DAsync(base + o_img, (size_t)cols * 4, depth, depth_step, (size_t)cols * 4, rows, hipMemcpyHostToDevice, st));
+        PostArgs A = post_args(cam);
+        A.kps = n ? (const plp_keypoint*)(base + o_k) : nullptr; A.counts = nullptr; A.cap = n;
+        A.depth = depth ? (const float*)(base + o_img) : nullptr; A.depth_step = (size_t)cols * 4; A.depth_frame_stride = 0;
+        A.undist = (plp_keypoint*)(base + o_u); A.bearings = bearings ? (double*)(base + o_b) : nullptr;
+        A.x_right = (depth && x_right && depths) ? (float*)(base + o_x) : nullptr; A.depths = A.x_right ? (float*)(base + o_d) : nullptr;
+        A.kl = n_kl ? (const plp_keyline*)(base + o_l) : nullptr; A.kl_counts = nullptr; A.kl_cap = n_kl;
+        A.kl_depths = (float*)(base + o_ld); A.kl_x_right = (float*)(base + o_lx);
+        launch_post_extract(st, A, 1);
+        PLP_HIP(hipGetLastError());
+        if (n) {
+            PLP_HIP(hipMemcpyAsync(undist, base + o_u, (size_t)n * sizeof(plp_keypoint), hipMemcpyDeviceToHost, st));
+            if (bearings) PLP_HIP(hipMemcpyAsync(bearings, base + o_b, (size_t)n * 24, hipMemcpyDeviceToHost, st));
+            if (A.x_right) {
+                PLP_HIP(hipMemcpyAsync(x_right, base + o_x, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+                PLP_HIP(hipMemcpyAsync(depths, base + o_d, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+            }
+        }
+        if (n_kl) {
+            PLP_HIP(hipMemcpyAsync(kl_depths, base + o_ld, (size_t)n_kl * 8, hipMemcpyDeviceToHost, st));
+            PLP_HIP(hipMemcpyAsync(kl_x_right, base + o_lx, (size_t)n_kl * 8, hipMemcpyDeviceToHost, st));
+        }
+        PLP_HIP(hipStreamSynchronize(st));
+    }
+    return PLP_OK;
+}
+
 plp_status plp_match_debug_counters(plp_matcher* c, int64_t* out4) {
     if (!c || !out4) return set_error(PLP_ERR_INVALID_ARG, "NULL argument");
     std::lock_guard<std::mutex> lk(c->mu);

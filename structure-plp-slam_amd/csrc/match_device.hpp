@@ -79,4 +79,17 @@ struct AreaArgs {
 void launch_match_area(hipStream_t st, const AreaArgs& A);
 void launch_hamming_matrix(hipStream_t st, const uint8_t* q, int nq, const uint8_t* t, int nt, uint16_t* dist);
 
+// post-extract step (post_kernels.hip)
+struct PostArgs {
+    double fx, fy, cx, cy;            // camera::perspective doubles (bearings)
+    double fx_f, fy_f, cx_f, cy_f;    // the float-rounded matrix cv::undistortPoints sees
+    double k[5];                      // float-rounded k1, k2, p1, p2, k3
+    double fxb;                       // focal_x_baseline_
+    const plp_keypoint* kps; const int32_t* counts; int cap;
+    const float* depth; size_t depth_step, depth_frame_stride;
+    plp_keypoint* undist; double* bearings; float* x_right; float* depths;
+    const plp_keyline* kl; const int32_t* kl_counts; int kl_cap; float* kl_depths; float* kl_x_right;
+};
+void launch_post_extract(hipStream_t st, const PostArgs& A, int B);
+
 }  // namespace plp

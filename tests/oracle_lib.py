@@ -466,3 +466,24 @@ def match_for_triangulation(q_desc, q_angle, q_node, q_has_lm, q_x_right, q_octa
     c = [_c(sf, np.float32), _c(E_12, np.float64), _c(epipole, np.float64)]
     num = _call("oracle_match_for_triangulation", a + [m] + b + [n] + c + [int(check), out], C.c_uint)
     return out[:m].copy(), num
+
+
+# ---- post-extract step (oracle/post_oracle.cpp)
+def post_extract(cam10, kps, depth=None, keylines=None, kl_depths=None, kl_x_right=None):
+    cam = _c(cam10, np.float64)
+    k = _c(kps, KP_DTYPE); n = len(k)
+    und = np.zeros(max(n, 1), KP_DTYPE); bear = np.zeros((max(n, 1), 3), np.float64)
+    _call("oracle_undistort_keypoints", [cam, k, n, und])
+    _call("oracle_bearings", [cam, und, n, bear])
+    out = dict(undist_keypts=und[:n].copy(), bearings=bear[:n].copy())
+    if depth is not None:
+        d = _c(depth, np.float32)
+        xr = np.zeros(max(n, 1), np.float32); dep = np.zeros(max(n, 1), np.float32)
+        _call("oracle_stereo_from_depth", [cam, d, d.shape[0], d.shape[1], k, und, n, xr, dep])
+        out.update(stereo_x_right=xr[:n].copy(), depths=dep[:n].copy())
+        if keylines is not None:
+            kl = _c(keylines, KL_DTYPE)
+            kd = _c(kl_depths, np.float32).copy(); kx = _c(kl_x_right, np.float32).copy()
+            _call("oracle_stereo_from_depth_lines", [cam, d, d.shape[0], d.shape[1], kl, len(kl), kd, kx])
+            out.update(kl_depths=kd, kl_x_right=kx)
+    return out

@@ -1,0 +1,97 @@
+"""Post-extract per-key-point step (undistort_keypoints, convert_keypoints_to_bearings, compute_stereo_from_depth):
+HIP path vs oracle, bit-exact (f64 arithmetic with +, -, *, /, sqrt only)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from plp import plp, synth
+
+pytestmark = pytest.mark.gpu
+
+# TUM RGB-D freiburg1 / freiburg2 (distorted) and freiburg3 (rectified) intrinsics as in the reference's example configs
+CAMS = {
+    "fr1": (517.306408, 516.469215, 318.643040, 255.313989, 0.262383, -0.953104, -0.005358, 0.002628, 1.163314, 40.0),
+    "fr2": (520.908620, 521.007327, 325.141442, 249.701764, 0.231222, -0.784899, -0.003257, -0.000105, 0.917205, 40.0),
+    "fr3": (535.4, 539.2, 320.1, 247.6, 0.0, 0.0, 0.0, 0.0, 0.0, 40.0),
+    "kitti": (718.856, 718.856, 607.1928, 185.2157, 0.0, 0.0, 0.0, 0.0, 0.0, 386.1448),
+    "wide": (300.0, 305.0, 322.0, 241.0, -0.35, 0.12, 0.001, -0.0007, -0.02, 30.0),
+}
+
+
+def cam_struct(v):
+    c = plp.camera_c()
+    for name, val in zip(("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "k3", "focal_x_baseline"), v):
+        setattr(c, name, float(val))
+    return c
+
+
+@pytest.mark.parametrize("name", list(CAMS))
+def test_post_extract_matches_oracle(name):
+    cam = CAMS[name]
+    rng = np.random.default_rng(5)
+    img = synth.replay(3, 1, 480, 640)[0]
+    kps, _ = O.OrbOracle(1500).extract(img)
+    # a few exact corners / borders in addition to the extractor's key points
+    extra = np.zeros(6, O.KP_DTYPE)
+    extra["x"] = [0, 639, 0, 639, 320.25, 19.5]; extra["y"] = [0, 0, 479, 479, 240.75, 460.0]; extra["octave"] = [0, 1, 2, 3, 4, 5]
+    kps = np.concatenate([kps, extra])
+    depth = rng.uniform(0.3, 8.0, (480, 640)).astype(np.float32)
+    depth[rng.uniform(size=depth.shape) < 0.2] = 0.0            # missing depth
+    depth[rng.uniform(size=depth.shape) < 0.02] = -1.0
+    kl = np.zeros(40, O.KL_DTYPE)
+    kl["startPointX"] = rng.uniform(0, 639, 40); kl["startPointY"] = rng.uniform(0, 479, 40)
+    kl["endPointX"] = rng.uniform(0, 639, 40); kl["endPointY"] = rng.uniform(0, 479, 40)
+    pre_d = np.full((40, 2), -1, np.float32); pre_x = np.full((40, 2), -1, np.float32)
+    want = O.post_extract(cam, kps, depth, kl, pre_d, pre_x)
+    got = plp.matcher().post_extract(cam_struct(cam), kps, depth, kl, pre_d, pre_x)
+    for key in want:
+        assert np.array_equal(got[key], want[key]), key
+    assert (want["stereo_x_right"] >= 0).sum() > 500 and (want["depths"] < 0).sum() > 100
+    if name in ("fr3", "kitti"):     # no distortion: the fixed-point iteration returns the input up to the final float rounding
+        assert np.abs(want["undist_keypts"]["x"] - kps["x"]).max() < 1e-3
+    else:
+        assert np.abs(want["undist_keypts"]["x"] - kps["x"]).max() > 0.5
+    nb = np.linalg.norm(want["bearings"], axis=1)
+    assert np.abs(nb - 1).max() < 1e-12
+
+
+def test_post_extract_without_depth_and_empty():
+    cam = CAMS["fr1"]
+    kps = np.zeros(3, O.KP_DTYPE); kps["x"] = [10, 300, 630]; kps["y"] = [20, 240, 470]
+    want = O.post_extract(cam, kps)
+    got = plp.matcher().post_extract(cam_struct(cam), kps)
+    assert set(got) == {"undist_keypts", "bearings"}
+    assert np.array_equal(got["undist_keypts"], want["undist_keypts"]) and np.array_equal(got["bearings"], want["bearings"])
+    assert len(plp.matcher().post_extract(cam_struct(cam), np.zeros(0, O.KP_DTYPE))["undist_keypts"]) == 0
+
+
+def test_post_extract_batched_device():
+    import torch
+    cam = CAMS["fr2"]
+    frames = synth.replay(9, 3, 480, 640)
+    ex = plp.orb_extractor(1000)
+    B, cap = len(frames), 2064
+    dev = torch.device("cuda", 0)
+    d_fr = torch.from_numpy(frames).to(dev)
+    d_k = torch.zeros((B, cap, 28), dtype=torch.uint8, device=dev); d_d = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_c = torch.zeros(B, dtype=torch.int32, device=dev)
+    ex.extract_batch(d_fr, d_k, d_d, d_c)
+    rng = np.random.default_rng(2)
+    depth = rng.uniform(0.5, 6.0, (B, 480, 640)).astype(np.float32)
+    d_depth = torch.from_numpy(depth).to(dev)
+    d_u = torch.zeros_like(d_k); d_b = torch.zeros((B, cap, 3), dtype=torch.float64, device=dev)
+    d_x = torch.zeros((B, cap), dtype=torch.float32, device=dev); d_z = torch.zeros((B, cap), dtype=torch.float32, device=dev)
+    mt = plp.matcher()
+    c = cam_struct(cam)
+    import ctypes as C
+    plp._check(plp.lib().plp_post_extract_device(mt._h, C.byref(c), d_k.data_ptr(), d_c.data_ptr(), cap, B, d_depth.data_ptr(), 480, 640, 640 * 4, 480 * 640 * 4,
+                                                d_u.data_ptr(), d_b.data_ptr(), d_x.data_ptr(), d_z.data_ptr(), None, None, 0, None, None, None))
+    torch.cuda.synchronize()
+    cnt = d_c.cpu().numpy()
+    for b in range(B):
+        n = int(cnt[b])
+        kps = d_k[b].cpu().numpy().view(plp.KP_DTYPE).reshape(cap)[:n]
+        want = O.post_extract(cam, kps, depth[b])
+        assert np.array_equal(d_u[b].cpu().numpy().view(plp.KP_DTYPE).reshape(cap)[:n], want["undist_keypts"])
+        assert np.array_equal(d_b[b].cpu().numpy()[:n], want["bearings"])
+        assert np.array_equal(d_x[b].cpu().numpy()[:n], want["stereo_x_right"]) and np.array_equal(d_z[b].cpu().numpy()[:n], want["depths"])
