@@ -379,6 +379,15 @@ plp_status plp_post_extract_host(plp_matcher* ctx, const plp_camera* cam, const 
                                  int32_t cols, size_t depth_step, plp_keypoint* undist, double* bearings, float* x_right, float* depths,
                                  const plp_keyline* kl, int32_t n_kl, float* kl_depths, float* kl_x_right);
 
+/* landmark::compute_descriptor (src/PLPSLAM/data/landmark.cc:181-245) and Line::compute_descriptor
+ * (data/landmark_line.cc:256-320), the search part, for L landmarks at once: landmark l owns the
+ * descriptors descs[offsets[l] .. offsets[l+1]) (32 B rows, observation order); best_idx[l] = the row (relative to
+ * offsets[l]) whose median Hamming distance to all rows of the landmark -- itself included, rank (unsigned)(0.5 * (n - 1)) --
+ * is smallest, first such row; -1 for a landmark without rows.  At most 1024 rows per landmark. */
+plp_status plp_landmark_descriptor_device(plp_matcher* ctx, const uint8_t* d_descs, const int32_t* d_offsets, int32_t L, int32_t* d_best_idx,
+                                          void* hip_stream);
+plp_status plp_landmark_descriptor_host(plp_matcher* ctx, const uint8_t* descs, const int32_t* offsets, int32_t L, int32_t* best_idx);
+
 /* Diagnostics: {exact full rescans, resolve rounds, 0, 0} accumulated over all calls of this context (synchronous). */
 plp_status plp_match_debug_counters(plp_matcher* ctx, int64_t* out4);
 

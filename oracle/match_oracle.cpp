@@ -771,3 +771,32 @@ unsigned oracle_match_for_triangulation(const uint8_t* q_desc, const float* q_an
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------- landmark descriptor maintenance
+extern "C" {
+
+// landmark::compute_descriptor (data/landmark.cc:181-245; Line::compute_descriptor data/landmark_line.cc:256-320 is the same
+// on LBD rows), array form: descs = the num_descs observation descriptors in observation (std::map) order.  Returns
+// best_idx: the descriptor whose MEDIAN Hamming distance to all of them (itself included, rank (unsigned)(0.5 * (n - 1)))
+// is smallest, first such index.  n == 0 returns -1 (the reference returns before touching descriptor_).
+int oracle_landmark_descriptor(const uint8_t* descs, int num_descs) {
+    if (num_descs <= 0) return -1;
+    std::vector<std::vector<unsigned>> hamm(num_descs, std::vector<unsigned>(num_descs));
+    for (int i = 0; i < num_descs; ++i) {
+        hamm[i][i] = 0;
+        for (int j = i + 1; j < num_descs; ++j) {
+            const unsigned d = hamming32(descs + 32 * (size_t)i, descs + 32 * (size_t)j);
+            hamm[i][j] = d; hamm[j][i] = d;
+        }
+    }
+    unsigned best_median = MAX_HAMMING_DIST, best_idx = 0;
+    for (int idx = 0; idx < num_descs; ++idx) {
+        std::vector<unsigned> part(hamm[idx].begin(), hamm[idx].begin() + num_descs);
+        std::sort(part.begin(), part.end());
+        const unsigned median = part.at(static_cast<unsigned>(0.5 * (num_descs - 1)));
+        if (median < best_median) { best_median = median; best_idx = (unsigned)idx; }
+    }
+    return (int)best_idx;
+}
+
+}  // extern "C"

@@ -84,6 +84,8 @@ _API = [
     ("plp_match_host", C.c_int, [_VP, _VP]),
     ("plp_match_debug_counters", C.c_int, [_VP, _VP]),
     ("plp_match_area_host", C.c_int, [_VP, _VP, _VP, _I32, _VP, _VP, _I32, _VP, _VP, _I32, C.c_float, _I32, _VP, _VP]),
+    ("plp_landmark_descriptor_device", C.c_int, [_VP, _VP, _VP, _I32, _VP, _VP]),
+    ("plp_landmark_descriptor_host", C.c_int, [_VP, _VP, _VP, _I32, _VP]),
     ("plp_post_extract_device", C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _VP, _I32, _I32, C.c_size_t, C.c_size_t, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _VP, _VP, _VP]),
     ("plp_post_extract_host", C.c_int, [_VP, _VP, _VP, _I32, _VP, _I32, _I32, C.c_size_t, _VP, _VP, _VP, _VP, _VP, _I32, _VP, _VP]),
     ("plp_lbd_match_1nn_host", C.c_int, [_VP, _VP, _I32, _VP, _I32, _VP, _VP]),
@@ -473,6 +475,13 @@ class matcher:
         _check(lib().plp_match_area_host(self._h, _p(k1), _p(d1), len(k1), _p(k2), _p(d2), len(k2), C.byref(grid), _p(pp), int(margin),
                                          float(self.lowe_ratio), int(self.check_orientation), _p(out), C.byref(num)))
         return out[:len(k1)].copy(), pp, num.value
+
+    def landmark_descriptors(self, descs, offsets):
+        """landmark::compute_descriptor for L landmarks: descs [total, 32] u8, offsets [L + 1] -> best row per landmark (-1: none)"""
+        d = np.ascontiguousarray(descs, np.uint8).reshape(-1, 32); o = np.ascontiguousarray(offsets, np.int32)
+        out = np.zeros(max(len(o) - 1, 1), np.int32)
+        _check(lib().plp_landmark_descriptor_host(self._h, _p(d) if len(d) else None, _p(o), len(o) - 1, _p(out)))
+        return out[:len(o) - 1].copy()
 
     def post_extract(self, camera, keypts, depth=None, keylines=None, kl_depths=None, kl_x_right=None):
         """undistort_keypoints + convert_keypoints_to_bearings (+ compute_stereo_from_depth when a depth image is given).

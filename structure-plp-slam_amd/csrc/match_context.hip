@@ -386,6 +386,40 @@ plp_status plp_post_extract_host(plp_matcher* c, const plp_camera* cam, const pl
     return PLP_OK;
 }
 
+plp_status plp_landmark_descriptor_device(plp_matcher* c, const uint8_t* d_descs, const int32_t* d_offsets, int32_t L, int32_t* d_best_idx,
+                                          void* hip_stream) {
+    if (!c || !d_offsets || !d_best_idx || L < 0) return set_error(PLP_ERR_INVALID_ARG, "bad argument");
+    if (L == 0) return PLP_OK;
+    std::lock_guard<std::mutex> lk(c->mu);
+    PLP_HIP(hipSetDevice(c->device));
+    launch_landmark_descriptor(hip_stream ? (hipStream_t)hip_stream : c->stream, d_descs, d_offsets, L, d_best_idx);
+    PLP_HIP(hipGetLastError());
+    return PLP_OK;
+}
+
+plp_status plp_landmark_descriptor_host(plp_matcher* c, const uint8_t* descs, const int32_t* offsets, int32_t L, int32_t* best_idx) {
+    if (!c || !offsets || !best_idx || L < 0) return set_error(PLP_ERR_INVALID_ARG, "bad argument");
+    if (L == 0) return PLP_OK;
+    const int64_t total = offsets[L];
+    if (total < 0 || (total > 0 && !descs)) return set_error(PLP_ERR_INVALID_ARG, "bad offsets / descs");
+    for (int l = 0; l < L; ++l)
+        if (offsets[l + 1] < offsets[l] || offsets[l + 1] - offsets[l] > 1024) return set_error(PLP_ERR_UNSUPPORTED, "offsets must ascend, at most 1024 rows per landmark");
+    std::lock_guard<std::mutex> lk(c->mu);
+    PLP_HIP(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    auto al = [](size_t v) { return (v + 255) / 256 * 256; };
+    const size_t o_d = 0, o_o = al((size_t)std::max<int64_t>(total, 1) * 32), o_b = o_o + al((size_t)(L + 1) * 4), tot = o_b + al((size_t)L * 4);
+    PLP_HIP(c->stage.reserve(tot));
+    uint8_t* base = (uint8_t*)c->stage.p;
+    if (total) PLP_HIP(hipMemcpyAsync(base + o_d, descs, (size_t)total * 32, hipMemcpyHostToDevice, st));
+    PLP_HIP(hipMemcpyAsync(base + o_o, offsets, (size_t)(L + 1) * 4, hipMemcpyHostToDevice, st));
+    launch_landmark_descriptor(st, base + o_d, (const int32_t*)(base + o_o), L, (int32_t*)(base + o_b));
+    PLP_HIP(hipGetLastError());
+    PLP_HIP(hipMemcpyAsync(best_idx, base + o_b, (size_t)L * 4, hipMemcpyDeviceToHost, st));
+    PLP_HIP(hipStreamSynchronize(st));
+    return PLP_OK;
+}
+
 plp_status plp_match_debug_counters(plp_matcher* c, int64_t* out4) {
     if (!c || !out4) return set_error(PLP_ERR_INVALID_ARG, "NULL argument");
     std::lock_guard<std::mutex> lk(c->mu);

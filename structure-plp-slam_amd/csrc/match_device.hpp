@@ -91,5 +91,6 @@ struct PostArgs {
     const plp_keyline* kl; const int32_t* kl_counts; int kl_cap; float* kl_depths; float* kl_x_right;
 };
 void launch_post_extract(hipStream_t st, const PostArgs& A, int B);
+void launch_landmark_descriptor(hipStream_t st, const uint8_t* descs, const int32_t* offsets, int L, int32_t* best_idx);
 
 }  // namespace plp

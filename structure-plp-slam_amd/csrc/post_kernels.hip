@@ -99,6 +99,48 @@ __global__ __launch_bounds__(256) void k_post_extract(PostArgs A) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// landmark::compute_descriptor (data/landmark.cc:181-245): median-of-Hamming-distances selection, one wave per landmark.
+// Lane = candidate row i (rows i, i + 64, ... for more than 64 observations); its median is found by counting, without a
+// sort: the rank-r element of the row's distances is the smallest distance v with #(distances <= v) > r.
+// grid = (ceil(L / 4)), block = 256.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_landmark_descriptor(const uint8_t* __restrict__ descs, const int32_t* __restrict__ offsets, int L,
+                                                             int32_t* __restrict__ best_idx) {
+    const int lane = threadIdx.x & 63, l = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (l >= L) return;
+    const int o0 = offsets[l], n = offsets[l + 1] - o0;
+    if (n <= 0) { if (lane == 0) best_idx[l] = -1; return; }
+    const uint4* D = reinterpret_cast<const uint4*>(descs + 32 * (size_t)o0);
+    const int r = (int)(unsigned)(0.5 * (double)(n - 1));
+    unsigned best = 0xffffffffu;   // (median << 16 | row): smallest median, then first row
+    for (int i = lane; i < n; i += 64) {
+        const uint4 a0 = D[2 * i], a1 = D[2 * i + 1];
+        // histogram-free selection: distances are 0..256, so binary-search the value v with count(d <= v) > r
+        int lo = 0, hi = 256;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            int cnt = 0;
+            for (int j = 0; j < n; ++j) {
+                const uint4 b0 = D[2 * j], b1 = D[2 * j + 1];
+                const int d = __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) + __popc(a1.x ^ b1.x) +
+                              __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+                cnt += d <= mid;
+            }
+            if (cnt > r) hi = mid; else lo = mid + 1;
+        }
+        const unsigned key = ((unsigned)lo << 16) | (unsigned)i;
+        best = key < best ? key : best;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned w = (unsigned)__shfl_xor((int)best, o); best = w < best ? w : best; }
+    if (lane == 0) best_idx[l] = (int32_t)(best & 0xffffu);
+}
+
+void launch_landmark_descriptor(hipStream_t st, const uint8_t* descs, const int32_t* offsets, int L, int32_t* best_idx) {
+    hipLaunchKernelGGL(k_landmark_descriptor, dim3((L + 3) / 4), dim3(256), 0, st, descs, offsets, L, best_idx);
+}
+
 void launch_post_extract(hipStream_t st, const PostArgs& A, int B) {
     const int n = A.cap > A.kl_cap ? A.cap : A.kl_cap;
     hipLaunchKernelGGL(k_post_extract, dim3((n + 255) / 256, B), dim3(256), 0, st, A);

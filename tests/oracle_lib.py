@@ -487,3 +487,8 @@ def post_extract(cam10, kps, depth=None, keylines=None, kl_depths=None, kl_x_rig
             _call("oracle_stereo_from_depth_lines", [cam, d, d.shape[0], d.shape[1], kl, len(kl), kd, kx])
             out.update(kl_depths=kd, kl_x_right=kx)
     return out
+
+
+def landmark_descriptor(descs):
+    d = _c(descs, np.uint8).reshape(-1, 32)
+    return _call("oracle_landmark_descriptor", [d, len(d)], C.c_int)

@@ -95,3 +95,22 @@ def test_post_extract_batched_device():
         assert np.array_equal(d_u[b].cpu().numpy().view(plp.KP_DTYPE).reshape(cap)[:n], want["undist_keypts"])
         assert np.array_equal(d_b[b].cpu().numpy()[:n], want["bearings"])
         assert np.array_equal(d_x[b].cpu().numpy()[:n], want["stereo_x_right"]) and np.array_equal(d_z[b].cpu().numpy()[:n], want["depths"])
+
+
+def test_landmark_descriptor_selection():
+    rng = np.random.default_rng(21)
+    sizes = [0, 1, 2, 3, 4, 5, 7, 8, 15, 33, 64, 65, 100, 200] + rng.integers(1, 40, 300).tolist()
+    descs, offsets = [], [0]
+    for n in sizes:
+        base = rng.integers(0, 256, 32, dtype=np.uint8)
+        d = np.tile(base, (n, 1))
+        for i in range(n):                      # observations of one landmark: noisy copies (ties in the medians are common)
+            for b in rng.choice(256, int(rng.integers(0, 30)), replace=False):
+                d[i, b >> 3] ^= np.uint8(1 << (b & 7))
+        if n >= 4 and rng.uniform() < 0.3:
+            d[1] = d[0]                          # exact duplicates
+        descs.append(d); offsets.append(offsets[-1] + n)
+    alld = np.concatenate(descs) if descs else np.zeros((0, 32), np.uint8)
+    got = plp.matcher().landmark_descriptors(alld, offsets)
+    want = [O.landmark_descriptor(d) if len(d) else -1 for d in descs]
+    assert got.tolist() == want
