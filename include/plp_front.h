@@ -7,7 +7,9 @@
  *
  * Pointer naming: `h_` / unprefixed = host memory, `d_` = device (HBM) memory of the
  * context's GPU.  Batched `_device` entry points are asynchronous on `hip_stream`
- * (a hipStream_t passed as void*, NULL = the context's own stream) unless stated otherwise.
+ * (a hipStream_t passed as void*; NULL = HIP's default stream, so that callers working on the
+ * default stream -- e.g. PyTorch's current stream -- stay ordered) unless stated otherwise.  The host-pointer entry
+ * points use the context's own non-blocking stream and synchronise it before returning.
  */
 #ifndef PLP_FRONT_H
 #define PLP_FRONT_H
@@ -363,7 +365,7 @@ plp_status plp_lbd_match_1nn_device(plp_matcher* ctx, const uint8_t* d_q, const 
  * undist gets pt / angle / size / octave of the distorted key point, response 0 and class_id -1, as the reference's resize()
  * + field copies do.  depth: B x rows x cols f32 (depth_step = bytes per row) or NULL (then x_right / depths may be NULL);
  * key-line outputs are written only for lines with both end-point depths >= 0, like the reference (pre-fill them).
- * Device pointers, asynchronous on hip_stream (NULL = the context's stream). */
+ * Device pointers, asynchronous on hip_stream. */
 typedef struct plp_camera {
     double fx, fy, cx, cy;          /* camera::perspective fx_, fy_, cx_, cy_ */
     double k1, k2, p1, p2, k3;      /* distortion */
@@ -378,6 +380,17 @@ plp_status plp_post_extract_device(plp_matcher* ctx, const plp_camera* cam, cons
 plp_status plp_post_extract_host(plp_matcher* ctx, const plp_camera* cam, const plp_keypoint* kps, int32_t n, const float* depth, int32_t rows,
                                  int32_t cols, size_t depth_step, plp_keypoint* undist, double* bearings, float* x_right, float* depths,
                                  const plp_keyline* kl, int32_t n_kl, float* kl_depths, float* kl_x_right);
+
+/* Input side: util::convert_to_grayscale (src/PLPSLAM/util/image_converter.cc:33-75, cv::cvtColor
+ * RGB/BGR[A] -> gray on CV_8U) and util::convert_to_true_depth (:77-80, convertTo(CV_32F, 1 / depthmap_factor)), so that the
+ * raw colour / 16-bit depth frames can go straight to HBM.  B frames, device pointers, asynchronous.
+ * channels 3 or 4; color_order 0 = RGB(A), 1 = BGR(A).  src_is_u16 != 0: CV_16UC1 depth, else CV_32FC1. */
+plp_status plp_convert_to_grayscale_device(plp_matcher* ctx, const uint8_t* d_src, int32_t rows, int32_t cols, size_t src_step,
+                                           size_t src_frame_stride, int32_t channels, int32_t color_order, int32_t B, uint8_t* d_gray,
+                                           size_t gray_step, size_t gray_frame_stride, void* hip_stream);
+plp_status plp_convert_to_true_depth_device(plp_matcher* ctx, const void* d_src, int32_t src_is_u16, int32_t rows, int32_t cols, size_t src_step,
+                                            size_t src_frame_stride, double depthmap_factor, int32_t B, float* d_dst, size_t dst_step,
+                                            size_t dst_frame_stride, void* hip_stream);
 
 /* landmark::compute_descriptor (src/PLPSLAM/data/landmark.cc:181-245) and Line::compute_descriptor
  * (data/landmark_line.cc:256-320), the search part, for L landmarks at once: landmark l owns the

@@ -133,3 +133,30 @@ void oracle_stereo_from_depth_lines(const double* cam, const float* depth, int r
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------- input side
+// util::convert_to_grayscale (util/image_converter.cc:33-75): cv::cvtColor(RGB2GRAY / BGR2GRAY / RGBA2GRAY / BGRA2GRAY) on
+// CV_8U.  OpenCV-knowledge (3.4.16 color_rgb: RGB2Gray<uchar>, 14-bit fixed point R2Y = 4899, G2Y = 9617, B2Y = 1868,
+// rounding term 1 << 13 folded into the red table); parity unpinned.
+// util::convert_to_true_depth (:77-80): img.convertTo(img, CV_32F, 1.0 / depthmap_factor); OpenCV-knowledge: the scale is
+// narrowed to float and applied in float (cvtScale work type for 16u->32f and 32f->32f is float).
+extern "C" {
+
+void oracle_convert_to_grayscale(const uint8_t* src, int rows, int cols, int channels, int bgr, uint8_t* dst) {
+    for (size_t i = 0; i < (size_t)rows * cols; ++i) {
+        const uint8_t* p = src + i * channels;
+        const int r = bgr ? p[2] : p[0], g = p[1], b = bgr ? p[0] : p[2];
+        dst[i] = (uint8_t)((b * 1868 + g * 9617 + r * 4899 + (1 << 13)) >> 14);
+    }
+}
+
+void oracle_convert_to_true_depth_u16(const uint16_t* src, size_t n, double depthmap_factor, float* dst) {
+    const float scale = (float)(1.0 / depthmap_factor);
+    for (size_t i = 0; i < n; ++i) dst[i] = (float)src[i] * scale + 0.0f;
+}
+void oracle_convert_to_true_depth_f32(const float* src, size_t n, double depthmap_factor, float* dst) {
+    const float scale = (float)(1.0 / depthmap_factor);
+    for (size_t i = 0; i < n; ++i) dst[i] = src[i] * scale + 0.0f;
+}
+
+}  // extern "C"

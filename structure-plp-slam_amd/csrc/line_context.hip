@@ -202,7 +202,7 @@ plp_status plp_line_extract_batch_device(plp_line* c, const uint8_t* d_imgs, int
     if (!c || !d_imgs || !d_kl || !d_lbd || !d_linefn || !d_counts) return set_error(PLP_ERR_INVALID_ARG, "NULL argument");
     if (B <= 0 || rows <= 0 || cols <= 0 || cap <= 0 || step < (size_t)cols) return set_error(PLP_ERR_INVALID_ARG, "bad batch geometry");
     std::lock_guard<std::mutex> lk(c->mu);
-    return run(c, d_imgs, B, rows, cols, step, frame_stride, d_kl, d_lbd, d_linefn, cap, d_counts, hip_stream ? (hipStream_t)hip_stream : c->stream);
+    return run(c, d_imgs, B, rows, cols, step, frame_stride, d_kl, d_lbd, d_linefn, cap, d_counts, (hipStream_t)hip_stream);
 }
 
 plp_status plp_line_last_batch_status(plp_line* c) {

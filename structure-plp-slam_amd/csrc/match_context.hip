@@ -123,7 +123,7 @@ plp_status plp_match_device(plp_matcher* c, const plp_match_args* a, void* hip_s
     if (!c) return set_error(PLP_ERR_INVALID_ARG, "ctx is NULL");
     PLP_TRY(check_args(a));
     std::lock_guard<std::mutex> lk(c->mu);
-    return run_device(c, a, hip_stream ? (hipStream_t)hip_stream : c->stream);
+    return run_device(c, a, (hipStream_t)hip_stream);
 }
 
 plp_status plp_match_host(plp_matcher* c, const plp_match_args* a) {
@@ -232,7 +232,7 @@ plp_status plp_lbd_match_1nn_device(plp_matcher* c, const uint8_t* d_q, const in
     if (nq_cap <= 0 || nt_cap <= 0 || B <= 0 || nt_cap > 65535) return set_error(PLP_ERR_INVALID_ARG, "bad sizes");
     PLP_HIP(hipSetDevice(c->device));
     static const MihRanks R = mih_ranks();
-    launch_lbd_match_1nn(hip_stream ? (hipStream_t)hip_stream : c->stream, d_q, d_q_counts, nq_cap, d_t, d_t_counts, nt_cap, R, d_train_idx, d_dist, B);
+    launch_lbd_match_1nn((hipStream_t)hip_stream, d_q, d_q_counts, nq_cap, d_t, d_t_counts, nt_cap, R, d_train_idx, d_dist, B);
     PLP_HIP(hipGetLastError());
     return PLP_OK;
 }
@@ -327,7 +327,7 @@ plp_status plp_post_extract_device(plp_matcher* c, const plp_camera* cam, const 
     A.depth = d_depth; A.depth_step = depth_step; A.depth_frame_stride = depth_frame_stride;
     A.undist = d_undist; A.bearings = d_bearings; A.x_right = d_x_right; A.depths = d_depths;
     A.kl = d_kl; A.kl_counts = d_kl_counts; A.kl_cap = d_kl ? kl_cap : 0; A.kl_depths = d_kl_depths; A.kl_x_right = d_kl_x_right;
-    launch_post_extract(hip_stream ? (hipStream_t)hip_stream : c->stream, A, B);
+    launch_post_extract((hipStream_t)hip_stream, A, B);
     PLP_HIP(hipGetLastError());
     return PLP_OK;
 }
@@ -386,13 +386,41 @@ plp_status plp_post_extract_host(plp_matcher* c, const plp_camera* cam, const pl
     return PLP_OK;
 }
 
+plp_status plp_convert_to_grayscale_device(plp_matcher* c, const uint8_t* d_src, int32_t rows, int32_t cols, size_t src_step,
+                                           size_t src_frame_stride, int32_t channels, int32_t color_order, int32_t B, uint8_t* d_gray,
+                                           size_t gray_step, size_t gray_frame_stride, void* hip_stream) {
+    if (!c || !d_src || !d_gray) return set_error(PLP_ERR_INVALID_ARG, "NULL argument");
+    if (rows <= 0 || cols <= 0 || B <= 0 || (channels != 3 && channels != 4) || (color_order != 0 && color_order != 1) ||
+        src_step < (size_t)cols * channels || gray_step < (size_t)cols) return set_error(PLP_ERR_INVALID_ARG, "bad geometry");
+    std::lock_guard<std::mutex> lk(c->mu);
+    PLP_HIP(hipSetDevice(c->device));
+    launch_to_gray((hipStream_t)hip_stream, d_src, rows, cols, src_step, src_frame_stride, channels, color_order, B, d_gray,
+                   gray_step, gray_frame_stride);
+    PLP_HIP(hipGetLastError());
+    return PLP_OK;
+}
+
+plp_status plp_convert_to_true_depth_device(plp_matcher* c, const void* d_src, int32_t src_is_u16, int32_t rows, int32_t cols, size_t src_step,
+                                            size_t src_frame_stride, double depthmap_factor, int32_t B, float* d_dst, size_t dst_step,
+                                            size_t dst_frame_stride, void* hip_stream) {
+    if (!c || !d_src || !d_dst) return set_error(PLP_ERR_INVALID_ARG, "NULL argument");
+    if (rows <= 0 || cols <= 0 || B <= 0 || src_step < (size_t)cols * (src_is_u16 ? 2 : 4) || dst_step < (size_t)cols * 4)
+        return set_error(PLP_ERR_INVALID_ARG, "bad geometry");
+    std::lock_guard<std::mutex> lk(c->mu);
+    PLP_HIP(hipSetDevice(c->device));
+    launch_to_depth((hipStream_t)hip_stream, d_src, src_is_u16 != 0, rows, cols, src_step, src_frame_stride,
+                    (float)(1.0 / depthmap_factor), B, d_dst, dst_step, dst_frame_stride);
+    PLP_HIP(hipGetLastError());
+    return PLP_OK;
+}
+
 plp_status plp_landmark_descriptor_device(plp_matcher* c, const uint8_t* d_descs, const int32_t* d_offsets, int32_t L, int32_t* d_best_idx,
                                           void* hip_stream) {
     if (!c || !d_offsets || !d_best_idx || L < 0) return set_error(PLP_ERR_INVALID_ARG, "bad argument");
     if (L == 0) return PLP_OK;
     std::lock_guard<std::mutex> lk(c->mu);
     PLP_HIP(hipSetDevice(c->device));
-    launch_landmark_descriptor(hip_stream ? (hipStream_t)hip_stream : c->stream, d_descs, d_offsets, L, d_best_idx);
+    launch_landmark_descriptor((hipStream_t)hip_stream, d_descs, d_offsets, L, d_best_idx);
     PLP_HIP(hipGetLastError());
     return PLP_OK;
 }
@@ -435,7 +463,7 @@ plp_status plp_hamming_matrix_device(plp_matcher* c, const uint8_t* d_q, int32_t
     if (!c || !d_q || !d_t || !d_dist) return set_error(PLP_ERR_INVALID_ARG, "NULL argument");
     if (nq <= 0 || nt <= 0) return PLP_OK;
     PLP_HIP(hipSetDevice(c->device));
-    launch_hamming_matrix(hip_stream ? (hipStream_t)hip_stream : c->stream, d_q, nq, d_t, nt, d_dist);
+    launch_hamming_matrix((hipStream_t)hip_stream, d_q, nq, d_t, nt, d_dist);
     PLP_HIP(hipGetLastError());
     return PLP_OK;
 }

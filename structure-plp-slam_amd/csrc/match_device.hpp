@@ -91,6 +91,10 @@ struct PostArgs {
     const plp_keyline* kl; const int32_t* kl_counts; int kl_cap; float* kl_depths; float* kl_x_right;
 };
 void launch_post_extract(hipStream_t st, const PostArgs& A, int B);
+void launch_to_gray(hipStream_t st, const uint8_t* src, int rows, int cols, size_t src_step, size_t src_fs, int channels, int bgr, int B, uint8_t* dst,
+                    size_t dst_step, size_t dst_fs);
+void launch_to_depth(hipStream_t st, const void* src, int is_u16, int rows, int cols, size_t src_step, size_t src_fs, float scale, int B, float* dst,
+                     size_t dst_step, size_t dst_fs);
 void launch_landmark_descriptor(hipStream_t st, const uint8_t* descs, const int32_t* offsets, int L, int32_t* best_idx);
 
 }  // namespace plp

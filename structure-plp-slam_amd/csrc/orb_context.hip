@@ -370,7 +370,7 @@ plp_status plp_orb_extract_batch_device(plp_orb* c, const uint8_t* d_imgs, int32
     if (B <= 0 || rows <= 0 || cols <= 0 || cap <= 0 || step < (size_t)cols) return set_error(PLP_ERR_INVALID_ARG, "bad batch geometry");
     std::lock_guard<std::mutex> lk(c->mu);
     return run_batch(c, d_imgs, B, rows, cols, step, frame_stride, d_mask, mask_step, mask_frame_stride, d_kps, d_desc, cap, d_counts,
-                     hip_stream ? (hipStream_t)hip_stream : c->stream);
+                     (hipStream_t)hip_stream);
 }
 
 plp_status plp_orb_last_batch_status(plp_orb* c) {
@@ -537,7 +537,7 @@ plp_status plp_stereo_compute_batch_device(plp_orb* left, plp_orb* right, const 
     StereoArgs A{};
     A.kps_l = d_kps_l; A.kps_r = d_kps_r; A.desc_l = d_desc_l; A.desc_r = d_desc_r; A.cnt_l = d_cnt_l; A.cnt_r = d_cnt_r; A.cap = cap;
     A.fxb = focal_x_baseline; A.tb = true_baseline; A.x_right = d_x_right; A.depth = d_depths;
-    return stereo_run(left, right, A, B, hip_stream ? (hipStream_t)hip_stream : left->stream);
+    return stereo_run(left, right, A, B, (hipStream_t)hip_stream);
 }
 
 plp_status plp_stereo_compute(plp_orb* left, plp_orb* right, const plp_keypoint* kps_l, int32_t n_l, const plp_keypoint* kps_r, int32_t n_r,

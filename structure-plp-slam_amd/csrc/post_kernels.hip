@@ -141,6 +141,48 @@ void launch_landmark_descriptor(hipStream_t st, const uint8_t* descs, const int3
     hipLaunchKernelGGL(k_landmark_descriptor, dim3((L + 3) / 4), dim3(256), 0, st, descs, offsets, L, best_idx);
 }
 
+// ------------------------------------------------------------------------------------------
+// util::convert_to_grayscale / convert_to_true_depth (util/image_converter.cc:33-80).  4 pixels per thread.
+// grid = (ceil(cols / 1024), rows, B), block = 256.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_to_gray(const uint8_t* __restrict__ src, int cols, size_t src_step, size_t src_fs, int channels, int bgr,
+                                                 uint8_t* __restrict__ dst, size_t dst_step, size_t dst_fs) {
+    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y, b = blockIdx.z;
+    if (x0 >= cols) return;
+    const uint8_t* s = src + (size_t)b * src_fs + (size_t)y * src_step + (size_t)x0 * channels;
+    uint8_t* d = dst + (size_t)b * dst_fs + (size_t)y * dst_step + x0;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (x0 + i >= cols) break;
+        const uint8_t* p = s + i * channels;
+        const int r = bgr ? p[2] : p[0], g = p[1], bl = bgr ? p[0] : p[2];
+        packed |= (uint32_t)((bl * 1868 + g * 9617 + r * 4899 + (1 << 13)) >> 14) << (8 * i);
+    }
+    if (x0 + 3 < cols && (((uintptr_t)d) & 3) == 0) *reinterpret_cast<uint32_t*>(d) = packed;
+    else
+        for (int i = 0; i < 4 && x0 + i < cols; ++i) d[i] = (uint8_t)(packed >> (8 * i));
+}
+
+__global__ __launch_bounds__(256) void k_to_depth(const void* __restrict__ src, int is_u16, int cols, size_t src_step, size_t src_fs, float scale,
+                                                  float* __restrict__ dst, size_t dst_step, size_t dst_fs) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+    if (x >= cols) return;
+    const uint8_t* row = reinterpret_cast<const uint8_t*>(src) + (size_t)b * src_fs + (size_t)y * src_step;
+    const float v = is_u16 ? (float)reinterpret_cast<const uint16_t*>(row)[x] : reinterpret_cast<const float*>(row)[x];
+    float* o = reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(dst) + (size_t)b * dst_fs + (size_t)y * dst_step);
+    o[x] = __fadd_rn(__fmul_rn(v, scale), 0.0f);
+}
+
+void launch_to_gray(hipStream_t st, const uint8_t* src, int rows, int cols, size_t src_step, size_t src_fs, int channels, int bgr, int B, uint8_t* dst,
+                    size_t dst_step, size_t dst_fs) {
+    hipLaunchKernelGGL(k_to_gray, dim3((cols + 1023) / 1024, rows, B), dim3(256), 0, st, src, cols, src_step, src_fs, channels, bgr, dst, dst_step, dst_fs);
+}
+void launch_to_depth(hipStream_t st, const void* src, int is_u16, int rows, int cols, size_t src_step, size_t src_fs, float scale, int B, float* dst,
+                     size_t dst_step, size_t dst_fs) {
+    hipLaunchKernelGGL(k_to_depth, dim3((cols + 255) / 256, rows, B), dim3(256), 0, st, src, is_u16, cols, src_step, src_fs, scale, dst, dst_step, dst_fs);
+}
+
 void launch_post_extract(hipStream_t st, const PostArgs& A, int B) {
     const int n = A.cap > A.kl_cap ? A.cap : A.kl_cap;
     hipLaunchKernelGGL(k_post_extract, dim3((n + 255) / 256, B), dim3(256), 0, st, A);

@@ -84,6 +84,7 @@ def test_post_extract_batched_device():
     mt = plp.matcher()
     c = cam_struct(cam)
     import ctypes as C
+    torch.cuda.synchronize()   # the tensor fills above ran on torch's stream, the call below uses the context's
     plp._check(plp.lib().plp_post_extract_device(mt._h, C.byref(c), d_k.data_ptr(), d_c.data_ptr(), cap, B, d_depth.data_ptr(), 480, 640, 640 * 4, 480 * 640 * 4,
                                                 d_u.data_ptr(), d_b.data_ptr(), d_x.data_ptr(), d_z.data_ptr(), None, None, 0, None, None, None))
     torch.cuda.synchronize()
@@ -114,3 +115,44 @@ def test_landmark_descriptor_selection():
     got = plp.matcher().landmark_descriptors(alld, offsets)
     want = [O.landmark_descriptor(d) if len(d) else -1 for d in descs]
     assert got.tolist() == want
+
+
+def test_input_side_grayscale_and_true_depth():
+    import ctypes as C
+    import torch
+    rng = np.random.default_rng(33)
+    dev = torch.device("cuda", 0)
+    mt = plp.matcher()
+    L = plp.lib()
+    cur = None   # the context's own stream: synchronise torch's fills first (torch's default stream is the NULL stream = 'use the context stream')
+    for (rows, cols, ch, bgr) in [(480, 640, 3, 0), (480, 640, 3, 1), (376, 1241, 4, 1), (61, 77, 4, 0), (5, 3, 3, 1)]:
+        B = 2
+        src = rng.integers(0, 256, (B, rows, cols, ch), dtype=np.uint8)
+        src[0, 0, 0] = 255; src[0, 0, min(1, cols - 1)] = 0
+        d_src = torch.from_numpy(src).to(dev); d_g = torch.zeros((B, rows, cols), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        plp._check(L.plp_convert_to_grayscale_device(mt._h, d_src.data_ptr(), rows, cols, cols * ch, rows * cols * ch, ch, bgr, B, d_g.data_ptr(), cols, rows * cols, cur))
+        torch.cuda.synchronize()
+        want = np.zeros((B, rows, cols), np.uint8)
+        for b in range(B):
+            O._call("oracle_convert_to_grayscale", [np.ascontiguousarray(src[b]), rows, cols, ch, bgr, want[b]])
+        assert np.array_equal(d_g.cpu().numpy(), want)
+    for factor in (5000.0, 5208.0, 1000.0, 1.0):
+        raw = rng.integers(0, 65536, (2, 120, 161), dtype=np.uint16); raw[0, 0, :3] = [0, 65535, 5000]
+        d_raw = torch.from_numpy(raw.view(np.int16)).to(dev); d_f = torch.zeros((2, 120, 161), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        plp._check(L.plp_convert_to_true_depth_device(mt._h, d_raw.data_ptr(), 1, 120, 161, 161 * 2, 120 * 161 * 2, C.c_double(factor), 2, d_f.data_ptr(), 161 * 4, 120 * 161 * 4, cur))
+        torch.cuda.synchronize()
+        want = np.zeros(raw.size, np.float32)
+        fn = O.lib().oracle_convert_to_true_depth_u16; fn.restype = None
+        fn(C.c_void_p(raw.ctypes.data), C.c_size_t(raw.size), C.c_double(factor), C.c_void_p(want.ctypes.data))
+        got = d_f.cpu().numpy().ravel()
+        assert np.array_equal(got, want), (factor, raw.ravel()[got != want][:4], got[got != want][:4], want[got != want][:4])
+        f32 = rng.uniform(0, 40000, (2, 120, 161)).astype(np.float32)
+        d_in = torch.from_numpy(f32).to(dev)
+        torch.cuda.synchronize()
+        plp._check(L.plp_convert_to_true_depth_device(mt._h, d_in.data_ptr(), 0, 120, 161, 161 * 4, 120 * 161 * 4, C.c_double(factor), 2, d_f.data_ptr(), 161 * 4, 120 * 161 * 4, cur))
+        torch.cuda.synchronize()
+        fn2 = O.lib().oracle_convert_to_true_depth_f32; fn2.restype = None
+        fn2(C.c_void_p(f32.ctypes.data), C.c_size_t(f32.size), C.c_double(factor), C.c_void_p(want.ctypes.data))
+        assert np.array_equal(d_f.cpu().numpy().ravel(), want)
