@@ -392,6 +392,16 @@ plp_status plp_convert_to_true_depth_device(plp_matcher* ctx, const void* d_src,
                                             size_t src_frame_stride, double depthmap_factor, int32_t B, float* d_dst, size_t dst_step,
                                             size_t dst_frame_stride, void* hip_stream);
 
+/* Planar_Mapping_module::create_ColorToPlane (src/PLPSLAM/planar_mapping_module.cc:185-345), the per-key-point part
+ * (BASELINE config 5): labels[b][i] = colour label c0 + (c1 << 8) + (c2 << 16) of the CV_8UC3
+ * instance mask under undistorted key point i, or 0 when the point is flagged invalid (valid == NULL: all valid), outside
+ * the mask, on label 0, or (check_3x3_window) not surrounded by its own label.  The `> 0` neighbour tests of the
+ * reference are kept (row 0 / column 0 are never looked at).  New data::Plane objects and add_landmark stay on the host.
+ * Device pointers, asynchronous. */
+plp_status plp_color_vote_device(plp_matcher* ctx, const uint8_t* d_mask, int32_t rows, int32_t cols, size_t mask_step,
+                                 size_t mask_frame_stride, const plp_keypoint* d_undist, const uint8_t* d_valid, const int32_t* d_counts,
+                                 int32_t cap, int32_t B, int32_t check_3x3_window, int32_t* d_labels, void* hip_stream);
+
 /* landmark::compute_descriptor (src/PLPSLAM/data/landmark.cc:181-245) and Line::compute_descriptor
  * (data/landmark_line.cc:256-320), the search part, for L landmarks at once: landmark l owns the
  * descriptors descs[offsets[l] .. offsets[l+1]) (32 B rows, observation order); best_idx[l] = the row (relative to

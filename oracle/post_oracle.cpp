@@ -160,3 +160,41 @@ void oracle_convert_to_true_depth_f32(const float* src, size_t n, double depthma
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------- plane colour vote (BASELINE config 5)
+// Planar_Mapping_module::create_ColorToPlane (src/PLPSLAM/planar_mapping_module.cc:185-345), the per-key-point part: the
+// colour label of the instance-segmentation mask (CV_8UC3) under an undistorted key point, kept only if it is non-zero and
+// (check_3x3_window) every existing 8-neighbour has the same non-zero label.  label = c0 + (c1 << 8) + (c2 << 16); 0 = none.
+// Quirks kept: the image-range test uses `>` rows / cols (:214-215), neighbours in row 0 / column 0 are never looked at
+// (`> 0`, :262-293).  A point with (int)y == rows or (int)x == cols passes the reference's range test and reads out of
+// bounds there; here it gets label 0.  The map mutation (new data::Plane, add_landmark) stays on the host.
+extern "C" {
+
+void oracle_color_vote(const uint8_t* mask, int rows, int cols, size_t step, const KeyPoint* undist, const uint8_t* valid, int n,
+                       int check_3x3_window, int* labels) {
+    auto at = [&](int y, int x) -> long { const uint8_t* p = mask + (size_t)y * step + 3 * (size_t)x; return p[0] + (p[1] << 8) + (p[2] << 16); };
+    for (int i = 0; i < n; ++i) {
+        labels[i] = 0;
+        if (valid && !valid[i]) continue;
+        const float px = undist[i].x, py = undist[i].y;
+        if (py < 0 || py > rows || px < 0 || px > cols) continue;
+        const int y = (int)py, x = (int)px;
+        if (y >= rows || x >= cols) continue;   // reference: out-of-bounds read
+        const long center = at(y, x);
+        if (center == 0) continue;
+        bool consistent = true;
+        if (check_3x3_window) {
+            static const int dy[8] = {1, -1, 1, -1, 1, -1, 0, 0}, dx[8] = {1, -1, -1, 1, 0, 0, -1, 1};
+            for (int k = 0; k < 8 && consistent; ++k) {
+                const int ny = y + dy[k], nx = x + dx[k];
+                if (ny > 0 && ny < rows && nx > 0 && nx < cols) {
+                    const long h = at(ny, nx);
+                    if (h == 0 || h != center) consistent = false;
+                }
+            }
+        }
+        if (consistent) labels[i] = (int)center;
+    }
+}
+
+}  // extern "C"

@@ -86,6 +86,7 @@ _API = [
     ("plp_match_area_host", C.c_int, [_VP, _VP, _VP, _I32, _VP, _VP, _I32, _VP, _VP, _I32, C.c_float, _I32, _VP, _VP]),
     ("plp_convert_to_grayscale_device", C.c_int, [_VP, _VP, _I32, _I32, C.c_size_t, C.c_size_t, _I32, _I32, _I32, _VP, C.c_size_t, C.c_size_t, _VP]),
     ("plp_convert_to_true_depth_device", C.c_int, [_VP, _VP, _I32, _I32, _I32, C.c_size_t, C.c_size_t, C.c_double, _I32, _VP, C.c_size_t, C.c_size_t, _VP]),
+    ("plp_color_vote_device", C.c_int, [_VP, _VP, _I32, _I32, C.c_size_t, C.c_size_t, _VP, _VP, _VP, _I32, _I32, _I32, _VP, _VP]),
     ("plp_landmark_descriptor_device", C.c_int, [_VP, _VP, _VP, _I32, _VP, _VP]),
     ("plp_landmark_descriptor_host", C.c_int, [_VP, _VP, _VP, _I32, _VP]),
     ("plp_post_extract_device", C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _VP, _I32, _I32, C.c_size_t, C.c_size_t, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _VP, _VP, _VP]),

@@ -414,6 +414,19 @@ plp_status plp_convert_to_true_depth_device(plp_matcher* c, const void* d_src, i
     return PLP_OK;
 }
 
+plp_status plp_color_vote_device(plp_matcher* c, const uint8_t* d_mask, int32_t rows, int32_t cols, size_t mask_step,
+                                 size_t mask_frame_stride, const plp_keypoint* d_undist, const uint8_t* d_valid, const int32_t* d_counts,
+                                 int32_t cap, int32_t B, int32_t check_3x3_window, int32_t* d_labels, void* hip_stream) {
+    if (!c || !d_mask || !d_undist || !d_labels) return set_error(PLP_ERR_INVALID_ARG, "NULL argument");
+    if (rows <= 0 || cols <= 0 || cap <= 0 || B <= 0 || mask_step < (size_t)cols * 3) return set_error(PLP_ERR_INVALID_ARG, "bad geometry");
+    std::lock_guard<std::mutex> lk(c->mu);
+    PLP_HIP(hipSetDevice(c->device));
+    launch_color_vote((hipStream_t)hip_stream, d_mask, rows, cols, mask_step, mask_frame_stride, d_undist, d_valid, d_counts, cap, B,
+                      check_3x3_window != 0, d_labels);
+    PLP_HIP(hipGetLastError());
+    return PLP_OK;
+}
+
 plp_status plp_landmark_descriptor_device(plp_matcher* c, const uint8_t* d_descs, const int32_t* d_offsets, int32_t L, int32_t* d_best_idx,
                                           void* hip_stream) {
     if (!c || !d_offsets || !d_best_idx || L < 0) return set_error(PLP_ERR_INVALID_ARG, "bad argument");

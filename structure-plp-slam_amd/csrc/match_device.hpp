@@ -95,6 +95,8 @@ void launch_to_gray(hipStream_t st, const uint8_t* src, int rows, int cols, size
                     size_t dst_step, size_t dst_fs);
 void launch_to_depth(hipStream_t st, const void* src, int is_u16, int rows, int cols, size_t src_step, size_t src_fs, float scale, int B, float* dst,
                      size_t dst_step, size_t dst_fs);
+void launch_color_vote(hipStream_t st, const uint8_t* mask, int rows, int cols, size_t step, size_t fs, const plp_keypoint* undist, const uint8_t* valid,
+                       const int32_t* counts, int cap, int B, int check3, int32_t* labels);
 void launch_landmark_descriptor(hipStream_t st, const uint8_t* descs, const int32_t* offsets, int L, int32_t* best_idx);
 
 }  // namespace plp

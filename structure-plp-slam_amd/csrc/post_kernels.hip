@@ -183,6 +183,45 @@ void launch_to_depth(hipStream_t st, const void* src, int is_u16, int rows, int 
     hipLaunchKernelGGL(k_to_depth, dim3((cols + 255) / 256, rows, B), dim3(256), 0, st, src, is_u16, cols, src_step, src_fs, scale, dst, dst_step, dst_fs);
 }
 
+// ------------------------------------------------------------------------------------------
+// Planar_Mapping_module::create_ColorToPlane, per key point (planar_mapping_module.cc:203-330).  grid = (ceil(cap/256), B).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_color_vote(const uint8_t* __restrict__ mask, int rows, int cols, size_t step, size_t fs,
+                                                    const plp_keypoint* __restrict__ undist, const uint8_t* __restrict__ valid,
+                                                    const int32_t* __restrict__ counts, int cap, int check3, int32_t* __restrict__ labels) {
+    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= cap) return;
+    const size_t o = (size_t)b * cap + i;
+    int label = 0;
+    if (i < (counts ? counts[b] : cap) && !(valid && !valid[o])) {
+        const uint8_t* M = mask + (size_t)b * fs;
+        auto at = [&](int y, int x) -> int { const uint8_t* p = M + (size_t)y * step + 3 * (size_t)x; return p[0] + (p[1] << 8) + (p[2] << 16); };
+        const float px = undist[o].x, py = undist[o].y;
+        if (!(py < 0 || py > (float)rows || px < 0 || px > (float)cols)) {
+            const int y = (int)py, x = (int)px;
+            if (y < rows && x < cols) {
+                const int center = at(y, x);
+                bool ok = center != 0;
+                if (ok && check3) {
+                    const int dy[8] = {1, -1, 1, -1, 1, -1, 0, 0}, dx[8] = {1, -1, -1, 1, 0, 0, -1, 1};
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int ny = y + dy[k], nx = x + dx[k];
+                        if (ny > 0 && ny < rows && nx > 0 && nx < cols && at(ny, nx) != center) ok = false;
+                    }
+                }
+                if (ok) label = center;
+            }
+        }
+    }
+    labels[o] = label;
+}
+
+void launch_color_vote(hipStream_t st, const uint8_t* mask, int rows, int cols, size_t step, size_t fs, const plp_keypoint* undist, const uint8_t* valid,
+                       const int32_t* counts, int cap, int B, int check3, int32_t* labels) {
+    hipLaunchKernelGGL(k_color_vote, dim3((cap + 255) / 256, B), dim3(256), 0, st, mask, rows, cols, step, fs, undist, valid, counts, cap, check3, labels);
+}
+
 void launch_post_extract(hipStream_t st, const PostArgs& A, int B) {
     const int n = A.cap > A.kl_cap ? A.cap : A.kl_cap;
     hipLaunchKernelGGL(k_post_extract, dim3((n + 255) / 256, B), dim3(256), 0, st, A);

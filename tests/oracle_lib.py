@@ -396,8 +396,8 @@ def _call(name, args, restype=None):
             conv.append(C.c_void_p(a.ctypes.data))
         elif isinstance(a, float):
             conv.append(C.c_float(a))
-        elif isinstance(a, tuple):      # ("u", v): unsigned
-            conv.append(C.c_uint(a[1]))
+        elif isinstance(a, tuple):      # ("u", v): unsigned, ("z", v): size_t
+            conv.append(C.c_size_t(a[1]) if a[0] == "z" else C.c_uint(a[1]))
         else:
             conv.append(C.c_int(int(a)))
     return fn(*conv)

@@ -156,3 +156,39 @@ def test_input_side_grayscale_and_true_depth():
         fn2 = O.lib().oracle_convert_to_true_depth_f32; fn2.restype = None
         fn2(C.c_void_p(f32.ctypes.data), C.c_size_t(f32.size), C.c_double(factor), C.c_void_p(want.ctypes.data))
         assert np.array_equal(d_f.cpu().numpy().ravel(), want)
+
+
+def test_plane_colour_vote():
+    import ctypes as C
+    import torch
+    rng = np.random.default_rng(44)
+    dev = torch.device("cuda", 0)
+    rows, cols, B, cap = 480, 640, 2, 1500
+    mask = np.zeros((B, rows, cols, 3), np.uint8)
+    for b in range(B):                                   # six random convex colour regions + unlabelled background
+        for k in range(6):
+            cy, cx, ry, rx = rng.integers(0, rows), rng.integers(0, cols), rng.integers(30, 200), rng.integers(30, 250)
+            yy, xx = np.ogrid[:rows, :cols]
+            mask[b][((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 < 1] = rng.integers(1, 256, 3)
+    und = np.zeros((B, cap), O.KP_DTYPE)
+    und["x"] = rng.uniform(-5, cols + 5, (B, cap)).astype(np.float32); und["y"] = rng.uniform(-5, rows + 5, (B, cap)).astype(np.float32)
+    und["x"][:, :8] = [0, 0.5, 1.2, cols - 1, cols - 0.5, cols, 320, 1]; und["y"][:, :8] = [0, 1, 0.7, rows - 1, rows - 0.2, 100, rows, 1]
+    valid = (rng.uniform(size=(B, cap)) > 0.1).astype(np.uint8)
+    counts = np.array([cap, cap - 77], np.int32)
+    d_mask = torch.from_numpy(mask).to(dev); d_und = torch.from_numpy(und.view(np.uint8).reshape(B, cap, 28)).to(dev)
+    d_valid = torch.from_numpy(valid).to(dev); d_cnt = torch.from_numpy(counts).to(dev)
+    mt = plp.matcher()
+    for check in (1, 0):
+        d_lab = torch.full((B, cap), -5, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        plp._check(plp.lib().plp_color_vote_device(mt._h, d_mask.data_ptr(), rows, cols, cols * 3, rows * cols * 3, d_und.data_ptr(), d_valid.data_ptr(),
+                                                  d_cnt.data_ptr(), cap, B, check, d_lab.data_ptr(), None))
+        torch.cuda.synchronize()
+        got = d_lab.cpu().numpy()
+        for b in range(B):
+            want = np.zeros(cap, np.int32)
+            n = int(counts[b])
+            O._call("oracle_color_vote", [np.ascontiguousarray(mask[b]), rows, cols, ("z", cols * 3), np.ascontiguousarray(und[b]), np.ascontiguousarray(valid[b]),
+                                          n, check, want])
+            assert np.array_equal(got[b], want), (check, b)
+            assert (want != 0).sum() > 100
