@@ -60,3 +60,40 @@ def test_stereo_from_depth_lookup_and_invalid_values():
     o2 = O.post_extract(FR3, kps, depth, kl, np.full((2, 2), -7, np.float32), np.full((2, 2), -7, np.float32))
     assert o2["kl_depths"].tolist() == [[2.0, 4.0], [-7.0, -7.0]]                       # a negative end-point depth skips the line
     assert o2["kl_x_right"][0].tolist() == [np.float32(10.9) - np.float32(20.0), np.float32(5.0 - 10.0)]
+
+
+def test_grayscale_known_values_and_depth_scale():
+    import ctypes as C
+    px = np.array([[[255, 255, 255], [0, 0, 0], [255, 0, 0], [0, 255, 0], [0, 0, 255], [10, 200, 77]]], np.uint8)
+    for bgr in (0, 1):
+        out = np.zeros((1, 6), np.uint8)
+        O._call("oracle_convert_to_grayscale", [np.ascontiguousarray(px), 1, 6, 3, bgr, out])
+        r, g, b = (px[0, :, 2], px[0, :, 1], px[0, :, 0]) if bgr else (px[0, :, 0], px[0, :, 1], px[0, :, 2])
+        want = (r.astype(np.int64) * 4899 + g.astype(np.int64) * 9617 + b.astype(np.int64) * 1868 + 8192) >> 14
+        assert out[0].tolist() == want.tolist()
+        assert out[0, 0] == 255 and out[0, 1] == 0                    # the three weights sum to 1 << 14
+        assert abs(int(out[0, 5]) - round(0.299 * int(r[5]) + 0.587 * int(g[5]) + 0.114 * int(b[5]))) <= 1
+    raw = np.array([0, 1, 5000, 65535], np.uint16); dst = np.zeros(4, np.float32)
+    fn = O.lib().oracle_convert_to_true_depth_u16; fn.restype = None
+    fn(C.c_void_p(raw.ctypes.data), C.c_size_t(4), C.c_double(5000.0), C.c_void_p(dst.ctypes.data))
+    assert dst.tolist() == [0.0, float(np.float32(1) * np.float32(1.0 / 5000.0)), float(np.float32(5000) * np.float32(1.0 / 5000.0)),
+                            float(np.float32(65535) * np.float32(1.0 / 5000.0))]
+
+
+def test_landmark_descriptor_and_colour_vote_small_cases():
+    d = np.zeros((5, 32), np.uint8)
+    d[1, 0] = 0x01; d[2, 0] = 0x03; d[3, 0] = 0x07; d[4, 0] = 0xff      # distances to row 0: 0 1 2 3 8
+    # medians (rank 2 of 5): row0 {0,1,2,3,8}->2, row1 {1,0,1,2,7}->1, row2 {2,1,0,1,6}->1, row3 {3,2,1,0,5}->2, row4 {8,7,6,5,0}->6: first minimum = row 1
+    assert O.landmark_descriptor(d) == 1
+    assert O.landmark_descriptor(d[:1]) == 0 and O.landmark_descriptor(d[:2]) == 0      # rank (unsigned)(0.5 * 1) = 0: every median is 0
+    mask = np.zeros((6, 8, 3), np.uint8); mask[1:5, 1:6] = (10, 20, 30); mask[2, 3] = (10, 20, 31)
+    kps = np.zeros(5, O.KP_DTYPE)
+    kps["x"] = [1.9, 4.2, 2.5, 7.0, 1.0]; kps["y"] = [1.2, 3.9, 2.0, 5.0, 4.9]      # (1,1) (3,4) (2,2) background (4,1)
+    lab = np.zeros(5, np.int32)
+    O._call("oracle_color_vote", [mask, 6, 8, ("z", 24), kps, np.ones(5, np.uint8), 5, 0, lab])
+    h = 10 + (20 << 8) + (30 << 16)
+    assert lab.tolist() == [h, h, h, 0, h]
+    O._call("oracle_color_vote", [mask, 6, 8, ("z", 24), kps, np.ones(5, np.uint8), 5, 1, lab])
+    # (1,1): neighbours in row 0 / column 0 are never looked at, the others are its own colour; (3,4) and (2,2) touch the odd pixel (2,3);
+    # (4,1): its lower neighbours (5, .) are background
+    assert lab.tolist() == [h, 0, 0, 0, 0]
