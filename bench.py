@@ -6,12 +6,14 @@
 
 One "step" = one pass of the hot path over one batch of `--batch` frames that are already resident in HBM:
   ORB extract (8-level pyramid, FAST cells, quadtree, orientation, blur, rBRIEF)   stream A
-  LSD + LBD line extract                                                           stream B (concurrent, as the
+  LSD + LBD line extract, in PLP_BENCH_LINE_SPLIT (2) sub-blocks                   streams B1, B2 (concurrent, as the
                                                                                    reference runs two threads per frame)
-  match_current_and_last_frames  (frame b against frame b-1, margin 20, orientation check)     stream A
+  halo exchange (RCCL all-gather of the two-frame feature tails), then             stream C
+  match_current_and_last_frames  (frame b against frame b-1, margin 20, orientation check)
   match_frame_and_landmarks      (frame b against the key points of frames b-1 and b-2 as ~2K local landmarks, margin 10)
-Frames shard across ranks in contiguous blocks with no data-path collective (weak scaling: every rank owns its
-own batch); the timed region is bracketed by a barrier + synchronize and the max over ranks is used.  Rank 0
+Steps are software-pipelined (stream C matches step n while A/B extract step n+1); every step's work is inside the timed
+region.  Frames shard across ranks in contiguous blocks, the only exchange being that halo (weak scaling: every rank
+owns its own batch); the timed region is bracketed by a barrier + synchronize and the max over ranks is used.  Rank 0
 prints ONE JSON line.  `roofline` = the dominant kernel's algorithmic bytes per launch / its HIP-event duration
 measured on its launch stream; `cpu_baseline` = the oracle restatement of the same work on this box's host cores.
 """
@@ -70,7 +72,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=2048, help="frames per rank per step (the region-growing kernel is one latency-bound wave per frame: ~2048 frames fill the chip)")
+    ap.add_argument("--batch", type=int, default=2048, help="frames per rank per step (region growing is one wave per frame: 2048 frames put two of them on every SIMD; larger batches give the same throughput)")
     ap.add_argument("--keypoints", type=int, default=1000, help="Feature.max_num_keypoints (TUM RGB-D YAML: 1000)")
     ap.add_argument("--rows", type=int, default=480)
     ap.add_argument("--cols", type=int, default=640)
@@ -113,7 +115,7 @@ def main():
     m2 = torch.empty((B, cap), dtype=torch.int32, device=dev); n2 = torch.zeros(B, dtype=torch.int32, device=dev)
     ex = plp.orb_extractor(K, device=local_rank)
     lt = plp.LineFeatureTracker(device=local_rank)
-    # The line path is one long dependent chain per launch (region growing is a single latency-bound wave per frame), so
+    # The line path is one long dependent chain per launch (region growing is a single wave per frame), so
     # the batch is cut into n_line contiguous sub-blocks, each with its own context (scratch planes) and HIP stream.
     n_line = max(1, int(os.environ.get("PLP_BENCH_LINE_SPLIT", "2")))
     while B % n_line:
@@ -153,7 +155,7 @@ def main():
 
     # One step = ORB (stream A) || LSD+LBD (stream B), then the halo exchange and the two matchers (stream C) on that
     # step's features.  Steps are software-pipelined: stream C works on step n while A and B already extract step n + 1
-    # (every stage is latency-bound on its own, see profiles/r01g_sq_counters.md); all K steps' work, matchers
+    # (no stage fills the chip on its own, see profiles/r01i_sq_counters.md); all K steps' work, matchers
     # included, is inside the timed region because the closing barrier synchronises the device.
     sC = sA if serial else torch.cuda.Stream(dev)
     done_match = [None, None]

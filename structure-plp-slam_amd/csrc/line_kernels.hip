@@ -873,8 +873,8 @@ void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp,
     hipLaunchKernelGGL(k_lsd_order, dim3(B), dim3(256), 0, st, P);
     mark(3);
     // per wave: USED bitmap + frontier ring (a power of two; the HBM copy of the region list backs larger frontiers).
-    // One wave per workgroup keeps the LDS footprint small so that ~15 frames per CU are in flight: the kernel is
-    // latency bound (one dependent HBM gather per region point), occupancy is what buys throughput.
+    // One wave per workgroup keeps the LDS footprint small (~10.6 KB), so LDS never limits how many frames a CU hosts;
+    // at 2048 frames every SIMD carries two of these instruction-bound waves (profiles/r01i_sq_counters.md).
     static const int ring = [] { const char* e = getenv("PLP_LSD_RING"); int r = e ? atoi(e) : 256; return (r >= 64 && (r & (r - 1)) == 0) ? r : 256; }();
     static const int wpb_env = [] { const char* e = getenv("PLP_LSD_WPB"); return e ? atoi(e) : 1; }();
     const size_t per_wave = (size_t)((n + 31) / 32 + ring) * 4;
