@@ -291,14 +291,35 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbPlanes pl, const CellDesc
         if (found > 0 || min_thr >= ini_thr) break;
     }
 
-    // pass 5: ordered (row-major) compaction of the survivors.  The NMS survivors of a position row are one 64-bit
-    // mask; wave w owns rows 16w .. 16w+15: counts by popcount, one barrier for the wave bases, then the writes.
+    // pass 5: ordered (row-major) compaction of the survivors.  The NMS survivors of a position row are one 64-bit mask.
     uint32_t* out = cell_cand + (size_t)out_slot * kCellCap;
     const int lane = tid & 63, wv = tid >> 6;
+    if (!mk) {
+        // no image mask: one wave does it all.  Lane = row: popcount, exclusive scan over the 64 rows, then every lane
+        // writes the few survivors of its own row (a cell keeps ~20 of its 4096 positions).
+        if (wv != 0) return;
+        unsigned long long m = keepbits[lane];
+        const int cnt = __popcll(m);
+        int inc = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+        int pos = inc - cnt;
+        const uint32_t y = (uint32_t)(lane + 3 + cd.cy * kCellSize);
+        while (m) {
+            const int tx = __builtin_ctzll(m);
+            m &= m - 1;
+            // border-relative position: ROI coordinate + cell index * 64 (orb_extractor.cc:426-427)
+            const uint32_t v = score[(lane + 1) * kScoreW + tx + 1];
+            out[pos++] = (uint32_t)(tx + 3 + cd.cx * kCellSize) | (y << 12) | (v << 24);
+        }
+        if (lane == 63) cell_count[out_slot] = inc;
+        return;
+    }
+    // with an image mask every survivor is tested against it (orb_extractor.cc:429): wave w owns rows 16w .. 16w+15,
+    // counts by ballot, one barrier for the wave bases, then the writes
     auto row_mask = [&](int ty) -> unsigned long long {
-        unsigned long long m = keepbits[ty];
-        if (mk) m = __ballot(((m >> lane) & 1ull) && !masked(cd.min_y + ty + 3, cd.min_x + lane + 3));   // (:429)
-        return m;
+        const unsigned long long m = keepbits[ty];
+        return __ballot(((m >> lane) & 1ull) && !masked(cd.min_y + ty + 3, cd.min_x + lane + 3));
     };
     int cnt = 0;
     for (int ty = 16 * wv; ty < 16 * wv + 16; ++ty) cnt += __popcll(row_mask(ty));
@@ -309,7 +330,6 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbPlanes pl, const CellDesc
     for (int ty = 16 * wv; ty < 16 * wv + 16; ++ty) {
         const unsigned long long m = row_mask(ty);
         if ((m >> lane) & 1ull) {
-            // border-relative position: ROI coordinate + cell index * 64 (orb_extractor.cc:426-427)
             const uint32_t v = score[(ty + 1) * kScoreW + lane + 1];
             const uint32_t x = (uint32_t)(lane + 3 + cd.cx * kCellSize), y = (uint32_t)(ty + 3 + cd.cy * kCellSize);
             out[off + __popcll(m & ((1ull << lane) - 1ull))] = x | (y << 12) | (v << 24);
