@@ -417,6 +417,70 @@ __device__ void region2rect(const GrowCtx& g, int nreg, double reg_angle, double
     if (rec.width < 1.0) rec.width = 1.0;
 }
 
+// region2rect for a region that still sits completely in the LDS frontier ring (nreg <= ring size, at most 256 points):
+// coordinates come from LDS, every lane keeps its (up to four) points and their weights in registers, so the centroid
+// sums, the inertia sums and the extents need ONE round of gathers instead of three passes over the HBM copy of the
+// list.  Same additions in the same order as centroid_sums() + region2rect().
+__device__ void rect_from_ring(const GrowCtx& g, int nreg, double reg_angle, double prec, Rect& rec) {
+    const int lane = g.lane;
+    int px[4], py[4];
+    double w[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int j = lane + 64 * u;
+        px[u] = 0; py[u] = 0; w[u] = 0;
+        if (j < nreg) {
+            const uint32_t c = g.ring[j & g.ring_mask];
+            px[u] = (int)(c & 0xffff); py[u] = (int)(c >> 16);
+            w[u] = pix_mod(g.pix[py[u] * g.sw + px[u]]);
+        }
+    }
+    double sx = 0, sy = 0, sw = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int cnt = min(64, nreg - 64 * u);
+        const double tx = (double)px[u] * w[u], ty = (double)py[u] * w[u];
+        for (int t = 0; t < cnt; ++t) { sx += bcast_d(tx, t); sy += bcast_d(ty, t); sw += bcast_d(w[u], t); }
+    }
+    const double x = sx / sw, y = sy / sw;
+    double Ixx = 0.0, Iyy = 0.0, Ixy = 0.0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int cnt = min(64, nreg - 64 * u);
+        const double dx = (double)px[u] - x, dy = (double)py[u] - y;
+        const double txx = dy * dy * w[u], tyy = dx * dx * w[u], txy = dx * dy * w[u];
+        for (int t = 0; t < cnt; ++t) {
+            Ixx += bcast_d(txx, t);
+            Iyy += bcast_d(tyy, t);
+            Ixy -= bcast_d(txy, t);
+        }
+    }
+    const double lambda = 0.5 * (Ixx + Iyy - sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
+    double theta = (fabs(Ixx) > fabs(Iyy)) ? (double)fast_atan2_deg_l((float)(lambda - Ixx), (float)Ixy)
+                                           : (double)fast_atan2_deg_l((float)Ixy, (float)(lambda - Iyy));
+    theta *= (3.14159265358979323846 / 180);
+    if (fabs(angle_diff_signed(theta, reg_angle)) > prec) theta += 3.14159265358979323846;
+    const double dx = cos(theta), dy = sin(theta);
+    double l_min = 0, l_max = 0, w_min = 0, w_max = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (lane + 64 * u < nreg) {
+            const double rdx = (double)px[u] - x, rdy = (double)py[u] - y;
+            const double l = rdx * dx + rdy * dy, ww = -rdx * dy + rdy * dx;
+            l_max = fmax(l_max, l); l_min = fmin(l_min, l);
+            w_max = fmax(w_max, ww); w_min = fmin(w_min, ww);
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        l_max = fmax(l_max, shfl_d(l_max, lane ^ o)); l_min = fmin(l_min, shfl_d(l_min, lane ^ o));
+        w_max = fmax(w_max, shfl_d(w_max, lane ^ o)); w_min = fmin(w_min, shfl_d(w_min, lane ^ o));
+    }
+    rec.x1 = x + l_min * dx; rec.y1 = y + l_min * dy;
+    rec.x2 = x + l_max * dx; rec.y2 = y + l_max * dy;
+    rec.width = w_max - w_min;
+    if (rec.width < 1.0) rec.width = 1.0;
+}
+
 __device__ __forceinline__ double rect_density(int nreg, const Rect& r) {
     const double d = sqrt((r.x2 - r.x1) * (r.x2 - r.x1) + (r.y2 - r.y1) * (r.y2 - r.y1));
     return (double)nreg / (d * r.width);
@@ -488,11 +552,15 @@ __global__ __launch_bounds__(256) void k_lsd_grow(LinePlanes P, LsdParams lp, in
             int nreg = region_grow(g, seed, true, bcast_f(s_deg, t), &seed_cs, lp.prec, lp.c_pass, lp.c_fail, reg_angle);
             t_grow += clock64() - t0; ++n_seed; n_pix += nreg;
             if (nreg < lp.min_reg_size) continue;
-            region_list_fence();
             Rect rec;
             t0 = clock64();
-            centroid_sums(g, nreg, cen);
-            region2rect(g, nreg, reg_angle, lp.prec, cen, rec);
+            const int ring_cap = min(256, g.ring_mask + 1);
+            if (nreg <= ring_cap) rect_from_ring(g, nreg, reg_angle, lp.prec, rec);
+            else {
+                region_list_fence();
+                centroid_sums(g, nreg, cen);
+                region2rect(g, nreg, reg_angle, lp.prec, cen, rec);
+            }
             t_rect += clock64() - t0;
             t0 = clock64();
             bool keep = true;
@@ -500,6 +568,7 @@ __global__ __launch_bounds__(256) void k_lsd_grow(LinePlanes P, LsdParams lp, in
                 double density = rect_density(nreg, rec);
                 if (density < lp.density_th) {
                     // ---- refine: tighter angle tolerance from the points near the seed
+                    region_list_fence();
                     const uint32_t c0 = g.reg[0];
                     const double xc = (double)(int)(c0 & 0xffff), yc = (double)(int)(c0 >> 16);
                     const double ang_c = pix_ang(g.pix[(int)(c0 >> 16) * g.sw + (int)(c0 & 0xffff)]);
@@ -536,8 +605,11 @@ __global__ __launch_bounds__(256) void k_lsd_grow(LinePlanes P, LsdParams lp, in
                     region_list_fence();
                     if (nreg < 2) keep = false;
                     else {
-                        centroid_sums(g, nreg, cen);
-                        region2rect(g, nreg, reg_angle, lp.prec, cen, rec);
+                        if (nreg <= ring_cap) rect_from_ring(g, nreg, reg_angle, lp.prec, rec);
+                        else {
+                            centroid_sums(g, nreg, cen);
+                            region2rect(g, nreg, reg_angle, lp.prec, cen, rec);
+                        }
                         density = rect_density(nreg, rec);
                         if (density < lp.density_th) {
                             // ---- reduce_region_radius: shrink around the seed until dense enough
