@@ -396,7 +396,8 @@ __device__ void region2rect(const GrowCtx& g, int nreg, double reg_angle, double
                                            : (double)fast_atan2_deg_l((float)Ixy, (float)(lambda - Iyy));
     theta *= (3.14159265358979323846 / 180);
     if (fabs(angle_diff_signed(theta, reg_angle)) > prec) theta += 3.14159265358979323846;
-    const double dx = cos(theta), dy = sin(theta);
+    double dx, dy;
+    sincos(theta, &dy, &dx);
     // extents: min / max are order independent -> lane-parallel
     double l_min = 0, l_max = 0, w_min = 0, w_max = 0;
     for (int j = lane; j < nreg; j += 64) {
@@ -429,6 +430,7 @@ __device__ void rect_from_ring(const GrowCtx& g, int nreg, double reg_angle, dou
     for (int u = 0; u < 4; ++u) {
         const int j = lane + 64 * u;
         px[u] = 0; py[u] = 0; w[u] = 0;
+        if (64 * u >= nreg) continue;   // uniform: most fitted regions have fewer than 64 points
         if (j < nreg) {
             const uint32_t c = g.ring[j & g.ring_mask];
             px[u] = (int)(c & 0xffff); py[u] = (int)(c >> 16);
@@ -439,6 +441,7 @@ __device__ void rect_from_ring(const GrowCtx& g, int nreg, double reg_angle, dou
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int cnt = min(64, nreg - 64 * u);
+        if (cnt <= 0) continue;
         const double tx = (double)px[u] * w[u], ty = (double)py[u] * w[u];
         for (int t = 0; t < cnt; ++t) { sx += bcast_d(tx, t); sy += bcast_d(ty, t); sw += bcast_d(w[u], t); }
     }
@@ -447,6 +450,7 @@ __device__ void rect_from_ring(const GrowCtx& g, int nreg, double reg_angle, dou
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int cnt = min(64, nreg - 64 * u);
+        if (cnt <= 0) continue;
         const double dx = (double)px[u] - x, dy = (double)py[u] - y;
         const double txx = dy * dy * w[u], tyy = dx * dx * w[u], txy = dx * dy * w[u];
         for (int t = 0; t < cnt; ++t) {
@@ -460,7 +464,8 @@ __device__ void rect_from_ring(const GrowCtx& g, int nreg, double reg_angle, dou
                                            : (double)fast_atan2_deg_l((float)Ixy, (float)(lambda - Iyy));
     theta *= (3.14159265358979323846 / 180);
     if (fabs(angle_diff_signed(theta, reg_angle)) > prec) theta += 3.14159265358979323846;
-    const double dx = cos(theta), dy = sin(theta);
+    double dx, dy;
+    sincos(theta, &dy, &dx);
     double l_min = 0, l_max = 0, w_min = 0, w_max = 0;
 #pragma unroll
     for (int u = 0; u < 4; ++u)
