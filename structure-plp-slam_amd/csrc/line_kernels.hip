@@ -437,28 +437,38 @@ __device__ void rect_from_ring(const GrowCtx& g, int nreg, double reg_angle, dou
             w[u] = pix_mod(g.pix[py[u] * g.sw + px[u]]);
         }
     }
-    double sx = 0, sy = 0, sw = 0;
+    // The three running sums of a pass are three lanes of one loop: the addends go through LDS (3 doubles per point,
+    // 32 points at a time), lane k adds stream k in region order -- 2 instructions per point instead of 9 broadcasts and
+    // adds.  The scratch is the frontier ring itself: its coordinates are in registers by now and the next region_grow
+    // starts it afresh (256 words = 32 x 3 doubles + slack).
+    double* sc = reinterpret_cast<double*>(g.ring);
+    __builtin_amdgcn_wave_barrier();
+    auto chain3 = [&](auto addend) -> double {   // addend(u, k): stream k of this lane's point u
+        double acc = 0;
+        const int nchunk = (nreg + 31) >> 5;
+        for (int c = 0; c < nchunk; ++c) {
+            const int u = c >> 1;
+            if ((lane >> 5) == (c & 1) && lane + 64 * u < nreg) {
+                double* o = sc + 3 * (lane & 31);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int cnt = min(64, nreg - 64 * u);
-        if (cnt <= 0) continue;
-        const double tx = (double)px[u] * w[u], ty = (double)py[u] * w[u];
-        for (int t = 0; t < cnt; ++t) { sx += bcast_d(tx, t); sy += bcast_d(ty, t); sw += bcast_d(w[u], t); }
-    }
-    const double x = sx / sw, y = sy / sw;
-    double Ixx = 0.0, Iyy = 0.0, Ixy = 0.0;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int cnt = min(64, nreg - 64 * u);
-        if (cnt <= 0) continue;
-        const double dx = (double)px[u] - x, dy = (double)py[u] - y;
-        const double txx = dy * dy * w[u], tyy = dx * dx * w[u], txy = dx * dy * w[u];
-        for (int t = 0; t < cnt; ++t) {
-            Ixx += bcast_d(txx, t);
-            Iyy += bcast_d(tyy, t);
-            Ixy -= bcast_d(txy, t);
+                for (int uu = 0; uu < 4; ++uu)
+                    if (uu == u) { o[0] = addend(uu, 0); o[1] = addend(uu, 1); o[2] = addend(uu, 2); }
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int cnt = min(32, nreg - 32 * c);
+            if (lane < 3) for (int t = 0; t < cnt; ++t) acc += sc[3 * t + lane];
+            __builtin_amdgcn_wave_barrier();
         }
-    }
+        return acc;
+    };
+    double acc = chain3([&](int u, int k) -> double { return k == 0 ? (double)px[u] * w[u] : k == 1 ? (double)py[u] * w[u] : w[u]; });
+    const double sx = bcast_d(acc, 0), sy = bcast_d(acc, 1), sw = bcast_d(acc, 2);
+    const double x = sx / sw, y = sy / sw;
+    acc = chain3([&](int u, int k) -> double {
+        const double dx = (double)px[u] - x, dy = (double)py[u] - y;
+        return k == 0 ? dy * dy * w[u] : k == 1 ? dx * dx * w[u] : -(dx * dy * w[u]);   // Ixy -= v  ==  Ixy += -v
+    });
+    const double Ixx = bcast_d(acc, 0), Iyy = bcast_d(acc, 1), Ixy = bcast_d(acc, 2);
     const double lambda = 0.5 * (Ixx + Iyy - sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
     double theta = (fabs(Ixx) > fabs(Iyy)) ? (double)fast_atan2_deg_l((float)(lambda - Ixx), (float)Ixy)
                                            : (double)fast_atan2_deg_l((float)Ixy, (float)(lambda - Iyy));
@@ -510,14 +520,15 @@ __device__ void centroid_sums(const GrowCtx& g, int nreg, double cen[3]) {
 // grid = (ceil(B / wpb)), block = 64 * wpb: wave w of a block handles frame wpb*blockIdx.x + w (wpb = waves whose
 // USED bitmap + frontier ring fit 64 KB of LDS together, at most 4).
 __global__ __launch_bounds__(256) void k_lsd_grow(LinePlanes P, LsdParams lp, int B, int wpb, int ring) {
-    extern __shared__ uint32_t s_bits[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_bits[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int b = blockIdx.x * wpb + wv;
     if (b >= B) return;
     const int n = P.sw * P.sh, nwords = (n + 31) / 32, nv = (P.sw - 1) * (P.sh - 1);
     GrowCtx g;
     g.pix = P.pix + (size_t)b * n;
-    g.reg = P.reg + (size_t)b * n; g.used = s_bits + (size_t)wv * (nwords + ring); g.ring = g.used + nwords; g.ring_mask = ring - 1;
+    g.reg = P.reg + (size_t)b * n; const int nw_al = (nwords + 1) & ~1;   // the ring doubles as f64 scratch: 8-byte aligned
+    g.used = s_bits + (size_t)wv * (nw_al + ring); g.ring = g.used + nw_al; g.ring_mask = ring - 1;
     g.sw = P.sw; g.sh = P.sh; g.lane = lane;
     // USED map starts as the NOTDEF mask: an undefined pixel is never a seed and never aligned, so
     // treating it as used is equivalent and spares a global load per rejected seed
@@ -559,7 +570,7 @@ __global__ __launch_bounds__(256) void k_lsd_grow(LinePlanes P, LsdParams lp, in
             if (nreg < lp.min_reg_size) continue;
             Rect rec;
             t0 = clock64();
-            const int ring_cap = min(256, g.ring_mask + 1);
+            const int ring_cap = g.ring_mask + 1 >= 256 ? 256 : 0;   // the fit from the ring needs the whole 256-word ring as scratch
             if (nreg <= ring_cap) rect_from_ring(g, nreg, reg_angle, lp.prec, rec);
             else {
                 region_list_fence();
@@ -954,7 +965,7 @@ void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp,
     // at 2048 frames every SIMD carries two of these instruction-bound waves (profiles/r01i_sq_counters.md).
     static const int ring = [] { const char* e = getenv("PLP_LSD_RING"); int r = e ? atoi(e) : 256; return (r >= 64 && (r & (r - 1)) == 0) ? r : 256; }();
     static const int wpb_env = [] { const char* e = getenv("PLP_LSD_WPB"); return e ? atoi(e) : 1; }();
-    const size_t per_wave = (size_t)((n + 31) / 32 + ring) * 4;
+    const size_t per_wave = (size_t)((((n + 31) / 32 + 1) & ~1) + ring) * 4;
     const int wpb = (int)std::max<size_t>(1, std::min<size_t>(std::min(4, std::max(1, wpb_env)), 65536 / per_wave));
     hipLaunchKernelGGL(k_lsd_grow, dim3((B + wpb - 1) / wpb), dim3(64 * wpb), per_wave * wpb, st, P, lp, B, wpb, ring);
     mark(4);
