@@ -11,7 +11,8 @@
 
 namespace plp {
 
-constexpr int kBlurTW = 128, kBlurTH = 64, kBlurPad = 8;
+constexpr int kBlurTW = 128, kBlurTH = 32, kBlurPad = 8;
+constexpr int kBlurRS = kBlurTH / 8;   // output rows per thread in the vertical pass (8 strips of a 256-thread workgroup)
 
 __device__ __forceinline__ int blur_reflect101(int p, int len) {
     if (len == 1) return 0;
@@ -91,18 +92,18 @@ __device__ __forceinline__ void blur_tile(BlurTileLds<R>& S, const uint8_t* __re
     // ---- vertical: 4 columns x 8 rows per thread; the (2R+1)-row window lives unpacked in registers (the loop is
     // fully unrolled, so sliding it is register renaming)
     const int cg = tid & 31, strip = tid >> 5;
-    const int c4 = cg * 4, r0 = strip * 8;
+    const int c4 = cg * 4, r0 = strip * kBlurRS;
     const int x = tx0 + c4;
     if (x >= w) return;
-    uint32_t win[K + 7][4];
+    uint32_t win[K + kBlurRS - 1][4];
 #pragma unroll
-    for (int k = 0; k < K + 7; ++k) {
+    for (int k = 0; k < K + kBlurRS - 1; ++k) {
         const uint32_t* q = reinterpret_cast<const uint32_t*>(&S.hs[(r0 + k) * kBlurTW + c4]);
         const uint32_t q0 = q[0], q1 = q[1];
         win[k][0] = q0 & 0xffffu; win[k][1] = q0 >> 16; win[k][2] = q1 & 0xffffu; win[k][3] = q1 >> 16;
     }
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
+    for (int rr = 0; rr < kBlurRS; ++rr) {
         uint32_t a0 = 32768u, a1 = 32768u, a2 = 32768u, a3 = 32768u;
 #pragma unroll
         for (int k = 0; k < K; ++k) {

@@ -10,6 +10,7 @@
 #include <string>
 #include <vector>
 
+#include "blur_tile.hpp"
 #include "orb_device.hpp"
 #include "plp_common.hpp"
 #include "quadtree_model.hpp"
@@ -103,7 +104,7 @@ plp_status build_geometry(plp_orb* c, int rows, int cols) {
         const LevelGeom& G = c->geo.lv[l];
         LevelDev& L = c->h_lv[l];
         L.w = G.w; L.h = G.h; L.pitch = G.pitch; L.off = G.off;
-        L.blur_tiles = ((G.w + 127) / 128) * ((G.h + 63) / 64);
+        L.blur_tiles = ((G.w + 127) / 128) * ((G.h + plp::kBlurTH - 1) / plp::kBlurTH);
         c->total_blur_tiles += L.blur_tiles;
         L.scale = c->st.sf[l];
         L.sel_base = G.sel_base; L.sel_cap = G.sel_cap;
