@@ -131,6 +131,7 @@ __global__ __launch_bounds__(256) void k_resize_linear(const uint8_t* __restrict
 // Hence one score map serves both the thr=ini pass and the thr=min fallback of an empty cell.
 // grid = (n_cells, B), block = 256.
 // ------------------------------------------------------------------------------------------
+constexpr int kFastQ1 = 1536, kFastQ2 = 512;
 constexpr int kTileW = 76;            // LDS row pitch of the u8 ROI tile (>= 70 + 3 alignment slack)
 constexpr int kScoreW = 68;           // 64 tested + 2 zero border, padded
 
@@ -144,7 +145,12 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbPlanes pl, const CellDesc
     __shared__ __attribute__((aligned(16))) uint8_t tile[70 * kTileW];
     __shared__ __attribute__((aligned(16))) uint8_t score[66 * kScoreW];   // score map of the tested interior, +1 zero ring
     __shared__ unsigned long long keepbits[64];                            // NMS survivors, one bit per tested position
-    __shared__ uint16_t queue[4096], queue2[4096];
+    // work queues between the passes.  They are capped (a 64 x 64 cell of a textured frame yields ~500 compass survivors
+    // and ~100 corners); the position bit masks are always complete, and a pass whose queue overflowed walks all positions
+    // and tests the bit instead.  (Uncapped queues cost 16 KB: beside region growing's LDS only two of these workgroups
+    // fitted a CU and the kernel ran three times slower there than alone.)
+    __shared__ uint16_t queue[kFastQ1], queue2[kFastQ2];
+    __shared__ unsigned long long bits1[64], bits2[64];
     __shared__ int q_count, q2_count, n_ini, wave_tot[4], run_base;
 
     unsigned ucell, uframe;
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbPlanes pl, const CellDesc
     for (int attempt = 0; attempt < 2; ++attempt) {
         thr = attempt == 0 ? ini_thr : min_thr;
         for (int i = tid; i < 66 * kScoreW / 4; i += 256) reinterpret_cast<uint32_t*>(score)[i] = 0;
-        if (tid < 64) keepbits[tid] = 0ull;
+        if (tid < 64) { keepbits[tid] = 0ull; bits1[tid] = 0ull; bits2[tid] = 0ull; }
         if (tid == 0) { q_count = 0; q2_count = 0; n_ini = 0; run_base = 0; }
         __syncthreads();
         // pass 1: every arc of 9 contains two neighbouring compass pixels (0, 4, 8, 12): five dword reads serve four
@@ -217,15 +223,21 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbPlanes pl, const CellDesc
                           p12 = (int)((Lq >> (8 * k)) & 255u);
                 const bool b0 = p0 > hi, b4 = p4 > hi, b8 = p8 > hi, b12 = p12 > hi;
                 const bool d0 = p0 < lo, d4 = p4 < lo, d8 = p8 < lo, d12 = p12 < lo;
-                if (((b0 | b8) & (b4 | b12)) | ((d0 | d8) & (d4 | d12))) queue[atomicAdd(&q_count, 1)] = (uint16_t)((ty << 6) | (tx4 + k));
+                if (((b0 | b8) & (b4 | b12)) | ((d0 | d8) & (d4 | d12))) {
+                    atomicOr(&bits1[ty], 1ull << (tx4 + k));
+                    const int slot = atomicAdd(&q_count, 1);
+                    if (slot < kFastQ1) queue[slot] = (uint16_t)((ty << 6) | (tx4 + k));
+                }
             }
         }
         __syncthreads();
         // pass 2: 16-bit brighter / darker masks of the survivors -> "has an arc of 9" -> second queue
         const int nq1 = q_count;
-        for (int j = tid; j < nq1; j += 256) {
-            const int i = queue[j];
+        const bool dense1 = nq1 <= kFastQ1;
+        for (int j = tid; j < (dense1 ? nq1 : 4096); j += 256) {
+            const int i = dense1 ? (int)queue[j] : j;
             const int ty = i >> 6, tx = i & 63;
+            if (!dense1 && !((bits1[ty] >> tx) & 1ull)) continue;
             const uint8_t* c = &tile[(ty + 3) * kTileW + tx + 4];
             const int v = c[0];
             const int hi = v + thr, lo = v - thr;
@@ -242,13 +254,20 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbPlanes pl, const CellDesc
                 x &= m >> 8;
                 return (x & 0xffffu) != 0;
             };
-            if (arc9(B) || arc9(D)) queue2[atomicAdd(&q2_count, 1)] = (uint16_t)i;
+            if (arc9(B) || arc9(D)) {
+                atomicOr(&bits2[ty], 1ull << tx);
+                const int slot = atomicAdd(&q2_count, 1);
+                if (slot < kFastQ2) queue2[slot] = (uint16_t)i;
+            }
         }
         __syncthreads();
         // pass 3: exact score of the corners (dense over the queue: no lane idles on non-corners)
         const int nq = q2_count;
-        for (int j = tid; j < nq; j += 256) {
-            const int ty = queue2[j] >> 6, tx = queue2[j] & 63;
+        const bool dense2 = nq <= kFastQ2;
+        for (int j = tid; j < (dense2 ? nq : 4096); j += 256) {
+            const int i = dense2 ? (int)queue2[j] : j;
+            const int ty = i >> 6, tx = i & 63;
+            if (!dense2 && !((bits2[ty] >> tx) & 1ull)) continue;
             const uint8_t* c = &tile[(ty + 3) * kTileW + tx + 4];
             const int v = c[0];
             int d[16];
@@ -276,8 +295,10 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbPlanes pl, const CellDesc
         __syncthreads();
         // pass 4: 3x3 strict NMS, only around the corners
         int my_ini = 0;
-        for (int j = tid; j < nq; j += 256) {
-            const int ty = queue2[j] >> 6, tx = queue2[j] & 63;
+        for (int j = tid; j < (dense2 ? nq : 4096); j += 256) {
+            const int i = dense2 ? (int)queue2[j] : j;
+            const int ty = i >> 6, tx = i & 63;
+            if (!dense2 && !((bits2[ty] >> tx) & 1ull)) continue;
             const uint8_t* sp = &score[(ty + 1) * kScoreW + tx + 1];
             const int v = sp[0];
             const bool ok = v > 0 && v > sp[-1] && v > sp[1] && v > sp[-kScoreW - 1] && v > sp[-kScoreW] && v > sp[-kScoreW + 1] &&
