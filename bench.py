@@ -128,10 +128,8 @@ def main():
     cur = torch.cuda.current_stream(dev)
     sA = torch.cuda.Stream(dev)
     serial = bool(os.environ.get("PLP_BENCH_SERIAL"))                            # diagnostic: one stream for everything
-    # the line path is the longest chain of a step: its streams get the higher hardware-queue priority
-    line_prio = int(os.environ.get("PLP_BENCH_LINE_PRIO", "-1"))
-    sB = sA if serial else torch.cuda.Stream(dev, priority=line_prio)
-    sBs = [sB] + [sA if serial else torch.cuda.Stream(dev, priority=line_prio) for _ in range(n_line - 1)]
+    sB = sA if serial else torch.cuda.Stream(dev)
+    sBs = [sB] + [sA if serial else torch.cuda.Stream(dev) for _ in range(n_line - 1)]
     slot = torch.arange(cap, device=dev, dtype=torch.int32)[None, :]
 
     replay = importlib.import_module("structure-plp-slam_amd.replay")
@@ -160,13 +158,6 @@ def main():
     # (no stage fills the chip on its own, see profiles/r01i_sq_counters.md); all K steps' work, matchers
     # included, is inside the timed region because the closing barrier synchronises the device.
     sC = sA if serial else torch.cuda.Stream(dev)
-    # Gated schedule: region growing (one wave per frame, ~85 KB of LDS per CU for half of the step) does not share a CU
-    # well with the tile kernels of the point path, but it does with the matchers.  So region growing of step n starts
-    # when ORB of step n is done (and then overlaps its matchers), and ORB of step n + 1 starts when it is over.
-    gated = os.environ.get("PLP_BENCH_GATED", "1") != "0" and not serial and not args.orb_only
-    grow_done = [torch.cuda.Event() for _ in range(n_line)]
-    for e in grow_done:
-        e.record(sA)          # creates the underlying hipEvent_t before its handle is handed to the line context
     done_match = [None, None]
     step_no = [0]
 
@@ -176,9 +167,6 @@ def main():
         if done_match[buf] is not None:
             sA.wait_event(done_match[buf])          # the matchers of step n - 2 have read this set
         parts = os.environ.get("PLP_BENCH_PARTS", "orb,lines,match")   # diagnostic: time a subset of the step
-        if gated:
-            for e in grow_done:
-                sA.wait_event(e)                    # region growing of step n - 1 is over: the tile kernels get the LDS back
         if "orb" in parts:
             ex.extract_batch(d_frames, kps2[buf], desc2[buf], cnt2[buf], stream=sA)
         ready = torch.cuda.Event(); ready.record(sA)
@@ -187,8 +175,6 @@ def main():
             for i, (lti, sbi) in enumerate(zip(lts, sBs)):
                 sl = slice(i * bs, (i + 1) * bs)
                 if "lines" in parts:
-                    if gated:
-                        lti.set_grow_hooks(ready, grow_done[i])
                     lti.extract_batch(d_frames[sl], d_kl[sl], d_lbd[sl], d_fn[sl], d_lcnt[sl], stream=sbi)
             if "match" not in parts:
                 return
@@ -214,9 +200,6 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if gated:
-        for lti in lts:
-            lti.set_grow_hooks(None, None)
     ex.last_batch_status()
     if not args.orb_only:
         for lti in lts:

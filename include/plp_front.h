@@ -186,12 +186,6 @@ plp_status plp_line_extract_batch_device(plp_line* ctx, const uint8_t* d_imgs, i
 plp_status plp_line_last_batch_status(plp_line* ctx);
 /* HIP-event stage timing (profiling mode makes batches synchronous).  ms9 = accumulated ms of {11-tap blur + x0.5 resize,
  * gradient + bins, seed order, region growing, key lines, 5-tap blur + Sobel, LBD, finalize, whole batch}. */
-/* Scheduling hooks of the batched path: region growing is the one long kernel of the line chain (half of a front-end
- * step) and shares a CU's LDS badly with the tile kernels of the point path.  A caller that runs both paths on separate
- * streams can have the next plp_line_extract_batch_device calls wait for `wait_before_grow` (a hipEvent_t, e.g. "the point
- * extractor of this batch is done") right before that kernel and record `record_after_grow` right after it, and gate its
- * next point-extractor launch on the latter.  NULL clears a hook.  The caller owns the events. */
-plp_status plp_line_set_grow_hooks(plp_line* ctx, void* wait_before_grow, void* record_after_grow);
 plp_status plp_line_set_profiling(plp_line* ctx, int32_t enable);
 plp_status plp_line_get_stage_times(plp_line* ctx, double* ms9, int64_t* n_batches);
 

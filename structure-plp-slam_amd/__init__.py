@@ -73,7 +73,6 @@ _API = [
     ("plp_line_extract", C.c_int, [_VP, _VP, _I32, _I32, _SZ, _VP, _VP, _VP, _I32, _VP]),
     ("plp_line_extract_batch_device", C.c_int, [_VP, _VP, _I32, _I32, _I32, _SZ, _SZ, _VP, _VP, _VP, _I32, _VP, _VP]),
     ("plp_line_last_batch_status", C.c_int, [_VP]),
-    ("plp_line_set_grow_hooks", C.c_int, [_VP, _VP, _VP]),
     ("plp_line_set_profiling", C.c_int, [_VP, _I32]),
     ("plp_line_get_stage_times", C.c_int, [_VP, _VP, _VP]),
     ("plp_line_debug_read", C.c_int, [_VP, C.c_int, _I32, _VP, _SZ, _VP]),
@@ -314,12 +313,6 @@ class LineFeatureTracker:
         n = C.c_int32(0)
         _check(lib().plp_line_extract(self._h, _p(img), img.shape[0], img.shape[1], img.strides[0], _p(kl), _p(lbd), _p(fn), LINE_CAP, C.byref(n)))
         return kl[:n.value].copy(), lbd[:n.value].copy(), fn[:n.value].copy()
-
-    def set_grow_hooks(self, wait_before_grow=None, record_after_grow=None):
-        """torch.cuda.Event objects (or None): see plp_line_set_grow_hooks"""
-        w = wait_before_grow.cuda_event if wait_before_grow is not None else None
-        r = record_after_grow.cuda_event if record_after_grow is not None else None
-        _check(lib().plp_line_set_grow_hooks(self._h, w, r))
 
     def extract_batch(self, d_imgs, d_kl, d_lbd, d_fn, d_counts, stream=None):
         """d_imgs torch uint8 [B,H,W]; d_kl uint8 [B,cap,68]; d_lbd uint8 [B,cap,32]; d_fn float64 [B,cap,3]; d_counts int32 [B]"""

@@ -153,7 +153,7 @@ plp_status run(plp_line* c, const uint8_t* d_imgs, int B, int rows, int cols, si
     }
     PLP_HIP(hipMemsetAsync(c->status.p, 0, 16, st));
     launch_line_front(st, c->P, c->lp, c->rt, c->t11, c->t5, c->w, d_kl, d_lbd, d_fn, cap, d_counts, B, c->profiling ? c->ev : nullptr,
-                      (c->side.stream || c->side.wait_before_grow || c->side.record_after_grow) ? &c->side : nullptr);
+                      c->side.stream ? &c->side : nullptr);
     PLP_HIP(hipGetLastError());
     if (c->profiling) {
         PLP_HIP(hipEventSynchronize(c->ev[8]));
@@ -261,14 +261,6 @@ plp_status plp_line_debug_grow_profile(plp_line* c, int64_t* out6) {
     long long v[8] = {0};
     PLP_HIP(hipMemcpy(v, c->prof.p, 48, hipMemcpyDeviceToHost));
     for (int i = 0; i < 6; ++i) out6[i] = v[i];
-    return PLP_OK;
-}
-
-plp_status plp_line_set_grow_hooks(plp_line* c, void* wait_before_grow, void* record_after_grow) {
-    if (!c) return set_error(PLP_ERR_INVALID_ARG, "ctx is NULL");
-    std::lock_guard<std::mutex> lk(c->mu);
-    c->side.wait_before_grow = (hipEvent_t)wait_before_grow;
-    c->side.record_after_grow = (hipEvent_t)record_after_grow;
     return PLP_OK;
 }
 

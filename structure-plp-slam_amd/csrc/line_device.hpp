@@ -54,8 +54,7 @@ struct ResizeExactTab { const int16_t *xo, *xc, *yo, *yc; };   // offsets + 8.8 
 struct BlurTapsN { int k[11]; };
 struct LbdWeightsDev { float g[63], l[21]; };
 
-// optional second stream of a line context + the caller's scheduling hooks around the region-growing kernel
-struct LineSideStream { hipStream_t stream; hipEvent_t fork, join; hipEvent_t wait_before_grow, record_after_grow; };
+struct LineSideStream { hipStream_t stream; hipEvent_t fork, join; };   // optional second stream of a line context
 
 // ev: NULL or 9 events recorded around the 8 stages {blur11+resize, gradient+bins, seed order, region grow, key lines,
 // blur5+sobel, LBD, finalize}

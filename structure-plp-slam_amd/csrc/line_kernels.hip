@@ -967,9 +967,7 @@ void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp,
     static const int wpb_env = [] { const char* e = getenv("PLP_LSD_WPB"); return e ? atoi(e) : 1; }();
     const size_t per_wave = (size_t)((((n + 31) / 32 + 1) & ~1) + ring) * 4;
     const int wpb = (int)std::max<size_t>(1, std::min<size_t>(std::min(4, std::max(1, wpb_env)), 65536 / per_wave));
-    if (side && side->wait_before_grow) (void)hipStreamWaitEvent(st, side->wait_before_grow, 0);
     hipLaunchKernelGGL(k_lsd_grow, dim3((B + wpb - 1) / wpb), dim3(64 * wpb), per_wave * wpb, st, P, lp, B, wpb, ring);
-    if (side && side->record_after_grow) (void)hipEventRecord(side->record_after_grow, st);
     mark(4);
     hipLaunchKernelGGL(k_keylines, dim3(B), dim3(64), 0, st, P, lp);
     mark(5);
