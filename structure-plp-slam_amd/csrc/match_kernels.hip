@@ -392,16 +392,23 @@ __global__ __launch_bounds__(256) void k_match_topk_cells(MatchProblem P) {
     if (q_begin >= m) return;
     const int ncell = P.grid_cols * P.grid_rows, rows = P.grid_rows;
     const uint8_t* t_desc = P.t_desc + (size_t)b * P.n_cap * 32;
-    StagedTarget* st = reinterpret_cast<StagedTarget*>(smem);
-    float* sxr = reinterpret_cast<float*>(smem + (size_t)P.n_cap * sizeof(StagedTarget));
-    uint16_t* cs = reinterpret_cast<uint16_t*>(smem + (size_t)P.n_cap * (sizeof(StagedTarget) + 4));
-    __shared__ uint16_t s_cand[256 * kLaneCand];
+    // LDS (12 or 16 bytes per target: beside region growing's 85 KB per CU a 50 KB workgroup fitted only once per CU):
+    //   sxy[n_cap] position, sto[n_cap] = index | octave << 16, sxr[n_cap] stereo coordinate (only if given), cell index
     const bool has_xr = P.t_x_right != nullptr;
+    float2* sxy = reinterpret_cast<float2*>(smem);
+    uint32_t* sto = reinterpret_cast<uint32_t*>(smem + (size_t)P.n_cap * 8);
+    float* sxr = reinterpret_cast<float*>(smem + (size_t)P.n_cap * 12);
+    uint16_t* cs = reinterpret_cast<uint16_t*>(smem + (size_t)P.n_cap * (has_xr ? 16 : 12));
+    __shared__ uint16_t s_cand[256 * kLaneCand];
     {
         const uint16_t* gcs = P.cell_start + (size_t)b * kCellStride;
         const int used = gcs[ncell];
         const uint4* src = reinterpret_cast<const uint4*>(P.sorted + (size_t)b * P.n_cap);
-        for (int i = tid; i < used; i += 256) reinterpret_cast<uint4*>(st)[i] = src[i];
+        for (int i = tid; i < used; i += 256) {
+            const uint4 r = src[i];   // {x, y, octave | cell, index}
+            sxy[i] = make_float2(__uint_as_float(r.x), __uint_as_float(r.y));
+            sto[i] = (r.w & 0xffffu) | ((r.z & 0xffu) << 16);
+        }
         if (has_xr) for (int i = tid; i < used; i += 256) sxr[i] = P.sorted_xr[(size_t)b * P.n_cap + i];
         const uint32_t* g32 = reinterpret_cast<const uint32_t*>(gcs);
         for (int i = tid; i < (ncell + 2) / 2; i += 256) reinterpret_cast<uint32_t*>(cs)[i] = g32[i];
@@ -433,7 +440,7 @@ __global__ __launch_bounds__(256) void k_match_topk_cells(MatchProblem P) {
 #pragma unroll
                     for (int k = 0; k < kLaneCand; ++k)
                         if (k < nc) {
-                            const uint4* d = reinterpret_cast<const uint4*>(t_desc + 32 * (size_t)st[my[k]].t);
+                            const uint4* d = reinterpret_cast<const uint4*>(t_desc + 32 * (size_t)(sto[my[k]] & 0xffffu));
                             d0[k] = d[0]; d1[k] = d[1];
                         }
 #pragma unroll
@@ -453,13 +460,13 @@ __global__ __launch_bounds__(256) void k_match_topk_cells(MatchProblem P) {
                 for (int col = c.min_cx + sub; col <= c.max_cx; col += 16) {
                     const int i0 = cs[col * rows + c.min_cy], i1 = cs[col * rows + c.max_cy + 1];
                     for (int i = i0; i < i1; ++i) {
-                        const StagedTarget s = st[i];
-                        const int oct = (int)(s.packed & 0xff);
+                        const float2 sp = sxy[i];
                         if (check_level) {
+                            const int oct = (int)(sto[i] >> 16);
                             if (oct < c.min_level) continue;
                             if (0 <= c.max_level && c.max_level < oct) continue;
                         }
-                        if (!(fabsf(__fsub_rn(s.x, c.rx)) < c.mg && fabsf(__fsub_rn(s.y, c.ry)) < c.mg)) continue;
+                        if (!(fabsf(__fsub_rn(sp.x, c.rx)) < c.mg && fabsf(__fsub_rn(sp.y, c.ry)) < c.mg)) continue;
                         if (has_xr) {
                             const float xr = sxr[i];
                             if (0 < xr && c.mg < fabsf(__fsub_rn(c.xr, xr))) continue;
@@ -487,8 +494,8 @@ __global__ __launch_bounds__(256) void k_match_topk_cells(MatchProblem P) {
             if (sub < kMatchK) {
                 uint32_t e = 0xffffffffu;
                 if (mine != 0xffffffffu) {
-                    const StagedTarget s = st[mine & 0xffffu];
-                    e = ((mine >> 16) << 20) | ((s.packed & 15u) << 16) | (s.t & 0xffffu);
+                    const uint32_t to = sto[mine & 0xffffu];
+                    e = ((mine >> 16) << 20) | (((to >> 16) & 15u) << 16) | (to & 0xffffu);
                 }
                 P.klist[((size_t)b * P.m_cap + q) * kMatchK + sub] = e;
             }
@@ -900,7 +907,7 @@ void launch_match(hipStream_t st, const MatchProblem& P, int B) {
     Q.sorted_valid = 0;
     const bool windowed = P.mode == PLP_MATCH_MODE_LANDMARKS || P.mode == PLP_MATCH_MODE_LAST_FRAME;
     const bool line = is_line_mode_host(P.mode) || P.mode == PLP_MATCH_MODE_BOW || P.mode == PLP_MATCH_MODE_TRIANGULATION;
-    const size_t staged = windowed ? (size_t)P.n_cap * (sizeof(StagedTarget) + 4) + 2 * kCellStride : (size_t)P.n_cap * 32;
+    const size_t staged = windowed ? (size_t)P.n_cap * (P.t_x_right ? 16 : 12) + 2 * kCellStride : (size_t)P.n_cap * 32;
     const dim3 qgrid((P.m_cap + kQueriesPerBlock - 1) / kQueriesPerBlock, B);
     if (!line && windowed && staged <= 64 * 1024 && P.grid_cols <= 255 && P.grid_rows <= 255) {
         hipLaunchKernelGGL(k_match_prep, dim3(B), dim3(256), 0, st, P);
