@@ -558,7 +558,7 @@ __device__ __forceinline__ bool accept(const MatchProblem& P, unsigned best, int
 }
 
 // grid = (B), block = 256.  LDS: owner[2][n_cap] (dynamic).
-__global__ __launch_bounds__(256) void k_match_resolve(MatchProblem P) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_match_resolve(MatchProblem P) {
     extern __shared__ int32_t lds[];
     __shared__ int s_changed, s_num, s_hist[32], s_valid_bin[32], s_full_n, s_claim_tmp[256];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.x;

@@ -125,7 +125,7 @@ plp_status build_geometry(plp_orb* c, int rows, int cols) {
         while ((1 << nb) < n_init) ++nb;
         L.sort_lo = 2 * (kQtDepth - d_eff);
         L.sort_hi = 2 * kQtDepth + nb;
-        if (L.n_cells > 4096 || L.sel_cap > 2048 || n_init > 32)
+        if (L.n_cells > 2048 || L.sel_cap > 2048 || n_init > 32)
             return set_error(PLP_ERR_UNSUPPORTED, "frame/keypoint budget exceeds the quadtree kernel limits (quota per level <= 1022)");
     }
     PLP_HIP(c->d_lv.upload(c->h_lv.data(), sizeof(LevelDev) * nl, c->stream));

@@ -16,14 +16,14 @@
 namespace plp {
 
 constexpr int kQtMaxNodes = 2048;            // hard upper bound of the node arrays (quota up to ~680 per level)
-constexpr int kQtSegLds = 512;               // radix counters for up to 512 wave-sized segments live in LDS (n <= 32768) ...
-constexpr int kQtKeyCache = 4096;            // ... and share it with the sorted-key cache; larger levels use the HBM scratch
+constexpr int kQtSegLds = 256;               // radix counters for up to 256 wave-sized segments live in LDS (n <= 16384) ...
+constexpr int kQtKeyCache = 2048;            // ... and share it with the sorted-key cache; larger levels use the HBM scratch
 
 // LDS of one workgroup, carved from dynamic shared memory: the node arrays are sized by the largest per-level quota
 // (a list never holds more than 3 * quota + 3 nodes), so that 2-3 workgroups fit a CU for the usual K = 1000..2000
 // (a fixed 85 KB layout had left one workgroup = four waves per CU).
 struct QtShared {
-    uint16_t* cnt;                  // [16 * kQtSegLds] radix counters [digit][segment]      } one 16 KB block
+    uint16_t* cnt;                  // [16 * kQtSegLds] radix counters [digit][segment]      } one 8 KB block
     uint32_t* big;                  // [kQtKeyCache] cell prefix, later the sorted-key cache  }
     uint16_t *ns[2], *ne[2];
     uint8_t *nd[2], *nleaf[2];
@@ -35,12 +35,12 @@ struct QtShared {
     int max_nodes;
 };
 __host__ __device__ inline size_t qt_lds_bytes(int max_nodes) {
-    return 16384 + (size_t)max_nodes * (4 * 2 + 4 * 1 + 3 * 2 + 4 + 2 * 2) + 16 + 32;
+    return 8192 + (size_t)max_nodes * (4 * 2 + 4 * 1 + 3 * 2 + 4 + 2 * 2) + 16 + 32;
 }
 __device__ __forceinline__ QtShared qt_carve(uint8_t* base, int mn) {
     QtShared S;
     S.cnt = reinterpret_cast<uint16_t*>(base); S.big = reinterpret_cast<uint32_t*>(base);
-    uint8_t* p = base + 16384;
+    uint8_t* p = base + 8192;
     S.pk = reinterpret_cast<uint32_t*>(p); p += 4 * (size_t)mn;
     S.partial = reinterpret_cast<uint32_t*>(p); p += 16;
     S.misc = reinterpret_cast<int*>(p); p += 32;
