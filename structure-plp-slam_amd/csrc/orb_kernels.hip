@@ -137,7 +137,7 @@ constexpr int kScoreW = 68;           // 64 tested + 2 zero border, padded
 
 __device__ __forceinline__ int min3(int a, int b, int c) { return min(a, min(b, c)); }
 
-__global__ __launch_bounds__(256) void k_fast_cells(OrbPlanes pl, const CellDesc* __restrict__ cells,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fast_cells(OrbPlanes pl, const CellDesc* __restrict__ cells,
                                                     const LevelDev* __restrict__ lv, int ini_thr, int min_thr,
                                                     const uint8_t* __restrict__ mask, size_t mask_step,
                                                     size_t mask_frame_stride, uint32_t* __restrict__ cell_cand,
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbPlanes pl, const CellDesc
 // One workgroup = 128 x 64 output tile of one level of one frame; all levels in one launch.
 // grid = (tiles of all levels, B), block = 256.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_blur7(OrbPlanes pl, uint8_t* __restrict__ blur_base, size_t blur_frame_stride,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_blur7(OrbPlanes pl, uint8_t* __restrict__ blur_base, size_t blur_frame_stride,
                                                const LevelDev* __restrict__ lv, int n_levels, BlurTaps taps) {
     __shared__ BlurTileLds<3> S;
     unsigned ut, uf;
