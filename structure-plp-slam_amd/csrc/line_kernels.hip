@@ -59,7 +59,7 @@ __device__ __forceinline__ float fast_atan2_deg_l(float y, float x) {   // cv::f
 // ------------------------------------------------------------------------------------------ blur
 // (2R+1)-tap fixed-point Gaussian of one plane per frame (blur_tile.hpp); 128 x 64 output tile per workgroup.
 template <int R>
-__global__ __launch_bounds__(256) void k_blur_plane(const uint8_t* __restrict__ src, size_t src_fs, int src_pitch,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_blur_plane(const uint8_t* __restrict__ src, size_t src_fs, int src_pitch,
                                                     uint8_t* __restrict__ dst, size_t dst_fs, int dst_pitch, int w, int h, BlurTapsN taps) {
     __shared__ BlurTileLds<R> S;
     const int tiles_x = (w + kBlurTW - 1) / kBlurTW;
