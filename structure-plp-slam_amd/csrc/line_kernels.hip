@@ -144,20 +144,26 @@ __global__ __launch_bounds__(256) void k_lsd_gradient(LinePlanes P, LsdParams lp
         P.undef[(size_t)b * ((n + 63) / 64) + (blockIdx.x * 256 + threadIdx.x) / 64] = undef;
 }
 
-__global__ __launch_bounds__(256) void k_lsd_bins(LinePlanes P, LsdParams lp) {
-    const int b = blockIdx.y, idx = blockIdx.x * 256 + threadIdx.x, n = P.sw * P.sh;
+// grid = (ceil(n / 1024), B): four pixels per thread, so the per-frame maximum (the reduction of k_lsd_gradient's
+// per-workgroup values) is recomputed by a quarter of the workgroups.
+__global__ __launch_bounds__(256) void k_lsd_bins(LinePlanes P, LsdParams lp, int n_grad_blocks) {
+    const int b = blockIdx.y, idx0 = (blockIdx.x * 256 + threadIdx.x) * 4, n = P.sw * P.sh;
     __shared__ uint32_t s_red[4];
     uint32_t mx = 0;
-    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) mx = max(mx, P.blockmax[(size_t)b * gridDim.x + i]);   // same grid as k_lsd_gradient
+    for (int i = threadIdx.x; i < n_grad_blocks; i += 256) mx = max(mx, P.blockmax[(size_t)b * n_grad_blocks + i]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
     if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = mx;
     __syncthreads();
     mx = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
-    if (idx >= n) return;
+    if (idx0 >= n) return;
     const double max_grad = sqrt((double)mx / 4.0);
     const double bin_coef = (max_grad > 0) ? (double)(lp.n_bins - 1) / max_grad : 0;
-    P.bin[(size_t)b * n + idx] = (uint16_t)(int)(pix_mod(P.pix[(size_t)b * n + idx]) * bin_coef);
+    const LsdPix* px = P.pix + (size_t)b * n + idx0;
+    uint16_t* out = P.bin + (size_t)b * n + idx0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (idx0 + k < n) out[k] = (uint16_t)(int)(pix_mod(px[k]) * bin_coef);
 }
 
 // ------------------------------------------------------------------------------------------ seed ordering
@@ -956,7 +962,7 @@ void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp,
     mark(1);
     const int n = P.sw * P.sh;
     hipLaunchKernelGGL(k_lsd_gradient, dim3((n + 255) / 256, B), dim3(256), 0, st, P, lp);
-    hipLaunchKernelGGL(k_lsd_bins, dim3((n + 255) / 256, B), dim3(256), 0, st, P, lp);
+    hipLaunchKernelGGL(k_lsd_bins, dim3((n + 1023) / 1024, B), dim3(256), 0, st, P, lp, (n + 255) / 256);
     mark(2);
     hipLaunchKernelGGL(k_lsd_order, dim3(B), dim3(256), 0, st, P);
     mark(3);
