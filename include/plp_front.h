@@ -392,6 +392,21 @@ plp_status plp_convert_to_true_depth_device(plp_matcher* ctx, const void* d_src,
                                             size_t src_frame_stride, double depthmap_factor, int32_t B, float* d_dst, size_t dst_step,
                                             size_t dst_frame_stride, void* hip_stream);
 
+/* util::stereo_rectifier (src/PLPSLAM/util/stereo_rectifier.cc:38-85), perspective model.
+ * plp_rectify_map_device = the constructor's cv::initUndistortRectifyMap(K, D, R, K_rect, img_size, CV_32F, map_x, map_y)
+ * for one eye (:61-62): K, R row-major 3x3 doubles and D (n_dist in {0, 4, 5, 8, 12}: k1 k2 p1 p2 [k3 [k4 k5 k6 [s1..s4]]])
+ * as read from the yaml; rect_cam = the rectified camera, whose fx, fy, cx, cy are rounded to float like
+ * camera::perspective::cv_cam_matrix_ (perspective.cc:47).  Writes rows x cols CV_32F maps (map_step bytes per row).
+ * plp_remap_linear_device = rectify()'s cv::remap(in, out, map_x, map_y, cv::INTER_LINEAR) (:83-84) on B 8UC1 frames that
+ * share one map pair: 1/32-pixel fixed point, 15-bit weights, constant border 0.  The fisheye model (TUM-VI yaml) is not
+ * provided: PLP_ERR_UNSUPPORTED is the caller's cue to keep cv::fisheye on the host.  Device pointers, asynchronous. */
+plp_status plp_rectify_map_device(plp_matcher* ctx, const double* K, const double* D, int32_t n_dist, const double* R,
+                                  const plp_camera* rect_cam, int32_t rows, int32_t cols, float* d_map_x, float* d_map_y, size_t map_step,
+                                  void* hip_stream);
+plp_status plp_remap_linear_device(plp_matcher* ctx, const uint8_t* d_src, int32_t rows, int32_t cols, size_t src_step, size_t src_frame_stride,
+                                   const float* d_map_x, const float* d_map_y, size_t map_step, int32_t dst_rows, int32_t dst_cols, int32_t B,
+                                   uint8_t* d_dst, size_t dst_step, size_t dst_frame_stride, void* hip_stream);
+
 /* Planar_Mapping_module::create_ColorToPlane (src/PLPSLAM/planar_mapping_module.cc:185-345), the per-key-point part
  * (BASELINE config 5): labels[b][i] = colour label c0 + (c1 << 8) + (c2 << 16) of the CV_8UC3
  * instance mask under undistorted key point i, or 0 when the point is flagged invalid (valid == NULL: all valid), outside

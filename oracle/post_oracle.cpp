@@ -198,3 +198,146 @@ void oracle_color_vote(const uint8_t* mask, int rows, int cols, size_t step, con
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------- stereo rectification
+// util::stereo_rectifier (src/PLPSLAM/util/stereo_rectifier.cc:38-85): the constructor builds one CV_32F map pair per eye
+// with cv::initUndistortRectifyMap(K, D, R, K_rect, img_size, CV_32F, ...) (perspective model, :61-62), rectify() is
+// cv::remap(in, out, map_x, map_y, cv::INTER_LINEAR) (:83-84, BORDER_CONSTANT, value 0) on the 8-bit images read by the
+// EuRoC drivers (example/run_euroc_slam.cc:246).  Both are third-party (OpenCV, not under /root/reference): restated
+// from the scalar code of OpenCV 3.4/4.x imgproc (undistort.cpp, imgwarp.cpp) = "OpenCV-knowledge", PARITY UNPINNED.
+//   * K_rect is camera::perspective::cv_cam_matrix_, a cv::Mat_<float> (perspective.cc:47): the map sees FLOAT-rounded
+//     fx, fy, cx, cy of the rectified camera; K, D, R come from the yaml as doubles (stereo_rectifier.cc:48-57).
+//   * iR = (K_rect * R)^-1 by the closed-form 3x3 inverse of cv::Matx; one row walks _x, _y, _w by repeated addition.
+//   * remap: float maps -> 1/32-pixel fixed point with cvRound (half to even), 15-bit bilinear weights, (sum + 2^14) >> 15.
+//     The weight table is built the way initInterTab2D does, including its saturation of the weight 1.0 to 32767 and the
+//     compensation that follows; the result is the same as with exact weights (tests/test_oracle_post.py checks that).
+// The fisheye model (cv::fisheye::initUndistortRectifyMap, SVD inverse + atan) is not restated.
+namespace {
+
+void matx33_mul(const double a[9], const double b[9], double c[9]) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double s = 0;
+            for (int k = 0; k < 3; ++k) s += a[i * 3 + k] * b[k * 3 + j];
+            c[i * 3 + j] = s;
+        }
+}
+
+bool matx33_inv(const double a[9], double b[9]) {
+    auto A = [&](int i, int j) { return a[i * 3 + j]; };
+    double d = A(0, 0) * (A(1, 1) * A(2, 2) - A(2, 1) * A(1, 2)) - A(0, 1) * (A(1, 0) * A(2, 2) - A(2, 0) * A(1, 2)) +
+               A(0, 2) * (A(1, 0) * A(2, 1) - A(2, 0) * A(1, 1));
+    if (d == 0) return false;
+    d = 1 / d;
+    b[0] = (A(1, 1) * A(2, 2) - A(1, 2) * A(2, 1)) * d;
+    b[1] = (A(0, 2) * A(2, 1) - A(0, 1) * A(2, 2)) * d;
+    b[2] = (A(0, 1) * A(1, 2) - A(0, 2) * A(1, 1)) * d;
+    b[3] = (A(1, 2) * A(2, 0) - A(1, 0) * A(2, 2)) * d;
+    b[4] = (A(0, 0) * A(2, 2) - A(0, 2) * A(2, 0)) * d;
+    b[5] = (A(0, 2) * A(1, 0) - A(0, 0) * A(1, 2)) * d;
+    b[6] = (A(1, 0) * A(2, 1) - A(1, 1) * A(2, 0)) * d;
+    b[7] = (A(0, 1) * A(2, 0) - A(0, 0) * A(2, 1)) * d;
+    b[8] = (A(0, 0) * A(1, 1) - A(0, 1) * A(1, 0)) * d;
+    return true;
+}
+
+int cv_round(double v) { return (int)std::nearbyint(v); }   // default rounding mode: half to even, like cvRound
+
+// initInterTab2D(INTER_LINEAR, fixpt = true): 32 x 32 sub-pixel positions, 2 x 2 short weights each
+const short* bilinear_tab_i() {
+    static short tab[32 * 32 * 4];
+    static bool ready = false;
+    if (ready) return tab;
+    float lin[32][2];
+    for (int i = 0; i < 32; ++i) { const float x = i * (1.f / 32); lin[i][0] = 1.f - x; lin[i][1] = x; }
+    for (int i = 0; i < 32; ++i)
+        for (int j = 0; j < 32; ++j) {
+            short* it = tab + (i * 32 + j) * 4;
+            int isum = 0;
+            for (int k1 = 0; k1 < 2; ++k1)
+                for (int k2 = 0; k2 < 2; ++k2) {
+                    const float v = lin[i][k1] * lin[j][k2] * 32768.f;
+                    int r = cv_round(v);
+                    r = r > 32767 ? 32767 : (r < -32768 ? -32768 : r);
+                    it[k1 * 2 + k2] = (short)r;
+                    isum += r;
+                }
+            if (isum != 32768) {
+                // the compensation looks at the 2 x 2 taps starting at ksize/2 = 1; for a 2 x 2 kernel only tap (1, 1)
+                // is inside the block and the entries behind it are still zero while the table is being filled
+                const int diff = isum - 32768;
+                it[3] = (short)(it[3] - diff);
+            }
+        }
+    ready = true;
+    return tab;
+}
+
+}  // namespace
+
+extern "C" {
+
+// returns 0, or -1 when K_rect * R is singular.  D: n_dist in {0, 4, 5, 8, 12} (k1 k2 p1 p2 [k3 [k4 k5 k6 [s1 s2 s3 s4]]])
+int oracle_init_undistort_rectify_map(const double* K, const double* D, int n_dist, const double* R, const double* K_rect_f32, int rows,
+                                      int cols, float* map_x, float* map_y) {
+    double Ar[9], ArR[9], ir[9];
+    for (int i = 0; i < 9; ++i) Ar[i] = (double)(float)K_rect_f32[i];
+    matx33_mul(Ar, R, ArR);
+    if (!matx33_inv(ArR, ir)) return -1;
+    const double u0 = K[2], v0 = K[5], fx = K[0], fy = K[4];
+    double d[12] = {0};
+    for (int i = 0; i < n_dist && i < 12; ++i) d[i] = D[i];
+    const double k1 = d[0], k2 = d[1], p1 = d[2], p2 = d[3], k3 = d[4], k4 = d[5], k5 = d[6], k6 = d[7], s1 = d[8], s2 = d[9], s3 = d[10],
+                 s4 = d[11];
+    for (int i = 0; i < rows; ++i) {
+        double _x = i * ir[1] + ir[2], _y = i * ir[4] + ir[5], _w = i * ir[7] + ir[8];
+        for (int j = 0; j < cols; ++j, _x += ir[0], _y += ir[3], _w += ir[6]) {
+            const double w = 1. / _w, x = _x * w, y = _y * w;
+            const double x2 = x * x, y2 = y * y;
+            const double r2 = x2 + y2, _2xy = 2 * x * y;
+            const double kr = (1 + ((k3 * r2 + k2) * r2 + k1) * r2) / (1 + ((k6 * r2 + k5) * r2 + k4) * r2);
+            const double xd = (x * kr + p1 * _2xy + p2 * (r2 + 2 * x2) + s1 * r2 + s2 * r2 * r2);
+            const double yd = (y * kr + p1 * (r2 + 2 * y2) + p2 * _2xy + s3 * r2 + s4 * r2 * r2);
+            // tilt with the identity matrix: vecTilt = (xd, yd, 1), invProj = 1
+            const double vt0 = 1.0 * xd + 0.0 * yd + 0.0 * 1.0, vt1 = 0.0 * xd + 1.0 * yd + 0.0 * 1.0, vt2 = 0.0 * xd + 0.0 * yd + 1.0 * 1.0;
+            const double invProj = vt2 ? 1. / vt2 : 1;
+            const double u = fx * invProj * vt0 + u0;
+            const double v = fy * invProj * vt1 + v0;
+            map_x[(size_t)i * cols + j] = (float)u;
+            map_y[(size_t)i * cols + j] = (float)v;
+        }
+    }
+    return 0;
+}
+
+// cv::remap(src 8UC1, dst, map_x, map_y CV_32FC1, INTER_LINEAR, BORDER_CONSTANT, 0); dst has the maps' size
+void oracle_remap_linear(const uint8_t* src, int rows, int cols, size_t step, const float* map_x, const float* map_y, int drows, int dcols,
+                         uint8_t* dst) {
+    const short* wtab = bilinear_tab_i();
+    const int width1 = cols - 1 > 0 ? cols - 1 : 0, height1 = rows - 1 > 0 ? rows - 1 : 0;
+    auto sat_short = [](int v) { return v > 32767 ? 32767 : (v < -32768 ? -32768 : v); };
+    for (int dy = 0; dy < drows; ++dy)
+        for (int dx = 0; dx < dcols; ++dx) {
+            const int fsx = cv_round(map_x[(size_t)dy * dcols + dx] * 32.f), fsy = cv_round(map_y[(size_t)dy * dcols + dx] * 32.f);
+            const short* w = wtab + (((fsy & 31) * 32) + (fsx & 31)) * 4;
+            const int sx = sat_short(fsx >> 5), sy = sat_short(fsy >> 5);
+            int val;
+            if ((unsigned)sx < (unsigned)width1 && (unsigned)sy < (unsigned)height1) {
+                const uint8_t* S = src + (size_t)sy * step + sx;
+                val = S[0] * w[0] + S[1] * w[1] + S[step] * w[2] + S[step + 1] * w[3];
+            } else if (sx >= cols || sx + 1 < 0 || sy >= rows || sy + 1 < 0) {
+                dst[(size_t)dy * dcols + dx] = 0;
+                continue;
+            } else {
+                const int v0 = (sx >= 0 && sy >= 0) ? src[(size_t)sy * step + sx] : 0;
+                const int v1 = (sx + 1 < cols && sy >= 0) ? src[(size_t)sy * step + sx + 1] : 0;
+                const int v2 = (sx >= 0 && sy + 1 < rows) ? src[(size_t)(sy + 1) * step + sx] : 0;
+                const int v3 = (sx + 1 < cols && sy + 1 < rows) ? src[(size_t)(sy + 1) * step + sx + 1] : 0;
+                val = v0 * w[0] + v1 * w[1] + v2 * w[2] + v3 * w[3];
+            }
+            const int r = (val + (1 << 14)) >> 15;
+            dst[(size_t)dy * dcols + dx] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+        }
+}
+
+}  // extern "C"

@@ -86,6 +86,8 @@ _API = [
     ("plp_match_area_host", C.c_int, [_VP, _VP, _VP, _I32, _VP, _VP, _I32, _VP, _VP, _I32, C.c_float, _I32, _VP, _VP]),
     ("plp_convert_to_grayscale_device", C.c_int, [_VP, _VP, _I32, _I32, C.c_size_t, C.c_size_t, _I32, _I32, _I32, _VP, C.c_size_t, C.c_size_t, _VP]),
     ("plp_convert_to_true_depth_device", C.c_int, [_VP, _VP, _I32, _I32, _I32, C.c_size_t, C.c_size_t, C.c_double, _I32, _VP, C.c_size_t, C.c_size_t, _VP]),
+    ("plp_rectify_map_device", C.c_int, [_VP, _VP, _VP, _I32, _VP, _VP, _I32, _I32, _VP, _VP, C.c_size_t, _VP]),
+    ("plp_remap_linear_device", C.c_int, [_VP, _VP, _I32, _I32, C.c_size_t, C.c_size_t, _VP, _VP, C.c_size_t, _I32, _I32, _I32, _VP, C.c_size_t, C.c_size_t, _VP]),
     ("plp_color_vote_device", C.c_int, [_VP, _VP, _I32, _I32, C.c_size_t, C.c_size_t, _VP, _VP, _VP, _I32, _I32, _I32, _VP, _VP]),
     ("plp_landmark_descriptor_device", C.c_int, [_VP, _VP, _VP, _I32, _VP, _VP]),
     ("plp_landmark_descriptor_host", C.c_int, [_VP, _VP, _VP, _I32, _VP]),
@@ -529,3 +531,54 @@ class matcher:
         d = np.zeros((len(q), len(t)), np.uint16)
         _check(lib().plp_hamming_matrix_host(self._h, _p(q), len(q), _p(t), len(t), _p(d)))
         return d
+
+
+# ------------------------------------------------------------------------------------------------
+# util::stereo_rectifier of the reference (src/PLPSLAM/util/stereo_rectifier.cc:38-85), perspective model
+# ------------------------------------------------------------------------------------------------
+class stereo_rectifier:
+    """Mirror of util::stereo_rectifier: the constructor takes the rectified camera (fx, fy, cx, cy, cols, rows) and the
+    yaml node's StereoRectifier.{K,D,R}_{left,right} lists and builds the two CV_32F map pairs in HBM
+    (cv::initUndistortRectifyMap, :61-62); rectify() is the two cv::remap(INTER_LINEAR) calls (:83-84) on batches of 8-bit
+    frames.  StereoRectifier.model other than "perspective" raises, like an unknown model does in the reference (:108)."""
+
+    def __init__(self, camera, yaml_node, device=0):
+        import torch
+        model = yaml_node.get("StereoRectifier.model", "perspective")
+        if model != "perspective":
+            raise PlpError(6, f"Invalid model type for stereo rectification on the device: {model}")
+        self._mt = matcher(device=device)
+        self._dev = torch.device("cuda", device)
+        self.rows, self.cols = int(camera["rows"]), int(camera["cols"])
+        cam = camera_c()
+        for k in ("fx", "fy", "cx", "cy"):
+            setattr(cam, k, float(camera[k]))
+        self.maps = {}
+        for eye in ("left", "right"):
+            K = np.ascontiguousarray(yaml_node[f"StereoRectifier.K_{eye}"], np.float64)
+            D = np.ascontiguousarray(yaml_node[f"StereoRectifier.D_{eye}"], np.float64)
+            R = np.ascontiguousarray(yaml_node[f"StereoRectifier.R_{eye}"], np.float64)
+            if K.size != 9 or R.size != 9:
+                raise PlpError(1, "StereoRectifier.K / R must have 9 entries")
+            mx = torch.empty((self.rows, self.cols), dtype=torch.float32, device=self._dev)
+            my = torch.empty_like(mx)
+            _check(lib().plp_rectify_map_device(self._mt._h, _p(K), _p(D) if D.size else None, int(D.size), _p(R), C.byref(cam), self.rows, self.cols,
+                                                mx.data_ptr(), my.data_ptr(), self.cols * 4, None))
+            self.maps[eye] = (mx, my)
+
+    def _remap(self, img, eye, stream=None):
+        import torch
+        if img.dtype != torch.uint8 or img.dim() not in (2, 3) or not img.is_contiguous():
+            raise PlpError(1, "rectify expects contiguous uint8 [B,] rows x cols frames on the device")
+        B = 1 if img.dim() == 2 else img.shape[0]
+        rows, cols = img.shape[-2:]
+        out = torch.empty((B, self.rows, self.cols), dtype=torch.uint8, device=img.device)
+        mx, my = self.maps[eye]
+        st = torch.cuda.current_stream(img.device).cuda_stream if stream is None else stream.cuda_stream
+        _check(lib().plp_remap_linear_device(self._mt._h, img.data_ptr(), rows, cols, cols, rows * cols, mx.data_ptr(), my.data_ptr(), self.cols * 4,
+                                             self.rows, self.cols, B, out.data_ptr(), self.cols, self.rows * self.cols, st))
+        return out[0] if img.dim() == 2 else out
+
+    def rectify(self, in_img_l, in_img_r, stream=None):
+        """returns (out_img_l, out_img_r)"""
+        return self._remap(in_img_l, "left", stream), self._remap(in_img_r, "right", stream)

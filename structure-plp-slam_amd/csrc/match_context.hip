@@ -414,6 +414,53 @@ plp_status plp_convert_to_true_depth_device(plp_matcher* c, const void* d_src, i
     return PLP_OK;
 }
 
+plp_status plp_rectify_map_device(plp_matcher* c, const double* K, const double* D, int32_t n_dist, const double* R, const plp_camera* rect_cam,
+                                  int32_t rows, int32_t cols, float* d_map_x, float* d_map_y, size_t map_step, void* hip_stream) {
+    if (!c || !K || !R || !rect_cam || !d_map_x || !d_map_y || (n_dist > 0 && !D)) return set_error(PLP_ERR_INVALID_ARG, "NULL argument");
+    if (rows <= 0 || cols <= 0 || map_step < (size_t)cols * 4 || (map_step & 3)) return set_error(PLP_ERR_INVALID_ARG, "bad geometry");
+    if (n_dist != 0 && n_dist != 4 && n_dist != 5 && n_dist != 8 && n_dist != 12)
+        return set_error(PLP_ERR_INVALID_ARG, "distortion vector must have 0, 4, 5, 8 or 12 entries");
+    RectifyArgs A{};
+    // iR = (K_rect * R)^-1, K_rect float-rounded; closed-form 3x3 inverse in the order cv::Matx evaluates it
+    const double Ar[9] = {(double)(float)rect_cam->fx, 0, (double)(float)rect_cam->cx, 0, (double)(float)rect_cam->fy, (double)(float)rect_cam->cy, 0, 0, 1};
+    double m[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double s = 0;
+            for (int k = 0; k < 3; ++k) s += Ar[i * 3 + k] * R[k * 3 + j];
+            m[i * 3 + j] = s;
+        }
+    double det = m[0] * (m[4] * m[8] - m[7] * m[5]) - m[1] * (m[3] * m[8] - m[6] * m[5]) + m[2] * (m[3] * m[7] - m[6] * m[4]);
+    if (det == 0) return set_error(PLP_ERR_INVALID_ARG, "K_rect * R is singular");
+    det = 1 / det;
+    A.ir[0] = (m[4] * m[8] - m[5] * m[7]) * det; A.ir[1] = (m[2] * m[7] - m[1] * m[8]) * det; A.ir[2] = (m[1] * m[5] - m[2] * m[4]) * det;
+    A.ir[3] = (m[5] * m[6] - m[3] * m[8]) * det; A.ir[4] = (m[0] * m[8] - m[2] * m[6]) * det; A.ir[5] = (m[2] * m[3] - m[0] * m[5]) * det;
+    A.ir[6] = (m[3] * m[7] - m[4] * m[6]) * det; A.ir[7] = (m[1] * m[6] - m[0] * m[7]) * det; A.ir[8] = (m[0] * m[4] - m[1] * m[3]) * det;
+    for (int i = 0; i < n_dist; ++i) A.d[i] = D[i];
+    A.fx = K[0]; A.fy = K[4]; A.u0 = K[2]; A.v0 = K[5];
+    A.rows = rows; A.cols = cols; A.map_x = d_map_x; A.map_y = d_map_y; A.map_step = map_step;
+    std::lock_guard<std::mutex> lk(c->mu);
+    PLP_HIP(hipSetDevice(c->device));
+    launch_rectify_map((hipStream_t)hip_stream, A);
+    PLP_HIP(hipGetLastError());
+    return PLP_OK;
+}
+
+plp_status plp_remap_linear_device(plp_matcher* c, const uint8_t* d_src, int32_t rows, int32_t cols, size_t src_step, size_t src_frame_stride,
+                                   const float* d_map_x, const float* d_map_y, size_t map_step, int32_t dst_rows, int32_t dst_cols, int32_t B,
+                                   uint8_t* d_dst, size_t dst_step, size_t dst_frame_stride, void* hip_stream) {
+    if (!c || !d_src || !d_map_x || !d_map_y || !d_dst) return set_error(PLP_ERR_INVALID_ARG, "NULL argument");
+    if (rows <= 0 || cols <= 0 || dst_rows <= 0 || dst_cols <= 0 || B <= 0 || rows > 32767 || cols > 32767 || src_step < (size_t)cols ||
+        dst_step < (size_t)dst_cols || map_step < (size_t)dst_cols * 4 || (map_step & 3))
+        return set_error(PLP_ERR_INVALID_ARG, "bad geometry");
+    std::lock_guard<std::mutex> lk(c->mu);
+    PLP_HIP(hipSetDevice(c->device));
+    launch_remap_linear((hipStream_t)hip_stream, d_src, rows, cols, src_step, src_frame_stride, d_map_x, d_map_y, map_step, dst_rows, dst_cols, B, d_dst,
+                        dst_step, dst_frame_stride);
+    PLP_HIP(hipGetLastError());
+    return PLP_OK;
+}
+
 plp_status plp_color_vote_device(plp_matcher* c, const uint8_t* d_mask, int32_t rows, int32_t cols, size_t mask_step,
                                  size_t mask_frame_stride, const plp_keypoint* d_undist, const uint8_t* d_valid, const int32_t* d_counts,
                                  int32_t cap, int32_t B, int32_t check_3x3_window, int32_t* d_labels, void* hip_stream) {

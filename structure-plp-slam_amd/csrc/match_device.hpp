@@ -98,5 +98,15 @@ void launch_to_depth(hipStream_t st, const void* src, int is_u16, int rows, int 
 void launch_color_vote(hipStream_t st, const uint8_t* mask, int rows, int cols, size_t step, size_t fs, const plp_keypoint* undist, const uint8_t* valid,
                        const int32_t* counts, int cap, int B, int check3, int32_t* labels);
 void launch_landmark_descriptor(hipStream_t st, const uint8_t* descs, const int32_t* offsets, int L, int32_t* best_idx);
+struct RectifyArgs {
+    double ir[9];                     // (K_rect * R)^-1
+    double d[12];                     // k1 k2 p1 p2 k3 k4 k5 k6 s1 s2 s3 s4
+    double fx, fy, u0, v0;            // the unrectified camera
+    int rows, cols;
+    float* map_x; float* map_y; size_t map_step;
+};
+void launch_rectify_map(hipStream_t st, const RectifyArgs& A);
+void launch_remap_linear(hipStream_t st, const uint8_t* src, int rows, int cols, size_t step, size_t fs, const float* map_x, const float* map_y,
+                         size_t map_step, int drows, int dcols, int B, uint8_t* dst, size_t dst_step, size_t dst_fs);
 
 }  // namespace plp

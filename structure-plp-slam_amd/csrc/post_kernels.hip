@@ -222,6 +222,75 @@ void launch_color_vote(hipStream_t st, const uint8_t* mask, int rows, int cols, 
     hipLaunchKernelGGL(k_color_vote, dim3((cap + 255) / 256, B), dim3(256), 0, st, mask, rows, cols, step, fs, undist, valid, counts, cap, check3, labels);
 }
 
+// ------------------------------------------------------------------------------------------
+// util::stereo_rectifier (util/stereo_rectifier.cc:61-62, 83-84).
+// k_rectify_map: cv::initUndistortRectifyMap(CV_32F) -- a row is one dependent chain (_x += ir[0] ...), so one thread
+// walks one row; this runs once per camera.  grid = ceil(rows / 64), block = 64.
+// k_remap_linear: cv::remap(INTER_LINEAR, BORDER_CONSTANT 0) on 8UC1, 4 destination pixels per thread, the map pair shared
+// by the B frames of a launch.  grid = (ceil(dcols / 1024), drows, B), block = 256.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_rectify_map(RectifyArgs A) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= A.rows) return;
+    const double* ir = A.ir;
+    const double* d = A.d;
+    double _x = i * ir[1] + ir[2], _y = i * ir[4] + ir[5], _w = i * ir[7] + ir[8];
+    float* mx = reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(A.map_x) + (size_t)i * A.map_step);
+    float* my = reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(A.map_y) + (size_t)i * A.map_step);
+    for (int j = 0; j < A.cols; ++j, _x += ir[0], _y += ir[3], _w += ir[6]) {
+        const double w = 1. / _w, x = _x * w, y = _y * w;
+        const double x2 = x * x, y2 = y * y;
+        const double r2 = x2 + y2, _2xy = 2 * x * y;
+        const double kr = (1 + ((d[4] * r2 + d[1]) * r2 + d[0]) * r2) / (1 + ((d[7] * r2 + d[6]) * r2 + d[5]) * r2);
+        const double xd = (x * kr + d[2] * _2xy + d[3] * (r2 + 2 * x2) + d[8] * r2 + d[9] * r2 * r2);
+        const double yd = (y * kr + d[2] * (r2 + 2 * y2) + d[3] * _2xy + d[10] * r2 + d[11] * r2 * r2);
+        mx[j] = (float)(A.fx * xd + A.u0);
+        my[j] = (float)(A.fy * yd + A.v0);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_remap_linear(const uint8_t* __restrict__ src, int rows, int cols, size_t step, size_t fs,
+                                                      const float* __restrict__ map_x, const float* __restrict__ map_y, size_t map_step, int dcols,
+                                                      uint8_t* __restrict__ dst, size_t dst_step, size_t dst_fs) {
+    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y, b = blockIdx.z;
+    if (x0 >= dcols) return;
+    const uint8_t* S = src + (size_t)b * fs;
+    const float* mx = reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(map_x) + (size_t)y * map_step) + x0;
+    const float* my = reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(map_y) + (size_t)y * map_step) + x0;
+    uint8_t* d = dst + (size_t)b * dst_fs + (size_t)y * dst_step + x0;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (x0 + i >= dcols) break;
+        const int fsx = __float2int_rn(__fmul_rn(mx[i], 32.f)), fsy = __float2int_rn(__fmul_rn(my[i], 32.f));
+        const int ax = fsx & 31, ay = fsy & 31;
+        int sx = fsx >> 5, sy = fsy >> 5;
+        sx = sx > 32767 ? 32767 : (sx < -32768 ? -32768 : sx);
+        sy = sy > 32767 ? 32767 : (sy < -32768 ? -32768 : sy);
+        // 15-bit weights 32 (32 - ax)(32 - ay) ...; cv's table stores 1.0 as 32767 + 1 on the opposite tap, same result
+        const int w0 = 32 * (32 - ax) * (32 - ay), w1 = 32 * ax * (32 - ay), w2 = 32 * (32 - ax) * ay, w3 = 32 * ax * ay;
+        const bool xin0 = sx >= 0 && sx < cols, xin1 = sx + 1 >= 0 && sx + 1 < cols, yin0 = sy >= 0 && sy < rows, yin1 = sy + 1 >= 0 && sy + 1 < rows;
+        const uint8_t* r0 = S + (size_t)(yin0 ? sy : 0) * step;
+        const uint8_t* r1 = S + (size_t)(yin1 ? sy + 1 : 0) * step;
+        const int v0 = (xin0 && yin0) ? r0[sx] : 0, v1 = (xin1 && yin0) ? r0[sx + 1] : 0;
+        const int v2 = (xin0 && yin1) ? r1[sx] : 0, v3 = (xin1 && yin1) ? r1[sx + 1] : 0;
+        const int r = (v0 * w0 + v1 * w1 + v2 * w2 + v3 * w3 + (1 << 14)) >> 15;
+        packed |= (uint32_t)(r > 255 ? 255 : r) << (8 * i);
+    }
+    if (x0 + 3 < dcols && (((uintptr_t)d) & 3) == 0) *reinterpret_cast<uint32_t*>(d) = packed;
+    else
+        for (int i = 0; i < 4 && x0 + i < dcols; ++i) d[i] = (uint8_t)(packed >> (8 * i));
+}
+
+void launch_rectify_map(hipStream_t st, const RectifyArgs& A) {
+    hipLaunchKernelGGL(k_rectify_map, dim3((A.rows + 63) / 64), dim3(64), 0, st, A);
+}
+void launch_remap_linear(hipStream_t st, const uint8_t* src, int rows, int cols, size_t step, size_t fs, const float* map_x, const float* map_y,
+                         size_t map_step, int drows, int dcols, int B, uint8_t* dst, size_t dst_step, size_t dst_fs) {
+    hipLaunchKernelGGL(k_remap_linear, dim3((dcols + 1023) / 1024, drows, B), dim3(256), 0, st, src, rows, cols, step, fs, map_x, map_y, map_step, dcols,
+                       dst, dst_step, dst_fs);
+}
+
 void launch_post_extract(hipStream_t st, const PostArgs& A, int B) {
     const int n = A.cap > A.kl_cap ? A.cap : A.kl_cap;
     hipLaunchKernelGGL(k_post_extract, dim3((n + 255) / 256, B), dim3(256), 0, st, A);

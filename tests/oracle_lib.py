@@ -492,3 +492,35 @@ def post_extract(cam10, kps, depth=None, keylines=None, kl_depths=None, kl_x_rig
 def landmark_descriptor(descs):
     d = _c(descs, np.uint8).reshape(-1, 32)
     return _call("oracle_landmark_descriptor", [d, len(d)], C.c_int)
+
+
+# EuRoC MAV stereo calibration as quoted by the reference's example/euroc/EuRoC_stereo.yaml
+EUROC = {
+    "camera": dict(fx=435.2046959714599, fy=435.2046959714599, cx=367.4517211914062, cy=252.2008514404297, cols=752, rows=480),
+    "StereoRectifier.K_left": [458.654, 0.0, 367.215, 0.0, 457.296, 248.375, 0.0, 0.0, 1.0],
+    "StereoRectifier.D_left": [-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05, 0.0],
+    "StereoRectifier.R_left": [0.999966347530033, -0.001422739138722922, 0.008079580483432283, 0.001365741834644127, 0.9999741760894847,
+                               0.007055629199258132, -0.008089410156878961, -0.007044357138835809, 0.9999424675829176],
+    "StereoRectifier.K_right": [457.587, 0.0, 379.999, 0.0, 456.134, 255.238, 0.0, 0.0, 1],
+    "StereoRectifier.D_right": [-0.28368365, 0.07451284, -0.00010473, -3.555907e-05, 0.0],
+    "StereoRectifier.R_right": [0.9999633526194376, -0.003625811871560086, 0.007755443660172947, 0.003680398547259526, 0.9999684752771629,
+                                -0.007035845251224894, -0.007729688520722713, 0.007064130529506649, 0.999945173484644],
+}
+
+
+def rectify_map(K, D, R, cam, rows, cols):
+    """cv::initUndistortRectifyMap(K, D, R, K_rect(float), (cols, rows), CV_32F) -> map_x, map_y"""
+    K = _c(K, np.float64); D = _c(D, np.float64); R = _c(R, np.float64)
+    Kr = np.array([cam["fx"], 0, cam["cx"], 0, cam["fy"], cam["cy"], 0, 0, 1], np.float64)
+    mx = np.zeros((rows, cols), np.float32); my = np.zeros((rows, cols), np.float32)
+    rc = _call("oracle_init_undistort_rectify_map", [K, D if D.size else np.zeros(1), int(D.size), R, Kr, rows, cols, mx, my], C.c_int)
+    if rc != 0:
+        raise ValueError("K_rect * R is singular")
+    return mx, my
+
+
+def remap_linear(src, map_x, map_y):
+    src = _c(src, np.uint8); map_x = _c(map_x, np.float32); map_y = _c(map_y, np.float32)
+    dst = np.zeros(map_x.shape, np.uint8)
+    _call("oracle_remap_linear", [src, src.shape[0], src.shape[1], ("z", src.shape[1]), map_x, map_y, map_x.shape[0], map_x.shape[1], dst])
+    return dst

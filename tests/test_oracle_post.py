@@ -1,6 +1,7 @@
 """Oracle of the post-extract step (oracle/post_oracle.cpp): properties that hold for any correct cv::undistortPoints /
 bearing / depth-lookup restatement.  (The reference has no test for this step: parity unpinned, see the file header.)"""
 import numpy as np
+import pytest
 
 import oracle_lib as O
 
@@ -97,3 +98,48 @@ def test_landmark_descriptor_and_colour_vote_small_cases():
     # (1,1): neighbours in row 0 / column 0 are never looked at, the others are its own colour; (3,4) and (2,2) touch the odd pixel (2,3);
     # (4,1): its lower neighbours (5, .) are background
     assert lab.tolist() == [h, 0, 0, 0, 0]
+
+
+def test_rectify_map_and_remap_known_cases():
+    rng = np.random.default_rng(8)
+    img = rng.integers(0, 256, (48, 64), dtype=np.uint8)
+    yy, xx = np.mgrid[0:48, 0:64].astype(np.float32)
+    # identity and whole-pixel shifts copy pixels; what falls outside is the constant border 0
+    assert np.array_equal(O.remap_linear(img, xx, yy), img)
+    sh = O.remap_linear(img, xx + 3, yy - 2)
+    assert np.array_equal(sh[2:, :61], img[:46, 3:]) and not sh[:2].any() and not sh[:, 61:].any()
+    # half-pixel: exact bilinear mean, rounded half up by (sum + 2^14) >> 15
+    hp = O.remap_linear(img, xx + 0.5, yy)
+    a, b = img[:, :-1].astype(np.int32), img[:, 1:].astype(np.int32)
+    assert np.array_equal(hp[:, :-1], ((a + b + 1) >> 1).astype(np.uint8))
+    assert np.array_equal(hp[:, -1], ((img[:, -1].astype(np.int32) + 1) >> 1).astype(np.uint8))     # right neighbour is the border
+    # the 1/32 grid: 0.49 px rounds to 16/32, closed-form weights 32 (32 - ax)(32 - ay) reproduce the table path
+    mx = (xx + rng.uniform(-1.5, 1.5, xx.shape)).astype(np.float32); my = (yy + rng.uniform(-1.5, 1.5, yy.shape)).astype(np.float32)
+    got = O.remap_linear(img, mx, my)
+    fx = np.rint(mx.astype(np.float64) * 32).astype(np.int64); fy = np.rint(my.astype(np.float64) * 32).astype(np.int64)
+    sx, sy, ax, ay = fx >> 5, fy >> 5, fx & 31, fy & 31
+    pad = np.zeros((48 + 8, 64 + 8), np.int64); pad[4:52, 4:68] = img
+    g = lambda dy, dx: pad[np.clip(sy + dy + 4, 0, 55), np.clip(sx + dx + 4, 0, 71)]
+    want = (g(0, 0) * 32 * (32 - ax) * (32 - ay) + g(0, 1) * 32 * ax * (32 - ay) + g(1, 0) * 32 * (32 - ax) * ay + g(1, 1) * 32 * ax * ay + (1 << 14)) >> 15
+    assert np.array_equal(got, want.astype(np.uint8))
+    # no distortion, R = I, K = float(K_rect): the map is the pixel grid
+    cam = dict(fx=435.25, fy=435.25, cx=367.5, cy=252.25)
+    K = [435.25, 0, 367.5, 0, 435.25, 252.25, 0, 0, 1]
+    mx, my = O.rectify_map(K, [], np.eye(3).ravel(), cam, 40, 60)
+    gy, gx = np.mgrid[0:40, 0:60]
+    assert np.abs(mx - gx).max() < 1e-3 and np.abs(my - gy).max() < 1e-3
+    # EuRoC: the rectified principal point looks along R^T e_z, and the distortion model is applied (forward check of one pixel)
+    E = O.EUROC
+    mx, my = O.rectify_map(E["StereoRectifier.K_left"], E["StereoRectifier.D_left"], E["StereoRectifier.R_left"], E["camera"], 480, 752)
+    Kl = np.array(E["StereoRectifier.K_left"]).reshape(3, 3); R = np.array(E["StereoRectifier.R_left"]).reshape(3, 3)
+    k1, k2, p1, p2, k3 = E["StereoRectifier.D_left"]
+    c = E["camera"]
+    for (i, j) in [(0, 0), (479, 751), (252, 367), (100, 600)]:
+        ray = R.T @ np.array([(j - np.float32(c["cx"])) / np.float32(c["fx"]), (i - np.float32(c["cy"])) / np.float32(c["fy"]), 1.0])
+        x, y = ray[0] / ray[2], ray[1] / ray[2]
+        r2 = x * x + y * y
+        kr = 1 + k1 * r2 + k2 * r2 * r2 + k3 * r2 ** 3
+        xd = x * kr + 2 * p1 * x * y + p2 * (r2 + 2 * x * x); yd = y * kr + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+        assert abs(mx[i, j] - (Kl[0, 0] * xd + Kl[0, 2])) < 2e-3 and abs(my[i, j] - (Kl[1, 1] * yd + Kl[1, 2])) < 2e-3
+    with pytest.raises(ValueError):
+        O.rectify_map(K, [], np.zeros(9), cam, 4, 4)
