@@ -417,6 +417,43 @@ plp_status plp_color_vote_device(plp_matcher* ctx, const uint8_t* d_mask, int32_
                                  size_t mask_frame_stride, const plp_keypoint* d_undist, const uint8_t* d_valid, const int32_t* d_counts,
                                  int32_t cap, int32_t B, int32_t check_3x3_window, int32_t* d_labels, void* hip_stream);
 
+/* Bag-of-words transform: data::frame::compute_bow / data::keyframe::compute_bow
+ * (src/PLPSLAM/data/frame.cc:785-795) = bow_vocab_->transform(to_desc_vec(descriptors_), bow_vec_, bow_feat_vec_, 4) of
+ * DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB> (data/bow_vocabulary.h:22; the USE_DBOW2 build).  DBoW2 and the
+ * vocabulary file are not part of the reference tree, so the tree is handed over flat (the host walks m_nodes once after
+ * loadFromBinaryFile): node 0 is the root, children of node i are children[child_offset[i] .. child_offset[i+1]) in
+ * the order of Node::children (ties go to the first), leaves carry word_id and weight.
+ *   accumulate: 1 for TF / TF_IDF weighting (a word's weight is added once per feature), 0 for IDF / BINARY;
+ *   norm: what ScoringObject::mustNormalize asks for: 0 none (DOT_PRODUCT), 1 L1 (L1_NORM, CHI_SQUARE, KL, BHATTACHARYYA), 2 L2.
+ * Outputs per frame b (arrays [B][cap]):
+ *   word_id / node_id  per feature (may be NULL): the word, and the node at level L - levelsup that FeatureVector files
+ *                      the feature under; 0xFFFFFFFF for a stopped word (weight <= 0), which enters neither map.  node_id
+ *                      is what PLP_MATCH_MODE_BOW takes as q_group / t_group.
+ *   bow_word / bow_value / n_bow   the BowVector (std::map<WordId, WordValue>) in key order, normalised;
+ *   fv_node / fv_feat / n_fv       the FeatureVector (std::map<NodeId, std::vector<unsigned>>) flattened in key order,
+ *                                  the features of a node in increasing index.
+ * Limits: cap <= 4096.  One transform in flight per vocabulary handle.  Device pointers, asynchronous. */
+typedef struct plp_bow_vocab plp_bow_vocab;
+typedef struct plp_bow_tree {
+    int32_t n_nodes;               /* >= 2 */
+    int32_t L;                     /* depth levels (m_L), 6 for the ORB vocabulary */
+    const int32_t* child_offset;   /* n_nodes + 1 */
+    const int32_t* children;       /* n_nodes - 1 */
+    const uint8_t* node_desc;      /* n_nodes x 32 (row 0, the root, is not read) */
+    const double* node_weight;     /* n_nodes (read at leaves) */
+    const uint32_t* node_word;     /* n_nodes (read at leaves) */
+    int32_t accumulate;
+    int32_t norm;
+} plp_bow_tree;
+plp_status plp_bow_vocab_create(int device, const plp_bow_tree* tree, plp_bow_vocab** out);   /* host pointers, copied */
+void plp_bow_vocab_destroy(plp_bow_vocab* vocab);
+plp_status plp_bow_transform_device(plp_bow_vocab* vocab, const uint8_t* d_desc, const int32_t* d_counts, int32_t cap, int32_t B, int32_t levelsup,
+                                    uint32_t* d_word_id, uint32_t* d_node_id, uint32_t* d_bow_word, double* d_bow_value, int32_t* d_n_bow,
+                                    uint32_t* d_fv_node, uint32_t* d_fv_feat, int32_t* d_n_fv, void* hip_stream);
+/* One frame, host pointers, synchronous; the output arrays hold n entries. */
+plp_status plp_bow_transform_host(plp_bow_vocab* vocab, const uint8_t* desc, int32_t n, int32_t levelsup, uint32_t* word_id, uint32_t* node_id,
+                                  uint32_t* bow_word, double* bow_value, int32_t* n_bow, uint32_t* fv_node, uint32_t* fv_feat, int32_t* n_fv);
+
 /* landmark::compute_descriptor (src/PLPSLAM/data/landmark.cc:181-245) and Line::compute_descriptor
  * (data/landmark_line.cc:256-320), the search part, for L landmarks at once: landmark l owns the
  * descriptors descs[offsets[l] .. offsets[l+1]) (32 B rows, observation order); best_idx[l] = the row (relative to

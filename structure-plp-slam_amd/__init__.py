@@ -88,6 +88,10 @@ _API = [
     ("plp_convert_to_true_depth_device", C.c_int, [_VP, _VP, _I32, _I32, _I32, C.c_size_t, C.c_size_t, C.c_double, _I32, _VP, C.c_size_t, C.c_size_t, _VP]),
     ("plp_rectify_map_device", C.c_int, [_VP, _VP, _VP, _I32, _VP, _VP, _I32, _I32, _VP, _VP, C.c_size_t, _VP]),
     ("plp_remap_linear_device", C.c_int, [_VP, _VP, _I32, _I32, C.c_size_t, C.c_size_t, _VP, _VP, C.c_size_t, _I32, _I32, _I32, _VP, C.c_size_t, C.c_size_t, _VP]),
+    ("plp_bow_vocab_create", C.c_int, [C.c_int, _VP, _VP]),
+    ("plp_bow_vocab_destroy", None, [_VP]),
+    ("plp_bow_transform_device", C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    ("plp_bow_transform_host", C.c_int, [_VP, _VP, _I32, _I32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     ("plp_color_vote_device", C.c_int, [_VP, _VP, _I32, _I32, C.c_size_t, C.c_size_t, _VP, _VP, _VP, _I32, _I32, _I32, _VP, _VP]),
     ("plp_landmark_descriptor_device", C.c_int, [_VP, _VP, _VP, _I32, _VP, _VP]),
     ("plp_landmark_descriptor_host", C.c_int, [_VP, _VP, _VP, _I32, _VP]),
@@ -582,3 +586,97 @@ class stereo_rectifier:
     def rectify(self, in_img_l, in_img_r, stream=None):
         """returns (out_img_l, out_img_r)"""
         return self._remap(in_img_l, "left", stream), self._remap(in_img_r, "right", stream)
+
+
+# ------------------------------------------------------------------------------------------------
+# data::bow_vocabulary (DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>) -- the transform of compute_bow
+# ------------------------------------------------------------------------------------------------
+class bow_tree_c(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("L", C.c_int32), ("child_offset", _VP), ("children", _VP), ("node_desc", _VP), ("node_weight", _VP),
+                ("node_word", _VP), ("accumulate", C.c_int32), ("norm", C.c_int32)]
+
+
+# DBoW2 enums (BowVector.h): WeightingType and ScoringType
+TF_IDF, TF, IDF, BINARY = 0, 1, 2, 3
+L1_NORM, L2_NORM, CHI_SQUARE, KL, BHATTACHARYYA, DOT_PRODUCT = 0, 1, 2, 3, 4, 5
+
+
+class bow_vocabulary:
+    """Mirror of data::bow_vocabulary for the one call the front-end makes: transform(descriptors, bow_vec, bow_feat_vec,
+    levelsup) (data/frame.cc:785-795).  Built from the node list in m_nodes order: parents[i] (node 0 = root, -1), is_leaf,
+    descriptors, weights -- the id rules of DBoW2's loaders (node ids in file order, children appended in file order, word
+    ids handed to leaves in file order)."""
+
+    def __init__(self, L, parents, is_leaf, descs, weights, weighting=TF_IDF, scoring=L1_NORM, device=0):
+        parents = np.asarray(parents, np.int64); is_leaf = np.asarray(is_leaf, bool)
+        n = len(parents)
+        descs = np.ascontiguousarray(descs, np.uint8).reshape(n, 32); weights = np.ascontiguousarray(weights, np.float64)
+        if n < 2 or parents[0] != -1 or (parents[1:] < 0).any() or (parents[1:] >= np.arange(1, n)).any():
+            raise PlpError(1, "node 0 must be the root and every node must follow its parent")
+        order = np.argsort(parents[1:], kind="stable") + 1           # children grouped by parent, file order inside a group
+        counts = np.bincount(parents[1:], minlength=n)
+        if (counts[is_leaf] != 0).any() or (counts[~is_leaf] == 0).any():
+            raise PlpError(1, "is_leaf does not agree with the child lists")
+        self.child_offset = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+        self.children = order.astype(np.int32)
+        self.node_word = np.zeros(n, np.uint32)
+        self.node_word[is_leaf] = np.arange(int(is_leaf.sum()), dtype=np.uint32)
+        self.node_desc, self.node_weight, self.L = descs, weights, int(L)
+        self.accumulate = 1 if weighting in (TF_IDF, TF) else 0
+        self.norm = {L1_NORM: 1, L2_NORM: 2, CHI_SQUARE: 1, KL: 1, BHATTACHARYYA: 1, DOT_PRODUCT: 0}[scoring]
+        t = bow_tree_c(n, self.L, _p(self.child_offset), _p(self.children), _p(self.node_desc), _p(self.node_weight), _p(self.node_word),
+                       self.accumulate, self.norm)
+        h = C.c_void_p()
+        _check(lib().plp_bow_vocab_create(device, C.byref(t), C.byref(h)))
+        self._h = h
+        self.device = device
+
+    @classmethod
+    def from_text_file(cls, path, device=0):
+        """ORB-SLAM2-style ORBvoc.txt: 'k L scoring weighting', then one line per node 'parent is_leaf d0 .. d31 weight'"""
+        with open(path) as f:
+            k, L, scoring, weighting = (int(v) for v in f.readline().split())
+            rows = [ln.split() for ln in f if ln.strip()]
+        parents = [-1] + [int(r[0]) for r in rows]
+        leaf = [False] + [int(r[1]) > 0 for r in rows]
+        descs = np.zeros((len(rows) + 1, 32), np.uint8)
+        descs[1:] = np.array([[int(v) for v in r[2:34]] for r in rows], np.uint8)
+        weights = [0.0] + [float(r[34]) for r in rows]
+        return cls(L, parents, leaf, descs, weights, weighting, scoring, device)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib().plp_bow_vocab_destroy(h)
+            self._h = None
+
+    def transform_device(self, desc, counts=None, levelsup=4, stream=None):
+        """desc: uint8 [B, cap, 32] on the device.  Returns a dict of device tensors:
+        word_id, node_id [B, cap]; bow_word, bow_value, n_bow; fv_node, fv_feat, n_fv."""
+        import torch
+        B, cap = desc.shape[0], desc.shape[1]
+        dev = desc.device
+        o = dict(word_id=torch.empty((B, cap), dtype=torch.int32, device=dev), node_id=torch.empty((B, cap), dtype=torch.int32, device=dev),
+                 bow_word=torch.empty((B, cap), dtype=torch.int32, device=dev), bow_value=torch.empty((B, cap), dtype=torch.float64, device=dev),
+                 n_bow=torch.empty(B, dtype=torch.int32, device=dev), fv_node=torch.empty((B, cap), dtype=torch.int32, device=dev),
+                 fv_feat=torch.empty((B, cap), dtype=torch.int32, device=dev), n_fv=torch.empty(B, dtype=torch.int32, device=dev))
+        st = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream.cuda_stream
+        _check(lib().plp_bow_transform_device(self._h, desc.data_ptr(), counts.data_ptr() if counts is not None else None, cap, B, levelsup,
+                                              o["word_id"].data_ptr(), o["node_id"].data_ptr(), o["bow_word"].data_ptr(), o["bow_value"].data_ptr(),
+                                              o["n_bow"].data_ptr(), o["fv_node"].data_ptr(), o["fv_feat"].data_ptr(), o["n_fv"].data_ptr(), st))
+        return o
+
+    def transform(self, desc, levelsup=4):
+        """one frame, numpy in / out: (bow_vec {word: value}, bow_feat_vec {node: [features]}, word_id, node_id)"""
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        n = len(desc)
+        word = np.zeros(max(n, 1), np.uint32); node = np.zeros(max(n, 1), np.uint32)
+        bw = np.zeros(max(n, 1), np.uint32); bv = np.zeros(max(n, 1), np.float64); fn = np.zeros(max(n, 1), np.uint32); ff = np.zeros(max(n, 1), np.uint32)
+        nb, nf = C.c_int32(), C.c_int32()
+        _check(lib().plp_bow_transform_host(self._h, _p(desc) if n else None, n, levelsup, _p(word), _p(node), _p(bw), _p(bv), C.byref(nb), _p(fn), _p(ff),
+                                            C.byref(nf)))
+        bow_vec = dict(zip(bw[:nb.value].tolist(), bv[:nb.value].tolist()))
+        feat_vec = {}
+        for nd, fi in zip(fn[:nf.value].tolist(), ff[:nf.value].tolist()):
+            feat_vec.setdefault(nd, []).append(fi)
+        return bow_vec, feat_vec, word[:n].copy(), node[:n].copy()

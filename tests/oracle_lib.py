@@ -524,3 +524,42 @@ def remap_linear(src, map_x, map_y):
     dst = np.zeros(map_x.shape, np.uint8)
     _call("oracle_remap_linear", [src, src.shape[0], src.shape[1], ("z", src.shape[1]), map_x, map_y, map_x.shape[0], map_x.shape[1], dst])
     return dst
+
+
+def random_vocab(rng, k, L, p_leaf=0.08, p_dup=0.1, p_stop=0.05, k_jitter=0):
+    """A DBoW2-shaped tree in m_nodes order (the k children of a node are created together, then each is expanded):
+    returns parents, is_leaf, descs, weights.  Some leaves sit above level L, some siblings share a descriptor (ties),
+    some words have weight 0 (stopped)."""
+    parents, level = [-1], [0]
+    todo = [0]
+    while todo:
+        p = todo.pop()
+        if level[p] == L or (p != 0 and rng.uniform() < p_leaf):
+            continue
+        kk = max(1, k + int(rng.integers(-k_jitter, k_jitter + 1)))
+        first = len(parents)
+        parents += [p] * kk; level += [level[p] + 1] * kk
+        todo += list(range(first + kk - 1, first - 1, -1))
+    n = len(parents)
+    parents = np.array(parents)
+    is_leaf = np.bincount(parents[1:], minlength=n) == 0
+    descs = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    for i in range(2, n):
+        if parents[i] == parents[i - 1] and rng.uniform() < p_dup:
+            descs[i] = descs[i - 1]
+    weights = np.where(is_leaf, rng.uniform(0.1, 12.0, n), 0.0)
+    weights[is_leaf & (rng.uniform(size=n) < p_stop)] = 0.0
+    return parents, is_leaf, descs, weights
+
+
+def bow_transform(child_offset, children, node_desc, node_weight, node_word, L, desc, levelsup, accumulate, norm):
+    """DBoW2 transform(features, BowVector, FeatureVector, levelsup) on the flat tree -> (word_id, node_id, bow_word, bow_value, fv_node, fv_feat)"""
+    desc = _c(desc, np.uint8).reshape(-1, 32)
+    n = len(desc)
+    word = np.zeros(max(n, 1), np.uint32); node = np.zeros(max(n, 1), np.uint32)
+    bw = np.zeros(max(n, 1), np.uint32); bv = np.zeros(max(n, 1), np.float64); fn = np.zeros(max(n, 1), np.uint32); ff = np.zeros(max(n, 1), np.uint32)
+    cnt = np.zeros(2, np.int32)
+    _call("oracle_bow_transform", [len(node_weight), int(L), _c(child_offset, np.int32), _c(children, np.int32), _c(node_desc, np.uint8),
+                                   _c(node_weight, np.float64), _c(node_word, np.uint32), desc if n else np.zeros(32, np.uint8), n, int(levelsup),
+                                   int(accumulate), int(norm), word, node, bw, bv, cnt[0:1], fn, ff, cnt[1:2]])
+    return word[:n], node[:n], bw[:cnt[0]], bv[:cnt[0]], fn[:cnt[1]], ff[:cnt[1]]

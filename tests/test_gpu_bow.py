@@ -1,0 +1,110 @@
+"""Bag-of-words transform (DBoW2 transform with levelsup, data/frame.cc:785-795): HIP path vs oracle, bit-exact
+(integer descent, IEEE f64 sums / divisions in the reference's order)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from plp import plp, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def make(rng, k, L, weighting=plp.TF_IDF, scoring=plp.L1_NORM, **kw):
+    parents, is_leaf, descs, weights = O.random_vocab(rng, k, L, **kw)
+    return plp.bow_vocabulary(L, parents, is_leaf, descs, weights, weighting, scoring)
+
+
+def oracle(v, desc, levelsup):
+    return O.bow_transform(v.child_offset, v.children, v.node_desc, v.node_weight, v.node_word, v.L, desc, levelsup, v.accumulate, v.norm)
+
+
+def check_frame(v, desc, levelsup, got, b, n):
+    wid, nid, bw, bv, fn, ff = oracle(v, desc, levelsup)
+    assert np.array_equal(got["word_id"][b][:n].view(np.uint32), wid)
+    assert np.array_equal(got["node_id"][b][:n].view(np.uint32), nid)
+    assert got["n_bow"][b] == len(bw) and got["n_fv"][b] == len(fn)
+    assert np.array_equal(got["bow_word"][b][:len(bw)].view(np.uint32), bw)
+    assert np.array_equal(got["bow_value"][b][:len(bw)], bv), np.abs(got["bow_value"][b][:len(bw)] - bv).max()
+    assert np.array_equal(got["fv_node"][b][:len(fn)].view(np.uint32), fn)
+    assert np.array_equal(got["fv_feat"][b][:len(ff)].view(np.uint32), ff)
+
+
+@pytest.mark.parametrize("k,L,levelsup,weighting,scoring", [
+    (10, 4, 2, plp.TF_IDF, plp.L1_NORM), (10, 3, 4, plp.TF_IDF, plp.L1_NORM), (9, 4, 1, plp.TF, plp.L2_NORM),
+    (4, 6, 4, plp.IDF, plp.DOT_PRODUCT), (23, 3, 1, plp.TF_IDF, plp.DOT_PRODUCT), (2, 9, 3, plp.BINARY, plp.L1_NORM)])
+def test_batched_transform_matches_oracle(k, L, levelsup, weighting, scoring):
+    import torch
+    rng = np.random.default_rng(100 * k + L)
+    v = make(rng, k, L, weighting, scoring, k_jitter=1 if k > 2 else 0)
+    B, cap = 5, 700
+    desc = rng.integers(0, 256, (B, cap, 32), dtype=np.uint8)
+    leaves = np.flatnonzero(np.diff(v.child_offset) == 0)
+    desc[0, :200] = v.node_desc[rng.choice(leaves, 200)]                  # exact words, many repeats of a word in one frame
+    desc[1, :300] = v.node_desc[rng.choice(leaves[:7], 300)]
+    counts = np.array([cap, 650, 0, 1, 333], np.int32)
+    dev = torch.device("cuda", 0)
+    out = v.transform_device(torch.from_numpy(desc).to(dev), torch.from_numpy(counts).to(dev), levelsup)
+    torch.cuda.synchronize()
+    got = {kk: vv.cpu().numpy() for kk, vv in out.items()}
+    for b in range(B):
+        check_frame(v, desc[b][:counts[b]], levelsup, got, b, counts[b])
+
+
+def test_orb_vocabulary_shape_on_extracted_descriptors_and_bow_matcher_groups():
+    """k = 10, L = 6 like the ORB vocabulary (here with early leaves so that it stays small), levelsup = 4 as in compute_bow,
+    on real extractor output; the node ids are what PLP_MATCH_MODE_BOW groups by."""
+    import torch
+    rng = np.random.default_rng(6)
+    v = make(rng, 10, 6, p_leaf=0.55, p_stop=0.02)
+    assert 2000 < len(v.node_weight) < 2_000_000
+    frames = synth.replay(9, 2, 480, 640)
+    ex = plp.orb_extractor(1000)
+    dev = torch.device("cuda", 0)
+    cap = 2064
+    d_kps = torch.empty((2, cap, 28), dtype=torch.uint8, device=dev); d_desc = torch.zeros((2, cap, 32), dtype=torch.uint8, device=dev)
+    d_cnt = torch.zeros(2, dtype=torch.int32, device=dev)
+    ex.extract_batch(torch.from_numpy(frames).to(dev), d_kps, d_desc, d_cnt)
+    torch.cuda.synchronize()
+    out = v.transform_device(d_desc, d_cnt, 4)
+    torch.cuda.synchronize()
+    got = {kk: vv.cpu().numpy() for kk, vv in out.items()}
+    desc, cnt = d_desc.cpu().numpy(), d_cnt.cpu().numpy()
+    for b in range(2):
+        assert cnt[b] > 500
+        check_frame(v, desc[b][:cnt[b]], 4, got, b, cnt[b])
+    # host entry point, one frame
+    bow_vec, feat_vec, wid, nid = v.transform(desc[0][:cnt[0]], 4)
+    w0, n0, bw, bv, fn, ff = oracle(v, desc[0][:cnt[0]], 4)
+    assert np.array_equal(wid, w0) and np.array_equal(nid, n0)
+    assert list(bow_vec.keys()) == bw.tolist() and list(bow_vec.values()) == bv.tolist()
+    assert [(nd, f) for nd, fs in feat_vec.items() for f in fs] == list(zip(fn.tolist(), ff.tolist()))
+    assert v.transform(np.zeros((0, 32), np.uint8))[0] == {}
+
+
+def test_maximum_frame_size_and_errors():
+    import ctypes as C
+    import torch
+    rng = np.random.default_rng(77)
+    v = make(rng, 10, 3)
+    desc = rng.integers(0, 256, (2, 4096, 32), dtype=np.uint8)
+    dev = torch.device("cuda", 0)
+    out = v.transform_device(torch.from_numpy(desc).to(dev), None, 1)
+    torch.cuda.synchronize()
+    got = {kk: vv.cpu().numpy() for kk, vv in out.items()}
+    for b in range(2):
+        check_frame(v, desc[b], 1, got, b, 4096)
+    with pytest.raises(plp.PlpError):
+        v.transform_device(torch.zeros((1, 4097, 32), dtype=torch.uint8, device=dev))
+    # malformed trees are refused at create time: a cycle / unreachable node, a second parent, an empty vocabulary
+    co = np.array([0, 1, 2, 3], np.int32); w = np.zeros(3); word = np.zeros(3, np.uint32); d = np.zeros((3, 32), np.uint8)
+    for children in ([1, 1], [1, 0], [2, 2]):
+        ch = np.array(children, np.int32)
+        t = plp.bow_tree_c(3, 2, plp._p(np.array([0, 1, 2, 2], np.int32)), plp._p(ch), plp._p(d), plp._p(w), plp._p(word), 1, 1)
+        h = C.c_void_p()
+        with pytest.raises(plp.PlpError):
+            plp._check(plp.lib().plp_bow_vocab_create(0, C.byref(t), C.byref(h)))
+    t = plp.bow_tree_c(1, 2, plp._p(co), plp._p(co), plp._p(d), plp._p(w), plp._p(word), 1, 1)
+    with pytest.raises(plp.PlpError):
+        plp._check(plp.lib().plp_bow_vocab_create(0, C.byref(t), C.byref(C.c_void_p())))
+    with pytest.raises(plp.PlpError):
+        plp.bow_vocabulary(2, [-1, 0, 0], [False, True, False], d, w)      # a childless node that is not a leaf
