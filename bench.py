@@ -87,7 +87,11 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if os.environ.get("PLP_BENCH_SHARE_GPU"):      # diagnostic: all ranks on GPU 0 over gloo, to exercise the N > 1 plumbing on a 1-GPU box
+            local_rank = 0
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback exists)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -284,7 +288,7 @@ def main():
                    "sharding": "contiguous frame blocks per rank; RCCL all-gather of the 2-frame feature halo for the matchers"},
         "roofline": roofline,
     }
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:      # the CPU baseline is reported at N = 1 only
         import ctypes as C
         import oracle_lib as O
         cores = os.cpu_count() or 1

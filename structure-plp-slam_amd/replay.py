@@ -26,10 +26,12 @@ def exchange_halo(tensors, halo=2, group=None):
     out = []
     for t in tensors:
         tail = t[-halo:].contiguous()
-        gathered = torch.empty((world * halo,) + tuple(tail.shape[1:]), dtype=tail.dtype, device=tail.device)
-        dist.all_gather_into_tensor(gathered, tail, group=group)     # concatenated along dim 0 (nccl and gloo agree on this form)
+        bounce = tail.is_cuda and dist.get_backend(group) == "gloo"     # gloo gathers host tensors only (diagnostic runs)
+        src = tail.cpu() if bounce else tail
+        gathered = torch.empty((world * halo,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+        dist.all_gather_into_tensor(gathered, src, group=group)     # concatenated along dim 0 (nccl and gloo agree on this form)
         prev = (rank - 1) % world
-        out.append(gathered[prev * halo:(prev + 1) * halo].clone())
+        out.append(gathered[prev * halo:(prev + 1) * halo].to(tail.device, copy=True))
     return out
 
 
