@@ -548,7 +548,10 @@ __global__ __launch_bounds__(256) void k_lsd_grow(LinePlanes P, LsdParams lp, in
     float4* raw = P.raw + (size_t)b * kLineCap;
     int n_lines = 0;
     long long t_grow = 0, t_rect = 0, t_refine = 0, n_seed = 0, n_pix = 0;
-    const long long t_begin = clock64();
+    // phase clocks only for the frame that reports them (every s_memtime is a scalar-memory round trip the wave waits for)
+    const bool prof_on = P.prof != nullptr && b == 0;
+    auto tick = [&]() -> long long { return prof_on ? clock64() : 0ll; };
+    const long long t_begin = tick();
     for (int base = 0; base < nv; base += 64) {
         const bool in_range = base + lane < nv;
         const uint32_t mine = in_range ? order[base + lane] : 0u;
@@ -569,13 +572,13 @@ __global__ __launch_bounds__(256) void k_lsd_grow(LinePlanes P, LsdParams lp, in
             const int seed = bcast_i((int)mine, t);
             if (is_used(g, seed)) continue;   // claimed by a region grown since the ballot
             double reg_angle, cen[3];
-            long long t0 = clock64();
+            long long t0 = tick();
             const float2 seed_cs = make_float2(bcast_f(s_cs.x, t), bcast_f(s_cs.y, t));
             int nreg = region_grow(g, seed, true, bcast_f(s_deg, t), &seed_cs, lp.prec, lp.c_pass, lp.c_fail, reg_angle);
-            t_grow += clock64() - t0; ++n_seed; n_pix += nreg;
+            t_grow += tick() - t0; ++n_seed; n_pix += nreg;
             if (nreg < lp.min_reg_size) continue;
             Rect rec;
-            t0 = clock64();
+            t0 = tick();
             const int ring_cap = g.ring_mask + 1 >= 256 ? 256 : 0;   // the fit from the ring needs the whole 256-word ring as scratch
             if (nreg <= ring_cap) rect_from_ring(g, nreg, reg_angle, lp.prec, rec);
             else {
@@ -583,8 +586,8 @@ __global__ __launch_bounds__(256) void k_lsd_grow(LinePlanes P, LsdParams lp, in
                 centroid_sums(g, nreg, cen);
                 region2rect(g, nreg, reg_angle, lp.prec, cen, rec);
             }
-            t_rect += clock64() - t0;
-            t0 = clock64();
+            t_rect += tick() - t0;
+            t0 = tick();
             bool keep = true;
             if (lp.refine > 0) {
                 double density = rect_density(nreg, rec);
@@ -667,7 +670,7 @@ __global__ __launch_bounds__(256) void k_lsd_grow(LinePlanes P, LsdParams lp, in
                     }
                 }
             }
-            t_refine += clock64() - t0;
+            t_refine += tick() - t0;
             if (!keep) continue;
             // +0.5 offset, undo the sub-sampling, cast to f32 (lsd.cpp flsd)
             rec.x1 += 0.5; rec.y1 += 0.5; rec.x2 += 0.5; rec.y2 += 0.5;
@@ -678,7 +681,7 @@ __global__ __launch_bounds__(256) void k_lsd_grow(LinePlanes P, LsdParams lp, in
         }
     }
     if (lane == 0) P.n_raw[b] = min(n_lines, kLineCap);
-    if (lane == 0 && b == 0 && P.prof) {   // diagnostics of frame 0: cycles per phase
+    if (lane == 0 && prof_on) {   // diagnostics of frame 0: cycles per phase
         P.prof[0] = clock64() - t_begin; P.prof[1] = t_grow; P.prof[2] = t_rect; P.prof[3] = t_refine; P.prof[4] = n_seed; P.prof[5] = n_pix;
     }
 }
