@@ -11,6 +11,7 @@ One "step" = one pass of the hot path over one batch of `--batch` frames that ar
   halo exchange (RCCL all-gather of the two-frame feature tails), then             stream C
   match_current_and_last_frames  (frame b against frame b-1, margin 20, orientation check)
   match_frame_and_landmarks      (frame b against the key points of frames b-1 and b-2 as ~2K local landmarks, margin 10)
+  match_current_and_last_frames_line (frame b's key lines against frame b-1's, margin 20)
 Steps are software-pipelined (stream C matches step n while A/B extract step n+1); every step's work is inside the timed
 region.  Frames shard across ranks in contiguous blocks, the only exchange being that halo (weak scaling: every rank
 owns its own batch); the timed region is bracketed by a barrier + synchronize and the max over ranks is used.  Rank 0
@@ -111,10 +112,12 @@ def main():
     desc2 = [torch.empty((B, cap, 32), dtype=torch.uint8, device=dev) for _ in range(2)]
     cnt2 = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2)]
     d_kps, d_desc, d_cnt = kps2[0], desc2[0], cnt2[0]
-    d_kl = torch.empty((B, lcap, 68), dtype=torch.uint8, device=dev)
-    d_lbd = torch.empty((B, lcap, 32), dtype=torch.uint8, device=dev)
-    d_fn = torch.empty((B, lcap, 3), dtype=torch.float64, device=dev)
-    d_lcnt = torch.zeros(B, dtype=torch.int32, device=dev)
+    kl2 = [torch.zeros((B, lcap, 68), dtype=torch.uint8, device=dev) for _ in range(2)]
+    lbd2 = [torch.zeros((B, lcap, 32), dtype=torch.uint8, device=dev) for _ in range(2)]
+    fn2 = [torch.empty((B, lcap, 3), dtype=torch.float64, device=dev) for _ in range(2)]
+    lcnt2 = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2)]
+    d_kl, d_lbd, d_fn, d_lcnt = kl2[0], lbd2[0], fn2[0], lcnt2[0]
+    m3 = torch.empty((B, lcap), dtype=torch.int32, device=dev); n3 = torch.zeros(B, dtype=torch.int32, device=dev)
     m1 = torch.empty((B, cap), dtype=torch.int32, device=dev); n1 = torch.zeros(B, dtype=torch.int32, device=dev)
     m2 = torch.empty((B, cap), dtype=torch.int32, device=dev); n2 = torch.zeros(B, dtype=torch.int32, device=dev)
     ex = plp.orb_extractor(K, device=local_rank)
@@ -127,6 +130,8 @@ def main():
     lts = [lt] + [plp.LineFeatureTracker(device=local_rank) for _ in range(n_line - 1)]
     mt_last = plp.matcher(0.9, True, device=local_rank)     # motion_based_track: match::projection(0.9, true)
     mt_lm = plp.matcher(0.8, True, device=local_rank)       # search_local_landmarks: match::projection(0.8)
+    mt_line = plp.matcher(0.9, True, device=local_rank)     # motion_based_track, lines: match_current_and_last_frames_line
+    sf_lsd = np.ones(1, np.float32)                         # LineFeatureTracker: one LSD level (line_extractor.cc:34-35)
     grid = plp.make_grid(args.cols, args.rows)
     sf = ex.get_scale_factors()
     cur = torch.cuda.current_stream(dev)
@@ -138,7 +143,7 @@ def main():
 
     replay = importlib.import_module("structure-plp-slam_amd.replay")
 
-    def match_stage(d_kps=d_kps, d_desc=d_desc, d_cnt=d_cnt, st=None):
+    def match_stage(d_kps=d_kps, d_desc=d_desc, d_cnt=d_cnt, st=None, d_kl=d_kl, d_lbd=d_lbd, d_lcnt=d_lcnt, before_lines=None):
         st = st or sA
         kf = d_kps.view(torch.float32).view(B, cap, 7)
         # the two frames preceding this rank's block come from the previous rank (RCCL all-gather of the tails)
@@ -156,6 +161,20 @@ def main():
         q2 = dict(q_reproj=rp2, q_level=torch.cat([p1i[:, :, 5], p2i[:, :, 5]], 1).contiguous(), q_desc=torch.cat([p1d, p2d], 1),
                   q_valid=torch.cat([slot < c1[:, None], slot < c2[:, None]], 1).to(torch.uint8).contiguous())
         mt_lm.match_device(plp.MODE_LANDMARKS, cap, 2 * cap, {**t, **q2}, m2, n2, margin=10.0, scale_factors=sf, grid=grid, B=B, stream=st)
+        if args.orb_only:
+            return
+        if before_lines is not None:
+            before_lines()          # the point matchers only needed the ORB stream; the line matcher waits for the line streams here
+        # key lines of the previous frame, both end points moved by the pan, against this frame's key lines
+        lf = d_kl.view(torch.float32).view(B, lcap, 17)
+        hl, hb, hn = replay.exchange_halo([lf, d_lbd, d_lcnt], halo=2)
+        pl = replay.with_halo(lf, hl)[1:B + 1]
+        pli = pl.view(torch.int32)
+        q3 = dict(q_reproj=(pl[:, :, 7:9] + shift).contiguous(), q_reproj2=(pl[:, :, 9:11] + shift).contiguous(), q_level=pli[:, :, 2].contiguous(),
+                  q_desc=replay.with_halo(d_lbd, hb)[1:B + 1].contiguous(), q_counts=replay.with_halo(d_lcnt, hn)[1:B + 1].contiguous(),
+                  is_rgbd=0, num_levels_lsd=1)
+        mt_line.match_device(plp.MODE_LAST_FRAME_LINE, lcap, lcap, {**dict(t_kl=d_kl, t_desc=d_lbd, t_counts=d_lcnt), **q3}, m3, n3, margin=20.0,
+                             direction=0, scale_factors=sf_lsd, B=B, stream=st)
 
     # One step = ORB (stream A) || LSD+LBD (stream B), then the halo exchange and the two matchers (stream C) on that
     # step's features.  Steps are software-pipelined: stream C works on step n while A and B already extract step n + 1
@@ -176,15 +195,20 @@ def main():
         ready = torch.cuda.Event(); ready.record(sA)
         if not args.orb_only:
             bs = B // n_line
+            line_ready = []
             for i, (lti, sbi) in enumerate(zip(lts, sBs)):
                 sl = slice(i * bs, (i + 1) * bs)
+                if done_match[buf] is not None:
+                    sbi.wait_event(done_match[buf])     # the line matcher of step n - 2 has read this set
                 if "lines" in parts:
-                    lti.extract_batch(d_frames[sl], d_kl[sl], d_lbd[sl], d_fn[sl], d_lcnt[sl], stream=sbi)
+                    lti.extract_batch(d_frames[sl], kl2[buf][sl], lbd2[buf][sl], fn2[buf][sl], lcnt2[buf][sl], stream=sbi)
+                ev = torch.cuda.Event(); ev.record(sbi); line_ready.append(ev)
             if "match" not in parts:
                 return
             sC.wait_event(ready)
             with torch.cuda.stream(sC):
-                match_stage(kps2[buf], desc2[buf], cnt2[buf], sC)
+                match_stage(kps2[buf], desc2[buf], cnt2[buf], sC, kl2[buf], lbd2[buf], lcnt2[buf],
+                            before_lines=lambda: [sC.wait_event(ev) for ev in line_ready])
                 done_match[buf] = torch.cuda.Event(); done_match[buf].record(sC)
 
     def barrier():
@@ -274,16 +298,16 @@ def main():
                 "stage_ms_per_batch": {k: round(v, 4) for k, v in stage_ms.items()},
                 "stage_GBps": {k: round(per_frame[k] * B / (kern[k] * 1e-3) / 1e9, 1) for k in kern}}
 
-    what = "ORB extract only" if args.orb_only else "ORB extract || LSD+LBD extract, then match_current_and_last_frames + match_frame_and_landmarks (~2K landmarks)"
+    what = "ORB extract only" if args.orb_only else "ORB extract || LSD+LBD extract, then match_current_and_last_frames + match_frame_and_landmarks (~2K landmarks) + match_current_and_last_frames_line"
     out = {
         "metric": "frames/sec ORB+LSD extract+match, 640x480 TUM-RGBD, 1/2/4/8 GPU",
         "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": f"TUM-RGBD-shaped replay {args.cols}x{args.rows} (BASELINE configs[1]): {what}; K={K}, 8 levels, 1.2; "
-                               "line matchers / BoW matchers not included",
+                               "+ match_current_and_last_frames_line on the key lines; BoW matchers not included",
                    "frames_per_rank_per_step": B, "keypoints_mean": round(mean_kp, 1), "lines_mean": round(mean_lines, 1),
-                   "matches_mean": [round(float(n1.float().mean().item()), 1), round(float(n2.float().mean().item()), 1)],
+                   "matches_mean": [round(float(n1.float().mean().item()), 1), round(float(n2.float().mean().item()), 1)] + ([] if args.orb_only else [round(float(n3.float().mean().item()), 1)]),
                    "match_rescans_rounds": (match_dbg if not args.orb_only else None),
                    "sharding": "contiguous frame blocks per rank; RCCL all-gather of the 2-frame feature halo for the matchers"},
         "roofline": roofline,

@@ -158,13 +158,20 @@ double oracle_orb_time_frames(const uint8_t* frames, int n_frames, int rows, int
 }  // extern "C"
 
 // ---- CPU baseline of the whole front-end (bench.py cpu_baseline leg only): per frame ORB extract + LSD/LBD
-// extract + match_current_and_last_frames + match_frame_and_landmarks against the two previous frames,
+// extract + match_current_and_last_frames[_line] + match_frame_and_landmarks against the two previous frames,
 // the same work bench.py times on the GPU.  Frame-parallel over n_threads workers; returns wall seconds.
 namespace oracle { struct LineResult; }
 extern "C" {
 void* oracle_line_extract(const uint8_t* img, int rows, int cols, long step, int stable_order);
 void oracle_line_free(void* h);
 int oracle_line_count(void* h, int which);
+struct CapiKeyLine { float angle; int class_id, octave; float f[13]; int numOfPixels; };   // 68-byte cv KeyLine record (line_oracle.cpp:35)
+void oracle_line_get(void* h, int which, CapiKeyLine* kl, uint8_t* lbd, double* linefn, float* desc_f);
+unsigned oracle_match_current_and_last_line(const CapiKeyLine* kl, const uint8_t* lbd, const float* xr_pair, const uint8_t* occupied, int n,
+                                            const float* scale_factors_lsd, int num_levels_lsd, const uint8_t* valid, const float* sp,
+                                            const float* ep, const float* lxr_sp, const float* lxr_ep, const int* loctave,
+                                            const uint8_t* ldesc, const uint8_t* l_has_obs, int m, float margin, int direction, int is_rgbd,
+                                            int* line_last);
 unsigned oracle_match_frame_and_landmarks(const double* grid6, const KeyPoint* kps, const uint8_t* desc, const float* x_right,
                                           const uint8_t* occupied, int n, const float* scale_factors, const uint8_t* lm_valid,
                                           const float* lm_reproj, const float* lm_x_right, const int* lm_level,
@@ -192,14 +199,38 @@ double oracle_front_time_frames(const uint8_t* frames, int n_frames, int rows, i
             const int per = (n_frames + n_threads - 1) / n_threads, f0 = t * per, f1 = std::min(n_frames, f0 + per);
             std::vector<KeyPoint> k[3];
             std::vector<uint8_t> d[3];
+            std::vector<CapiKeyLine> kl[2];
+            std::vector<uint8_t> lbd[2];
+            int have_lines[2] = {-1, -1};
             for (int f = f0; f < f1; ++f) {
                 const int cur = f % 3;
                 Image im = wrap(frames + (size_t)f * rows * cols, rows, cols, cols);
                 ex.extract(im, nullptr, k[cur], d[cur]);
                 kp[t] += (long)k[cur].size();
                 void* lh = oracle_line_extract(im.data.data(), rows, cols, cols, 1);
-                ln[t] += oracle_line_count(lh, 0);
+                const int nl = oracle_line_count(lh, 0);
+                ln[t] += nl;
+                kl[f & 1].assign((size_t)nl, CapiKeyLine{}); lbd[f & 1].assign((size_t)nl * 32, 0);
+                oracle_line_get(lh, 0, kl[f & 1].data(), lbd[f & 1].data(), nullptr, nullptr);
                 oracle_line_free(lh);
+                have_lines[f & 1] = f;
+                // match_current_and_last_frames_line: the previous frame's key lines, both end points moved by the pan
+                if (f > f0 && have_lines[(f & 1) ^ 1] == f - 1 && nl > 0) {
+                    const auto& pk = kl[(f & 1) ^ 1];
+                    const int m = (int)pk.size();
+                    std::vector<float> sp(2 * (size_t)m), ep(2 * (size_t)m), lxr((size_t)m, -1.f), xrp(2 * (size_t)nl, -1.f);
+                    std::vector<int> loct((size_t)m), lout((size_t)nl);
+                    std::vector<uint8_t> one((size_t)m, 1), occl((size_t)nl, 0);
+                    for (int i = 0; i < m; ++i) {   // f[4..7] = startPointX, startPointY, endPointX, endPointY
+                        sp[2 * i] = pk[i].f[4] + shift_x; sp[2 * i + 1] = pk[i].f[5];
+                        ep[2 * i] = pk[i].f[6] + shift_x; ep[2 * i + 1] = pk[i].f[7];
+                        loct[i] = pk[i].octave;
+                    }
+                    const float sf_lsd[1] = {1.f};
+                    mt[t] += oracle_match_current_and_last_line(kl[f & 1].data(), lbd[f & 1].data(), xrp.data(), occl.data(), nl, sf_lsd, 1,
+                                                                one.data(), sp.data(), ep.data(), lxr.data(), lxr.data(), loct.data(),
+                                                                lbd[(f & 1) ^ 1].data(), one.data(), m, 20.f, 0, 0, lout.data());
+                }
                 const int n = (int)k[cur].size();
                 if (f - f0 < 2 || n == 0) continue;
                 std::vector<float> xr(n, -1.f);
