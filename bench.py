@@ -107,15 +107,16 @@ def main():
     if uniq < B:
         d_frames = d_frames.repeat((B + uniq - 1) // uniq, 1, 1)[:B].contiguous()
     cap, lcap = 2 * K + 64, 512
-    # two sets of ORB outputs: the matchers of step n read set n % 2 while the extractor of step n + 1 fills the other
-    kps2 = [torch.empty((B, cap, 28), dtype=torch.uint8, device=dev) for _ in range(2)]
-    desc2 = [torch.empty((B, cap, 32), dtype=torch.uint8, device=dev) for _ in range(2)]
-    cnt2 = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2)]
+    # NBUF sets of outputs: the matchers of step n read set n % NBUF while the extractors of the next steps fill the others
+    NBUF = max(2, int(os.environ.get("PLP_BENCH_NBUF", "2")))
+    kps2 = [torch.empty((B, cap, 28), dtype=torch.uint8, device=dev) for _ in range(NBUF)]
+    desc2 = [torch.empty((B, cap, 32), dtype=torch.uint8, device=dev) for _ in range(NBUF)]
+    cnt2 = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(NBUF)]
     d_kps, d_desc, d_cnt = kps2[0], desc2[0], cnt2[0]
-    kl2 = [torch.zeros((B, lcap, 68), dtype=torch.uint8, device=dev) for _ in range(2)]
-    lbd2 = [torch.zeros((B, lcap, 32), dtype=torch.uint8, device=dev) for _ in range(2)]
-    fn2 = [torch.empty((B, lcap, 3), dtype=torch.float64, device=dev) for _ in range(2)]
-    lcnt2 = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2)]
+    kl2 = [torch.zeros((B, lcap, 68), dtype=torch.uint8, device=dev) for _ in range(NBUF)]
+    lbd2 = [torch.zeros((B, lcap, 32), dtype=torch.uint8, device=dev) for _ in range(NBUF)]
+    fn2 = [torch.empty((B, lcap, 3), dtype=torch.float64, device=dev) for _ in range(NBUF)]
+    lcnt2 = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(NBUF)]
     d_kl, d_lbd, d_fn, d_lcnt = kl2[0], lbd2[0], fn2[0], lcnt2[0]
     m3 = torch.empty((B, lcap), dtype=torch.int32, device=dev); n3 = torch.zeros(B, dtype=torch.int32, device=dev)
     m1 = torch.empty((B, cap), dtype=torch.int32, device=dev); n1 = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -181,12 +182,12 @@ def main():
     # (no stage fills the chip on its own, see profiles/r01i_sq_counters.md); all K steps' work, matchers
     # included, is inside the timed region because the closing barrier synchronises the device.
     sC = sA if serial else torch.cuda.Stream(dev)
-    done_match = [None, None]
+    done_match = [None] * NBUF
     step_no = [0]
 
     def step():
         n = step_no[0]; step_no[0] += 1
-        buf = n % 2
+        buf = n % NBUF
         if done_match[buf] is not None:
             sA.wait_event(done_match[buf])          # the matchers of step n - 2 have read this set
         parts = os.environ.get("PLP_BENCH_PARTS", "orb,lines,match")   # diagnostic: time a subset of the step
