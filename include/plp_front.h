@@ -237,6 +237,9 @@ typedef enum plp_match_mode {
                                            declares `const int pred_scale_level`, fuse.cc:109,126) */
 #define PLP_MATCH_FLAG_UNSIGNED_LEVEL 4 /* LAST_FRAME with level_window 1: the manual window of match_by_Sim3_transform
                                            (projection.cc:862) in unsigned arithmetic, q_level == 0 matches nothing */
+#define PLP_MATCH_FLAG_MARK_INVALIDATED 8 /* out_match = -2 (instead of -1) for a key point whose match the orientation check
+                                           removed: the reference writes nullptr there (projection.cc:350-354), which differs
+                                           from "never matched" when the slot held an observation-less landmark before */
 /* plp_match_args.level_window (LAST_FRAME / LAST_FRAME_LINE): 0 = from `direction`, 1 = [q_level-1, q_level],
  * 2 = [q_level-1, q_level+1] */
 

@@ -1,0 +1,40 @@
+// TEST INFRASTRUCTURE ONLY.  Stand-in for the reference's src/PLPSLAM/type.h (Eigen aliases) so that the shipped matcher
+// facade can be compiled and run in an image without Eigen: just enough of Matrix3d / Vector3d / Vector2d / Matrix4d for
+// the expressions projection.cc:220-231 uses (block<3,3>, block<3,1>, transpose, unary minus, M * v, v + v, v(i)).
+#pragma once
+namespace PLPSLAM {
+struct Vec2_t { double v[2] = {0, 0}; double& operator()(int i) { return v[i]; } double operator()(int i) const { return v[i]; } };
+struct Vec3_t {
+    double v[3] = {0, 0, 0};
+    double& operator()(int i) { return v[i]; }
+    double operator()(int i) const { return v[i]; }
+    Vec3_t operator+(const Vec3_t& o) const { Vec3_t r; for (int i = 0; i < 3; ++i) r.v[i] = v[i] + o.v[i]; return r; }
+};
+struct Mat33_t {
+    double m[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    double& operator()(int i, int j) { return m[i][j]; }
+    double operator()(int i, int j) const { return m[i][j]; }
+    Mat33_t transpose() const { Mat33_t r; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r.m[i][j] = m[j][i]; return r; }
+    Mat33_t operator-() const { Mat33_t r; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r.m[i][j] = -m[i][j]; return r; }
+    Vec3_t operator*(const Vec3_t& x) const {
+        Vec3_t r;
+        for (int i = 0; i < 3; ++i) r.v[i] = m[i][0] * x.v[0] + m[i][1] * x.v[1] + m[i][2] * x.v[2];
+        return r;
+    }
+};
+namespace type_detail {
+template <int R, int C> struct block_t;
+template <> struct block_t<3, 3> { using type = Mat33_t; };
+template <> struct block_t<3, 1> { using type = Vec3_t; };
+}  // namespace type_detail
+struct Mat44_t {
+    double m[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+    double& operator()(int i, int j) { return m[i][j]; }
+    template <int R, int C> typename type_detail::block_t<R, C>::type block(int i0, int j0) const {
+        typename type_detail::block_t<R, C>::type r;
+        if constexpr (C == 3) { for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r.m[i][j] = m[i0 + i][j0 + j]; }
+        else { for (int i = 0; i < 3; ++i) r.v[i] = m[i0 + i][j0]; }
+        return r;
+    }
+};
+}  // namespace PLPSLAM

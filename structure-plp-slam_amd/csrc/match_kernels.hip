@@ -721,7 +721,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         float delta = (P.mode == PLP_MATCH_MODE_LAST_FRAME || is_group_mode(P.mode)) ? __fsub_rn(q_angle[q], ta) : __fsub_rn(ta, q_angle[q]);
         if (delta < 0.0) delta = (float)((double)delta + 360.0);
         if (360.0 <= delta) delta = (float)((double)delta - 360.0);
-        return __float2int_rn(__fmul_rn(delta, 1.0f / 30));
+        // angles outside [0, 360) can leave delta negative: the reference throws there (angle_histogram_.at(bin)); here such a
+        // match lands in bin 31, which is never among the kept bins
+        const int bin = __float2int_rn(__fmul_rn(delta, 1.0f / 30));
+        return (unsigned)bin > 31u ? 31 : bin;
     };
     int my = 0;
     for (int q = tid; q < m; q += 256) {
@@ -746,7 +749,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         for (int q = tid; q < m; q += 256) {
             const int t = claim[q];
             if (t < 0) continue;
-            if (!s_valid_bin[min(bin_of(q, t), 31)]) { out[t] = -1; ++bad; }
+            if (!s_valid_bin[min(bin_of(q, t), 31)]) { out[t] = (P.flags & PLP_MATCH_FLAG_MARK_INVALIDATED) ? -2 : -1; ++bad; }
         }
         if (bad) atomicSub(&s_num, bad);
         __syncthreads();
@@ -829,7 +832,8 @@ __global__ __launch_bounds__(64) void k_match_area(AreaArgs A) {
         float delta = __fsub_rn(A.kps1[i1].angle, A.kps2[i2].angle);
         if (delta < 0.0) delta = (float)((double)delta + 360.0);
         if (360.0 <= delta) delta = (float)((double)delta - 360.0);
-        return min(__float2int_rn(__fmul_rn(delta, 1.0f / 30)), 31);
+        const int bin = __float2int_rn(__fmul_rn(delta, 1.0f / 30));
+        return (unsigned)bin > 31u ? 31 : bin;
     };
     for (int i1 = 0; i1 < A.n1; ++i1) {
         const plp_keypoint k1 = A.kps1[i1];

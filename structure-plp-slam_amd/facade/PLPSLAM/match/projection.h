@@ -1,0 +1,195 @@
+// Drop-in replacement of the reference header src/PLPSLAM/match/projection.h for the two calls the tracker makes every
+// frame: projection::match_frame_and_landmarks (projection.cc:37-121, called from tracking_module::search_local_landmarks)
+// and projection::match_current_and_last_frames (projection.cc:214-358, called from frame_tracker::motion_based_track).
+// Same class name, constructor, method names, argument meaning and return value; the search itself runs in
+// libplp_front.so (PLP_MATCH_MODE_LANDMARKS / PLP_MATCH_MODE_LAST_FRAME through plp_match_host).
+//
+// The methods are templates on the frame / landmark types: inside the reference tree they are instantiated with
+// data::frame and data::landmark (the call sites compile unchanged), and they only touch the members the reference's own
+// loops touch -- undist_keypts_, descriptors_, stereo_x_right_, landmarks_, scale_factors_, camera_ (grid, setup_type_,
+// true_baseline_, reproject_to_image), cam_pose_cw_, keypts_, outlier_flags_; is_observable_in_tracking_, will_be_erased(),
+// scale_level_in_tracking_, reproj_in_tracking_, x_right_in_tracking_, get_descriptor(), has_observation(),
+// get_pos_in_world().  What stays on the host is exactly what the reference computes per landmark before the descriptor
+// search: the skip tests and the reprojection.  The map mutation (frm.landmarks_.at(idx) = lm) is applied from the
+// matcher's out_match array, which already holds the sequential loop's "last writer wins" result.
+#ifndef PLPSLAM_MATCH_PROJECTION_H
+#define PLPSLAM_MATCH_PROJECTION_H
+
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <stdexcept>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "PLPSLAM/type.h"
+#include "plp_front.h"
+
+namespace PLPSLAM {
+namespace match {
+
+namespace detail {
+
+// match::projection is value-constructed at every call site (tracking_module.cc, frame_tracker.cc): the device context
+// behind it is shared per thread instead of being created per object.
+inline plp_matcher* shared_matcher() {
+    struct holder {
+        plp_matcher* h = nullptr;
+        ~holder() { if (h) plp_matcher_destroy(h); }
+    };
+    thread_local holder H;
+    if (!H.h) {
+        const char* e = std::getenv("PLP_DEVICE");
+        if (plp_matcher_create(e ? std::atoi(e) : 0, &H.h) != PLP_OK) throw std::runtime_error(std::string("plp_matcher_create: ") + plp_last_error());
+    }
+    return H.h;
+}
+
+inline void check(plp_status s) {
+    if (s != PLP_OK) throw std::runtime_error(std::string("plp_front: ") + plp_last_error());
+}
+
+template <class Camera>
+plp_match_grid grid_of(const Camera* cam) {   // camera::base, camera/base.h:147-160
+    plp_match_grid g;
+    g.min_x = cam->img_bounds_.min_x_; g.min_y = cam->img_bounds_.min_y_;
+    g.inv_cell_width = cam->inv_cell_width_; g.inv_cell_height = cam->inv_cell_height_;
+    g.cols = static_cast<int32_t>(cam->num_grid_cols_); g.rows = static_cast<int32_t>(cam->num_grid_rows_);
+    return g;
+}
+
+// the current frame as targets: undist_keypts_, descriptors_, stereo_x_right_, "has a landmark with observations"
+template <class Frame>
+struct frame_targets {
+    std::vector<uint8_t> desc, occupied;
+    const plp_keypoint* kps;
+    int n;
+    explicit frame_targets(const Frame& frm) {
+        n = static_cast<int>(frm.undist_keypts_.size());
+        static_assert(sizeof(frm.undist_keypts_[0]) == sizeof(plp_keypoint), "cv::KeyPoint must be the 28-byte POD");
+        kps = reinterpret_cast<const plp_keypoint*>(frm.undist_keypts_.data());
+        desc.resize(static_cast<size_t>(n) * 32);
+        occupied.resize(static_cast<size_t>(n));
+        for (int i = 0; i < n; ++i) {
+            const unsigned char* row = frm.descriptors_.template ptr<unsigned char>(i);
+            for (int k = 0; k < 32; ++k) desc[static_cast<size_t>(i) * 32 + k] = row[k];
+            const auto* lm = frm.landmarks_.at(i);
+            occupied[i] = (lm && lm->has_observation()) ? 1 : 0;
+        }
+    }
+};
+
+}  // namespace detail
+
+class projection {
+public:
+    explicit projection(const float lowe_ratio = 0.6, const bool check_orientation = true)
+        : lowe_ratio_(lowe_ratio), check_orientation_(check_orientation) {}
+    ~projection() = default;
+
+    //! projection.cc:37-121
+    template <class Frame, class Landmark>
+    unsigned int match_frame_and_landmarks(Frame& frm, const std::vector<Landmark*>& local_landmarks, const float margin = 5.0) const {
+        std::vector<Landmark*> lms;                    // the landmarks that pass the skip tests, in list order
+        std::vector<float> reproj, x_right;
+        std::vector<int32_t> level;
+        std::vector<uint8_t> desc, has_obs;
+        for (auto local_lm : local_landmarks) {
+            if (!local_lm->is_observable_in_tracking_) continue;
+            if (local_lm->will_be_erased()) continue;
+            lms.push_back(local_lm);
+            reproj.push_back(static_cast<float>(local_lm->reproj_in_tracking_(0)));
+            reproj.push_back(static_cast<float>(local_lm->reproj_in_tracking_(1)));
+            x_right.push_back(static_cast<float>(local_lm->x_right_in_tracking_));
+            level.push_back(static_cast<int32_t>(local_lm->scale_level_in_tracking_));
+            const auto lm_desc = local_lm->get_descriptor();
+            const unsigned char* p = lm_desc.template ptr<unsigned char>(0);
+            desc.insert(desc.end(), p, p + 32);
+            has_obs.push_back(local_lm->has_observation() ? 1 : 0);
+        }
+        const detail::frame_targets<Frame> T(frm);
+        if (lms.empty() || T.n == 0) return 0;
+        std::vector<int32_t> out(static_cast<size_t>(T.n), -1);
+        int32_t num = 0;
+        plp_match_args a{};
+        a.mode = PLP_MATCH_MODE_LANDMARKS; a.B = 1; a.n_cap = T.n; a.m_cap = static_cast<int32_t>(lms.size());
+        a.t_kps = T.kps; a.t_desc = T.desc.data(); a.t_x_right = frm.stereo_x_right_.data(); a.t_occupied = T.occupied.data();
+        a.q_reproj = reproj.data(); a.q_x_right = x_right.data(); a.q_level = level.data(); a.q_desc = desc.data(); a.q_has_obs = has_obs.data();
+        a.margin = margin; a.lowe_ratio = lowe_ratio_; a.check_orientation = check_orientation_ ? 1 : 0;
+        a.num_levels = static_cast<int32_t>(frm.scale_factors_.size()); a.scale_factors = frm.scale_factors_.data();
+        a.grid = detail::grid_of(frm.camera_);
+        a.out_match = out.data(); a.out_num = &num;
+        detail::check(plp_match_host(detail::shared_matcher(), &a));
+        for (int i = 0; i < T.n; ++i)
+            if (out[i] >= 0) frm.landmarks_.at(i) = lms[static_cast<size_t>(out[i])];
+        return static_cast<unsigned int>(num);
+    }
+
+    //! projection.cc:214-358
+    template <class Frame>
+    unsigned int match_current_and_last_frames(Frame& curr_frm, const Frame& last_frm, const float margin) const {
+        const Mat33_t rot_cw = curr_frm.cam_pose_cw_.template block<3, 3>(0, 0);
+        const Vec3_t trans_cw = curr_frm.cam_pose_cw_.template block<3, 1>(0, 3);
+        const Vec3_t trans_wc = -rot_cw.transpose() * trans_cw;
+        const Mat33_t rot_lw = last_frm.cam_pose_cw_.template block<3, 3>(0, 0);
+        const Vec3_t trans_lw = last_frm.cam_pose_cw_.template block<3, 1>(0, 3);
+        const Vec3_t trans_lc = rot_lw * trans_wc + trans_lw;
+        const bool mono = static_cast<int>(curr_frm.camera_->setup_type_) == 0;   // camera::setup_type_t::Monocular
+        const bool assume_forward = mono ? false : trans_lc(2) > curr_frm.camera_->true_baseline_;
+        const bool assume_backward = mono ? false : -trans_lc(2) > curr_frm.camera_->true_baseline_;
+
+        using LandmarkPtr = typename std::decay<decltype(last_frm.landmarks_.at(0))>::type;
+        std::vector<LandmarkPtr> lms;
+        std::vector<float> reproj_f, x_right_f, angle;
+        std::vector<int32_t> level;
+        std::vector<uint8_t> desc;
+        for (unsigned int idx_last = 0; idx_last < last_frm.num_keypts_; ++idx_last) {
+            auto lm = last_frm.landmarks_.at(idx_last);
+            if (!lm) continue;
+            if (last_frm.outlier_flags_.at(idx_last)) continue;
+            const Vec3_t pos_w = lm->get_pos_in_world();
+            Vec2_t reproj;
+            float x_right;
+            if (!curr_frm.camera_->reproject_to_image(rot_cw, trans_cw, pos_w, reproj, x_right)) continue;
+            lms.push_back(lm);
+            reproj_f.push_back(static_cast<float>(reproj(0))); reproj_f.push_back(static_cast<float>(reproj(1)));
+            x_right_f.push_back(x_right);
+            level.push_back(static_cast<int32_t>(last_frm.keypts_.at(idx_last).octave));
+            angle.push_back(last_frm.undist_keypts_.at(idx_last).angle);
+            const auto lm_desc = lm->get_descriptor();
+            const unsigned char* p = lm_desc.template ptr<unsigned char>(0);
+            desc.insert(desc.end(), p, p + 32);
+        }
+        const detail::frame_targets<Frame> T(curr_frm);
+        if (lms.empty() || T.n == 0) return 0;
+        std::vector<int32_t> out(static_cast<size_t>(T.n), -1);
+        int32_t num = 0;
+        plp_match_args a{};
+        a.mode = PLP_MATCH_MODE_LAST_FRAME; a.B = 1; a.n_cap = T.n; a.m_cap = static_cast<int32_t>(lms.size());
+        a.t_kps = T.kps; a.t_desc = T.desc.data(); a.t_x_right = curr_frm.stereo_x_right_.data(); a.t_occupied = T.occupied.data();
+        a.q_reproj = reproj_f.data(); a.q_x_right = x_right_f.data(); a.q_level = level.data(); a.q_angle = angle.data(); a.q_desc = desc.data();
+        a.margin = margin; a.lowe_ratio = lowe_ratio_; a.check_orientation = check_orientation_ ? 1 : 0;
+        a.direction = assume_forward ? 1 : (assume_backward ? 2 : 0);
+        a.flags = PLP_MATCH_FLAG_MARK_INVALIDATED;
+        // the upper octave of the assume_forward window is last_frm.num_scale_levels_ - 1 (projection.cc:280)
+        a.num_levels = static_cast<int32_t>(last_frm.num_scale_levels_); a.scale_factors = curr_frm.scale_factors_.data();
+        a.grid = detail::grid_of(curr_frm.camera_);
+        a.out_match = out.data(); a.out_num = &num;
+        detail::check(plp_match_host(detail::shared_matcher(), &a));
+        for (int i = 0; i < T.n; ++i) {
+            if (out[i] >= 0) curr_frm.landmarks_.at(i) = lms[static_cast<size_t>(out[i])];
+            else if (out[i] == -2) curr_frm.landmarks_.at(i) = nullptr;     // matched, then removed by the orientation check (:350-354)
+        }
+        return static_cast<unsigned int>(num);
+    }
+
+protected:
+    const float lowe_ratio_;
+    const bool check_orientation_;
+};
+
+}  // namespace match
+}  // namespace PLPSLAM
+
+#endif  // PLPSLAM_MATCH_PROJECTION_H
