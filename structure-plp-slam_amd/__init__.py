@@ -401,7 +401,7 @@ class match_args_c(C.Structure):
 
 
 MODE_LANDMARKS, MODE_LAST_FRAME, MODE_BRUTE_FORCE, MODE_LANDMARKS_LINE, MODE_LAST_FRAME_LINE, MODE_BOW, MODE_FUSE, MODE_FUSE_LINE, MODE_TRIANGULATION = 0, 1, 2, 3, 4, 5, 6, 7, 8
-FLAG_NO_CHI2, FLAG_SIGNED_LEVEL, FLAG_UNSIGNED_LEVEL = 1, 2, 4
+FLAG_NO_CHI2, FLAG_SIGNED_LEVEL, FLAG_UNSIGNED_LEVEL, FLAG_MARK_INVALIDATED = 1, 2, 4, 8
 
 
 def make_grid(cols_px, rows_px, grid_cols=64, grid_rows=48, min_x=0.0, min_y=0.0):

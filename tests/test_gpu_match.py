@@ -30,6 +30,14 @@ def run_last(t, q, margin, direction, check, grid):
                             scale_factors=SF, grid=grid)
     assert gn[0] == wn
     assert np.array_equal(got[0], want)
+    if check:
+        # PLP_MATCH_FLAG_MARK_INVALIDATED: -2 exactly where the orientation check removed a match (projection.cc:350-354)
+        raw, _ = O.match_current_and_last(O.grid6(grid), t["t_kps"], t["t_desc"], t["t_x_right"], t["t_occupied"], SF, q["q_valid"],
+                                          q["q_reproj"], q["q_x_right"], q["q_level"], q["q_angle"], q["q_desc"], q["q_has_obs"], margin,
+                                          direction, False)
+        marked, mn = mt.match_host(plp.MODE_LAST_FRAME, len(t["t_kps"]), len(q["q_level"]), {**t, **q, "flags": plp.FLAG_MARK_INVALIDATED},
+                                   margin=margin, direction=direction, scale_factors=SF, grid=grid)
+        assert mn[0] == wn and np.array_equal(marked[0], np.where((raw >= 0) & (want < 0), -2, want))
     return wn
 
 
