@@ -6,6 +6,7 @@
 // by oracle/ref_shim.  Expected results come from the array-form oracle (liboracle.so), fed with a flattening written
 // independently of the facade's (validity flags over all landmarks instead of compaction).
 //   facade_match_check <seed> <n_keypts> <n_landmarks>        exit code 0 = identical
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -25,6 +26,16 @@ unsigned oracle_match_frame_and_landmarks(const double* grid6, const OKeyPoint* 
                                           const uint8_t* occupied, int n, const float* scale_factors, const uint8_t* lm_valid,
                                           const float* lm_reproj, const float* lm_x_right, const int* lm_level, const uint8_t* lm_desc,
                                           const uint8_t* lm_has_obs, int m, float margin, float lowe_ratio, int* kp_landmark);
+struct OKeyLine { float angle; int class_id, octave; float pt_x, pt_y, response, size, startPointX, startPointY, endPointX, endPointY,
+                  sPointInOctaveX, sPointInOctaveY, ePointInOctaveX, ePointInOctaveY, lineLength; int numOfPixels; };
+unsigned oracle_match_frame_and_landmarks_line(const OKeyLine* kl, const uint8_t* lbd, const int* kp_octave, const uint8_t* occupied, int n,
+                                               const float* scale_factors_lsd, const uint8_t* lm_valid, const float* lm_sp, const float* lm_ep,
+                                               const int* lm_level, const uint8_t* lm_desc, const uint8_t* lm_has_obs, int m, float margin,
+                                               float lowe_ratio, int* line_landmark);
+unsigned oracle_match_current_and_last_line(const OKeyLine* kl, const uint8_t* lbd, const float* xr_pair, const uint8_t* occupied, int n,
+                                            const float* scale_factors_lsd, int num_levels_lsd, const uint8_t* valid, const float* sp,
+                                            const float* ep, const float* lxr_sp, const float* lxr_ep, const int* loctave, const uint8_t* ldesc,
+                                            const uint8_t* l_has_obs, int m, float margin, int direction, int is_rgbd, int* line_last);
 unsigned oracle_match_current_and_last(const double* grid6, const OKeyPoint* kps, const uint8_t* desc, const float* x_right,
                                        const uint8_t* occupied, int n, const float* scale_factors, int num_levels, const uint8_t* valid,
                                        const float* reproj, const float* lx_right, const int* loctave, const float* langle,
@@ -73,7 +84,27 @@ struct landmark {
     cv::Mat get_descriptor() const { return desc_.clone(); }
     Vec3_t get_pos_in_world() const { return pos_w_; }
 };
+struct Line {
+    bool _is_observable_in_tracking = true;
+    bool erased_ = false, observed_ = true;
+    unsigned int _scale_level_in_tracking = 0;
+    Vec2_t _reproj_in_tracking_sp, _reproj_in_tracking_ep;
+    Vec6_t pos_w_;
+    cv::Mat desc_;
+    bool will_be_erased() const { return erased_; }
+    bool has_observation() const { return observed_; }
+    cv::Mat get_descriptor() const { return desc_.clone(); }
+    Vec6_t get_pos_in_world() const { return pos_w_; }
+};
 struct frame {
+    // FW: line members of data::frame
+    unsigned int _num_keylines = 0, _num_scale_levels_lsd = 2;
+    std::vector<float> _scale_factors_lsd;
+    std::vector<OKeyLine> _keylsd;
+    cv::Mat _lbd_descr;
+    std::vector<Line*> _landmarks_line;
+    std::vector<bool> _outlier_flags_line;
+    std::vector<std::pair<float, float>> _stereo_x_right_cooresponding_to_keylines;
     camera::base* camera_ = nullptr;
     unsigned int num_keypts_ = 0, num_scale_levels_ = 8;
     std::vector<float> scale_factors_;
@@ -112,6 +143,34 @@ void fill_frame(data::frame& f, camera::base* cam, int n) {
         random_desc(f.descriptors_.ptr<uint8_t>(i));
     }
     f.undist_keypts_ = f.keypts_;
+}
+
+void fill_lines(data::frame& f, int n) {
+    f._num_keylines = (unsigned)n;
+    f._scale_factors_lsd = {1.f, 2.f};
+    f._keylsd.assign(n, OKeyLine{}); f._landmarks_line.assign(n, nullptr); f._outlier_flags_line.assign(n, false);
+    f._stereo_x_right_cooresponding_to_keylines.resize(n);
+    f._lbd_descr = cv::Mat(n, 32, CV_8U);
+    for (int i = 0; i < n; ++i) {
+        OKeyLine& k = f._keylsd[i];
+        const double x = uni(20, 620), y = uni(20, 460), a = uni(-3.14159, 3.14159), len = uni(15, 120);
+        k.startPointX = (float)x; k.startPointY = (float)y; k.endPointX = (float)(x + len * std::cos(a)); k.endPointY = (float)(y + len * std::sin(a));
+        k.pt_x = 0.5f * (k.startPointX + k.endPointX); k.pt_y = 0.5f * (k.startPointY + k.endPointY);
+        k.angle = (float)a; k.octave = irand(0, 1); k.class_id = i; k.lineLength = (float)len; k.response = (float)(len / 640.0);
+        f._stereo_x_right_cooresponding_to_keylines[i] = uni(0, 1) < 0.6 ? std::make_pair((float)(x - uni(0, 30)), (float)(k.endPointX - uni(0, 30)))
+                                                                          : std::make_pair(-1.f, -1.f);
+        random_desc(f._lbd_descr.ptr<uint8_t>(i));
+    }
+}
+std::vector<uint8_t> line_occupied_of(const data::frame& f) {
+    std::vector<uint8_t> o(f._landmarks_line.size());
+    for (size_t i = 0; i < o.size(); ++i) o[i] = f._landmarks_line[i] && f._landmarks_line[i]->has_observation();
+    return o;
+}
+std::vector<uint8_t> lbd_of(const data::frame& f) {
+    std::vector<uint8_t> d((size_t)f._num_keylines * 32);
+    for (unsigned i = 0; i < f._num_keylines; ++i) std::copy(f._lbd_descr.ptr<uint8_t>((int)i), f._lbd_descr.ptr<uint8_t>((int)i) + 32, d.begin() + (size_t)i * 32);
+    return d;
 }
 
 std::vector<uint8_t> occupied_of(const data::frame& f) {
@@ -270,6 +329,132 @@ int main(int argc, char** argv) {
             if (got_num != want_num) ++failures;
             std::printf("match_current_and_last_frames[direction %d]: %u matches (oracle %u), %d removed by the orientation check\n", direction, got_num,
                         want_num, removed);
+        }
+        // ---------------- match_frame_and_landmarks_line
+        const int nl = std::max(2, n / 6), ml = std::max(2, m / 6);
+        {
+            data::frame frm;
+            fill_frame(frm, &cam, std::max(n, nl));               // undist_keypts_ is read with line indices (:187, :192)
+            fill_lines(frm, nl);
+            std::vector<std::unique_ptr<data::Line>> pool;
+            for (int i = 0; i < nl; ++i)
+                if (uni(0, 1) < 0.15) { pool.emplace_back(new data::Line()); pool.back()->observed_ = uni(0, 1) < 0.7; frm._landmarks_line[i] = pool.back().get(); }
+            std::vector<data::Line*> local;
+            for (int j = 0; j < ml; ++j) {
+                pool.emplace_back(new data::Line());
+                auto* lm = pool.back().get();
+                lm->_is_observable_in_tracking = uni(0, 1) < 0.9; lm->erased_ = uni(0, 1) < 0.05; lm->observed_ = uni(0, 1) < 0.85;
+                const int ki = irand(0, nl - 1);
+                const OKeyLine& k = frm._keylsd[(size_t)ki];
+                lm->_scale_level_in_tracking = (unsigned)irand(0, 1);
+                lm->_reproj_in_tracking_sp(0) = k.startPointX + uni(-4, 4); lm->_reproj_in_tracking_sp(1) = k.startPointY + uni(-4, 4);
+                lm->_reproj_in_tracking_ep(0) = k.endPointX + uni(-4, 4); lm->_reproj_in_tracking_ep(1) = k.endPointY + uni(-4, 4);
+                lm->desc_ = cv::Mat(1, 32, CV_8U);
+                std::copy(frm._lbd_descr.ptr<uint8_t>(ki), frm._lbd_descr.ptr<uint8_t>(ki) + 32, lm->desc_.ptr<uint8_t>(0));
+                for (int f = irand(0, 5); f > 0; --f) lm->desc_.ptr<uint8_t>(0)[irand(0, 31)] ^= (uint8_t)(1u << irand(0, 7));
+                local.push_back(lm);
+            }
+            std::vector<uint8_t> valid(ml), hobs(ml), ld((size_t)ml * 32);
+            std::vector<float> sp(2 * (size_t)ml), ep(2 * (size_t)ml);
+            std::vector<int> lvl(ml), want(nl), kpo(nl);
+            for (int j = 0; j < ml; ++j) {
+                valid[j] = local[j]->_is_observable_in_tracking && !local[j]->will_be_erased(); hobs[j] = local[j]->has_observation();
+                sp[2 * j] = (float)local[j]->_reproj_in_tracking_sp(0); sp[2 * j + 1] = (float)local[j]->_reproj_in_tracking_sp(1);
+                ep[2 * j] = (float)local[j]->_reproj_in_tracking_ep(0); ep[2 * j + 1] = (float)local[j]->_reproj_in_tracking_ep(1);
+                lvl[j] = (int)local[j]->_scale_level_in_tracking;
+                std::copy(local[j]->desc_.ptr<uint8_t>(0), local[j]->desc_.ptr<uint8_t>(0) + 32, ld.begin() + (size_t)j * 32);
+            }
+            for (int i = 0; i < nl; ++i) kpo[i] = frm.undist_keypts_[(size_t)i].octave;
+            const auto occ = line_occupied_of(frm);
+            const auto fd = lbd_of(frm);
+            const float margin = 10.f;
+            const unsigned want_num = oracle_match_frame_and_landmarks_line(frm._keylsd.data(), fd.data(), kpo.data(), occ.data(), nl, frm._scale_factors_lsd.data(),
+                                                                            valid.data(), sp.data(), ep.data(), lvl.data(), ld.data(), hobs.data(), ml, margin,
+                                                                            0.8f, want.data());
+            const std::vector<data::Line*> before = frm._landmarks_line;
+            const match::projection projection_matcher(0.8);
+            const unsigned got_num = projection_matcher.match_frame_and_landmarks_line(frm, local, margin);
+            for (int i = 0; i < nl; ++i)
+                if (frm._landmarks_line[i] != (want[i] >= 0 ? local[(size_t)want[i]] : before[i])) ++failures;
+            if (got_num != want_num) ++failures;
+            std::printf("match_frame_and_landmarks_line: %u matches (oracle %u)\n", got_num, want_num);
+        }
+        // ---------------- match_current_and_last_frames_line: RGB-D forward, RGB-D backward, monocular
+        for (int motion = 0; motion < 3; ++motion) {
+            data::frame last, curr;
+            fill_frame(last, &cam, 4); fill_frame(curr, &cam, 4);
+            fill_lines(last, ml); fill_lines(curr, nl);
+            cam.setup_type_ = motion == 2 ? camera::setup_type_t::Monocular : camera::setup_type_t::RGBD;
+            curr.cam_pose_cw_(0, 3) = 0.01;
+            curr.cam_pose_cw_(2, 3) = motion == 0 ? -0.3 : (motion == 1 ? 0.3 : 0.0);
+            const Mat33_t rot_cw = curr.cam_pose_cw_.block<3, 3>(0, 0);
+            const Vec3_t trans_cw = curr.cam_pose_cw_.block<3, 1>(0, 3);
+            std::vector<std::unique_ptr<data::Line>> pool;
+            for (int j = 0; j < ml; ++j) {
+                if (uni(0, 1) < 0.2) continue;
+                pool.emplace_back(new data::Line());
+                auto* lm = pool.back().get();
+                const OKeyLine& k = last._keylsd[(size_t)j];
+                const double z1 = uni(0.8, 6.0), z2 = z1 + uni(-0.3, 0.3);
+                // some 3D lines stick out of the image (one end point outside, mid point inside or not) or behind the camera
+                const double stretch = uni(0, 1) < 0.2 ? uni(2, 12) : 1.0;
+                lm->pos_w_(0) = (k.startPointX - cam.cx_) / cam.fx_ * z1; lm->pos_w_(1) = (k.startPointY - cam.cy_) / cam.fy_ * z1; lm->pos_w_(2) = z1;
+                lm->pos_w_(3) = (k.startPointX + stretch * (k.endPointX - k.startPointX) - cam.cx_) / cam.fx_ * z2;
+                lm->pos_w_(4) = (k.startPointY + stretch * (k.endPointY - k.startPointY) - cam.cy_) / cam.fy_ * z2; lm->pos_w_(5) = z2;
+                lm->desc_ = cv::Mat(1, 32, CV_8U);
+                std::copy(last._lbd_descr.ptr<uint8_t>(j), last._lbd_descr.ptr<uint8_t>(j) + 32, lm->desc_.ptr<uint8_t>(0));
+                last._landmarks_line[j] = lm;
+                last._outlier_flags_line[j] = uni(0, 1) < 0.1;
+            }
+            for (int i = 0; i < nl; ++i)
+                if (uni(0, 1) < 0.1) { pool.emplace_back(new data::Line()); pool.back()->observed_ = uni(0, 1) < 0.5; curr._landmarks_line[i] = pool.back().get(); }
+            for (int i = 0; i < nl; i += 2) {          // half of the current key lines sit where a 3D line reprojects
+                const int j = irand(0, ml - 1);
+                if (!last._landmarks_line[j]) continue;
+                Vec2_t a, b; float xa, xb;
+                const bool ia = cam.reproject_to_image(rot_cw, trans_cw, last._landmarks_line[j]->pos_w_.head<3>(), a, xa);
+                const bool ib = cam.reproject_to_image(rot_cw, trans_cw, last._landmarks_line[j]->pos_w_.tail<3>(), b, xb);
+                if (!ia || !ib) continue;
+                OKeyLine& k = curr._keylsd[(size_t)i];
+                k.startPointX = (float)(a(0) + uni(-2, 2)); k.startPointY = (float)(a(1) + uni(-2, 2));
+                k.endPointX = (float)(b(0) + uni(-2, 2)); k.endPointY = (float)(b(1) + uni(-2, 2));
+                k.octave = last._keylsd[(size_t)j].octave;
+                if (uni(0, 1) < 0.7) curr._stereo_x_right_cooresponding_to_keylines[i] = std::make_pair((float)(xa + uni(-2, 2)), (float)(xb + uni(-2, 2)));
+                std::copy(last._lbd_descr.ptr<uint8_t>(j), last._lbd_descr.ptr<uint8_t>(j) + 32, curr._lbd_descr.ptr<uint8_t>(i));
+                curr._lbd_descr.ptr<uint8_t>(i)[irand(0, 31)] ^= 2;
+            }
+            std::vector<uint8_t> valid(ml, 0), ones(ml, 1), ld((size_t)ml * 32, 0);
+            std::vector<float> sp(2 * (size_t)ml, 0.f), ep(2 * (size_t)ml, 0.f), xsp(ml, 0.f), xep(ml, 0.f), xrp(2 * (size_t)nl);
+            std::vector<int> loct(ml, 0), want(nl);
+            for (int j = 0; j < ml; ++j) {
+                auto* lm = last._landmarks_line[j];
+                if (!lm || last._outlier_flags_line[j]) continue;
+                Vec2_t a, b, c; float xa = 0, xb = 0, xc;
+                const bool ia = cam.reproject_to_image(rot_cw, trans_cw, lm->pos_w_.head<3>(), a, xa);
+                const bool ib = cam.reproject_to_image(rot_cw, trans_cw, lm->pos_w_.tail<3>(), b, xb);
+                if (!ia && !ib) continue;
+                if ((!ia || !ib) && !cam.reproject_to_image(rot_cw, trans_cw, 0.5 * (lm->pos_w_.head<3>() + lm->pos_w_.tail<3>()), c, xc)) continue;
+                valid[j] = 1; sp[2 * j] = (float)a(0); sp[2 * j + 1] = (float)a(1); ep[2 * j] = (float)b(0); ep[2 * j + 1] = (float)b(1);
+                xsp[j] = xa; xep[j] = xb; loct[j] = last._keylsd[(size_t)j].octave;
+                std::copy(lm->desc_.ptr<uint8_t>(0), lm->desc_.ptr<uint8_t>(0) + 32, ld.begin() + (size_t)j * 32);
+            }
+            for (int i = 0; i < nl; ++i) { xrp[2 * i] = curr._stereo_x_right_cooresponding_to_keylines[i].first; xrp[2 * i + 1] = curr._stereo_x_right_cooresponding_to_keylines[i].second; }
+            const double tz_lc = -curr.cam_pose_cw_.m[2][3];
+            const bool mono = cam.setup_type_ == camera::setup_type_t::Monocular;
+            const int direction = mono ? 0 : (tz_lc > cam.true_baseline_ ? 1 : (-tz_lc > cam.true_baseline_ ? 2 : 0));
+            const auto occ = line_occupied_of(curr);
+            const auto fd = lbd_of(curr);
+            const float margin = 12.f;
+            const unsigned want_num = oracle_match_current_and_last_line(curr._keylsd.data(), fd.data(), xrp.data(), occ.data(), nl, curr._scale_factors_lsd.data(),
+                                                                         (int)last._num_scale_levels_lsd, valid.data(), sp.data(), ep.data(), xsp.data(), xep.data(),
+                                                                         loct.data(), ld.data(), ones.data(), ml, margin, direction, mono ? 0 : 1, want.data());
+            const std::vector<data::Line*> before = curr._landmarks_line;
+            const match::projection projection_matcher(0.9, true);
+            const unsigned got_num = projection_matcher.match_current_and_last_frames_line(curr, last, margin);
+            for (int i = 0; i < nl; ++i)
+                if (curr._landmarks_line[i] != (want[i] >= 0 ? last._landmarks_line[(size_t)want[i]] : before[i])) ++failures;
+            if (got_num != want_num) ++failures;
+            std::printf("match_current_and_last_frames_line[direction %d, rgbd %d]: %u matches (oracle %u)\n", direction, mono ? 0 : 1, got_num, want_num);
         }
     } catch (const std::exception& e) {
         std::fprintf(stderr, "facade_match_check: %s\n", e.what());

@@ -1,6 +1,7 @@
 // TEST INFRASTRUCTURE ONLY.  Stand-in for the reference's src/PLPSLAM/type.h (Eigen aliases) so that the shipped matcher
 // facade can be compiled and run in an image without Eigen: just enough of Matrix3d / Vector3d / Vector2d / Matrix4d for
-// the expressions projection.cc:220-231 uses (block<3,3>, block<3,1>, transpose, unary minus, M * v, v + v, v(i)).
+// the expressions projection.cc:220-231 and :389-402 use (block<3,3>, block<3,1>, transpose, unary minus, M * v, v + v,
+// s * v, v(i), Vec6 head<3> / tail<3>).
 #pragma once
 namespace PLPSLAM {
 struct Vec2_t { double v[2] = {0, 0}; double& operator()(int i) { return v[i]; } double operator()(int i) const { return v[i]; } };
@@ -9,6 +10,13 @@ struct Vec3_t {
     double& operator()(int i) { return v[i]; }
     double operator()(int i) const { return v[i]; }
     Vec3_t operator+(const Vec3_t& o) const { Vec3_t r; for (int i = 0; i < 3; ++i) r.v[i] = v[i] + o.v[i]; return r; }
+};
+inline Vec3_t operator*(double a, const Vec3_t& x) { Vec3_t r; for (int i = 0; i < 3; ++i) r.v[i] = a * x.v[i]; return r; }
+struct Vec6_t {
+    double v[6] = {0, 0, 0, 0, 0, 0};
+    double& operator()(int i) { return v[i]; }
+    template <int N> Vec3_t head() const { static_assert(N == 3, "head<3> only"); Vec3_t r; for (int i = 0; i < 3; ++i) r.v[i] = v[i]; return r; }
+    template <int N> Vec3_t tail() const { static_assert(N == 3, "tail<3> only"); Vec3_t r; for (int i = 0; i < 3; ++i) r.v[i] = v[3 + i]; return r; }
 };
 struct Mat33_t {
     double m[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};

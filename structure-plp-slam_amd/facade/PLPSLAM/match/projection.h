@@ -1,8 +1,9 @@
-// Drop-in replacement of the reference header src/PLPSLAM/match/projection.h for the two calls the tracker makes every
-// frame: projection::match_frame_and_landmarks (projection.cc:37-121, called from tracking_module::search_local_landmarks)
-// and projection::match_current_and_last_frames (projection.cc:214-358, called from frame_tracker::motion_based_track).
-// Same class name, constructor, method names, argument meaning and return value; the search itself runs in
-// libplp_front.so (PLP_MATCH_MODE_LANDMARKS / PLP_MATCH_MODE_LAST_FRAME through plp_match_host).
+// Drop-in replacement of the reference header src/PLPSLAM/match/projection.h for the calls the tracker makes every
+// frame: projection::match_frame_and_landmarks[_line] (projection.cc:37-121, 124-212, called from
+// tracking_module::search_local_landmarks) and projection::match_current_and_last_frames[_line] (projection.cc:214-358,
+// 361-527, called from frame_tracker::motion_based_track).  Same class name, constructor, method names, argument meaning
+// and return value; the search itself runs in libplp_front.so (PLP_MATCH_MODE_LANDMARKS[_LINE] /
+// PLP_MATCH_MODE_LAST_FRAME[_LINE] through plp_match_host).
 //
 // The methods are templates on the frame / landmark types: inside the reference tree they are instantiated with
 // data::frame and data::landmark (the call sites compile unchanged), and they only touch the members the reference's own
@@ -75,6 +76,27 @@ struct frame_targets {
             const unsigned char* row = frm.descriptors_.template ptr<unsigned char>(i);
             for (int k = 0; k < 32; ++k) desc[static_cast<size_t>(i) * 32 + k] = row[k];
             const auto* lm = frm.landmarks_.at(i);
+            occupied[i] = (lm && lm->has_observation()) ? 1 : 0;
+        }
+    }
+};
+
+// the current frame's key lines as targets: _keylsd, _lbd_descr, "has a line landmark with observations"
+template <class Frame>
+struct frame_line_targets {
+    std::vector<uint8_t> desc, occupied;
+    const plp_keyline* kl;
+    int n;
+    explicit frame_line_targets(const Frame& frm) {
+        n = static_cast<int>(frm._keylsd.size());
+        static_assert(sizeof(frm._keylsd[0]) == sizeof(plp_keyline), "KeyLine must be the 68-byte record of descriptor_custom.hpp");
+        kl = reinterpret_cast<const plp_keyline*>(frm._keylsd.data());
+        desc.resize(static_cast<size_t>(n) * 32);
+        occupied.resize(static_cast<size_t>(n));
+        for (int i = 0; i < n; ++i) {
+            const unsigned char* row = frm._lbd_descr.template ptr<unsigned char>(i);
+            for (int k = 0; k < 32; ++k) desc[static_cast<size_t>(i) * 32 + k] = row[k];
+            const auto* lm = frm._landmarks_line.at(i);
             occupied[i] = (lm && lm->has_observation()) ? 1 : 0;
         }
     }
@@ -181,6 +203,118 @@ public:
             if (out[i] >= 0) curr_frm.landmarks_.at(i) = lms[static_cast<size_t>(out[i])];
             else if (out[i] == -2) curr_frm.landmarks_.at(i) = nullptr;     // matched, then removed by the orientation check (:350-354)
         }
+        return static_cast<unsigned int>(num);
+    }
+
+    //! projection.cc:124-212
+    template <class Frame, class Line>
+    unsigned int match_frame_and_landmarks_line(Frame& frm, const std::vector<Line*>& local_landmarks_line, const float margin = 5.0) const {
+        if (local_landmarks_line.empty()) return 0;
+        std::vector<Line*> lms;
+        std::vector<float> sp, ep;
+        std::vector<int32_t> level;
+        std::vector<uint8_t> desc, has_obs;
+        for (auto local_lm_line : local_landmarks_line) {
+            if (!local_lm_line->_is_observable_in_tracking) continue;
+            if (local_lm_line->will_be_erased()) continue;
+            lms.push_back(local_lm_line);
+            sp.push_back(static_cast<float>(local_lm_line->_reproj_in_tracking_sp(0))); sp.push_back(static_cast<float>(local_lm_line->_reproj_in_tracking_sp(1)));
+            ep.push_back(static_cast<float>(local_lm_line->_reproj_in_tracking_ep(0))); ep.push_back(static_cast<float>(local_lm_line->_reproj_in_tracking_ep(1)));
+            level.push_back(static_cast<int32_t>(local_lm_line->_scale_level_in_tracking));
+            const auto lm_desc = local_lm_line->get_descriptor();
+            const unsigned char* p = lm_desc.template ptr<unsigned char>(0);
+            desc.insert(desc.end(), p, p + 32);
+            has_obs.push_back(local_lm_line->has_observation() ? 1 : 0);
+        }
+        const detail::frame_line_targets<Frame> T(frm);
+        if (lms.empty() || T.n == 0) return 0;
+        // the reference reads undist_keypts_.at(idx).octave with a LINE index for the ratio test (:187, :192)
+        std::vector<int32_t> kp_octave(static_cast<size_t>(T.n));
+        for (int i = 0; i < T.n; ++i) kp_octave[i] = frm.undist_keypts_.at(i).octave;
+        std::vector<int32_t> out(static_cast<size_t>(T.n), -1);
+        int32_t num = 0;
+        plp_match_args a{};
+        a.mode = PLP_MATCH_MODE_LANDMARKS_LINE; a.B = 1; a.n_cap = T.n; a.m_cap = static_cast<int32_t>(lms.size());
+        a.t_kl = T.kl; a.t_desc = T.desc.data(); a.t_occupied = T.occupied.data(); a.t_kp_octave = kp_octave.data();
+        a.q_reproj = sp.data(); a.q_reproj2 = ep.data(); a.q_level = level.data(); a.q_desc = desc.data(); a.q_has_obs = has_obs.data();
+        a.margin = margin; a.lowe_ratio = lowe_ratio_;
+        a.num_levels = static_cast<int32_t>(frm._scale_factors_lsd.size()); a.scale_factors = frm._scale_factors_lsd.data();
+        a.grid = detail::grid_of(frm.camera_);
+        a.out_match = out.data(); a.out_num = &num;
+        detail::check(plp_match_host(detail::shared_matcher(), &a));
+        for (int i = 0; i < T.n; ++i)
+            if (out[i] >= 0) frm._landmarks_line.at(i) = lms[static_cast<size_t>(out[i])];
+        return static_cast<unsigned int>(num);
+    }
+
+    //! projection.cc:361-527
+    template <class Frame>
+    unsigned int match_current_and_last_frames_line(Frame& curr_frm, const Frame& last_frm, const float margin) const {
+        const Mat33_t rot_cw = curr_frm.cam_pose_cw_.template block<3, 3>(0, 0);
+        const Vec3_t trans_cw = curr_frm.cam_pose_cw_.template block<3, 1>(0, 3);
+        const Vec3_t trans_wc = -rot_cw.transpose() * trans_cw;
+        const Mat33_t rot_lw = last_frm.cam_pose_cw_.template block<3, 3>(0, 0);
+        const Vec3_t trans_lw = last_frm.cam_pose_cw_.template block<3, 1>(0, 3);
+        const Vec3_t trans_lc = rot_lw * trans_wc + trans_lw;
+        const int setup = static_cast<int>(curr_frm.camera_->setup_type_);        // 0 Monocular, 1 Stereo, 2 RGBD
+        const bool assume_forward = setup == 0 ? false : trans_lc(2) > curr_frm.camera_->true_baseline_;
+        const bool assume_backward = setup == 0 ? false : -trans_lc(2) > curr_frm.camera_->true_baseline_;
+
+        using LinePtr = typename std::decay<decltype(last_frm._landmarks_line.at(0))>::type;
+        std::vector<LinePtr> lms;
+        std::vector<float> sp, ep, xr_sp, xr_ep;
+        std::vector<int32_t> level;
+        std::vector<uint8_t> desc;
+        for (unsigned int idx_last = 0; idx_last < last_frm._num_keylines; ++idx_last) {
+            auto lm_line = last_frm._landmarks_line.at(idx_last);
+            if (!lm_line) continue;
+            if (last_frm._outlier_flags_line.at(idx_last)) continue;
+            const Vec6_t pos_w = lm_line->get_pos_in_world();
+            Vec2_t reproj_sp, reproj_ep;
+            float x_right_sp, x_right_ep;
+            const Vec3_t pos_sp = pos_w.template head<3>(), pos_ep = pos_w.template tail<3>();
+            const bool in_image_sp = curr_frm.camera_->reproject_to_image(rot_cw, trans_cw, pos_sp, reproj_sp, x_right_sp);
+            const bool in_image_ep = curr_frm.camera_->reproject_to_image(rot_cw, trans_cw, pos_ep, reproj_ep, x_right_ep);
+            if (!in_image_sp && !in_image_ep) continue;
+            if (!in_image_sp || !in_image_ep) {      // one end point outside: kept only if the mid point is visible (:397-412)
+                const Vec3_t pos_w_mp = 0.5 * (pos_sp + pos_ep);
+                Vec2_t reproj_mp;
+                float x_right_mp;
+                if (!curr_frm.camera_->reproject_to_image(rot_cw, trans_cw, pos_w_mp, reproj_mp, x_right_mp)) continue;
+            }
+            lms.push_back(lm_line);
+            sp.push_back(static_cast<float>(reproj_sp(0))); sp.push_back(static_cast<float>(reproj_sp(1)));
+            ep.push_back(static_cast<float>(reproj_ep(0))); ep.push_back(static_cast<float>(reproj_ep(1)));
+            xr_sp.push_back(x_right_sp); xr_ep.push_back(x_right_ep);
+            level.push_back(static_cast<int32_t>(last_frm._keylsd.at(idx_last).octave));
+            const auto lm_desc = lm_line->get_descriptor();
+            const unsigned char* p = lm_desc.template ptr<unsigned char>(0);
+            desc.insert(desc.end(), p, p + 32);
+        }
+        const detail::frame_line_targets<Frame> T(curr_frm);
+        if (lms.empty() || T.n == 0) return 0;
+        std::vector<float> t_xr(static_cast<size_t>(T.n)), t_xr2(static_cast<size_t>(T.n));
+        for (int i = 0; i < T.n; ++i) {
+            t_xr[i] = curr_frm._stereo_x_right_cooresponding_to_keylines.at(i).first;
+            t_xr2[i] = curr_frm._stereo_x_right_cooresponding_to_keylines.at(i).second;
+        }
+        std::vector<int32_t> out(static_cast<size_t>(T.n), -1);
+        int32_t num = 0;
+        plp_match_args a{};
+        a.mode = PLP_MATCH_MODE_LAST_FRAME_LINE; a.B = 1; a.n_cap = T.n; a.m_cap = static_cast<int32_t>(lms.size());
+        a.t_kl = T.kl; a.t_desc = T.desc.data(); a.t_occupied = T.occupied.data(); a.t_x_right = t_xr.data(); a.t_x_right2 = t_xr2.data();
+        a.q_reproj = sp.data(); a.q_reproj2 = ep.data(); a.q_x_right = xr_sp.data(); a.q_x_right2 = xr_ep.data(); a.q_level = level.data();
+        a.q_desc = desc.data();
+        a.margin = margin; a.lowe_ratio = lowe_ratio_;
+        a.direction = assume_forward ? 1 : (assume_backward ? 2 : 0);
+        a.is_rgbd = setup == 2 ? 1 : 0;
+        a.num_levels_lsd = static_cast<int32_t>(last_frm._num_scale_levels_lsd);
+        a.num_levels = static_cast<int32_t>(curr_frm._scale_factors_lsd.size()); a.scale_factors = curr_frm._scale_factors_lsd.data();
+        a.grid = detail::grid_of(curr_frm.camera_);
+        a.out_match = out.data(); a.out_num = &num;
+        detail::check(plp_match_host(detail::shared_matcher(), &a));
+        for (int i = 0; i < T.n; ++i)
+            if (out[i] >= 0) curr_frm._landmarks_line.at(i) = lms[static_cast<size_t>(out[i])];
         return static_cast<unsigned int>(num);
     }
 
