@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Randomised parity sweep on the GPU box: HIP path vs oracle on random frames / parameters / matcher problems.
-   python tools/fuzz_gpu.py --seconds 240 [--seed N]      -> prints one summary line per family, exit code 1 on any mismatch"""
+   python tools/fuzz_gpu.py --seconds 240 [--seed N] [--aux-seconds 120]
+   -> prints one summary line per family, exit code 1 on any mismatch.  --aux-seconds adds the steps either side of the
+   path: bag-of-words transform on random vocabularies, stereo rectification maps + remap on random calibrations."""
 import argparse, importlib, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
@@ -24,8 +26,81 @@ def rand_image(rng, h, w):
     return fr
 
 
+def aux_families(rng, seconds):
+    import ctypes as C
+    import torch
+    bad = 0
+    dev = torch.device("cuda", 0)
+    # ---- bag of words
+    t0, n = time.time(), 0
+    while time.time() - t0 < seconds / 2:
+        k, L = int(rng.integers(2, 24)), int(rng.integers(1, 7))
+        if k ** L > 200000:
+            L = max(1, int(np.log(200000) / np.log(k)))
+        weighting, scoring = int(rng.integers(0, 4)), int(rng.integers(0, 6))
+        parents, is_leaf, descs, weights = O.random_vocab(rng, k, L, p_leaf=float(rng.uniform(0, 0.4)), p_dup=float(rng.uniform(0, 0.3)),
+                                                          p_stop=float(rng.uniform(0, 0.2)), k_jitter=int(rng.integers(0, 3)) if k > 3 else 0)
+        if len(parents) < 2:
+            continue
+        v = plp.bow_vocabulary(L, parents, is_leaf, descs, weights, weighting, scoring)
+        B, cap = int(rng.integers(1, 6)), int(rng.integers(1, 2500))
+        levelsup = int(rng.integers(0, L + 2))
+        desc = rng.integers(0, 256, (B, cap, 32), dtype=np.uint8)
+        leaves = np.flatnonzero(is_leaf)
+        rep = rng.uniform(size=(B, cap)) < 0.3
+        desc[rep] = descs[rng.choice(leaves, int(rep.sum()))]
+        counts = rng.integers(0, cap + 1, B).astype(np.int32)
+        out = v.transform_device(torch.from_numpy(desc).to(dev), torch.from_numpy(counts).to(dev), levelsup)
+        torch.cuda.synchronize()
+        got = {kk: vv.cpu().numpy() for kk, vv in out.items()}
+        for b in range(B):
+            c = int(counts[b])
+            wid, nid, bw, bv, fn, ff = O.bow_transform(v.child_offset, v.children, v.node_desc, v.node_weight, v.node_word, v.L, desc[b][:c], levelsup,
+                                                       v.accumulate, v.norm)
+            ok = (np.array_equal(got["word_id"][b][:c].view(np.uint32), wid) and np.array_equal(got["node_id"][b][:c].view(np.uint32), nid)
+                  and got["n_bow"][b] == len(bw) and got["n_fv"][b] == len(fn) and np.array_equal(got["bow_word"][b][:len(bw)].view(np.uint32), bw)
+                  and np.array_equal(got["bow_value"][b][:len(bw)], bv) and np.array_equal(got["fv_node"][b][:len(fn)].view(np.uint32), fn)
+                  and np.array_equal(got["fv_feat"][b][:len(ff)].view(np.uint32), ff))
+            if not ok:
+                bad += 1; print("BOW MISMATCH", k, L, weighting, scoring, levelsup, cap, c)
+            n += 1
+    print(f"bow: {n} random frames on random vocabularies, mismatches so far {bad}")
+    # ---- rectification maps and remap
+    t0, n = time.time(), 0
+    mt = plp.matcher()
+    while time.time() - t0 < seconds / 2:
+        rows, cols = int(rng.integers(8, 520)), int(rng.integers(8, 800))
+        f = float(rng.uniform(150, 900))
+        K = np.array([f, 0, cols / 2 + rng.uniform(-20, 20), 0, f * rng.uniform(0.97, 1.03), rows / 2 + rng.uniform(-20, 20), 0, 0, 1])
+        nd = int(rng.choice([0, 4, 5, 8, 12]))
+        D = (rng.normal(size=12) * np.array([0.2, 0.1, 2e-3, 2e-3, 0.05, 0.02, 0.01, 0.01, 1e-3, 1e-3, 1e-3, 1e-3]))[:nd]
+        ax = rng.normal(size=3) * 0.03
+        th = np.linalg.norm(ax); kx = ax / th
+        Kx = np.array([[0, -kx[2], kx[1]], [kx[2], 0, -kx[0]], [-kx[1], kx[0], 0]])
+        R = (np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx).ravel()
+        cam = dict(fx=f * rng.uniform(0.9, 1.1), fy=f * rng.uniform(0.9, 1.1), cx=cols / 2 + rng.uniform(-5, 5), cy=rows / 2 + rng.uniform(-5, 5))
+        c = plp.camera_c()
+        for kk, vv in cam.items():
+            setattr(c, kk, float(vv))
+        d_mx = torch.zeros((rows, cols), dtype=torch.float32, device=dev); d_my = torch.zeros_like(d_mx)
+        plp._check(plp.lib().plp_rectify_map_device(mt._h, plp._p(K), plp._p(D) if nd else None, nd, plp._p(R), C.byref(c), rows, cols, d_mx.data_ptr(),
+                                                    d_my.data_ptr(), cols * 4, None))
+        src = rand_image(rng, rows, cols) if rows >= 120 and cols >= 160 else rng.integers(0, 256, (rows, cols), dtype=np.uint8)
+        d_src = torch.from_numpy(np.ascontiguousarray(src)).to(dev); d_out = torch.zeros((rows, cols), dtype=torch.uint8, device=dev)
+        plp._check(plp.lib().plp_remap_linear_device(mt._h, d_src.data_ptr(), rows, cols, cols, rows * cols, d_mx.data_ptr(), d_my.data_ptr(), cols * 4,
+                                                     rows, cols, 1, d_out.data_ptr(), cols, rows * cols, None))
+        torch.cuda.synchronize()
+        mx, my = O.rectify_map(K, D, R, cam, rows, cols)
+        ok = np.array_equal(d_mx.cpu().numpy(), mx) and np.array_equal(d_my.cpu().numpy(), my) and np.array_equal(d_out.cpu().numpy(), O.remap_linear(src, mx, my))
+        if not ok:
+            bad += 1; print("RECTIFY MISMATCH", rows, cols, nd)
+        n += 1
+    print(f"rectify: {n} random calibrations / frames, mismatches so far {bad}")
+    return bad
+
+
 def main():
-    ap = argparse.ArgumentParser(); ap.add_argument("--seconds", type=float, default=120); ap.add_argument("--seed", type=int, default=0)
+    ap = argparse.ArgumentParser(); ap.add_argument("--seconds", type=float, default=120); ap.add_argument("--seed", type=int, default=0); ap.add_argument("--aux-seconds", type=float, default=0.0)
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     budget = a.seconds / 3
@@ -87,6 +162,8 @@ def main():
             bad += 1; print("LAST_FRAME MISMATCH", nt, m, margin, d, chk)
         n += 1
     print(f"matchers: {n} random problems x 2 modes, mismatches so far {bad}")
+    if a.aux_seconds > 0:
+        bad += aux_families(rng, a.aux_seconds)
     sys.exit(1 if bad else 0)
 
 
