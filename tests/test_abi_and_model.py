@@ -32,6 +32,12 @@ def test_no_gpu_is_loud():
     with pytest.raises(plp.PlpError) as e:
         plp.orb_extractor()
     assert e.value.status == plp.PLP_ERR_NO_DEVICE
+    # every other context of the product path refuses as well: there is no CPU fallback anywhere
+    for make in (plp.LineFeatureTracker, plp.matcher,
+                 lambda: plp.bow_vocabulary(1, [-1, 0, 0], [False, True, True], np.zeros((3, 32), np.uint8), [0.0, 1.0, 1.0])):
+        with pytest.raises(plp.PlpError) as e:
+            make()
+        assert e.value.status in (plp.PLP_ERR_NO_DEVICE, plp.PLP_ERR_HIP)
 
 
 def test_param_validation_matches_orb_params():
