@@ -248,11 +248,7 @@ __device__ __forceinline__ void topk_merge_store(unsigned long long (&top)[kMatc
 
 // Fallback for frames with more key points than the LDS staging of k_match_topk_lds holds:
 // grid = (ceil(m_cap / 4), B), block = 256: one wave per query, targets read from HBM/L2.
-__global__ __launch_bounds__(256) void k_match_topk(MatchProblem P) {
-    const int lane = threadIdx.x & 63, b = blockIdx.y;
-    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int m = P.q_counts ? P.q_counts[b] : P.m_cap;
-    if (q >= m) return;
+__device__ __forceinline__ void match_topk_query(const MatchProblem& P, int b, int q, int lane) {
     uint32_t* klist = P.klist + ((size_t)b * P.m_cap + q) * kMatchK;
     int32_t* kcount = P.kcount + (size_t)b * P.m_cap + q;
     const uint8_t* q_valid = P.q_valid ? P.q_valid + (size_t)b * P.m_cap : nullptr;
@@ -280,6 +276,14 @@ __global__ __launch_bounds__(256) void k_match_topk(MatchProblem P) {
     for (int o = 32; o > 0; o >>= 1) passed += __shfl_xor(passed, o);
     topk_merge_store(top, lane, klist);
     if (lane == 0) *kcount = passed;
+}
+
+// grid = (gx, B) with gx <= ceil(m_cap / 4): the waves of a frame stride over its queries, so a batch of frames with few
+// queries each (key lines: ~50 of a 512 capacity) does not launch hundreds of thousands of workgroups that only exit.
+__global__ __launch_bounds__(256) void k_match_topk(MatchProblem P) {
+    const int lane = threadIdx.x & 63, b = blockIdx.y;
+    const int m = P.q_counts ? P.q_counts[b] : P.m_cap;
+    for (int q = blockIdx.x * 4 + (threadIdx.x >> 6); q < m; q += gridDim.x * 4) match_topk_query(P, b, q, lane);
 }
 
 // Main path.  k_match_prep buckets each frame's free, in-grid targets by grid ROW once (counting sort with LDS
@@ -919,8 +923,10 @@ void launch_match(hipStream_t st, const MatchProblem& P, int B) {
         hipLaunchKernelGGL(k_match_topk_cells, qgrid, dim3(256), staged, st, P);
     } else if (!line && !windowed && staged <= 64 * 1024) {
         hipLaunchKernelGGL(k_match_topk_lds, qgrid, dim3(256), staged, st, P);
-    } else
-        hipLaunchKernelGGL(k_match_topk, dim3((P.m_cap + 3) / 4, B), dim3(256), 0, st, P);
+    } else {
+        const int gx_full = (P.m_cap + 3) / 4, gx_min = std::max(16, (8192 + B - 1) / B);   // keep >= ~8K workgroups in flight
+        hipLaunchKernelGGL(k_match_topk, dim3(std::min(gx_full, gx_min), B), dim3(256), 0, st, P);
+    }
     static bool attr_set = false;   // up to 8192 targets: 96 KB of owner arrays
     if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_match_resolve), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 12); attr_set = true; }
     hipLaunchKernelGGL(k_match_resolve, dim3(B), dim3(256), (size_t)P.n_cap * 12, st, Q);
