@@ -18,8 +18,6 @@
 
 #include "PLPSLAM/match/projection.h"
 
-using namespace PLPSLAM;
-
 extern "C" {
 struct OKeyPoint { float x, y, size, angle, response; int octave, class_id; };
 unsigned oracle_match_frame_and_landmarks(const double* grid6, const OKeyPoint* kps, const uint8_t* desc, const float* x_right,
@@ -43,6 +41,7 @@ unsigned oracle_match_current_and_last(const double* grid6, const OKeyPoint* kps
                                        int check_orientation, int* kp_last);
 }
 
+namespace PLPSLAM {
 namespace camera {
 enum class setup_type_t { Monocular = 0, Stereo = 1, RGBD = 2 };
 struct image_bounds { float min_x_ = 0, max_x_ = 0, min_y_ = 0, max_y_ = 0; };
@@ -116,6 +115,9 @@ struct frame {
     Mat44_t cam_pose_cw_;
 };
 }  // namespace data
+}  // namespace PLPSLAM
+
+using namespace PLPSLAM;
 
 namespace {
 

@@ -24,8 +24,41 @@
 #include <type_traits>
 #include <vector>
 
+#include <set>
+
 #include "PLPSLAM/type.h"
+#if defined(__has_include)
+#if __has_include("PLPSLAM/match/base.h")
+#include "PLPSLAM/match/base.h"     // the reference's own base class and Hamming constants (match/base.h:12-84)
+#define PLP_FACADE_HAS_MATCH_BASE 1
+#endif
+#endif
 #include "plp_front.h"
+
+#ifndef PLP_FACADE_HAS_MATCH_BASE
+namespace PLPSLAM {
+namespace match {
+class base {   // stand-in with the members of match/base.h:70-82, for builds outside the reference tree
+public:
+    base(const float lowe_ratio, const bool check_orientation) : lowe_ratio_(lowe_ratio), check_orientation_(check_orientation) {}
+    virtual ~base() = default;
+
+protected:
+    const float lowe_ratio_;
+    const bool check_orientation_;
+};
+}  // namespace match
+}  // namespace PLPSLAM
+#endif
+
+namespace PLPSLAM {
+namespace data {
+class frame;
+class keyframe;
+class landmark;
+class Line;
+}  // namespace data
+}  // namespace PLPSLAM
 
 namespace PLPSLAM {
 namespace match {
@@ -104,11 +137,22 @@ struct frame_line_targets {
 
 }  // namespace detail
 
-class projection {
+class projection final : public base {
 public:
-    explicit projection(const float lowe_ratio = 0.6, const bool check_orientation = true)
-        : lowe_ratio_(lowe_ratio), check_orientation_(check_orientation) {}
-    ~projection() = default;
+    explicit projection(const float lowe_ratio = 0.6, const bool check_orientation = true) : base(lowe_ratio, check_orientation) {}
+    ~projection() final = default;
+
+    // The key-frame matchers keep their reference declarations and their bodies in the reference's match/projection.cc
+    // (:529-1142; only the four per-frame functions are deleted from that file).  Their searches are available through the
+    // C ABI as well, but they are not on the per-frame path.
+    unsigned int match_frame_and_keyframe(data::frame& curr_frm, data::keyframe* keyfrm, const std::set<data::landmark*>& already_matched_lms,
+                                          const float margin, const unsigned int hamm_dist_thr) const;
+    unsigned int match_frame_and_keyframe_line(data::frame& curr_frm, data::keyframe* keyfrm, const std::set<data::Line*>& already_matched_lms,
+                                               const float margin, const unsigned int hamm_dist_thr) const;
+    unsigned int match_by_Sim3_transform(data::keyframe* keyfrm, const Mat44_t& Sim3_cw, const std::vector<data::landmark*>& landmarks,
+                                         std::vector<data::landmark*>& matched_lms_in_keyfrm, const float margin) const;
+    unsigned int match_keyframes_mutually(data::keyframe* keyfrm_1, data::keyframe* keyfrm_2, std::vector<data::landmark*>& matched_lms_in_keyfrm_1,
+                                          const float& s_12, const Mat33_t& rot_12, const Vec3_t& trans_12, const float margin) const;
 
     //! projection.cc:37-121
     template <class Frame, class Landmark>
@@ -317,10 +361,6 @@ public:
             if (out[i] >= 0) curr_frm._landmarks_line.at(i) = lms[static_cast<size_t>(out[i])];
         return static_cast<unsigned int>(num);
     }
-
-protected:
-    const float lowe_ratio_;
-    const bool check_orientation_;
 };
 
 }  // namespace match
