@@ -680,8 +680,7 @@ __global__ __launch_bounds__(256) void k_stereo_median(StereoArgs A) {
     float* dp_out = A.depth + (size_t)b * A.cap;
     hist[tid] = 0;
     __syncthreads();
-    int mine = 0;
-    for (int i = tid; i < nl; i += 256) { const int c = corr[i]; if (c >= 0) { ++mine; atomicAdd(&hist[min(c >> 8, 255)], 1); } }
+    for (int i = tid; i < nl; i += 256) { const int c = corr[i]; if (c >= 0) atomicAdd(&hist[min(c >> 8, 255)], 1); }
     __syncthreads();
     if (tid == 0) {
         int total = 0;
