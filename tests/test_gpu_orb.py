@@ -136,3 +136,19 @@ def test_empty_image_is_noop():
     ex = plp.orb_extractor()
     k, d = ex.extract(np.zeros((0, 0), np.uint8))
     assert len(k) == 0 and len(d) == 0
+
+
+def test_extract_equals_committed_reference_vectors(golden_dir):
+    """HIP path vs tests/golden/ref_orb.npz, the output of the reference's own ORB sources on the fixture frames
+    (tools/make_golden_ref.py): bit-exact key points (position, size, angle, response, octave) and descriptors."""
+    z = np.load(golden_dir / "ref_orb.npz")
+    n = 0
+    for key in sorted(k for k in z.files if k.endswith("__kps")):
+        name, K = key.split("__")[0], int(key.split("__")[1][1:])
+        want_k = np.ascontiguousarray(z[key]).view(O.KP_DTYPE).reshape(-1)
+        want_d = z[key.replace("__kps", "__desc")]
+        img = np.asarray(Image.open(golden_dir / f"{name}.png").convert("L"), dtype=np.uint8)
+        kps, desc = plp.orb_extractor(K).extract(img)
+        assert len(kps) == len(want_k) and np.array_equal(kps, want_k) and np.array_equal(desc, want_d), (name, K)
+        n += 1
+    assert n == 6

@@ -191,3 +191,23 @@ def test_empty_image_is_noop():
     ex = O.OrbOracle()
     kps, desc = ex.extract(np.zeros((0, 0), np.uint8))
     assert len(kps) == 0
+
+
+def _golden_ref_cases(golden_dir):
+    z = np.load(golden_dir / "ref_orb.npz")
+    for key in sorted(k for k in z.files if k.endswith("__kps")):
+        name, K = key.split("__")[0], int(key.split("__")[1][1:])
+        kps = np.ascontiguousarray(z[key]).view(O.KP_DTYPE).reshape(-1)
+        yield name, K, kps, z[key.replace("__kps", "__desc")]
+
+
+def test_oracle_equals_committed_reference_vectors(golden_dir):
+    """tests/golden/ref_orb.npz = key points and descriptors of the reference's OWN ORB sources (oracle/_ref, made by
+    tools/make_golden_ref.py where /root/reference is mounted) on the fixture frames: the pin travels with the repository."""
+    n = 0
+    for name, K, kps, desc in _golden_ref_cases(golden_dir):
+        img = np.asarray(Image.open(golden_dir / f"{name}.png").convert("L"), dtype=np.uint8)
+        ok, od = O.OrbOracle(K).extract(img)
+        assert len(ok) == len(kps) and np.array_equal(ok, kps) and np.array_equal(od, desc), (name, K)
+        n += 1
+    assert n == 6
