@@ -9,9 +9,61 @@
 #include <cstdlib>
 #include <vector>
 
+#include <string>
+
 #include "PLPSLAM/feature/orb_extractor.h"
+#include "PLPSLAM/match/stereo.h"
+
+// facade_orb_check stereo <left raw> <right raw> <rows> <cols> <max_kp> <focal_x_baseline> <true_baseline> <out file>
+// two extractor facades + the match::stereo facade, wired exactly like the stereo data::frame constructor (data/frame.cc:250-281)
+static int stereo_main(int argc, char** argv) {
+    if (argc < 10) return 2;
+    const int rows = std::atoi(argv[4]), cols = std::atoi(argv[5]), K = std::atoi(argv[6]);
+    const float fxb = (float)std::atof(argv[7]), tb = (float)std::atof(argv[8]);
+    std::vector<unsigned char> bl((size_t)rows * cols), br((size_t)rows * cols);
+    FILE* f = std::fopen(argv[2], "rb");
+    if (!f || std::fread(bl.data(), 1, bl.size(), f) != bl.size()) return 3;
+    std::fclose(f);
+    f = std::fopen(argv[3], "rb");
+    if (!f || std::fread(br.data(), 1, br.size(), f) != br.size()) return 3;
+    std::fclose(f);
+    try {
+        auto* extractor_left = new PLPSLAM::feature::orb_extractor(K, 1.2f, 8, 20, 7);
+        auto* extractor_right = new PLPSLAM::feature::orb_extractor(K, 1.2f, 8, 20, 7);
+        cv::Mat left(rows, cols, CV_8UC1, bl.data()), right(rows, cols, CV_8UC1, br.data());
+        std::vector<cv::KeyPoint> keypts, keypts_right;
+        cv::Mat descriptors, descriptors_right;
+        extractor_left->extract(cv::_InputArray(left), cv::_InputArray(), keypts, cv::_OutputArray(descriptors));
+        extractor_right->extract(cv::_InputArray(right), cv::_InputArray(), keypts_right, cv::_OutputArray(descriptors_right));
+        const std::vector<float> scale_factors = extractor_left->get_scale_factors(), inv_scale_factors = extractor_left->get_inv_scale_factors();
+        std::vector<float> stereo_x_right, depths;
+        PLPSLAM::match::stereo stereo_matcher(extractor_left->image_pyramid_, extractor_right->image_pyramid_, keypts, keypts_right, descriptors,
+                                              descriptors_right, scale_factors, inv_scale_factors, fxb, tb);
+        stereo_matcher.compute(stereo_x_right, depths);
+        bool refused = false;      // pyramids that do not belong to an extractor are refused loudly
+        try {
+            std::vector<cv::Mat> stray(8);
+            PLPSLAM::match::stereo bad(stray, extractor_right->image_pyramid_, keypts, keypts_right, descriptors, descriptors_right, scale_factors,
+                                       inv_scale_factors, fxb, tb);
+        } catch (const std::runtime_error&) { refused = true; }
+        delete extractor_left; delete extractor_right;
+        if (!refused) return 5;
+        FILE* o = std::fopen(argv[9], "wb");
+        if (!o) return 4;
+        const int n = (int)keypts.size(), nr = (int)keypts_right.size();
+        std::fwrite(&n, 4, 1, o); std::fwrite(&nr, 4, 1, o);
+        std::fwrite(stereo_x_right.data(), 4, stereo_x_right.size(), o);
+        std::fwrite(depths.data(), 4, depths.size(), o);
+        std::fclose(o);
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "facade_orb_check stereo: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}
 
 int main(int argc, char** argv) {
+    if (argc > 1 && std::string(argv[1]) == "stereo") return stereo_main(argc, argv);
     if (argc < 6) return 2;
     const int rows = std::atoi(argv[2]), cols = std::atoi(argv[3]), K = std::atoi(argv[4]);
     std::vector<unsigned char> buf((size_t)rows * cols);

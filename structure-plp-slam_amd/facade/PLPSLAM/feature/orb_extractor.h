@@ -12,6 +12,7 @@
 #include <opencv2/core.hpp>
 
 #include "PLPSLAM/feature/orb_params.h"
+#include "PLPSLAM/feature/plp_registry.h"
 #include "plp_front.h"
 
 namespace PLPSLAM {
@@ -33,9 +34,10 @@ public:
                           rects.empty() ? nullptr : rects.data(), static_cast<int32_t>(p.mask_rects_.size())};
         check(plp_orb_create(&cp, device_from_env(), &ctx_));
         image_pyramid_.resize(p.num_levels_);
+        plp_registry::add(&image_pyramid_, ctx_);       // match::stereo is handed image_pyramid_ and finds the context by it
     }
 
-    virtual ~orb_extractor() { plp_orb_destroy(ctx_); }
+    virtual ~orb_extractor() { plp_registry::remove(&image_pyramid_); plp_orb_destroy(ctx_); }
     orb_extractor(const orb_extractor&) = delete;
     orb_extractor& operator=(const orb_extractor&) = delete;
 

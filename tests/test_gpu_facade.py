@@ -64,3 +64,30 @@ def test_cpp_matcher_facade_equals_oracle(seed, n, m):
         import re
         assert all(int(re.search(r"(\d+) matches", ln).group(1)) > 30 for ln in lines[:4])
         assert all(int(re.search(r"(\d+) matches", ln).group(1)) > 10 for ln in lines[4:])
+
+
+@pytest.mark.skipif(not os.path.exists(_EXE), reason="oracle/_ref/facade_orb_check not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("seed,K", [(0, 1000), (3, 2000)])
+def test_cpp_stereo_facade_equals_oracle(tmp_path, seed, K):
+    """Two feature::orb_extractor facades and the match::stereo facade wired like the stereo data::frame constructor
+    (data/frame.cc:250-281): stereo_x_right / depths equal the oracle's; a pyramid vector that does not belong to an
+    extractor is refused."""
+    from test_gpu_stereo_lbdmatch import stereo_pair
+    left, right = stereo_pair(seed)
+    rows, cols = left.shape
+    (tmp_path / "l.raw").write_bytes(np.ascontiguousarray(left).tobytes()); (tmp_path / "r.raw").write_bytes(np.ascontiguousarray(right).tobytes())
+    fxb, tb = 435.2 * 0.11 * 10, 0.11 * 10
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = "/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    out = tmp_path / "s.bin"
+    r = subprocess.run([_EXE, "stereo", str(tmp_path / "l.raw"), str(tmp_path / "r.raw"), str(rows), str(cols), str(K), repr(fxb), repr(tb), str(out)],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr
+    b = out.read_bytes()
+    n, nr = struct.unpack_from("<ii", b, 0)
+    xr = np.frombuffer(b, np.float32, n, 8); dp = np.frombuffer(b, np.float32, n, 8 + 4 * n)
+    ol, orr = O.OrbOracle(K), O.OrbOracle(K)
+    kl, dl = ol.extract(left); kr, dr = orr.extract(right)
+    want_x, want_d = O.stereo_compute(ol, orr, kl, kr, dl, dr, np.float32(fxb), np.float32(tb))
+    assert n == len(kl) and nr == len(kr) and (want_x > 0).sum() > 100
+    assert np.array_equal(xr, want_x) and np.array_equal(dp, want_d)
