@@ -7,6 +7,8 @@ namespace PLPSLAM {
 struct Vec2_t { double v[2] = {0, 0}; double& operator()(int i) { return v[i]; } double operator()(int i) const { return v[i]; } };
 struct Vec3_t {
     double v[3] = {0, 0, 0};
+    Vec3_t() = default;
+    Vec3_t(double x, double y, double z) : v{x, y, z} {}
     double& operator()(int i) { return v[i]; }
     double operator()(int i) const { return v[i]; }
     Vec3_t operator+(const Vec3_t& o) const { Vec3_t r; for (int i = 0; i < 3; ++i) r.v[i] = v[i] + o.v[i]; return r; }

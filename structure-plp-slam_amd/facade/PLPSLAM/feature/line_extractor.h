@@ -4,6 +4,7 @@
 #ifndef PLPSLAM_FEATURE_LINE_EXTRACTOR_H
 #define PLPSLAM_FEATURE_LINE_EXTRACTOR_H
 
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 #include <vector>

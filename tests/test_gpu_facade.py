@@ -91,3 +91,30 @@ def test_cpp_stereo_facade_equals_oracle(tmp_path, seed, K):
     want_x, want_d = O.stereo_compute(ol, orr, kl, kr, dl, dr, np.float32(fxb), np.float32(tb))
     assert n == len(kl) and nr == len(kr) and (want_x > 0).sum() > 100
     assert np.array_equal(xr, want_x) and np.array_equal(dp, want_d)
+
+
+_LINE_EXE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle", "facade_line_check")
+
+
+@pytest.mark.skipif(not os.path.exists(_LINE_EXE), reason="oracle/facade_line_check not built (make -C oracle after the product library)")
+@pytest.mark.parametrize("seed,shape", [(5, (480, 640)), (6, (376, 1241))])
+def test_cpp_line_facade_equals_oracle(tmp_path, seed, shape):
+    """structure-plp-slam_amd/facade/PLPSLAM/feature/line_extractor.h driven like data/frame.cc:1143-1167: key lines (all 17
+    fields), LBD rows and line functions equal the oracle's."""
+    img = synth.replay(seed, 1, *shape)[0]
+    raw, out = tmp_path / "img.raw", tmp_path / "out.bin"
+    raw.write_bytes(np.ascontiguousarray(img).tobytes())
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = "/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    r = subprocess.run([_LINE_EXE, str(raw), str(shape[0]), str(shape[1]), str(out)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr
+    b = out.read_bytes()
+    n, nl = struct.unpack_from("<ii", b, 0)
+    sf = struct.unpack_from("<f", b, 8)[0]
+    off = 12
+    kl = np.frombuffer(b, O.KL_DTYPE, n, off); off += 68 * n
+    lbd = np.frombuffer(b, np.uint8, 32 * n, off).reshape(n, 32); off += 32 * n
+    fn = np.frombuffer(b, np.float64, 3 * n, off).reshape(n, 3)
+    o = O.LineOracle(img)
+    assert nl == 1 and sf == 2.0 and n == len(o.keylsd) and n > 20
+    assert np.array_equal(kl, o.keylsd) and np.array_equal(lbd, o.lbd) and np.array_equal(fn, o.linefn)
