@@ -92,7 +92,7 @@ def main():
     out.append({"config": "configs[2] EuRoC stereo 752x480 x2 K=1000: 2x ORB, 2x LSD+LBD, stereo::compute, LBD 1-NN L<->R", "stereo_frames_per_s": round(B / sec, 1),
                 "ms_per_batch": round(sec * 1e3, 3), "keypoints_mean": round(float(cl.float().mean()), 1), "lines_mean": round(float(LL[3].float().mean()), 1),
                 "stereo_matches_mean": round(float((xr >= 0).float().sum(1).mean()), 1),
-                "line_matches_mean": round(float((tidx >= 0).float().sum(1).mean()), 1)})
+                "line_matches_mean": round(float(((tidx >= 0) & (torch.arange(tidx.shape[1], device=tidx.device)[None, :] < LL[3][:, None])).float().sum(1).mean()), 1)})
     del exl, exr, ltl, ltr, left, right
 
     # ---- configs[3]: KITTI mono 1241x376
