@@ -401,11 +401,15 @@ plp_status plp_convert_to_true_depth_device(plp_matcher* ctx, const void* d_src,
  * as read from the yaml; rect_cam = the rectified camera, whose fx, fy, cx, cy are rounded to float like
  * camera::perspective::cv_cam_matrix_ (perspective.cc:47).  Writes rows x cols CV_32F maps (map_step bytes per row).
  * plp_remap_linear_device = rectify()'s cv::remap(in, out, map_x, map_y, cv::INTER_LINEAR) (:83-84) on B 8UC1 frames that
- * share one map pair: 1/32-pixel fixed point, 15-bit weights, constant border 0.  The fisheye model (TUM-VI yaml) is not
- * provided: PLP_ERR_UNSUPPORTED is the caller's cue to keep cv::fisheye on the host.  Device pointers, asynchronous. */
+ * share one map pair: 1/32-pixel fixed point, 15-bit weights, constant border 0.  Device pointers, asynchronous. */
 plp_status plp_rectify_map_device(plp_matcher* ctx, const double* K, const double* D, int32_t n_dist, const double* R,
                                   const plp_camera* rect_cam, int32_t rows, int32_t cols, float* d_map_x, float* d_map_y, size_t map_step,
                                   void* hip_stream);
+/* The "fisheye" StereoRectifier.model (util/stereo_rectifier.cc:65-70, the TUM-VI yaml): cv::fisheye::initUndistortRectifyMap,
+ * equidistant model with 4 coefficients.  Not bit-defined like the perspective map: OpenCV inverts K_rect * R by SVD (here
+ * closed form) and the map goes through atan(); the tests hold it to 1e-4 px against the oracle.  The remap is the same. */
+plp_status plp_rectify_map_fisheye_device(plp_matcher* ctx, const double* K, const double* D4, const double* R, const plp_camera* rect_cam,
+                                          int32_t rows, int32_t cols, float* d_map_x, float* d_map_y, size_t map_step, void* hip_stream);
 plp_status plp_remap_linear_device(plp_matcher* ctx, const uint8_t* d_src, int32_t rows, int32_t cols, size_t src_step, size_t src_frame_stride,
                                    const float* d_map_x, const float* d_map_y, size_t map_step, int32_t dst_rows, int32_t dst_cols, int32_t B,
                                    uint8_t* d_dst, size_t dst_step, size_t dst_frame_stride, void* hip_stream);

@@ -310,6 +310,43 @@ int oracle_init_undistort_rectify_map(const double* K, const double* D, int n_di
     return 0;
 }
 
+// cv::fisheye::initUndistortRectifyMap(K, D(4), R, K_rect, size, CV_32F) (util/stereo_rectifier.cc:67-68, the TUM-VI
+// yaml): equidistant model theta_d = theta (1 + k1 theta^2 + k2 theta^4 + k3 theta^6 + k4 theta^8), restated from OpenCV
+// 4.x fisheye.cpp (the _w <= 0 branch of 4.5+ included).  Two things keep this one from being bit-defined: OpenCV inverts
+// K_rect * R with DECOMP_SVD (here: the closed-form 3x3 inverse, equal to ~1e-15 relative) and the map goes through
+// atan(), whose last bit differs between libm implementations -- the map is compared with a tolerance (tests: 1e-4 px).
+int oracle_fisheye_rectify_map(const double* K, const double* D4, const double* R, const double* K_rect_f32, int rows, int cols, float* map_x,
+                               float* map_y) {
+    double Ar[9], ArR[9], ir[9];
+    for (int i = 0; i < 9; ++i) Ar[i] = (double)(float)K_rect_f32[i];
+    matx33_mul(Ar, R, ArR);
+    if (!matx33_inv(ArR, ir)) return -1;
+    const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+    for (int i = 0; i < rows; ++i) {
+        double _x = i * ir[1] + ir[2], _y = i * ir[4] + ir[5], _w = i * ir[7] + ir[8];
+        for (int j = 0; j < cols; ++j) {
+            double u, v;
+            if (_w <= 0) {
+                u = (_x > 0) ? -std::numeric_limits<double>::infinity() : std::numeric_limits<double>::infinity();
+                v = (_y > 0) ? -std::numeric_limits<double>::infinity() : std::numeric_limits<double>::infinity();
+            } else {
+                const double x = _x / _w, y = _y / _w;
+                const double r = std::sqrt(x * x + y * y);
+                const double theta = std::atan(r);
+                const double theta2 = theta * theta, theta4 = theta2 * theta2, theta6 = theta4 * theta2, theta8 = theta4 * theta4;
+                const double theta_d = theta * (1 + D4[0] * theta2 + D4[1] * theta4 + D4[2] * theta6 + D4[3] * theta8);
+                const double scale = (r == 0) ? 1.0 : theta_d / r;
+                u = fx * x * scale + cx;
+                v = fy * y * scale + cy;
+            }
+            map_x[(size_t)i * cols + j] = (float)u;
+            map_y[(size_t)i * cols + j] = (float)v;
+            _x += ir[0]; _y += ir[3]; _w += ir[6];
+        }
+    }
+    return 0;
+}
+
 // cv::remap(src 8UC1, dst, map_x, map_y CV_32FC1, INTER_LINEAR, BORDER_CONSTANT, 0); dst has the maps' size
 void oracle_remap_linear(const uint8_t* src, int rows, int cols, size_t step, const float* map_x, const float* map_y, int drows, int dcols,
                          uint8_t* dst) {

@@ -87,6 +87,7 @@ _API = [
     ("plp_convert_to_grayscale_device", C.c_int, [_VP, _VP, _I32, _I32, C.c_size_t, C.c_size_t, _I32, _I32, _I32, _VP, C.c_size_t, C.c_size_t, _VP]),
     ("plp_convert_to_true_depth_device", C.c_int, [_VP, _VP, _I32, _I32, _I32, C.c_size_t, C.c_size_t, C.c_double, _I32, _VP, C.c_size_t, C.c_size_t, _VP]),
     ("plp_rectify_map_device", C.c_int, [_VP, _VP, _VP, _I32, _VP, _VP, _I32, _I32, _VP, _VP, C.c_size_t, _VP]),
+    ("plp_rectify_map_fisheye_device", C.c_int, [_VP, _VP, _VP, _VP, _VP, _I32, _I32, _VP, _VP, C.c_size_t, _VP]),
     ("plp_remap_linear_device", C.c_int, [_VP, _VP, _I32, _I32, C.c_size_t, C.c_size_t, _VP, _VP, C.c_size_t, _I32, _I32, _I32, _VP, C.c_size_t, C.c_size_t, _VP]),
     ("plp_bow_vocab_create", C.c_int, [C.c_int, _VP, _VP]),
     ("plp_bow_vocab_destroy", None, [_VP]),
@@ -544,13 +545,15 @@ class stereo_rectifier:
     """Mirror of util::stereo_rectifier: the constructor takes the rectified camera (fx, fy, cx, cy, cols, rows) and the
     yaml node's StereoRectifier.{K,D,R}_{left,right} lists and builds the two CV_32F map pairs in HBM
     (cv::initUndistortRectifyMap, :61-62); rectify() is the two cv::remap(INTER_LINEAR) calls (:83-84) on batches of 8-bit
-    frames.  StereoRectifier.model other than "perspective" raises, like an unknown model does in the reference (:108)."""
+    frames.  StereoRectifier.model "perspective" or "fisheye" (cv::fisheye::initUndistortRectifyMap, :67-68); anything else
+    raises, like the reference (:72-75, :108)."""
 
     def __init__(self, camera, yaml_node, device=0):
         import torch
         model = yaml_node.get("StereoRectifier.model", "perspective")
-        if model != "perspective":
-            raise PlpError(6, f"Invalid model type for stereo rectification on the device: {model}")
+        if model not in ("perspective", "fisheye"):     # "equirectangular" parses in the reference and then throws (:72-75)
+            raise PlpError(1, f"Invalid model type for stereo rectification: {model}")
+        self.model = model
         self._mt = matcher(device=device)
         self._dev = torch.device("cuda", device)
         self.rows, self.cols = int(camera["rows"]), int(camera["cols"])
@@ -566,8 +569,14 @@ class stereo_rectifier:
                 raise PlpError(1, "StereoRectifier.K / R must have 9 entries")
             mx = torch.empty((self.rows, self.cols), dtype=torch.float32, device=self._dev)
             my = torch.empty_like(mx)
-            _check(lib().plp_rectify_map_device(self._mt._h, _p(K), _p(D) if D.size else None, int(D.size), _p(R), C.byref(cam), self.rows, self.cols,
-                                                mx.data_ptr(), my.data_ptr(), self.cols * 4, None))
+            if model == "fisheye":
+                if D.size != 4:
+                    raise PlpError(1, "the fisheye model takes 4 distortion coefficients")
+                _check(lib().plp_rectify_map_fisheye_device(self._mt._h, _p(K), _p(D), _p(R), C.byref(cam), self.rows, self.cols, mx.data_ptr(),
+                                                            my.data_ptr(), self.cols * 4, None))
+            else:
+                _check(lib().plp_rectify_map_device(self._mt._h, _p(K), _p(D) if D.size else None, int(D.size), _p(R), C.byref(cam), self.rows,
+                                                    self.cols, mx.data_ptr(), my.data_ptr(), self.cols * 4, None))
             self.maps[eye] = (mx, my)
 
     def _remap(self, img, eye, stream=None):

@@ -414,12 +414,12 @@ plp_status plp_convert_to_true_depth_device(plp_matcher* c, const void* d_src, i
     return PLP_OK;
 }
 
-plp_status plp_rectify_map_device(plp_matcher* c, const double* K, const double* D, int32_t n_dist, const double* R, const plp_camera* rect_cam,
-                                  int32_t rows, int32_t cols, float* d_map_x, float* d_map_y, size_t map_step, void* hip_stream) {
+static plp_status rectify_map_impl(plp_matcher* c, const double* K, const double* D, int32_t n_dist, const double* R, const plp_camera* rect_cam,
+                                   int32_t rows, int32_t cols, float* d_map_x, float* d_map_y, size_t map_step, void* hip_stream, bool fisheye) {
     if (!c || !K || !R || !rect_cam || !d_map_x || !d_map_y || (n_dist > 0 && !D)) return set_error(PLP_ERR_INVALID_ARG, "NULL argument");
     if (rows <= 0 || cols <= 0 || map_step < (size_t)cols * 4 || (map_step & 3)) return set_error(PLP_ERR_INVALID_ARG, "bad geometry");
-    if (n_dist != 0 && n_dist != 4 && n_dist != 5 && n_dist != 8 && n_dist != 12)
-        return set_error(PLP_ERR_INVALID_ARG, "distortion vector must have 0, 4, 5, 8 or 12 entries");
+    if (fisheye ? n_dist != 4 : (n_dist != 0 && n_dist != 4 && n_dist != 5 && n_dist != 8 && n_dist != 12))
+        return set_error(PLP_ERR_INVALID_ARG, fisheye ? "the fisheye model takes 4 distortion coefficients" : "distortion vector must have 0, 4, 5, 8 or 12 entries");
     RectifyArgs A{};
     // iR = (K_rect * R)^-1, K_rect float-rounded; closed-form 3x3 inverse in the order cv::Matx evaluates it
     const double Ar[9] = {(double)(float)rect_cam->fx, 0, (double)(float)rect_cam->cx, 0, (double)(float)rect_cam->fy, (double)(float)rect_cam->cy, 0, 0, 1};
@@ -441,9 +441,19 @@ plp_status plp_rectify_map_device(plp_matcher* c, const double* K, const double*
     A.rows = rows; A.cols = cols; A.map_x = d_map_x; A.map_y = d_map_y; A.map_step = map_step;
     std::lock_guard<std::mutex> lk(c->mu);
     PLP_HIP(hipSetDevice(c->device));
-    launch_rectify_map((hipStream_t)hip_stream, A);
+    launch_rectify_map((hipStream_t)hip_stream, A, fisheye);
     PLP_HIP(hipGetLastError());
     return PLP_OK;
+}
+
+plp_status plp_rectify_map_device(plp_matcher* c, const double* K, const double* D, int32_t n_dist, const double* R, const plp_camera* rect_cam,
+                                  int32_t rows, int32_t cols, float* d_map_x, float* d_map_y, size_t map_step, void* hip_stream) {
+    return rectify_map_impl(c, K, D, n_dist, R, rect_cam, rows, cols, d_map_x, d_map_y, map_step, hip_stream, false);
+}
+
+plp_status plp_rectify_map_fisheye_device(plp_matcher* c, const double* K, const double* D4, const double* R, const plp_camera* rect_cam, int32_t rows,
+                                          int32_t cols, float* d_map_x, float* d_map_y, size_t map_step, void* hip_stream) {
+    return rectify_map_impl(c, K, D4, 4, R, rect_cam, rows, cols, d_map_x, d_map_y, map_step, hip_stream, true);
 }
 
 plp_status plp_remap_linear_device(plp_matcher* c, const uint8_t* d_src, int32_t rows, int32_t cols, size_t src_step, size_t src_frame_stride,

@@ -105,7 +105,7 @@ struct RectifyArgs {
     int rows, cols;
     float* map_x; float* map_y; size_t map_step;
 };
-void launch_rectify_map(hipStream_t st, const RectifyArgs& A);
+void launch_rectify_map(hipStream_t st, const RectifyArgs& A, bool fisheye);
 void launch_remap_linear(hipStream_t st, const uint8_t* src, int rows, int cols, size_t step, size_t fs, const float* map_x, const float* map_y,
                          size_t map_step, int drows, int dcols, int B, uint8_t* dst, size_t dst_step, size_t dst_fs);
 

@@ -249,6 +249,34 @@ __global__ __launch_bounds__(64) void k_rectify_map(RectifyArgs A) {
     }
 }
 
+// cv::fisheye::initUndistortRectifyMap (equidistant model), same walk along a row
+__global__ __launch_bounds__(64) void k_rectify_map_fisheye(RectifyArgs A) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= A.rows) return;
+    const double* ir = A.ir;
+    const double* d = A.d;
+    double _x = i * ir[1] + ir[2], _y = i * ir[4] + ir[5], _w = i * ir[7] + ir[8];
+    float* mx = reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(A.map_x) + (size_t)i * A.map_step);
+    float* my = reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(A.map_y) + (size_t)i * A.map_step);
+    const double inf = __longlong_as_double(0x7ff0000000000000ll);
+    for (int j = 0; j < A.cols; ++j, _x += ir[0], _y += ir[3], _w += ir[6]) {
+        double u, v;
+        if (_w <= 0) { u = (_x > 0) ? -inf : inf; v = (_y > 0) ? -inf : inf; }
+        else {
+            const double x = _x / _w, y = _y / _w;
+            const double r = sqrt(x * x + y * y);
+            const double theta = atan(r);
+            const double theta2 = theta * theta, theta4 = theta2 * theta2, theta6 = theta4 * theta2, theta8 = theta4 * theta4;
+            const double theta_d = theta * (1 + d[0] * theta2 + d[1] * theta4 + d[2] * theta6 + d[3] * theta8);
+            const double scale = (r == 0) ? 1.0 : theta_d / r;
+            u = A.fx * x * scale + A.u0;
+            v = A.fy * y * scale + A.v0;
+        }
+        mx[j] = (float)u;
+        my[j] = (float)v;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_remap_linear(const uint8_t* __restrict__ src, int rows, int cols, size_t step, size_t fs,
                                                       const float* __restrict__ map_x, const float* __restrict__ map_y, size_t map_step, int dcols,
                                                       uint8_t* __restrict__ dst, size_t dst_step, size_t dst_fs) {
@@ -282,8 +310,9 @@ __global__ __launch_bounds__(256) void k_remap_linear(const uint8_t* __restrict_
         for (int i = 0; i < 4 && x0 + i < dcols; ++i) d[i] = (uint8_t)(packed >> (8 * i));
 }
 
-void launch_rectify_map(hipStream_t st, const RectifyArgs& A) {
-    hipLaunchKernelGGL(k_rectify_map, dim3((A.rows + 63) / 64), dim3(64), 0, st, A);
+void launch_rectify_map(hipStream_t st, const RectifyArgs& A, bool fisheye) {
+    if (fisheye) hipLaunchKernelGGL(k_rectify_map_fisheye, dim3((A.rows + 63) / 64), dim3(64), 0, st, A);
+    else hipLaunchKernelGGL(k_rectify_map, dim3((A.rows + 63) / 64), dim3(64), 0, st, A);
 }
 void launch_remap_linear(hipStream_t st, const uint8_t* src, int rows, int cols, size_t step, size_t fs, const float* map_x, const float* map_y,
                          size_t map_step, int drows, int dcols, int B, uint8_t* dst, size_t dst_step, size_t dst_fs) {

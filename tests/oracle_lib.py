@@ -563,3 +563,28 @@ def bow_transform(child_offset, children, node_desc, node_weight, node_word, L, 
                                    _c(node_weight, np.float64), _c(node_word, np.uint32), desc if n else np.zeros(32, np.uint8), n, int(levelsup),
                                    int(accumulate), int(norm), word, node, bw, bv, cnt[0:1], fn, ff, cnt[1:2]])
     return word[:n], node[:n], bw[:cnt[0]], bv[:cnt[0]], fn[:cnt[1]], ff[:cnt[1]]
+
+
+# TUM-VI stereo calibration as quoted by the reference's example/tum_vi/TUM_VI_stereo.yaml (equidistant fisheye lenses)
+TUM_VI = {
+    "camera": dict(fx=61.75453410721205, fy=61.75453410721205, cx=240.22941720459062, cy=255.73235402091632, cols=512, rows=512),
+    "StereoRectifier.model": "fisheye",
+    "StereoRectifier.K_left": [190.97847715128717, 0.0, 254.93170605935475, 0.0, 190.9733070521226, 256.8974428996504, 0.0, 0.0, 1.0],
+    "StereoRectifier.D_left": [0.0034823894022493434, 0.0007150348452162257, -0.0020532361418706202, 0.00020293673591811182],
+    "StereoRectifier.R_left": [0.9997641946925044, 0.01925271884177015, 0.010044293307535757, -0.01901185247371587, 0.9995418997803748,
+                               -0.02354867403818772, -0.010493068014919314, 0.02335216051329943, 0.99967223234568],
+    "StereoRectifier.K_right": [190.44236969414825, 0.0, 252.59949716835982, 0.0, 190.4344384721956, 254.91723064636983, 0.0, 0.0, 1.0],
+    "StereoRectifier.D_right": [0.0034003170790442797, 0.001766278153469831, -0.00266312569781606, 0.0003299517423931039],
+    "StereoRectifier.R_right": [0.9997411981023351, 0.01955199401713946, 0.011629976219300583, -0.019819377433695273, 0.9995311538731381,
+                                0.02333805294307984, -0.011168218078479885, -0.023562511898925578, 0.9996599816627474],
+}
+
+
+def fisheye_rectify_map(K, D4, R, cam, rows, cols):
+    """cv::fisheye::initUndistortRectifyMap(K, D, R, K_rect(float), (cols, rows), CV_32F) -> map_x, map_y"""
+    K = _c(K, np.float64); D4 = _c(D4, np.float64); R = _c(R, np.float64)
+    Kr = np.array([cam["fx"], 0, cam["cx"], 0, cam["fy"], cam["cy"], 0, 0, 1], np.float64)
+    mx = np.zeros((rows, cols), np.float32); my = np.zeros((rows, cols), np.float32)
+    if _call("oracle_fisheye_rectify_map", [K, D4, R, Kr, rows, cols, mx, my], C.c_int) != 0:
+        raise ValueError("K_rect * R is singular")
+    return mx, my

@@ -92,6 +92,8 @@ def test_remap_borders_fractions_strides_and_errors():
         plp._check(L.plp_remap_linear_device(mt._h, d_src.data_ptr(), 0, cols, cols, 0, d_mx.data_ptr(), d_my.data_ptr(), dcols * 4, drows, dcols, 1,
                                              d_out.data_ptr(), dcols, 0, None))
     with pytest.raises(plp.PlpError):
+        plp.stereo_rectifier(O.EUROC["camera"], {**O.EUROC, "StereoRectifier.model": "equirectangular"})
+    with pytest.raises(plp.PlpError):                                        # the fisheye model has exactly 4 coefficients
         plp.stereo_rectifier(O.EUROC["camera"], {**O.EUROC, "StereoRectifier.model": "fisheye"})
     c = plp.camera_c(); c.fx = c.fy = 1.0
     with pytest.raises(plp.PlpError):                                        # singular K_rect * R
@@ -99,3 +101,26 @@ def test_remap_borders_fractions_strides_and_errors():
     with pytest.raises(plp.PlpError):                                        # 3 distortion coefficients
         plp._check(L.plp_rectify_map_device(mt._h, plp._p(np.eye(3).ravel()), plp._p(np.zeros(3)), 3, plp._p(np.eye(3).ravel()), C.byref(c), 4, 4,
                                             d_mx.data_ptr(), d_my.data_ptr(), 16, None))
+
+
+def test_tum_vi_fisheye_rectifier():
+    """cv::fisheye::initUndistortRectifyMap on the TUM-VI calibration: the map goes through atan() and is held to 1e-4 px
+    against the oracle (in practice all but a handful of the 2 x 512 x 512 floats are identical); the remap on the device's
+    own maps is exact."""
+    import torch
+    E = O.TUM_VI
+    cam = E["camera"]
+    rect = plp.stereo_rectifier(cam, E)
+    frames = synth.replay(8, 2, 512, 512)
+    dev = torch.device("cuda", 0)
+    d_l = torch.from_numpy(frames).to(dev); d_r = torch.from_numpy(np.ascontiguousarray(frames[:, ::-1])).to(dev)
+    out_l, out_r = rect.rectify(d_l, d_r)
+    torch.cuda.synchronize()
+    for eye, src, out in (("left", frames, out_l), ("right", frames[:, ::-1], out_r)):
+        mx, my = O.fisheye_rectify_map(E[f"StereoRectifier.K_{eye}"], E[f"StereoRectifier.D_{eye}"], E[f"StereoRectifier.R_{eye}"], cam, 512, 512)
+        gx, gy = rect.maps[eye][0].cpu().numpy(), rect.maps[eye][1].cpu().numpy()
+        assert np.abs(gx - mx).max() <= 1e-4 and np.abs(gy - my).max() <= 1e-4
+        assert (gx == mx).mean() > 0.99 and (gy == my).mean() > 0.99
+        for b in range(2):
+            assert np.array_equal(out[b].cpu().numpy(), O.remap_linear(src[b], gx, gy)), (eye, b)
+        assert out[0].cpu().numpy().any()

@@ -143,3 +143,25 @@ def test_rectify_map_and_remap_known_cases():
         assert abs(mx[i, j] - (Kl[0, 0] * xd + Kl[0, 2])) < 2e-3 and abs(my[i, j] - (Kl[1, 1] * yd + Kl[1, 2])) < 2e-3
     with pytest.raises(ValueError):
         O.rectify_map(K, [], np.zeros(9), cam, 4, 4)
+
+
+def test_fisheye_rectify_map_follows_the_equidistant_model():
+    E = O.TUM_VI
+    c = E["camera"]
+    mx, my = O.fisheye_rectify_map(E["StereoRectifier.K_left"], E["StereoRectifier.D_left"], E["StereoRectifier.R_left"], c, 512, 512)
+    Kl = np.array(E["StereoRectifier.K_left"]).reshape(3, 3); R = np.array(E["StereoRectifier.R_left"]).reshape(3, 3)
+    k = E["StereoRectifier.D_left"]
+    for (i, j) in [(0, 0), (511, 511), (256, 240), (100, 400), (500, 20)]:
+        ray = R.T @ np.array([(j - np.float32(c["cx"])) / np.float32(c["fx"]), (i - np.float32(c["cy"])) / np.float32(c["fy"]), 1.0])
+        x, y = ray[0] / ray[2], ray[1] / ray[2]
+        r = np.hypot(x, y); th = np.arctan(r)
+        thd = th * (1 + k[0] * th ** 2 + k[1] * th ** 4 + k[2] * th ** 6 + k[3] * th ** 8)
+        s = thd / r if r > 0 else 1.0
+        assert abs(mx[i, j] - (Kl[0, 0] * x * s + Kl[0, 2])) < 2e-3 and abs(my[i, j] - (Kl[1, 1] * y * s + Kl[1, 2])) < 2e-3
+    # the wide rectified view (fx = 61.8 on a 512 px image, +-76 degrees) still lands on (or a few pixels off) the fisheye sensor
+    assert np.isfinite(mx).all() and np.isfinite(my).all() and -8 < min(mx.min(), my.min()) and max(mx.max(), my.max()) < 520
+    # rays behind the camera (a rectifying rotation by more than 90 degrees) map to +-inf, which remap treats as outside
+    Rb = np.diag([1.0, -1.0, -1.0])
+    bx, by = O.fisheye_rectify_map(E["StereoRectifier.K_left"], E["StereoRectifier.D_left"], Rb.ravel(), c, 8, 8)
+    assert np.isinf(bx).all() and np.isinf(by).all()
+    assert not O.remap_linear(np.full((16, 16), 200, np.uint8), bx, by).any()
