@@ -1,11 +1,32 @@
-import sys; sys.path.insert(0,'tests'); sys.path.insert(0,'.')
-from plp import plp, synth
-import torch, numpy as np
-fr = synth.replay(1234, 64)
-d = torch.from_numpy(fr).cuda().repeat(16,1,1).contiguous()
-B=len(d); cap=512
-lt = plp.LineFeatureTracker()
-kl=torch.zeros((B,cap,68),dtype=torch.uint8,device='cuda'); lb=torch.zeros((B,cap,32),dtype=torch.uint8,device='cuda'); fn=torch.zeros((B,cap,3),dtype=torch.float64,device='cuda'); cn=torch.zeros(B,dtype=torch.int32,device='cuda')
-for _ in range(2): lt.extract_batch(d,kl,lb,fn,cn)
-torch.cuda.synchronize()
-print(B, lt.grow_profile())
+#!/usr/bin/env python3
+"""Phase clocks of k_lsd_grow for frame 0 of a batch (GPU box): total / region growing / rectangle fit / refinement in shader
+cycles, plus the number of regions grown and pixels accepted.  Only frame 0 pays for the s_memtime reads.
+    python tools/grow_profile.py [frames]"""
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+plp = importlib.import_module("structure-plp-slam_amd")
+synth = importlib.import_module("structure-plp-slam_amd.synth")
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+    uniq = min(B, 64)
+    frames = torch.from_numpy(synth.replay(1234, uniq)).cuda().repeat((B + uniq - 1) // uniq, 1, 1)[:B].contiguous()
+    cap = 512
+    lt = plp.LineFeatureTracker()
+    kl = torch.zeros((B, cap, 68), dtype=torch.uint8, device="cuda"); lbd = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    fn = torch.zeros((B, cap, 3), dtype=torch.float64, device="cuda"); cnt = torch.zeros(B, dtype=torch.int32, device="cuda")
+    for _ in range(2):
+        lt.extract_batch(frames, kl, lbd, fn, cnt)
+    torch.cuda.synchronize()
+    print(B, lt.grow_profile(), "lines per frame", float(cnt.float().mean()))
+
+
+if __name__ == "__main__":
+    main()
