@@ -253,7 +253,7 @@ __device__ __forceinline__ void match_topk_query(const MatchProblem& P, int b, i
     int32_t* kcount = P.kcount + (size_t)b * P.m_cap + q;
     const uint8_t* q_valid = P.q_valid ? P.q_valid + (size_t)b * P.m_cap : nullptr;
     if (q_valid && !q_valid[q]) { if (lane == 0) *kcount = -1; return; }
-    const int n = P.t_counts ? P.t_counts[b] : P.n_cap;
+    const int n = P.t_counts ? min(P.t_counts[b], P.n_cap) : P.n_cap;
     const plp_keypoint* kps = P.t_kps ? P.t_kps + (size_t)b * P.n_cap : nullptr;
     const uint8_t* t_desc = P.t_desc + (size_t)b * P.n_cap * 32;
     const float* t_xr = P.t_x_right ? P.t_x_right + (size_t)b * P.n_cap : nullptr;
@@ -282,7 +282,7 @@ __device__ __forceinline__ void match_topk_query(const MatchProblem& P, int b, i
 // queries each (key lines: ~50 of a 512 capacity) does not launch hundreds of thousands of workgroups that only exit.
 __global__ __launch_bounds__(256) void k_match_topk(MatchProblem P) {
     const int lane = threadIdx.x & 63, b = blockIdx.y;
-    const int m = P.q_counts ? P.q_counts[b] : P.m_cap;
+    const int m = P.q_counts ? min(P.q_counts[b], P.m_cap) : P.m_cap;
     for (int q = blockIdx.x * 4 + (threadIdx.x >> 6); q < m; q += gridDim.x * 4) match_topk_query(P, b, q, lane);
 }
 
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void k_match_prep(MatchProblem P) {
     __shared__ uint16_t tmp_t[8192];
     __shared__ int part[256];
     const int tid = threadIdx.x, b = blockIdx.x;
-    const int n = P.t_counts ? P.t_counts[b] : P.n_cap;
+    const int n = P.t_counts ? min(P.t_counts[b], P.n_cap) : P.n_cap;
     const int ncell = P.grid_cols * P.grid_rows;
     const plp_keypoint* kps = P.t_kps + (size_t)b * P.n_cap;
     const float* t_xr = P.t_x_right ? P.t_x_right + (size_t)b * P.n_cap : nullptr;
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void k_match_topk_cells(MatchProblem P) {
     unsigned uqb, ub;
     xcd_frame_major(uqb, ub);   // the query blocks of a frame all stage the same sorted target array
     const int tid = threadIdx.x, sub = tid & 15, grp = tid >> 4, b = (int)ub;
-    const int m = P.q_counts ? P.q_counts[b] : P.m_cap;
+    const int m = P.q_counts ? min(P.q_counts[b], P.m_cap) : P.m_cap;
     const int q_begin = (int)uqb * kQueriesPerBlock;
     if (q_begin >= m) return;
     const int ncell = P.grid_cols * P.grid_rows, rows = P.grid_rows;
@@ -513,10 +513,10 @@ __global__ __launch_bounds__(256) void k_match_topk_cells(MatchProblem P) {
 __global__ __launch_bounds__(256) void k_match_topk_lds(MatchProblem P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.y;
-    const int m = P.q_counts ? P.q_counts[b] : P.m_cap;
+    const int m = P.q_counts ? min(P.q_counts[b], P.m_cap) : P.m_cap;
     const int q_begin = blockIdx.x * kQueriesPerBlock;
     if (q_begin >= m) return;
-    const int n = P.t_counts ? P.t_counts[b] : P.n_cap;
+    const int n = P.t_counts ? min(P.t_counts[b], P.n_cap) : P.n_cap;
     const uint8_t* t_desc = P.t_desc + (size_t)b * P.n_cap * 32;
     uint4* sdesc = reinterpret_cast<uint4*>(smem);
     {
@@ -566,8 +566,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     extern __shared__ int32_t lds[];
     __shared__ int s_changed, s_num, s_hist[32], s_valid_bin[32], s_full_n, s_claim_tmp[256];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.x;
-    const int m = P.q_counts ? P.q_counts[b] : P.m_cap;
-    const int n = P.t_counts ? P.t_counts[b] : P.n_cap;
+    const int m = P.q_counts ? min(P.q_counts[b], P.m_cap) : P.m_cap;
+    const int n = P.t_counts ? min(P.t_counts[b], P.n_cap) : P.n_cap;
     int32_t* owner_final = lds;                 // smallest claimant among the chunks already finished
     int32_t* owner_prev = lds + P.n_cap;        // claims inside the current chunk, previous / current inner iteration
     int32_t* owner_next = lds + 2 * P.n_cap;
@@ -794,12 +794,12 @@ __global__ __launch_bounds__(256) void k_hamming_matrix(const uint8_t* __restric
 __global__ __launch_bounds__(256) void k_match_fuse(MatchProblem P) {
     const int lane = threadIdx.x & 63, b = blockIdx.y;
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int m = P.q_counts ? P.q_counts[b] : P.m_cap;
+    const int m = P.q_counts ? min(P.q_counts[b], P.m_cap) : P.m_cap;
     if (q >= m) return;
     int32_t* out = P.out_query_best + (size_t)b * P.m_cap + q;
     const uint8_t* q_valid = P.q_valid ? P.q_valid + (size_t)b * P.m_cap : nullptr;
     if (q_valid && !q_valid[q]) { if (lane == 0) *out = -1; return; }
-    const int n = P.t_counts ? P.t_counts[b] : P.n_cap;
+    const int n = P.t_counts ? min(P.t_counts[b], P.n_cap) : P.n_cap;
     const plp_keypoint* kps = P.t_kps + (size_t)b * P.n_cap;
     const uint8_t* t_desc = P.t_desc + (size_t)b * P.n_cap * 32;
     const float* t_xr = P.t_x_right ? P.t_x_right + (size_t)b * P.n_cap : nullptr;
@@ -952,7 +952,7 @@ __global__ __launch_bounds__(256) void k_lbd_match_1nn(const uint8_t* __restrict
                                                        const uint8_t* __restrict__ t, const int32_t* __restrict__ t_counts, int nt_cap,
                                                        MihRanks R, int32_t* __restrict__ out_idx, int32_t* __restrict__ out_dist) {
     const int lane = threadIdx.x & 63, b = blockIdx.y, qi = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int nq = q_counts ? q_counts[b] : nq_cap, nt = t_counts ? t_counts[b] : nt_cap;
+    const int nq = q_counts ? min(q_counts[b], nq_cap) : nq_cap, nt = t_counts ? min(t_counts[b], nt_cap) : nt_cap;
     if (qi >= nq) return;
     const uint8_t* Q = q + ((size_t)b * nq_cap + qi) * 32;
     const uint8_t* T = t + (size_t)b * nt_cap * 32;

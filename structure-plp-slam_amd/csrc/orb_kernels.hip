@@ -594,7 +594,7 @@ void launch_orient_rbrief(hipStream_t st, const OrbPlanes& pl, const uint8_t* bl
 __global__ __launch_bounds__(256) void k_stereo_match(OrbPlanes pl_l, OrbPlanes pl_r, const LevelDev* __restrict__ lv, StereoArgs A) {
     const int lane = threadIdx.x & 63, b = blockIdx.y;
     const int il = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int nl = A.cnt_l ? A.cnt_l[b] : A.cap, nr = A.cnt_r ? A.cnt_r[b] : A.cap;
+    const int nl = A.cnt_l ? min(A.cnt_l[b], A.cap) : A.cap, nr = A.cnt_r ? min(A.cnt_r[b], A.cap) : A.cap;
     if (il >= A.cap) return;
     float* xr_out = A.x_right + (size_t)b * A.cap;
     float* dp_out = A.depth + (size_t)b * A.cap;
@@ -674,7 +674,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(OrbPlanes pl_l, OrbPlanes 
 __global__ __launch_bounds__(256) void k_stereo_median(StereoArgs A) {
     __shared__ int hist[256], s_sel[3];
     const int tid = threadIdx.x, b = blockIdx.x;
-    const int nl = A.cnt_l ? A.cnt_l[b] : A.cap;
+    const int nl = A.cnt_l ? min(A.cnt_l[b], A.cap) : A.cap;
     int32_t* corr = A.corr + (size_t)b * A.cap;
     float* xr_out = A.x_right + (size_t)b * A.cap;
     float* dp_out = A.depth + (size_t)b * A.cap;

@@ -64,7 +64,7 @@ __device__ __forceinline__ void undistort_point(const PostArgs& A, float u_in, f
 
 __global__ __launch_bounds__(256) void k_post_extract(PostArgs A) {
     const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
-    if (A.kps && i < (A.counts ? A.counts[b] : A.cap)) {
+    if (A.kps && i < (A.counts ? min(A.counts[b], A.cap) : A.cap)) {
         const size_t o = (size_t)b * A.cap + i;
         const plp_keypoint k = A.kps[o];
         plp_keypoint un;
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void k_post_extract(PostArgs A) {
             A.x_right[o] = xr; A.depths[o] = dp;
         }
     }
-    if (A.kl && A.depth && i < (A.kl_counts ? A.kl_counts[b] : A.kl_cap)) {   // frame.cc:1196-1217
+    if (A.kl && A.depth && i < (A.kl_counts ? min(A.kl_counts[b], A.kl_cap) : A.kl_cap)) {   // frame.cc:1196-1217
         const size_t o = (size_t)b * A.kl_cap + i;
         const plp_keyline l = A.kl[o];
         const uint8_t* D = reinterpret_cast<const uint8_t*>(A.depth) + (size_t)b * A.depth_frame_stride;

@@ -357,3 +357,22 @@ def test_large_frames_take_the_global_memory_path():
                                                 q["q_x_right"], q["q_level"], q["q_angle"], q["q_desc"], q["q_has_obs"], 15.0, 0, check)
             got, gn = plp.matcher(0.9, check).match_host(plp.MODE_LAST_FRAME, n, m, {**t, **q}, margin=15.0, direction=0, scale_factors=SF, grid=grid)
             assert gn[0] == wn and np.array_equal(got[0], want), (n, m, check)
+
+
+def test_counts_beyond_the_capacity_are_clamped():
+    """t_counts / q_counts come from device memory and cannot be validated on the host: a count larger than the array
+    capacity must behave like the capacity (no out-of-bounds reads), a negative one like zero."""
+    rng = np.random.default_rng(9)
+    grid = plp.make_grid(640, 480)
+    n, m = 700, 900
+    t, q = MC.random_problem(rng, n, m, n_words=6)
+    ref, rn = plp.matcher(0.8, True).match_host(plp.MODE_LANDMARKS, n, m, {**t, **q}, margin=10.0, scale_factors=SF, grid=grid)
+    big = dict(t_counts=np.array([n + 1000], np.int32), q_counts=np.array([m + 5000], np.int32))
+    got, gn = plp.matcher(0.8, True).match_host(plp.MODE_LANDMARKS, n, m, {**t, **q, **big}, margin=10.0, scale_factors=SF, grid=grid)
+    assert gn[0] == rn[0] and np.array_equal(got[0], ref[0])
+    got, gn = plp.matcher(0.9, True).match_host(plp.MODE_LAST_FRAME, n, m, {**t, **q, **big}, margin=10.0, direction=0, scale_factors=SF, grid=grid)
+    ref2, rn2 = plp.matcher(0.9, True).match_host(plp.MODE_LAST_FRAME, n, m, {**t, **q}, margin=10.0, direction=0, scale_factors=SF, grid=grid)
+    assert gn[0] == rn2[0] and np.array_equal(got[0], ref2[0])
+    neg = dict(t_counts=np.array([n], np.int32), q_counts=np.array([-3], np.int32))
+    got, gn = plp.matcher(0.8, True).match_host(plp.MODE_LANDMARKS, n, m, {**t, **q, **neg}, margin=10.0, scale_factors=SF, grid=grid)
+    assert gn[0] == 0 and (got[0] == -1).all()
