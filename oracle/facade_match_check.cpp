@@ -16,6 +16,9 @@
 
 #include <opencv2/core.hpp>
 
+#include <map>
+
+#include "PLPSLAM/match/bow_tree.h"
 #include "PLPSLAM/match/projection.h"
 
 extern "C" {
@@ -34,6 +37,8 @@ unsigned oracle_match_current_and_last_line(const OKeyLine* kl, const uint8_t* l
                                             const float* scale_factors_lsd, int num_levels_lsd, const uint8_t* valid, const float* sp,
                                             const float* ep, const float* lxr_sp, const float* lxr_ep, const int* loctave, const uint8_t* ldesc,
                                             const uint8_t* l_has_obs, int m, float margin, int direction, int is_rgbd, int* line_last);
+unsigned oracle_match_bow(const uint8_t* q_desc, const float* q_angle, const int* q_node, const uint8_t* q_valid, int m, const uint8_t* t_desc,
+                          const float* t_angle, const int* t_node, const uint8_t* t_skip, int n, float lowe_ratio, int check_orientation, int* t_match);
 unsigned oracle_match_current_and_last(const double* grid6, const OKeyPoint* kps, const uint8_t* desc, const float* x_right,
                                        const uint8_t* occupied, int n, const float* scale_factors, int num_levels, const uint8_t* valid,
                                        const float* reproj, const float* lx_right, const int* loctave, const float* langle,
@@ -113,6 +118,14 @@ struct frame {
     std::vector<landmark*> landmarks_;
     std::vector<bool> outlier_flags_;
     Mat44_t cam_pose_cw_;
+    std::map<unsigned int, std::vector<unsigned int>> bow_feat_vec_;    // DBoW2::FeatureVector
+};
+struct keyframe {
+    std::vector<cv::KeyPoint> keypts_;
+    cv::Mat descriptors_;
+    std::vector<landmark*> landmarks_;
+    std::map<unsigned int, std::vector<unsigned int>> bow_feat_vec_;
+    std::vector<landmark*> get_landmarks() const { return landmarks_; }
 };
 }  // namespace data
 }  // namespace PLPSLAM
@@ -331,6 +344,49 @@ int main(int argc, char** argv) {
             if (got_num != want_num) ++failures;
             std::printf("match_current_and_last_frames[direction %d]: %u matches (oracle %u), %d removed by the orientation check\n", direction, got_num,
                         want_num, removed);
+        }
+        // ---------------- bow_tree::match_frame_and_keyframe
+        for (int check = 0; check < 2; ++check) {
+            data::frame frm;
+            fill_frame(frm, &cam, n);
+            data::keyframe kf;
+            kf.keypts_.resize(m); kf.descriptors_ = cv::Mat(m, 32, CV_8U); kf.landmarks_.assign(m, nullptr);
+            std::vector<std::unique_ptr<data::landmark>> pool;
+            const unsigned n_nodes = 37;
+            for (int j = 0; j < m; ++j) {
+                const int src = irand(0, n - 1);                 // key-frame features resemble frame features
+                std::copy(frm.descriptors_.ptr<uint8_t>(src), frm.descriptors_.ptr<uint8_t>(src) + 32, kf.descriptors_.ptr<uint8_t>(j));
+                for (int f = irand(0, 4); f > 0; --f) kf.descriptors_.ptr<uint8_t>(j)[irand(1, 31)] ^= (uint8_t)(1u << irand(0, 7));
+                kf.keypts_[j].angle = frm.keypts_[src].angle + (uni(0, 1) < 0.8 ? (float)uni(-3, 3) : (float)uni(0, 300));
+                if (kf.keypts_[j].angle < 0.f) kf.keypts_[j].angle += 360.f;
+                if (kf.keypts_[j].angle >= 360.f) kf.keypts_[j].angle -= 360.f;
+                if (uni(0, 1) < 0.85) { pool.emplace_back(new data::landmark()); pool.back()->erased_ = uni(0, 1) < 0.05; kf.landmarks_[j] = pool.back().get(); }
+                if (uni(0, 1) < 0.95) kf.bow_feat_vec_[(unsigned)(kf.descriptors_.ptr<uint8_t>(j)[0] * 7 + 3) % n_nodes].push_back((unsigned)j);
+            }
+            for (int i = 0; i < n; ++i)
+                if (uni(0, 1) < 0.95) frm.bow_feat_vec_[(unsigned)(frm.descriptors_.ptr<uint8_t>(i)[0] * 7 + 3) % n_nodes].push_back((unsigned)i);
+            // expectation: queries in feature-vector order
+            std::vector<uint8_t> qd, qv, td((size_t)n * 32), tskip(n, 0);
+            std::vector<float> qa, ta(n);
+            std::vector<int> qn, tn(n, -1), qi, want(n);
+            for (const auto& node : kf.bow_feat_vec_)
+                for (unsigned j : node.second) {
+                    qi.push_back((int)j); qn.push_back((int)node.first); qa.push_back(kf.keypts_[j].angle);
+                    qv.push_back(kf.landmarks_[j] && !kf.landmarks_[j]->will_be_erased());
+                    qd.insert(qd.end(), kf.descriptors_.ptr<uint8_t>((int)j), kf.descriptors_.ptr<uint8_t>((int)j) + 32);
+                }
+            for (const auto& node : frm.bow_feat_vec_) for (unsigned i : node.second) tn[i] = (int)node.first;
+            for (int i = 0; i < n; ++i) { ta[i] = frm.keypts_[i].angle; std::copy(frm.descriptors_.ptr<uint8_t>(i), frm.descriptors_.ptr<uint8_t>(i) + 32, td.begin() + (size_t)i * 32); }
+            const unsigned want_num = oracle_match_bow(qd.data(), qa.data(), qn.data(), qv.data(), (int)qi.size(), td.data(), ta.data(), tn.data(), tskip.data(), n,
+                                                       0.75f, check, want.data());
+            std::vector<data::landmark*> matched;
+            const match::bow_tree bow_matcher(0.75, check != 0);
+            const unsigned got_num = bow_matcher.match_frame_and_keyframe(&kf, frm, matched);
+            if ((int)matched.size() != n) ++failures;
+            for (int i = 0; i < n && i < (int)matched.size(); ++i)
+                if (matched[i] != (want[i] >= 0 ? kf.landmarks_[(size_t)qi[(size_t)want[i]]] : nullptr)) ++failures;
+            if (got_num != want_num) ++failures;
+            std::printf("bow_tree::match_frame_and_keyframe[check_orientation %d]: %u matches (oracle %u)\n", check, got_num, want_num);
         }
         // ---------------- match_frame_and_landmarks_line
         const int nl = std::max(2, n / 6), ml = std::max(2, m / 6);
