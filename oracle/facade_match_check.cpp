@@ -18,6 +18,7 @@
 
 #include <map>
 
+#include "PLPSLAM/match/area.h"
 #include "PLPSLAM/match/bow_tree.h"
 #include "PLPSLAM/match/projection.h"
 
@@ -37,6 +38,8 @@ unsigned oracle_match_current_and_last_line(const OKeyLine* kl, const uint8_t* l
                                             const float* scale_factors_lsd, int num_levels_lsd, const uint8_t* valid, const float* sp,
                                             const float* ep, const float* lxr_sp, const float* lxr_ep, const int* loctave, const uint8_t* ldesc,
                                             const uint8_t* l_has_obs, int m, float margin, int direction, int is_rgbd, int* line_last);
+unsigned oracle_match_area(const double* grid6, const OKeyPoint* kps1, const uint8_t* desc1, int n1, const OKeyPoint* kps2, const uint8_t* desc2,
+                           int n2, float* prev_pts, int margin, float lowe_ratio, int check_orientation, int* matched_2_in_1);
 unsigned oracle_match_bow(const uint8_t* q_desc, const float* q_angle, const int* q_node, const uint8_t* q_valid, int m, const uint8_t* t_desc,
                           const float* t_angle, const int* t_node, const uint8_t* t_skip, int n, float lowe_ratio, int check_orientation, int* t_match);
 unsigned oracle_match_current_and_last(const double* grid6, const OKeyPoint* kps, const uint8_t* desc, const float* x_right,
@@ -387,6 +390,40 @@ int main(int argc, char** argv) {
                 if (matched[i] != (want[i] >= 0 ? kf.landmarks_[(size_t)qi[(size_t)want[i]]] : nullptr)) ++failures;
             if (got_num != want_num) ++failures;
             std::printf("bow_tree::match_frame_and_keyframe[check_orientation %d]: %u matches (oracle %u)\n", check, got_num, want_num);
+        }
+        // ---------------- area::match_in_consistent_area (monocular initialisation: frame 2 = frame 1 moved by a few pixels)
+        for (int check = 0; check < 2; ++check) {
+            data::frame frm_1, frm_2;
+            fill_frame(frm_1, &cam, m); fill_frame(frm_2, &cam, n);
+            for (int i = 0; i < n; i += 2) {
+                const int j = irand(0, m - 1);
+                frm_2.keypts_[i] = frm_1.keypts_[j];
+                frm_2.keypts_[i].pt.x += (float)uni(-12, 12); frm_2.keypts_[i].pt.y += (float)uni(-12, 12);
+                frm_2.keypts_[i].angle = frm_1.keypts_[j].angle + (float)uni(-2, 2);
+                if (frm_2.keypts_[i].angle < 0.f) frm_2.keypts_[i].angle += 360.f;
+                if (frm_2.keypts_[i].angle >= 360.f) frm_2.keypts_[i].angle -= 360.f;
+                std::copy(frm_1.descriptors_.ptr<uint8_t>(j), frm_1.descriptors_.ptr<uint8_t>(j) + 32, frm_2.descriptors_.ptr<uint8_t>(i));
+                frm_2.descriptors_.ptr<uint8_t>(i)[irand(0, 31)] ^= 4;
+            }
+            for (int j = 0; j < m; ++j) if (uni(0, 1) < 0.6) frm_1.keypts_[j].octave = 0;      // only level-0 key points take part
+            for (int i = 0; i < n; ++i) if (uni(0, 1) < 0.6) frm_2.keypts_[i].octave = 0;
+            frm_1.undist_keypts_ = frm_1.keypts_; frm_2.undist_keypts_ = frm_2.keypts_;
+            std::vector<cv::Point2f> prev_matched_pts((size_t)m);
+            for (int j = 0; j < m; ++j) prev_matched_pts[(size_t)j] = frm_1.undist_keypts_[(size_t)j].pt;     // initializer.cc:62-66
+            std::vector<float> want_prev(2 * (size_t)m);
+            for (int j = 0; j < m; ++j) { want_prev[2 * j] = prev_matched_pts[(size_t)j].x; want_prev[2 * j + 1] = prev_matched_pts[(size_t)j].y; }
+            const auto d1 = desc_of(frm_1), d2 = desc_of(frm_2);
+            std::vector<int> want(m);
+            const unsigned want_num = oracle_match_area(grid6, reinterpret_cast<const OKeyPoint*>(frm_1.undist_keypts_.data()), d1.data(), m,
+                                                        reinterpret_cast<const OKeyPoint*>(frm_2.undist_keypts_.data()), d2.data(), n, want_prev.data(), 50, 0.9f,
+                                                        check, want.data());
+            std::vector<int> got;
+            match::area matcher(0.9, check != 0);
+            const unsigned got_num = matcher.match_in_consistent_area(frm_1, frm_2, prev_matched_pts, got, 50);
+            if (got != want || got_num != want_num) ++failures;
+            for (int j = 0; j < m; ++j)
+                if (prev_matched_pts[(size_t)j].x != want_prev[2 * j] || prev_matched_pts[(size_t)j].y != want_prev[2 * j + 1]) { ++failures; break; }
+            std::printf("area::match_in_consistent_area[check_orientation %d]: %u matches (oracle %u)\n", check, got_num, want_num);
         }
         // ---------------- match_frame_and_landmarks_line
         const int nl = std::max(2, n / 6), ml = std::max(2, m / 6);

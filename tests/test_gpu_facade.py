@@ -54,18 +54,19 @@ def test_cpp_matcher_facade_equals_oracle(seed, n, m):
     call and the returned match count equal the array-form oracle's (match_frame_and_landmarks; match_current_and_last_frames
     for the monocular, forward and backward cases, including the nullptr left by the orientation check; the two line
     variants on key lines / 3D lines, with partially visible lines and the RGB-D stereo gate; bow_tree::match_frame_and_keyframe
-    (facade/PLPSLAM/match/bow_tree.h) on DBoW2-shaped feature vectors, with and without the orientation check)."""
+    (facade/PLPSLAM/match/bow_tree.h) on DBoW2-shaped feature vectors and area::match_in_consistent_area (facade/PLPSLAM/match/area.h), each with and without the
+    orientation check)."""
     env = dict(os.environ)
     env["LD_LIBRARY_PATH"] = "/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
     r = subprocess.run([_MATCH_EXE, str(seed), str(n), str(m)], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = r.stdout.strip().splitlines()
-    assert len(lines) == 10 and lines[0].startswith("match_frame_and_landmarks") and lines[4].startswith("bow_tree::match_frame_and_keyframe")
-    assert lines[6].startswith("match_frame_and_landmarks_line")
+    assert len(lines) == 12 and lines[0].startswith("match_frame_and_landmarks") and lines[4].startswith("bow_tree::match_frame_and_keyframe")
+    assert lines[6].startswith("area::match_in_consistent_area") and lines[8].startswith("match_frame_and_landmarks_line")
     if n >= 900:     # the scenes are built so that the matchers have work to do
         import re
-        assert all(int(re.search(r"(\d+) matches", ln).group(1)) > 30 for ln in lines[:6])
-        assert all(int(re.search(r"(\d+) matches", ln).group(1)) > 10 for ln in lines[6:])
+        assert all(int(re.search(r"(\d+) matches", ln).group(1)) > 30 for ln in lines[:8])
+        assert all(int(re.search(r"(\d+) matches", ln).group(1)) > 10 for ln in lines[8:])
 
 
 @pytest.mark.skipif(not os.path.exists(_EXE), reason="oracle/_ref/facade_orb_check not built (needs /root/reference at build time)")
