@@ -640,17 +640,31 @@ class bow_vocabulary:
         self._h = h
         self.device = device
 
-    @classmethod
-    def from_text_file(cls, path, device=0):
-        """ORB-SLAM2-style ORBvoc.txt: 'k L scoring weighting', then one line per node 'parent is_leaf d0 .. d31 weight'"""
+    @staticmethod
+    def parse_text_file(path):
+        """ORB-SLAM2-style ORBvoc.txt (DBoW2 TemplatedVocabulary::loadFromTextFile): 'k L scoring weighting', then one line per
+        node 'parent is_leaf d0 .. d31 weight'.  Host only.  Returns (L, parents, is_leaf, descs, weights, weighting, scoring)."""
         with open(path) as f:
-            k, L, scoring, weighting = (int(v) for v in f.readline().split())
+            head = f.readline().split()
+            if len(head) != 4:
+                raise PlpError(1, "vocabulary header must be 'k L scoring weighting'")
+            k, L, scoring, weighting = (int(v) for v in head)
+            if not (0 <= k <= 20 and 1 <= L <= 10 and 0 <= scoring <= 5 and 0 <= weighting <= 3):
+                raise PlpError(1, "vocabulary parameters out of range")      # the same sanity check loadFromTextFile makes
             rows = [ln.split() for ln in f if ln.strip()]
+        if any(len(r) != 35 for r in rows):
+            raise PlpError(1, "a node line must hold parent, is_leaf, 32 descriptor bytes and the weight")
         parents = [-1] + [int(r[0]) for r in rows]
         leaf = [False] + [int(r[1]) > 0 for r in rows]
         descs = np.zeros((len(rows) + 1, 32), np.uint8)
-        descs[1:] = np.array([[int(v) for v in r[2:34]] for r in rows], np.uint8)
+        if rows:
+            descs[1:] = np.array([[int(v) for v in r[2:34]] for r in rows], np.uint8)
         weights = [0.0] + [float(r[34]) for r in rows]
+        return L, parents, leaf, descs, weights, weighting, scoring
+
+    @classmethod
+    def from_text_file(cls, path, device=0):
+        L, parents, leaf, descs, weights, weighting, scoring = cls.parse_text_file(path)
         return cls(L, parents, leaf, descs, weights, weighting, scoring, device)
 
     def __del__(self):

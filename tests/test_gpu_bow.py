@@ -108,3 +108,21 @@ def test_maximum_frame_size_and_errors():
         plp._check(plp.lib().plp_bow_vocab_create(0, C.byref(t), C.byref(C.c_void_p())))
     with pytest.raises(plp.PlpError):
         plp.bow_vocabulary(2, [-1, 0, 0], [False, True, False], d, w)      # a childless node that is not a leaf
+
+
+def test_vocabulary_from_text_file_equals_vocabulary_from_arrays(tmp_path):
+    """ORBvoc.txt layout written from a random tree and read back (bow_vocabulary.from_text_file): same words, same vectors"""
+    rng = np.random.default_rng(21)
+    parents, is_leaf, descs, weights = O.random_vocab(rng, 5, 3)
+    lines = ["5 3 0 0"]
+    for i in range(1, len(parents)):
+        lines.append(f"{parents[i]} {int(is_leaf[i])} " + " ".join(str(int(v)) for v in descs[i]) + f" {weights[i]!r}")
+    path = tmp_path / "voc.txt"
+    path.write_text("\n".join(lines) + "\n")
+    a = plp.bow_vocabulary(3, parents, is_leaf, descs, weights)
+    b = plp.bow_vocabulary.from_text_file(str(path))
+    assert np.array_equal(a.child_offset, b.child_offset) and np.array_equal(a.children, b.children) and np.array_equal(a.node_word, b.node_word)
+    desc = rng.integers(0, 256, (400, 32), dtype=np.uint8)
+    va, fa, wa, na = a.transform(desc, 2)
+    vb, fb, wb, nb = b.transform(desc, 2)
+    assert va == vb and fa == fb and np.array_equal(wa, wb) and np.array_equal(na, nb) and len(va) > 10

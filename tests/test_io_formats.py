@@ -91,3 +91,26 @@ def test_map_database_wire_format_round_trips():
         assert np.array_equal(bl[f], kl[f])
     assert np.array_equal(bl["pt_x"], (0.5 * (kl["startPointX"].astype(np.float64) + kl["endPointX"])).astype(np.float32))
     assert (bl["class_id"] == -1).all() and (bl["lineLength"] == 0).all()
+
+
+def test_vocabulary_text_file_parser(tmp_path):
+    """ORBvoc.txt layout: header 'k L scoring weighting', one line per node 'parent is_leaf d0..d31 weight' (host-side parse)"""
+    rng = np.random.default_rng(4)
+    lines = ["3 2 0 0"]
+    nodes = [(0, 0), (0, 0), (0, 1), (1, 1), (1, 1), (1, 1), (2, 1), (2, 1)]          # (parent, is_leaf)
+    descs = rng.integers(0, 256, (len(nodes), 32))
+    for (par, leaf), d in zip(nodes, descs):
+        lines.append(f"{par} {leaf} " + " ".join(str(int(v)) for v in d) + f" {0.0 if not leaf else 1.5 + par}")
+    path = tmp_path / "voc.txt"
+    path.write_text("\n".join(lines) + "\n")
+    L, parents, leaf, d, w, weighting, scoring = plp.bow_vocabulary.parse_text_file(str(path))
+    assert (L, weighting, scoring) == (2, 0, 0)
+    assert parents == [-1, 0, 0, 0, 1, 1, 1, 2, 2] and leaf == [False, False, False, True, True, True, True, True, True]
+    assert np.array_equal(d[1:], descs) and not d[0].any()
+    assert w == [0.0, 0.0, 0.0, 1.5, 2.5, 2.5, 2.5, 3.5, 3.5]
+    (tmp_path / "bad.txt").write_text("3 2 0\n")
+    with pytest.raises(plp.PlpError):
+        plp.bow_vocabulary.parse_text_file(str(tmp_path / "bad.txt"))
+    (tmp_path / "bad2.txt").write_text("3 2 0 0\n0 1 1 2 3\n")
+    with pytest.raises(plp.PlpError):
+        plp.bow_vocabulary.parse_text_file(str(tmp_path / "bad2.txt"))
