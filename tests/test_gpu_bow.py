@@ -116,7 +116,7 @@ def test_vocabulary_from_text_file_equals_vocabulary_from_arrays(tmp_path):
     parents, is_leaf, descs, weights = O.random_vocab(rng, 5, 3)
     lines = ["5 3 0 0"]
     for i in range(1, len(parents)):
-        lines.append(f"{parents[i]} {int(is_leaf[i])} " + " ".join(str(int(v)) for v in descs[i]) + f" {weights[i]!r}")
+        lines.append(f"{parents[i]} {int(is_leaf[i])} " + " ".join(str(int(v)) for v in descs[i]) + f" {float(weights[i])!r}")
     path = tmp_path / "voc.txt"
     path.write_text("\n".join(lines) + "\n")
     a = plp.bow_vocabulary(3, parents, is_leaf, descs, weights)
