@@ -391,6 +391,53 @@ int main(int argc, char** argv) {
             if (got_num != want_num) ++failures;
             std::printf("bow_tree::match_frame_and_keyframe[check_orientation %d]: %u matches (oracle %u)\n", check, got_num, want_num);
         }
+        // ---------------- bow_tree::match_keyframes
+        {
+            const unsigned n_nodes = 29;
+            auto fill_kf = [&](data::keyframe& kf, int cnt, std::vector<std::unique_ptr<data::landmark>>& pool, const data::keyframe* like) {
+                kf.keypts_.resize(cnt); kf.descriptors_ = cv::Mat(cnt, 32, CV_8U); kf.landmarks_.assign(cnt, nullptr);
+                for (int j = 0; j < cnt; ++j) {
+                    kf.keypts_[j].angle = (float)uni(0, 360);
+                    if (like && uni(0, 1) < 0.7) {
+                        const int src = irand(0, (int)like->keypts_.size() - 1);
+                        std::copy(like->descriptors_.ptr<uint8_t>(src), like->descriptors_.ptr<uint8_t>(src) + 32, kf.descriptors_.ptr<uint8_t>(j));
+                        for (int f = irand(0, 3); f > 0; --f) kf.descriptors_.ptr<uint8_t>(j)[irand(1, 31)] ^= (uint8_t)(1u << irand(0, 7));
+                        float ang = like->keypts_[src].angle + (uni(0, 1) < 0.8 ? (float)uni(-3, 3) : (float)uni(0, 300));
+                        if (ang >= 360.f) ang -= 360.f;
+                        if (ang < 0.f) ang += 360.f;
+                        kf.keypts_[j].angle = ang;
+                    } else random_desc(kf.descriptors_.ptr<uint8_t>(j));
+                    if (uni(0, 1) < 0.8) { pool.emplace_back(new data::landmark()); pool.back()->erased_ = uni(0, 1) < 0.05; kf.landmarks_[j] = pool.back().get(); }
+                    if (uni(0, 1) < 0.95) kf.bow_feat_vec_[(unsigned)(kf.descriptors_.ptr<uint8_t>(j)[0] * 5 + 1) % n_nodes].push_back((unsigned)j);
+                }
+            };
+            std::vector<std::unique_ptr<data::landmark>> pool;
+            data::keyframe kf1, kf2;
+            fill_kf(kf2, n, pool, nullptr);
+            fill_kf(kf1, m, pool, &kf2);
+            std::vector<uint8_t> qd, qv, td((size_t)n * 32), tskip(n);
+            std::vector<float> qa, ta(n);
+            std::vector<int> qn, tn(n, -1), qi, want(n);
+            for (const auto& node : kf1.bow_feat_vec_)
+                for (unsigned j : node.second) {
+                    qi.push_back((int)j); qn.push_back((int)node.first); qa.push_back(kf1.keypts_[j].angle);
+                    qv.push_back(kf1.landmarks_[j] && !kf1.landmarks_[j]->will_be_erased());
+                    qd.insert(qd.end(), kf1.descriptors_.ptr<uint8_t>((int)j), kf1.descriptors_.ptr<uint8_t>((int)j) + 32);
+                }
+            for (const auto& node : kf2.bow_feat_vec_) for (unsigned i : node.second) tn[i] = (int)node.first;
+            for (int i = 0; i < n; ++i) {
+                ta[i] = kf2.keypts_[i].angle; tskip[i] = !kf2.landmarks_[i] || kf2.landmarks_[i]->will_be_erased();
+                std::copy(kf2.descriptors_.ptr<uint8_t>(i), kf2.descriptors_.ptr<uint8_t>(i) + 32, td.begin() + (size_t)i * 32);
+            }
+            const unsigned want_num = oracle_match_bow(qd.data(), qa.data(), qn.data(), qv.data(), (int)qi.size(), td.data(), ta.data(), tn.data(), tskip.data(), n,
+                                                       0.75f, 1, want.data());
+            std::vector<data::landmark*> expect((size_t)m, nullptr), matched;
+            for (int i = 0; i < n; ++i) if (want[i] >= 0) expect[(size_t)qi[(size_t)want[i]]] = kf2.landmarks_[(size_t)i];
+            const match::bow_tree bow_matcher(0.75, true);
+            const unsigned got_num = bow_matcher.match_keyframes(&kf1, &kf2, matched);
+            if (matched != expect || got_num != want_num) ++failures;
+            std::printf("bow_tree::match_keyframes: %u matches (oracle %u)\n", got_num, want_num);
+        }
         // ---------------- area::match_in_consistent_area (monocular initialisation: frame 2 = frame 1 moved by a few pixels)
         for (int check = 0; check < 2; ++check) {
             data::frame frm_1, frm_2;
