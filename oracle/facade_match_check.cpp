@@ -20,6 +20,7 @@
 
 #include "PLPSLAM/match/area.h"
 #include "PLPSLAM/match/bow_tree.h"
+#include "PLPSLAM/match/fuse.h"
 #include "PLPSLAM/match/projection.h"
 
 extern "C" {
@@ -40,6 +41,9 @@ unsigned oracle_match_current_and_last_line(const OKeyLine* kl, const uint8_t* l
                                             const uint8_t* l_has_obs, int m, float margin, int direction, int is_rgbd, int* line_last);
 unsigned oracle_match_area(const double* grid6, const OKeyPoint* kps1, const uint8_t* desc1, int n1, const OKeyPoint* kps2, const uint8_t* desc2,
                            int n2, float* prev_pts, int margin, float lowe_ratio, int check_orientation, int* matched_2_in_1);
+void oracle_fuse_search(const double* grid6, const OKeyPoint* kps, const uint8_t* desc, const float* x_right, int n, const float* scale_factors,
+                        const float* inv_level_sigma_sq, const uint8_t* lm_valid, const double* reproj_d, const float* lm_x_right,
+                        const unsigned* pred_level, const uint8_t* lm_desc, int m, float margin, int* best_idx);
 unsigned oracle_match_bow(const uint8_t* q_desc, const float* q_angle, const int* q_node, const uint8_t* q_valid, int m, const uint8_t* t_desc,
                           const float* t_angle, const int* t_node, const uint8_t* t_skip, int n, float lowe_ratio, int check_orientation, int* t_match);
 unsigned oracle_match_current_and_last(const double* grid6, const OKeyPoint* kps, const uint8_t* desc, const float* x_right,
@@ -90,6 +94,21 @@ struct landmark {
     bool has_observation() const { return observed_; }
     cv::Mat get_descriptor() const { return desc_.clone(); }
     Vec3_t get_pos_in_world() const { return pos_w_; }
+    // the part of data::landmark that match::fuse touches
+    float min_dist_ = 0.f, max_dist_ = 1e9f;
+    Vec3_t mean_normal_;
+    unsigned int pred_level_ = 0, num_obs_ = 1;
+    bool observed_in_target_ = false;
+    landmark* replaced_by_ = nullptr;
+    std::vector<std::pair<const void*, unsigned int>> observations_;
+    template <class KF> bool is_observed_in_keyframe(KF*) const { return observed_in_target_; }
+    float get_min_valid_distance() const { return min_dist_; }
+    float get_max_valid_distance() const { return max_dist_; }
+    Vec3_t get_obs_mean_normal() const { return mean_normal_; }
+    template <class KF> unsigned int predict_scale_level(double, KF*) const { return pred_level_; }
+    unsigned int num_observations() const { return num_obs_; }
+    void replace(landmark* lm) { replaced_by_ = lm; erased_ = true; }
+    template <class KF> void add_observation(KF* kf, unsigned int idx) { observations_.emplace_back((const void*)kf, idx); ++num_obs_; }
 };
 struct Line {
     bool _is_observable_in_tracking = true;
@@ -129,6 +148,16 @@ struct keyframe {
     std::vector<landmark*> landmarks_;
     std::map<unsigned int, std::vector<unsigned int>> bow_feat_vec_;
     std::vector<landmark*> get_landmarks() const { return landmarks_; }
+    // the part of data::keyframe that match::fuse touches
+    camera::base* camera_ = nullptr;
+    std::vector<cv::KeyPoint> undist_keypts_;
+    std::vector<float> stereo_x_right_, scale_factors_, inv_level_sigma_sq_;
+    Mat44_t cam_pose_cw_;
+    Mat33_t get_rotation() const { return cam_pose_cw_.block<3, 3>(0, 0); }
+    Vec3_t get_translation() const { return cam_pose_cw_.block<3, 1>(0, 3); }
+    Vec3_t get_cam_center() const { return -get_rotation().transpose() * get_translation(); }
+    landmark* get_landmark(unsigned int idx) const { return landmarks_.at(idx); }
+    void add_landmark(landmark* lm, unsigned int idx) { landmarks_.at(idx) = lm; }
 };
 }  // namespace data
 }  // namespace PLPSLAM
@@ -437,6 +466,95 @@ int main(int argc, char** argv) {
             const unsigned got_num = bow_matcher.match_keyframes(&kf1, &kf2, matched);
             if (matched != expect || got_num != want_num) ++failures;
             std::printf("bow_tree::match_keyframes: %u matches (oracle %u)\n", got_num, want_num);
+        }
+        // ---------------- fuse::replace_duplication
+        {
+            data::frame tmp;
+            fill_frame(tmp, &cam, n);
+            data::keyframe kf;
+            kf.camera_ = &cam; kf.keypts_ = tmp.keypts_; kf.undist_keypts_ = tmp.undist_keypts_; kf.descriptors_ = tmp.descriptors_;
+            kf.stereo_x_right_ = tmp.stereo_x_right_; kf.scale_factors_ = tmp.scale_factors_;
+            kf.inv_level_sigma_sq_.resize(8);
+            for (int l = 0; l < 8; ++l) kf.inv_level_sigma_sq_[l] = 1.f / (kf.scale_factors_[l] * kf.scale_factors_[l]);
+            kf.cam_pose_cw_(0, 3) = 0.02; kf.cam_pose_cw_(2, 3) = 0.05;
+            kf.landmarks_.assign(n, nullptr);
+            std::vector<std::unique_ptr<data::landmark>> pool;
+            for (int i = 0; i < n; ++i)
+                if (uni(0, 1) < 0.5) { pool.emplace_back(new data::landmark()); pool.back()->num_obs_ = (unsigned)irand(1, 6); pool.back()->erased_ = uni(0, 1) < 0.05; kf.landmarks_[i] = pool.back().get(); }
+            const Mat33_t rot_cw = kf.get_rotation();
+            const Vec3_t trans_cw = kf.get_translation(), cam_center = kf.get_cam_center();
+            std::vector<data::landmark*> to_check;
+            for (int j = 0; j < m; ++j) {
+                if (uni(0, 1) < 0.03) { to_check.push_back(nullptr); continue; }
+                pool.emplace_back(new data::landmark());
+                auto* lm = pool.back().get();
+                const int ki = irand(0, n - 1);
+                const auto& k = kf.undist_keypts_[(size_t)ki];
+                const double z = uni(0.5, 8.0);
+                // a point that reprojects near key point ki (camera-frame point moved back to the world: R = I)
+                const double px = k.pt.x + uni(-2.5, 2.5), py = k.pt.y + uni(-2.5, 2.5);
+                lm->pos_w_(0) = (px - cam.cx_) / cam.fx_ * z - trans_cw(0); lm->pos_w_(1) = (py - cam.cy_) / cam.fy_ * z - trans_cw(1); lm->pos_w_(2) = z - trans_cw(2);
+                lm->erased_ = uni(0, 1) < 0.04; lm->observed_in_target_ = uni(0, 1) < 0.05;
+                lm->min_dist_ = (float)(uni(0, 1) < 0.05 ? z + 1 : 0.1); lm->max_dist_ = (float)(uni(0, 1) < 0.05 ? z - 0.2 : 50.0);
+                const Vec3_t v = lm->pos_w_ - cam_center;
+                const double s = (uni(0, 1) < 0.9 ? 1.0 : -1.0) / v.norm();
+                lm->mean_normal_ = Vec3_t(v(0) * s, v(1) * s, v(2) * s);
+                lm->pred_level_ = (unsigned)std::max(0, std::min(7, k.octave + irand(-1, 1)));
+                lm->num_obs_ = (unsigned)irand(1, 6);
+                lm->desc_ = cv::Mat(1, 32, CV_8U);
+                std::copy(kf.descriptors_.ptr<uint8_t>(ki), kf.descriptors_.ptr<uint8_t>(ki) + 32, lm->desc_.ptr<uint8_t>(0));
+                for (int f = irand(0, 5); f > 0; --f) lm->desc_.ptr<uint8_t>(0)[irand(0, 31)] ^= (uint8_t)(1u << irand(0, 7));
+                to_check.push_back(lm);
+            }
+            // expectation: the reference's pre-tests as validity flags, the oracle's search, then the reference's mutation rules
+            const int mm = (int)to_check.size();
+            std::vector<uint8_t> valid(mm, 0), ld((size_t)mm * 32, 0);
+            std::vector<double> rp(2 * (size_t)mm, 0.0);
+            std::vector<float> lxr(mm, -1.f);
+            std::vector<unsigned> lvl(mm, 0);
+            std::vector<int> best(mm, -1);
+            for (int j = 0; j < mm; ++j) {
+                auto* lm = to_check[(size_t)j];
+                if (!lm || lm->will_be_erased() || lm->is_observed_in_keyframe(&kf)) continue;
+                Vec2_t r; float xr;
+                if (!cam.reproject_to_image(rot_cw, trans_cw, lm->pos_w_, r, xr)) continue;
+                const Vec3_t v = lm->pos_w_ - cam_center;
+                const double dist = v.norm();
+                if (dist < lm->min_dist_ || lm->max_dist_ < dist) continue;
+                if (v.dot(lm->mean_normal_) < 0.5 * dist) continue;
+                valid[j] = 1; rp[2 * j] = r(0); rp[2 * j + 1] = r(1); lxr[j] = xr; lvl[j] = lm->pred_level_;
+                std::copy(lm->desc_.ptr<uint8_t>(0), lm->desc_.ptr<uint8_t>(0) + 32, ld.begin() + (size_t)j * 32);
+            }
+            std::vector<uint8_t> kd((size_t)n * 32);
+            for (int i = 0; i < n; ++i) std::copy(kf.descriptors_.ptr<uint8_t>(i), kf.descriptors_.ptr<uint8_t>(i) + 32, kd.begin() + (size_t)i * 32);
+            const float margin = 3.f;
+            oracle_fuse_search(grid6, reinterpret_cast<const OKeyPoint*>(kf.undist_keypts_.data()), kd.data(), kf.stereo_x_right_.data(), n, kf.scale_factors_.data(),
+                               kf.inv_level_sigma_sq_.data(), valid.data(), rp.data(), lxr.data(), lvl.data(), ld.data(), mm, margin, best.data());
+            std::vector<data::landmark*> exp_slots = kf.landmarks_;
+            std::map<data::landmark*, data::landmark*> exp_replaced;
+            std::map<data::landmark*, unsigned> exp_obs;
+            unsigned want_num = 0;
+            for (int j = 0; j < mm; ++j) {
+                if (best[j] < 0) continue;
+                auto* lm = to_check[(size_t)j];
+                auto* in_kf = exp_slots[(size_t)best[j]];
+                const bool in_kf_erased = in_kf && (in_kf->erased_ || exp_replaced.count(in_kf));
+                if (in_kf) {
+                    if (!in_kf_erased) {
+                        const unsigned a = lm->num_obs_ + (exp_obs.count(lm) ? exp_obs[lm] : 0), b = in_kf->num_obs_ + (exp_obs.count(in_kf) ? exp_obs[in_kf] : 0);
+                        if (a < b) exp_replaced[lm] = in_kf; else exp_replaced[in_kf] = lm;
+                    }
+                } else { exp_obs[lm] += 1; exp_slots[(size_t)best[j]] = lm; }
+                ++want_num;
+            }
+            match::fuse fuse_matcher(0.6);
+            const unsigned got_num = fuse_matcher.replace_duplication(&kf, to_check, margin);
+            if (got_num != want_num || kf.landmarks_ != exp_slots) ++failures;
+            for (auto& up : pool) {
+                auto it = exp_replaced.find(up.get());
+                if (up->replaced_by_ != (it == exp_replaced.end() ? nullptr : it->second)) { ++failures; break; }
+            }
+            std::printf("fuse::replace_duplication: %u fused (oracle %u), %zu replacements\n", got_num, want_num, exp_replaced.size());
         }
         // ---------------- area::match_in_consistent_area (monocular initialisation: frame 2 = frame 1 moved by a few pixels)
         for (int check = 0; check < 2; ++check) {

@@ -12,6 +12,9 @@ struct Vec3_t {
     double& operator()(int i) { return v[i]; }
     double operator()(int i) const { return v[i]; }
     Vec3_t operator+(const Vec3_t& o) const { Vec3_t r; for (int i = 0; i < 3; ++i) r.v[i] = v[i] + o.v[i]; return r; }
+    Vec3_t operator-(const Vec3_t& o) const { Vec3_t r; for (int i = 0; i < 3; ++i) r.v[i] = v[i] - o.v[i]; return r; }
+    double dot(const Vec3_t& o) const { return v[0] * o.v[0] + v[1] * o.v[1] + v[2] * o.v[2]; }
+    double norm() const { return __builtin_sqrt(dot(*this)); }
 };
 inline Vec3_t operator*(double a, const Vec3_t& x) { Vec3_t r; for (int i = 0; i < 3; ++i) r.v[i] = a * x.v[i]; return r; }
 struct Vec6_t {
