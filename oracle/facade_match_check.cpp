@@ -41,6 +41,9 @@ unsigned oracle_match_current_and_last_line(const OKeyLine* kl, const uint8_t* l
                                             const uint8_t* l_has_obs, int m, float margin, int direction, int is_rgbd, int* line_last);
 unsigned oracle_match_area(const double* grid6, const OKeyPoint* kps1, const uint8_t* desc1, int n1, const OKeyPoint* kps2, const uint8_t* desc2,
                            int n2, float* prev_pts, int margin, float lowe_ratio, int check_orientation, int* matched_2_in_1);
+void oracle_fuse_search_line(const OKeyLine* kl, const uint8_t* lbd, int n, const float* scale_factors_lsd, const float* inv_level_sigma_sq_lsd,
+                             const uint8_t* valid, const double* sp_d, const double* ep_d, const unsigned* pred_level, const uint8_t* ldesc, int m,
+                             float margin, int* best_idx_out);
 void oracle_fuse_search(const double* grid6, const OKeyPoint* kps, const uint8_t* desc, const float* x_right, int n, const float* scale_factors,
                         const float* inv_level_sigma_sq, const uint8_t* lm_valid, const double* reproj_d, const float* lm_x_right,
                         const unsigned* pred_level, const uint8_t* lm_desc, int m, float margin, int* best_idx);
@@ -121,6 +124,18 @@ struct Line {
     bool has_observation() const { return observed_; }
     cv::Mat get_descriptor() const { return desc_.clone(); }
     Vec6_t get_pos_in_world() const { return pos_w_; }
+    // the part of data::Line that match::fuse touches
+    float min_dist_ = 0.f, max_dist_ = 1e9f;
+    unsigned int pred_level_ = 0, num_obs_ = 1;
+    bool observed_in_target_ = false;
+    Line* replaced_by_ = nullptr;
+    template <class KF> bool is_observed_in_keyframe(KF*) const { return observed_in_target_; }
+    float get_min_valid_distance() const { return min_dist_; }
+    float get_max_valid_distance() const { return max_dist_; }
+    unsigned int predict_scale_level(double, float, unsigned int) const { return pred_level_; }
+    unsigned int num_observations() const { return num_obs_; }
+    void replace(Line* lm) { replaced_by_ = lm; erased_ = true; }
+    template <class KF> void add_observation(KF*, unsigned int) { ++num_obs_; }
 };
 struct frame {
     // FW: line members of data::frame
@@ -158,6 +173,15 @@ struct keyframe {
     Vec3_t get_cam_center() const { return -get_rotation().transpose() * get_translation(); }
     landmark* get_landmark(unsigned int idx) const { return landmarks_.at(idx); }
     void add_landmark(landmark* lm, unsigned int idx) { landmarks_.at(idx) = lm; }
+    // FW: line members
+    float _log_scale_factor_lsd = 0.6931472f;
+    unsigned int _num_scale_levels_lsd = 2;
+    std::vector<float> _scale_factors_lsd, _inv_level_sigma_sq_lsd;
+    std::vector<OKeyLine> _keylsd;
+    cv::Mat _lbd_descr;
+    std::vector<Line*> _landmarks_line;
+    Line* get_landmark_line(unsigned int idx) const { return _landmarks_line.at(idx); }
+    void add_landmark_line(Line* lm, unsigned int idx) { _landmarks_line.at(idx) = lm; }
 };
 }  // namespace data
 }  // namespace PLPSLAM
@@ -555,6 +579,87 @@ int main(int argc, char** argv) {
                 if (up->replaced_by_ != (it == exp_replaced.end() ? nullptr : it->second)) { ++failures; break; }
             }
             std::printf("fuse::replace_duplication: %u fused (oracle %u), %zu replacements\n", got_num, want_num, exp_replaced.size());
+        }
+        // ---------------- fuse::replace_duplication_line
+        {
+            const int nlk = std::max(4, n / 5), mlk = std::max(4, m / 5);
+            data::frame tmp;
+            fill_frame(tmp, &cam, 4);
+            fill_lines(tmp, nlk);
+            data::keyframe kf;
+            kf.camera_ = &cam; kf._keylsd = tmp._keylsd; kf._lbd_descr = tmp._lbd_descr; kf._scale_factors_lsd = {1.f, 2.f}; kf._inv_level_sigma_sq_lsd = {1.f, 0.25f};
+            kf.cam_pose_cw_(0, 3) = -0.03; kf.cam_pose_cw_(2, 3) = 0.04;
+            kf._landmarks_line.assign(nlk, nullptr);
+            std::vector<std::unique_ptr<data::Line>> pool;
+            for (int i = 0; i < nlk; ++i)
+                if (uni(0, 1) < 0.5) { pool.emplace_back(new data::Line()); pool.back()->num_obs_ = (unsigned)irand(1, 6); pool.back()->erased_ = uni(0, 1) < 0.05; kf._landmarks_line[i] = pool.back().get(); }
+            const Mat33_t rot_cw = kf.get_rotation();
+            const Vec3_t trans_cw = kf.get_translation(), cam_center = kf.get_cam_center();
+            std::vector<data::Line*> to_check;
+            for (int j = 0; j < mlk; ++j) {
+                pool.emplace_back(new data::Line());
+                auto* lm = pool.back().get();
+                const int ki = irand(0, nlk - 1);
+                const OKeyLine& k = kf._keylsd[(size_t)ki];
+                const double z1 = uni(0.6, 7.0), z2 = z1 + uni(-0.2, 0.2);
+                const double stretch = uni(0, 1) < 0.15 ? uni(2, 10) : 1.0;       // some 3D lines leave the image
+                const double sx = k.startPointX + uni(-1, 1), sy = k.startPointY + uni(-1, 1);
+                const double ex = k.startPointX + stretch * (k.endPointX - k.startPointX) + uni(-1, 1), ey = k.startPointY + stretch * (k.endPointY - k.startPointY) + uni(-1, 1);
+                lm->pos_w_(0) = (sx - cam.cx_) / cam.fx_ * z1 - trans_cw(0); lm->pos_w_(1) = (sy - cam.cy_) / cam.fy_ * z1 - trans_cw(1); lm->pos_w_(2) = z1 - trans_cw(2);
+                lm->pos_w_(3) = (ex - cam.cx_) / cam.fx_ * z2 - trans_cw(0); lm->pos_w_(4) = (ey - cam.cy_) / cam.fy_ * z2 - trans_cw(1); lm->pos_w_(5) = z2 - trans_cw(2);
+                lm->erased_ = uni(0, 1) < 0.04; lm->observed_in_target_ = uni(0, 1) < 0.05;
+                lm->min_dist_ = (float)(uni(0, 1) < 0.05 ? z1 + 1 : 0.1); lm->max_dist_ = (float)(uni(0, 1) < 0.05 ? z1 - 0.3 : 50.0);
+                lm->pred_level_ = (unsigned)irand(0, 1); lm->num_obs_ = (unsigned)irand(1, 6);
+                lm->desc_ = cv::Mat(1, 32, CV_8U);
+                std::copy(kf._lbd_descr.ptr<uint8_t>(ki), kf._lbd_descr.ptr<uint8_t>(ki) + 32, lm->desc_.ptr<uint8_t>(0));
+                for (int f = irand(0, 5); f > 0; --f) lm->desc_.ptr<uint8_t>(0)[irand(0, 31)] ^= (uint8_t)(1u << irand(0, 7));
+                to_check.push_back(lm);
+            }
+            std::vector<uint8_t> valid(mlk, 0), ld((size_t)mlk * 32, 0), kd((size_t)nlk * 32);
+            std::vector<double> sp(2 * (size_t)mlk, 0.0), ep(2 * (size_t)mlk, 0.0);
+            std::vector<unsigned> lvl(mlk, 0);
+            std::vector<int> best(mlk, -1);
+            for (int j = 0; j < mlk; ++j) {
+                auto* lm = to_check[(size_t)j];
+                if (lm->will_be_erased() || lm->observed_in_target_) continue;
+                const Vec3_t a3 = lm->pos_w_.head(3), b3 = lm->pos_w_.tail(3);
+                Vec2_t a, b, c; float xa, xb, xc;
+                const bool ia = cam.reproject_to_image(rot_cw, trans_cw, a3, a, xa), ib = cam.reproject_to_image(rot_cw, trans_cw, b3, b, xb);
+                if (!ia && !ib) continue;
+                if ((!ia || !ib) && !cam.reproject_to_image(rot_cw, trans_cw, 0.5 * (a3 + b3), c, xc)) continue;
+                const double da = (a3 - cam_center).norm(), db = (b3 - cam_center).norm();
+                if (da < lm->min_dist_ || lm->max_dist_ < da || db < lm->min_dist_ || lm->max_dist_ < db) continue;
+                valid[j] = 1; sp[2 * j] = a(0); sp[2 * j + 1] = a(1); ep[2 * j] = b(0); ep[2 * j + 1] = b(1); lvl[j] = lm->pred_level_;
+                std::copy(lm->desc_.ptr<uint8_t>(0), lm->desc_.ptr<uint8_t>(0) + 32, ld.begin() + (size_t)j * 32);
+            }
+            for (int i = 0; i < nlk; ++i) std::copy(kf._lbd_descr.ptr<uint8_t>(i), kf._lbd_descr.ptr<uint8_t>(i) + 32, kd.begin() + (size_t)i * 32);
+            const float margin = 4.f;
+            oracle_fuse_search_line(kf._keylsd.data(), kd.data(), nlk, kf._scale_factors_lsd.data(), kf._inv_level_sigma_sq_lsd.data(), valid.data(), sp.data(),
+                                    ep.data(), lvl.data(), ld.data(), mlk, margin, best.data());
+            std::vector<data::Line*> exp_slots = kf._landmarks_line;
+            std::map<data::Line*, data::Line*> exp_replaced;
+            std::map<data::Line*, unsigned> exp_obs;
+            unsigned want_num = 0;
+            for (int j = 0; j < mlk; ++j) {
+                if (best[j] < 0) continue;
+                auto* lm = to_check[(size_t)j];
+                auto* in_kf = exp_slots[(size_t)best[j]];
+                if (in_kf) {
+                    if (!(in_kf->erased_ || exp_replaced.count(in_kf))) {
+                        const unsigned a = lm->num_obs_ + (exp_obs.count(lm) ? exp_obs[lm] : 0), b = in_kf->num_obs_ + (exp_obs.count(in_kf) ? exp_obs[in_kf] : 0);
+                        if (a < b) exp_replaced[lm] = in_kf; else exp_replaced[in_kf] = lm;
+                    }
+                } else { exp_obs[lm] += 1; exp_slots[(size_t)best[j]] = lm; }
+                ++want_num;
+            }
+            match::fuse fuse_matcher(0.6);
+            const unsigned got_num = fuse_matcher.replace_duplication_line(&kf, to_check, margin);
+            if (got_num != want_num || kf._landmarks_line != exp_slots) ++failures;
+            for (auto& up : pool) {
+                auto it = exp_replaced.find(up.get());
+                if (up->replaced_by_ != (it == exp_replaced.end() ? nullptr : it->second)) { ++failures; break; }
+            }
+            std::printf("fuse::replace_duplication_line: %u fused (oracle %u), %zu replacements\n", got_num, want_num, exp_replaced.size());
         }
         // ---------------- area::match_in_consistent_area (monocular initialisation: frame 2 = frame 1 moved by a few pixels)
         for (int check = 0; check < 2; ++check) {

@@ -22,6 +22,8 @@ struct Vec6_t {
     double& operator()(int i) { return v[i]; }
     template <int N> Vec3_t head() const { static_assert(N == 3, "head<3> only"); Vec3_t r; for (int i = 0; i < 3; ++i) r.v[i] = v[i]; return r; }
     template <int N> Vec3_t tail() const { static_assert(N == 3, "tail<3> only"); Vec3_t r; for (int i = 0; i < 3; ++i) r.v[i] = v[3 + i]; return r; }
+    Vec3_t head(int) const { return head<3>(); }      // pos_w.head(3) / pos_w.tail(3) (fuse.cc:357-358)
+    Vec3_t tail(int) const { return tail<3>(); }
 };
 struct Mat33_t {
     double m[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};

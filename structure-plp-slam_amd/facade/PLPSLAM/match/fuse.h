@@ -5,9 +5,9 @@
 // mutation (:300-324) in the reference's order; the windowed chi-square / Hamming search (:233-298) runs in
 // libplp_front.so (PLP_MATCH_MODE_FUSE) for all landmarks of the call at once -- the pre-tests of a landmark do not depend on
 // the mutations made for the landmarks before it as long as landmarks_to_check holds every landmark once, which is how the
-// reference's callers build it (a set, or a vector filled through a set).  detect_duplication and the line variant keep
-// their declarations and their bodies in the reference's fuse.cc (their searches: PLP_MATCH_MODE_FUSE with
-// NO_CHI2 | SIGNED_LEVEL, PLP_MATCH_MODE_FUSE_LINE).  Templates on the key-frame / container types, like match/projection.h.
+// reference's callers build it (a set, or a vector filled through a set).  replace_duplication_line (:335-505) is the same with PLP_MATCH_MODE_FUSE_LINE.
+// detect_duplication keeps its declaration and its body in the reference's fuse.cc (its search: PLP_MATCH_MODE_FUSE with
+// NO_CHI2 | SIGNED_LEVEL).  Templates on the key-frame / container types, like match/projection.h.
 #ifndef PLPSLAM_MATCH_FUSE_H
 #define PLPSLAM_MATCH_FUSE_H
 
@@ -103,8 +103,88 @@ public:
         return num_fused;
     }
 
-    template <typename T>
-    unsigned int replace_duplication_line(data::keyframe* keyfrm, const T& landmarks_to_check, const float margin = 3.0);
+    //! fuse.cc:335-505 (3D lines against the key lines of a key frame)
+    template <class KeyFrame, class T>
+    unsigned int replace_duplication_line(KeyFrame* keyfrm, const T& landmarks_to_check, const float margin = 3.0) {
+        const Mat33_t rot_cw = keyfrm->get_rotation();
+        const Vec3_t trans_cw = keyfrm->get_translation();
+        const Vec3_t cam_center = keyfrm->get_cam_center();
+        using LinePtr = typename std::decay<decltype(*landmarks_to_check.begin())>::type;
+        std::vector<LinePtr> lms;
+        std::vector<double> sp_d, ep_d;
+        std::vector<int32_t> level;
+        std::vector<uint8_t> desc;
+        for (const auto lm : landmarks_to_check) {
+            if (!lm) continue;
+            if (lm->will_be_erased()) continue;
+            if (lm->is_observed_in_keyframe(keyfrm)) continue;
+            const Vec6_t pos_w = lm->get_pos_in_world();
+            const Vec3_t pos_w_sp = pos_w.head(3), pos_w_ep = pos_w.tail(3);
+            Vec2_t reproj_sp, reproj_ep;
+            float x_right_sp, x_right_ep;
+            const bool in_image_sp = keyfrm->camera_->reproject_to_image(rot_cw, trans_cw, pos_w_sp, reproj_sp, x_right_sp);
+            const bool in_image_ep = keyfrm->camera_->reproject_to_image(rot_cw, trans_cw, pos_w_ep, reproj_ep, x_right_ep);
+            if (!in_image_sp && !in_image_ep) continue;
+            if (!in_image_sp || !in_image_ep) {
+                const Vec3_t pos_w_mp = 0.5 * (pos_w_sp + pos_w_ep);
+                Vec2_t reproj_mp;
+                float x_right_mp;
+                if (!keyfrm->camera_->reproject_to_image(rot_cw, trans_cw, pos_w_mp, reproj_mp, x_right_mp)) continue;
+            }
+            const Vec3_t cam_to_lm_vec_sp = pos_w_sp - cam_center, cam_to_lm_vec_ep = pos_w_ep - cam_center;
+            const auto cam_to_lm_dist_sp = cam_to_lm_vec_sp.norm(), cam_to_lm_dist_ep = cam_to_lm_vec_ep.norm();
+            const auto max_cam_to_lm_dist = lm->get_max_valid_distance();
+            const auto min_cam_to_lm_dist = lm->get_min_valid_distance();
+            if (cam_to_lm_dist_sp < min_cam_to_lm_dist || max_cam_to_lm_dist < cam_to_lm_dist_sp || cam_to_lm_dist_ep < min_cam_to_lm_dist ||
+                max_cam_to_lm_dist < cam_to_lm_dist_ep)
+                continue;
+            const Vec3_t cam_to_lm_vec_mp = 0.5 * (pos_w_sp + pos_w_ep) - cam_center;
+            const auto pred_scale_level = lm->predict_scale_level(cam_to_lm_vec_mp.norm(), keyfrm->_log_scale_factor_lsd, keyfrm->_num_scale_levels_lsd);
+            lms.push_back(lm);
+            sp_d.push_back(reproj_sp(0)); sp_d.push_back(reproj_sp(1)); ep_d.push_back(reproj_ep(0)); ep_d.push_back(reproj_ep(1));
+            level.push_back(static_cast<int32_t>(pred_scale_level));
+            const auto lm_desc = lm->get_descriptor();
+            const unsigned char* p = lm_desc.template ptr<unsigned char>(0);
+            desc.insert(desc.end(), p, p + 32);
+        }
+        const int n = static_cast<int>(keyfrm->_keylsd.size()), m = static_cast<int>(lms.size());
+        if (n == 0 || m == 0) return 0;
+        static_assert(sizeof(keyfrm->_keylsd[0]) == sizeof(plp_keyline), "KeyLine must be the 68-byte record of descriptor_custom.hpp");
+        std::vector<uint8_t> t_desc(static_cast<size_t>(n) * 32);
+        for (int i = 0; i < n; ++i) {
+            const unsigned char* p = keyfrm->_lbd_descr.template ptr<unsigned char>(i);
+            for (int k = 0; k < 32; ++k) t_desc[static_cast<size_t>(i) * 32 + k] = p[k];
+        }
+        std::vector<int32_t> best(static_cast<size_t>(m), -1);
+        plp_match_args a{};
+        a.mode = PLP_MATCH_MODE_FUSE_LINE; a.B = 1; a.n_cap = n; a.m_cap = m;
+        a.t_kl = reinterpret_cast<const plp_keyline*>(keyfrm->_keylsd.data()); a.t_desc = t_desc.data();
+        a.q_reproj_d = sp_d.data(); a.q_reproj2_d = ep_d.data(); a.q_level = level.data(); a.q_desc = desc.data();
+        a.margin = margin; a.lowe_ratio = lowe_ratio_;
+        a.num_levels = static_cast<int32_t>(keyfrm->_scale_factors_lsd.size()); a.scale_factors = keyfrm->_scale_factors_lsd.data();
+        a.inv_level_sigma_sq = keyfrm->_inv_level_sigma_sq_lsd.data();
+        a.grid = detail::grid_of(keyfrm->camera_);
+        a.out_query_best = best.data();
+        detail::check(plp_match_host(detail::shared_matcher(), &a));
+        unsigned int num_fused = 0;
+        for (int q = 0; q < m; ++q) {      // :478-501, in the reference's order
+            const int best_idx = best[static_cast<size_t>(q)];
+            if (best_idx < 0) continue;
+            auto lm = lms[static_cast<size_t>(q)];
+            auto* lm_in_keyfrm = keyfrm->get_landmark_line(best_idx);
+            if (lm_in_keyfrm) {
+                if (!lm_in_keyfrm->will_be_erased()) {
+                    if (lm->num_observations() < lm_in_keyfrm->num_observations()) lm->replace(lm_in_keyfrm);
+                    else lm_in_keyfrm->replace(lm);
+                }
+            } else {
+                lm->add_observation(keyfrm, best_idx);
+                keyfrm->add_landmark_line(lm, best_idx);
+            }
+            ++num_fused;
+        }
+        return num_fused;
+    }
 };
 
 }  // namespace match
