@@ -21,6 +21,7 @@
 #include "PLPSLAM/match/area.h"
 #include "PLPSLAM/match/bow_tree.h"
 #include "PLPSLAM/match/fuse.h"
+#include "PLPSLAM/match/robust.h"
 #include "PLPSLAM/match/projection.h"
 
 extern "C" {
@@ -41,6 +42,10 @@ unsigned oracle_match_current_and_last_line(const OKeyLine* kl, const uint8_t* l
                                             const uint8_t* l_has_obs, int m, float margin, int direction, int is_rgbd, int* line_last);
 unsigned oracle_match_area(const double* grid6, const OKeyPoint* kps1, const uint8_t* desc1, int n1, const OKeyPoint* kps2, const uint8_t* desc2,
                            int n2, float* prev_pts, int margin, float lowe_ratio, int check_orientation, int* matched_2_in_1);
+unsigned oracle_match_for_triangulation(const uint8_t* q_desc, const float* q_angle, const int* q_node, const uint8_t* q_has_lm, const float* q_x_right,
+                                        const int* q_octave, const double* q_bearing, int m, const uint8_t* t_desc, const float* t_angle,
+                                        const int* t_node, const uint8_t* t_has_lm, const float* t_x_right, const double* t_bearing, int n,
+                                        const float* scale_factors, const double* E_12, const double* epipole, int check_orientation, int* match_2_of_q);
 void oracle_fuse_search_line(const OKeyLine* kl, const uint8_t* lbd, int n, const float* scale_factors_lsd, const float* inv_level_sigma_sq_lsd,
                              const uint8_t* valid, const double* sp_d, const double* ep_d, const unsigned* pred_level, const uint8_t* ldesc, int m,
                              float margin, int* best_idx_out);
@@ -80,6 +85,12 @@ struct base {   // a perspective camera without distortion
         reproj(1) = fy_ * pos_c(1) * z_inv + cy_;
         x_right = static_cast<float>(reproj(0) - focal_x_baseline_ * z_inv);
         return !(reproj(0) < img_bounds_.min_x_ || reproj(0) > img_bounds_.max_x_ || reproj(1) < img_bounds_.min_y_ || reproj(1) > img_bounds_.max_y_);
+    }
+    bool reproject_to_bearing(const Mat33_t& rot_cw, const Vec3_t& trans_cw, const Vec3_t& pos_w, Vec3_t& reproj) const {
+        const Vec3_t p = rot_cw * pos_w + trans_cw;
+        const double nrm = p.norm();
+        reproj = Vec3_t(p(0) / nrm, p(1) / nrm, p(2) / nrm);
+        return p(2) > 0;
     }
 };
 }  // namespace camera
@@ -173,6 +184,8 @@ struct keyframe {
     Vec3_t get_cam_center() const { return -get_rotation().transpose() * get_translation(); }
     landmark* get_landmark(unsigned int idx) const { return landmarks_.at(idx); }
     void add_landmark(landmark* lm, unsigned int idx) { landmarks_.at(idx) = lm; }
+    unsigned int num_keypts_ = 0;
+    std::vector<Vec3_t> bearings_;
     // FW: line members
     float _log_scale_factor_lsd = 0.6931472f;
     unsigned int _num_scale_levels_lsd = 2;
@@ -579,6 +592,83 @@ int main(int argc, char** argv) {
                 if (up->replaced_by_ != (it == exp_replaced.end() ? nullptr : it->second)) { ++failures; break; }
             }
             std::printf("fuse::replace_duplication: %u fused (oracle %u), %zu replacements\n", got_num, want_num, exp_replaced.size());
+        }
+        // ---------------- robust::match_for_triangulation
+        for (int check = 0; check < 2; ++check) {
+            const unsigned n_nodes = 23;
+            data::frame tmp2, tmp1;
+            fill_frame(tmp2, &cam, n); fill_frame(tmp1, &cam, m);
+            std::vector<std::unique_ptr<data::landmark>> pool;
+            data::keyframe kf1, kf2;
+            const double tr[3] = {0.25, -0.04, 0.06};                         // p2 = p1 - tr (key frame 2 = key frame 1 translated)
+            auto init = [&](data::keyframe& kf, const data::frame& f, int cnt) {
+                kf.camera_ = &cam; kf.num_keypts_ = (unsigned)cnt; kf.keypts_ = f.keypts_; kf.undist_keypts_ = f.undist_keypts_; kf.descriptors_ = f.descriptors_;
+                kf.stereo_x_right_ = f.stereo_x_right_; kf.scale_factors_ = f.scale_factors_; kf.landmarks_.assign(cnt, nullptr); kf.bearings_.resize(cnt);
+                for (int i = 0; i < cnt; ++i) if (uni(0, 1) < 0.3) { pool.emplace_back(new data::landmark()); kf.landmarks_[i] = pool.back().get(); }
+            };
+            init(kf2, tmp2, n); init(kf1, tmp1, m);
+            kf2.cam_pose_cw_(0, 3) = -tr[0]; kf2.cam_pose_cw_(1, 3) = -tr[1]; kf2.cam_pose_cw_(2, 3) = -tr[2];
+            std::vector<Vec3_t> pts2((size_t)n);
+            for (int i = 0; i < n; ++i) {
+                Vec3_t p1(uni(-2, 2), uni(-1.5, 1.5), uni(1, 8));            // the 3D point in key frame 1
+                pts2[(size_t)i] = p1;
+                Vec3_t p2(p1(0) - tr[0], p1(1) - tr[1], p1(2) - tr[2]);
+                if (uni(0, 1) < 0.05) p2 = Vec3_t(-tr[0] * 3 + uni(-0.01, 0.01), -tr[1] * 3 + uni(-0.01, 0.01), -tr[2] * 3 + uni(-0.01, 0.01));   // next to the epipole
+                const double nn = p2.norm();
+                kf2.bearings_[(size_t)i] = Vec3_t(p2(0) / nn, p2(1) / nn, p2(2) / nn);
+                if (uni(0, 1) < 0.95) kf2.bow_feat_vec_[(unsigned)(kf2.descriptors_.ptr<uint8_t>(i)[0] * 3 + 1) % n_nodes].push_back((unsigned)i);
+            }
+            for (int j = 0; j < m; ++j) {                                     // key frame 1 features observe (noisy) points of key frame 2's features
+                const int src = irand(0, n - 1);
+                const Vec3_t& p1 = pts2[(size_t)src];
+                Vec3_t q(p1(0) + uni(-0.004, 0.004) * p1(2), p1(1) + uni(-0.004, 0.004) * p1(2), p1(2));
+                const double nn = q.norm();
+                kf1.bearings_[(size_t)j] = Vec3_t(q(0) / nn, q(1) / nn, q(2) / nn);
+                std::copy(kf2.descriptors_.ptr<uint8_t>(src), kf2.descriptors_.ptr<uint8_t>(src) + 32, kf1.descriptors_.ptr<uint8_t>(j));
+                for (int f = irand(0, 3); f > 0; --f) kf1.descriptors_.ptr<uint8_t>(j)[irand(1, 31)] ^= (uint8_t)(1u << irand(0, 7));
+                float ang = kf2.undist_keypts_[(size_t)src].angle + (uni(0, 1) < 0.8 ? (float)uni(-3, 3) : (float)uni(0, 300));
+                if (ang >= 360.f) ang -= 360.f;
+                if (ang < 0.f) ang += 360.f;
+                kf1.undist_keypts_[(size_t)j].angle = ang;
+                if (uni(0, 1) < 0.95) kf1.bow_feat_vec_[(unsigned)(kf1.descriptors_.ptr<uint8_t>(j)[0] * 3 + 1) % n_nodes].push_back((unsigned)j);
+            }
+            // E_12 = [t]x R with R = I, t = translation of 2 w.r.t. 1 expressed so that b1^T E b2 = 0 for p2 = p1 - tr
+            Mat33_t E_12;
+            E_12(0, 1) = -tr[2]; E_12(0, 2) = tr[1]; E_12(1, 0) = tr[2]; E_12(1, 2) = -tr[0]; E_12(2, 0) = -tr[1]; E_12(2, 1) = tr[0];
+            // expectation
+            std::vector<uint8_t> qd, qhas, td((size_t)n * 32), thas(n);
+            std::vector<float> qa, qx, ta(n);
+            std::vector<int> qn, qo, tn(n, -1), qi;
+            std::vector<double> qb, tb(3 * (size_t)n);
+            for (const auto& node : kf1.bow_feat_vec_)
+                for (unsigned j : node.second) {
+                    qi.push_back((int)j); qn.push_back((int)node.first); qa.push_back(kf1.undist_keypts_[j].angle); qhas.push_back(kf1.landmarks_[j] != nullptr);
+                    qx.push_back(kf1.stereo_x_right_[j]); qo.push_back(kf1.undist_keypts_[j].octave);
+                    for (int c = 0; c < 3; ++c) qb.push_back(kf1.bearings_[j](c));
+                    qd.insert(qd.end(), kf1.descriptors_.ptr<uint8_t>((int)j), kf1.descriptors_.ptr<uint8_t>((int)j) + 32);
+                }
+            for (const auto& node : kf2.bow_feat_vec_) for (unsigned i : node.second) tn[i] = (int)node.first;
+            for (int i = 0; i < n; ++i) {
+                ta[i] = kf2.undist_keypts_[(size_t)i].angle; thas[i] = kf2.landmarks_[(size_t)i] != nullptr;
+                for (int c = 0; c < 3; ++c) tb[3 * (size_t)i + c] = kf2.bearings_[(size_t)i](c);
+                std::copy(kf2.descriptors_.ptr<uint8_t>(i), kf2.descriptors_.ptr<uint8_t>(i) + 32, td.begin() + (size_t)i * 32);
+            }
+            Vec3_t epi;
+            cam.reproject_to_bearing(kf2.get_rotation(), kf2.get_translation(), kf1.get_cam_center(), epi);
+            double E9[9], ep3[3] = {epi(0), epi(1), epi(2)};
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) E9[3 * r + c] = E_12(r, c);
+            std::vector<int> m2((size_t)qi.size());
+            const unsigned want_num = oracle_match_for_triangulation(qd.data(), qa.data(), qn.data(), qhas.data(), qx.data(), qo.data(), qb.data(), (int)qi.size(),
+                                                                     td.data(), ta.data(), tn.data(), thas.data(), kf2.stereo_x_right_.data(), tb.data(), n,
+                                                                     kf1.scale_factors_.data(), E9, ep3, check, m2.data());
+            std::vector<std::pair<unsigned, unsigned>> want_pairs, got_pairs;
+            std::vector<int> by1((size_t)m, -1);
+            for (size_t q = 0; q < qi.size(); ++q) if (m2[q] >= 0) by1[(size_t)qi[q]] = m2[q];
+            for (int j = 0; j < m; ++j) if (by1[(size_t)j] >= 0) want_pairs.emplace_back((unsigned)j, (unsigned)by1[(size_t)j]);
+            match::robust robust_matcher(0.75, check != 0);
+            const unsigned got_num = robust_matcher.match_for_triangulation(&kf1, &kf2, E_12, got_pairs);
+            if (got_num != want_num || got_pairs != want_pairs) ++failures;
+            std::printf("robust::match_for_triangulation[check_orientation %d]: %u matches (oracle %u)\n", check, got_num, want_num);
         }
         // ---------------- fuse::replace_duplication_line
         {
