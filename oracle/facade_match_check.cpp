@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <memory>
 #include <random>
+#include <set>
 #include <vector>
 
 #include <opencv2/core.hpp>
@@ -42,6 +43,9 @@ unsigned oracle_match_current_and_last_line(const OKeyLine* kl, const uint8_t* l
                                             const uint8_t* l_has_obs, int m, float margin, int direction, int is_rgbd, int* line_last);
 unsigned oracle_match_area(const double* grid6, const OKeyPoint* kps1, const uint8_t* desc1, int n1, const OKeyPoint* kps2, const uint8_t* desc2,
                            int n2, float* prev_pts, int margin, float lowe_ratio, int check_orientation, int* matched_2_in_1);
+unsigned oracle_match_frame_and_keyframe(const double* grid6, const OKeyPoint* kps, const uint8_t* desc, const uint8_t* occupied, int n, const float* scale_factors,
+                                         const uint8_t* valid, const float* reproj, const unsigned* pred_level, const float* langle, const uint8_t* ldesc, int m,
+                                         float margin, unsigned hamm_dist_thr, int check_orientation, int* kp_match);
 unsigned oracle_match_for_triangulation(const uint8_t* q_desc, const float* q_angle, const int* q_node, const uint8_t* q_has_lm, const float* q_x_right,
                                         const int* q_octave, const double* q_bearing, int m, const uint8_t* t_desc, const float* t_angle,
                                         const int* t_node, const uint8_t* t_has_lm, const float* t_x_right, const double* t_bearing, int n,
@@ -592,6 +596,77 @@ int main(int argc, char** argv) {
                 if (up->replaced_by_ != (it == exp_replaced.end() ? nullptr : it->second)) { ++failures; break; }
             }
             std::printf("fuse::replace_duplication: %u fused (oracle %u), %zu replacements\n", got_num, want_num, exp_replaced.size());
+        }
+        // ---------------- projection::match_frame_and_keyframe (relocalisation)
+        for (int check = 0; check < 2; ++check) {
+            data::frame curr;
+            fill_frame(curr, &cam, n);
+            curr.cam_pose_cw_(0, 3) = 0.03; curr.cam_pose_cw_(2, 3) = -0.02;
+            data::frame tmpk;
+            fill_frame(tmpk, &cam, m);
+            data::keyframe kf;
+            kf.camera_ = &cam; kf.undist_keypts_ = tmpk.undist_keypts_; kf.landmarks_.assign(m, nullptr);
+            std::vector<std::unique_ptr<data::landmark>> pool;
+            std::set<data::landmark*> already;
+            const Mat33_t rot_cw = curr.cam_pose_cw_.block<3, 3>(0, 0);
+            const Vec3_t trans_cw = curr.cam_pose_cw_.block<3, 1>(0, 3);
+            const Vec3_t cam_center = -rot_cw.transpose() * trans_cw;
+            for (int i = 0; i < n; ++i)
+                if (uni(0, 1) < 0.15) { pool.emplace_back(new data::landmark()); pool.back()->observed_ = uni(0, 1) < 0.5; curr.landmarks_[i] = pool.back().get(); }
+            for (int j = 0; j < m; ++j) {
+                if (uni(0, 1) < 0.15) continue;
+                pool.emplace_back(new data::landmark());
+                auto* lm = pool.back().get();
+                const int ki = irand(0, n - 1);
+                const auto& k = curr.undist_keypts_[(size_t)ki];
+                const double z = uni(0.5, 8.0), px = k.pt.x + uni(-5, 5), py = k.pt.y + uni(-5, 5);
+                lm->pos_w_(0) = (px - cam.cx_) / cam.fx_ * z - trans_cw(0); lm->pos_w_(1) = (py - cam.cy_) / cam.fy_ * z - trans_cw(1); lm->pos_w_(2) = z - trans_cw(2);
+                lm->erased_ = uni(0, 1) < 0.04;
+                lm->min_dist_ = (float)(uni(0, 1) < 0.05 ? z + 1 : 0.1); lm->max_dist_ = (float)(uni(0, 1) < 0.05 ? z - 0.2 : 50.0);
+                lm->pred_level_ = (unsigned)std::max(0, std::min(7, k.octave + irand(-1, 1)));
+                lm->desc_ = cv::Mat(1, 32, CV_8U);
+                std::copy(curr.descriptors_.ptr<uint8_t>(ki), curr.descriptors_.ptr<uint8_t>(ki) + 32, lm->desc_.ptr<uint8_t>(0));
+                for (int f = irand(0, 6); f > 0; --f) lm->desc_.ptr<uint8_t>(0)[irand(0, 31)] ^= (uint8_t)(1u << irand(0, 7));
+                float ang = k.angle + (uni(0, 1) < 0.8 ? (float)uni(-3, 3) : (float)uni(0, 300));
+                if (ang >= 360.f) ang -= 360.f;
+                if (ang < 0.f) ang += 360.f;
+                kf.undist_keypts_[(size_t)j].angle = ang;
+                kf.landmarks_[(size_t)j] = lm;
+                if (uni(0, 1) < 0.1) already.insert(lm);
+            }
+            std::vector<uint8_t> valid(m, 0), ld((size_t)m * 32, 0), occ(n);
+            std::vector<float> rp(2 * (size_t)m, 0.f), lang(m, 0.f);
+            std::vector<unsigned> lvl(m, 0);
+            std::vector<int> want(n);
+            for (int j = 0; j < m; ++j) {
+                auto* lm = kf.landmarks_[(size_t)j];
+                if (!lm || lm->will_be_erased() || already.count(lm)) continue;
+                Vec2_t r; float xr;
+                if (!cam.reproject_to_image(rot_cw, trans_cw, lm->pos_w_, r, xr)) continue;
+                const double dist = (lm->pos_w_ - cam_center).norm();
+                if (dist < lm->min_dist_ || lm->max_dist_ < dist) continue;
+                valid[j] = 1; rp[2 * j] = (float)r(0); rp[2 * j + 1] = (float)r(1); lvl[j] = lm->pred_level_; lang[j] = kf.undist_keypts_[(size_t)j].angle;
+                std::copy(lm->desc_.ptr<uint8_t>(0), lm->desc_.ptr<uint8_t>(0) + 32, ld.begin() + (size_t)j * 32);
+            }
+            for (int i = 0; i < n; ++i) occ[i] = curr.landmarks_[(size_t)i] != nullptr;
+            const auto fd = desc_of(curr);
+            const unsigned thr = check ? 50u : 100u;
+            const float margin = 10.f;
+            std::vector<int> raw(n);
+            oracle_match_frame_and_keyframe(grid6, reinterpret_cast<const OKeyPoint*>(curr.undist_keypts_.data()), fd.data(), occ.data(), n, curr.scale_factors_.data(),
+                                            valid.data(), rp.data(), lvl.data(), lang.data(), ld.data(), m, margin, thr, 0, raw.data());
+            const unsigned want_num = oracle_match_frame_and_keyframe(grid6, reinterpret_cast<const OKeyPoint*>(curr.undist_keypts_.data()), fd.data(), occ.data(), n,
+                                                                      curr.scale_factors_.data(), valid.data(), rp.data(), lvl.data(), lang.data(), ld.data(), m,
+                                                                      margin, thr, check, want.data());
+            const std::vector<data::landmark*> before = curr.landmarks_;
+            const match::projection projection_matcher(0.9, check != 0);
+            const unsigned got_num = projection_matcher.match_frame_and_keyframe(curr, &kf, already, margin, thr);
+            for (int i = 0; i < n; ++i) {
+                data::landmark* expect = want[i] >= 0 ? kf.landmarks_[(size_t)want[i]] : (raw[i] >= 0 ? nullptr : before[i]);
+                if (curr.landmarks_[(size_t)i] != expect) ++failures;
+            }
+            if (got_num != want_num) ++failures;
+            std::printf("projection::match_frame_and_keyframe[check_orientation %d, thr %u]: %u matches (oracle %u)\n", check, thr, got_num, want_num);
         }
         // ---------------- robust::match_for_triangulation
         for (int check = 0; check < 2; ++check) {

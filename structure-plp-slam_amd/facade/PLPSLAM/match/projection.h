@@ -142,11 +142,64 @@ public:
     explicit projection(const float lowe_ratio = 0.6, const bool check_orientation = true) : base(lowe_ratio, check_orientation) {}
     ~projection() final = default;
 
-    // The key-frame matchers keep their reference declarations and their bodies in the reference's match/projection.cc
-    // (:529-1142; only the four per-frame functions are deleted from that file).  Their searches are available through the
+    // The other key-frame matchers keep their reference declarations and their bodies in the reference's match/projection.cc
+    // (:648-1142; the four per-frame functions and match_frame_and_keyframe are deleted from that file).  Their searches are available through the
     // C ABI as well, but they are not on the per-frame path.
-    unsigned int match_frame_and_keyframe(data::frame& curr_frm, data::keyframe* keyfrm, const std::set<data::landmark*>& already_matched_lms,
-                                          const float margin, const unsigned int hamm_dist_thr) const;
+    //! projection.cc:529-645 (relocalisation: the key frame's landmarks reprojected with the pose PnP found)
+    template <class Frame, class KeyFrame, class Landmark>
+    unsigned int match_frame_and_keyframe(Frame& curr_frm, KeyFrame* keyfrm, const std::set<Landmark*>& already_matched_lms, const float margin,
+                                          const unsigned int hamm_dist_thr) const {
+        const Mat33_t rot_cw = curr_frm.cam_pose_cw_.template block<3, 3>(0, 0);
+        const Vec3_t trans_cw = curr_frm.cam_pose_cw_.template block<3, 1>(0, 3);
+        const Vec3_t cam_center = -rot_cw.transpose() * trans_cw;
+        const auto landmarks = keyfrm->get_landmarks();
+        std::vector<Landmark*> lms;
+        std::vector<float> reproj_f, angle;
+        std::vector<int32_t> level;
+        std::vector<uint8_t> desc;
+        for (unsigned int idx = 0; idx < landmarks.size(); idx++) {
+            auto* lm = landmarks.at(idx);
+            if (!lm) continue;
+            if (lm->will_be_erased()) continue;
+            if (already_matched_lms.count(lm)) continue;
+            const Vec3_t pos_w = lm->get_pos_in_world();
+            Vec2_t reproj;
+            float x_right;
+            if (!curr_frm.camera_->reproject_to_image(rot_cw, trans_cw, pos_w, reproj, x_right)) continue;
+            const Vec3_t cam_to_lm_vec = pos_w - cam_center;
+            const auto cam_to_lm_dist = cam_to_lm_vec.norm();
+            if (cam_to_lm_dist < lm->get_min_valid_distance() || lm->get_max_valid_distance() < cam_to_lm_dist) continue;
+            const auto pred_scale_level = lm->predict_scale_level(cam_to_lm_dist, &curr_frm);
+            lms.push_back(lm);
+            reproj_f.push_back(static_cast<float>(reproj(0))); reproj_f.push_back(static_cast<float>(reproj(1)));
+            level.push_back(static_cast<int32_t>(pred_scale_level));
+            angle.push_back(keyfrm->undist_keypts_.at(idx).angle);
+            const auto lm_desc = lm->get_descriptor();
+            const unsigned char* p = lm_desc.template ptr<unsigned char>(0);
+            desc.insert(desc.end(), p, p + 32);
+        }
+        const detail::frame_targets<Frame> T(curr_frm);
+        if (lms.empty() || T.n == 0) return 0;
+        std::vector<uint8_t> taken(static_cast<size_t>(T.n));
+        for (int i = 0; i < T.n; ++i) taken[i] = curr_frm.landmarks_.at(i) ? 1 : 0;       // any landmark blocks the slot (:602-605)
+        std::vector<int32_t> out(static_cast<size_t>(T.n), -1);
+        int32_t num = 0;
+        plp_match_args a{};
+        a.mode = PLP_MATCH_MODE_LAST_FRAME; a.B = 1; a.n_cap = T.n; a.m_cap = static_cast<int32_t>(lms.size());
+        a.t_kps = T.kps; a.t_desc = T.desc.data(); a.t_occupied = taken.data();
+        a.q_reproj = reproj_f.data(); a.q_level = level.data(); a.q_angle = angle.data(); a.q_desc = desc.data();
+        a.margin = margin; a.lowe_ratio = lowe_ratio_; a.check_orientation = check_orientation_ ? 1 : 0;
+        a.direction = 0; a.hamm_dist_thr = static_cast<int32_t>(hamm_dist_thr); a.flags = PLP_MATCH_FLAG_MARK_INVALIDATED;
+        a.num_levels = static_cast<int32_t>(curr_frm.scale_factors_.size()); a.scale_factors = curr_frm.scale_factors_.data();
+        a.grid = detail::grid_of(curr_frm.camera_);
+        a.out_match = out.data(); a.out_num = &num;
+        detail::check(plp_match_host(detail::shared_matcher(), &a));
+        for (int i = 0; i < T.n; ++i) {
+            if (out[i] >= 0) curr_frm.landmarks_.at(i) = lms[static_cast<size_t>(out[i])];
+            else if (out[i] == -2) curr_frm.landmarks_.at(i) = nullptr;
+        }
+        return static_cast<unsigned int>(num);
+    }
     unsigned int match_frame_and_keyframe_line(data::frame& curr_frm, data::keyframe* keyfrm, const std::set<data::Line*>& already_matched_lms,
                                                const float margin, const unsigned int hamm_dist_thr) const;
     unsigned int match_by_Sim3_transform(data::keyframe* keyfrm, const Mat44_t& Sim3_cw, const std::vector<data::landmark*>& landmarks,
