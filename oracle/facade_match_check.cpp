@@ -46,6 +46,9 @@ unsigned oracle_match_area(const double* grid6, const OKeyPoint* kps1, const uin
 unsigned oracle_match_frame_and_keyframe(const double* grid6, const OKeyPoint* kps, const uint8_t* desc, const uint8_t* occupied, int n, const float* scale_factors,
                                          const uint8_t* valid, const float* reproj, const unsigned* pred_level, const float* langle, const uint8_t* ldesc, int m,
                                          float margin, unsigned hamm_dist_thr, int check_orientation, int* kp_match);
+unsigned oracle_match_frame_and_keyframe_line(const OKeyLine* kl, const uint8_t* lbd, const uint8_t* occupied, int n, const float* scale_factors_lsd,
+                                              const uint8_t* valid, const float* sp, const float* ep, const unsigned* pred_level, const uint8_t* ldesc, int m,
+                                              float margin, unsigned hamm_dist_thr, int* line_match);
 unsigned oracle_match_for_triangulation(const uint8_t* q_desc, const float* q_angle, const int* q_node, const uint8_t* q_has_lm, const float* q_x_right,
                                         const int* q_octave, const double* q_bearing, int m, const uint8_t* t_desc, const float* t_angle,
                                         const int* t_node, const uint8_t* t_has_lm, const float* t_x_right, const double* t_bearing, int n,
@@ -155,6 +158,7 @@ struct Line {
 struct frame {
     // FW: line members of data::frame
     unsigned int _num_keylines = 0, _num_scale_levels_lsd = 2;
+    float _log_scale_factor_lsd = 0.6931472f;
     std::vector<float> _scale_factors_lsd;
     std::vector<OKeyLine> _keylsd;
     cv::Mat _lbd_descr;
@@ -197,6 +201,7 @@ struct keyframe {
     std::vector<OKeyLine> _keylsd;
     cv::Mat _lbd_descr;
     std::vector<Line*> _landmarks_line;
+    std::vector<Line*> get_landmarks_line() const { return _landmarks_line; }
     Line* get_landmark_line(unsigned int idx) const { return _landmarks_line.at(idx); }
     void add_landmark_line(Line* lm, unsigned int idx) { _landmarks_line.at(idx) = lm; }
 };
@@ -667,6 +672,72 @@ int main(int argc, char** argv) {
             }
             if (got_num != want_num) ++failures;
             std::printf("projection::match_frame_and_keyframe[check_orientation %d, thr %u]: %u matches (oracle %u)\n", check, thr, got_num, want_num);
+        }
+        // ---------------- projection::match_frame_and_keyframe_line
+        {
+            const int nlk = std::max(4, n / 5), mlk = std::max(4, m / 5);
+            data::frame curr;
+            fill_frame(curr, &cam, 4);
+            fill_lines(curr, nlk);
+            curr.cam_pose_cw_(0, 3) = 0.02; curr.cam_pose_cw_(2, 3) = 0.03;
+            const Mat33_t rot_cw = curr.cam_pose_cw_.block<3, 3>(0, 0);
+            const Vec3_t trans_cw = curr.cam_pose_cw_.block<3, 1>(0, 3);
+            const Vec3_t cam_center = -rot_cw.transpose() * trans_cw;
+            data::keyframe kf;
+            kf._landmarks_line.assign(mlk, nullptr);
+            std::vector<std::unique_ptr<data::Line>> pool;
+            std::set<data::Line*> already;
+            for (int i = 0; i < nlk; ++i)
+                if (uni(0, 1) < 0.15) { pool.emplace_back(new data::Line()); curr._landmarks_line[i] = pool.back().get(); }
+            for (int j = 0; j < mlk; ++j) {
+                if (uni(0, 1) < 0.15) continue;
+                pool.emplace_back(new data::Line());
+                auto* lm = pool.back().get();
+                const int ki = irand(0, nlk - 1);
+                const OKeyLine& k = curr._keylsd[(size_t)ki];
+                const double z1 = uni(0.6, 7.0), z2 = z1 + uni(-0.2, 0.2), stretch = uni(0, 1) < 0.15 ? uni(2, 10) : 1.0;
+                const double sx = k.startPointX + uni(-2, 2), sy = k.startPointY + uni(-2, 2);
+                const double ex = k.startPointX + stretch * (k.endPointX - k.startPointX) + uni(-2, 2), ey = k.startPointY + stretch * (k.endPointY - k.startPointY) + uni(-2, 2);
+                lm->pos_w_(0) = (sx - cam.cx_) / cam.fx_ * z1 - trans_cw(0); lm->pos_w_(1) = (sy - cam.cy_) / cam.fy_ * z1 - trans_cw(1); lm->pos_w_(2) = z1 - trans_cw(2);
+                lm->pos_w_(3) = (ex - cam.cx_) / cam.fx_ * z2 - trans_cw(0); lm->pos_w_(4) = (ey - cam.cy_) / cam.fy_ * z2 - trans_cw(1); lm->pos_w_(5) = z2 - trans_cw(2);
+                lm->erased_ = uni(0, 1) < 0.04;
+                lm->min_dist_ = (float)(uni(0, 1) < 0.05 ? z1 + 1 : 0.1); lm->max_dist_ = (float)(uni(0, 1) < 0.05 ? z1 - 0.3 : 50.0);
+                lm->pred_level_ = (unsigned)irand(0, 1);
+                lm->desc_ = cv::Mat(1, 32, CV_8U);
+                std::copy(curr._lbd_descr.ptr<uint8_t>(ki), curr._lbd_descr.ptr<uint8_t>(ki) + 32, lm->desc_.ptr<uint8_t>(0));
+                for (int f = irand(0, 6); f > 0; --f) lm->desc_.ptr<uint8_t>(0)[irand(0, 31)] ^= (uint8_t)(1u << irand(0, 7));
+                kf._landmarks_line[(size_t)j] = lm;
+                if (uni(0, 1) < 0.1) already.insert(lm);
+            }
+            std::vector<uint8_t> valid(mlk, 0), ld((size_t)mlk * 32, 0), occ(nlk);
+            std::vector<float> sp(2 * (size_t)mlk, 0.f), ep(2 * (size_t)mlk, 0.f);
+            std::vector<unsigned> lvl(mlk, 0);
+            std::vector<int> want(nlk);
+            for (int j = 0; j < mlk; ++j) {
+                auto* lm = kf._landmarks_line[(size_t)j];
+                if (!lm || lm->will_be_erased() || already.count(lm)) continue;
+                const Vec3_t a3 = lm->pos_w_.head(3), b3 = lm->pos_w_.tail(3);
+                Vec2_t a, b, c; float xa, xb, xc;
+                const bool ia = cam.reproject_to_image(rot_cw, trans_cw, a3, a, xa), ib = cam.reproject_to_image(rot_cw, trans_cw, b3, b, xb);
+                if (!ia && !ib) continue;
+                if ((!ia || !ib) && !cam.reproject_to_image(rot_cw, trans_cw, 0.5 * (a3 + b3), c, xc)) continue;
+                const double dist = (0.5 * (a3 + b3) - cam_center).norm();
+                if (dist < lm->min_dist_ || lm->max_dist_ < dist) continue;
+                valid[j] = 1; sp[2 * j] = (float)a(0); sp[2 * j + 1] = (float)a(1); ep[2 * j] = (float)b(0); ep[2 * j + 1] = (float)b(1); lvl[j] = lm->pred_level_;
+                std::copy(lm->desc_.ptr<uint8_t>(0), lm->desc_.ptr<uint8_t>(0) + 32, ld.begin() + (size_t)j * 32);
+            }
+            for (int i = 0; i < nlk; ++i) occ[i] = curr._landmarks_line[(size_t)i] != nullptr;
+            const auto fd = lbd_of(curr);
+            const float margin = 12.f;
+            const unsigned want_num = oracle_match_frame_and_keyframe_line(curr._keylsd.data(), fd.data(), occ.data(), nlk, curr._scale_factors_lsd.data(), valid.data(),
+                                                                           sp.data(), ep.data(), lvl.data(), ld.data(), mlk, margin, 60u, want.data());
+            const std::vector<data::Line*> before = curr._landmarks_line;
+            const match::projection projection_matcher(0.9, false);
+            const unsigned got_num = projection_matcher.match_frame_and_keyframe_line(curr, &kf, already, margin, 60u);
+            for (int i = 0; i < nlk; ++i)
+                if (curr._landmarks_line[(size_t)i] != (want[i] >= 0 ? kf._landmarks_line[(size_t)want[i]] : before[(size_t)i])) ++failures;
+            if (got_num != want_num) ++failures;
+            std::printf("projection::match_frame_and_keyframe_line: %u matches (oracle %u)\n", got_num, want_num);
         }
         // ---------------- robust::match_for_triangulation
         for (int check = 0; check < 2; ++check) {

@@ -143,7 +143,7 @@ public:
     ~projection() final = default;
 
     // The other key-frame matchers keep their reference declarations and their bodies in the reference's match/projection.cc
-    // (:648-1142; the four per-frame functions and match_frame_and_keyframe are deleted from that file).  Their searches are available through the
+    // (:781-1142; the four per-frame functions and match_frame_and_keyframe[_line] are deleted from that file).  Their searches are available through the
     // C ABI as well, but they are not on the per-frame path.
     //! projection.cc:529-645 (relocalisation: the key frame's landmarks reprojected with the pose PnP found)
     template <class Frame, class KeyFrame, class Landmark>
@@ -200,8 +200,69 @@ public:
         }
         return static_cast<unsigned int>(num);
     }
-    unsigned int match_frame_and_keyframe_line(data::frame& curr_frm, data::keyframe* keyfrm, const std::set<data::Line*>& already_matched_lms,
-                                               const float margin, const unsigned int hamm_dist_thr) const;
+    //! projection.cc:648-779
+    template <class Frame, class KeyFrame, class Line>
+    unsigned int match_frame_and_keyframe_line(Frame& curr_frm, KeyFrame* keyfrm, const std::set<Line*>& already_matched_lms, const float margin,
+                                               const unsigned int hamm_dist_thr) const {
+        const Mat33_t rot_cw = curr_frm.cam_pose_cw_.template block<3, 3>(0, 0);
+        const Vec3_t trans_cw = curr_frm.cam_pose_cw_.template block<3, 1>(0, 3);
+        const Vec3_t cam_center = -rot_cw.transpose() * trans_cw;
+        const auto landmarks_line = keyfrm->get_landmarks_line();
+        std::vector<Line*> lms;
+        std::vector<float> sp, ep;
+        std::vector<int32_t> level;
+        std::vector<uint8_t> desc;
+        for (unsigned int idx = 0; idx < landmarks_line.size(); idx++) {
+            auto* lm_line = landmarks_line.at(idx);
+            if (!lm_line) continue;
+            if (lm_line->will_be_erased()) continue;
+            if (already_matched_lms.count(lm_line)) continue;
+            const Vec6_t pos_w = lm_line->get_pos_in_world();
+            const Vec3_t pos_w_sp = pos_w.template head<3>(), pos_w_ep = pos_w.template tail<3>();
+            Vec2_t reproj_sp, reproj_ep;
+            float x_right_sp, x_right_ep;
+            const bool in_image_sp = curr_frm.camera_->reproject_to_image(rot_cw, trans_cw, pos_w_sp, reproj_sp, x_right_sp);
+            const bool in_image_ep = curr_frm.camera_->reproject_to_image(rot_cw, trans_cw, pos_w_ep, reproj_ep, x_right_ep);
+            if (!in_image_sp && !in_image_ep) continue;
+            if (!in_image_sp || !in_image_ep) {
+                const Vec3_t pos_w_mp = 0.5 * (pos_w_sp + pos_w_ep);
+                Vec2_t reproj_mp;
+                float x_right_mp;
+                if (!curr_frm.camera_->reproject_to_image(rot_cw, trans_cw, pos_w_mp, reproj_mp, x_right_mp)) continue;
+            }
+            const Vec3_t cam_to_lm_vec = 0.5 * (pos_w_sp + pos_w_ep) - cam_center;
+            const auto cam_to_lm_dist = cam_to_lm_vec.norm();
+            if (cam_to_lm_dist < lm_line->get_min_valid_distance() || lm_line->get_max_valid_distance() < cam_to_lm_dist) continue;
+            const auto pred_scale_level = lm_line->predict_scale_level(cam_to_lm_dist, curr_frm._log_scale_factor_lsd, curr_frm._num_scale_levels_lsd);
+            lms.push_back(lm_line);
+            sp.push_back(static_cast<float>(reproj_sp(0))); sp.push_back(static_cast<float>(reproj_sp(1)));
+            ep.push_back(static_cast<float>(reproj_ep(0))); ep.push_back(static_cast<float>(reproj_ep(1)));
+            level.push_back(static_cast<int32_t>(pred_scale_level));
+            const auto lm_desc = lm_line->get_descriptor();
+            const unsigned char* p = lm_desc.template ptr<unsigned char>(0);
+            desc.insert(desc.end(), p, p + 32);
+        }
+        const detail::frame_line_targets<Frame> T(curr_frm);
+        if (lms.empty() || T.n == 0) return 0;
+        std::vector<uint8_t> taken(static_cast<size_t>(T.n));
+        for (int i = 0; i < T.n; ++i) taken[i] = curr_frm._landmarks_line.at(i) ? 1 : 0;
+        std::vector<int32_t> out(static_cast<size_t>(T.n), -1);
+        int32_t num = 0;
+        plp_match_args a{};
+        a.mode = PLP_MATCH_MODE_LAST_FRAME_LINE; a.B = 1; a.n_cap = T.n; a.m_cap = static_cast<int32_t>(lms.size());
+        a.t_kl = T.kl; a.t_desc = T.desc.data(); a.t_occupied = taken.data();
+        a.q_reproj = sp.data(); a.q_reproj2 = ep.data(); a.q_level = level.data(); a.q_desc = desc.data();
+        a.margin = margin; a.lowe_ratio = lowe_ratio_;
+        a.direction = 0; a.is_rgbd = 0; a.hamm_dist_thr = static_cast<int32_t>(hamm_dist_thr);
+        a.num_levels_lsd = static_cast<int32_t>(curr_frm._num_scale_levels_lsd);
+        a.num_levels = static_cast<int32_t>(curr_frm._scale_factors_lsd.size()); a.scale_factors = curr_frm._scale_factors_lsd.data();
+        a.grid = detail::grid_of(curr_frm.camera_);
+        a.out_match = out.data(); a.out_num = &num;
+        detail::check(plp_match_host(detail::shared_matcher(), &a));
+        for (int i = 0; i < T.n; ++i)
+            if (out[i] >= 0) curr_frm._landmarks_line.at(i) = lms[static_cast<size_t>(out[i])];
+        return static_cast<unsigned int>(num);
+    }
     unsigned int match_by_Sim3_transform(data::keyframe* keyfrm, const Mat44_t& Sim3_cw, const std::vector<data::landmark*>& landmarks,
                                          std::vector<data::landmark*>& matched_lms_in_keyfrm, const float margin) const;
     unsigned int match_keyframes_mutually(data::keyframe* keyfrm_1, data::keyframe* keyfrm_2, std::vector<data::landmark*>& matched_lms_in_keyfrm_1,

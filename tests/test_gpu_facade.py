@@ -61,16 +61,17 @@ def test_cpp_matcher_facade_equals_oracle(seed, n, m):
     r = subprocess.run([_MATCH_EXE, str(seed), str(n), str(m)], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = r.stdout.strip().splitlines()
-    assert len(lines) == 19 and lines[0].startswith("match_frame_and_landmarks") and lines[4].startswith("bow_tree::match_frame_and_keyframe")
+    assert len(lines) == 20 and lines[0].startswith("match_frame_and_landmarks") and lines[4].startswith("bow_tree::match_frame_and_keyframe")
     assert lines[6].startswith("bow_tree::match_keyframes") and lines[7].startswith("fuse::replace_duplication:")
-    assert lines[8].startswith("projection::match_frame_and_keyframe") and lines[10].startswith("robust::match_for_triangulation")
-    assert lines[12].startswith("fuse::replace_duplication_line") and lines[13].startswith("area::match_in_consistent_area")
-    assert lines[15].startswith("match_frame_and_landmarks_line")
+    assert lines[8].startswith("projection::match_frame_and_keyframe[") and lines[10].startswith("projection::match_frame_and_keyframe_line")
+    assert lines[11].startswith("robust::match_for_triangulation") and lines[13].startswith("fuse::replace_duplication_line")
+    assert lines[14].startswith("area::match_in_consistent_area") and lines[16].startswith("match_frame_and_landmarks_line")
     if n >= 900:     # the scenes are built so that the matchers have work to do
         import re
         count = lambda ln: int(re.search(r"(\d+) (matches|fused)", ln).group(1))
-        assert all(count(ln) > 30 for ln in lines[:12] + lines[13:15])
-        assert all(count(ln) > 10 for ln in [lines[12]] + lines[15:])
+        point_lines = lines[:10] + lines[11:13] + lines[14:16]
+        assert all(count(ln) > 30 for ln in point_lines)
+        assert all(count(ln) > 10 for ln in [lines[10], lines[13]] + lines[16:])
 
 
 @pytest.mark.skipif(not os.path.exists(_EXE), reason="oracle/_ref/facade_orb_check not built (needs /root/reference at build time)")
