@@ -72,3 +72,20 @@ def test_quadtree_model_equals_oracle_list(seed):
         got = xys[pick]
         want = np.stack([ref["x"], ref["y"], ref["response"]], 1).astype(np.int32)
         assert np.array_equal(got, want), (w, h, n, quota)
+
+
+def test_facade_check_programs_are_built_and_load():
+    """The C++ facade check programs (oracle/facade_*_check, oracle/_ref/facade_orb_check) are compiled by build(); without
+    arguments they only print nothing and return 2, which proves that they link against libplp_front.so / liboracle.so."""
+    import os
+    import subprocess
+    root = plp.ROOT
+    exes = [root / "oracle" / "facade_match_check", root / "oracle" / "facade_line_check"]
+    if (root / "oracle" / "_ref" / "facade_orb_check").exists():
+        exes.append(root / "oracle" / "_ref" / "facade_orb_check")
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = "/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    for exe in exes:
+        assert exe.exists(), f"{exe} missing: run python -c 'import __graft_entry__ as g; g.build()'"
+        r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60, env=env)
+        assert r.returncode == 2, (exe, r.returncode, r.stderr)
