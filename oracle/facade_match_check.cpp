@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <memory>
 #include <random>
+#include <string>
 #include <set>
 #include <vector>
 
@@ -49,6 +50,11 @@ unsigned oracle_match_frame_and_keyframe(const double* grid6, const OKeyPoint* k
 unsigned oracle_match_frame_and_keyframe_line(const OKeyLine* kl, const uint8_t* lbd, const uint8_t* occupied, int n, const float* scale_factors_lsd,
                                               const uint8_t* valid, const float* sp, const float* ep, const unsigned* pred_level, const uint8_t* ldesc, int m,
                                               float margin, unsigned hamm_dist_thr, int* line_match);
+unsigned oracle_match_by_sim3(const double* grid6, const OKeyPoint* kps, const uint8_t* desc, const uint8_t* occupied, int n, const float* scale_factors,
+                              const uint8_t* valid, const float* reproj, const unsigned* pred_level, const uint8_t* ldesc, int m, float margin, int* kp_lm);
+void oracle_project_best(const double* grid6, const OKeyPoint* kps, const uint8_t* desc, int n, const float* scale_factors, const uint8_t* valid,
+                         const double* reproj_d, const unsigned* pred_level, const uint8_t* ldesc, int m, float margin, unsigned thr, int signed_level,
+                         int* best_idx_out);
 unsigned oracle_match_for_triangulation(const uint8_t* q_desc, const float* q_angle, const int* q_node, const uint8_t* q_has_lm, const float* q_x_right,
                                         const int* q_octave, const double* q_bearing, int m, const uint8_t* t_desc, const float* t_angle,
                                         const int* t_node, const uint8_t* t_has_lm, const float* t_x_right, const double* t_bearing, int n,
@@ -190,6 +196,11 @@ struct keyframe {
     Mat33_t get_rotation() const { return cam_pose_cw_.block<3, 3>(0, 0); }
     Vec3_t get_translation() const { return cam_pose_cw_.block<3, 1>(0, 3); }
     Vec3_t get_cam_center() const { return -get_rotation().transpose() * get_translation(); }
+    std::set<landmark*> get_valid_landmarks() const {
+        std::set<landmark*> v;
+        for (auto* lm : landmarks_) if (lm && !lm->will_be_erased()) v.insert(lm);
+        return v;
+    }
     landmark* get_landmark(unsigned int idx) const { return landmarks_.at(idx); }
     void add_landmark(landmark* lm, unsigned int idx) { landmarks_.at(idx) = lm; }
     unsigned int num_keypts_ = 0;
@@ -601,6 +612,125 @@ int main(int argc, char** argv) {
                 if (up->replaced_by_ != (it == exp_replaced.end() ? nullptr : it->second)) { ++failures; break; }
             }
             std::printf("fuse::replace_duplication: %u fused (oracle %u), %zu replacements\n", got_num, want_num, exp_replaced.size());
+        }
+        // ---------------- the two Sim3 matchers (only with a 4th argument "sim3")
+        if (argc > 4 && std::string(argv[4]) == "sim3") {
+            data::frame tmp;
+            fill_frame(tmp, &cam, n);
+            Mat44_t Sim3_cw;      // s = 2 and R = I: the decomposition sqrt(row . row), R / s, t / s is then exact and the expectation can use (R, t / s) directly
+            const double s = 2.0, cz = 1.0, sz = 0.0, t3[3] = {0.06, -0.04, 0.1};
+            const double R[3][3] = {{cz, -sz, 0}, {sz, cz, 0}, {0, 0, 1}};
+            for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) Sim3_cw(r, c) = s * R[r][c]; Sim3_cw(r, 3) = t3[r]; }
+            Mat33_t rot_cw; Vec3_t trans_cw;
+            for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) rot_cw(r, c) = R[r][c]; trans_cw(r) = t3[r] / s; }
+            const Vec3_t cam_center = -rot_cw.transpose() * trans_cw;
+            auto make_kf = [&](data::keyframe& kf, std::vector<std::unique_ptr<data::landmark>>& pool) {
+                kf.camera_ = &cam; kf.keypts_ = tmp.keypts_; kf.undist_keypts_ = tmp.undist_keypts_; kf.descriptors_ = tmp.descriptors_;
+                kf.scale_factors_ = tmp.scale_factors_; kf.landmarks_.assign(n, nullptr);
+                for (int i = 0; i < n; ++i)
+                    if (uni(0, 1) < 0.4) { pool.emplace_back(new data::landmark()); pool.back()->erased_ = uni(0, 1) < 0.05; kf.landmarks_[i] = pool.back().get(); }
+            };
+            auto make_lms = [&](const data::keyframe& kf, std::vector<std::unique_ptr<data::landmark>>& pool, std::vector<data::landmark*>& out) {
+                for (int j = 0; j < m; ++j) {
+                    pool.emplace_back(new data::landmark());
+                    auto* lm = pool.back().get();
+                    const int ki = irand(0, n - 1);
+                    const auto& k = kf.undist_keypts_[(size_t)ki];
+                    const double z = uni(0.5, 8.0), px = k.pt.x + uni(-3, 3), py = k.pt.y + uni(-3, 3);
+                    const Vec3_t pc((px - cam.cx_) / cam.fx_ * z, (py - cam.cy_) / cam.fy_ * z, z);      // in the camera frame
+                    lm->pos_w_ = rot_cw.transpose() * (pc - trans_cw);
+                    lm->erased_ = uni(0, 1) < 0.04;
+                    lm->min_dist_ = (float)(uni(0, 1) < 0.05 ? z + 1 : 0.1); lm->max_dist_ = (float)(uni(0, 1) < 0.05 ? z - 0.2 : 50.0);
+                    const Vec3_t v = lm->pos_w_ - cam_center;
+                    const double f = (uni(0, 1) < 0.9 ? 1.0 : -1.0) / v.norm();
+                    lm->mean_normal_ = Vec3_t(v(0) * f, v(1) * f, v(2) * f);
+                    lm->pred_level_ = (unsigned)std::max(0, std::min(7, k.octave + irand(-1, 1)));
+                    lm->desc_ = cv::Mat(1, 32, CV_8U);
+                    std::copy(kf.descriptors_.ptr<uint8_t>(ki), kf.descriptors_.ptr<uint8_t>(ki) + 32, lm->desc_.ptr<uint8_t>(0));
+                    for (int fl = irand(0, 5); fl > 0; --fl) lm->desc_.ptr<uint8_t>(0)[irand(0, 31)] ^= (uint8_t)(1u << irand(0, 7));
+                    out.push_back(lm);
+                }
+            };
+            auto pretest = [&](data::landmark* lm, Vec2_t& r) {
+                float xr;
+                if (!cam.reproject_to_image(rot_cw, trans_cw, lm->pos_w_, r, xr)) return false;
+                const Vec3_t v = lm->pos_w_ - cam_center;
+                const double dist = v.norm();
+                if (dist < lm->min_dist_ || lm->max_dist_ < dist) return false;
+                return !(v.dot(lm->mean_normal_) < 0.5 * dist);
+            };
+            std::vector<uint8_t> kd((size_t)n * 32);
+            for (int i = 0; i < n; ++i) std::copy(tmp.descriptors_.ptr<uint8_t>(i), tmp.descriptors_.ptr<uint8_t>(i) + 32, kd.begin() + (size_t)i * 32);
+            {   // fuse::detect_duplication
+                std::vector<std::unique_ptr<data::landmark>> pool;
+                data::keyframe kf;
+                make_kf(kf, pool);
+                std::vector<data::landmark*> to_check;
+                make_lms(kf, pool, to_check);
+                for (int j = 0; j < m; j += 17) if (kf.landmarks_[(size_t)(j % n)]) to_check[(size_t)j] = kf.landmarks_[(size_t)(j % n)];     // some already belong to the key frame
+                const auto valid_in_kf = kf.get_valid_landmarks();
+                std::vector<uint8_t> valid(m, 0), ld((size_t)m * 32, 0);
+                std::vector<double> rp(2 * (size_t)m, 0.0);
+                std::vector<unsigned> lvl(m, 0);
+                std::vector<int> best(m, -1);
+                for (int j = 0; j < m; ++j) {
+                    auto* lm = to_check[(size_t)j];
+                    Vec2_t r;
+                    if (lm->will_be_erased() || valid_in_kf.count(lm) || !pretest(lm, r)) continue;
+                    valid[j] = 1; rp[2 * j] = r(0); rp[2 * j + 1] = r(1); lvl[j] = lm->pred_level_;
+                    std::copy(lm->desc_.ptr<uint8_t>(0), lm->desc_.ptr<uint8_t>(0) + 32, ld.begin() + (size_t)j * 32);
+                }
+                const float margin = 4.f;
+                oracle_project_best(grid6, reinterpret_cast<const OKeyPoint*>(kf.undist_keypts_.data()), kd.data(), n, kf.scale_factors_.data(), valid.data(), rp.data(),
+                                    lvl.data(), ld.data(), m, margin, 50u, 1, best.data());
+                std::vector<data::landmark*> exp_slots = kf.landmarks_, exp_dup((size_t)m, nullptr);
+                unsigned want_num = 0;
+                for (int j = 0; j < m; ++j) {
+                    if (best[j] < 0) continue;
+                    auto* in_kf = exp_slots[(size_t)best[j]];
+                    if (in_kf) { if (!in_kf->erased_) exp_dup[(size_t)j] = in_kf; }
+                    else exp_slots[(size_t)best[j]] = to_check[(size_t)j];
+                    ++want_num;
+                }
+                std::vector<data::landmark*> dup;
+                match::fuse fuse_matcher(0.6);
+                const unsigned got_num = fuse_matcher.detect_duplication(&kf, Sim3_cw, to_check, margin, dup);
+                if (got_num != want_num || dup != exp_dup || kf.landmarks_ != exp_slots) ++failures;
+                std::printf("fuse::detect_duplication: %u fused (oracle %u)\n", got_num, want_num);
+            }
+            {   // projection::match_by_Sim3_transform
+                std::vector<std::unique_ptr<data::landmark>> pool;
+                data::keyframe kf;
+                make_kf(kf, pool);
+                std::vector<data::landmark*> lms_in;
+                make_lms(kf, pool, lms_in);
+                std::vector<data::landmark*> matched = kf.landmarks_;      // slots already matched (some non-null)
+                for (int i = 0; i < n; ++i) if (uni(0, 1) < 0.5) matched[(size_t)i] = nullptr;
+                for (int j = 0; j < m; j += 19) { const int sidx = j % n; if (matched[(size_t)sidx]) lms_in[(size_t)j] = matched[(size_t)sidx]; }   // and some of the inputs are among them
+                std::set<data::landmark*> already(matched.begin(), matched.end());
+                already.erase(nullptr);
+                std::vector<uint8_t> valid(m, 0), ld((size_t)m * 32, 0), occ(n);
+                std::vector<float> rp(2 * (size_t)m, 0.f);
+                std::vector<unsigned> lvl(m, 0);
+                std::vector<int> want(n);
+                for (int j = 0; j < m; ++j) {
+                    auto* lm = lms_in[(size_t)j];
+                    Vec2_t r;
+                    if (lm->will_be_erased() || already.count(lm) || !lm->desc_.data || !pretest(lm, r)) continue;
+                    valid[j] = 1; rp[2 * j] = (float)r(0); rp[2 * j + 1] = (float)r(1); lvl[j] = lm->pred_level_;
+                    std::copy(lm->desc_.ptr<uint8_t>(0), lm->desc_.ptr<uint8_t>(0) + 32, ld.begin() + (size_t)j * 32);
+                }
+                for (int i = 0; i < n; ++i) occ[i] = matched[(size_t)i] != nullptr;
+                const float margin = 7.5f;
+                const unsigned want_num = oracle_match_by_sim3(grid6, reinterpret_cast<const OKeyPoint*>(kf.undist_keypts_.data()), kd.data(), occ.data(), n,
+                                                               kf.scale_factors_.data(), valid.data(), rp.data(), lvl.data(), ld.data(), m, margin, want.data());
+                std::vector<data::landmark*> expect = matched;
+                for (int i = 0; i < n; ++i) if (want[i] >= 0) expect[(size_t)i] = lms_in[(size_t)want[i]];
+                const match::projection projection_matcher(0.9, true);
+                const unsigned got_num = projection_matcher.match_by_Sim3_transform(&kf, Sim3_cw, lms_in, matched, margin);
+                if (got_num != want_num || matched != expect) ++failures;
+                std::printf("projection::match_by_Sim3_transform: %u matches (oracle %u)\n", got_num, want_num);
+            }
         }
         // ---------------- projection::match_frame_and_keyframe (relocalisation)
         for (int check = 0; check < 2; ++check) {

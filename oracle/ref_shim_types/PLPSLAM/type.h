@@ -13,6 +13,7 @@ struct Vec3_t {
     double operator()(int i) const { return v[i]; }
     Vec3_t operator+(const Vec3_t& o) const { Vec3_t r; for (int i = 0; i < 3; ++i) r.v[i] = v[i] + o.v[i]; return r; }
     Vec3_t operator-(const Vec3_t& o) const { Vec3_t r; for (int i = 0; i < 3; ++i) r.v[i] = v[i] - o.v[i]; return r; }
+    Vec3_t operator/(double a) const { Vec3_t r; for (int i = 0; i < 3; ++i) r.v[i] = v[i] / a; return r; }
     double dot(const Vec3_t& o) const { return v[0] * o.v[0] + v[1] * o.v[1] + v[2] * o.v[2]; }
     double norm() const { return __builtin_sqrt(dot(*this)); }
 };
@@ -30,6 +31,11 @@ struct Mat33_t {
     double& operator()(int i, int j) { return m[i][j]; }
     double operator()(int i, int j) const { return m[i][j]; }
     Mat33_t transpose() const { Mat33_t r; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r.m[i][j] = m[j][i]; return r; }
+    Mat33_t operator/(double a) const { Mat33_t r; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r.m[i][j] = m[i][j] / a; return r; }
+    template <int R, int C> Vec3_t block(int i0, int j0) const {      // block<1, 3>(i, 0): a row (projection.cc:786)
+        static_assert(R == 1 && C == 3, "block<1, 3> only");
+        Vec3_t r; for (int j = 0; j < 3; ++j) r.v[j] = m[i0][j0 + j]; return r;
+    }
     Mat33_t operator-() const { Mat33_t r; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r.m[i][j] = -m[i][j]; return r; }
     Vec3_t operator*(const Vec3_t& x) const {
         Vec3_t r;

@@ -142,8 +142,8 @@ public:
     explicit projection(const float lowe_ratio = 0.6, const bool check_orientation = true) : base(lowe_ratio, check_orientation) {}
     ~projection() final = default;
 
-    // The other key-frame matchers keep their reference declarations and their bodies in the reference's match/projection.cc
-    // (:781-1142; the four per-frame functions and match_frame_and_keyframe[_line] are deleted from that file).  Their searches are available through the
+    // match_keyframes_mutually keeps its reference declaration and its body in the reference's match/projection.cc (:894-1142;
+    // everything above it is deleted from that file).  Their searches are available through the
     // C ABI as well, but they are not on the per-frame path.
     //! projection.cc:529-645 (relocalisation: the key frame's landmarks reprojected with the pose PnP found)
     template <class Frame, class KeyFrame, class Landmark>
@@ -263,8 +263,66 @@ public:
             if (out[i] >= 0) curr_frm._landmarks_line.at(i) = lms[static_cast<size_t>(out[i])];
         return static_cast<unsigned int>(num);
     }
-    unsigned int match_by_Sim3_transform(data::keyframe* keyfrm, const Mat44_t& Sim3_cw, const std::vector<data::landmark*>& landmarks,
-                                         std::vector<data::landmark*>& matched_lms_in_keyfrm, const float margin) const;
+    //! projection.cc:781-892 (loop closure: more landmarks of the candidate's neighbourhood through the estimated Sim3)
+    template <class KeyFrame, class Landmark>
+    unsigned int match_by_Sim3_transform(KeyFrame* keyfrm, const Mat44_t& Sim3_cw, const std::vector<Landmark*>& landmarks,
+                                         std::vector<Landmark*>& matched_lms_in_keyfrm, const float margin) const {
+        const Mat33_t s_rot_cw = Sim3_cw.template block<3, 3>(0, 0);
+        const auto s_cw = std::sqrt(s_rot_cw.template block<1, 3>(0, 0).dot(s_rot_cw.template block<1, 3>(0, 0)));
+        const Mat33_t rot_cw = s_rot_cw / s_cw;
+        const Vec3_t trans_cw = Sim3_cw.template block<3, 1>(0, 3) / s_cw;
+        const Vec3_t cam_center = -rot_cw.transpose() * trans_cw;
+        std::set<Landmark*> already_matched(matched_lms_in_keyfrm.begin(), matched_lms_in_keyfrm.end());
+        already_matched.erase(static_cast<Landmark*>(nullptr));
+        std::vector<Landmark*> lms;
+        std::vector<float> reproj_f;
+        std::vector<int32_t> level;
+        std::vector<uint8_t> desc;
+        for (auto lm : landmarks) {
+            if (lm->will_be_erased()) continue;
+            if (already_matched.count(lm)) continue;
+            const Vec3_t pos_w = lm->get_pos_in_world();
+            Vec2_t reproj;
+            float x_right;
+            if (!keyfrm->camera_->reproject_to_image(rot_cw, trans_cw, pos_w, reproj, x_right)) continue;
+            const Vec3_t cam_to_lm_vec = pos_w - cam_center;
+            const auto cam_to_lm_dist = cam_to_lm_vec.norm();
+            if (cam_to_lm_dist < lm->get_min_valid_distance() || lm->get_max_valid_distance() < cam_to_lm_dist) continue;
+            const Vec3_t obs_mean_normal = lm->get_obs_mean_normal();
+            if (cam_to_lm_vec.dot(obs_mean_normal) < 0.5 * cam_to_lm_dist) continue;
+            const auto pred_scale_level = lm->predict_scale_level(cam_to_lm_dist, keyfrm);
+            lms.push_back(lm);
+            reproj_f.push_back(static_cast<float>(reproj(0))); reproj_f.push_back(static_cast<float>(reproj(1)));
+            level.push_back(static_cast<int32_t>(pred_scale_level));
+            const auto lm_desc = lm->get_descriptor();
+            const unsigned char* p = lm_desc.template ptr<unsigned char>(0);
+            desc.insert(desc.end(), p, p + 32);
+        }
+        const int n = static_cast<int>(keyfrm->undist_keypts_.size());
+        if (lms.empty() || n == 0) return 0;
+        static_assert(sizeof(keyfrm->undist_keypts_[0]) == sizeof(plp_keypoint), "cv::KeyPoint must be the 28-byte POD");
+        std::vector<uint8_t> t_desc(static_cast<size_t>(n) * 32), taken(static_cast<size_t>(n));
+        for (int i = 0; i < n; ++i) {
+            const unsigned char* p = keyfrm->descriptors_.template ptr<unsigned char>(i);
+            for (int k = 0; k < 32; ++k) t_desc[static_cast<size_t>(i) * 32 + k] = p[k];
+            taken[i] = matched_lms_in_keyfrm.at(i) ? 1 : 0;
+        }
+        std::vector<int32_t> out(static_cast<size_t>(n), -1);
+        int32_t num = 0;
+        plp_match_args a{};
+        a.mode = PLP_MATCH_MODE_LAST_FRAME; a.B = 1; a.n_cap = n; a.m_cap = static_cast<int32_t>(lms.size());
+        a.t_kps = reinterpret_cast<const plp_keypoint*>(keyfrm->undist_keypts_.data()); a.t_desc = t_desc.data(); a.t_occupied = taken.data();
+        a.q_reproj = reproj_f.data(); a.q_level = level.data(); a.q_desc = desc.data();
+        a.margin = margin; a.lowe_ratio = lowe_ratio_; a.check_orientation = 0;
+        a.hamm_dist_thr = 50; a.level_window = 1; a.flags = PLP_MATCH_FLAG_UNSIGNED_LEVEL;      // [pred - 1, pred] in unsigned arithmetic (:862)
+        a.num_levels = static_cast<int32_t>(keyfrm->scale_factors_.size()); a.scale_factors = keyfrm->scale_factors_.data();
+        a.grid = detail::grid_of(keyfrm->camera_);
+        a.out_match = out.data(); a.out_num = &num;
+        detail::check(plp_match_host(detail::shared_matcher(), &a));
+        for (int i = 0; i < n; ++i)
+            if (out[i] >= 0) matched_lms_in_keyfrm.at(i) = lms[static_cast<size_t>(out[i])];
+        return static_cast<unsigned int>(num);
+    }
     unsigned int match_keyframes_mutually(data::keyframe* keyfrm_1, data::keyframe* keyfrm_2, std::vector<data::landmark*>& matched_lms_in_keyfrm_1,
                                           const float& s_12, const Mat33_t& rot_12, const Vec3_t& trans_12, const float margin) const;
 
