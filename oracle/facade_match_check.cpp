@@ -129,6 +129,8 @@ struct landmark {
     landmark* replaced_by_ = nullptr;
     std::vector<std::pair<const void*, unsigned int>> observations_;
     template <class KF> bool is_observed_in_keyframe(KF*) const { return observed_in_target_; }
+    int index_in_other_ = -1;
+    template <class KF> int get_index_in_keyframe(KF*) const { return index_in_other_; }
     float get_min_valid_distance() const { return min_dist_; }
     float get_max_valid_distance() const { return max_dist_; }
     Vec3_t get_obs_mean_normal() const { return mean_normal_; }
@@ -614,7 +616,7 @@ int main(int argc, char** argv) {
             std::printf("fuse::replace_duplication: %u fused (oracle %u), %zu replacements\n", got_num, want_num, exp_replaced.size());
         }
         // ---------------- the two Sim3 matchers (only with a 4th argument "sim3")
-        if (argc > 4 && std::string(argv[4]) == "sim3") {
+        if (argc > 4 && std::string(argv[4]).find("sim3") != std::string::npos) {
             data::frame tmp;
             fill_frame(tmp, &cam, n);
             Mat44_t Sim3_cw;      // s = 2 and R = I: the decomposition sqrt(row . row), R / s, t / s is then exact and the expectation can use (R, t / s) directly
@@ -731,6 +733,101 @@ int main(int argc, char** argv) {
                 if (got_num != want_num || matched != expect) ++failures;
                 std::printf("projection::match_by_Sim3_transform: %u matches (oracle %u)\n", got_num, want_num);
             }
+        }
+        // ---------------- projection::match_keyframes_mutually (only with a 4th argument "mutual" or "sim3+mutual")
+        if (argc > 4 && std::string(argv[4]).find("mutual") != std::string::npos) {
+            std::vector<std::unique_ptr<data::landmark>> pool;
+            data::frame t1, t2;
+            fill_frame(t1, &cam, n); fill_frame(t2, &cam, m);
+            data::keyframe kf1, kf2;
+            auto init = [&](data::keyframe& kf, const data::frame& f, int cnt) {
+                kf.camera_ = &cam; kf.keypts_ = f.keypts_; kf.undist_keypts_ = f.undist_keypts_; kf.descriptors_ = f.descriptors_;
+                kf.scale_factors_ = f.scale_factors_; kf.landmarks_.assign(cnt, nullptr);
+            };
+            init(kf1, t1, n); init(kf2, t2, m);
+            kf2.cam_pose_cw_(0, 3) = 0.05; kf2.cam_pose_cw_(1, 3) = -0.02; kf2.cam_pose_cw_(2, 3) = 0.03;       // key frame 1 sits at the origin
+            const float s_12 = 2.0f;
+            Mat33_t rot_12; rot_12(0, 0) = rot_12(1, 1) = rot_12(2, 2) = 1.0;
+            const Vec3_t trans_12(0.12, -0.06, 0.08);
+            // the reference's formulas, evaluated with the same stand-in types
+            const Mat33_t rot_1w = kf1.get_rotation(), rot_2w = kf2.get_rotation();
+            const Vec3_t trans_1w = kf1.get_translation(), trans_2w = kf2.get_translation();
+            const Mat33_t s_rot_12 = s_12 * rot_12, s_rot_21 = (1.0 / s_12) * rot_12.transpose();
+            const Vec3_t trans_21 = -s_rot_21 * trans_12;
+            const Mat33_t s_rot_21w = s_rot_21 * rot_1w, s_rot_12w = s_rot_12 * rot_2w;
+            const Vec3_t trans_21w = s_rot_21 * trans_1w + trans_21, trans_12w = s_rot_12 * trans_2w + trans_12;
+            // key frame 2's key points partly copy key frame 1's (moved to where the Sim3 sends their landmark), so that mutual best matches exist
+            auto place = [&](data::keyframe& from, int idx_from, data::keyframe& to, int idx_to, const Mat33_t& srot, const Vec3_t& tr, const Mat33_t& srot_back, const Vec3_t& tr_back) {
+                pool.emplace_back(new data::landmark());
+                auto* lm = pool.back().get();
+                const auto& k = to.undist_keypts_[(size_t)idx_to];
+                const double z = uni(0.8, 6.0), px = k.pt.x + uni(-1.5, 1.5), py = k.pt.y + uni(-1.5, 1.5);
+                const Vec3_t p_to((px - cam.cx_) / cam.fx_ * z, (py - cam.cy_) / cam.fy_ * z, z);      // where it must land in `to`
+                lm->pos_w_ = srot_back * p_to + tr_back;                                               // inverse similarity (R = I: exact enough for a scene)
+                (void)srot; (void)tr;
+                lm->min_dist_ = 0.05f; lm->max_dist_ = 80.f;
+                lm->pred_level_ = (unsigned)std::max(0, std::min(7, k.octave + irand(0, 1)));
+                lm->erased_ = uni(0, 1) < 0.03;
+                lm->desc_ = cv::Mat(1, 32, CV_8U);
+                std::copy(to.descriptors_.ptr<uint8_t>(idx_to), to.descriptors_.ptr<uint8_t>(idx_to) + 32, lm->desc_.ptr<uint8_t>(0));
+                for (int f = irand(0, 4); f > 0; --f) lm->desc_.ptr<uint8_t>(0)[irand(0, 31)] ^= (uint8_t)(1u << irand(0, 7));
+                from.landmarks_[(size_t)idx_from] = lm;
+                return lm;
+            };
+            // pairs (i in key frame 1, j in key frame 2) that are the same scene point: descriptors tied together, landmarks on both sides
+            for (int c = 0; c < std::min(n, m) / 2; ++c) {
+                const int i = irand(0, n - 1), j = irand(0, m - 1);
+                if (kf1.landmarks_[(size_t)i] || kf2.landmarks_[(size_t)j]) continue;
+                std::copy(kf1.descriptors_.ptr<uint8_t>(i), kf1.descriptors_.ptr<uint8_t>(i) + 32, kf2.descriptors_.ptr<uint8_t>(j));
+                kf2.keypts_[(size_t)j].octave = kf1.keypts_[(size_t)i].octave; kf2.undist_keypts_[(size_t)j].octave = kf1.undist_keypts_[(size_t)i].octave;
+                // landmark of key frame 1 (world = frame 1 coordinates) that projects onto key point j of key frame 2: x_2 = s_rot_21w x_w + trans_21w
+                place(kf1, i, kf2, j, s_rot_21w, trans_21w, s_rot_12, Vec3_t(trans_12(0), trans_12(1), trans_12(2)));
+                // landmark of key frame 2 (its own world) that projects onto key point i of key frame 1: x_1 = s_rot_12w x_w + trans_12w
+                auto* l2 = place(kf2, j, kf1, i, s_rot_12w, trans_12w, s_rot_21, trans_21);
+                l2->pos_w_ = l2->pos_w_ - trans_2w;                                                   // undo key frame 2's own pose (R = I)
+            }
+            for (int i = 0; i < n; ++i) if (!kf1.landmarks_[(size_t)i] && uni(0, 1) < 0.2) place(kf1, i, kf2, irand(0, m - 1), s_rot_21w, trans_21w, s_rot_12, trans_12);
+            std::vector<data::landmark*> matched((size_t)n, nullptr);
+            for (int i = 0; i < n; i += 23) if (kf1.landmarks_[(size_t)i]) { matched[(size_t)i] = kf1.landmarks_[(size_t)i]; kf1.landmarks_[(size_t)i]->index_in_other_ = irand(-1, m - 1); }
+            // expectation
+            auto one_way = [&](const data::keyframe& from, const std::vector<bool>& already, const Mat33_t& srot, const Vec3_t& tr, const data::keyframe& to,
+                               std::vector<int>& best_of_from) {
+                const int mf = (int)from.landmarks_.size(), nt = (int)to.undist_keypts_.size();
+                std::vector<uint8_t> valid(mf, 0), ld((size_t)mf * 32, 0), kd((size_t)nt * 32);
+                std::vector<double> rp(2 * (size_t)mf, 0.0);
+                std::vector<unsigned> lvl(mf, 0);
+                for (int j = 0; j < mf; ++j) {
+                    auto* lm = from.landmarks_[(size_t)j];
+                    if (!lm || lm->will_be_erased() || already[(size_t)j]) continue;
+                    Vec2_t r; float xr;
+                    if (!cam.reproject_to_image(srot, tr, lm->pos_w_, r, xr)) continue;
+                    const double dist = (srot * lm->pos_w_ + tr).norm();
+                    if (dist < lm->min_dist_ || lm->max_dist_ < dist) continue;
+                    valid[j] = 1; rp[2 * j] = r(0); rp[2 * j + 1] = r(1); lvl[j] = lm->pred_level_;
+                    std::copy(lm->desc_.ptr<uint8_t>(0), lm->desc_.ptr<uint8_t>(0) + 32, ld.begin() + (size_t)j * 32);
+                }
+                for (int i = 0; i < nt; ++i) std::copy(to.descriptors_.ptr<uint8_t>(i), to.descriptors_.ptr<uint8_t>(i) + 32, kd.begin() + (size_t)i * 32);
+                best_of_from.assign(mf, -1);
+                oracle_project_best(grid6, reinterpret_cast<const OKeyPoint*>(to.undist_keypts_.data()), kd.data(), nt, to.scale_factors_.data(), valid.data(), rp.data(),
+                                    lvl.data(), ld.data(), mf, 6.f, 100u, 0, best_of_from.data());
+            };
+            std::vector<bool> a1((size_t)n, false), a2((size_t)m, false);
+            for (int i = 0; i < n; ++i)
+                if (matched[(size_t)i]) { const int j2 = matched[(size_t)i]->index_in_other_; if (0 <= j2 && j2 < m) { a1[(size_t)i] = true; a2[(size_t)j2] = true; } }
+            std::vector<int> b21, b12;
+            one_way(kf1, a1, s_rot_21w, trans_21w, kf2, b21);
+            one_way(kf2, a2, s_rot_12w, trans_12w, kf1, b12);
+            std::vector<data::landmark*> expect = matched;
+            unsigned want_num = 0;
+            for (int i = 0; i < n; ++i) {
+                const int j2 = b21[(size_t)i];
+                if (j2 < 0) continue;
+                if (b12[(size_t)j2] == i) { expect[(size_t)i] = kf2.landmarks_[(size_t)j2]; ++want_num; }
+            }
+            const match::projection projection_matcher(0.9, true);
+            const unsigned got_num = projection_matcher.match_keyframes_mutually(&kf1, &kf2, matched, s_12, rot_12, trans_12, 6.f);
+            if (got_num != want_num || matched != expect) ++failures;
+            std::printf("projection::match_keyframes_mutually: %u matches (oracle %u)\n", got_num, want_num);
         }
         // ---------------- projection::match_frame_and_keyframe (relocalisation)
         for (int check = 0; check < 2; ++check) {

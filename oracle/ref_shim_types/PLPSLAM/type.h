@@ -31,6 +31,11 @@ struct Mat33_t {
     double& operator()(int i, int j) { return m[i][j]; }
     double operator()(int i, int j) const { return m[i][j]; }
     Mat33_t transpose() const { Mat33_t r; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r.m[i][j] = m[j][i]; return r; }
+    Mat33_t operator*(const Mat33_t& o) const {
+        Mat33_t r;
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r.m[i][j] = m[i][0] * o.m[0][j] + m[i][1] * o.m[1][j] + m[i][2] * o.m[2][j];
+        return r;
+    }
     Mat33_t operator/(double a) const { Mat33_t r; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r.m[i][j] = m[i][j] / a; return r; }
     template <int R, int C> Vec3_t block(int i0, int j0) const {      // block<1, 3>(i, 0): a row (projection.cc:786)
         static_assert(R == 1 && C == 3, "block<1, 3> only");
@@ -43,6 +48,7 @@ struct Mat33_t {
         return r;
     }
 };
+inline Mat33_t operator*(double a, const Mat33_t& x) { Mat33_t r; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r.m[i][j] = a * x.m[i][j]; return r; }
 namespace type_detail {
 template <int R, int C> struct block_t;
 template <> struct block_t<3, 3> { using type = Mat33_t; };

@@ -323,8 +323,103 @@ public:
             if (out[i] >= 0) matched_lms_in_keyfrm.at(i) = lms[static_cast<size_t>(out[i])];
         return static_cast<unsigned int>(num);
     }
-    unsigned int match_keyframes_mutually(data::keyframe* keyfrm_1, data::keyframe* keyfrm_2, std::vector<data::landmark*>& matched_lms_in_keyfrm_1,
-                                          const float& s_12, const Mat33_t& rot_12, const Vec3_t& trans_12, const float margin) const;
+    //! projection.cc:894-1142 (loop closure: landmarks of each key frame projected into the other through the Sim3, kept when
+    //! the two best matches agree)
+    template <class KeyFrame, class Landmark>
+    unsigned int match_keyframes_mutually(KeyFrame* keyfrm_1, KeyFrame* keyfrm_2, std::vector<Landmark*>& matched_lms_in_keyfrm_1, const float& s_12,
+                                          const Mat33_t& rot_12, const Vec3_t& trans_12, const float margin) const {
+        const Mat33_t rot_1w = keyfrm_1->get_rotation();
+        const Vec3_t trans_1w = keyfrm_1->get_translation();
+        const Mat33_t rot_2w = keyfrm_2->get_rotation();
+        const Vec3_t trans_2w = keyfrm_2->get_translation();
+        const Mat33_t s_rot_12 = s_12 * rot_12;
+        const Mat33_t s_rot_21 = (1.0 / s_12) * rot_12.transpose();
+        const Vec3_t trans_21 = -s_rot_21 * trans_12;
+        const auto landmarks_1 = keyfrm_1->get_landmarks();
+        const auto landmarks_2 = keyfrm_2->get_landmarks();
+        std::vector<bool> is_already_matched_in_keyfrm_1(landmarks_1.size(), false), is_already_matched_in_keyfrm_2(landmarks_2.size(), false);
+        for (unsigned int idx_1 = 0; idx_1 < landmarks_1.size(); ++idx_1) {
+            auto* lm = matched_lms_in_keyfrm_1.at(idx_1);
+            if (!lm) continue;
+            const auto idx_2 = lm->get_index_in_keyframe(keyfrm_2);
+            if (0 <= idx_2 && idx_2 < static_cast<int>(landmarks_2.size())) {
+                is_already_matched_in_keyfrm_1.at(idx_1) = true;
+                is_already_matched_in_keyfrm_2.at(idx_2) = true;
+            }
+        }
+        // one direction: the landmarks of `from` projected with (s_rot, trans) and searched among the key points of `to`
+        // (the camera model of key frame 2 does the projection in BOTH directions, as in the reference: :957, :1040)
+        auto project_and_search = [&](const std::vector<Landmark*>& lms_from, const std::vector<bool>& already, const Mat33_t& s_rot, const Vec3_t& trans,
+                                      KeyFrame* to, std::vector<int>& matched_in_to) {
+            std::vector<unsigned int> q_i;
+            std::vector<double> reproj_d;
+            std::vector<int32_t> level;
+            std::vector<uint8_t> desc;
+            for (unsigned int idx = 0; idx < lms_from.size(); ++idx) {
+                auto* lm = lms_from.at(idx);
+                if (!lm) continue;
+                if (lm->will_be_erased()) continue;
+                if (already.at(idx)) continue;
+                const Vec3_t pos_w = lm->get_pos_in_world();
+                const Vec3_t pos_to = s_rot * pos_w + trans;
+                Vec2_t reproj;
+                float x_right;
+                if (!keyfrm_2->camera_->reproject_to_image(s_rot, trans, pos_w, reproj, x_right)) continue;
+                const auto cam_to_lm_dist = pos_to.norm();
+                if (cam_to_lm_dist < lm->get_min_valid_distance() || lm->get_max_valid_distance() < cam_to_lm_dist) continue;
+                const auto pred_scale_level = lm->predict_scale_level(cam_to_lm_dist, to);
+                q_i.push_back(idx);
+                reproj_d.push_back(reproj(0)); reproj_d.push_back(reproj(1));
+                level.push_back(static_cast<int32_t>(pred_scale_level));
+                const auto lm_desc = lm->get_descriptor();
+                const unsigned char* p = lm_desc.template ptr<unsigned char>(0);
+                desc.insert(desc.end(), p, p + 32);
+            }
+            const int n = static_cast<int>(to->undist_keypts_.size()), m = static_cast<int>(q_i.size());
+            if (n == 0 || m == 0) return;
+            std::vector<uint8_t> t_desc(static_cast<size_t>(n) * 32);
+            for (int k = 0; k < n; ++k) {
+                const unsigned char* p = to->descriptors_.template ptr<unsigned char>(k);
+                for (int b = 0; b < 32; ++b) t_desc[static_cast<size_t>(k) * 32 + b] = p[b];
+            }
+            std::vector<float> inv_sigma(to->scale_factors_.size(), 1.0f);
+            std::vector<int32_t> best(static_cast<size_t>(m), -1);
+            plp_match_args a{};
+            a.mode = PLP_MATCH_MODE_FUSE; a.B = 1; a.n_cap = n; a.m_cap = m;
+            a.flags = PLP_MATCH_FLAG_NO_CHI2; a.hamm_dist_thr = 100;                       // HAMMING_DIST_THR_HIGH (:1015, :1096)
+            a.t_kps = reinterpret_cast<const plp_keypoint*>(to->undist_keypts_.data()); a.t_desc = t_desc.data();
+            a.q_reproj_d = reproj_d.data(); a.q_level = level.data(); a.q_desc = desc.data();
+            a.margin = margin; a.lowe_ratio = lowe_ratio_;
+            a.num_levels = static_cast<int32_t>(to->scale_factors_.size()); a.scale_factors = to->scale_factors_.data();
+            a.inv_level_sigma_sq = inv_sigma.data();
+            a.grid = detail::grid_of(to->camera_);
+            a.out_query_best = best.data();
+            detail::check(plp_match_host(detail::shared_matcher(), &a));
+            for (int q = 0; q < m; ++q) matched_in_to.at(q_i[static_cast<size_t>(q)]) = best[static_cast<size_t>(q)];
+        };
+        std::vector<int> matched_indices_2_in_keyfrm_1(landmarks_1.size(), -1), matched_indices_1_in_keyfrm_2(landmarks_2.size(), -1);
+        {
+            const Mat33_t s_rot_21w = s_rot_21 * rot_1w;
+            const Vec3_t trans_21w = s_rot_21 * trans_1w + trans_21;
+            project_and_search(landmarks_1, is_already_matched_in_keyfrm_1, s_rot_21w, trans_21w, keyfrm_2, matched_indices_2_in_keyfrm_1);
+        }
+        {
+            const Mat33_t s_rot_12w = s_rot_12 * rot_2w;
+            const Vec3_t trans_12w = s_rot_12 * trans_2w + trans_12;
+            project_and_search(landmarks_2, is_already_matched_in_keyfrm_2, s_rot_12w, trans_12w, keyfrm_1, matched_indices_1_in_keyfrm_2);
+        }
+        unsigned int num_matches = 0;
+        for (unsigned int i = 0; i < landmarks_1.size(); ++i) {      // the cross check (:1124-1139)
+            const auto idx_2 = matched_indices_2_in_keyfrm_1.at(i);
+            if (idx_2 < 0) continue;
+            const auto idx_1 = matched_indices_1_in_keyfrm_2.at(idx_2);
+            if (idx_1 == static_cast<int>(i)) {
+                matched_lms_in_keyfrm_1.at(idx_1) = landmarks_2.at(idx_2);
+                ++num_matches;
+            }
+        }
+        return num_matches;
+    }
 
     //! projection.cc:37-121
     template <class Frame, class Landmark>

@@ -55,24 +55,25 @@ def test_cpp_matcher_facade_equals_oracle(seed, n, m):
     for the monocular, forward and backward cases, including the nullptr left by the orientation check; the two line
     variants on key lines / 3D lines, with partially visible lines and the RGB-D stereo gate; bow_tree::match_frame_and_keyframe
     (facade/PLPSLAM/match/bow_tree.h) on DBoW2-shaped feature vectors and area::match_in_consistent_area (facade/PLPSLAM/match/area.h), each with and without the
-    orientation check; fuse::detect_duplication and projection::match_by_Sim3_transform through a Sim3)."""
+    orientation check; fuse::detect_duplication, projection::match_by_Sim3_transform and match_keyframes_mutually through a Sim3)."""
     env = dict(os.environ)
     env["LD_LIBRARY_PATH"] = "/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
-    r = subprocess.run([_MATCH_EXE, str(seed), str(n), str(m), "sim3"], capture_output=True, text=True, timeout=300, env=env)
+    r = subprocess.run([_MATCH_EXE, str(seed), str(n), str(m), "sim3+mutual"], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = r.stdout.strip().splitlines()
-    assert len(lines) == 22 and lines[0].startswith("match_frame_and_landmarks") and lines[4].startswith("bow_tree::match_frame_and_keyframe")
+    assert len(lines) == 23 and lines[0].startswith("match_frame_and_landmarks") and lines[4].startswith("bow_tree::match_frame_and_keyframe")
     assert lines[6].startswith("bow_tree::match_keyframes") and lines[7].startswith("fuse::replace_duplication:")
     assert lines[8].startswith("fuse::detect_duplication") and lines[9].startswith("projection::match_by_Sim3_transform")
-    assert lines[10].startswith("projection::match_frame_and_keyframe[") and lines[12].startswith("projection::match_frame_and_keyframe_line")
-    assert lines[13].startswith("robust::match_for_triangulation") and lines[15].startswith("fuse::replace_duplication_line")
-    assert lines[16].startswith("area::match_in_consistent_area") and lines[18].startswith("match_frame_and_landmarks_line")
+    assert lines[10].startswith("projection::match_keyframes_mutually")
+    assert lines[11].startswith("projection::match_frame_and_keyframe[") and lines[13].startswith("projection::match_frame_and_keyframe_line")
+    assert lines[14].startswith("robust::match_for_triangulation") and lines[16].startswith("fuse::replace_duplication_line")
+    assert lines[17].startswith("area::match_in_consistent_area") and lines[19].startswith("match_frame_and_landmarks_line")
     if n >= 900:     # the scenes are built so that the matchers have work to do
         import re
         count = lambda ln: int(re.search(r"(\d+) (matches|fused)", ln).group(1))
-        point_lines = lines[:12] + lines[13:15] + lines[16:18]
+        point_lines = lines[:13] + lines[14:16] + lines[17:19]
         assert all(count(ln) > 30 for ln in point_lines)
-        assert all(count(ln) > 10 for ln in [lines[12], lines[15]] + lines[18:])
+        assert all(count(ln) > 10 for ln in [lines[13], lines[16]] + lines[19:])
 
 
 @pytest.mark.skipif(not os.path.exists(_EXE), reason="oracle/_ref/facade_orb_check not built (needs /root/reference at build time)")
