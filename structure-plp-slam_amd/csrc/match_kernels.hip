@@ -3,16 +3,24 @@
 // The reference's point matchers (src/PLPSLAM/match/projection.cc:37-121, :214-358 and
 // robust.cc:257-385) are sequential loops: each query (landmark / last-frame key point /
 // key-frame key point) takes the best still-free key point in its candidate set, and a taken
-// key point is skipped by every later query.  Two kernels reproduce that exactly:
+// key point is skipped by every later query.  Two steps reproduce that exactly: a top-K candidate list per query
+// (independent of the other queries), then the resolution of the claims in query order.
 //
-//   k_match_topk     one wave64 per query: filter all targets (grid-window + level + stereo gate
-//                    of data::get_keypoints_in_cell, common.cc:241-313), 256-bit popcount distance,
-//                    keep the K best by (distance, reference visiting order).
-//   k_match_resolve  one workgroup per problem: fixed-point iteration of "best free candidate given
-//                    the claims of all EARLIER queries" (claims of queries < q are final after q
-//                    rounds, in practice 2-4 rounds), then the accept rules, the delta-angle
-//                    histogram check (match/angle_checker.h) and the scatter of the results.
-//   k_hamming_matrix full nq x nt distance matrix (K16), 64x64 tiles staged through LDS.
+//   k_match_prep        per frame: free in-grid targets counting-sorted by (grid column, grid row, index) = the visiting
+//                       order of data::get_keypoints_in_cell (common.cc:241-313), 16-byte records + cell starts
+//   k_match_topk_cells  windowed modes, main path: 16 lanes per query walk the window's grid columns staged in LDS
+//                       (12-byte records), keep the K = 8 best by (distance, visiting order)
+//   k_match_topk_lds    brute-force mode: the target descriptors staged in LDS, one wave per query
+//   k_match_topk        generic path (line modes, BoW / triangulation groups, frames beyond the LDS budget): one wave per
+//                       query scans all targets through candidate_key(); waves stride over a frame's queries
+//   k_match_resolve     one workgroup per problem: chunk-wise fixed point of "best free candidate given the claims of
+//                       all EARLIER queries" (2-3 iterations per chunk of 256 queries), an exact wave-wide rescan for a
+//                       query whose truncated list ran dry, then the accept rules, the delta-angle histogram check
+//                       (match/angle_checker.h) and the scatter of the results
+//   k_match_fuse        independent searches (fuse.cc, projection.cc:894-1142): best candidate per query, no claims
+//   k_match_area        area::match_in_consistent_area (area.cc:33-153), one wave per problem
+//   k_lbd_match_1nn     BinaryDescriptorMatcher::match: exact 1-NN with MIH discovery-order ties
+//   k_hamming_matrix    full nq x nt distance matrix, 64x64 tiles staged through LDS
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
