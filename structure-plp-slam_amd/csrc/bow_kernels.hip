@@ -262,14 +262,14 @@ void plp_bow_vocab_destroy(plp_bow_vocab* v) {
     delete v;
 }
 
-plp_status plp_bow_transform_device(plp_bow_vocab* v, const uint8_t* d_desc, const int32_t* d_counts, int32_t cap, int32_t B, int32_t levelsup,
-                                    uint32_t* d_word_id, uint32_t* d_node_id, uint32_t* d_bow_word, double* d_bow_value, int32_t* d_n_bow,
-                                    uint32_t* d_fv_node, uint32_t* d_fv_feat, int32_t* d_n_fv, void* hip_stream) {
+// the transform proper; the caller holds v->mu (the scratch arrays word / node / weight / stage belong to the handle)
+static plp_status bow_transform_locked(plp_bow_vocab* v, const uint8_t* d_desc, const int32_t* d_counts, int32_t cap, int32_t B, int32_t levelsup,
+                                       uint32_t* d_word_id, uint32_t* d_node_id, uint32_t* d_bow_word, double* d_bow_value, int32_t* d_n_bow,
+                                       uint32_t* d_fv_node, uint32_t* d_fv_feat, int32_t* d_n_fv, void* hip_stream) {
     if (!v || !d_desc || !d_bow_word || !d_bow_value || !d_n_bow || !d_fv_node || !d_fv_feat || !d_n_fv)
         return set_error(PLP_ERR_INVALID_ARG, "NULL argument");
     if (cap <= 0 || B <= 0 || levelsup < 0) return set_error(PLP_ERR_INVALID_ARG, "cap, B must be positive, levelsup >= 0");
     if (cap > 4096) return set_error(PLP_ERR_UNSUPPORTED, "more than 4096 descriptors per frame");
-    std::lock_guard<std::mutex> lk(v->mu);
     PLP_HIP(hipSetDevice(v->device));
     const size_t tot = (size_t)B * cap;
     if (!d_word_id) { PLP_HIP(v->word.reserve(tot * 4)); d_word_id = (uint32_t*)v->word.p; }
@@ -288,6 +288,15 @@ plp_status plp_bow_transform_device(plp_bow_vocab* v, const uint8_t* d_desc, con
     return PLP_OK;
 }
 
+plp_status plp_bow_transform_device(plp_bow_vocab* v, const uint8_t* d_desc, const int32_t* d_counts, int32_t cap, int32_t B, int32_t levelsup,
+                                    uint32_t* d_word_id, uint32_t* d_node_id, uint32_t* d_bow_word, double* d_bow_value, int32_t* d_n_bow,
+                                    uint32_t* d_fv_node, uint32_t* d_fv_feat, int32_t* d_n_fv, void* hip_stream) {
+    if (!v) return set_error(PLP_ERR_INVALID_ARG, "NULL argument");
+    std::lock_guard<std::mutex> lk(v->mu);
+    return bow_transform_locked(v, d_desc, d_counts, cap, B, levelsup, d_word_id, d_node_id, d_bow_word, d_bow_value, d_n_bow, d_fv_node, d_fv_feat,
+                                d_n_fv, hip_stream);
+}
+
 plp_status plp_bow_transform_host(plp_bow_vocab* v, const uint8_t* desc, int32_t n, int32_t levelsup, uint32_t* word_id, uint32_t* node_id,
                                   uint32_t* bow_word, double* bow_value, int32_t* n_bow, uint32_t* fv_node, uint32_t* fv_feat, int32_t* n_fv) {
     if (!v || !n_bow || !n_fv || n < 0 || (n > 0 && (!desc || !bow_word || !bow_value || !fv_node || !fv_feat)))
@@ -300,17 +309,16 @@ plp_status plp_bow_transform_host(plp_bow_vocab* v, const uint8_t* desc, int32_t
     // desc | word | node | bow_word | bow_value | fv_node | fv_feat | n_bow, n_fv
     const size_t o_desc = 0, o_word = o_desc + cap * 32, o_node = o_word + cap * 4, o_bw = o_node + cap * 4, o_bv = (o_bw + cap * 4 + 7) & ~(size_t)7,
                  o_fn = o_bv + cap * 8, o_ff = o_fn + cap * 4, o_cnt = o_ff + cap * 4, total = o_cnt + 8;
-    {
-        std::lock_guard<std::mutex> lk(v->mu);
-        PLP_HIP(hipSetDevice(v->device));
-        PLP_HIP(v->stage.reserve(total));
-        slab = (uint8_t*)v->stage.p;
-        PLP_HIP(hipMemcpyAsync(slab + o_desc, desc, cap * 32, hipMemcpyHostToDevice, v->stream));
-    }
-    PLP_TRY(plp_bow_transform_device(v, slab + o_desc, nullptr, n, 1, levelsup, (uint32_t*)(slab + o_word), (uint32_t*)(slab + o_node),
+    // one lock across staging, transform and read-back: DBoW2's transform is const and the reference calls one vocabulary
+    // from several threads (frame::compute_bow, keyframe::compute_bow), so callers may share a handle
+    std::lock_guard<std::mutex> lk(v->mu);
+    PLP_HIP(hipSetDevice(v->device));
+    PLP_HIP(v->stage.reserve(total));
+    slab = (uint8_t*)v->stage.p;
+    PLP_HIP(hipMemcpyAsync(slab + o_desc, desc, cap * 32, hipMemcpyHostToDevice, v->stream));
+    PLP_TRY(bow_transform_locked(v, slab + o_desc, nullptr, n, 1, levelsup, (uint32_t*)(slab + o_word), (uint32_t*)(slab + o_node),
                                      (uint32_t*)(slab + o_bw), (double*)(slab + o_bv), (int32_t*)(slab + o_cnt), (uint32_t*)(slab + o_fn),
                                      (uint32_t*)(slab + o_ff), (int32_t*)(slab + o_cnt + 4), v->stream));
-    std::lock_guard<std::mutex> lk(v->mu);
     int32_t cnt[2];
     PLP_HIP(hipMemcpyAsync(cnt, slab + o_cnt, 8, hipMemcpyDeviceToHost, v->stream));
     if (word_id) PLP_HIP(hipMemcpyAsync(word_id, slab + o_word, cap * 4, hipMemcpyDeviceToHost, v->stream));

@@ -105,6 +105,7 @@ plp_status plp_matcher_create(int device, plp_matcher** out) {
     if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return set_error(PLP_ERR_NO_DEVICE, "no HIP device visible: the matchers have no CPU fallback");
     if (device < 0 || device >= n) return set_error(PLP_ERR_INVALID_ARG, "device index out of range");
     PLP_HIP(hipSetDevice(device));
+    PLP_HIP(configure_match_kernels());
     plp_matcher* c = new plp_matcher();
     c->device = device;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return set_error(PLP_ERR_HIP, "hipStreamCreate failed"); }
@@ -240,6 +241,7 @@ plp_status plp_lbd_match_1nn_device(plp_matcher* c, const uint8_t* d_q, const in
 plp_status plp_lbd_match_1nn_host(plp_matcher* c, const uint8_t* q, int32_t nq, const uint8_t* t, int32_t nt, int32_t* train_idx, int32_t* dist) {
     if (!c || !q || !t || !train_idx || !dist) return set_error(PLP_ERR_INVALID_ARG, "NULL argument");
     if (nq <= 0 || nt <= 0) return PLP_OK;   // the reference prints an error and returns with `matches` untouched (:201-205)
+    if (nt > 65535) return set_error(PLP_ERR_UNSUPPORTED, "more than 65535 train descriptors (16-bit index in the tie-break key)");
     std::lock_guard<std::mutex> lk(c->mu);
     PLP_HIP(hipSetDevice(c->device));
     const size_t bq = ((size_t)nq * 32 + 255) / 256 * 256, bt = ((size_t)nt * 32 + 255) / 256 * 256, bo = ((size_t)nq * 4 + 255) / 256 * 256;

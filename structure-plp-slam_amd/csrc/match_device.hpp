@@ -69,6 +69,7 @@ struct MihRanks { uint8_t rank[256]; };   // enumeration rank of an 8-bit flip p
 void launch_lbd_match_1nn(hipStream_t st, const uint8_t* q, const int32_t* q_counts, int nq_cap, const uint8_t* t, const int32_t* t_counts,
                           int nt_cap, const MihRanks& R, int32_t* out_idx, int32_t* out_dist, int B);
 void launch_match(hipStream_t st, const MatchProblem& P, int B);
+hipError_t configure_match_kernels();   // per-device kernel attributes (dynamic LDS of k_match_resolve)
 struct AreaArgs {
     const plp_keypoint *kps1, *kps2; const uint8_t *desc1, *desc2; int n1, n2;
     float grid_min_x, grid_min_y; double inv_cell_w, inv_cell_h; int grid_cols, grid_rows;

@@ -83,8 +83,11 @@ __device__ __forceinline__ QueryCtx make_query(const MatchProblem& P, int q, int
     }
     if (!c.windowed) return c;
     const int lvl = q_level[q];
+    // the reference indexes scale_factors_.at(level) and throws on a level outside the table; device arrays cannot be validated by
+    // the host entry, so the table lookup is clamped (the level WINDOW below still uses the caller's value)
+    const int lvl_tab = min(max(lvl, 0), max(P.num_levels, 1) - 1);
     if (c.line) {   // data::get_keylines_in_cell (common.cc:315-363) + the level windows of projection.cc:138-144, :429-450
-        c.mg = __fmul_rn(P.margin, P.scale_factors[lvl]);
+        c.mg = __fmul_rn(P.margin, P.scale_factors[lvl_tab]);
         double x1, y1, x2, y2;
         if (P.mode == PLP_MATCH_MODE_FUSE_LINE) {   // the f64 reprojections are narrowed to float by the call (fuse.cc:420-422)
             const double* a = P.q_reproj_d + (qoff + q) * 2; const double* e = P.q_reproj2_d + (qoff + q) * 2;
@@ -114,7 +117,7 @@ __device__ __forceinline__ QueryCtx make_query(const MatchProblem& P, int q, int
         c.rx = (float)c.rdx; c.ry = (float)c.rdy;
         c.pred = (unsigned)lvl;
     } else { c.rx = reproj[2 * q]; c.ry = reproj[2 * q + 1]; }
-    c.mg = __fmul_rn(P.margin, P.scale_factors[lvl]);
+    c.mg = __fmul_rn(P.margin, P.scale_factors[lvl_tab]);
     c.xr = q_xr ? q_xr[q] : -1.f;
     if (P.mode == PLP_MATCH_MODE_LANDMARKS || (P.mode == PLP_MATCH_MODE_LAST_FRAME && P.level_window == 1)) { c.min_level = lvl - 1; c.max_level = lvl; }
     else if (P.mode == PLP_MATCH_MODE_FUSE) { c.min_level = -1; c.max_level = -1; }
@@ -935,9 +938,13 @@ void launch_match(hipStream_t st, const MatchProblem& P, int B) {
         const int gx_full = (P.m_cap + 3) / 4, gx_min = std::max(16, (8192 + B - 1) / B);   // keep >= ~8K workgroups in flight
         hipLaunchKernelGGL(k_match_topk, dim3(std::min(gx_full, gx_min), B), dim3(256), 0, st, P);
     }
-    static bool attr_set = false;   // up to 8192 targets: 96 KB of owner arrays
-    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_match_resolve), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 12); attr_set = true; }
     hipLaunchKernelGGL(k_match_resolve, dim3(B), dim3(256), (size_t)P.n_cap * 12, st, Q);
+}
+
+// up to 8192 targets: 96 KB of owner arrays.  The attribute belongs to the function ON THE CURRENT DEVICE: called by
+// plp_matcher_create after hipSetDevice, once per context.
+hipError_t configure_match_kernels() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_match_resolve), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 12);
 }
 
 void launch_hamming_matrix(hipStream_t st, const uint8_t* q, int nq, const uint8_t* t, int nt, uint16_t* dist) {

@@ -55,7 +55,6 @@ struct plp_orb {
     int last_B = 0;
     OrbPlanes last_planes{};
     hipStream_t last_stream = nullptr;
-    bool use_host_quadtree = false;
     // per-stage HIP-event timing (profiling mode only; makes every batch synchronous)
     bool profiling = false;
     hipEvent_t ev[8] = {};
@@ -84,8 +83,18 @@ void reinitialize(plp_orb* c) {   // orb_extractor::initialize()
     c->geo = OrbGeometry{};   // force a geometry rebuild at the next frame
 }
 
+plp_status build_geometry_impl(plp_orb* c, int rows, int cols);
+
+// A failed build must not leave a half-initialised geometry behind: the next call at the same size would pass the early-out
+// below and launch kernels on tables that were never uploaded.
 plp_status build_geometry(plp_orb* c, int rows, int cols) {
     if (c->geo.rows == rows && c->geo.cols == cols && c->geo.n_levels == (int)c->p.num_levels) return PLP_OK;
+    const plp_status s = build_geometry_impl(c, rows, cols);
+    if (s != PLP_OK) { c->geo = OrbGeometry{}; c->h_lv.clear(); c->capB = 0; }
+    return s;
+}
+
+plp_status build_geometry_impl(plp_orb* c, int rows, int cols) {
     const int nl = (int)c->p.num_levels;
     // every level must keep a non-empty FAST region; the reference underflows (UB) otherwise
     {
@@ -182,45 +191,6 @@ void build_rect_mask(plp_orb* c, int rows, int cols) {
     c->rect_mask_uploaded = false;
 }
 
-// the temporary host stage of the quadtree (PLP_ORB_HOST_QUADTREE=1): same arithmetic as the kernel
-plp_status host_quadtree(plp_orb* c, hipStream_t st, int B) {
-    const OrbGeometry& g = c->geo;
-    const size_t n_cells = g.cells.size();
-    std::vector<int32_t> counts(n_cells * B);
-    std::vector<uint32_t> cand((size_t)kCellCap * n_cells * B);
-    PLP_HIP(hipMemcpyAsync(counts.data(), c->cell_count.p, counts.size() * 4, hipMemcpyDeviceToHost, st));
-    PLP_HIP(hipMemcpyAsync(cand.data(), c->cell_cand.p, cand.size() * 4, hipMemcpyDeviceToHost, st));
-    PLP_HIP(hipStreamSynchronize(st));
-    std::vector<int32_t> sel((size_t)g.total_sel_cap * B, 0), sel_count((size_t)kMaxLevels * B, 0);
-    int overflow = 0;
-    for (int f = 0; f < B; ++f)
-        for (int l = 0; l < g.n_levels; ++l) {
-            const LevelGeom& L = g.lv[l];
-            std::vector<QtCand> cs;
-            const int nc = L.n_cell_rows * L.n_cell_cols;
-            for (int k = 0; k < nc; ++k) {
-                const size_t slot = (size_t)f * n_cells + L.cell_base + k;
-                for (int i = 0; i < counts[slot]; ++i) {
-                    const uint32_t pk = cand[slot * kCellCap + i];
-                    cs.push_back({(int)(pk & 0xfff), (int)((pk >> 12) & 0xfff), (int)(pk >> 24)});
-                }
-            }
-            std::vector<int> pick = quadtree_select(cs.data(), (int)cs.size(), L, c->st.quota[l]);
-            int n = (int)pick.size();
-            if (n > L.sel_cap) { n = L.sel_cap; overflow = 1; }
-            for (int i = 0; i < n; ++i) {
-                const QtCand& q = cs[pick[i]];
-                sel[(size_t)f * g.total_sel_cap + L.sel_base + i] = (int32_t)((uint32_t)q.x | ((uint32_t)q.y << 12) | ((uint32_t)q.score << 24));
-            }
-            sel_count[(size_t)f * kMaxLevels + l] = n;
-        }
-    PLP_HIP(hipMemcpyAsync(c->sel.p, sel.data(), sel.size() * 4, hipMemcpyHostToDevice, st));
-    PLP_HIP(hipMemcpyAsync(c->sel_count.p, sel_count.data(), sel_count.size() * 4, hipMemcpyHostToDevice, st));
-    PLP_HIP(hipStreamSynchronize(st));
-    if (overflow) return set_error(PLP_ERR_OVERFLOW, "selected-list overflow");
-    return PLP_OK;
-}
-
 plp_status run_batch(plp_orb* c, const uint8_t* d_imgs, int B, int rows, int cols, size_t step, size_t frame_stride,
                      const uint8_t* d_mask, size_t mask_step, size_t mask_frame_stride, plp_keypoint* d_kps, uint8_t* d_desc,
                      int cap, int32_t* d_counts, hipStream_t st) {
@@ -265,10 +235,9 @@ plp_status run_batch(plp_orb* c, const uint8_t* d_imgs, int B, int rows, int col
     BlurTaps taps{{18, 34, 48, 56, 48, 34, 18}};   // 7 taps, sigma 2, 8.8 fixed point, sum 256
     launch_blur(st, pl, (uint8_t*)c->blur.p, g.frame_plane_bytes, (const LevelDev*)c->d_lv.p, nl, c->total_blur_tiles, B, taps);
     mark(4);
-    if (c->use_host_quadtree) PLP_TRY(host_quadtree(c, st, B));
-    else launch_quadtree(st, (const LevelDev*)c->d_lv.p, nl, (int)g.cells.size(), (const uint32_t*)c->cell_cand.p,
-                         (const int32_t*)c->cell_count.p, (int32_t*)c->sel.p, (int32_t*)c->sel_count.p, g.total_sel_cap,
-                         (uint32_t*)c->qt_scratch.p, c->qt_frame_stride, (int32_t*)c->status.p, B, c->max_quota);
+    launch_quadtree(st, (const LevelDev*)c->d_lv.p, nl, (int)g.cells.size(), (const uint32_t*)c->cell_cand.p,
+                    (const int32_t*)c->cell_count.p, (int32_t*)c->sel.p, (int32_t*)c->sel_count.p, g.total_sel_cap,
+                    (uint32_t*)c->qt_scratch.p, c->qt_frame_stride, (int32_t*)c->status.p, B, c->max_quota);
     mark(5);
     UMax um;
     for (int v = 0; v <= kHalfPatch; ++v) um.v[v] = c->st.u_max[v];
@@ -310,8 +279,6 @@ plp_status plp_orb_create(const plp_orb_params* params, int device, plp_orb** ou
     c->p.mask_rects = nullptr;
     c->device = device;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return set_error(PLP_ERR_HIP, "hipStreamCreate failed"); }
-    const char* e = getenv("PLP_ORB_HOST_QUADTREE");
-    c->use_host_quadtree = e && e[0] == '1';
     reinitialize(c);
     *out = c;
     return PLP_OK;

@@ -476,7 +476,7 @@ public:
         std::vector<LandmarkPtr> lms;
         std::vector<float> reproj_f, x_right_f, angle;
         std::vector<int32_t> level;
-        std::vector<uint8_t> desc;
+        std::vector<uint8_t> desc, has_obs;
         for (unsigned int idx_last = 0; idx_last < last_frm.num_keypts_; ++idx_last) {
             auto lm = last_frm.landmarks_.at(idx_last);
             if (!lm) continue;
@@ -490,6 +490,8 @@ public:
             x_right_f.push_back(x_right);
             level.push_back(static_cast<int32_t>(last_frm.keypts_.at(idx_last).octave));
             angle.push_back(last_frm.undist_keypts_.at(idx_last).angle);
+            // a key point taken by this landmark blocks later queries only if the landmark has observations (:300)
+            has_obs.push_back(lm->has_observation() ? 1 : 0);
             const auto lm_desc = lm->get_descriptor();
             const unsigned char* p = lm_desc.template ptr<unsigned char>(0);
             desc.insert(desc.end(), p, p + 32);
@@ -502,6 +504,7 @@ public:
         a.mode = PLP_MATCH_MODE_LAST_FRAME; a.B = 1; a.n_cap = T.n; a.m_cap = static_cast<int32_t>(lms.size());
         a.t_kps = T.kps; a.t_desc = T.desc.data(); a.t_x_right = curr_frm.stereo_x_right_.data(); a.t_occupied = T.occupied.data();
         a.q_reproj = reproj_f.data(); a.q_x_right = x_right_f.data(); a.q_level = level.data(); a.q_angle = angle.data(); a.q_desc = desc.data();
+        a.q_has_obs = has_obs.data();
         a.margin = margin; a.lowe_ratio = lowe_ratio_; a.check_orientation = check_orientation_ ? 1 : 0;
         a.direction = assume_forward ? 1 : (assume_backward ? 2 : 0);
         a.flags = PLP_MATCH_FLAG_MARK_INVALIDATED;
@@ -575,7 +578,7 @@ public:
         std::vector<LinePtr> lms;
         std::vector<float> sp, ep, xr_sp, xr_ep;
         std::vector<int32_t> level;
-        std::vector<uint8_t> desc;
+        std::vector<uint8_t> desc, has_obs;
         for (unsigned int idx_last = 0; idx_last < last_frm._num_keylines; ++idx_last) {
             auto lm_line = last_frm._landmarks_line.at(idx_last);
             if (!lm_line) continue;
@@ -598,6 +601,7 @@ public:
             ep.push_back(static_cast<float>(reproj_ep(0))); ep.push_back(static_cast<float>(reproj_ep(1)));
             xr_sp.push_back(x_right_sp); xr_ep.push_back(x_right_ep);
             level.push_back(static_cast<int32_t>(last_frm._keylsd.at(idx_last).octave));
+            has_obs.push_back(lm_line->has_observation() ? 1 : 0);     // (:485): only an observed landmark blocks its key line
             const auto lm_desc = lm_line->get_descriptor();
             const unsigned char* p = lm_desc.template ptr<unsigned char>(0);
             desc.insert(desc.end(), p, p + 32);
@@ -615,7 +619,7 @@ public:
         a.mode = PLP_MATCH_MODE_LAST_FRAME_LINE; a.B = 1; a.n_cap = T.n; a.m_cap = static_cast<int32_t>(lms.size());
         a.t_kl = T.kl; a.t_desc = T.desc.data(); a.t_occupied = T.occupied.data(); a.t_x_right = t_xr.data(); a.t_x_right2 = t_xr2.data();
         a.q_reproj = sp.data(); a.q_reproj2 = ep.data(); a.q_x_right = xr_sp.data(); a.q_x_right2 = xr_ep.data(); a.q_level = level.data();
-        a.q_desc = desc.data();
+        a.q_desc = desc.data(); a.q_has_obs = has_obs.data();
         a.margin = margin; a.lowe_ratio = lowe_ratio_;
         a.direction = assume_forward ? 1 : (assume_backward ? 2 : 0);
         a.is_rgbd = setup == 2 ? 1 : 0;
