@@ -59,6 +59,10 @@ inline unsigned hamming64(const uint8_t* a, const uint8_t* b) {  // base.h:70-92
 // comparator (angle_checker.h:165-176), so which of several EQUALLY full bins makes the top 3 is
 // unspecified there.  Deliberate definition (oracle and HIP path alike): equally full bins keep
 // ascending bin order (a stable sort).
+// set by AngleChecker::collect: the thr-th and (thr+1)-th fullest bins held equally many (> 0) matches, i.e. the reference's
+// unstable std::sort (angle_checker.h:165-176) decides which of them is kept (definition D3); read by tests through
+// oracle_angle_checker_last_tie() to tell a D3 case from a real difference
+static int g_angle_tie = 0;
 struct AngleChecker {
     std::vector<std::vector<int>> hist;
     unsigned len, thr;
@@ -79,6 +83,7 @@ struct AngleChecker {
     std::vector<int> collect(bool valid) const {
         std::vector<int> out;
         const auto bins = order();
+        g_angle_tie = (thr < len && thr > 0 && !hist[bins[thr]].empty() && hist[bins[thr - 1]].size() == hist[bins[thr]].size()) ? 1 : 0;
         for (unsigned bin = 0; bin < len; ++bin) {
             const bool is_valid = std::any_of(bins.begin(), bins.begin() + thr, [bin](unsigned i) { return bin == i; });
             if (is_valid == valid) out.insert(out.end(), hist[bin].begin(), hist[bin].end());
@@ -144,6 +149,7 @@ using namespace oracle;
 
 extern "C" {
 
+int oracle_angle_checker_last_tie() { return g_angle_tie; }
 unsigned oracle_hamming32(const uint8_t* a, const uint8_t* b) { return hamming32(a, b); }
 unsigned oracle_hamming64(const uint8_t* a, const uint8_t* b) { return hamming64(a, b); }
 

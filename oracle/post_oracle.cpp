@@ -16,6 +16,8 @@
 #include <cstdint>
 #include <limits>
 
+#include "cv_restated.hpp"
+
 namespace {
 
 struct KeyPoint { float x, y, size, angle, response; int octave, class_id; };
@@ -241,37 +243,7 @@ bool matx33_inv(const double a[9], double b[9]) {
     return true;
 }
 
-int cv_round(double v) { return (int)std::nearbyint(v); }   // default rounding mode: half to even, like cvRound
-
-// initInterTab2D(INTER_LINEAR, fixpt = true): 32 x 32 sub-pixel positions, 2 x 2 short weights each
-const short* bilinear_tab_i() {
-    static short tab[32 * 32 * 4];
-    static bool ready = false;
-    if (ready) return tab;
-    float lin[32][2];
-    for (int i = 0; i < 32; ++i) { const float x = i * (1.f / 32); lin[i][0] = 1.f - x; lin[i][1] = x; }
-    for (int i = 0; i < 32; ++i)
-        for (int j = 0; j < 32; ++j) {
-            short* it = tab + (i * 32 + j) * 4;
-            int isum = 0;
-            for (int k1 = 0; k1 < 2; ++k1)
-                for (int k2 = 0; k2 < 2; ++k2) {
-                    const float v = lin[i][k1] * lin[j][k2] * 32768.f;
-                    int r = cv_round(v);
-                    r = r > 32767 ? 32767 : (r < -32768 ? -32768 : r);
-                    it[k1 * 2 + k2] = (short)r;
-                    isum += r;
-                }
-            if (isum != 32768) {
-                // the compensation looks at the 2 x 2 taps starting at ksize/2 = 1; for a 2 x 2 kernel only tap (1, 1)
-                // is inside the block and the entries behind it are still zero while the table is being filled
-                const int diff = isum - 32768;
-                it[3] = (short)(it[3] - diff);
-            }
-        }
-    ready = true;
-    return tab;
-}
+using oracle::cv_round;
 
 }  // namespace
 
@@ -350,31 +322,7 @@ int oracle_fisheye_rectify_map(const double* K, const double* D4, const double* 
 // cv::remap(src 8UC1, dst, map_x, map_y CV_32FC1, INTER_LINEAR, BORDER_CONSTANT, 0); dst has the maps' size
 void oracle_remap_linear(const uint8_t* src, int rows, int cols, size_t step, const float* map_x, const float* map_y, int drows, int dcols,
                          uint8_t* dst) {
-    const short* wtab = bilinear_tab_i();
-    const int width1 = cols - 1 > 0 ? cols - 1 : 0, height1 = rows - 1 > 0 ? rows - 1 : 0;
-    auto sat_short = [](int v) { return v > 32767 ? 32767 : (v < -32768 ? -32768 : v); };
-    for (int dy = 0; dy < drows; ++dy)
-        for (int dx = 0; dx < dcols; ++dx) {
-            const int fsx = cv_round(map_x[(size_t)dy * dcols + dx] * 32.f), fsy = cv_round(map_y[(size_t)dy * dcols + dx] * 32.f);
-            const short* w = wtab + (((fsy & 31) * 32) + (fsx & 31)) * 4;
-            const int sx = sat_short(fsx >> 5), sy = sat_short(fsy >> 5);
-            int val;
-            if ((unsigned)sx < (unsigned)width1 && (unsigned)sy < (unsigned)height1) {
-                const uint8_t* S = src + (size_t)sy * step + sx;
-                val = S[0] * w[0] + S[1] * w[1] + S[step] * w[2] + S[step + 1] * w[3];
-            } else if (sx >= cols || sx + 1 < 0 || sy >= rows || sy + 1 < 0) {
-                dst[(size_t)dy * dcols + dx] = 0;
-                continue;
-            } else {
-                const int v0 = (sx >= 0 && sy >= 0) ? src[(size_t)sy * step + sx] : 0;
-                const int v1 = (sx + 1 < cols && sy >= 0) ? src[(size_t)sy * step + sx + 1] : 0;
-                const int v2 = (sx >= 0 && sy + 1 < rows) ? src[(size_t)(sy + 1) * step + sx] : 0;
-                const int v3 = (sx + 1 < cols && sy + 1 < rows) ? src[(size_t)(sy + 1) * step + sx + 1] : 0;
-                val = v0 * w[0] + v1 * w[1] + v2 * w[2] + v3 * w[3];
-            }
-            const int r = (val + (1 << 14)) >> 15;
-            dst[(size_t)dy * dcols + dx] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
-        }
+    oracle::remap_linear_u8(src, rows, cols, step, map_x, map_y, drows, dcols, dst);
 }
 
 }  // extern "C"

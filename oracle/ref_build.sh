@@ -12,6 +12,17 @@ g++ -O2 -std=c++17 -fPIC -shared -Wl,-Bsymbolic -ffp-contract=off -fno-fast-math
     "$REF/src/PLPSLAM/feature/orb_extractor.cc" "$REF/src/PLPSLAM/feature/orb_extractor_node.cc" "$REF/src/PLPSLAM/feature/orb_params.cc" \
     "$HERE/ref_driver.cpp" -o "$HERE/_ref/libplpref.so"
 echo "ref_build: built $HERE/_ref/libplpref.so"
+# The matcher / stereo / grid / line / LBD / MIH translation units of the reference, unmodified, against the OpenCV stand-in
+# (ref_shim) and the include-shadowing stand-ins of the data / camera / Eigen / DBoW2 / json headers (ref_shadow): a second
+# library, because libplpref.so replaces operator new for the quadtree's pointer ordering (ref_driver.cpp) and these do not want that.
+R="$REF/src/PLPSLAM"
+g++ -O2 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math -DUSE_DBOW2 -w \
+    -I"$HERE/ref_shadow" -I"$HERE/ref_shim" -I"$REF/src" \
+    "$R/match/stereo.cc" "$R/match/area.cc" "$R/match/bow_tree.cc" "$R/match/fuse.cc" "$R/match/projection.cc" "$R/match/robust.cc" \
+    "$R/data/common.cc" "$R/feature/line_extractor.cc" "$R/feature/line_descriptor/LSDDetector_custom.cpp" \
+    "$R/feature/line_descriptor/binary_descriptor_custom.cpp" "$R/feature/line_descriptor/binary_descriptor_matcher.cpp" \
+    "$HERE/ref_driver2.cpp" -o "$HERE/_ref/libplpref2.so"
+echo "ref_build: built $HERE/_ref/libplpref2.so"
 # the shipped C++ facade, compiled like a reference translation unit and linked to the product library
 PKG="$HERE/../structure-plp-slam_amd"
 if [ -f "$PKG/libplp_front.so" ]; then

@@ -1,57 +1,154 @@
-// TEST INFRASTRUCTURE ONLY (oracle/_ref).  A minimal stand-in for the OpenCV types and calls that the reference's
-// own ORB extractor sources use (src/PLPSLAM/feature/orb_extractor{,_node}.cc, orb_params.cc, util/trigonometric.h,
-// match/base.h, match/angle_checker.h), so that THOSE FILES compile unmodified, from where they lie under
-// /root/reference, into oracle/_ref/libplpref.so (recipe: oracle/ref_build.sh).  OpenCV itself is not available in the
-// build container; the four image primitives (cv::resize, cv::FAST, cv::GaussianBlur, cv::fastAtan2) forward to the
-// restatement in oracle/cv_restated.hpp.  What oracle/_ref therefore pins is every line the REFERENCE owns on this
-// path: cell / ROI / border logic, the threshold fallback, masks, the std::list quadtree with its pointer-ordered
-// pool, orientation, the rBRIEF rotation and its trigonometric polynomials, scale correction, tables, Hamming
-// distances and the angle histogram.  It does not pin the OpenCV primitives (see cv_restated.hpp's header).
+// TEST INFRASTRUCTURE ONLY (oracle/_ref).  A stand-in for the OpenCV types and calls that the reference's own sources on
+// the hot path use, so that THOSE FILES compile unmodified, from where they lie under /root/reference, into
+// oracle/_ref/libplpref.so (ORB) and oracle/_ref/libplpref2.so (lines, LBD, MIH, matchers, stereo) -- recipe:
+// oracle/ref_build.sh.  OpenCV itself is not available in the build container.
+//   * Types (cv::Mat with a run-time element type, Mat_<T>, Point_, Size, Rect, Vec, KeyPoint, DMatch, Ptr, Algorithm,
+//     _InputArray/_OutputArray, FileNode/FileStorage) are re-implemented here, generically.
+//   * The image primitives the path CALLS forward to the restatements in oracle/cv_restated.hpp / lsd_restated.hpp
+//     (cv::resize INTER_LINEAR, cv::FAST, cv::GaussianBlur on u8, cv::fastAtan2, cv::Sobel 3x3, cv::remap INTER_LINEAR,
+//     cv::createLineSegmentDetector, cv::LineIterator::count, cv::norm L1).  What oracle/_ref therefore pins is every line
+//     the REFERENCE owns; it cannot pin those OpenCV primitives (same restatement on both sides; tools/opencv_crosscheck.cpp
+//     is the route to pinning them).
+//   * Calls that only the reference's DEAD code makes (the EDLines detector inside binary_descriptor_custom.cpp, pyrDown of
+//     higher octaves, CLAHE, cvtColor of colour input, drawing) are declared and throw std::logic_error when reached.
 #pragma once
+#include <algorithm>
 #include <cassert>
+#include <climits>
+#include <cfloat>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
+#include <iostream>
 #include <memory>
 #include <stdexcept>
+#include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../cv_restated.hpp"
+#include "../lsd_restated.hpp"
 
 typedef unsigned char uchar;
+typedef signed char schar;
+typedef unsigned short ushort;
+
+#define CV_CN_SHIFT 3
 #define CV_8U 0
-#define CV_8UC1 0
+#define CV_8S 1
+#define CV_16U 2
+#define CV_16S 3
+#define CV_32S 4
 #define CV_32F 5
+#define CV_64F 6
+#define CV_MAKETYPE(depth, cn) ((depth) + (((cn)-1) << CV_CN_SHIFT))
+#define CV_MAT_DEPTH(t) ((t) & 7)
+#define CV_MAT_CN(t) ((((t) >> CV_CN_SHIFT) & 63) + 1)
+#define CV_8UC1 CV_MAKETYPE(CV_8U, 1)
+#define CV_8UC3 CV_MAKETYPE(CV_8U, 3)
+#define CV_8UC4 CV_MAKETYPE(CV_8U, 4)
+#define CV_8SC1 CV_MAKETYPE(CV_8S, 1)
+#define CV_16UC1 CV_MAKETYPE(CV_16U, 1)
+#define CV_16SC1 CV_MAKETYPE(CV_16S, 1)
+#define CV_16SC2 CV_MAKETYPE(CV_16S, 2)
+#define CV_32SC1 CV_MAKETYPE(CV_32S, 1)
+#define CV_32FC1 CV_MAKETYPE(CV_32F, 1)
+#define CV_32FC2 CV_MAKETYPE(CV_32F, 2)
+#define CV_64FC1 CV_MAKETYPE(CV_64F, 1)
 #define CV_PI 3.1415926535897932384626433832795
+#define CV_EXPORTS
+#define CV_EXPORTS_W
+#define CV_WRAP
+#define CV_OUT
+#define CV_IN_OUT
+#define CV_INTER_LINEAR 1
 #define CV_Assert(expr) do { if (!(expr)) throw std::runtime_error("CV_Assert failed: " #expr); } while (0)
+#define CV_DbgAssert(expr)
+#define CV_Error(code, msg) throw std::runtime_error(msg)
 
 inline int cvRound(double v) { return oracle::cv_round(v); }
 inline int cvRound(float v) { return oracle::cv_round(v); }
 inline int cvRound(int v) { return v; }
 inline int cvFloor(double v) { return oracle::cv_floor(v); }
 inline int cvFloor(float v) { return oracle::cv_floor(v); }
+inline int cvFloor(int v) { return v; }
 inline int cvCeil(double v) { return oracle::cv_ceil(v); }
 inline int cvCeil(float v) { return oracle::cv_ceil((double)v); }
+inline int cvCeil(int v) { return v; }
 
 namespace cv {
+
+using std::min; using std::max; using std::abs; using std::swap; using std::sqrt; using std::exp; using std::pow; using std::log;   // opencv2/core/base.hpp
+typedef std::string String;
+[[noreturn]] inline void shim_dead(const char* what) { throw std::logic_error(std::string("oracle/ref_shim: ") + what + " is not on the reference's live path"); }
+
+template <typename T> inline T saturate_cast(double v);
+template <> inline uchar saturate_cast<uchar>(double v) { const int i = cvRound(v); return (uchar)(i < 0 ? 0 : i > 255 ? 255 : i); }
+template <> inline schar saturate_cast<schar>(double v) { const int i = cvRound(v); return (schar)(i < -128 ? -128 : i > 127 ? 127 : i); }
+template <> inline short saturate_cast<short>(double v) { const int i = cvRound(v); return (short)(i < -32768 ? -32768 : i > 32767 ? 32767 : i); }
+template <> inline ushort saturate_cast<ushort>(double v) { const int i = cvRound(v); return (ushort)(i < 0 ? 0 : i > 65535 ? 65535 : i); }
+template <> inline int saturate_cast<int>(double v) { return cvRound(v); }
+template <> inline float saturate_cast<float>(double v) { return (float)v; }
+template <> inline double saturate_cast<double>(double v) { return v; }
 
 template <typename T> struct Point_ {
     T x, y;
     Point_() : x(0), y(0) {}
     Point_(T x_, T y_) : x(x_), y(y_) {}
-    template <typename U> Point_(const Point_<U>& o) : x((T)o.x), y((T)o.y) {}
+    // Point(Point2f) rounds (saturate_cast<int>), every other conversion is a plain cast
+    template <typename U> Point_(const Point_<U>& o) : x(conv(o.x)), y(conv(o.y)) {}
     Point_& operator*=(T s) { x *= s; y *= s; return *this; }
+    bool operator==(const Point_& o) const { return x == o.x && y == o.y; }
+private:
+    template <typename U> static T conv(U v) {
+        if constexpr (std::is_integral<T>::value && std::is_floating_point<U>::value) return (T)cvRound(v);
+        else return (T)v;
+    }
 };
 typedef Point_<int> Point2i;
 typedef Point_<int> Point;
 typedef Point_<float> Point2f;
+typedef Point_<double> Point2d;
 template <typename T> inline Point_<T> operator+(const Point_<T>& a, const Point_<T>& b) { return Point_<T>(a.x + b.x, a.y + b.y); }
 template <typename T> inline Point_<T> operator-(const Point_<T>& a, const Point_<T>& b) { return Point_<T>(a.x - b.x, a.y - b.y); }
 template <typename T, typename S> inline Point_<T> operator*(const Point_<T>& a, S s) { return Point_<T>((T)(a.x * s), (T)(a.y * s)); }
 
-struct Size { int width, height; Size() : width(0), height(0) {} Size(int w, int h) : width(w), height(h) {} };
-struct Scalar { double val[4]; Scalar(double v0 = 0) : val{v0, 0, 0, 0} {} };
+template <typename T> struct Size_ {
+    T width, height;
+    Size_() : width(0), height(0) {}
+    Size_(T w, T h) : width(w), height(h) {}
+    bool operator==(const Size_& o) const { return width == o.width && height == o.height; }
+    bool operator!=(const Size_& o) const { return !(*this == o); }
+    T area() const { return width * height; }
+};
+typedef Size_<int> Size;
+struct Scalar {
+    double val[4];
+    Scalar(double v0 = 0, double v1 = 0, double v2 = 0, double v3 = 0) : val{v0, v1, v2, v3} {}
+    static Scalar all(double v) { return Scalar(v, v, v, v); }
+    double operator[](int i) const { return val[i]; }
+};
 struct Range { int start, end; Range(int s, int e) : start(s), end(e) {} };
+template <typename T> struct Rect_ {
+    T x, y, width, height;
+    Rect_() : x(0), y(0), width(0), height(0) {}
+    Rect_(T x_, T y_, T w, T h) : x(x_), y(y_), width(w), height(h) {}
+};
+typedef Rect_<int> Rect;
+template <typename T, int N> struct Vec {
+    T val[N];
+    Vec() { for (int i = 0; i < N; ++i) val[i] = T(); }
+    Vec(T a, T b) { static_assert(N == 2, ""); val[0] = a; val[1] = b; }
+    Vec(T a, T b, T c) { static_assert(N == 3, ""); val[0] = a; val[1] = b; val[2] = c; }
+    Vec(T a, T b, T c, T d) { static_assert(N == 4, ""); val[0] = a; val[1] = b; val[2] = c; val[3] = d; }
+    T& operator[](int i) { return val[i]; }
+    const T& operator[](int i) const { return val[i]; }
+};
+typedef Vec<float, 4> Vec4f;
+typedef Vec<int, 4> Vec4i;
+typedef Vec<uchar, 3> Vec3b;
+typedef Vec<float, 2> Vec2f;
 
 struct KeyPoint {   // 28 bytes, the layout of cv::KeyPoint
     Point2f pt;
@@ -61,65 +158,223 @@ struct KeyPoint {   // 28 bytes, the layout of cv::KeyPoint
     KeyPoint(Point2f p, float s, float a = -1, float r = 0, int o = 0, int c = -1) : pt(p), size(s), angle(a), response(r), octave(o), class_id(c) {}
     KeyPoint(float x, float y, float s, float a = -1, float r = 0, int o = 0, int c = -1) : pt(x, y), size(s), angle(a), response(r), octave(o), class_id(c) {}
 };
+struct DMatch {
+    int queryIdx, trainIdx, imgIdx;
+    float distance;
+    DMatch() : queryIdx(-1), trainIdx(-1), imgIdx(-1), distance(FLT_MAX) {}
+    DMatch(int q, int t, float d) : queryIdx(q), trainIdx(t), imgIdx(-1), distance(d) {}
+    bool operator<(const DMatch& m) const { return distance < m.distance; }
+};
 
-struct MatZeros { int rows, cols, type; };
+inline size_t depth_size(int depth) { static const size_t s[8] = {1, 1, 2, 2, 4, 4, 8, 0}; return s[depth & 7]; }
+template <typename T> struct depth_of;
+template <> struct depth_of<uchar> { enum { value = CV_8U }; };
+template <> struct depth_of<schar> { enum { value = CV_8S }; };
+template <> struct depth_of<ushort> { enum { value = CV_16U }; };
+template <> struct depth_of<short> { enum { value = CV_16S }; };
+template <> struct depth_of<int> { enum { value = CV_32S }; };
+template <> struct depth_of<float> { enum { value = CV_32F }; };
+template <> struct depth_of<double> { enum { value = CV_64F }; };
 
-// single-channel 8-bit matrix header with shared ownership and row/column views
+// Mat::zeros / ones / eye / `scalar * Mat`: a fully evaluated expression (rows x cols doubles)
+struct MatExpr {
+    int rows = 0, cols = 0, type = 0;
+    std::vector<double> v;
+};
+
+class _InputArray;
+class _OutputArray;
+
+// matrix header with a run-time element type, shared ownership, row/column views
 class Mat {
 public:
-    int rows = 0, cols = 0;
+    int flags = 0, rows = 0, cols = 0;
     uchar* data = nullptr;
     size_t step = 0;
     Mat() = default;
-    Mat(int r, int c, int /*type*/) { create(r, c, 0); }
-    Mat(int r, int c, int /*type*/, const Scalar& s) { create(r, c, 0); std::memset(data, (int)s.val[0], (size_t)r * c); }
-    Mat(int r, int c, int /*type*/, void* ext, size_t st = 0) : rows(r), cols(c), data((uchar*)ext), step(st ? st : (size_t)c) {}
-    void create(int r, int c, int /*type*/) {
-        if (data && r == rows && c == cols) return;
-        buf_ = std::make_shared<std::vector<uchar>>((size_t)r * c);
-        rows = r; cols = c; step = (size_t)c; data = buf_->data();
-    }
-    void release() { buf_.reset(); rows = cols = 0; data = nullptr; step = 0; }
+    Mat(int r, int c, int type) { create(r, c, type); }
+    Mat(Size s, int type) { create(s.height, s.width, type); }
+    Mat(int r, int c, int type, const Scalar& s) { create(r, c, type); setTo(s); }
+    Mat(int r, int c, int type, void* ext, size_t st = 0) : flags(type), rows(r), cols(c), data((uchar*)ext), step(st ? st : (size_t)c * esz(type)) {}
+    Mat(const MatExpr& e) { *this = e; }
+    int type() const { return flags; }
+    int depth() const { return CV_MAT_DEPTH(flags); }
+    int channels() const { return CV_MAT_CN(flags); }
+    size_t elemSize() const { return esz(flags); }
+    size_t elemSize1() const { return depth_size(depth()); }
+    size_t step1() const { return step / elemSize1(); }
+    size_t total() const { return (size_t)rows * cols; }
+    Size size() const { return Size(cols, rows); }
     bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
-    int type() const { return CV_8UC1; }
-    size_t step1() const { return step; }
+    bool isContinuous() const { return step == (size_t)cols * elemSize() || rows <= 1; }
+    void create(int r, int c, int type) {
+        if (data && r == rows && c == cols && type == flags) return;
+        buf_ = std::make_shared<std::vector<uchar>>((size_t)r * c * esz(type) + 16);
+        flags = type; rows = r; cols = c; step = (size_t)c * esz(type); data = buf_->data();
+    }
+    void create(Size s, int type) { create(s.height, s.width, type); }
+    void release() { buf_.reset(); rows = cols = 0; data = nullptr; step = 0; }
     Mat clone() const {
         Mat m;
         if (empty()) return m;
-        m.create(rows, cols, 0);
-        for (int y = 0; y < rows; ++y) std::memcpy(m.data + (size_t)y * m.step, data + (size_t)y * step, cols);
+        m.create(rows, cols, flags);
+        for (int y = 0; y < rows; ++y) std::memcpy(m.data + (size_t)y * m.step, data + (size_t)y * step, (size_t)cols * elemSize());
         return m;
     }
+    Mat row(int y) const { return rowRange(y, y + 1); }
+    Mat col(int x) const { return colRange(x, x + 1); }
     Mat rowRange(int a, int b) const { Mat m = *this; m.data = data + (size_t)a * step; m.rows = b - a; return m; }
-    Mat colRange(int a, int b) const { Mat m = *this; m.data = data + a; m.cols = b - a; return m; }
-    template <typename T> T& at(int y, int x) { return *reinterpret_cast<T*>(data + (size_t)y * step + x * sizeof(T)); }
-    template <typename T> const T& at(int y, int x) const { return *reinterpret_cast<const T*>(data + (size_t)y * step + x * sizeof(T)); }
+    Mat colRange(int a, int b) const { Mat m = *this; m.data = data + (size_t)a * elemSize(); m.cols = b - a; return m; }
+    Mat operator()(const Rect& r) const { return rowRange(r.y, r.y + r.height).colRange(r.x, r.x + r.width); }
+    template <typename T> T& at(int y, int x) { return *reinterpret_cast<T*>(data + (size_t)y * step + (size_t)x * sizeof(T)); }
+    template <typename T> const T& at(int y, int x) const { return *reinterpret_cast<const T*>(data + (size_t)y * step + (size_t)x * sizeof(T)); }
+    template <typename T> T& at(int i) { return rows == 1 ? at<T>(0, i) : at<T>(i, 0); }
+    template <typename T> const T& at(int i) const { return rows == 1 ? at<T>(0, i) : at<T>(i, 0); }
+    template <typename T> T& at(Point p) { return at<T>(p.y, p.x); }
     uchar* ptr(int y = 0) { return data + (size_t)y * step; }
     const uchar* ptr(int y = 0) const { return data + (size_t)y * step; }
+    template <typename T> T* ptr(int y = 0) { return reinterpret_cast<T*>(data + (size_t)y * step); }
+    template <typename T> const T* ptr(int y = 0) const { return reinterpret_cast<const T*>(data + (size_t)y * step); }
     template <typename T> T* ptr(unsigned y) { return ptr<T>((int)y); }
     template <typename T> const T* ptr(unsigned y) const { return ptr<T>((int)y); }
     template <typename T> T* ptr(size_t y) { return ptr<T>((int)y); }
-    template <typename T> T* ptr(int y = 0) { return reinterpret_cast<T*>(data + (size_t)y * step); }
-    template <typename T> const T* ptr(int y = 0) const { return reinterpret_cast<const T*>(data + (size_t)y * step); }
-    void copyTo(const class _OutputArray& dst) const;
-    static MatZeros zeros(int r, int c, int type) { return MatZeros{r, c, type}; }
-    // Mat = Mat::zeros(...) evaluates the expression INTO an existing matrix of the same size (cv::MatExpr semantics): a
-    // row-range view keeps pointing into its parent
-    Mat& operator=(const MatZeros& z) {
-        if (!(data && rows == z.rows && cols == z.cols)) create(z.rows, z.cols, 0);
-        for (int y = 0; y < rows; ++y) std::memset(data + (size_t)y * step, 0, cols);
+    template <typename T> const T* ptr(size_t y) const { return ptr<T>((int)y); }
+    double get(int y, int x) const {
+        const uchar* p = data + (size_t)y * step + (size_t)x * elemSize();
+        switch (depth()) {
+            case CV_8U: return *p;
+            case CV_8S: return *(const schar*)p;
+            case CV_16U: return *(const ushort*)p;
+            case CV_16S: return *(const short*)p;
+            case CV_32S: return *(const int*)p;
+            case CV_32F: return *(const float*)p;
+            default: return *(const double*)p;
+        }
+    }
+    void put(int y, int x, double v) {
+        uchar* p = data + (size_t)y * step + (size_t)x * elemSize();
+        switch (depth()) {
+            case CV_8U: *p = saturate_cast<uchar>(v); break;
+            case CV_8S: *(schar*)p = saturate_cast<schar>(v); break;
+            case CV_16U: *(ushort*)p = saturate_cast<ushort>(v); break;
+            case CV_16S: *(short*)p = saturate_cast<short>(v); break;
+            case CV_32S: *(int*)p = saturate_cast<int>(v); break;
+            case CV_32F: *(float*)p = (float)v; break;
+            default: *(double*)p = v; break;
+        }
+    }
+    Mat& setTo(const Scalar& s) {
+        for (int y = 0; y < rows; ++y) for (int x = 0; x < cols * channels(); ++x) put1(y, x, s.val[x % channels()]);
         return *this;
     }
-    Mat(const MatZeros& z) { create(z.rows, z.cols, 0); std::memset(data, 0, (size_t)rows * cols); }
+    void copyTo(Mat& dst) const {
+        if (empty()) { dst.release(); return; }
+        Mat out = (dst.data == data) ? Mat() : dst;
+        out.create(rows, cols, flags);
+        for (int y = 0; y < rows; ++y) std::memcpy(out.data + (size_t)y * out.step, data + (size_t)y * step, (size_t)cols * elemSize());
+        dst = out;
+    }
+    void copyTo(const _OutputArray& dst) const;
+    // dst may be *this (match/stereo.cc:257): evaluated into a temporary first
+    void convertTo(Mat& dst, int rtype, double alpha = 1, double beta = 0) const {
+        Mat out(rows, cols, CV_MAKETYPE(CV_MAT_DEPTH(rtype), channels()));
+        const bool plain = alpha == 1 && beta == 0;
+        for (int y = 0; y < rows; ++y)
+            for (int x = 0; x < cols * channels(); ++x) out.put1(y, x, plain ? get1(y, x) : get1(y, x) * alpha + beta);
+        dst = out;
+    }
+    // vertical concatenation (BinaryDescriptorMatcher::add, line_extractor.cc:139)
+    void push_back(const Mat& m) {
+        if (m.empty()) return;
+        if (empty()) { *this = m.clone(); return; }
+        assert(m.cols == cols && m.type() == type());
+        Mat out(rows + m.rows, cols, flags);
+        for (int y = 0; y < rows; ++y) std::memcpy(out.ptr(y), ptr(y), (size_t)cols * elemSize());
+        for (int y = 0; y < m.rows; ++y) std::memcpy(out.ptr(rows + y), m.ptr(y), (size_t)cols * elemSize());
+        *this = out;
+    }
+    static MatExpr zeros(int r, int c, int type) { return MatExpr{r, c, type, std::vector<double>((size_t)r * c, 0.0)}; }
+    static MatExpr ones(int r, int c, int type) { return MatExpr{r, c, type, std::vector<double>((size_t)r * c, 1.0)}; }
+    static MatExpr eye(int r, int c, int type) {
+        MatExpr e{r, c, type, std::vector<double>((size_t)r * c, 0.0)};
+        for (int i = 0; i < std::min(r, c); ++i) e.v[(size_t)i * c + i] = 1.0;
+        return e;
+    }
+    // Mat = <expression> evaluates INTO an existing matrix of the same size and type (cv::MatExpr semantics): a row-range
+    // view keeps pointing into its parent (orb_extractor.cc:151-152)
+    Mat& operator=(const MatExpr& e) {
+        if (!(data && rows == e.rows && cols == e.cols && flags == e.type)) create(e.rows, e.cols, e.type);
+        for (int y = 0; y < rows; ++y) for (int x = 0; x < cols; ++x) put(y, x, e.v[(size_t)y * cols + x]);
+        return *this;
+    }
+    Mat& operator-=(const MatExpr& e) {   // element-wise, in the matrix's own type (CV_32F in match/stereo.cc:258,267)
+        assert(e.rows == rows && e.cols == cols);
+        for (int y = 0; y < rows; ++y)
+            for (int x = 0; x < cols; ++x) {
+                if (depth() == CV_32F) at<float>(y, x) = at<float>(y, x) - (float)e.v[(size_t)y * cols + x];
+                else put(y, x, get(y, x) - e.v[(size_t)y * cols + x]);
+            }
+        return *this;
+    }
 
-private:
+    double get1(int y, int xc) const {   // channel-interleaved element access
+        const uchar* p = data + (size_t)y * step + (size_t)xc * elemSize1();
+        switch (depth()) {
+            case CV_8U: return *p;
+            case CV_8S: return *(const schar*)p;
+            case CV_16U: return *(const ushort*)p;
+            case CV_16S: return *(const short*)p;
+            case CV_32S: return *(const int*)p;
+            case CV_32F: return *(const float*)p;
+            default: return *(const double*)p;
+        }
+    }
+    void put1(int y, int xc, double v) {
+        uchar* p = data + (size_t)y * step + (size_t)xc * elemSize1();
+        switch (depth()) {
+            case CV_8U: *p = saturate_cast<uchar>(v); break;
+            case CV_8S: *(schar*)p = saturate_cast<schar>(v); break;
+            case CV_16U: *(ushort*)p = saturate_cast<ushort>(v); break;
+            case CV_16S: *(short*)p = saturate_cast<short>(v); break;
+            case CV_32S: *(int*)p = saturate_cast<int>(v); break;
+            case CV_32F: *(float*)p = (float)v; break;
+            default: *(double*)p = v; break;
+        }
+    }
+
+protected:
+    static size_t esz(int type) { return depth_size(CV_MAT_DEPTH(type)) * CV_MAT_CN(type); }
     std::shared_ptr<std::vector<uchar>> buf_;
 };
+// `float * Mat::ones(...)` (match/stereo.cc:258): products in float, as OpenCV scales a CV_32F expression
+inline MatExpr operator*(double s, const MatExpr& e) {
+    MatExpr r = e;
+    for (auto& x : r.v) x = (e.type == CV_32F) ? (double)((float)s * (float)x) : s * x;
+    return r;
+}
+inline MatExpr operator*(const MatExpr& e, double s) { return s * e; }
+
+template <typename T> class Mat_ : public Mat {
+public:
+    Mat_() = default;
+    Mat_(int r, int c) : Mat(r, c, depth_of<T>::value) {}
+    Mat_(const Mat& m) : Mat(m) {}
+    // (dead EDLines code assigns Mat_<int> to Mat_<float> members)
+    template <typename U> Mat_(const Mat_<U>& m) { m.convertTo(*this, depth_of<T>::value); }
+    T* operator[](int y) { return ptr<T>(y); }
+    const T* operator[](int y) const { return ptr<T>(y); }
+    T& operator()(int y, int x) { return at<T>(y, x); }
+    Mat_ t() const { shim_dead("Mat_::t (EDLines line fit)"); }
+};
+template <typename T> inline Mat_<T> operator*(const Mat_<T>&, const Mat_<T>&) { shim_dead("Mat_ product (EDLines line fit)"); }
+template <typename T> inline Mat_<T> operator+(const Mat_<T>&, const Mat_<T>&) { shim_dead("Mat_ sum (EDLines line fit)"); }
+template <typename T> inline Mat_<T> operator-(const Mat_<T>&, const Mat_<T>&) { shim_dead("Mat_ difference (EDLines line fit)"); }
 
 class _InputArray {
 public:
     _InputArray() : m_(nullptr) {}
     _InputArray(const Mat& m) : m_(const_cast<Mat*>(&m)) {}
+    template <typename T> _InputArray(const std::vector<T>&) : m_(nullptr) {}
     bool empty() const { return !m_ || m_->empty(); }
     Mat getMat() const { return m_ ? *m_ : Mat(); }
 protected:
@@ -127,34 +382,81 @@ protected:
 };
 class _OutputArray : public _InputArray {
 public:
+    _OutputArray() {}
     _OutputArray(Mat& m) { m_ = &m; }
+    _OutputArray(std::vector<Vec4f>& v) : lines_(&v) {}
     void create(int r, int c, int type) const { m_->create(r, c, type); }
     void release() const { m_->release(); }
+    Mat& getMatRef() const { return *m_; }
+    std::vector<Vec4f>* lines() const { return lines_; }
+protected:
+    std::vector<Vec4f>* lines_ = nullptr;
 };
-inline void Mat::copyTo(const _OutputArray& dst) const {
-    dst.create(rows, cols, 0);
-    Mat d = dst.getMat();
-    for (int y = 0; y < rows; ++y) std::memcpy(d.data + (size_t)y * d.step, data + (size_t)y * step, cols);
-}
+inline void Mat::copyTo(const _OutputArray& dst) const { copyTo(dst.getMatRef()); }
 typedef const _InputArray& InputArray;
 typedef const _OutputArray& OutputArray;
+typedef const _OutputArray& InputOutputArray;
+inline InputArray noArray() { static const _InputArray none; return none; }
 
-enum { INTER_LINEAR = 1 };
-enum { BORDER_REFLECT_101 = 4, BORDER_DEFAULT = 4 };
+template <typename T> struct Ptr : std::shared_ptr<T> {
+    Ptr() = default;
+    Ptr(T* p) : std::shared_ptr<T>(p) {}
+    template <typename U> Ptr(const std::shared_ptr<U>& o) : std::shared_ptr<T>(o) {}
+    operator T*() const { return this->get(); }
+};
+template <typename T, typename... A> inline Ptr<T> makePtr(A&&... a) { return Ptr<T>(new T(std::forward<A>(a)...)); }
+
+class FileNode {
+public:
+    FileNode operator[](const char*) const { return FileNode(); }
+    FileNode operator[](const std::string&) const { return FileNode(); }
+    operator int() const { return 0; }
+    operator float() const { return 0.f; }
+    operator double() const { return 0.0; }
+    bool empty() const { return true; }
+};
+class FileStorage {
+public:
+    template <typename T> FileStorage& operator<<(const T&) { return *this; }
+};
+class Algorithm {
+public:
+    virtual ~Algorithm() {}
+    virtual void clear() {}
+    virtual void write(FileStorage&) const {}
+    virtual void read(const FileNode&) {}
+    virtual bool empty() const { return false; }
+};
+
+enum { INTER_NEAREST = 0, INTER_LINEAR = 1, INTER_CUBIC = 2, INTER_AREA = 3, INTER_LINEAR_EXACT = 5 };
+enum { BORDER_CONSTANT = 0, BORDER_REPLICATE = 1, BORDER_REFLECT_101 = 4, BORDER_DEFAULT = 4 };
 enum { LINE_AA = 16 };
+enum { NORM_L1 = 2, NORM_L2 = 4, NORM_HAMMING = 6 };
+enum { THRESH_TOZERO = 3 };
+enum { CMP_LT = 3 };
+enum { COLOR_BGR2GRAY = 6, COLOR_RGB2GRAY = 7, COLOR_BGRA2GRAY = 10, COLOR_RGBA2GRAY = 11 };
+enum { LSD_REFINE_NONE = 0, LSD_REFINE_STD = 1, LSD_REFINE_ADV = 2 };
 
 inline oracle::Image to_image(const Mat& m) {
+    if (m.type() != CV_8UC1) throw std::runtime_error("ref_shim: 8-bit single-channel image expected");
     oracle::Image im(m.rows, m.cols);
     for (int y = 0; y < m.rows; ++y) std::memcpy(im.row(y), m.data + (size_t)y * m.step, m.cols);
     return im;
 }
 inline void from_image(const oracle::Image& im, Mat& m) {
-    m.create(im.rows, im.cols, 0);
+    m.create(im.rows, im.cols, CV_8UC1);
     for (int y = 0; y < im.rows; ++y) std::memcpy(m.data + (size_t)y * m.step, im.row(y), im.cols);
 }
+// writes `out` into dst: in place when dst already has that size and type (a caller may hold views of it), else rebinds
+inline void assign_result(Mat& dst, const Mat& out) {
+    if (dst.data && dst.rows == out.rows && dst.cols == out.cols && dst.type() == out.type())
+        for (int y = 0; y < out.rows; ++y) std::memcpy(dst.data + (size_t)y * dst.step, out.data + (size_t)y * out.step, (size_t)out.cols * out.elemSize());
+    else dst = out;
+}
 
-// ---- the four OpenCV primitives on the path: forwarded to the restatement (cv_restated.hpp)
-inline void resize(const Mat& src, Mat& dst, Size dsize, double, double, int) {
+// ---- the OpenCV primitives on the live path: forwarded to the restatements
+inline void resize(const Mat& src, Mat& dst, Size dsize, double fx = 0, double fy = 0, int interpolation = INTER_LINEAR) {
+    if (interpolation != INTER_LINEAR || dsize.width <= 0) shim_dead("cv::resize other than INTER_LINEAR to an explicit size");
     Mat out;   // src and dst may be the same object
     from_image(oracle::resize_linear_u8(to_image(src), dsize.width, dsize.height), out);
     dst = out;
@@ -166,14 +468,22 @@ inline void FAST(const Mat& roi, std::vector<KeyPoint>& kps, int threshold, bool
     kps.clear();
     for (const auto& p : pts) kps.emplace_back((float)p.x, (float)p.y, 7.f, -1.f, (float)p.score);
 }
-inline void GaussianBlur(const Mat& src, Mat& dst, Size k, double sx, double, int) {
+inline void GaussianBlur(const Mat& src, Mat& dst, Size k, double sx, double = 0, int = BORDER_DEFAULT) {
     Mat out;
     from_image(oracle::gaussian_blur_u8(to_image(src), k.width, sx), out);
-    if (dst.data && dst.rows == out.rows && dst.cols == out.cols)
-        for (int y = 0; y < out.rows; ++y) std::memcpy(dst.data + (size_t)y * dst.step, out.data + (size_t)y * out.step, out.cols);
-    else dst = out;
+    assign_result(dst, out);
 }
 inline float fastAtan2(float y, float x) { return oracle::fast_atan2f_deg(y, x); }
+// cv::Sobel(u8 -> CV_16S, dx, dy, ksize 3), BORDER_REFLECT_101 (binary_descriptor_custom.cpp:392-393)
+inline void Sobel(const Mat& src, Mat& dst, int ddepth, int dx, int dy, int ksize = 3) {
+    if (CV_MAT_DEPTH(ddepth) != CV_16S || ksize != 3 || dx + dy != 1) shim_dead("cv::Sobel other than 3x3 first derivative to CV_16S");
+    std::vector<int16_t> gx, gy;
+    oracle::sobel3_s16(to_image(src), gx, gy);
+    Mat out(src.rows, src.cols, CV_16SC1);
+    const std::vector<int16_t>& g = dx ? gx : gy;
+    for (int y = 0; y < src.rows; ++y) std::memcpy(out.ptr(y), g.data() + (size_t)y * src.cols, (size_t)src.cols * 2);
+    assign_result(dst, out);
+}
 // filled axis-aligned rectangle, both corners inclusive (thickness -1; LINE_AA does not soften a filled rectangle)
 inline void rectangle(Mat& img, Point2i a, Point2i b, const Scalar& color, int thickness, int) {
     assert(thickness < 0);
@@ -182,5 +492,66 @@ inline void rectangle(Mat& img, Point2i a, Point2i b, const Scalar& color, int t
     for (int y = y0; y <= y1; ++y)
         for (int x = x0; x <= x1; ++x) img.at<uchar>(y, x) = (uchar)color.val[0];
 }
+// cv::norm(a, b, NORM_L1) on CV_32F: sum of |a - b| accumulated in f64
+inline double norm(const Mat& a, const Mat& b, int normType) {
+    if (normType != NORM_L1) shim_dead("cv::norm other than NORM_L1");
+    double s = 0;
+    for (int y = 0; y < a.rows; ++y)
+        for (int x = 0; x < a.cols; ++x) s += std::fabs(a.depth() == CV_32F ? (double)(a.at<float>(y, x) - b.at<float>(y, x)) : a.get(y, x) - b.get(y, x));
+    return s;
+}
+// cv::convertMaps(map1, map2, dst1, dst2, CV_32FC1, false) with CV_32FC1 inputs: copies
+inline void convertMaps(const Mat& map1, const Mat& map2, Mat& dst1, Mat& dst2, int dstmap1type, bool = false) {
+    if (dstmap1type != CV_32FC1 || map1.type() != CV_32FC1) shim_dead("cv::convertMaps other than CV_32FC1 -> CV_32FC1");
+    dst1 = map1.clone(); dst2 = map2.clone();
+}
+// cv::remap(u8, CV_32FC1 maps, INTER_LINEAR, BORDER_CONSTANT 0) = oracle::remap_linear_u8 (cv_restated.hpp; App. C.6)
+inline void remap(const Mat& src, Mat& dst, const Mat& map1, const Mat& map2, int interpolation, int = BORDER_CONSTANT, const Scalar& = Scalar()) {
+    if (interpolation != INTER_LINEAR || src.type() != CV_8UC1 || map1.type() != CV_32FC1 || !map1.isContinuous() || !map2.isContinuous())
+        shim_dead("cv::remap other than u8 / dense CV_32FC1 maps / INTER_LINEAR");
+    Mat out(map1.rows, map1.cols, CV_8UC1);
+    oracle::remap_linear_u8(src.data, src.rows, src.cols, src.step, map1.ptr<float>(0), map2.ptr<float>(0), map1.rows, map1.cols, out.data);
+    dst = out;
+}
+// cv::LineIterator(img, p1, p2).count: 8-connected (App. C.8); the reference's end points lie inside the image already
+class LineIterator {
+public:
+    int count;
+    LineIterator(const Mat&, Point p1, Point p2, int = 8, bool = false) { count = std::max(std::abs(p2.x - p1.x), std::abs(p2.y - p1.y)) + 1; }
+};
+// cv::LineSegmentDetector = the LSD restatement (oracle/lsd_restated.hpp), definition D1 (stable seed order) as everywhere else
+class LineSegmentDetector : public Algorithm {
+public:
+    explicit LineSegmentDetector(const oracle::LsdOptions& o) : o_(o) {}
+    void detect(const Mat& image, std::vector<Vec4f>& lines) {
+        oracle::Lsd lsd(o_, true);
+        const auto segs = lsd.detect(to_image(image));
+        lines.clear();
+        for (const auto& s : segs) lines.emplace_back(s[0], s[1], s[2], s[3]);
+    }
+private:
+    oracle::LsdOptions o_;
+};
+inline Ptr<LineSegmentDetector> createLineSegmentDetector(int refine = LSD_REFINE_STD, double scale = 0.8, double sigma_scale = 0.6, double quant = 2.0,
+                                                          double ang_th = 22.5, double log_eps = 0, double density_th = 0.7, int n_bins = 1024) {
+    oracle::LsdOptions o;
+    o.refine = refine; o.scale = scale; o.sigma_scale = sigma_scale; o.quant = quant; o.ang_th = ang_th; o.log_eps = log_eps; o.density_th = density_th;
+    o.n_bins = n_bins;
+    return Ptr<LineSegmentDetector>(new LineSegmentDetector(o));
+}
+
+// ---- calls made only by dead code of the reference
+inline void pyrDown(const Mat&, Mat&, Size = Size()) { shim_dead("cv::pyrDown"); }
+inline void cvtColor(const Mat&, Mat&, int) { shim_dead("cv::cvtColor"); }
+inline Mat abs(const Mat&) { shim_dead("cv::abs(Mat)"); }
+inline Mat operator/(const Mat&, double) { shim_dead("Mat / scalar"); }
+inline void add(const Mat&, const Mat&, Mat&) { shim_dead("cv::add"); }
+inline double threshold(const Mat&, Mat&, double, double, int) { shim_dead("cv::threshold"); }
+inline void compare(const Mat&, const Mat&, Mat&, int) { shim_dead("cv::compare"); }
+class CLAHE : public Algorithm { public: void apply(const Mat&, Mat&) { shim_dead("cv::CLAHE"); } };
+inline Ptr<CLAHE> createCLAHE(double = 40.0, Size = Size(8, 8)) { shim_dead("cv::createCLAHE"); }
+inline void line(Mat&, Point, Point, const Scalar&, int = 1, int = 8, int = 0) { shim_dead("cv::line"); }
+inline int64_t getTickCount() { return 0; }
+inline double getTickFrequency() { return 1.0; }
 
 }  // namespace cv

@@ -20,7 +20,54 @@ def build():
     subprocess.run(["make", "-s", "-C", str(ORACLE_DIR)], check=True)
 
 
+_backend = None          # set by reference(): the oracle_* names resolve to the ref_* entry points of oracle/_ref/libplpref2.so
+_ref2 = None
+
+
+def ref2_path():
+    return ORACLE_DIR / "_ref" / "libplpref2.so"
+
+
+class _RefProxy:
+    """Resolves oracle_NAME to ref_NAME in libplpref2.so (the reference's own matcher / line sources compiled unmodified,
+    oracle/ref_driver2.cpp) with the argtypes / restype of the oracle's entry point: every wrapper below then runs the
+    REFERENCE on the same arrays."""
+
+    def __init__(self, ref, orc):
+        self._ref, self._orc = ref, orc
+
+    def __getattr__(self, name):
+        if not name.startswith("oracle_"):
+            raise AttributeError(name)
+        fn = getattr(self._ref, "ref_" + name[len("oracle_"):])
+        src = getattr(self._orc, name)
+        if src.argtypes is not None:
+            fn.argtypes = src.argtypes
+        fn.restype = src.restype
+        return fn
+
+
+class reference:
+    """context manager: inside it the matcher / line wrappers of this module call the reference build instead of the oracle"""
+
+    def __enter__(self):
+        global _backend, _ref2
+        if _ref2 is None:
+            _ref2 = C.CDLL(str(ref2_path()))
+        _backend = _RefProxy(_ref2, _load())
+        return _ref2
+
+    def __exit__(self, *exc):
+        global _backend
+        _backend = None
+        return False
+
+
 def lib():
+    return _backend if _backend is not None else _load()
+
+
+def _load():
     global _lib
     if _lib is None:
         so = ORACLE_DIR / "liboracle.so"
@@ -588,3 +635,101 @@ def fisheye_rectify_map(K, D4, R, cam, rows, cols):
     if _call("oracle_fisheye_rectify_map", [K, D4, R, Kr, rows, cols, mx, my], C.c_int) != 0:
         raise ValueError("K_rect * R is singular")
     return mx, my
+
+
+# ---- reference build only (oracle/_ref/libplpref2.so, oracle/ref_driver2.cpp): entry points whose oracle counterpart has another shape
+def _ref2_lib():
+    with reference() as L:
+        return L
+
+
+def ref_line_extract(img, fx=520.0, fy=521.0, cx=None, cy=None, cap=4096):
+    """feature::LineFeatureTracker(camera).extract_LSD_LBD of the reference build: (key lines, LBD, line functions)"""
+    img = np.ascontiguousarray(img, np.uint8)
+    L = _ref2_lib()
+    kl = np.zeros(cap, KL_DTYPE); lbd = np.zeros((cap, 32), np.uint8); fn = np.zeros((cap, 3), np.float64)
+    L.ref_line_extract.restype = C.c_int
+    L.ref_line_extract.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_double] * 4 + [C.c_void_p] * 3 + [C.c_int]
+    n = L.ref_line_extract(_p(img), img.shape[0], img.shape[1], fx, fy, img.shape[1] / 2 if cx is None else cx, img.shape[0] / 2 if cy is None else cy,
+                           _p(kl), _p(lbd), _p(fn), cap)
+    assert n >= 0
+    return kl[:n].copy(), lbd[:n].copy(), fn[:n].copy()
+
+
+def ref_lsd_keylines(img, cap=8192):
+    """LSDDetectorC::detect as line_extractor.cc calls it: every key line, before the length-60 filter"""
+    img = np.ascontiguousarray(img, np.uint8)
+    L = _ref2_lib()
+    kl = np.zeros(cap, KL_DTYPE)
+    L.ref_lsd_keylines.restype = C.c_int
+    L.ref_lsd_keylines.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    n = L.ref_lsd_keylines(_p(img), img.shape[0], img.shape[1], _p(kl), cap)
+    assert n >= 0
+    return kl[:n].copy()
+
+
+def ref_lbd(img, keylines):
+    """BinaryDescriptor::compute of the reference build on given key lines: (binary 32 B, float 72)"""
+    img = np.ascontiguousarray(img, np.uint8); kl = _c(keylines, KL_DTYPE)
+    L = _ref2_lib()
+    out = np.zeros((len(kl), 32), np.uint8); o72 = np.zeros((len(kl), 72), np.float32)
+    L.ref_lbd.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    if len(kl):
+        L.ref_lbd(_p(img), img.shape[0], img.shape[1], _p(kl), len(kl), _p(out), _p(o72))
+    return out, o72
+
+
+def lbd(img, keylines):
+    """the oracle's LBD on given key lines"""
+    img = np.ascontiguousarray(img, np.uint8); kl = _c(keylines, KL_DTYPE)
+    out = np.zeros((len(kl), 32), np.uint8); o72 = np.zeros((len(kl), 72), np.float32)
+    if len(kl):
+        _load().oracle_lbd(_p(img), img.shape[0], img.shape[1], _p(kl), len(kl), _p(out), _p(o72))
+    return out, o72
+
+
+def ref_stereo_compute(levels_left, levels_right, kl, kr, dl, dr, scale_factors, inv_scale_factors, fxb, tb):
+    """match::stereo(...).compute of the reference build; levels_*: lists of the pyramid level images"""
+    L = _ref2_lib()
+    nl = len(levels_left)
+    ll = [np.ascontiguousarray(a, np.uint8) for a in levels_left]; lr = [np.ascontiguousarray(a, np.uint8) for a in levels_right]
+    pl = (C.c_void_p * nl)(*[a.ctypes.data for a in ll]); pr = (C.c_void_p * nl)(*[a.ctypes.data for a in lr])
+    rows = np.array([a.shape[0] for a in ll], np.int32); cols = np.array([a.shape[1] for a in ll], np.int32)
+    kl = _c(kl, KP_DTYPE); kr = _c(kr, KP_DTYPE); dl = _c(dl, np.uint8); dr = _c(dr, np.uint8)
+    sf = _c(scale_factors, np.float32); isf = _c(inv_scale_factors, np.float32)
+    xr = np.zeros(max(len(kl), 1), np.float32); dp = np.zeros(max(len(kl), 1), np.float32)
+    L.ref_stereo_compute.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    L.ref_stereo_compute(pl, pr, _p(rows), _p(cols), nl, _p(kl), len(kl), _p(kr), len(kr), _p(dl), _p(dr), _p(sf), _p(isf), fxb, tb, _p(xr), _p(dp))
+    return xr[:len(kl)].copy(), dp[:len(kl)].copy()
+
+
+def ref_match_keyframes_mutually(g6, kps1, desc1, kps2, desc2, sf, lm1_valid, reproj_1in2, pred_1in2, lm2_valid, reproj_2in1, pred_2in1, margin):
+    """projection::match_keyframes_mutually of the reference build, complete (both passes + cross check)"""
+    L = _ref2_lib()
+    n1, n2 = len(kps1), len(kps2)
+    out = np.zeros(max(n1, 1), np.int32)
+    a = [_c(g6, np.float64), _c(kps1, KP_DTYPE), _c(desc1, np.uint8)]
+    b = [_c(kps2, KP_DTYPE), _c(desc2, np.uint8)]
+    sf = _c(sf, np.float32)
+    c = [_c(lm1_valid, np.uint8), _c(reproj_1in2, np.float64), _c(pred_1in2, np.uint32), _c(lm2_valid, np.uint8), _c(reproj_2in1, np.float64), _c(pred_2in1, np.uint32)]
+    L.ref_match_keyframes_mutually.restype = C.c_uint
+    L.ref_match_keyframes_mutually.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 2 + [C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_float, C.c_void_p]
+    num = L.ref_match_keyframes_mutually(_p(a[0]), _p(a[1]), _p(a[2]), n1, _p(b[0]), _p(b[1]), n2, _p(sf), len(sf), *[_p(v) for v in c], margin, _p(out))
+    return out[:n1].copy(), num
+
+
+def ref_robust_match_frame_and_keyframe(desc1, angle1, desc2, angle2, valid2, lowe_ratio, check_orientation):
+    """robust::match_frame_and_keyframe of the reference build with an all-inlier essential solver (= its brute_force_match)"""
+    L = _ref2_lib()
+    n1, n2 = len(desc1), len(desc2)
+    out = np.zeros(max(n1, 1), np.int32)
+    v = [_c(desc1, np.uint8), _c(angle1, np.float32), _c(desc2, np.uint8), _c(angle2, np.float32), _c(valid2, np.uint8)]
+    L.ref_robust_match_frame_and_keyframe.restype = C.c_uint
+    L.ref_robust_match_frame_and_keyframe.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p]
+    num = L.ref_robust_match_frame_and_keyframe(_p(v[0]), _p(v[1]), n1, _p(v[2]), _p(v[3]), _p(v[4]), n2, lowe_ratio, int(check_orientation), _p(out))
+    return out[:n1].copy(), num
+
+
+def angle_checker_last_tie():
+    """1 if the oracle's last orientation check met equally full bins at the cut (definition D3: the reference's unstable std::sort decides)"""
+    return int(_load().oracle_angle_checker_last_tie())
