@@ -171,3 +171,39 @@ def matcher_cases(rng, scale=1.0):
             arr[np.arange(k), rng.integers(0, 32, k)] ^= (np.uint8(1) << rng.integers(0, 8, k).astype(np.uint8)) * (rng.uniform(size=k) < 0.5).astype(np.uint8)
     out.append(("lbd_1nn", "lbd_match_1nn", (tq, tt)))
     return out
+
+
+def load_golden_match(path=None):
+    """tests/golden/ref_match.npz (tools/make_golden_ref.py): [(seed, label, wrapper name, args tuple, reference outputs tuple, extras)]"""
+    import pathlib
+    path = path or pathlib.Path(__file__).resolve().parent / "golden" / "ref_match.npz"
+    z = np.load(path)
+    blobs = {}
+    for k in z.files:
+        if k.startswith("blob"):
+            idx = int(k[4:].split("__")[0])
+            a = z[k]
+            if "__rec" in k:
+                a = np.ascontiguousarray(a).view(O.KP_DTYPE if a.shape[1] == 28 else O.KL_DTYPE).reshape(-1)
+            blobs[idx] = a
+    cases = []
+    for k in z.files:
+        if not k.endswith("__fn"):
+            continue
+        base = k[:-4]
+        seed, label = base.split("__")
+        spec = z[base + "__args"]
+        args = []
+        for i, b in enumerate(spec):
+            if b >= 0:
+                args.append(blobs[int(b)])
+            else:
+                v = z[f"{base}__arg{i}"]
+                args.append(bool(v) if v.dtype == np.bool_ else (float(v) if v.dtype.kind == "f" else int(v)))
+        outs = []
+        while f"{base}__out{len(outs)}" in z.files:
+            o = z[f"{base}__out{len(outs)}"]
+            outs.append(o if o.ndim else int(o))
+        extras = {"defined": z[base + "__defined"]} if base + "__defined" in z.files else {}
+        cases.append((int(seed[1:]), label, str(z[k]), tuple(args), tuple(outs), extras))
+    return sorted(cases, key=lambda c: (c[0], c[1]))
