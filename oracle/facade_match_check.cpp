@@ -23,9 +23,12 @@
 #include "PLPSLAM/match/area.h"
 #include "PLPSLAM/match/bow_tree.h"
 #include "PLPSLAM/match/fuse.h"
+#define PLP_FACADE_NO_SOLVER_INCLUDE      // the reference's solve::essential_solver needs Eigen; a stand-in that drops every third match is defined below
 #include "PLPSLAM/match/robust.h"
 #include "PLPSLAM/match/projection.h"
 
+extern "C" unsigned oracle_brute_force_match(const uint8_t* desc1, const float* angle1, int n1, const uint8_t* desc2, const float* angle2, const uint8_t* valid2, int n2,
+                                             float lowe_ratio, int check_orientation, int* match_2_in_1);
 extern "C" {
 struct OKeyPoint { float x, y, size, angle, response; int octave, class_id; };
 unsigned oracle_match_frame_and_landmarks(const double* grid6, const OKeyPoint* kps, const uint8_t* desc, const float* x_right,
@@ -183,6 +186,7 @@ struct frame {
     std::vector<bool> outlier_flags_;
     Mat44_t cam_pose_cw_;
     std::map<unsigned int, std::vector<unsigned int>> bow_feat_vec_;    // DBoW2::FeatureVector
+    std::vector<Vec3_t> bearings_;
 };
 struct keyframe {
     std::vector<cv::KeyPoint> keypts_;
@@ -219,6 +223,21 @@ struct keyframe {
     void add_landmark_line(Line* lm, unsigned int idx) { _landmarks_line.at(idx) = lm; }
 };
 }  // namespace data
+}  // namespace PLPSLAM
+
+namespace PLPSLAM {
+namespace solve {
+// stand-in for the reference's RANSAC (solve/essential_solver.h): same interface, keeps every match except each third one
+class essential_solver {
+public:
+    essential_solver(const std::vector<Vec3_t>&, const std::vector<Vec3_t>&, const std::vector<std::pair<int, int>>& matches_12) : n_(matches_12.size()) {}
+    void find_via_ransac(const unsigned int, const bool = true) {}
+    bool solution_is_valid() const { return true; }
+    std::vector<bool> get_inlier_matches() const { std::vector<bool> v(n_, true); for (size_t i = 2; i < n_; i += 3) v[i] = false; return v; }
+private:
+    size_t n_;
+};
+}  // namespace solve
 }  // namespace PLPSLAM
 
 using namespace PLPSLAM;
@@ -1042,6 +1061,52 @@ int main(int argc, char** argv) {
             const unsigned got_num = robust_matcher.match_for_triangulation(&kf1, &kf2, E_12, got_pairs);
             if (got_num != want_num || got_pairs != want_pairs) ++failures;
             std::printf("robust::match_for_triangulation[check_orientation %d]: %u matches (oracle %u)\n", check, got_num, want_num);
+        }
+        // ---------------- robust::brute_force_match and robust::match_frame_and_keyframe (robust.cc:218-385)
+        for (int check = 0; check < 2; ++check) {
+            data::frame frm;
+            fill_frame(frm, &cam, n);
+            data::frame src;
+            fill_frame(src, &cam, m);
+            data::keyframe kf;
+            kf.camera_ = &cam; kf.num_keypts_ = (unsigned)m; kf.keypts_ = src.keypts_; kf.undist_keypts_ = src.undist_keypts_; kf.descriptors_ = src.descriptors_;
+            kf.landmarks_.assign(m, nullptr); kf.bearings_.assign(m, Vec3_t(0, 0, 1)); frm.bearings_.assign(n, Vec3_t(0, 0, 1));
+            std::vector<std::unique_ptr<data::landmark>> pool;
+            for (int j = 0; j < m; ++j)
+                if (uni(0, 1) < 0.8) { pool.emplace_back(new data::landmark()); pool.back()->erased_ = uni(0, 1) < 0.05; kf.landmarks_[j] = pool.back().get(); }
+            for (int i = 0; i < n; i += 2) {        // half of the frame's key points resemble a key-frame key point
+                const int j = irand(0, m - 1);
+                std::copy(kf.descriptors_.ptr<uint8_t>(j), kf.descriptors_.ptr<uint8_t>(j) + 32, frm.descriptors_.ptr<uint8_t>(i));
+                frm.descriptors_.ptr<uint8_t>(i)[irand(0, 31)] ^= 2;
+                float ang = kf.keypts_[(size_t)j].angle + (float)uni(-5, 5);
+                if (ang < 0.f) ang += 360.f;
+                if (ang >= 360.f) ang -= 360.f;
+                frm.keypts_[(size_t)i].angle = ang;
+            }
+            std::vector<uint8_t> valid2(m);
+            std::vector<float> a1(n), a2(m);
+            for (int j = 0; j < m; ++j) { valid2[j] = kf.landmarks_[j] && !kf.landmarks_[j]->will_be_erased(); a2[j] = kf.keypts_[(size_t)j].angle; }
+            for (int i = 0; i < n; ++i) a1[i] = frm.keypts_[(size_t)i].angle;
+            std::vector<int> want(n);
+            const auto d1 = desc_of(frm);
+            std::vector<uint8_t> d2((size_t)m * 32);
+            for (int j = 0; j < m; ++j) std::copy(kf.descriptors_.ptr<uint8_t>(j), kf.descriptors_.ptr<uint8_t>(j) + 32, d2.begin() + (size_t)j * 32);
+            const unsigned want_num = oracle_brute_force_match(d1.data(), a1.data(), n, d2.data(), a2.data(), valid2.data(), m, 0.75f, check, want.data());
+            match::robust robust_matcher(0.75, check != 0);
+            std::vector<std::pair<int, int>> matches, want_pairs;
+            for (int i = 0; i < n; ++i) if (want[i] >= 0) want_pairs.emplace_back(i, want[i]);
+            const unsigned got_num = robust_matcher.brute_force_match(frm, &kf, matches);
+            if (got_num != want_num || matches != want_pairs) ++failures;
+            // match_frame_and_keyframe: the stand-in solver keeps matches 0, 1, 3, 4, 6, ... (drops every third)
+            std::vector<data::landmark*> matched;
+            const unsigned got_inliers = robust_matcher.match_frame_and_keyframe<data::frame, data::keyframe, solve::essential_solver>(frm, &kf, matched);
+            unsigned want_inliers = 0;
+            std::vector<data::landmark*> want_matched(n, nullptr);
+            for (size_t k = 0; k < want_pairs.size(); ++k)
+                if (k % 3 != 2) { want_matched[(size_t)want_pairs[k].first] = kf.landmarks_[(size_t)want_pairs[k].second]; ++want_inliers; }
+            if (got_inliers != want_inliers || matched != want_matched) ++failures;
+            std::printf("robust::brute_force_match[check_orientation %d]: %u matches (oracle %u); match_frame_and_keyframe: %u inliers (%u)\n", check, got_num, want_num,
+                        got_inliers, want_inliers);
         }
         // ---------------- fuse::replace_duplication_line
         {

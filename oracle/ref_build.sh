@@ -30,4 +30,9 @@ if [ -f "$PKG/libplp_front.so" ]; then
         "$HERE/facade_check.cpp" "$REF/src/PLPSLAM/feature/orb_params.cc" -L"$PKG" -lplp_front -Wl,-rpath,'$ORIGIN/../../structure-plp-slam_amd' \
         -Wl,--allow-shlib-undefined -o "$HERE/_ref/facade_orb_check"
     echo "ref_build: built $HERE/_ref/facade_orb_check"
+    # the reference's own line_descriptor header + the shipped replacement of binary_descriptor_matcher.cpp, at the reference's call sites
+    g++ -O2 -std=c++17 -w -I"$HERE/../include" -I"$HERE/ref_shadow" -I"$HERE/ref_shim" -I"$REF/src" \
+        "$HERE/facade_lbdmatch_check.cpp" "$PKG/facade/src/binary_descriptor_matcher_plp.cpp" -L"$HERE" -loracle -L"$PKG" -lplp_front \
+        -Wl,-rpath,'$ORIGIN/..:$ORIGIN/../../structure-plp-slam_amd' -Wl,--allow-shlib-undefined -o "$HERE/_ref/facade_lbdmatch_check"
+    echo "ref_build: built $HERE/_ref/facade_lbdmatch_check"
 fi

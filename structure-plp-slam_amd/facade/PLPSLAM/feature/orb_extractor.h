@@ -34,6 +34,7 @@ public:
                           rects.empty() ? nullptr : rects.data(), static_cast<int32_t>(p.mask_rects_.size())};
         check(plp_orb_create(&cp, device_from_env(), &ctx_));
         image_pyramid_.resize(p.num_levels_);
+        image_pyramid_.owner_ = this;
         plp_registry::add(&image_pyramid_, ctx_);       // match::stereo is handed image_pyramid_ and finds the context by it
     }
 
@@ -59,14 +60,11 @@ public:
         keypts.resize(n);
         if (n == 0) out_descriptors.release();
         else desc.rowRange(0, n).copyTo(out_descriptors);
-        // image_pyramid_ is public and read by match::stereo (data/frame.cc:277-281): keep a host copy
-        image_pyramid_.at(0) = image;
-        for (unsigned int l = 1; l < orb_params_.num_levels_; ++l) {
-            int32_t r = 0, c = 0;
-            check(plp_orb_pyramid_level_size(ctx_, static_cast<int32_t>(l), &r, &c));
-            image_pyramid_.at(l).create(r, c, CV_8UC1);
-            check(plp_orb_pyramid_host(ctx_, 0, static_cast<int32_t>(l), image_pyramid_.at(l).data, image_pyramid_.at(l).step));
-        }
+        // image_pyramid_ is public (orb_extractor.h:101); its only reader in the reference is match::stereo (data/frame.cc:277-281),
+        // whose facade reads the pyramids in HBM through plp_registry.  Levels 1.. are therefore fetched from the device only when
+        // host code actually looks at them (lazy_pyramid below): 0.64 MB of D2H per frame that mono / RGB-D tracking never needs.
+        image_pyramid_.raw(0) = image;
+        image_pyramid_.mark_stale();
     }
 
     unsigned int get_max_num_keypoints() const { return static_cast<unsigned int>(get(PLP_ORB_MAX_NUM_KEYPOINTS)); }
@@ -85,10 +83,43 @@ public:
     std::vector<float> get_level_sigma_sq() const { return table(2); }
     std::vector<float> get_inv_level_sigma_sq() const { return table(3); }
 
+    //! std::vector<cv::Mat> whose element accessors first bring levels 1.. over from the device, once per extracted frame.  A
+    //! reader that takes it as `const std::vector<cv::Mat>&` (the reference's match::stereo constructor) sees level 0 and stale
+    //! or empty upper levels -- that reader is replaced by facade/PLPSLAM/match/stereo.h, which never touches the host copy.
+    class lazy_pyramid : public std::vector<cv::Mat> {
+    public:
+        typedef std::vector<cv::Mat> base;
+        cv::Mat& at(size_t i) { fetch(); return base::at(i); }
+        const cv::Mat& at(size_t i) const { fetch(); return base::at(i); }
+        cv::Mat& operator[](size_t i) { fetch(); return base::operator[](i); }
+        const cv::Mat& operator[](size_t i) const { fetch(); return base::operator[](i); }
+        base::iterator begin() { fetch(); return base::begin(); }
+        base::const_iterator begin() const { fetch(); return base::begin(); }
+        cv::Mat& back() { fetch(); return base::back(); }
+        cv::Mat& raw(size_t i) { return base::at(i); }
+        void mark_stale() { stale_ = true; }
+        const orb_extractor* owner_ = nullptr;
+    private:
+        void fetch() const {
+            if (!stale_ || !owner_) return;
+            stale_ = false;
+            owner_->download_pyramid(*const_cast<lazy_pyramid*>(this));
+        }
+        mutable bool stale_ = false;
+    };
     //! Image pyramid (public in the reference, orb_extractor.h:101)
-    std::vector<cv::Mat> image_pyramid_;
+    lazy_pyramid image_pyramid_;
 
 private:
+    friend class lazy_pyramid;
+    void download_pyramid(lazy_pyramid& pyr) const {
+        for (unsigned int l = 1; l < orb_params_.num_levels_ && l < pyr.size(); ++l) {
+            int32_t r = 0, c = 0;
+            check(plp_orb_pyramid_level_size(ctx_, static_cast<int32_t>(l), &r, &c));
+            pyr.raw(l).create(r, c, CV_8UC1);
+            check(plp_orb_pyramid_host(ctx_, 0, static_cast<int32_t>(l), pyr.raw(l).data, pyr.raw(l).step));
+        }
+    }
     static int device_from_env() { const char* e = std::getenv("PLP_DEVICE"); return e ? std::atoi(e) : 0; }
     static void check(plp_status s) {
         if (s != PLP_OK) throw std::runtime_error(std::string("plp_front: ") + plp_strerror(s) + ": " + plp_last_error());

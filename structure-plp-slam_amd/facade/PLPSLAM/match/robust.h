@@ -2,19 +2,26 @@
 // (match/robust.cc:43-216; mapping_module::create_new_landmarks calls it for every covisible key frame of a new key
 // frame): same class, constructor, method name, arguments and return value.  The node-guided search with its epipole and
 // epipolar-constraint gates (:88-150, :387-405, f64 on the bearings) runs in libplp_front.so (PLP_MATCH_MODE_TRIANGULATION);
-// the host lists key frame 1's features in feature-vector order, as the reference walks them.  match_frame_and_keyframe and
-// brute_force_match keep their declarations and their bodies in the reference's robust.cc.
-// Templates on the key-frame type, like match/projection.h.
+// the host lists key frame 1's features in feature-vector order, as the reference walks them.
+// robust::brute_force_match (:257-385) is PLP_MATCH_MODE_BRUTE_FORCE (all-pairs Hamming with greedy exclusivity, ratio test and
+// orientation check on the device); robust::match_frame_and_keyframe (:218-255) runs it and then the REFERENCE'S OWN
+// solve::essential_solver on the host, exactly as robust.cc does -- the RANSAC is geometry outside this library.
+// With this header robust.cc leaves the build.  Templates on the frame / key-frame types, like match/projection.h.
 #ifndef PLPSLAM_MATCH_ROBUST_H
 #define PLPSLAM_MATCH_ROBUST_H
 
 #include <cstdint>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
 #include "PLPSLAM/match/projection.h"   // match::base (the reference's or its stand-in), detail::*
+#if !defined(PLP_FACADE_NO_SOLVER_INCLUDE)
+#include "PLPSLAM/solve/essential_solver.h"   // the reference's RANSAC (host side), used by match_frame_and_keyframe as in robust.cc:232-239
+#endif
 
 namespace PLPSLAM {
+namespace solve { class essential_solver; }
 namespace match {
 
 class robust final : public base {
@@ -95,8 +102,62 @@ public:
         return static_cast<unsigned int>(num);
     }
 
-    unsigned int match_frame_and_keyframe(data::frame& frm, data::keyframe* keyfrm, std::vector<data::landmark*>& matched_lms_in_frm);
-    unsigned int brute_force_match(data::frame& frm, data::keyframe* keyfrm, std::vector<std::pair<int, int>>& matches);
+    //! robust.cc:257-385.  matches: (idx_1 in the frame, idx_2 in the key frame), ascending idx_1
+    template <class Frame, class KeyFrame>
+    unsigned int brute_force_match(Frame& frm, KeyFrame* keyfrm, std::vector<std::pair<int, int>>& matches) {
+        matches.clear();
+        const int n1 = static_cast<int>(frm.num_keypts_), n2 = static_cast<int>(keyfrm->num_keypts_);
+        if (n1 == 0 || n2 == 0) return 0;
+        const auto lms_2 = keyfrm->get_landmarks();
+        std::vector<uint8_t> d1(static_cast<size_t>(n1) * 32), d2(static_cast<size_t>(n2) * 32), valid2(static_cast<size_t>(n2));
+        std::vector<float> a1(static_cast<size_t>(n1)), a2(static_cast<size_t>(n2));
+        for (int i = 0; i < n1; ++i) {
+            const unsigned char* p = frm.descriptors_.template ptr<unsigned char>(i);
+            for (int k = 0; k < 32; ++k) d1[static_cast<size_t>(i) * 32 + k] = p[k];
+            a1[i] = frm.keypts_.at(i).angle;                                                  // keypts_, not undist_keypts_ (:262-263, :339)
+        }
+        for (int i = 0; i < n2; ++i) {
+            const unsigned char* p = keyfrm->descriptors_.template ptr<unsigned char>(i);
+            for (int k = 0; k < 32; ++k) d2[static_cast<size_t>(i) * 32 + k] = p[k];
+            a2[i] = keyfrm->keypts_.at(i).angle;
+            auto lm_2 = lms_2.at(i);
+            valid2[i] = (lm_2 && !lm_2->will_be_erased()) ? 1 : 0;                            // (:280-291)
+        }
+        std::vector<int32_t> out(static_cast<size_t>(n1), -1);
+        int32_t num = 0;
+        plp_match_args a{};
+        a.mode = PLP_MATCH_MODE_BRUTE_FORCE; a.B = 1; a.n_cap = n1; a.m_cap = n2;
+        a.t_desc = d1.data(); a.t_angle = a1.data(); a.q_desc = d2.data(); a.q_angle = a2.data(); a.q_valid = valid2.data();
+        a.lowe_ratio = lowe_ratio_; a.check_orientation = check_orientation_ ? 1 : 0;
+        a.out_match = out.data(); a.out_num = &num;
+        detail::check(plp_match_host(detail::shared_matcher(), &a));
+        matches.reserve(static_cast<size_t>(num));
+        for (int idx_1 = 0; idx_1 < n1; ++idx_1)
+            if (out[idx_1] >= 0) matches.emplace_back(std::make_pair(idx_1, static_cast<int>(out[idx_1])));
+        return static_cast<unsigned int>(num);
+    }
+
+    //! robust.cc:218-255: brute-force matches filtered by the inliers of an essential-matrix RANSAC (the reference's own solver)
+    template <class Frame, class KeyFrame, class Solver = solve::essential_solver>
+    unsigned int match_frame_and_keyframe(Frame& frm, KeyFrame* keyfrm, std::vector<typename std::decay<decltype(keyfrm->get_landmarks().at(0))>::type>& matched_lms_in_frm) {
+        using LandmarkPtr = typename std::decay<decltype(keyfrm->get_landmarks().at(0))>::type;
+        const auto num_frm_keypts = frm.num_keypts_;
+        const auto keyfrm_lms = keyfrm->get_landmarks();
+        unsigned int num_inlier_matches = 0;
+        matched_lms_in_frm = std::vector<LandmarkPtr>(num_frm_keypts, nullptr);
+        std::vector<std::pair<int, int>> matches;
+        brute_force_match(frm, keyfrm, matches);
+        Solver solver(frm.bearings_, keyfrm->bearings_, matches);
+        solver.find_via_ransac(50, false);
+        if (!solver.solution_is_valid()) return 0;
+        const auto is_inlier_matches = solver.get_inlier_matches();
+        for (unsigned int i = 0; i < matches.size(); ++i) {
+            if (!is_inlier_matches.at(i)) continue;
+            matched_lms_in_frm.at(matches.at(i).first) = keyfrm_lms.at(matches.at(i).second);
+            ++num_inlier_matches;
+        }
+        return num_inlier_matches;
+    }
 };
 
 }  // namespace match

@@ -61,19 +61,20 @@ def test_cpp_matcher_facade_equals_oracle(seed, n, m):
     r = subprocess.run([_MATCH_EXE, str(seed), str(n), str(m), "sim3+mutual"], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = r.stdout.strip().splitlines()
-    assert len(lines) == 23 and lines[0].startswith("match_frame_and_landmarks") and lines[4].startswith("bow_tree::match_frame_and_keyframe")
+    assert len(lines) == 25 and lines[0].startswith("match_frame_and_landmarks") and lines[4].startswith("bow_tree::match_frame_and_keyframe")
     assert lines[6].startswith("bow_tree::match_keyframes") and lines[7].startswith("fuse::replace_duplication:")
     assert lines[8].startswith("fuse::detect_duplication") and lines[9].startswith("projection::match_by_Sim3_transform")
     assert lines[10].startswith("projection::match_keyframes_mutually")
     assert lines[11].startswith("projection::match_frame_and_keyframe[") and lines[13].startswith("projection::match_frame_and_keyframe_line")
-    assert lines[14].startswith("robust::match_for_triangulation") and lines[16].startswith("fuse::replace_duplication_line")
-    assert lines[17].startswith("area::match_in_consistent_area") and lines[19].startswith("match_frame_and_landmarks_line")
+    assert lines[14].startswith("robust::match_for_triangulation") and lines[16].startswith("robust::brute_force_match") and lines[17].startswith("robust::brute_force_match")
+    assert lines[18].startswith("fuse::replace_duplication_line")
+    assert lines[19].startswith("area::match_in_consistent_area") and lines[21].startswith("match_frame_and_landmarks_line")
     if n >= 900:     # the scenes are built so that the matchers have work to do
         import re
         count = lambda ln: int(re.search(r"(\d+) (matches|fused)", ln).group(1))
-        point_lines = lines[:13] + lines[14:16] + lines[17:19]
+        point_lines = lines[:13] + lines[14:18] + lines[19:21]
         assert all(count(ln) > 30 for ln in point_lines)
-        assert all(count(ln) > 10 for ln in [lines[13], lines[16]] + lines[19:])
+        assert all(count(ln) > 10 for ln in [lines[13], lines[18]] + lines[21:])
 
 
 @pytest.mark.skipif(not os.path.exists(_EXE), reason="oracle/_ref/facade_orb_check not built (needs /root/reference at build time)")
@@ -101,6 +102,22 @@ def test_cpp_stereo_facade_equals_oracle(tmp_path, seed, K):
     want_x, want_d = O.stereo_compute(ol, orr, kl, kr, dl, dr, np.float32(fxb), np.float32(tb))
     assert n == len(kl) and nr == len(kr) and (want_x > 0).sum() > 100
     assert np.array_equal(xr, want_x) and np.array_equal(dp, want_d)
+
+
+_LBDMATCH_EXE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle", "_ref", "facade_lbdmatch_check")
+
+
+@pytest.mark.skipif(not os.path.exists(_LBDMATCH_EXE), reason="oracle/_ref/facade_lbdmatch_check not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_cpp_binary_descriptor_matcher_equals_oracle(seed):
+    """cv::line_descriptor::BinaryDescriptorMatcher from the REFERENCE'S OWN descriptor_custom.hpp, linked with the shipped
+    replacement translation unit (facade/src/binary_descriptor_matcher_plp.cpp) instead of the reference's
+    binary_descriptor_matcher.cpp, driven like data/frame.cc:392-398: DMatch (queryIdx, trainIdx, distance) equal the oracle's."""
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = "/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    r = subprocess.run([_LBDMATCH_EXE, str(seed)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 failures" in r.stdout
 
 
 _LINE_EXE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle", "facade_line_check")
