@@ -667,6 +667,59 @@ class bow_vocabulary:
         L, parents, leaf, descs, weights, weighting, scoring = cls.parse_text_file(path)
         return cls(L, parents, leaf, descs, weights, weighting, scoring, device)
 
+    # ---- binary vocabulary (`orb_vocab.dbow2`, README.md:147 of the reference; system.cc loads it with loadFromBinaryFile)
+    # DBoW2 itself and the blob are not in the reference tree: the layout below is the published one of the binary-vocabulary
+    # patch that OpenVSLAM's DBoW2 fork carries (TemplatedVocabulary::saveToBinaryFile / loadFromBinaryFile), parity unpinned:
+    #   u32 nb_nodes (= m_nodes.size(), root included)   u32 size_node (= 4 + 32 + 4 + 1)   i32 k   i32 L   i32 scoring   i32 weighting
+    #   then, for node ids 1 .. nb_nodes-1 in order:  i32 parent | 32 descriptor bytes | f32 weight | u8 is_leaf
+    _DBOW2_NODE = np.dtype([("parent", "<i4"), ("desc", "u1", (32,)), ("weight", "<f4"), ("leaf", "u1")])
+
+    @staticmethod
+    def parse_dbow2_file(path, replicate_eof_node=True):
+        """Host only.  Returns (L, parents, is_leaf, descs, weights, weighting, scoring) like parse_text_file.
+        replicate_eof_node: the loader reads records `while (!f.eof())`, so after the last record one more iteration runs on the
+        stale buffer and appends a copy of the last node (same parent, same descriptor; a new word id if it is a leaf) -- which is
+        why it sizes m_nodes to nb_nodes + 1.  The copy can never win a descent (first minimum wins) but it is part of what the
+        reference holds in memory, so it is reproduced by default."""
+        raw = np.fromfile(path, np.uint8)
+        if raw.size < 24:
+            raise PlpError(1, "vocabulary file shorter than its header")
+        nb_nodes, size_node = (int(v) for v in raw[:8].view("<u4"))
+        k, L, scoring, weighting = (int(v) for v in raw[8:24].view("<i4"))
+        if size_node != bow_vocabulary._DBOW2_NODE.itemsize:
+            raise PlpError(1, f"node records of {size_node} bytes: not a 256-bit ORB vocabulary")
+        if not (0 <= k <= 20 and 1 <= L <= 10 and 0 <= scoring <= 5 and 0 <= weighting <= 3):
+            raise PlpError(1, "vocabulary parameters out of range")
+        body = raw[24:]
+        n_rec = body.size // size_node
+        if n_rec != nb_nodes - 1:
+            raise PlpError(1, f"{n_rec} node records for nb_nodes = {nb_nodes}")
+        rec = body[:n_rec * size_node].view(bow_vocabulary._DBOW2_NODE)
+        if replicate_eof_node and n_rec:
+            rec = np.concatenate([rec, rec[-1:]])
+        parents = np.concatenate([[-1], rec["parent"].astype(np.int64)])
+        leaf = np.concatenate([[False], rec["leaf"] != 0])
+        descs = np.concatenate([np.zeros((1, 32), np.uint8), rec["desc"]])
+        weights = np.concatenate([[0.0], rec["weight"].astype(np.float64)])
+        return L, parents, leaf, descs, weights, weighting, scoring
+
+    @staticmethod
+    def write_dbow2_file(path, k, L, parents, is_leaf, descs, weights, weighting=TF_IDF, scoring=L1_NORM):
+        """saveToBinaryFile's layout (node 0 = root is not written); for tests and for converting a text vocabulary"""
+        n = len(parents)
+        rec = np.zeros(n - 1, bow_vocabulary._DBOW2_NODE)
+        rec["parent"] = np.asarray(parents[1:], np.int32); rec["desc"] = np.asarray(descs, np.uint8).reshape(n, 32)[1:]
+        rec["weight"] = np.asarray(weights[1:], np.float32); rec["leaf"] = np.asarray(is_leaf[1:], bool)
+        with open(path, "wb") as f:
+            f.write(np.array([n, rec.dtype.itemsize], "<u4").tobytes())
+            f.write(np.array([k, L, scoring, weighting], "<i4").tobytes())
+            f.write(rec.tobytes())
+
+    @classmethod
+    def from_dbow2_file(cls, path, device=0, replicate_eof_node=True):
+        L, parents, leaf, descs, weights, weighting, scoring = cls.parse_dbow2_file(path, replicate_eof_node)
+        return cls(L, parents, leaf, descs, weights, weighting, scoring, device)
+
     def __del__(self):
         h = getattr(self, "_h", None)
         if h:

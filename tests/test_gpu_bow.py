@@ -126,3 +126,24 @@ def test_vocabulary_from_text_file_equals_vocabulary_from_arrays(tmp_path):
     va, fa, wa, na = a.transform(desc, 2)
     vb, fb, wb, nb = b.transform(desc, 2)
     assert va == vb and fa == fb and np.array_equal(wa, wb) and np.array_equal(na, nb) and len(va) > 10
+
+
+def test_vocabulary_from_dbow2_file_equals_vocabulary_from_arrays(tmp_path):
+    """binary `.dbow2` layout written from a random tree and read back (bow_vocabulary.from_dbow2_file): same words and vectors
+    as the tree built from arrays with the weights narrowed to f32 (the file stores floats); the node the loader duplicates at
+    end-of-file never wins a descent, so the transforms agree with and without it."""
+    rng = np.random.default_rng(22)
+    parents, is_leaf, descs, weights = O.random_vocab(rng, 5, 3)
+    w32 = np.asarray(weights, np.float32).astype(np.float64)
+    path = tmp_path / "voc.dbow2"
+    plp.bow_vocabulary.write_dbow2_file(str(path), 5, 3, parents, is_leaf, descs, w32)
+    a = plp.bow_vocabulary(3, parents, is_leaf, descs, w32)
+    b = plp.bow_vocabulary.from_dbow2_file(str(path), replicate_eof_node=False)
+    c = plp.bow_vocabulary.from_dbow2_file(str(path))
+    assert np.array_equal(a.child_offset, b.child_offset) and np.array_equal(a.children, b.children) and np.array_equal(a.node_word, b.node_word)
+    assert len(c.node_word) == len(a.node_word) + 1
+    desc = rng.integers(0, 256, (400, 32), dtype=np.uint8)
+    va, fa, wa, na = a.transform(desc, 2)
+    for other in (b, c):
+        vb, fb, wb, nb = other.transform(desc, 2)
+        assert va == vb and fa == fb and np.array_equal(wa, wb) and np.array_equal(na, nb) and len(va) > 10

@@ -114,3 +114,37 @@ def test_vocabulary_text_file_parser(tmp_path):
     (tmp_path / "bad2.txt").write_text("3 2 0 0\n0 1 1 2 3\n")
     with pytest.raises(plp.PlpError):
         plp.bow_vocabulary.parse_text_file(str(tmp_path / "bad2.txt"))
+
+
+def test_vocabulary_dbow2_binary_file_round_trip(tmp_path):
+    """`.dbow2` layout (saveToBinaryFile / loadFromBinaryFile of the DBoW2 fork OpenVSLAM-derived systems use): header
+    nb_nodes, size_node = 41, k, L, scoring, weighting; per node parent / 32 descriptor bytes / f32 weight / is_leaf.  Written
+    from a tree and read back; compared with the same tree read from the ORBvoc text layout."""
+    rng = np.random.default_rng(6)
+    nodes = [(0, 0), (0, 0), (0, 1), (1, 1), (1, 1), (1, 1), (2, 1), (2, 1)]
+    descs = np.concatenate([np.zeros((1, 32), np.uint8), rng.integers(0, 256, (len(nodes), 32), dtype=np.uint8)])
+    parents = [-1] + [p for p, _ in nodes]; leaf = [False] + [bool(l) for _, l in nodes]
+    weights = [0.0] + [0.0 if not l else float(np.float32(0.7 + 1.3 * p)) for p, l in nodes]
+    path = tmp_path / "voc.dbow2"
+    plp.bow_vocabulary.write_dbow2_file(str(path), 3, 2, parents, leaf, descs, weights, weighting=0, scoring=0)
+    assert path.stat().st_size == 24 + 41 * len(nodes)
+    L, par, lf, d, w, weighting, scoring = plp.bow_vocabulary.parse_dbow2_file(str(path), replicate_eof_node=False)
+    assert (L, weighting, scoring) == (2, 0, 0)
+    assert list(par) == parents and list(lf) == leaf and np.array_equal(d, descs) and list(w) == weights
+    # the text layout of the same tree parses to the same arrays
+    lines = ["3 2 0 0"] + [f"{p} {l} " + " ".join(str(int(v)) for v in descs[i + 1]) + f" {weights[i + 1]!r}" for i, (p, l) in enumerate(nodes)]
+    (tmp_path / "voc.txt").write_text("\n".join(lines) + "\n")
+    L2, par2, lf2, d2, w2, _, _ = plp.bow_vocabulary.parse_text_file(str(tmp_path / "voc.txt"))
+    assert L2 == L and par2 == parents and lf2 == leaf and np.array_equal(d2, d) and w2 == weights
+    # the loader's `while (!f.eof())` appends a copy of the last node: one more node (and word), same parent and descriptor
+    L, par, lf, d, w, _, _ = plp.bow_vocabulary.parse_dbow2_file(str(path))
+    assert len(par) == len(parents) + 1 and par[-1] == parents[-1] and lf[-1] == leaf[-1] and np.array_equal(d[-1], descs[-1]) and w[-1] == weights[-1]
+    # malformed files
+    raw = path.read_bytes()
+    (tmp_path / "short.dbow2").write_bytes(raw[:20])
+    (tmp_path / "trunc.dbow2").write_bytes(raw[:-41])
+    bad = bytearray(raw); bad[4] = 40
+    (tmp_path / "size.dbow2").write_bytes(bytes(bad))
+    for name in ("short", "trunc", "size"):
+        with pytest.raises(plp.PlpError):
+            plp.bow_vocabulary.parse_dbow2_file(str(tmp_path / f"{name}.dbow2"))
