@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--rows", type=int, default=480)
     ap.add_argument("--cols", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the PCIe-inclusive pass and the single-frame latency pass (profiling runs)")
     ap.add_argument("--orb-only", action="store_true", help="time the ORB extractor alone (config 1 shape)")
     args = ap.parse_args()
 
@@ -299,6 +300,92 @@ def main():
                 "stage_ms_per_batch": {k: round(v, 4) for k, v in stage_ms.items()},
                 "stage_GBps": {k: round(per_frame[k] * B / (kern[k] * 1e-3) / 1e9, 1) for k in kern}}
 
+    # ---- beside the headline (HBM-resident) number: (b) the same steps fed from pinned host memory with the results brought
+    # back, copies on their own streams inside the timed region; (c) latency of the synchronous single-frame entry points, the
+    # calls tracking_module makes once per frame (timing boundary of run_tum_rgbd_slam_with_line.cc:95-105)
+    extras = {}
+    if not args.no_extras and not args.orb_only and world == 1:
+        h_frames = torch.empty((B, args.rows, args.cols), dtype=torch.uint8, pin_memory=True)
+        h_frames.copy_(d_frames.cpu())
+        stage = [torch.empty_like(d_frames) for _ in range(2)]
+        outs = [kps2, desc2, cnt2, kl2, lbd2, fn2, lcnt2]
+        h_out = [[torch.empty(t[0].shape, dtype=t[0].dtype, pin_memory=True) for t in outs] for _ in range(NBUF)]
+        h_m = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in (m1, n1, m2, n2, m3, n3)]
+        sH, sD = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        stage_free = [None, None]; down_done = [None] * NBUF
+        frames_default = d_frames
+
+        def host_step(n):
+            nonlocal d_frames
+            sb = n % 2
+            if stage_free[sb] is not None:
+                sH.wait_event(stage_free[sb])                                # the step that last read this staging buffer has been matched
+            with torch.cuda.stream(sH):
+                stage[sb].copy_(h_frames, non_blocking=True)                 # H2D of this step's frames
+                ev = torch.cuda.Event(); ev.record(sH)
+            for s_ in [sA] + sBs:
+                s_.wait_event(ev)
+            buf = step_no[0] % NBUF
+            if down_done[buf] is not None:
+                sA.wait_event(down_done[buf])
+                for s_ in sBs:
+                    s_.wait_event(down_done[buf])
+            d_frames = stage[sb]
+            step()
+            d_frames = frames_default
+            sD.wait_event(done_match[buf])
+            with torch.cuda.stream(sD):                                      # D2H of this step's features and matches
+                for h, t in zip(h_out[buf], outs):
+                    h.copy_(t[buf], non_blocking=True)
+                for h, t in zip(h_m, (m1, n1, m2, n2, m3, n3)):
+                    h.copy_(t, non_blocking=True)
+                down_done[buf] = torch.cuda.Event(); down_done[buf].record(sD)
+            stage_free[sb] = done_match[buf]
+        for n in range(2):
+            host_step(n)
+        barrier()
+        t0 = time.perf_counter()
+        for n in range(args.steps):
+            host_step(n)
+        barrier()
+        el = time.perf_counter() - t0
+        extras["pcie_inclusive_value"] = round(B * args.steps / el, 1)
+        extras["pcie_inclusive_ms_per_step"] = round(1e3 * el / args.steps, 4)
+        extras["pcie_bytes_per_step"] = {"h2d": int(h_frames.numel()), "d2h": int(sum(h.numel() * h.element_size() for h in h_out[0]) + sum(h.numel() * h.element_size() for h in h_m))}
+        del h_frames, stage, h_out
+        # single-frame latency, 256 calls each, the host-pointer entry points on one frame at a time
+        lat = {}
+        n_lat = 256
+        imgs = [np.ascontiguousarray(frames_np[i % uniq]) for i in range(n_lat)]
+
+        def timed(fn):
+            ts = []
+            for i in range(n_lat):
+                t_ = time.perf_counter(); fn(i); ts.append(time.perf_counter() - t_)
+            return round(1e3 * float(np.median(ts)), 4), round(1e3 * float(np.mean(ts)), 4)
+        feats = {}
+
+        def run_orb(i):
+            feats["kd"] = ex.extract(imgs[i])
+        ex.extract(imgs[0]); lt.extract_LSD_LBD(imgs[0])
+        lat["orb_extract"] = timed(run_orb)
+        lat["line_extract"] = timed(lambda i: lt.extract_LSD_LBD(imgs[i]))
+        k0, d0 = ex.extract(imgs[0]); k1, d1 = ex.extract(imgs[1])
+        q = dict(q_valid=np.ones(len(k0), np.uint8), q_reproj=np.stack([k0["x"] + np.float32(SHIFT_X), k0["y"]], 1).astype(np.float32),
+                 q_x_right=np.full(len(k0), -1, np.float32), q_level=k0["octave"].astype(np.int32), q_angle=k0["angle"].astype(np.float32), q_desc=d0,
+                 q_has_obs=np.ones(len(k0), np.uint8))
+        t_ = dict(t_kps=k1, t_desc=d1, t_x_right=np.full(len(k1), -1, np.float32), t_occupied=np.zeros(len(k1), np.uint8))
+        lat["match_current_and_last_frames"] = timed(lambda i: mt_last.match_host(plp.MODE_LAST_FRAME, len(k1), len(k0), {**t_, **q}, margin=20.0, direction=0, scale_factors=sf, grid=grid))
+        lat["match_frame_and_landmarks"] = timed(lambda i: mt_lm.match_host(plp.MODE_LANDMARKS, len(k1), len(k0), {**t_, **q}, margin=10.0, scale_factors=sf, grid=grid))
+        import threading
+
+        def run_pair(i):            # ORB || LSD in two threads, as data/frame.cc:691-694
+            th = threading.Thread(target=lambda: lt.extract_LSD_LBD(imgs[i]))
+            th.start(); ex.extract(imgs[i]); th.join()
+        lat["orb_par_line_extract"] = timed(run_pair)
+        extras["latency_ms_median_mean"] = lat
+        extras["latency_note"] = f"{n_lat} synchronous single-frame calls each through the host-pointer C ABI (plp_orb_extract, plp_line_extract, plp_match_host), {uniq} distinct frames"
+
     what = "ORB extract only" if args.orb_only else "ORB extract || LSD+LBD extract, then match_current_and_last_frames + match_frame_and_landmarks (~2K landmarks) + match_current_and_last_frames_line"
     out = {
         "metric": "frames/sec ORB+LSD extract+match, 640x480 TUM-RGBD, 1/2/4/8 GPU",
@@ -313,20 +400,41 @@ def main():
                    "sharding": "contiguous frame blocks per rank; RCCL all-gather of the 2-frame feature halo for the matchers"},
         "roofline": roofline,
     }
+    out.update(extras)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # the CPU baseline is reported at N = 1 only
         import ctypes as C
         import oracle_lib as O
         cores = os.cpu_count() or 1
-        n_cpu = max(cores * 3, 24)   # >= 3 frames per worker block so the matchers run; ~15-25 s of CPU work
-        sample = np.ascontiguousarray(np.tile(frames_np, ((n_cpu + uniq - 1) // uniq, 1, 1))[:n_cpu])
         tot = (C.c_long * 3)()
         if args.orb_only:
+            n_cpu = max(cores * 3, 24)
+            sample = np.ascontiguousarray(np.tile(frames_np, ((n_cpu + uniq - 1) // uniq, 1, 1))[:n_cpu])
             sec = O.lib().oracle_orb_time_frames(sample.ctypes.data_as(C.c_void_p), n_cpu, args.rows, args.cols, K, cores, tot)
+            out["cpu_baseline"] = {"value": round(n_cpu / sec, 1), "unit": "frames/s", "cores": cores, "kind": "port",
+                                   "sample": f"{n_cpu} frames of the same replay on {cores} threads (oracle restatement, g++ -O2 strict FP)"}
         else:
-            sec = O.lib().oracle_front_time_frames(sample.ctypes.data_as(C.c_void_p), n_cpu, args.rows, args.cols, K, cores, SHIFT_X, tot)
-        out["cpu_baseline"] = {"value": round(n_cpu / sec, 1), "unit": "frames/s", "cores": cores, "kind": "port",
-                               "sample": f"{n_cpu} frames of the same replay, contiguous blocks on {cores} threads, same stages "
-                                         "(oracle restatement, g++ -O2 strict FP)"}
+            # three thread configurations x two builds of the oracle restatement (strict FP = the parity build;
+            # -O3 -ffast-math -mtune=native = the reference's Release flags, CMakeLists.txt:57-58, timing only)
+            libs = {"strict_O2": O.lib()}
+            fast = pathlib.Path(O.ORACLE_DIR) / "liboracle_fast.so"
+            if fast.exists():
+                libs["ref_flags_O3_fastmath"] = C.CDLL(str(fast))
+            cfgs = {}
+            for tag, L in libs.items():
+                fn = L.oracle_front_time_frames2
+                fn.restype = C.c_double
+                fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p]
+                for name, threads, pair, n_cpu in (("1_thread", 1, 0, 8), ("ref_2_threads_per_frame", 1, 1, 8), ("all_cores", cores, 0, max(cores * 3, 24))):
+                    sample = np.ascontiguousarray(np.tile(frames_np, ((n_cpu + uniq - 1) // uniq, 1, 1))[:n_cpu])
+                    st3 = (C.c_double * 3)()
+                    sec = fn(sample.ctypes.data_as(C.c_void_p), n_cpu, args.rows, args.cols, K, threads, SHIFT_X, pair, st3, tot)
+                    cfgs[f"{tag}/{name}"] = {"frames_per_s": round(n_cpu / sec, 2), "frames": n_cpu, "threads": threads * (2 if pair else 1),
+                                             "thread_ms_per_frame": {"orb": round(1e3 * st3[0] / n_cpu, 2), "lines" if not pair else "orb_par_lines_wall": round(1e3 * st3[1] / n_cpu, 2),
+                                                                     "match": round(1e3 * st3[2] / n_cpu, 2)}}
+            best = "ref_flags_O3_fastmath/all_cores" if "ref_flags_O3_fastmath/all_cores" in cfgs else "strict_O2/all_cores"
+            out["cpu_baseline"] = {"value": cfgs[best]["frames_per_s"], "unit": "frames/s", "cores": cores, "kind": "port",
+                                   "sample": f"{cfgs[best]['frames']} frames of the same replay, contiguous blocks on {cores} threads, same stages: the oracle RESTATEMENT "
+                                             f"({best.split('/')[0]}), not the reference's OpenCV build, which is not available here", "configs": cfgs}
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

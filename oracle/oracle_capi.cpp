@@ -183,9 +183,14 @@ unsigned oracle_match_current_and_last(const double* grid6, const KeyPoint* kps,
                                        const float* langle, const uint8_t* ldesc, const uint8_t* l_has_obs, int m, float margin,
                                        int direction, int check_orientation, int* kp_last);
 
-double oracle_front_time_frames(const uint8_t* frames, int n_frames, int rows, int cols, unsigned max_kp, int n_threads,
-                                float shift_x, long* totals3) {
+// two_threads_per_frame != 0: ORB and LSD+LBD of a frame run in two threads that are joined before the matchers, as the reference's
+// frame constructor does (data/frame.cc:691-694).  stage_sec3 (nullable): thread-seconds spent in ORB / lines / matchers.
+double oracle_front_time_frames2(const uint8_t* frames, int n_frames, int rows, int cols, unsigned max_kp, int n_threads, float shift_x,
+                                 int two_threads_per_frame, double* stage_sec3, long* totals3) {
     std::vector<long> kp(n_threads, 0), ln(n_threads, 0), mt(n_threads, 0);
+    std::vector<double> s_orb(n_threads, 0), s_line(n_threads, 0), s_match(n_threads, 0);
+    auto now = []() { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     const double grid6[6] = {0.0, 0.0, 64.0 / (double)(float)cols, 48.0 / (double)(float)rows, 64, 48};
     auto t0 = std::chrono::steady_clock::now();
     std::vector<std::thread> th;
@@ -205,9 +210,24 @@ double oracle_front_time_frames(const uint8_t* frames, int n_frames, int rows, i
             for (int f = f0; f < f1; ++f) {
                 const int cur = f % 3;
                 Image im = wrap(frames + (size_t)f * rows * cols, rows, cols, cols);
-                ex.extract(im, nullptr, k[cur], d[cur]);
+                void* lh = nullptr;
+                auto ta = now();
+                if (two_threads_per_frame) {
+                    std::thread line_thread([&]() { lh = oracle_line_extract(im.data.data(), rows, cols, cols, 1); });
+                    ex.extract(im, nullptr, k[cur], d[cur]);
+                    s_orb[t] += secs(ta, now());
+                    line_thread.join();
+                    s_line[t] += secs(ta, now());        // wall time of the pair: the frame waits for the slower of the two
+                } else {
+                    ex.extract(im, nullptr, k[cur], d[cur]);
+                    auto tb = now();
+                    s_orb[t] += secs(ta, tb);
+                    lh = oracle_line_extract(im.data.data(), rows, cols, cols, 1);
+                    s_line[t] += secs(tb, now());
+                }
+                auto tm = now();
+                struct Acc { double& s; std::chrono::steady_clock::time_point t0; ~Acc() { s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } acc{s_match[t], tm};
                 kp[t] += (long)k[cur].size();
-                void* lh = oracle_line_extract(im.data.data(), rows, cols, cols, 1);
                 const int nl = oracle_line_count(lh, 0);
                 ln[t] += nl;
                 kl[f & 1].assign((size_t)nl, CapiKeyLine{}); lbd[f & 1].assign((size_t)nl * 32, 0);
@@ -264,6 +284,13 @@ double oracle_front_time_frames(const uint8_t* frames, int n_frames, int rows, i
         totals3[0] = totals3[1] = totals3[2] = 0;
         for (int t = 0; t < n_threads; ++t) { totals3[0] += kp[t]; totals3[1] += ln[t]; totals3[2] += mt[t]; }
     }
+    if (stage_sec3) {
+        stage_sec3[0] = stage_sec3[1] = stage_sec3[2] = 0;
+        for (int t = 0; t < n_threads; ++t) { stage_sec3[0] += s_orb[t]; stage_sec3[1] += s_line[t]; stage_sec3[2] += s_match[t]; }
+    }
     return std::chrono::duration<double>(t1 - t0).count();
+}
+double oracle_front_time_frames(const uint8_t* frames, int n_frames, int rows, int cols, unsigned max_kp, int n_threads, float shift_x, long* totals3) {
+    return oracle_front_time_frames2(frames, n_frames, rows, cols, max_kp, n_threads, shift_x, 0, nullptr, totals3);
 }
 }

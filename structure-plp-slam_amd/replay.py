@@ -2,9 +2,10 @@
 
 Extraction needs no communication.  Matching frame f against frames f-1 and f-2 does at block
 boundaries: the first `halo` frames of rank r need the features of the last `halo` frames of rank r-1.
-`exchange_halo` is that one exchange step — an all-gather of the ranks' tail features (RCCL over xGMI on
-GPUs: backend "nccl"; gloo on CPU in the tests), after which every rank keeps its predecessor's tail
-(rank 0 takes the last rank's: the replay is circular).  ~2 x 2064 x 60 B = 250 KB per rank.
+`exchange_halo` is that one exchange step: the tail features packed into one record per frame and shifted to the
+successor rank (or all-gathered) in a single collective -- RCCL over xGMI on GPUs (backend "nccl"), gloo on CPU in the
+tests -- after which every rank holds its predecessor's tail (rank 0 takes the last rank's: the replay is circular).
+~2 x 2064 x 60 B = 250 KB per rank and step.
 """
 import torch
 import torch.distributed as dist
@@ -17,21 +18,39 @@ def frame_block(rank, world, n_frames):
     return start, start + per + (1 if rank < extra else 0)
 
 
-def exchange_halo(tensors, halo=2, group=None):
+def exchange_halo(tensors, halo=2, group=None, mode="ring"):
     """tensors: list of per-frame feature tensors [B, ...] of this rank (key points, descriptors, counts...).
-    Returns the list of [halo, ...] tensors holding the predecessor rank's last `halo` frames."""
+    Returns the list of [halo, ...] tensors holding the predecessor rank's last `halo` frames.
+
+    ONE exchange per call: the tails of all tensors are packed into a single byte record per frame
+    ({count, key points, descriptors, ...} back to back) and moved by
+      mode "ring"       one send to the successor + one receive from the predecessor (batch_isend_irecv): only the bytes that are
+                        needed cross a link -- xGMI is point-to-point, a neighbour shift is its natural pattern;
+      mode "allgather"  one all_gather_into_tensor of the packed tails (every rank sees every tail), the form north_star names."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return [t[-halo:].clone() for t in tensors]          # single rank: circular replay inside the block
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    out = []
-    for t in tensors:
-        tail = t[-halo:].contiguous()
-        bounce = tail.is_cuda and dist.get_backend(group) == "gloo"     # gloo gathers host tensors only (diagnostic runs)
-        src = tail.cpu() if bounce else tail
-        gathered = torch.empty((world * halo,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
-        dist.all_gather_into_tensor(gathered, src, group=group)     # concatenated along dim 0 (nccl and gloo agree on this form)
+    dev = tensors[0].device
+    tails = [t[-halo:].contiguous() for t in tensors]
+    sizes = [tl[0].numel() * tl.element_size() for tl in tails]          # bytes per frame of each tensor
+    packed = torch.cat([tl.view(torch.uint8).reshape(halo, -1) for tl in tails], 1).contiguous()      # [halo, record bytes]
+    bounce = packed.is_cuda and dist.get_backend(group) == "gloo"        # gloo moves host tensors only (diagnostic runs on one GPU)
+    src = packed.cpu() if bounce else packed
+    if mode == "allgather":
+        gathered = torch.empty((world * halo, src.shape[1]), dtype=torch.uint8, device=src.device)
+        dist.all_gather_into_tensor(gathered, src, group=group)
         prev = (rank - 1) % world
-        out.append(gathered[prev * halo:(prev + 1) * halo].to(tail.device, copy=True))
+        got = gathered[prev * halo:(prev + 1) * halo]
+    else:
+        got = torch.empty_like(src)
+        ops = [dist.P2POp(dist.isend, src, (rank + 1) % world, group), dist.P2POp(dist.irecv, got, (rank - 1) % world, group)]
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    got = got.to(dev) if bounce else got
+    out, off = [], 0
+    for tl, nbytes in zip(tails, sizes):
+        out.append(got[:, off:off + nbytes].contiguous().view(tl.dtype).reshape(tl.shape))
+        off += nbytes
     return out
 
 

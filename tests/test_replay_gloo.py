@@ -25,6 +25,9 @@ def _worker(rank, world, port, n_frames, q):
     desc = torch.arange(a, b, dtype=torch.int64)[:, None, None].repeat(1, 5, 32).to(torch.uint8)
     cnt = torch.arange(a, b, dtype=torch.int32)
     hk, hd, hc = replay.exchange_halo([kps, desc, cnt], halo=2)
+    ak, ad, ac = replay.exchange_halo([kps, desc, cnt], halo=2, mode="allgather")      # the two transports agree
+    assert torch.equal(hk, ak) and torch.equal(hd, ad) and torch.equal(hc, ac)
+    assert hk.dtype == kps.dtype and hd.dtype == desc.dtype and hc.dtype == cnt.dtype and hk.shape == (2, 5, 7)
     full = replay.with_halo(cnt, hc)
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)          # the max-over-ranks timing reduction of bench.py
