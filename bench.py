@@ -110,15 +110,17 @@ def main():
     cap, lcap = 2 * K + 64, 512
     # NBUF sets of outputs: the matchers of step n read set n % NBUF while the extractors of the next steps fill the others
     NBUF = max(2, int(os.environ.get("PLP_BENCH_NBUF", "2")))
-    kps2 = [torch.empty((B, cap, 28), dtype=torch.uint8, device=dev) for _ in range(NBUF)]
-    desc2 = [torch.empty((B, cap, 32), dtype=torch.uint8, device=dev) for _ in range(NBUF)]
-    cnt2 = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(NBUF)]
-    d_kps, d_desc, d_cnt = kps2[0], desc2[0], cnt2[0]
-    kl2 = [torch.zeros((B, lcap, 68), dtype=torch.uint8, device=dev) for _ in range(NBUF)]
-    lbd2 = [torch.zeros((B, lcap, 32), dtype=torch.uint8, device=dev) for _ in range(NBUF)]
+    HALO = 2    # the matchers of frame b read frames b-1 and b-2: rows 0..HALO-1 of every feature array hold the predecessor rank's tail
+    full = lambda shape, dt, zero=False: (torch.zeros if zero else torch.empty)((HALO + B,) + shape, dtype=dt, device=dev)
+    kps2 = [full((cap, 28), torch.uint8) for _ in range(NBUF)]
+    desc2 = [full((cap, 32), torch.uint8) for _ in range(NBUF)]
+    cnt2 = [full((), torch.int32, True) for _ in range(NBUF)]
+    kl2 = [full((lcap, 68), torch.uint8, True) for _ in range(NBUF)]
+    lbd2 = [full((lcap, 32), torch.uint8, True) for _ in range(NBUF)]
     fn2 = [torch.empty((B, lcap, 3), dtype=torch.float64, device=dev) for _ in range(NBUF)]
-    lcnt2 = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(NBUF)]
-    d_kl, d_lbd, d_fn, d_lcnt = kl2[0], lbd2[0], fn2[0], lcnt2[0]
+    lcnt2 = [full((), torch.int32, True) for _ in range(NBUF)]
+    d_kps, d_desc, d_cnt = kps2[0][HALO:], desc2[0][HALO:], cnt2[0][HALO:]
+    d_kl, d_lbd, d_fn, d_lcnt = kl2[0][HALO:], lbd2[0][HALO:], fn2[0], lcnt2[0][HALO:]
     m3 = torch.empty((B, lcap), dtype=torch.int32, device=dev); n3 = torch.zeros(B, dtype=torch.int32, device=dev)
     m1 = torch.empty((B, cap), dtype=torch.int32, device=dev); n1 = torch.zeros(B, dtype=torch.int32, device=dev)
     m2 = torch.empty((B, cap), dtype=torch.int32, device=dev); n2 = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -141,41 +143,34 @@ def main():
     serial = bool(os.environ.get("PLP_BENCH_SERIAL"))                            # diagnostic: one stream for everything
     sB = sA if serial else torch.cuda.Stream(dev)
     sBs = [sB] + [sA if serial else torch.cuda.Stream(dev) for _ in range(n_line - 1)]
-    slot = torch.arange(cap, device=dev, dtype=torch.int32)[None, :]
-
+    
     replay = importlib.import_module("structure-plp-slam_amd.replay")
+    pq = replay.point_queries(plp, B, cap, dev)
+    lq = replay.line_queries(plp, B, lcap, dev)
+    shift = (SHIFT_X, 0.0)
 
-    def match_stage(d_kps=d_kps, d_desc=d_desc, d_cnt=d_cnt, st=None, d_kl=d_kl, d_lbd=d_lbd, d_lcnt=d_lcnt, before_lines=None):
+    def match_stage(buf=0, st=None, before_lines=None):
+        """the tracker's three matcher calls for every frame of the step held in feature set `buf`, on stream st"""
         st = st or sA
-        kf = d_kps.view(torch.float32).view(B, cap, 7)
-        # the two frames preceding this rank's block come from the previous rank (RCCL all-gather of the tails)
-        hk, hd, hc = replay.exchange_halo([kf, d_desc, d_cnt], halo=2)
-        fk, fd, fc = replay.with_halo(kf, hk), replay.with_halo(d_desc, hd), replay.with_halo(d_cnt, hc)
-        fi = fk.view(torch.int32)
-        p1k, p2k, p1i, p2i = fk[1:B + 1], fk[0:B], fi[1:B + 1], fi[0:B]
-        p1d, p2d, c1, c2 = fd[1:B + 1], fd[0:B], fc[1:B + 1].contiguous(), fc[0:B].contiguous()
-        shift = torch.tensor([SHIFT_X, 0.0], device=dev)
-        q1 = dict(q_reproj=(p1k[:, :, 0:2] + shift).contiguous(), q_level=p1i[:, :, 5].contiguous(), q_angle=p1k[:, :, 3].contiguous(),
-                  q_desc=p1d.contiguous(), q_counts=c1)
-        t = dict(t_kps=d_kps, t_desc=d_desc, t_counts=d_cnt)
+        kps, desc, cnt = kps2[buf], desc2[buf], cnt2[buf]
+        # the two frames preceding this rank's block come from the previous rank: one packed exchange into rows 0..HALO-1
+        replay.exchange_halo_into([kps, desc, cnt], halo=HALO)
+        pq.build(kps, cnt, HALO, shift, st)       # reprojections / levels / angles / validity of the queries: one launch
+        t = dict(t_kps=kps[HALO:], t_desc=desc[HALO:], t_counts=cnt[HALO:])
+        # descriptors are read in place: the queries of frame b are rows (b + HALO - 1) resp. (b + HALO - 2 .. b + HALO - 1) of `desc`
+        q1 = dict(q_reproj=pq.q1_reproj, q_level=pq.q1_level, q_angle=pq.q1_angle, q_counts=pq.q1_counts, q_desc=desc[HALO - 1:], q_desc_stride=cap)
         mt_last.match_device(plp.MODE_LAST_FRAME, cap, cap, {**t, **q1}, m1, n1, margin=20.0, direction=0, scale_factors=sf, grid=grid, B=B, stream=st)
-        rp2 = torch.cat([p1k[:, :, 0:2] + shift, p2k[:, :, 0:2] + 2 * shift], 1).contiguous()
-        q2 = dict(q_reproj=rp2, q_level=torch.cat([p1i[:, :, 5], p2i[:, :, 5]], 1).contiguous(), q_desc=torch.cat([p1d, p2d], 1),
-                  q_valid=torch.cat([slot < c1[:, None], slot < c2[:, None]], 1).to(torch.uint8).contiguous())
+        q2 = dict(q_reproj=pq.q2_reproj, q_level=pq.q2_level, q_valid=pq.q2_valid, q_desc=desc[HALO - 2:], q_desc_stride=cap)
         mt_lm.match_device(plp.MODE_LANDMARKS, cap, 2 * cap, {**t, **q2}, m2, n2, margin=10.0, scale_factors=sf, grid=grid, B=B, stream=st)
         if args.orb_only:
             return
         if before_lines is not None:
             before_lines()          # the point matchers only needed the ORB stream; the line matcher waits for the line streams here
-        # key lines of the previous frame, both end points moved by the pan, against this frame's key lines
-        lf = d_kl.view(torch.float32).view(B, lcap, 17)
-        hl, hb, hn = replay.exchange_halo([lf, d_lbd, d_lcnt], halo=2)
-        pl = replay.with_halo(lf, hl)[1:B + 1]
-        pli = pl.view(torch.int32)
-        q3 = dict(q_reproj=(pl[:, :, 7:9] + shift).contiguous(), q_reproj2=(pl[:, :, 9:11] + shift).contiguous(), q_level=pli[:, :, 2].contiguous(),
-                  q_desc=replay.with_halo(d_lbd, hb)[1:B + 1].contiguous(), q_counts=replay.with_halo(d_lcnt, hn)[1:B + 1].contiguous(),
-                  is_rgbd=0, num_levels_lsd=1)
-        mt_line.match_device(plp.MODE_LAST_FRAME_LINE, lcap, lcap, {**dict(t_kl=d_kl, t_desc=d_lbd, t_counts=d_lcnt), **q3}, m3, n3, margin=20.0,
+        kl, lbd, lcnt = kl2[buf], lbd2[buf], lcnt2[buf]
+        replay.exchange_halo_into([kl, lbd, lcnt], halo=HALO)
+        lq.build(kl, lcnt, HALO, shift, st)       # key lines of the previous frame, both end points moved by the pan
+        q3 = dict(q_reproj=lq.q_sp, q_reproj2=lq.q_ep, q_level=lq.q_level, q_counts=lq.q_counts, q_desc=lbd[HALO - 1:], q_desc_stride=lcap, is_rgbd=0, num_levels_lsd=1)
+        mt_line.match_device(plp.MODE_LAST_FRAME_LINE, lcap, lcap, {**dict(t_kl=kl[HALO:], t_desc=lbd[HALO:], t_counts=lcnt[HALO:]), **q3}, m3, n3, margin=20.0,
                              direction=0, scale_factors=sf_lsd, B=B, stream=st)
 
     # One step = ORB (stream A) || LSD+LBD (stream B), then the halo exchange and the two matchers (stream C) on that
@@ -193,7 +188,7 @@ def main():
             sA.wait_event(done_match[buf])          # the matchers of step n - 2 have read this set
         parts = os.environ.get("PLP_BENCH_PARTS", "orb,lines,match")   # diagnostic: time a subset of the step
         if "orb" in parts:
-            ex.extract_batch(d_frames, kps2[buf], desc2[buf], cnt2[buf], stream=sA)
+            ex.extract_batch(d_frames, kps2[buf][HALO:], desc2[buf][HALO:], cnt2[buf][HALO:], stream=sA)
         ready = torch.cuda.Event(); ready.record(sA)
         if not args.orb_only:
             bs = B // n_line
@@ -203,14 +198,13 @@ def main():
                 if done_match[buf] is not None:
                     sbi.wait_event(done_match[buf])     # the line matcher of step n - 2 has read this set
                 if "lines" in parts:
-                    lti.extract_batch(d_frames[sl], kl2[buf][sl], lbd2[buf][sl], fn2[buf][sl], lcnt2[buf][sl], stream=sbi)
+                    lti.extract_batch(d_frames[sl], kl2[buf][HALO:][sl], lbd2[buf][HALO:][sl], fn2[buf][sl], lcnt2[buf][HALO:][sl], stream=sbi)
                 ev = torch.cuda.Event(); ev.record(sbi); line_ready.append(ev)
             if "match" not in parts:
                 return
             sC.wait_event(ready)
             with torch.cuda.stream(sC):
-                match_stage(kps2[buf], desc2[buf], cnt2[buf], sC, kl2[buf], lbd2[buf], lcnt2[buf],
-                            before_lines=lambda: [sC.wait_event(ev) for ev in line_ready])
+                match_stage(buf, sC, before_lines=lambda: [sC.wait_event(ev) for ev in line_ready])
                 done_match[buf] = torch.cuda.Event(); done_match[buf].record(sC)
 
     def barrier():
@@ -308,7 +302,7 @@ def main():
         h_frames = torch.empty((B, args.rows, args.cols), dtype=torch.uint8, pin_memory=True)
         h_frames.copy_(d_frames.cpu())
         stage = [torch.empty_like(d_frames) for _ in range(2)]
-        outs = [kps2, desc2, cnt2, kl2, lbd2, fn2, lcnt2]
+        outs = [[t[HALO:] for t in kps2], [t[HALO:] for t in desc2], [t[HALO:] for t in cnt2], [t[HALO:] for t in kl2], [t[HALO:] for t in lbd2], fn2, [t[HALO:] for t in lcnt2]]
         h_out = [[torch.empty(t[0].shape, dtype=t[0].dtype, pin_memory=True) for t in outs] for _ in range(NBUF)]
         h_m = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in (m1, n1, m2, n2, m3, n3)]
         sH, sD = torch.cuda.Stream(dev), torch.cuda.Stream(dev)

@@ -197,7 +197,8 @@ plp_status plp_line_get_stage_times(plp_line* ctx, double* ms9, int64_t* n_batch
  *   ALL_LBD  32 bytes per ALL_KL record
  *   SOBEL_DX / SOBEL_DY  int16 rows x cols */
 typedef enum plp_line_debug_id { PLP_LINE_DBG_SCALED = 0, PLP_LINE_DBG_ORDER = 1, PLP_LINE_DBG_RAW = 2, PLP_LINE_DBG_ALL_KL = 3,
-                                 PLP_LINE_DBG_ALL_LBD = 4, PLP_LINE_DBG_SOBEL_DX = 5, PLP_LINE_DBG_SOBEL_DY = 6 } plp_line_debug_id;
+                                 PLP_LINE_DBG_ALL_LBD = 4, PLP_LINE_DBG_SOBEL_DX = 5, PLP_LINE_DBG_SOBEL_DY = 6,
+                                 PLP_LINE_DBG_GROW_STATS = 7 /* int32[4]: regions grown, pixels accepted, exact (in-band) decisions, 0 */ } plp_line_debug_id;
 plp_status plp_line_debug_read(plp_line* ctx, plp_line_debug_id what, int32_t frame, void* dst, size_t dst_bytes, int64_t* n_out);
 plp_status plp_line_scaled_size(const plp_line* ctx, int32_t* rows, int32_t* cols);
 /* Diagnostics of frame 0 of the last batch: shader cycles {whole wave, region_grow, region2rect, refine}, regions grown, pixels grown. */
@@ -332,12 +333,30 @@ typedef struct plp_match_args {
      * out_num[b] = the matcher's return value (num_matches) */
     int32_t* out_match;             /* B x n_cap */
     int32_t* out_num;               /* B */
+    /* Rows between two problems' blocks in q_desc (0 = m_cap).  In a batched replay the queries of frame b are the features of the
+     * frames before it: with q_desc_stride = the per-frame capacity, q_desc may point INTO the batch's own descriptor array (one
+     * frame back, m_cap = cap; or two frames back, m_cap = 2 cap: overlapping windows) and no descriptor is copied. */
+    int32_t q_desc_stride;
 } plp_match_args;
 
 /* All array pointers in `a` are DEVICE pointers (except scale_factors); asynchronous on hip_stream. */
 plp_status plp_match_device(plp_matcher* ctx, const plp_match_args* a, void* hip_stream);
 /* Same with HOST pointers for one call (B problems are staged to HBM and back); synchronous. */
 plp_status plp_match_host(plp_matcher* ctx, const plp_match_args* a);
+
+/* Batched replay (bench.py, replay_driver.py): the queries of the tracker's per-frame matcher calls, built on the
+ * device from the features of the preceding frames of the batch -- what tracking_module does on the host with poses, here for a
+ * camera that pans by (shift_x, shift_y) pixels per frame (example/run_tum_rgbd_slam_with_line.cc replayed without a map).
+ * feat_*: [(halo + B)][cap] rows; row halo + b is frame b of this rank's block, rows 0 .. halo-1 the predecessor's tail (halo >= 2).
+ *   last-frame queries  (frame b-1 moved by 1 x shift):  q1_reproj [B][cap][2], q1_level [B][cap], q1_angle [B][cap], q1_counts [B]
+ *   local-landmark queries (frames b-2, b-1 moved by 2 x / 1 x shift): q2_reproj [B][2 cap][2], q2_level [B][2 cap], q2_valid [B][2 cap]
+ * Descriptors are not copied: pass q_desc = feat_desc + (halo - 1) * cap * 32 (resp. halo - 2) with q_desc_stride = cap. */
+plp_status plp_replay_point_queries_device(const plp_keypoint* feat_kps, const int32_t* feat_counts, int32_t halo, int32_t B, int32_t cap, float shift_x,
+                                           float shift_y, float* q1_reproj, int32_t* q1_level, float* q1_angle, int32_t* q1_counts, float* q2_reproj,
+                                           int32_t* q2_level, uint8_t* q2_valid, void* hip_stream);
+/* key lines of frame b-1, both end points moved by the shift: q_sp / q_ep [B][cap][2], q_level [B][cap] (KeyLine::octave), q_counts [B] */
+plp_status plp_replay_line_queries_device(const plp_keyline* feat_kl, const int32_t* feat_counts, int32_t halo, int32_t B, int32_t cap, float shift_x,
+                                          float shift_y, float* q_sp, float* q_ep, int32_t* q_level, int32_t* q_counts, void* hip_stream);
 
 /* area::match_in_consistent_area(frm_1, frm_2, prev_matched_pts, matched_indices_2_in_frm_1, margin)
  * (src/PLPSLAM/match/area.cc:33-153; monocular initialisation, module/initializer.cc:191-192).  Host pointers, one

@@ -272,7 +272,10 @@ double oracle_front_time_frames2(const uint8_t* frames, int n_frames, int rows, 
                 mt[t] += oracle_match_current_and_last(grid6, k[cur].data(), d[cur].data(), xr.data(), occ.data(), n, sf.data(), (int)sf.size(),
                                                        valid.data(), rp.data(), qx.data(), ql.data(), qa.data(), qd.data(), hobs.data(),
                                                        (int)ql.size(), 20.f, 0, 1, out.data());
+                // local landmarks: the key points of frame f - 2, then those of frame f - 1 (the order of the device replay, plp_replay_point_queries_device)
+                valid.clear(); hobs.clear(); rp.clear(); qx.clear(); qa.clear(); ql.clear(); qd.clear();
                 append((f + 1) % 3, 2 * shift_x);
+                append((f + 2) % 3, shift_x);
                 mt[t] += oracle_match_frame_and_landmarks(grid6, k[cur].data(), d[cur].data(), xr.data(), occ.data(), n, sf.data(), valid.data(),
                                                           rp.data(), qx.data(), ql.data(), qd.data(), hobs.data(), (int)ql.size(), 10.f, 0.8f,
                                                           out.data());

@@ -104,6 +104,8 @@ _API = [
     ("plp_stereo_compute_batch_device", C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, C.c_float, C.c_float, _VP, _VP, _VP]),
     ("plp_hamming_matrix_device", C.c_int, [_VP, _VP, _I32, _VP, _I32, _VP, _VP]),
     ("plp_hamming_matrix_host", C.c_int, [_VP, _VP, _I32, _VP, _I32, _VP]),
+    ("plp_replay_point_queries_device", C.c_int, [_VP, _VP, _I32, _I32, _I32, C.c_float, C.c_float, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    ("plp_replay_line_queries_device", C.c_int, [_VP, _VP, _I32, _I32, _I32, C.c_float, C.c_float, _VP, _VP, _VP, _VP, _VP]),
 ]
 
 
@@ -298,7 +300,7 @@ LINE_CAP = 2048
 class LineFeatureTracker:
     """Mirror of feature::LineFeatureTracker (src/PLPSLAM/feature/line_extractor.h:61-104) over the C ABI."""
 
-    DBG_SCALED, DBG_ORDER, DBG_RAW, DBG_ALL_KL, DBG_ALL_LBD, DBG_SOBEL_DX, DBG_SOBEL_DY = range(7)
+    DBG_SCALED, DBG_ORDER, DBG_RAW, DBG_ALL_KL, DBG_ALL_LBD, DBG_SOBEL_DX, DBG_SOBEL_DY, DBG_GROW_STATS = range(8)
 
     def __init__(self, device=0):
         h = C.c_void_p()
@@ -363,6 +365,8 @@ class LineFeatureTracker:
             a = np.zeros(LINE_CAP, KL_DTYPE)
         elif what == self.DBG_ALL_LBD:
             a = np.zeros((LINE_CAP, 32), np.uint8)
+        elif what == self.DBG_GROW_STATS:
+            a = np.zeros(4, np.int32)
         else:
             a = np.zeros(4 * r.value * c.value + 4 * (r.value + c.value) + 8, np.int16)
         _check(lib().plp_line_debug_read(self._h, what, frame, _p(a), a.nbytes, C.byref(n)))
@@ -398,7 +402,7 @@ class match_args_c(C.Structure):
                 ("q_group", _VP), ("t_group", _VP), ("q_reproj_d", _VP), ("inv_level_sigma_sq", _VP), ("out_query_best", _VP),
                 ("hamm_dist_thr", C.c_int32), ("level_window", C.c_int32), ("flags", C.c_int32),
                 ("q_reproj2_d", _VP), ("q_bearing", _VP), ("t_bearing", _VP), ("epipolar", _VP),
-                ("out_match", _VP), ("out_num", _VP)]
+                ("out_match", _VP), ("out_num", _VP), ("q_desc_stride", C.c_int32)]
 
 
 MODE_LANDMARKS, MODE_LAST_FRAME, MODE_BRUTE_FORCE, MODE_LANDMARKS_LINE, MODE_LAST_FRAME_LINE, MODE_BOW, MODE_FUSE, MODE_FUSE_LINE, MODE_TRIANGULATION = 0, 1, 2, 3, 4, 5, 6, 7, 8
@@ -434,7 +438,7 @@ class matcher:
         a = match_args_c()
         a.mode, a.B, a.n_cap, a.m_cap = mode, B, n_cap, m_cap
         for k, v in fields.items():
-            if k in ("is_rgbd", "num_levels_lsd", "hamm_dist_thr", "level_window", "flags"):
+            if k in ("is_rgbd", "num_levels_lsd", "hamm_dist_thr", "level_window", "flags", "q_desc_stride"):
                 setattr(a, k, int(v))
             elif k == "inv_level_sigma_sq":
                 arr = np.ascontiguousarray(v, np.float32)

@@ -21,7 +21,7 @@ struct plp_line {
     ResizeExactTab rt{};
     BlurTapsN t11{}, t5{};
     LbdWeightsDev w{};
-    DevBuf tabs, blur11, scaled, pix, bin, maxgrad, undef, order, reg, raw, n_raw, blur5, dx, dy, all_kl, all_lbd, n_all, status, prof;
+    DevBuf tabs, blur11, scaled, pix, bin, maxgrad, undef, order, reg, raw, n_raw, blur5, dx, dy, all_kl, all_lbd, n_all, status, prof, grow_stats;
     DevBuf l0copy, s_kl, s_lbd, s_fn, s_cnt;   // host-API staging
     DevBuf aligned;                             // aligned copy of odd-pitch device frames
     int s_cap = 0;
@@ -126,13 +126,13 @@ plp_status ensure(plp_line* c, int B) {
     PLP_HIP(c->raw.reserve(sizeof(float4) * kLineCap * B)); PLP_HIP(c->n_raw.reserve(4 * (size_t)B));
     PLP_HIP(c->dx.reserve(full * 4 * B));
     PLP_HIP(c->all_kl.reserve(sizeof(plp_keyline) * kLineCap * B)); PLP_HIP(c->all_lbd.reserve((size_t)32 * kLineCap * B));
-    PLP_HIP(c->n_all.reserve(4 * (size_t)B)); PLP_HIP(c->status.reserve(16)); PLP_HIP(c->prof.reserve(64));
+    PLP_HIP(c->n_all.reserve(4 * (size_t)B)); PLP_HIP(c->status.reserve(16)); PLP_HIP(c->prof.reserve(64)); PLP_HIP(c->grow_stats.reserve(16 * (size_t)B));
     P.blur11 = (uint8_t*)c->blur11.p; P.blur5 = (uint8_t*)c->blur5.p; P.scaled = (uint8_t*)c->scaled.p;
     P.pix = (LsdPix*)c->pix.p; P.bin = (uint16_t*)c->bin.p;
     P.blockmax = (uint32_t*)c->maxgrad.p; P.undef = (unsigned long long*)c->undef.p;
     P.order = (uint32_t*)c->order.p; P.reg = (uint32_t*)c->reg.p; P.raw = (float4*)c->raw.p; P.n_raw = (int32_t*)c->n_raw.p;
     P.dxy = (short2*)c->dx.p; P.all_kl = (plp_keyline*)c->all_kl.p; P.all_lbd = (uint8_t*)c->all_lbd.p;
-    P.n_all = (int32_t*)c->n_all.p; P.status = (int32_t*)c->status.p; P.prof = (long long*)c->prof.p;
+    P.n_all = (int32_t*)c->n_all.p; P.status = (int32_t*)c->status.p; P.prof = (long long*)c->prof.p; P.grow_stats = (int32_t*)c->grow_stats.p;
     c->capB = B;
     return PLP_OK;
 }
@@ -321,6 +321,10 @@ plp_status plp_line_debug_read(plp_line* c, plp_line_debug_id what, int32_t fram
             if (cnt) PLP_HIP(hipMemcpy(dst, src, (size_t)cnt * rec, hipMemcpyDeviceToHost));
             *n_out = cnt; return PLP_OK;
         }
+        case PLP_LINE_DBG_GROW_STATS:
+            if (dst_bytes < 16) return set_error(PLP_ERR_CAPACITY, "dst too small");
+            PLP_HIP(hipMemcpy(dst, P.grow_stats + (size_t)frame * 4, 16, hipMemcpyDeviceToHost));
+            *n_out = 4; return PLP_OK;
         case PLP_LINE_DBG_SOBEL_DX:
         case PLP_LINE_DBG_SOBEL_DY:
             if (dst_bytes < full * 2) return set_error(PLP_ERR_CAPACITY, "dst too small");

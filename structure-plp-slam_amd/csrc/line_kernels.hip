@@ -283,7 +283,7 @@ __device__ __forceinline__ void set_used(const GrowCtx& g, int p) { atomicOr(&g.
 // seed_cs: (float)cos / (float)sin of the seed's f64 angle when the caller has them (it evaluates them for 64 seeds in
 // one go: a sincos here runs with 64 lanes computing the same value), else NULL.
 __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed_deg, const float2* seed_cs, double prec, float c_pass,
-                           float c_fail, double& reg_angle) {
+                           float c_fail, double& reg_angle, int* n_exact_tests = nullptr) {
     const int lane = g.lane;
     int nreg = 1;
     const int sx = seed % g.sw, sy = seed / g.sw;
@@ -341,6 +341,7 @@ __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed
             const unsigned long long before = P ? ((P & (0ull - P)) - 1ull) : ~0ull;
             unsigned long long bal = P;
             if (U & before) {
+                if (n_exact_tests) ++*n_exact_tests;
                 if (!theta_valid) { reg_angle = (double)fast_atan2_deg_l(sumdy, sumdx) * (3.14159265358979323846 / 180); theta_valid = true; }
                 bal = __builtin_amdgcn_ballot_w64(aligned_to((double)deg * (3.14159265358979323846 / 180), reg_angle, prec)) & elig;
             }
@@ -548,6 +549,7 @@ __global__ __launch_bounds__(256) void k_lsd_grow(LinePlanes P, LsdParams lp, in
     float4* raw = P.raw + (size_t)b * kLineCap;
     int n_lines = 0;
     long long t_grow = 0, t_rect = 0, t_refine = 0, n_seed = 0, n_pix = 0;
+    int n_exact_tests = 0;
     // phase clocks only for the frame that reports them (every s_memtime is a scalar-memory round trip the wave waits for)
     const bool prof_on = P.prof != nullptr && b == 0;
     auto tick = [&]() -> long long { return prof_on ? clock64() : 0ll; };
@@ -574,7 +576,7 @@ __global__ __launch_bounds__(256) void k_lsd_grow(LinePlanes P, LsdParams lp, in
             double reg_angle, cen[3];
             long long t0 = tick();
             const float2 seed_cs = make_float2(bcast_f(s_cs.x, t), bcast_f(s_cs.y, t));
-            int nreg = region_grow(g, seed, true, bcast_f(s_deg, t), &seed_cs, lp.prec, lp.c_pass, lp.c_fail, reg_angle);
+            int nreg = region_grow(g, seed, true, bcast_f(s_deg, t), &seed_cs, lp.prec, lp.c_pass, lp.c_fail, reg_angle, &n_exact_tests);
             t_grow += tick() - t0; ++n_seed; n_pix += nreg;
             if (nreg < lp.min_reg_size) continue;
             Rect rec;
@@ -681,6 +683,7 @@ __global__ __launch_bounds__(256) void k_lsd_grow(LinePlanes P, LsdParams lp, in
         }
     }
     if (lane == 0) P.n_raw[b] = min(n_lines, kLineCap);
+    if (lane == 0) { int32_t* gs = P.grow_stats + (size_t)b * 4; gs[0] = (int32_t)n_seed; gs[1] = (int32_t)n_pix; gs[2] = n_exact_tests; gs[3] = 0; }
     if (lane == 0 && prof_on) {   // diagnostics of frame 0: cycles per phase
         P.prof[0] = clock64() - t_begin; P.prof[1] = t_grow; P.prof[2] = t_rect; P.prof[3] = t_refine; P.prof[4] = n_seed; P.prof[5] = n_pix;
     }

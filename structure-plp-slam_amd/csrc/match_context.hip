@@ -70,7 +70,7 @@ plp_status run_device(plp_matcher* c, const plp_match_args* a, hipStream_t st) {
     PLP_HIP(c->row_start.reserve((size_t)a->B * 4104 * 2));
     if (!c->dbg.p) { PLP_HIP(c->dbg.reserve(16)); PLP_HIP(hipMemsetAsync(c->dbg.p, 0, 16, st)); }
     MatchProblem P{};
-    P.mode = a->mode; P.n_cap = a->n_cap; P.m_cap = a->m_cap;
+    P.mode = a->mode; P.n_cap = a->n_cap; P.m_cap = a->m_cap; P.q_desc_stride = a->q_desc_stride > 0 ? a->q_desc_stride : a->m_cap;
     P.t_kps = (a->mode == PLP_MATCH_MODE_LANDMARKS || a->mode == PLP_MATCH_MODE_LAST_FRAME || a->mode == PLP_MATCH_MODE_FUSE) ? a->t_kps : nullptr;
     P.q_group = a->q_group; P.t_group = a->t_group; P.q_reproj_d = a->q_reproj_d; P.out_query_best = a->out_query_best;
     P.hamm_dist_thr = a->hamm_dist_thr; P.level_window = a->level_window; P.flags = a->flags;
@@ -130,6 +130,7 @@ plp_status plp_match_device(plp_matcher* c, const plp_match_args* a, void* hip_s
 plp_status plp_match_host(plp_matcher* c, const plp_match_args* a) {
     if (!c) return set_error(PLP_ERR_INVALID_ARG, "ctx is NULL");
     PLP_TRY(check_args(a));
+    if (a->q_desc_stride != 0 && a->q_desc_stride != a->m_cap) return set_error(PLP_ERR_UNSUPPORTED, "q_desc_stride is a device-path option (overlapping query windows of a batched replay)");
     std::lock_guard<std::mutex> lk(c->mu);
     PLP_HIP(hipSetDevice(c->device));
     hipStream_t st = c->stream;

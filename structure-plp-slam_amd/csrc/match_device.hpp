@@ -15,6 +15,7 @@ struct StagedTarget { float x, y; uint32_t packed; uint32_t t; };   // packed = 
 struct MatchProblem {
     int mode;                        // plp_match_mode
     int n_cap, m_cap;                // per-problem strides of the target / query arrays
+    int q_desc_stride;               // rows between two problems in q_desc (= m_cap unless the caller's queries overlap, plp_front.h)
     // targets = key points of the current frame (B x n_cap)
     const plp_keypoint* t_kps;       // undist_keypts_ (NULL in brute-force mode)
     const uint8_t* t_desc;           // descriptors_, 32 B rows

@@ -270,7 +270,7 @@ __device__ __forceinline__ void match_topk_query(const MatchProblem& P, int b, i
     const float* t_xr = P.t_x_right ? P.t_x_right + (size_t)b * P.n_cap : nullptr;
     const uint8_t* t_occ = P.t_occupied ? P.t_occupied + (size_t)b * P.n_cap : nullptr;
     const QueryCtx c = make_query(P, q, b);
-    const uint4* qd = reinterpret_cast<const uint4*>(P.q_desc + ((size_t)b * P.m_cap + q) * 32);
+    const uint4* qd = reinterpret_cast<const uint4*>(P.q_desc + ((size_t)b * P.q_desc_stride + q) * 32);
     const uint4 q0 = qd[0], q1 = qd[1];
     unsigned long long top[kMatchK];
 #pragma unroll
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256) void k_match_topk_cells(MatchProblem P) {
         if (active) {
             const QueryCtx c = make_query(P, q, b);
             if (!c.empty) {
-                const uint4* qd = reinterpret_cast<const uint4*>(P.q_desc + ((size_t)b * P.m_cap + q) * 32);
+                const uint4* qd = reinterpret_cast<const uint4*>(P.q_desc + ((size_t)b * P.q_desc_stride + q) * 32);
                 const uint4 q0 = qd[0], q1 = qd[1];
                 const bool check_level = (0 < c.min_level) || (0 <= c.max_level);
                 // Two phases so that the descriptor gathers of a lane are in flight together: (1) walk the column
@@ -540,7 +540,7 @@ __global__ __launch_bounds__(256) void k_match_topk_lds(MatchProblem P) {
         uint32_t* klist = P.klist + ((size_t)b * P.m_cap + q) * kMatchK;
         int32_t* kcount = P.kcount + (size_t)b * P.m_cap + q;
         if (q_valid && !q_valid[q]) { if (lane == 0) *kcount = -1; continue; }
-        const uint4* qd = reinterpret_cast<const uint4*>(P.q_desc + ((size_t)b * P.m_cap + q) * 32);
+        const uint4* qd = reinterpret_cast<const uint4*>(P.q_desc + ((size_t)b * P.q_desc_stride + q) * 32);
         const uint4 q0 = qd[0], q1 = qd[1];
         unsigned long long top[kMatchK];
 #pragma unroll
@@ -642,7 +642,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                         else { second = e8[e] >> 20; second_lvl = (int)((e8[e] >> 16) & 15); }
                         ++found;
                     }
-                    if (found < need && cnt > kMatchK) full_list[atomicAdd(&s_full_n, 1)] = q;   // exact rescan below
+                    // The truncated list ran dry (every entry taken, or only the best found) although the window holds more
+                    // candidates.  Whatever lies beyond the list is at least as far as its last entry, d8 -- often that alone
+                    // decides: no acceptable best exists beyond it (d8 above the mode's distance threshold), or the best that was
+                    // found passes (or fails) its test against ANY second-best >= d8.  Only the rest needs the exact rescan.
+                    bool rescan = found < need && cnt > kMatchK;
+                    if (rescan && P.mode != PLP_MATCH_MODE_TRIANGULATION) {
+                        const unsigned d8 = e8[kMatchK - 1] >> 20;
+                        const bool lm = P.mode == PLP_MATCH_MODE_LANDMARKS || P.mode == PLP_MATCH_MODE_LANDMARKS_LINE;
+                        const unsigned thr = (lm || is_last_frame_mode(P.mode)) ? (is_last_frame_mode(P.mode) && P.hamm_dist_thr > 0 ? (unsigned)P.hamm_dist_thr : 100u) : 50u;
+                        if (found == 0) { if (d8 > thr) rescan = false; }                       // nothing acceptable is left: no claim
+                        else if (best > thr) rescan = false;                                      // (found == 1, need == 2) rejected whatever the second is
+                        else if (lm) { if (!((float)best > __fmul_rn(P.lowe_ratio, (float)d8))) { rescan = false; second = d8; second_lvl = -2; } }
+                        else if (!(__fmul_rn(P.lowe_ratio, (float)d8) < (float)best)) { rescan = false; second = d8; }
+                    }
+                    if (rescan) full_list[atomicAdd(&s_full_n, 1)] = q;   // exact rescan below
                     else { decided = true; if (found > 0 && accept(P, best, best_lvl, second, second_lvl)) new_claim = best_t; }
                 }
             }
@@ -653,7 +667,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             for (int f = wv; f < nf; f += 4) {
                 const int fq = full_list[f];
                 const QueryCtx c = make_query(P, fq, b);
-                const uint4* qd = reinterpret_cast<const uint4*>(P.q_desc + ((size_t)b * P.m_cap + fq) * 32);
+                const uint4* qd = reinterpret_cast<const uint4*>(P.q_desc + ((size_t)b * P.q_desc_stride + fq) * 32);
                 const uint4 q0 = qd[0], q1 = qd[1];
                 unsigned long long k0 = ~0ull, k1 = ~0ull;
                 if (use_sorted) {
@@ -815,7 +829,7 @@ __global__ __launch_bounds__(256) void k_match_fuse(MatchProblem P) {
     const uint8_t* t_desc = P.t_desc + (size_t)b * P.n_cap * 32;
     const float* t_xr = P.t_x_right ? P.t_x_right + (size_t)b * P.n_cap : nullptr;
     const QueryCtx c = make_query(P, q, b);
-    const uint4* qd = reinterpret_cast<const uint4*>(P.q_desc + ((size_t)b * P.m_cap + q) * 32);
+    const uint4* qd = reinterpret_cast<const uint4*>(P.q_desc + ((size_t)b * P.q_desc_stride + q) * 32);
     const uint4 q0 = qd[0], q1 = qd[1];
     unsigned long long best = ~0ull;
     if (!c.empty)

@@ -270,25 +270,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             if (!dense2 && !((bits2[ty] >> tx) & 1ull)) continue;
             const uint8_t* c = &tile[(ty + 3) * kTileW + tx + 4];
             const int v = c[0];
-            int d[16];
-            d[0] = c[3 * kTileW] - v;        d[1] = c[3 * kTileW + 1] - v;    d[2] = c[2 * kTileW + 2] - v;   d[3] = c[kTileW + 3] - v;
-            d[4] = c[3] - v;                 d[5] = c[-kTileW + 3] - v;       d[6] = c[-2 * kTileW + 2] - v;  d[7] = c[-3 * kTileW + 1] - v;
-            d[8] = c[-3 * kTileW] - v;       d[9] = c[-3 * kTileW - 1] - v;   d[10] = c[-2 * kTileW - 2] - v; d[11] = c[-kTileW - 3] - v;
-            d[12] = c[-3] - v;               d[13] = c[kTileW - 3] - v;       d[14] = c[2 * kTileW - 2] - v;  d[15] = c[3 * kTileW - 1] - v;
-            // sliding min / max over windows of 9 on the ring, by doubling
-            int mn2[16], mx2[16], mn4[16], mx4[16];
+            // The 16 ring differences d[k] = p_k - v (|d| <= 255) as eight i16 pairs P[k] = (d[k], d[k + 8]): one packed min / max
+            // works on two ring positions, and a pair whose first index runs past 7 is the half-swapped pair of index - 8.  Sliding
+            // min / max over windows of 9 by doubling, as before (mn2, mn4, then mn9[k] = min(mn4[k], mn4[k + 4], d[k + 8])), in 40
+            // packed registers at most instead of 80 scalar ones: the kernel keeps 8 waves per SIMD without scratch (the scalar
+            // version spilled 9 VGPRs, and its scratch stores were this kernel's whole HBM write stream).
+            typedef short v2s __attribute__((ext_vector_type(2)));
+            auto pair = [&](int o_lo, int o_hi) -> v2s { v2s r; r.x = (short)((int)c[o_lo] - v); r.y = (short)((int)c[o_hi] - v); return r; };
+            auto sw = [](v2s x) -> v2s { return __builtin_shufflevector(x, x, 1, 0); };
+            v2s P[8];
+            P[0] = pair(3 * kTileW, -3 * kTileW);          P[1] = pair(3 * kTileW + 1, -3 * kTileW - 1);
+            P[2] = pair(2 * kTileW + 2, -2 * kTileW - 2);  P[3] = pair(kTileW + 3, -kTileW - 3);
+            P[4] = pair(3, -3);                            P[5] = pair(-kTileW + 3, kTileW - 3);
+            P[6] = pair(-2 * kTileW + 2, 2 * kTileW - 2);  P[7] = pair(-3 * kTileW + 1, 3 * kTileW - 1);
+            v2s n2[8], x2[8];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) { mn2[k] = min(d[k], d[(k + 1) & 15]); mx2[k] = max(d[k], d[(k + 1) & 15]); }
-#pragma unroll
-            for (int k = 0; k < 16; ++k) { mn4[k] = min(mn2[k], mn2[(k + 2) & 15]); mx4[k] = max(mx2[k], mx2[(k + 2) & 15]); }
-            int bright = -255, dark = 255;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int mn9 = min3(mn4[k], mn4[(k + 4) & 15], d[(k + 8) & 15]);
-                const int mx9 = max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
-                bright = max(bright, mn9);
-                dark = min(dark, mx9);
+            for (int k = 0; k < 8; ++k) {
+                const v2s nxt = k < 7 ? P[k + 1] : sw(P[0]);
+                n2[k] = __builtin_elementwise_min(P[k], nxt); x2[k] = __builtin_elementwise_max(P[k], nxt);
             }
+            v2s n4[8], x4[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                n4[k] = __builtin_elementwise_min(n2[k], k < 6 ? n2[k + 2] : sw(n2[k - 6]));
+                x4[k] = __builtin_elementwise_max(x2[k], k < 6 ? x2[k + 2] : sw(x2[k - 6]));
+            }
+            v2s br, dk;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const v2s d8 = sw(P[k]);                                  // (d[k + 8], d[k])
+                const v2s mn9 = __builtin_elementwise_min(__builtin_elementwise_min(n4[k], k < 4 ? n4[k + 4] : sw(n4[k - 4])), d8);
+                const v2s mx9 = __builtin_elementwise_max(__builtin_elementwise_max(x4[k], k < 4 ? x4[k + 4] : sw(x4[k - 4])), d8);
+                br = k ? __builtin_elementwise_max(br, mn9) : mn9;
+                dk = k ? __builtin_elementwise_min(dk, mx9) : mx9;
+            }
+            const int bright = max((int)br.x, (int)br.y), dark = min((int)dk.x, (int)dk.y);
             const int sc = max(bright, -dark) - 1;
             score[(ty + 1) * kScoreW + tx + 1] = (uint8_t)(sc >= thr ? sc : 0);
         }

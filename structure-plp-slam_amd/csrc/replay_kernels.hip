@@ -1,0 +1,77 @@
+// Batched replay helpers: the queries of the tracker's per-frame matcher calls, built on the device from the
+// features of the preceding frames of the batch.  In the reference, tracking_module reprojects the previous frame's landmarks with
+// the motion model (module/frame_tracker.cc:54-101) and the local map (tracking_module.cc:908-1064); a replay without a map stands
+// in a camera that pans by a fixed pixel shift per frame, so "reprojection" is the previous key point moved by that shift.
+// One launch per feature kind replaces the chain of tensor slices, additions, concatenations and copies that bench.py used to issue
+// (about forty small launches per step, a third of the matching stage's time).  C ABI: include/plp_front.h.
+#include <hip/hip_runtime.h>
+
+#include "plp_common.hpp"
+
+namespace plp {
+
+// grid = (ceil(cap / 256), B), block = 256
+__global__ __launch_bounds__(256) void k_replay_point_queries(const plp_keypoint* __restrict__ kps, const int32_t* __restrict__ counts, int halo, int cap, float sx,
+                                                              float sy, float2* __restrict__ q1_reproj, int32_t* __restrict__ q1_level, float* __restrict__ q1_angle,
+                                                              int32_t* __restrict__ q1_counts, float2* __restrict__ q2_reproj, int32_t* __restrict__ q2_level,
+                                                              uint8_t* __restrict__ q2_valid) {
+    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= cap) return;
+    const int f1 = halo + b - 1, f2 = halo + b - 2;            // frames b-1 and b-2 in the (halo + B)-frame feature arrays
+    const int c1 = min(max(counts[f1], 0), cap), c2 = min(max(counts[f2], 0), cap);
+    const plp_keypoint k1 = kps[(size_t)f1 * cap + i], k2 = kps[(size_t)f2 * cap + i];
+    const size_t o1 = (size_t)b * cap + i;
+    q1_reproj[o1] = make_float2(__fadd_rn(k1.x, sx), __fadd_rn(k1.y, sy));
+    q1_level[o1] = k1.octave; q1_angle[o1] = k1.angle;
+    if (i == 0) q1_counts[b] = c1;
+    // local landmarks of frame b: the key points of frame b-2 (two shifts away), then those of frame b-1
+    const size_t o2 = (size_t)b * 2 * cap;
+    q2_reproj[o2 + i] = make_float2(__fadd_rn(k2.x, __fmul_rn(2.f, sx)), __fadd_rn(k2.y, __fmul_rn(2.f, sy)));
+    q2_level[o2 + i] = k2.octave; q2_valid[o2 + i] = i < c2;
+    q2_reproj[o2 + cap + i] = make_float2(__fadd_rn(k1.x, sx), __fadd_rn(k1.y, sy));
+    q2_level[o2 + cap + i] = k1.octave; q2_valid[o2 + cap + i] = i < c1;
+}
+
+__global__ __launch_bounds__(256) void k_replay_line_queries(const plp_keyline* __restrict__ kl, const int32_t* __restrict__ counts, int halo, int cap, float sx, float sy,
+                                                             float2* __restrict__ q_sp, float2* __restrict__ q_ep, int32_t* __restrict__ q_level,
+                                                             int32_t* __restrict__ q_counts) {
+    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= cap) return;
+    const int f1 = halo + b - 1;
+    const plp_keyline k = kl[(size_t)f1 * cap + i];
+    const size_t o = (size_t)b * cap + i;
+    q_sp[o] = make_float2(__fadd_rn(k.startPointX, sx), __fadd_rn(k.startPointY, sy));
+    q_ep[o] = make_float2(__fadd_rn(k.endPointX, sx), __fadd_rn(k.endPointY, sy));
+    q_level[o] = k.octave;
+    if (i == 0) q_counts[b] = min(max(counts[f1], 0), cap);
+}
+
+}  // namespace plp
+
+using namespace plp;
+
+extern "C" {
+
+plp_status plp_replay_point_queries_device(const plp_keypoint* feat_kps, const int32_t* feat_counts, int32_t halo, int32_t B, int32_t cap, float shift_x,
+                                           float shift_y, float* q1_reproj, int32_t* q1_level, float* q1_angle, int32_t* q1_counts, float* q2_reproj,
+                                           int32_t* q2_level, uint8_t* q2_valid, void* hip_stream) {
+    if (!feat_kps || !feat_counts || !q1_reproj || !q1_level || !q1_angle || !q1_counts || !q2_reproj || !q2_level || !q2_valid)
+        return set_error(PLP_ERR_INVALID_ARG, "NULL argument");
+    if (halo < 2 || B <= 0 || cap <= 0) return set_error(PLP_ERR_INVALID_ARG, "halo must be >= 2, B and cap positive");
+    hipLaunchKernelGGL(k_replay_point_queries, dim3((cap + 255) / 256, B), dim3(256), 0, (hipStream_t)hip_stream, feat_kps, feat_counts, halo, cap, shift_x, shift_y,
+                       reinterpret_cast<float2*>(q1_reproj), q1_level, q1_angle, q1_counts, reinterpret_cast<float2*>(q2_reproj), q2_level, q2_valid);
+    PLP_HIP(hipGetLastError());
+    return PLP_OK;
+}
+
+plp_status plp_replay_line_queries_device(const plp_keyline* feat_kl, const int32_t* feat_counts, int32_t halo, int32_t B, int32_t cap, float shift_x,
+                                          float shift_y, float* q_sp, float* q_ep, int32_t* q_level, int32_t* q_counts, void* hip_stream) {
+    if (!feat_kl || !feat_counts || !q_sp || !q_ep || !q_level || !q_counts) return set_error(PLP_ERR_INVALID_ARG, "NULL argument");
+    if (halo < 1 || B <= 0 || cap <= 0) return set_error(PLP_ERR_INVALID_ARG, "halo must be >= 1, B and cap positive");
+    hipLaunchKernelGGL(k_replay_line_queries, dim3((cap + 255) / 256, B), dim3(256), 0, (hipStream_t)hip_stream, feat_kl, feat_counts, halo, cap, shift_x, shift_y,
+                       reinterpret_cast<float2*>(q_sp), reinterpret_cast<float2*>(q_ep), q_level, q_counts);
+    PLP_HIP(hipGetLastError());
+    return PLP_OK;
+}
+
+}  // extern "C"

@@ -54,6 +54,50 @@ def exchange_halo(tensors, halo=2, group=None, mode="ring"):
     return out
 
 
+def exchange_halo_into(buffers, halo=2, group=None, mode="ring"):
+    """buffers: feature tensors laid out [halo + B, ...] -- rows halo.. hold this rank's block (the extractors write there), rows
+    0..halo-1 receive the predecessor's tail.  Same single exchange as exchange_halo, without re-concatenating the block: the
+    matchers then read `buffer[halo - 1 + b]` as frame b's predecessor straight from the array the extractor filled."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        for t in buffers:
+            t[:halo].copy_(t[-halo:])          # single rank: circular replay inside the block
+        return
+    tails = exchange_halo([t[halo:] for t in buffers], halo=halo, group=group, mode=mode)
+    for t, tail in zip(buffers, tails):
+        t[:halo].copy_(tail)
+
+
+class point_queries:
+    """Device-side builder of the tracker's per-frame queries in a replay (plp_replay_point_queries_device): outputs are allocated
+    once and rewritten every step."""
+
+    def __init__(self, plp, B, cap, device):
+        import torch
+        self.plp, self.B, self.cap = plp, B, cap
+        z = lambda shape, dt: torch.empty(shape, dtype=dt, device=device)
+        self.q1_reproj, self.q1_level, self.q1_angle, self.q1_counts = z((B, cap, 2), torch.float32), z((B, cap), torch.int32), z((B, cap), torch.float32), z((B,), torch.int32)
+        self.q2_reproj, self.q2_level, self.q2_valid = z((B, 2 * cap, 2), torch.float32), z((B, 2 * cap), torch.int32), z((B, 2 * cap), torch.uint8)
+
+    def build(self, feat_kps, feat_counts, halo, shift, stream):
+        """feat_kps: uint8 [halo + B, cap, 28]; feat_counts: int32 [halo + B]"""
+        self.plp._check(self.plp.lib().plp_replay_point_queries_device(feat_kps.data_ptr(), feat_counts.data_ptr(), halo, self.B, self.cap, float(shift[0]), float(shift[1]),
+                                                                       self.q1_reproj.data_ptr(), self.q1_level.data_ptr(), self.q1_angle.data_ptr(), self.q1_counts.data_ptr(),
+                                                                       self.q2_reproj.data_ptr(), self.q2_level.data_ptr(), self.q2_valid.data_ptr(), stream.cuda_stream))
+
+
+class line_queries:
+    def __init__(self, plp, B, cap, device):
+        import torch
+        self.plp, self.B, self.cap = plp, B, cap
+        z = lambda shape, dt: torch.empty(shape, dtype=dt, device=device)
+        self.q_sp, self.q_ep, self.q_level, self.q_counts = z((B, cap, 2), torch.float32), z((B, cap, 2), torch.float32), z((B, cap), torch.int32), z((B,), torch.int32)
+
+    def build(self, feat_kl, feat_counts, halo, shift, stream):
+        self.plp._check(self.plp.lib().plp_replay_line_queries_device(feat_kl.data_ptr(), feat_counts.data_ptr(), halo, self.B, self.cap, float(shift[0]), float(shift[1]),
+                                                                      self.q_sp.data_ptr(), self.q_ep.data_ptr(), self.q_level.data_ptr(), self.q_counts.data_ptr(),
+                                                                      stream.cuda_stream))
+
+
 def with_halo(t, halo_t):
     """[halo + B, ...]: predecessor frames in front, so frame b's predecessors are rows b+halo-1, b+halo-2."""
     return torch.cat([halo_t, t], 0)
