@@ -191,7 +191,8 @@ plp_status plp_line_get_stage_times(plp_line* ctx, double* ms9, int64_t* n_batch
 
 /* Stage read-back for parity tests (synchronous, host destination, frame of the last call):
  *   SCALED   u8 sh x sw dense (the 11-tap blur + x0.5 image LSD works on)
- *   ORDER    int32 seed order (pixel index y*sw + x), (sh-1)*(sw-1) entries
+ *   ORDER    int32 seed order (pixel index y*sw + x) of the pixels whose level-line angle is defined (gradient magnitude > rho):
+ *            region growing starts nowhere else, so only those are ordered
  *   RAW      float x 4 per LSD segment (x1,y1,x2,y2), in detection order
  *   ALL_KL   plp_keyline of every segment longer than min_length (before the >= 60 px filter)
  *   ALL_LBD  32 bytes per ALL_KL record

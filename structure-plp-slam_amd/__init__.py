@@ -370,7 +370,7 @@ class LineFeatureTracker:
         else:
             a = np.zeros(4 * r.value * c.value + 4 * (r.value + c.value) + 8, np.int16)
         _check(lib().plp_line_debug_read(self._h, what, frame, _p(a), a.nbytes, C.byref(n)))
-        if what in (self.DBG_RAW, self.DBG_ALL_KL, self.DBG_ALL_LBD):
+        if what in (self.DBG_RAW, self.DBG_ALL_KL, self.DBG_ALL_LBD, self.DBG_ORDER):
             return a[:n.value].copy()
         if what in (self.DBG_SOBEL_DX, self.DBG_SOBEL_DY):
             return a[:n.value].copy()

@@ -1,10 +1,17 @@
-// Separable fixed-point Gaussian blur of one 128 x 64 output tile (cv::GaussianBlur on CV_8U: 8.8 taps that sum
+// Separable fixed-point Gaussian blur of one 128 x 32 output tile (cv::GaussianBlur on CV_8U: 8.8 taps that sum
 // to 256, out = (sum_j k[j] * (sum_i k[i] * src) + 32768) >> 16, BORDER_REFLECT_101), shared by the ORB 7-tap
-// blur (all pyramid levels) and the 11-/5-tap blurs of the line front-end.
+// blur (all pyramid levels) and the 11-/5-tap blurs of the line front-end.  Integer arithmetic throughout, no
+// intermediate rounding, so only the sums matter, not how they are grouped.
 //
-// 256 threads.  LDS: input rows with an 8-byte aligned left pad (so the global reads are aligned dwords),
-// horizontal sums as u16.  Horizontal pass: a thread makes 4 adjacent sums from 4+2R byte reads.  Vertical
-// pass: a thread owns 4 adjacent columns x 8 rows and slides a (2R+1)-row register window down the strip.
+// 256 threads, three phases:
+//   stage       input rows with an 8-byte left pad as aligned dwords; rows are reflected by index, the few dwords of a row
+//               that straddle the left / right image border are patched byte-wise by a second small pass (border tiles only)
+//   horizontal  a work item makes 4 adjacent sums for TWO rows: v_dot4_u32_u8 of aligned LDS dwords against taps that are
+//               pre-shifted to the window's byte offset (wave-uniform constants: no v_alignbyte), stored as (row 2p, row 2p+1)
+//               u16 pairs -- the layout the vertical pass multiplies directly
+//   vertical    a thread owns 4 columns x 4 rows: v_dot2_u32_u16 of the row pairs against tap pairs ((k0,k1),(k2,k3).. for
+//               an even output row, (0,k0),(k1,k2).. for an odd one): K/2+1 instructions per output instead of K multiply-adds
+//               on unpacked values; the four output bytes are cut out with v_perm_b32 (the sums cannot exceed 255 << 16)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -23,97 +30,121 @@ __device__ __forceinline__ int blur_reflect101(int p, int len) {
 template <int R>
 struct BlurTileLds {
     static constexpr int IW = kBlurTW + 2 * kBlurPad;          // 144 bytes per input row
-    static constexpr int IH = kBlurTH + 2 * R;
+    static constexpr int IH = kBlurTH + 2 * R;                 // even
+    static constexpr int NPR = IH / 2;                         // row pairs
     uint8_t in[IH * IW];
-    uint16_t hs[IH * kBlurTW];
+    uint32_t hs2[NPR * kBlurTW];                               // horizontal sums, (row 2p | row 2p+1 << 16) per column
 };
+
+typedef unsigned short blur_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t blur_dot2(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(blur_us2, a), __builtin_bit_cast(blur_us2, b), c, false);
+}
 
 // src: plane base (4-byte aligned, pitch % 4 == 0), dst: output plane (pitch % 4 == 0, rows padded to a multiple of 4)
 template <int R>
 __device__ __forceinline__ void blur_tile(BlurTileLds<R>& S, const uint8_t* __restrict__ src, int src_pitch, uint8_t* __restrict__ dst,
                                           int dst_pitch, int w, int h, int tx0, int ty0, const int* __restrict__ taps) {
-    constexpr int K = 2 * R + 1, IW = BlurTileLds<R>::IW, IH = BlurTileLds<R>::IH, DW = IW / 4;
+    constexpr int K = 2 * R + 1, IW = BlurTileLds<R>::IW, IH = BlurTileLds<R>::IH, DW = IW / 4, NPR = BlurTileLds<R>::NPR;
+    static_assert(IH % 2 == 0 && kBlurRS == 4, "row pairs");
     const int tid = threadIdx.x;
-    // ---- stage input rows [ty0-R, ty0+TH+R) x columns [tx0-PAD, tx0+TW+PAD) as dwords
+    // ---- stage input rows [ty0-R, ty0+TH+R) x columns [tx0-PAD, tx0+TW+PAD): whole dwords inside the image
     for (int i = tid; i < IH * DW; i += 256) {
         const int r = i / DW, d = i - r * DW;
-        const int y = blur_reflect101(ty0 + r - R, h);
         const int x = tx0 - kBlurPad + 4 * d;
-        const uint8_t* row = src + (size_t)y * src_pitch;
-        uint32_t v;
-        if (x >= 0 && x + 3 < w) v = *reinterpret_cast<const uint32_t*>(row + x);
-        else if (x + 3 < -R || x > w - 1 + R) v = 0;                  // never read by a valid output
-        else
-            v = (uint32_t)row[blur_reflect101(x, w)] | ((uint32_t)row[blur_reflect101(x + 1, w)] << 8) |
-                ((uint32_t)row[blur_reflect101(x + 2, w)] << 16) | ((uint32_t)row[blur_reflect101(x + 3, w)] << 24);
-        *reinterpret_cast<uint32_t*>(&S.in[r * IW + 4 * d]) = v;
+        if (x >= 0 && x + 3 < w) {
+            const int y = blur_reflect101(ty0 + r - R, h);
+            *reinterpret_cast<uint32_t*>(&S.in[r * IW + 4 * d]) = *reinterpret_cast<const uint32_t*>(src + (size_t)y * src_pitch + x);
+        }
+    }
+    // dwords that straddle a border: the left pad of the first tile column (2 per row), the ones around x = w (read by
+    // outputs up to x = w-1, i.e. bytes up to w-1+R).  Uniform test: interior tiles skip the pass.
+    const int dr0 = (w - 3 - (tx0 - kBlurPad) + 3) >> 2;   // first dword with x + 3 >= w
+    if (tx0 == 0 || dr0 < DW) {
+        for (int i = tid; i < IH * 8; i += 256) {
+            const int r = i >> 3, slot = i & 7;
+            const int d = slot < 2 ? slot : dr0 + slot - 2;
+            const int x = tx0 - kBlurPad + 4 * d;
+            const bool todo = slot < 2 ? tx0 == 0 : (d >= 0 && d < DW && x <= w - 1 + R);
+            if (todo) {
+                const uint8_t* row = src + (size_t)blur_reflect101(ty0 + r - R, h) * src_pitch;
+                const uint32_t v = (uint32_t)row[blur_reflect101(x, w)] | ((uint32_t)row[blur_reflect101(x + 1, w)] << 8) |
+                                   ((uint32_t)row[blur_reflect101(x + 2, w)] << 16) | ((uint32_t)row[blur_reflect101(x + 3, w)] << 24);
+                *reinterpret_cast<uint32_t*>(&S.in[r * IW + 4 * d]) = v;
+            }
+        }
     }
     __syncthreads();
-    // ---- horizontal: 4 adjacent sums per work item.  The taps are packed four to a dword and applied with
-    // v_dot4_u32_u8 on byte windows cut from aligned LDS dwords with v_alignbyte (2-3 dot products per output
-    // instead of 2R+1 multiply-adds on single bytes).
+    // ---- horizontal
     constexpr int RU = (R + 3) / 4 * 4;           // window start rounded down to a dword: RU - R bytes of slack
     constexpr int OFF = RU - R;                   // byte offset of tap 0 of output 0 inside the first dword
-    constexpr int ND = (OFF + K + 3 + 3) / 4;     // dwords covering the 4 windows
-    constexpr int NT = (K + 3) / 4;               // packed tap dwords
-    uint32_t tp[NT];
+    constexpr int ND = (OFF + 3 + K + 3) / 4;     // dwords covering the 4 windows
+    // taps shifted by e = 0..3 bytes, four to a dword (wave-uniform)
+    uint32_t tp[4][(K + 3 + 3) / 4];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        tp[j] = 0;
+    for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (4 * j + k < K) tp[j] |= (uint32_t)taps[4 * j + k] << (8 * k);
-    }
-    for (int i = tid; i < IH * (kBlurTW / 4); i += 256) {
-        const int r = i / (kBlurTW / 4), c4 = (i - r * (kBlurTW / 4)) * 4;
-        const uint32_t* p = reinterpret_cast<const uint32_t*>(&S.in[r * IW + kBlurPad - RU + c4]);
-        uint32_t d[ND + 1];
+        for (int m = 0; m < (K + 3 + 3) / 4; ++m) {
+            tp[e][m] = 0;
 #pragma unroll
-        for (int k = 0; k < ND; ++k) d[k] = p[k];
-        d[ND] = 0;
-        uint32_t a[4];
-#pragma unroll
-        for (int o = 0; o < 4; ++o) {
-            const int sh = OFF + o;               // first byte of this output's window
-            uint32_t acc = 0;
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int q = (sh + 4 * j) >> 2, e = (sh + 4 * j) & 3;
-                const uint32_t wnd = e == 0 ? d[q] : __builtin_amdgcn_alignbyte(d[q + 1], d[q], (uint32_t)e);
-                acc = __builtin_amdgcn_udot4(wnd, tp[j], acc, false);
+            for (int k = 0; k < 4; ++k) {
+                const int t = 4 * m + k - e;
+                if (t >= 0 && t < K) tp[e][m] |= (uint32_t)taps[t] << (8 * k);
             }
-            a[o] = acc;
         }
-        uint32_t* o2 = reinterpret_cast<uint32_t*>(&S.hs[r * kBlurTW + c4]);
-        o2[0] = a[0] | (a[1] << 16);
-        o2[1] = a[2] | (a[3] << 16);
+    for (int i = tid; i < NPR * (kBlurTW / 4); i += 256) {
+        const int p = i >> 5, c4 = (i & 31) * 4;
+        uint32_t a[2][4];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const uint32_t* q = reinterpret_cast<const uint32_t*>(&S.in[(2 * p + rr) * IW + kBlurPad - RU + c4]);
+            uint32_t d[ND];
+#pragma unroll
+            for (int k = 0; k < ND; ++k) d[k] = q[k];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                constexpr int dummy = 0; (void)dummy;
+                const int s = OFF + o, q0 = s >> 2, e = s & 3;
+                uint32_t acc = 0;
+#pragma unroll
+                for (int m = 0; m < (e + K + 3) / 4; ++m) acc = __builtin_amdgcn_udot4(d[q0 + m], tp[e][m], acc, false);
+                a[rr][o] = acc;
+            }
+        }
+        uint4 v;
+        v.x = a[0][0] | (a[1][0] << 16); v.y = a[0][1] | (a[1][1] << 16); v.z = a[0][2] | (a[1][2] << 16); v.w = a[0][3] | (a[1][3] << 16);
+        *reinterpret_cast<uint4*>(&S.hs2[p * kBlurTW + c4]) = v;
     }
     __syncthreads();
-    // ---- vertical: 4 columns x 8 rows per thread; the (2R+1)-row window lives unpacked in registers (the loop is
-    // fully unrolled, so sliding it is register renaming)
+    // ---- vertical: 4 columns x 4 rows per thread
     const int cg = tid & 31, strip = tid >> 5;
     const int c4 = cg * 4, r0 = strip * kBlurRS;
     const int x = tx0 + c4;
     if (x >= w) return;
-    uint32_t win[K + kBlurRS - 1][4];
+    constexpr int NP = K / 2 + 1;                 // tap pairs per output row
+    uint32_t te[NP], to[NP];                      // even rows: (k0,k1),(k2,k3),..,(k[K-1],0); odd rows: (0,k0),(k1,k2),..
 #pragma unroll
-    for (int k = 0; k < K + kBlurRS - 1; ++k) {
-        const uint32_t* q = reinterpret_cast<const uint32_t*>(&S.hs[(r0 + k) * kBlurTW + c4]);
-        const uint32_t q0 = q[0], q1 = q[1];
-        win[k][0] = q0 & 0xffffu; win[k][1] = q0 >> 16; win[k][2] = q1 & 0xffffu; win[k][3] = q1 >> 16;
+    for (int j = 0; j < NP; ++j) {
+        te[j] = (uint32_t)taps[2 * j] | (2 * j + 1 < K ? (uint32_t)taps[2 * j + 1] << 16 : 0u);
+        to[j] = (j > 0 ? (uint32_t)taps[2 * j - 1] : 0u) | ((uint32_t)taps[2 * j] << 16);
     }
+    uint4 wp[NP + 1];
+#pragma unroll
+    for (int j = 0; j <= NP; ++j) wp[j] = *reinterpret_cast<const uint4*>(&S.hs2[(r0 / 2 + j) * kBlurTW + c4]);
 #pragma unroll
     for (int rr = 0; rr < kBlurRS; ++rr) {
         uint32_t a0 = 32768u, a1 = 32768u, a2 = 32768u, a3 = 32768u;
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const uint32_t t = (uint32_t)taps[k];
-            a0 += t * win[rr + k][0]; a1 += t * win[rr + k][1]; a2 += t * win[rr + k][2]; a3 += t * win[rr + k][3];
+        for (int j = 0; j < NP; ++j) {
+            const uint32_t t = (rr & 1) ? to[j] : te[j];
+            const uint4 v = wp[rr / 2 + j];
+            a0 = blur_dot2(v.x, t, a0); a1 = blur_dot2(v.y, t, a1); a2 = blur_dot2(v.z, t, a2); a3 = blur_dot2(v.w, t, a3);
         }
         const int y = ty0 + r0 + rr;
         if (y < h) {
-            const uint32_t packed = min(a0 >> 16, 255u) | (min(a1 >> 16, 255u) << 8) | (min(a2 >> 16, 255u) << 16) | (min(a3 >> 16, 255u) << 24);
-            *reinterpret_cast<uint32_t*>(dst + (size_t)y * dst_pitch + x) = packed;
+            // byte 2 of each sum (sum <= 255 * 65536 + 32768): v_perm_b32 selects bytes of {src0, src1}, src1 = bytes 0-3
+            const uint32_t lo = __builtin_amdgcn_perm(a1, a0, 0x0c0c0602u), hi = __builtin_amdgcn_perm(a3, a2, 0x06020c0cu);
+            *reinterpret_cast<uint32_t*>(dst + (size_t)y * dst_pitch + x) = lo | hi;
         }
     }
 }

@@ -21,7 +21,7 @@ struct plp_line {
     ResizeExactTab rt{};
     BlurTapsN t11{}, t5{};
     LbdWeightsDev w{};
-    DevBuf tabs, blur11, scaled, pix, bin, maxgrad, undef, order, reg, raw, n_raw, blur5, dx, dy, all_kl, all_lbd, n_all, status, prof, grow_stats;
+    DevBuf tabs, blur11, scaled, pix, g2, maxgrad, undef, order, n_order, reg, raw, n_raw, blur5, dx, dy, all_kl, all_lbd, n_all, status, prof, grow_stats;
     DevBuf l0copy, s_kl, s_lbd, s_fn, s_cnt;   // host-API staging
     DevBuf aligned;                             // aligned copy of odd-pitch device frames
     int s_cap = 0;
@@ -82,6 +82,11 @@ plp_status build(plp_line* c, int rows, int cols) {
     const double ang_th = 22.5, quant = 2.0;
     lp.prec = M_PI * ang_th / 180; lp.p = ang_th / 180; lp.rho = quant / std::sin(lp.prec);
     lp.c_pass = (float)std::cos(lp.prec - kLsdAngleBand); lp.c_fail = (float)std::cos(lp.prec + kLsdAngleBand);
+    {   // lsd.cpp ll_angle: a pixel is undefined when norm = sqrt((gx^2 + gy^2) / 4.0) <= rho; gx^2 + gy^2 is an integer <= 2 * 510^2
+        uint32_t g = 0;
+        while (g < 600000u && std::sqrt((double)g / 4.0) <= lp.rho) ++g;
+        lp.g2_def_min = g;
+    }
     lp.density_th = 0.6; lp.scale = 0.5; lp.n_bins = 1024; lp.refine = 1;
     const double LOG_NT = 5 * (std::log10((double)P.sw) + std::log10((double)P.sh)) / 2 + std::log10(11.0);
     lp.min_reg_size = (int)(size_t)(-LOG_NT / std::log10(lp.p));
@@ -121,14 +126,14 @@ plp_status ensure(plp_line* c, int B) {
     PLP_HIP(c->blur11.reserve((size_t)P.pitch * P.H * B)); PLP_HIP(c->blur5.reserve((size_t)P.pitch * P.H * B));
     PLP_HIP(c->scaled.reserve((size_t)P.spitch * P.sh * B));
     PLP_HIP(c->pix.reserve(n * sizeof(LsdPix) * B));
-    PLP_HIP(c->bin.reserve(n * 2 * B)); PLP_HIP(c->maxgrad.reserve(4 * ((n + 255) / 256) * (size_t)B)); PLP_HIP(c->undef.reserve((n + 63) / 64 * 8 * B));
+    PLP_HIP(c->g2.reserve(n * 4 * B)); PLP_HIP(c->n_order.reserve(4 * (size_t)B)); PLP_HIP(c->maxgrad.reserve(4 * ((n + 255) / 256) * (size_t)B)); PLP_HIP(c->undef.reserve((n + 63) / 64 * 8 * B));
     PLP_HIP(c->order.reserve(nv * 4 * B)); PLP_HIP(c->reg.reserve(n * 4 * B));
     PLP_HIP(c->raw.reserve(sizeof(float4) * kLineCap * B)); PLP_HIP(c->n_raw.reserve(4 * (size_t)B));
     PLP_HIP(c->dx.reserve(full * 4 * B));
     PLP_HIP(c->all_kl.reserve(sizeof(plp_keyline) * kLineCap * B)); PLP_HIP(c->all_lbd.reserve((size_t)32 * kLineCap * B));
     PLP_HIP(c->n_all.reserve(4 * (size_t)B)); PLP_HIP(c->status.reserve(16)); PLP_HIP(c->prof.reserve(64)); PLP_HIP(c->grow_stats.reserve(16 * (size_t)B));
     P.blur11 = (uint8_t*)c->blur11.p; P.blur5 = (uint8_t*)c->blur5.p; P.scaled = (uint8_t*)c->scaled.p;
-    P.pix = (LsdPix*)c->pix.p; P.bin = (uint16_t*)c->bin.p;
+    P.pix = (LsdPix*)c->pix.p; P.g2 = (uint32_t*)c->g2.p; P.n_order = (int32_t*)c->n_order.p;
     P.blockmax = (uint32_t*)c->maxgrad.p; P.undef = (unsigned long long*)c->undef.p;
     P.order = (uint32_t*)c->order.p; P.reg = (uint32_t*)c->reg.p; P.raw = (float4*)c->raw.p; P.n_raw = (int32_t*)c->n_raw.p;
     P.dxy = (short2*)c->dx.p; P.all_kl = (plp_keyline*)c->all_kl.p; P.all_lbd = (uint8_t*)c->all_lbd.p;
@@ -304,9 +309,10 @@ plp_status plp_line_debug_read(plp_line* c, plp_line_debug_id what, int32_t fram
             PLP_HIP(hipMemcpy2D(dst, P.sw, P.scaled + (size_t)frame * P.spitch * P.sh, P.spitch, P.sw, P.sh, hipMemcpyDeviceToHost));
             *n_out = (int64_t)n; return PLP_OK;
         case PLP_LINE_DBG_ORDER:
-            if (dst_bytes < nv * 4) return set_error(PLP_ERR_CAPACITY, "dst too small");
-            PLP_HIP(hipMemcpy(dst, P.order + (size_t)frame * nv, nv * 4, hipMemcpyDeviceToHost));
-            *n_out = (int64_t)nv; return PLP_OK;
+            PLP_HIP(hipMemcpy(&cnt, P.n_order + frame, 4, hipMemcpyDeviceToHost));
+            if (dst_bytes < (size_t)cnt * 4) return set_error(PLP_ERR_CAPACITY, "dst too small");
+            if (cnt) PLP_HIP(hipMemcpy(dst, P.order + (size_t)frame * nv, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+            *n_out = cnt; return PLP_OK;
         case PLP_LINE_DBG_RAW:
             PLP_HIP(hipMemcpy(&cnt, P.n_raw + frame, 4, hipMemcpyDeviceToHost));
             if (dst_bytes < (size_t)cnt * 16) return set_error(PLP_ERR_CAPACITY, "dst too small");

@@ -28,10 +28,11 @@ struct LinePlanes {
     uint8_t* blur11;          // 11-tap sigma 1.2 blur (LSD)          [B][H][pitch]
     uint8_t* scaled;          // INTER_LINEAR_EXACT x0.5              [B][sh][spitch]
     LsdPix* pix;              // per scaled pixel: angle / magnitude^2 / cos,sin, 16 bytes  [B][sh*sw]
-    uint16_t* bin;            // pseudo-ordering bin                  [B][sh*sw]
+    uint32_t* g2;             // gx^2 + gy^2 of the defined pixels, 0 = undefined  [B][sh*sw]
     uint32_t* blockmax;       // per gradient workgroup: max g2 over its defined pixels   [B][ceil(sh*sw/256)]
     unsigned long long* undef;     // NOTDEF bitmask, 1 bit per scaled pixel          [B][ceil(sh*sw/64)]
-    uint32_t* order;          // seed order (pixel index y*sw+x)      [B][(sh-1)*(sw-1)]
+    uint32_t* order;          // seed order (pixel index y*sw+x), defined pixels only  [B][(sh-1)*(sw-1)]
+    int32_t* n_order;         // number of seeds                      [B]
     uint32_t* reg;            // region point list scratch            [B][sh*sw]
     float4* raw; int32_t* n_raw;          // LSD segments             [B][kLineCap], [B]
     uint8_t* blur5;           // 5-tap sigma 1 blur (LBD)             [B][H][pitch]
@@ -48,6 +49,7 @@ struct LsdParams {
     float min_length;         // LSDOptions.min_length (0.125 * min(W,H))
     float keep_length;        // hard filter of line_extractor.cc:136 (60 px)
     float c_pass, c_fail;     // cos(prec - eps), cos(prec + eps): the guard band of the angle test (region_grow)
+    uint32_t g2_def_min;      // smallest gx^2 + gy^2 whose magnitude sqrt(g2 / 4.0) exceeds rho (the pixel's angle is defined)
 };
 constexpr double kLsdAngleBand = 3.5e-4;   // rad (0.02 deg) >= 2x the largest error of cv::fastAtan2 (0.0096 deg) + f32 rounding
 

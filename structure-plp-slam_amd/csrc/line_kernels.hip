@@ -7,7 +7,6 @@
 //   k_blur_plane<R>    cv::GaussianBlur u8 fixed point, (2R+1) taps (R=5: LSD sigma 1.2, R=2: LBD sigma 1)
 //   k_resize_exact     cv::resize(x0.5, INTER_LINEAR_EXACT)
 //   k_lsd_gradient     ll_angle: 2x2 gradient, magnitude (f64), level-line angle, max magnitude
-//   k_lsd_bins         pseudo-ordering bins
 //   k_lsd_order        counting sort of the seeds: bin descending, row-major inside a bin
 //   k_lsd_grow         region_grow / region2rect / refine, ONE wave per frame (the algorithm is a
 //                      sequential scan over seeds; frames run in parallel)
@@ -24,6 +23,7 @@
 
 #include "blur_tile.hpp"
 #include "line_device.hpp"
+#include "sincos_ziv.hpp"
 #include "xcd_map.hpp"
 
 namespace plp {
@@ -98,108 +98,117 @@ __global__ __launch_bounds__(256) void k_resize_exact(const uint8_t* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------ ll_angle
+// One thread per scaled pixel.  "Defined" (magnitude > rho, lsd.cpp ll_angle) is an integer test: the magnitude
+// sqrt(g2 / 4.0) is monotone in the integer g2 = gx^2 + gy^2, so the host finds the smallest defined g2 once
+// (LsdParams::g2_def_min, same f64 operations).  Only defined pixels get a record (nothing ever reads the others);
+// the g2 plane holds g2 for defined pixels and 0 otherwise -- the seed sort works from it.
 __global__ __launch_bounds__(256) void k_lsd_gradient(LinePlanes P, LsdParams lp) {
     const int b = blockIdx.y;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int n = P.sw * P.sh;
-    double norm_def = 0.0;
-    uint32_t g2_mine = 0;
+    uint32_t g2_def = 0;
     if (idx < n) {
         const int y = idx / P.sw, x = idx - y * P.sw;
-        double norm = 0.0;
-        float deg = 0.f;
-        uint32_t g2 = 0;
-        float2 cs = make_float2(0.f, 0.f);
         if (x < P.sw - 1 && y < P.sh - 1) {
             const uint8_t* s = P.scaled + ((size_t)b * P.sh + y) * P.spitch + x;
             const int DA = (int)s[P.spitch + 1] - (int)s[0];
             const int BC = (int)s[1] - (int)s[P.spitch];
             const int gx = DA + BC, gy = DA - BC;
-            g2 = (uint32_t)(gx * gx + gy * gy);
-            norm = sqrt((double)(gx * gx + gy * gy) / 4.0);
-            if (!(norm <= lp.rho)) {
-                deg = fast_atan2_deg_l((float)gx, (float)-gy);
-                const float fa = (float)((double)deg * (3.14159265358979323846 / 180));
-                cs = make_float2((float)cos((double)fa), (float)sin((double)fa));
-                norm_def = norm; g2_mine = g2;
+            const uint32_t g2 = (uint32_t)(gx * gx + gy * gy);
+            if (g2 >= lp.g2_def_min) {
+                g2_def = g2;
+                LsdPix px;
+                px.deg = fast_atan2_deg_l((float)gx, (float)-gy);
+                px.g2 = g2;
+                const float fa = (float)((double)px.deg * (3.14159265358979323846 / 180));
+                if (!sincos_ziv(fa, &px.cs.x, &px.cs.y)) px.cs = make_float2((float)cos((double)fa), (float)sin((double)fa));   // ~1 pixel in a million
+                P.pix[(size_t)b * n + idx] = px;
             }
         }
-        const size_t o = (size_t)b * n + idx;
-        LsdPix px; px.deg = deg; px.g2 = g2; px.cs = cs;
-        P.pix[o] = px;
+        P.g2[(size_t)b * n + idx] = g2_def;
     }
     // max magnitude over the defined pixels = max of g2 (the magnitude is monotone in it).  One plain store per
-    // workgroup; k_lsd_bins reduces the per-workgroup values (2.4 M same-line atomics per launch had made this kernel
+    // workgroup; k_lsd_order reduces the per-workgroup values (2.4 M same-line atomics per launch had made this kernel
     // wait 86 % of its time).
-    uint32_t g2_def = norm_def > 0.0 ? g2_mine : 0u;
+    // one 64-bit word per wave: pixels that can never seed or join a region (angle NOTDEF)
+    const unsigned long long undef = __ballot(g2_def == 0);
+    if ((threadIdx.x & 63) == 0 && blockIdx.x * 256 + (int)threadIdx.x < ((n + 63) / 64) * 64)
+        P.undef[(size_t)b * ((n + 63) / 64) + (blockIdx.x * 256 + threadIdx.x) / 64] = undef;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) g2_def = max(g2_def, (uint32_t)__shfl_xor((int)g2_def, o));
     __shared__ uint32_t s_max[4];
     if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = g2_def;
     __syncthreads();
     if (threadIdx.x == 0) P.blockmax[(size_t)b * gridDim.x + blockIdx.x] = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
-    // one 64-bit word per wave: pixels that can never seed or join a region (angle NOTDEF)
-    const unsigned long long undef = __ballot(!(norm_def > 0.0));
-    if ((threadIdx.x & 63) == 0 && blockIdx.x * 256 + (int)threadIdx.x < ((n + 63) / 64) * 64)
-        P.undef[(size_t)b * ((n + 63) / 64) + (blockIdx.x * 256 + threadIdx.x) / 64] = undef;
-}
-
-// grid = (ceil(n / 1024), B): four pixels per thread, so the per-frame maximum (the reduction of k_lsd_gradient's
-// per-workgroup values) is recomputed by a quarter of the workgroups.
-__global__ __launch_bounds__(256) void k_lsd_bins(LinePlanes P, LsdParams lp, int n_grad_blocks) {
-    const int b = blockIdx.y, idx0 = (blockIdx.x * 256 + threadIdx.x) * 4, n = P.sw * P.sh;
-    __shared__ uint32_t s_red[4];
-    uint32_t mx = 0;
-    for (int i = threadIdx.x; i < n_grad_blocks; i += 256) mx = max(mx, P.blockmax[(size_t)b * n_grad_blocks + i]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
-    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = mx;
-    __syncthreads();
-    mx = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
-    if (idx0 >= n) return;
-    const double max_grad = sqrt((double)mx / 4.0);
-    const double bin_coef = (max_grad > 0) ? (double)(lp.n_bins - 1) / max_grad : 0;
-    const LsdPix* px = P.pix + (size_t)b * n + idx0;
-    uint16_t* out = P.bin + (size_t)b * n + idx0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (idx0 + k < n) out[k] = (uint16_t)(int)(pix_mod(px[k]) * bin_coef);
 }
 
 // ------------------------------------------------------------------------------------------ seed ordering
-// One workgroup per frame; wave q owns the q-th quarter of the row-major seed sequence.
-__global__ __launch_bounds__(256) void k_lsd_order(LinePlanes P) {
+// The reference's pseudo-ordering: all pixels by gradient bin, descending (definition D1: row-major inside a bin).  Region
+// growing starts from defined pixels only, so only those are ordered -- about a third of a frame; n_order[b] of them.
+// One workgroup per frame; wave q owns the q-th quarter of the row-major pixel sequence.
+//   1  frame maximum from the gradient kernel's per-workgroup values -> bin_coef
+//   2  per 64 pixels: bin = (int)(magnitude * bin_coef) for the defined ones, per-wave histogram (LDS atomics), the defined
+//      pixels compacted as (pixel | bin << 17) into the frame's region-list scratch (free until region growing)
+//   3  exclusive scan over (bin descending, wave ascending): 4 bins per thread, shuffles, one LDS hop across waves
+//   4  per 64 compacted entries: rank among equal bins by 10 ballots (stable), scatter
+__global__ __launch_bounds__(256) void k_lsd_order(LinePlanes P, LsdParams lp, int n_grad_blocks) {
     __shared__ uint32_t cnt[4][1024];
-    __shared__ uint32_t base[1024];
+    __shared__ uint32_t s_red[4], s_wsum[4];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
-    const int vw = P.sw - 1, vh = P.sh - 1, nv = vw * vh, n = P.sw * P.sh;
-    const uint16_t* bin = P.bin + (size_t)b * n;
-    uint32_t* order = P.order + (size_t)b * nv;
+    const int n = P.sw * P.sh, nv = (P.sw - 1) * (P.sh - 1);
+    uint32_t mx = 0;
+    for (int i = tid; i < n_grad_blocks; i += 256) mx = max(mx, P.blockmax[(size_t)b * n_grad_blocks + i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+    if (lane == 0) s_red[q] = mx;
     for (int i = tid; i < 4096; i += 256) (&cnt[0][0])[i] = 0;
     __syncthreads();
-    const int per = (nv + 3) / 4, j0 = q * per, j1 = min(nv, j0 + per);
-    for (int j = j0 + lane; j < j1; j += 64) {
-        const int y = j / vw, x = j - y * vw;
-        atomicAdd(&cnt[q][bin[y * P.sw + x]], 1u);
+    mx = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
+    const double max_grad = sqrt((double)mx / 4.0);
+    const double bin_coef = (max_grad > 0) ? (double)(lp.n_bins - 1) / max_grad : 0;
+    const uint32_t* g2 = P.g2 + (size_t)b * n;
+    uint32_t* order = P.order + (size_t)b * nv;
+    const int ngroups = (n + 63) / 64, gper = (ngroups + 3) / 4, g0 = q * gper, g1 = min(ngroups, g0 + gper);
+    uint32_t* comp = P.reg + (size_t)b * n + (size_t)g0 * 64;
+    int ncomp = 0;
+    for (int g = g0; g < g1; ++g) {
+        const int pix = g * 64 + lane;
+        const uint32_t v = pix < n ? g2[pix] : 0u;
+        const unsigned long long defm = __ballot(v != 0);
+        if (!defm) continue;
+        if (v) {
+            const uint32_t bin = (uint32_t)(int)(sqrt((double)v / 4.0) * bin_coef);
+            atomicAdd(&cnt[q][bin], 1u);
+            comp[ncomp + __popcll(defm & ((1ull << lane) - 1ull))] = (uint32_t)pix | (bin << 17);
+        }
+        ncomp += __popcll(defm);
     }
     __syncthreads();
-    // bins in descending order: base[v] = number of seeds with a larger bin
-    if (tid == 0) {
-        uint32_t run = 0;
-        for (int v = 1023; v >= 0; --v) { base[v] = run; run += cnt[0][v] + cnt[1][v] + cnt[2][v] + cnt[3][v]; }
+    {   // thread t owns bins 1023-4t .. 1020-4t (descending)
+        const int v0 = 1023 - 4 * tid;
+        uint32_t c[4][4], tot = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { c[j][k] = cnt[k][v0 - j]; tot += c[j][k]; }
+        uint32_t inc = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc, o); if (lane >= o) inc += t; }
+        if (lane == 63) s_wsum[q] = inc;
+        __syncthreads();
+        uint32_t run = inc - tot;
+        for (int k = 0; k < q; ++k) run += s_wsum[k];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { cnt[k][v0 - j] = run; run += c[j][k]; }
+        if (tid == 255) P.n_order[b] = (int32_t)run;
     }
     __syncthreads();
-    for (int v = tid; v < 1024; v += 256) {   // cnt[q][v] <- first slot of wave q inside bin v
-        uint32_t run = base[v];
-        for (int k = 0; k < 4; ++k) { const uint32_t c = cnt[k][v]; cnt[k][v] = run; run += c; }
-    }
-    __syncthreads();
-    for (int g = j0; g < j1; g += 64) {
-        const int j = g + lane;
-        const bool valid = j < j1;
-        unsigned v = 0;
-        int pix = 0;
-        if (valid) { const int y = j / vw, x = j - y * vw; pix = y * P.sw + x; v = bin[pix]; }
+    for (int i0 = 0; i0 < ncomp; i0 += 64) {
+        const bool valid = i0 + lane < ncomp;
+        const uint32_t e = valid ? comp[i0 + lane] : 0u;
+        const unsigned v = e >> 17;
         unsigned long long peers = __ballot(valid);
 #pragma unroll
         for (int bit = 0; bit < 10; ++bit) {
@@ -208,8 +217,7 @@ __global__ __launch_bounds__(256) void k_lsd_order(LinePlanes P) {
         }
         if (valid) {
             const int rank = __popcll(peers & ((1ull << lane) - 1ull));
-            const uint32_t slot = cnt[q][v] + rank;
-            order[slot] = (uint32_t)pix;
+            order[cnt[q][v] + rank] = e & 0x1ffffu;
         }
         __builtin_amdgcn_wave_barrier();
         if (valid && (peers & ((1ull << lane) - 1ull)) == 0) cnt[q][v] += (uint32_t)__popcll(peers);   // one leader per bin
@@ -546,6 +554,7 @@ __global__ __launch_bounds__(256) void k_lsd_grow(LinePlanes P, LsdParams lp, in
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     const uint32_t* order = P.order + (size_t)b * nv;
+    const int n_ord = P.n_order[b];   // defined pixels only (k_lsd_order)
     float4* raw = P.raw + (size_t)b * kLineCap;
     int n_lines = 0;
     long long t_grow = 0, t_rect = 0, t_refine = 0, n_seed = 0, n_pix = 0;
@@ -554,8 +563,8 @@ __global__ __launch_bounds__(256) void k_lsd_grow(LinePlanes P, LsdParams lp, in
     const bool prof_on = P.prof != nullptr && b == 0;
     auto tick = [&]() -> long long { return prof_on ? clock64() : 0ll; };
     const long long t_begin = tick();
-    for (int base = 0; base < nv; base += 64) {
-        const bool in_range = base + lane < nv;
+    for (int base = 0; base < n_ord; base += 64) {
+        const bool in_range = base + lane < n_ord;
         const uint32_t mine = in_range ? order[base + lane] : 0u;
         // most seeds are already inside an earlier region: test the 64 USED bits in parallel, visit the rest in order
         const bool fresh = in_range && !is_used(g, (int)mine);
@@ -968,9 +977,8 @@ void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp,
     mark(1);
     const int n = P.sw * P.sh;
     hipLaunchKernelGGL(k_lsd_gradient, dim3((n + 255) / 256, B), dim3(256), 0, st, P, lp);
-    hipLaunchKernelGGL(k_lsd_bins, dim3((n + 1023) / 1024, B), dim3(256), 0, st, P, lp, (n + 255) / 256);
     mark(2);
-    hipLaunchKernelGGL(k_lsd_order, dim3(B), dim3(256), 0, st, P);
+    hipLaunchKernelGGL(k_lsd_order, dim3(B), dim3(256), 0, st, P, lp, (n + 255) / 256);
     mark(3);
     // per wave: USED bitmap + frontier ring (a power of two; the HBM copy of the region list backs larger frontiers).
     // One wave per workgroup keeps the LDS footprint small (~10.6 KB), so LDS never limits how many frames a CU hosts;
@@ -979,7 +987,12 @@ void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp,
     static const int wpb_env = [] { const char* e = getenv("PLP_LSD_WPB"); return e ? atoi(e) : 1; }();
     const size_t per_wave = (size_t)((((n + 31) / 32 + 1) & ~1) + ring) * 4;
     const int wpb = (int)std::max<size_t>(1, std::min<size_t>(std::min(4, std::max(1, wpb_env)), 65536 / per_wave));
-    hipLaunchKernelGGL(k_lsd_grow, dim3((B + wpb - 1) / wpb), dim3(64 * wpb), per_wave * wpb, st, P, lp, B, wpb, ring);
+    // diagnostic only (what the rest of a step costs without region growing): PLP_LSD_SKIP_GROW=k leaves the kernel out after
+    // the k-th launch; the later stages then chew on the previous launch's segments
+    static const int skip_after = [] { const char* e = getenv("PLP_LSD_SKIP_GROW"); return e ? atoi(e) : -1; }();
+    static int n_launch = 0;
+    if (skip_after < 0 || n_launch++ < skip_after)
+        hipLaunchKernelGGL(k_lsd_grow, dim3((B + wpb - 1) / wpb), dim3(64 * wpb), per_wave * wpb, st, P, lp, B, wpb, ring);
     mark(4);
     hipLaunchKernelGGL(k_keylines, dim3(B), dim3(64), 0, st, P, lp);
     mark(5);
