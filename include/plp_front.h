@@ -201,6 +201,9 @@ typedef enum plp_line_debug_id { PLP_LINE_DBG_SCALED = 0, PLP_LINE_DBG_ORDER = 1
                                  PLP_LINE_DBG_ALL_LBD = 4, PLP_LINE_DBG_SOBEL_DX = 5, PLP_LINE_DBG_SOBEL_DY = 6,
                                  PLP_LINE_DBG_GROW_STATS = 7 /* int32[4]: regions grown, pixels accepted, exact (in-band) decisions, 0 */ } plp_line_debug_id;
 plp_status plp_line_debug_read(plp_line* ctx, plp_line_debug_id what, int32_t frame, void* dst, size_t dst_bytes, int64_t* n_out);
+/* Host model of the LSD gradient kernel's (float)cos((double)a), (float)sin((double)a) fast path (csrc/sincos_ziv.hpp): proven[i] = 0 marks the
+ * arguments for which the kernel falls back to the general f64 routine.  Returns the number of proven arguments.  No GPU needed. */
+int32_t plp_model_sincos_host(const float* a, int64_t n, float* c, float* s, uint8_t* proven);
 plp_status plp_line_scaled_size(const plp_line* ctx, int32_t* rows, int32_t* cols);
 /* Diagnostics of frame 0 of the last batch: shader cycles {whole wave, region_grow, region2rect, refine}, regions grown, pixels grown. */
 plp_status plp_line_debug_grow_profile(plp_line* ctx, int64_t* out6);

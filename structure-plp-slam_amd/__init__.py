@@ -68,6 +68,7 @@ _API = [
     ("plp_orb_pyramid_host", C.c_int, [_VP, _I32, _I32, _VP, _SZ]),
     ("plp_orb_debug_read", C.c_int, [_VP, C.c_int, _I32, _I32, _VP, _SZ, _VP]),
     ("plp_model_quadtree_host", _I32, [_VP, _I32, _I32, _I32, C.c_uint32, _VP]),
+    ("plp_model_sincos_host", _I32, [_VP, C.c_int64, _VP, _VP, _VP]),
     ("plp_line_create", C.c_int, [C.c_int, _VP]),
     ("plp_line_destroy", None, [_VP]),
     ("plp_line_extract", C.c_int, [_VP, _VP, _I32, _I32, _SZ, _VP, _VP, _VP, _I32, _VP]),
@@ -149,6 +150,14 @@ def model_quadtree(xys, level_w, level_h, quota):
     out = np.zeros(max(len(xys), 1), np.int32)
     m = lib().plp_model_quadtree_host(_p(xys), len(xys), level_w, level_h, quota, _p(out))
     return out[:m].copy()
+
+
+def model_sincos(a):
+    """Host model of the LSD gradient kernel's cos / sin fast path (no GPU needed): (cos f32, sin f32, proven bool)"""
+    a = np.ascontiguousarray(a, np.float32)
+    c = np.zeros(a.shape, np.float32); s = np.zeros(a.shape, np.float32); ok = np.zeros(a.shape, np.uint8)
+    lib().plp_model_sincos_host(_p(a), a.size, _p(c), _p(s), _p(ok))
+    return c, s, ok.astype(bool)
 
 
 class orb_extractor:

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "line_device.hpp"
+#include "sincos_ziv.hpp"
 #include "plp_common.hpp"
 
 using namespace plp;
@@ -343,6 +344,14 @@ plp_status plp_line_debug_read(plp_line* c, plp_line_debug_id what, int32_t fram
             *n_out = (int64_t)full; return PLP_OK;
     }
     return set_error(PLP_ERR_INVALID_ARG, "unknown debug id");
+}
+
+// Host model of the gradient kernel's cos/sin (sincos_ziv.hpp), callable without a GPU: proven[i] = 1 where the rounding test
+// succeeds (the kernel uses these values), 0 where the kernel evaluates the general f64 routine.
+int32_t plp_model_sincos_host(const float* a, int64_t n, float* c, float* s, uint8_t* proven) {
+    int32_t n_proven = 0;
+    for (int64_t i = 0; i < n; ++i) { proven[i] = plp::sincos_ziv(a[i], c + i, s + i) ? 1 : 0; n_proven += proven[i]; }
+    return n_proven;
 }
 
 }  // extern "C"

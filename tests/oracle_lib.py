@@ -99,6 +99,8 @@ def _load():
         L.oracle_fast9_16.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.oracle_fast_atan2.restype = C.c_float
         L.oracle_fast_atan2.argtypes = [C.c_float, C.c_float]
+        L.oracle_f_cos_sin.restype = None
+        L.oracle_f_cos_sin.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_void_p]
         L.oracle_trig_cos.restype = C.c_float
         L.oracle_trig_cos.argtypes = [C.c_float]
         L.oracle_trig_sin.restype = C.c_float
@@ -320,6 +322,14 @@ def brute_force_match(desc1, angle1, desc2, angle2, valid2, lowe_ratio, check_or
     w = [_c(desc2, np.uint8), _c(angle2, np.float32), _c(valid2, np.uint8)]
     num = lib().oracle_brute_force_match(_p(v[0]), _p(v[1]), n1, _p(w[0]), _p(w[1]), _p(w[2]), n2, lowe_ratio, int(check_orientation), _p(out))
     return out[:n1].copy(), num
+
+
+def f_cos_sin(a):
+    """D2: (float)cos((double)a), (float)sin((double)a) with this machine's libm (lsd_restated.hpp f_cos / f_sin)"""
+    a = np.ascontiguousarray(a, np.float32)
+    c = np.zeros(a.shape, np.float32); s = np.zeros(a.shape, np.float32)
+    lib().oracle_f_cos_sin(_p(a), a.size, _p(c), _p(s))
+    return c, s
 
 
 # ---- line front-end (oracle/line_oracle.cpp)

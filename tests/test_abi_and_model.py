@@ -74,6 +74,40 @@ def test_quadtree_model_equals_oracle_list(seed):
         assert np.array_equal(got, want), (w, h, n, quota)
 
 
+def test_sincos_fast_path_equals_libm_on_every_gradient_angle():
+    """csrc/sincos_ziv.hpp (the gradient kernel's cos / sin of the level-line angle): wherever its rounding test succeeds the result
+    must be (float)cos((double)a) / (float)sin((double)a) exactly (definition D2) -- checked for EVERY angle the kernel can see (all
+    (gx, gy) with |g| <= 510, through cv::fastAtan2 and the degree -> radian conversion of lsd.cpp) and for 4 M random floats in [0, 2 pi];
+    where the test fails (a few arguments per million) the kernel calls the general f64 routine."""
+    g = np.arange(-510, 511, dtype=np.float32)
+    gx, gy = np.meshgrid(g, g)
+    deg = np.array([O.lib().oracle_fast_atan2(float(y), float(x)) for x, y in zip(gx.ravel()[::97], gy.ravel()[::97])], np.float32)
+    # the full grid through a vectorised restatement of cv::fastAtan2 (checked against the oracle's on the sample above)
+    def fast_atan2(y, x):
+        f = np.float32
+        p1, p3, p5, p7 = (f(0.9997878412794807) * f(180 / np.pi), f(-0.3258083974640975) * f(180 / np.pi), f(0.1555786518463281) * f(180 / np.pi),
+                          f(-0.04432655554792128) * f(180 / np.pi))
+        ax, ay = np.abs(x), np.abs(y)
+        eps = f(2.2204460492503131e-16)
+        big = ax >= ay
+        num, den = np.where(big, ay, ax), np.where(big, ax, ay) + eps
+        c = (num / den).astype(f); c2 = c * c
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c
+        a = np.where(big, a, f(90) - a)
+        a = np.where(x < 0, f(180) - a, a)
+        a = np.where(y < 0, f(360) - a, a)
+        return a.astype(f)
+    full = fast_atan2(gy.ravel(), gx.ravel())
+    assert np.array_equal(full[::97], deg)
+    rng = np.random.default_rng(5)
+    args = np.concatenate([(full.astype(np.float64) * (np.pi / 180)).astype(np.float32), rng.uniform(0, 2 * np.pi, 4_000_000).astype(np.float32),
+                           np.array([0.0, np.pi / 2, np.pi, 3 * np.pi / 2, 2 * np.pi], np.float32)])
+    c, s, ok = plp.model_sincos(args)
+    want_c, want_s = O.f_cos_sin(args)
+    assert ok.mean() > 0.9999
+    assert np.array_equal(c[ok], want_c[ok]) and np.array_equal(s[ok], want_s[ok])
+
+
 def test_facade_check_programs_are_built_and_load():
     """The C++ facade check programs (oracle/facade_*_check, oracle/_ref/facade_orb_check) are compiled by build(); without
     arguments they only print nothing and return 2, which proves that they link against libplp_front.so / liboracle.so."""
