@@ -23,6 +23,7 @@
 //   k_hamming_matrix    full nq x nt distance matrix, 64x64 tiles staged through LDS
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
 
 #include "match_device.hpp"
 #include "xcd_map.hpp"
@@ -393,17 +394,19 @@ __device__ __forceinline__ int row16_sum_i32(int v) {
 
 // Main path of the point projection matchers.  The workgroup copies the frame's sorted targets (16 B each), their
 // stereo coordinates and the cell index into LDS once and reuses them for kQueriesPerBlock queries.  A query is served
-// by 16 lanes (four queries per wave): lane s walks grid columns min_cx + s, + 16, ... of the window, each column being
-// one contiguous range of the sorted array, so only the window's cells are touched.  Keys are 32 bits
-// (distance << 16 | position in visiting order); the 8 best are merged with DPP row reductions.
+// by ONE lane, which walks the grid columns of its window (each column one contiguous range of the sorted array, so only the
+// window's cells are touched) and keeps its 8 best keys (distance << 16 | position in visiting order) in registers.  A window at
+// the low pyramid levels is 4-5 columns with about five candidates: the earlier 16-lanes-per-query version left two thirds of
+// its lanes idle and spent more instructions merging the lanes' lists (8 DPP row minima per query) than finding candidates.
+// Consecutive queries sit on the same pyramid level (key points are stored by level), so the lanes of a wave run similar trip counts.
 // grid = (ceil(m_cap / kQueriesPerBlock), B), block = 256, dynamic LDS = n_cap * 20 + 2 * kCellStride bytes.
-__global__ __launch_bounds__(256) void k_match_topk_cells(MatchProblem P) {
+__global__ __launch_bounds__(256) void k_match_topk_cells(MatchProblem P, int qpb) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     unsigned uqb, ub;
     xcd_frame_major(uqb, ub);   // the query blocks of a frame all stage the same sorted target array
-    const int tid = threadIdx.x, sub = tid & 15, grp = tid >> 4, b = (int)ub;
+    const int tid = threadIdx.x, b = (int)ub;
     const int m = P.q_counts ? min(P.q_counts[b], P.m_cap) : P.m_cap;
-    const int q_begin = (int)uqb * kQueriesPerBlock;
+    const int q_begin = (int)uqb * qpb;
     if (q_begin >= m) return;
     const int ncell = P.grid_cols * P.grid_rows, rows = P.grid_rows;
     const uint8_t* t_desc = P.t_desc + (size_t)b * P.n_cap * 32;
@@ -430,10 +433,9 @@ __global__ __launch_bounds__(256) void k_match_topk_cells(MatchProblem P) {
     }
     __syncthreads();
     const uint8_t* q_valid = P.q_valid ? P.q_valid + (size_t)b * P.m_cap : nullptr;
-    const int q_end = min(m, q_begin + kQueriesPerBlock);
-    for (int q = q_begin + grp; q < q_begin + kQueriesPerBlock; q += 16) {   // same trip count for every lane of the wave
-        const bool in_range = q < q_end;
-        const bool active = in_range && !(q_valid && !q_valid[q]);
+    const int q_end = min(m, q_begin + qpb);
+    for (int q = q_begin + tid; q < q_end; q += 256) {
+        const bool active = !(q_valid && !q_valid[q]);
         uint32_t top[kMatchK];
 #pragma unroll
         for (int i = 0; i < kMatchK; ++i) top[i] = 0xffffffffu;
@@ -445,9 +447,9 @@ __global__ __launch_bounds__(256) void k_match_topk_cells(MatchProblem P) {
                 const uint4 q0 = qd[0], q1 = qd[1];
                 const bool check_level = (0 < c.min_level) || (0 <= c.max_level);
                 // Two phases so that the descriptor gathers of a lane are in flight together: (1) walk the column
-                // ranges and note the positions that pass the geometric tests (up to kLaneCand per lane in an LDS
-                // slot of this thread), (2) fetch their descriptors, (3) distances and the best-8 insertion.  A lane that
-                // finds more candidates drains its slot and goes on.
+                // ranges and note the positions that pass the geometric tests (up to kLaneCand in an LDS slot of this
+                // thread), (2) fetch their descriptors, (3) distances and the best-8 insertion.  A lane that finds more
+                // candidates drains its slot and goes on.
                 uint16_t* my = s_cand + tid * kLaneCand;
                 int nc = 0;
                 auto drain = [&]() {
@@ -472,7 +474,7 @@ __global__ __launch_bounds__(256) void k_match_topk_cells(MatchProblem P) {
                     passed += nc;
                     nc = 0;
                 };
-                for (int col = c.min_cx + sub; col <= c.max_cx; col += 16) {
+                for (int col = c.min_cx; col <= c.max_cx; ++col) {
                     const int i0 = cs[col * rows + c.min_cy], i1 = cs[col * rows + c.max_cy + 1];
                     for (int i = i0; i < i1; ++i) {
                         const float2 sp = sxy[i];
@@ -493,29 +495,20 @@ __global__ __launch_bounds__(256) void k_match_topk_cells(MatchProblem P) {
                 drain();
             }
         }
-        passed = row16_sum_i32(passed);
-        uint32_t mine = 0xffffffffu;   // lane s of the group ends up with the s-th best key
+        uint32_t e[kMatchK];
 #pragma unroll
-        for (int r = 0; r < kMatchK; ++r) {
-            const uint32_t mn = row16_min_u32(top[0]);
-            if (sub == r) mine = mn;
-            if (top[0] == mn && mn != 0xffffffffu) {
-#pragma unroll
-                for (int i = 0; i + 1 < kMatchK; ++i) top[i] = top[i + 1];
-                top[kMatchK - 1] = 0xffffffffu;
+        for (int k = 0; k < kMatchK; ++k) {
+            e[k] = 0xffffffffu;
+            if (top[k] != 0xffffffffu) {
+                const uint32_t to = sto[top[k] & 0xffffu];
+                e[k] = ((top[k] >> 16) << 20) | (((to >> 16) & 15u) << 16) | (to & 0xffffu);
             }
         }
-        if (in_range) {
-            if (sub < kMatchK) {
-                uint32_t e = 0xffffffffu;
-                if (mine != 0xffffffffu) {
-                    const uint32_t to = sto[mine & 0xffffu];
-                    e = ((mine >> 16) << 20) | (((to >> 16) & 15u) << 16) | (to & 0xffffu);
-                }
-                P.klist[((size_t)b * P.m_cap + q) * kMatchK + sub] = e;
-            }
-            if (sub == 0) P.kcount[(size_t)b * P.m_cap + q] = active ? passed : -1;
-        }
+        static_assert(kMatchK == 8, "two 16-byte stores per query");
+        uint4* out = reinterpret_cast<uint4*>(P.klist + ((size_t)b * P.m_cap + q) * kMatchK);
+        out[0] = make_uint4(e[0], e[1], e[2], e[3]);
+        out[1] = make_uint4(e[4], e[5], e[6], e[7]);
+        P.kcount[(size_t)b * P.m_cap + q] = active ? passed : -1;
     }
 }
 
@@ -945,7 +938,8 @@ void launch_match(hipStream_t st, const MatchProblem& P, int B) {
     if (!line && windowed && staged <= 64 * 1024 && P.grid_cols <= 255 && P.grid_rows <= 255) {
         hipLaunchKernelGGL(k_match_prep, dim3(B), dim3(256), 0, st, P);
         Q.sorted_valid = 1;
-        hipLaunchKernelGGL(k_match_topk_cells, qgrid, dim3(256), staged, st, P);
+        static const int qpb = [] { const char* e = getenv("PLP_MATCH_QPB"); const int v = e ? atoi(e) : 256; return v >= 16 && v % 16 == 0 ? v : 256; }();
+        hipLaunchKernelGGL(k_match_topk_cells, dim3((P.m_cap + qpb - 1) / qpb, B), dim3(256), staged, st, P, qpb);
     } else if (!line && !windowed && staged <= 64 * 1024) {
         hipLaunchKernelGGL(k_match_topk_lds, qgrid, dim3(256), staged, st, P);
     } else {
