@@ -457,6 +457,11 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p) {
     __builtin_memcpy(&v, p, 4);   // global loads take any byte address on gfx950 (unaligned access mode)
     return v;
 }
+__device__ __forceinline__ uint4 load_u128_unaligned(const uint8_t* p) {
+    uint4 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
 __device__ __forceinline__ int row16_sum(int v) {
     v += __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false);   // row_ror:8
     v += __builtin_amdgcn_update_dpp(v, v, 0x124, 0xf, 0xf, false);
@@ -474,6 +479,7 @@ __global__ __launch_bounds__(256) void k_orient_rbrief(OrbPlanes pl, const uint8
                                                        int32_t* __restrict__ status) {
     __shared__ uint32_t s_w0[16][8], s_w1[16][8];   // per |v|: byte weights 1 / (u + 15) inside the disc, 0 outside
     __shared__ uint32_t s_pat[256];                 // the 256 test pairs (ax, ay, bx, by as int8)
+    __shared__ __attribute__((aligned(16))) uint8_t s_patch[16 * 37 * 48];   // per key point: the disc of the level, then the patch of the blurred level
     unsigned ublk, uframe;
     xcd_frame_major(ublk, uframe);   // a frame's patches (two planes, ~2.6 MB) stay in one L2
     const int tid = threadIdx.x, sub = tid & 15, frame = (int)uframe;
@@ -507,17 +513,30 @@ __global__ __launch_bounds__(256) void k_orient_rbrief(OrbPlanes pl, const uint8
     const int cx = (int)(pk & 0xfff) + kOrbBorder, cy = (int)((pk >> 12) & 0xfff) + kOrbBorder;   // level pixel
     const int resp = (int)(pk >> 24);
 
+    // Both patches of a key point go through LDS (s_patch: 37 rows x 48 bytes per key point): the 16 lanes fetch them with 16-byte
+    // loads, neighbouring lanes taking neighbouring pieces of a row, so that one load instruction touches ~20 cache lines instead
+    // of 64 -- the kernel used to be bound by L1 tag look-ups (32 single-byte gathers per lane for the test pairs alone).
+    uint8_t* patch = s_patch + (tid >> 4) * (37 * 48);
     // intensity centroid over the radius-15 disc (key points keep 19 pixels from the border: every load is inside)
     const uint8_t* img = pl.level_ptr(frame, level, L);
     const int pitch = pl.level_pitch(level, L);
+    {   // rows cy-15 .. cy+15, columns cx-15 .. cx+16
+        const uint8_t* p0 = img + (size_t)(cy - 15) * pitch + cx - 15;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int item = sub + 16 * it, row = item >> 1, half = item & 1;
+            if (row < 31) *reinterpret_cast<uint4*>(patch + row * 48 + 16 * half) = load_u128_unaligned(p0 + (size_t)row * pitch + 16 * half);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
     int m10 = 0, m01 = 0;
     {
         const int vA = sub - 15, vB = sub + 1;   // rows -15..0 and 1..15 (lane 15 has no second row)
-        const uint8_t* pA = img + (size_t)(cy + vA) * pitch + cx - 15;
-        const uint8_t* pB = img + (size_t)(cy + min(vB, 15)) * pitch + cx - 15;
-        uint32_t dA[8], dB[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { dA[j] = load_u32_unaligned(pA + 4 * j); dB[j] = load_u32_unaligned(pB + 4 * j); }
+        const uint4* pA = reinterpret_cast<const uint4*>(patch + (vA + 15) * 48);
+        const uint4* pB = reinterpret_cast<const uint4*>(patch + (min(vB, 15) + 15) * 48);
+        const uint4 a0 = pA[0], a1 = pA[1], b0 = pB[0], b1 = pB[1];
+        const uint32_t dA[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, dB[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
         uint32_t sA = 0, tA = 0, sB = 0, tB = 0;   // s = sum I, t = sum (u + 15) I
         const int aA = -vA, aB = min(vB, 15);
 #pragma unroll
@@ -532,10 +551,22 @@ __global__ __launch_bounds__(256) void k_orient_rbrief(OrbPlanes pl, const uint8
     m10 = row16_sum(m10); m01 = row16_sum(m01);
     const float angle = fast_atan2_deg((float)m01, (float)m10);
 
-    // rBRIEF on the blurred level
+    // rBRIEF on the blurred level: rows cy-18 .. cy+18, columns cx-18 .. cx+29 (the rotated pattern stays within +-18)
     const float arad = (float)((double)angle * 3.14159265358979323846 / 180.0);
     const float ca = ref_cos(arad), sa = ref_sin(arad);
-    const uint8_t* bl = blur_base + (size_t)frame * blur_frame_stride + L.off + (size_t)cy * L.pitch + cx;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();   // every lane of the key point has read its disc rows
+    {
+        const uint8_t* b0 = blur_base + (size_t)frame * blur_frame_stride + L.off + (size_t)(cy - 18) * L.pitch + cx - 18;
+#pragma unroll
+        for (int it = 0; it < 7; ++it) {
+            const int item = sub + 16 * it, row = item / 3, seg = item - 3 * row;
+            if (row < 37) *reinterpret_cast<uint4*>(patch + row * 48 + 16 * seg) = load_u128_unaligned(b0 + (size_t)row * L.pitch + 16 * seg);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    const uint8_t* bl = patch + 18 * 48 + 18;
     uint32_t bits = 0;
     int ta[16], tb[16];
 #pragma unroll
@@ -547,7 +578,7 @@ __global__ __launch_bounds__(256) void k_orient_rbrief(OrbPlanes pl, const uint8
         const int ac = __float2int_rn(__fsub_rn(__fmul_rn(ax, ca), __fmul_rn(ay, sa)));
         const int br = __float2int_rn(__fadd_rn(__fmul_rn(bx, sa), __fmul_rn(by, ca)));
         const int bc = __float2int_rn(__fsub_rn(__fmul_rn(bx, ca), __fmul_rn(by, sa)));
-        ta[r] = bl[ar * L.pitch + ac]; tb[r] = bl[br * L.pitch + bc];
+        ta[r] = bl[ar * 48 + ac]; tb[r] = bl[br * 48 + bc];
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) bits |= (uint32_t)(ta[r] < tb[r]) << r;
