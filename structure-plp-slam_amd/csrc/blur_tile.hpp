@@ -41,10 +41,14 @@ __device__ __forceinline__ uint32_t blur_dot2(uint32_t a, uint32_t b, uint32_t c
     return __builtin_amdgcn_udot2(__builtin_bit_cast(blur_us2, a), __builtin_bit_cast(blur_us2, b), c, false);
 }
 
-// src: plane base (4-byte aligned, pitch % 4 == 0), dst: output plane (pitch % 4 == 0, rows padded to a multiple of 4)
-template <int R>
-__device__ __forceinline__ void blur_tile(BlurTileLds<R>& S, const uint8_t* __restrict__ src, int src_pitch, uint8_t* __restrict__ dst,
-                                          int dst_pitch, int w, int h, int tx0, int ty0, const int* __restrict__ taps) {
+// Core: stage, horizontal pass, vertical pass; every thread ends with the blurred bytes of its 4 columns x 4 rows (one dword per
+// row, tile-local rows r0..r0+3, columns c4..c4+3) and hands them to emit(r0, c4, rows).  The tile origin may lie outside the image
+// (tx0 a multiple of 4, possibly negative): the blur is then evaluated on the REFLECT_101 extension of the source, which for a
+// symmetric kernel equals the REFLECT_101 extension of the blurred image -- what a following 3x3 filter wants at the border.
+// src: plane base (4-byte aligned, pitch % 4 == 0)
+template <int R, class Emit>
+__device__ __forceinline__ void blur_tile_core(BlurTileLds<R>& S, const uint8_t* __restrict__ src, int src_pitch, int w, int h, int tx0, int ty0,
+                                               const int* __restrict__ taps, Emit emit) {
     constexpr int K = 2 * R + 1, IW = BlurTileLds<R>::IW, IH = BlurTileLds<R>::IH, DW = IW / 4, NPR = BlurTileLds<R>::NPR;
     static_assert(IH % 2 == 0 && kBlurRS == 4, "row pairs");
     const int tid = threadIdx.x;
@@ -57,15 +61,15 @@ __device__ __forceinline__ void blur_tile(BlurTileLds<R>& S, const uint8_t* __re
             *reinterpret_cast<uint32_t*>(&S.in[r * IW + 4 * d]) = *reinterpret_cast<const uint32_t*>(src + (size_t)y * src_pitch + x);
         }
     }
-    // dwords that straddle a border: the left pad of the first tile column (2 per row), the ones around x = w (read by
-    // outputs up to x = w-1, i.e. bytes up to w-1+R).  Uniform test: interior tiles skip the pass.
+    // dwords outside [0, w) or straddling x = w: the left pad of the first tile column (up to 4 per row), the ones around and
+    // beyond x = w (outputs up to x = w, for a following 3x3 filter, read bytes up to w + R).  Uniform test: interior tiles skip the pass.
     const int dr0 = (w - 3 - (tx0 - kBlurPad) + 3) >> 2;   // first dword with x + 3 >= w
-    if (tx0 == 0 || dr0 < DW) {
+    if (tx0 <= 0 || dr0 < DW) {
         for (int i = tid; i < IH * 8; i += 256) {
             const int r = i >> 3, slot = i & 7;
-            const int d = slot < 2 ? slot : dr0 + slot - 2;
+            const int d = slot < 4 ? slot : dr0 + slot - 4;
             const int x = tx0 - kBlurPad + 4 * d;
-            const bool todo = slot < 2 ? tx0 == 0 : (d >= 0 && d < DW && x <= w - 1 + R);
+            const bool todo = slot < 4 ? x < 0 : (d >= 0 && d < DW && x <= w + R + 3);
             if (todo) {
                 const uint8_t* row = src + (size_t)blur_reflect101(ty0 + r - R, h) * src_pitch;
                 const uint32_t v = (uint32_t)row[blur_reflect101(x, w)] | ((uint32_t)row[blur_reflect101(x + 1, w)] << 8) |
@@ -119,8 +123,6 @@ __device__ __forceinline__ void blur_tile(BlurTileLds<R>& S, const uint8_t* __re
     // ---- vertical: 4 columns x 4 rows per thread
     const int cg = tid & 31, strip = tid >> 5;
     const int c4 = cg * 4, r0 = strip * kBlurRS;
-    const int x = tx0 + c4;
-    if (x >= w) return;
     constexpr int NP = K / 2 + 1;                 // tap pairs per output row
     uint32_t te[NP], to[NP];                      // even rows: (k0,k1),(k2,k3),..,(k[K-1],0); odd rows: (0,k0),(k1,k2),..
 #pragma unroll
@@ -131,6 +133,7 @@ __device__ __forceinline__ void blur_tile(BlurTileLds<R>& S, const uint8_t* __re
     uint4 wp[NP + 1];
 #pragma unroll
     for (int j = 0; j <= NP; ++j) wp[j] = *reinterpret_cast<const uint4*>(&S.hs2[(r0 / 2 + j) * kBlurTW + c4]);
+    uint32_t rows[kBlurRS];
 #pragma unroll
     for (int rr = 0; rr < kBlurRS; ++rr) {
         uint32_t a0 = 32768u, a1 = 32768u, a2 = 32768u, a3 = 32768u;
@@ -140,13 +143,25 @@ __device__ __forceinline__ void blur_tile(BlurTileLds<R>& S, const uint8_t* __re
             const uint4 v = wp[rr / 2 + j];
             a0 = blur_dot2(v.x, t, a0); a1 = blur_dot2(v.y, t, a1); a2 = blur_dot2(v.z, t, a2); a3 = blur_dot2(v.w, t, a3);
         }
-        const int y = ty0 + r0 + rr;
-        if (y < h) {
-            // byte 2 of each sum (sum <= 255 * 65536 + 32768): v_perm_b32 selects bytes of {src0, src1}, src1 = bytes 0-3
-            const uint32_t lo = __builtin_amdgcn_perm(a1, a0, 0x0c0c0602u), hi = __builtin_amdgcn_perm(a3, a2, 0x06020c0cu);
-            *reinterpret_cast<uint32_t*>(dst + (size_t)y * dst_pitch + x) = lo | hi;
-        }
+        // byte 2 of each sum (sum <= 255 * 65536 + 32768): v_perm_b32 selects bytes of {src0, src1}, src1 = bytes 0-3
+        rows[rr] = __builtin_amdgcn_perm(a1, a0, 0x0c0c0602u) | __builtin_amdgcn_perm(a3, a2, 0x06020c0cu);
     }
+    emit(r0, c4, rows);
+}
+
+// The plain blur: the tile's bytes go to the output plane (pitch % 4 == 0, rows padded to a multiple of 4).
+template <int R>
+__device__ __forceinline__ void blur_tile(BlurTileLds<R>& S, const uint8_t* __restrict__ src, int src_pitch, uint8_t* __restrict__ dst,
+                                          int dst_pitch, int w, int h, int tx0, int ty0, const int* __restrict__ taps) {
+    blur_tile_core<R>(S, src, src_pitch, w, h, tx0, ty0, taps, [&](int r0, int c4, const uint32_t (&rows)[kBlurRS]) {
+        const int x = tx0 + c4;
+        if (x >= w) return;
+#pragma unroll
+        for (int rr = 0; rr < kBlurRS; ++rr) {
+            const int y = ty0 + r0 + rr;
+            if (y < h) *reinterpret_cast<uint32_t*>(dst + (size_t)y * dst_pitch + x) = rows[rr];
+        }
+    });
 }
 
 }  // namespace plp

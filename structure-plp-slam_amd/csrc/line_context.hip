@@ -109,6 +109,12 @@ plp_status build(plp_line* c, int rows, int cols) {
     std::vector<int16_t> xo, xc, yo, yc;
     exact_coeffs(cols, P.sw, xo, xc);
     exact_coeffs(rows, P.sh, yo, yc);
+    {   // the plain x0.5 case: both kernels of the LSD front as one (k_blur_half)
+        bool plain = cols == 2 * P.sw && rows == 2 * P.sh;
+        for (int i = 0; plain && i < P.sw; ++i) plain = xo[i] == 2 * i && xc[i] == 128;
+        for (int i = 0; plain && i < P.sh; ++i) plain = yo[i] == 2 * i && yc[i] == 128;
+        P.half_exact = plain ? 1 : 0;
+    }
     std::vector<int16_t> blob;
     blob.insert(blob.end(), xo.begin(), xo.end()); blob.insert(blob.end(), xc.begin(), xc.end());
     blob.insert(blob.end(), yo.begin(), yo.end()); blob.insert(blob.end(), yc.begin(), yc.end());

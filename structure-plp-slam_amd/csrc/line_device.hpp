@@ -39,6 +39,7 @@ struct LinePlanes {
     short2* dxy;              // Sobel 3x3, (dx, dy) per pixel        [B][H][W]
     plp_keyline* all_kl; uint8_t* all_lbd; int32_t* n_all;   // before the length filter  [B][kLineCap]
     int32_t* status;
+    int half_exact;           // 1: every INTER_LINEAR_EXACT table entry is (2d, 128): blur11 and the x0.5 resize run as one kernel
     int32_t* grow_stats;      // per frame {regions grown, pixels accepted, exact (in-band) decisions of the angle test, 0}: the USED map's history in three numbers  [B][4]
     long long* prof;          // optional diagnostics of frame 0: cycles {total, grow, rect, refine}, seeds grown, pixels grown
 };

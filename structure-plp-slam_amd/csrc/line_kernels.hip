@@ -11,7 +11,8 @@
 //   k_lsd_grow         region_grow / region2rect / refine, ONE wave per frame (the algorithm is a
 //                      sequential scan over seeds; frames run in parallel)
 //   k_keylines         KeyLine assembly + min_length filter
-//   k_sobel3           cv::Sobel 3x3 -> s16 dx, dy
+//   k_blur_sobel       cv::GaussianBlur(5x5, sigma 1) + cv::Sobel 3x3 -> s16 (dx, dy), the blurred image stays in LDS
+//   k_blur_half        11-tap blur + x0.5 resize in one pass (even frame sizes)
 //   k_lbd              63-row band descriptor, one wave per line (lane = row; each row is a strictly
 //                      sequential f32 sum, as in the reference), normalisation, 32-byte binarisation
 //   k_line_finalize    lineLength >= 60 filter, 2-D line function (f64), ordered compaction
@@ -95,6 +96,34 @@ __global__ __launch_bounds__(256) void k_resize_exact(const uint8_t* __restrict_
         packed |= min(v, 255u) << (8 * i);
     }
     *reinterpret_cast<uint32_t*>(dst + (size_t)blockIdx.z * dst_fs + (size_t)dy * dst_pitch + dx0) = packed;
+}
+
+// ------------------------------------------------------------------------------------------ blur11 + x0.5 in one pass
+// The plain case of the LSD front: even frame size, so every entry of the INTER_LINEAR_EXACT tables is (2d, weight 128) and a scaled
+// pixel is (a + b + c + d + 2) >> 2 of a 2x2 block of the blurred image -- exactly what k_resize_exact computes from those tables
+// ((128 * (128 a + 128 b) + 128 * (128 c + 128 d) + 32768) >> 16).  A thread of the blur's vertical pass owns 4 columns x 4 rows:
+// its own 2x2 blocks, so the blurred plane never goes to HBM.  The host checks the tables (line_context.hip) and falls back to
+// k_blur_plane<5> + k_resize_exact otherwise.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_blur_half(const uint8_t* __restrict__ src, size_t src_fs, int src_pitch,
+                                                                                           uint8_t* __restrict__ dst, size_t dst_fs, int dst_pitch, int w, int h, BlurTapsN taps) {
+    __shared__ BlurTileLds<5> S;
+    const int tiles_x = (w + kBlurTW - 1) / kBlurTW;
+    unsigned t, f;
+    xcd_frame_major(t, f);
+    const int tx0 = ((int)t % tiles_x) * kBlurTW, ty0 = ((int)t / tiles_x) * kBlurTH;
+    uint8_t* d = dst + (size_t)f * dst_fs;
+    blur_tile_core<5>(S, src + (size_t)f * src_fs, src_pitch, w, h, tx0, ty0, taps.k, [&](int r0, int c4, const uint32_t (&rows)[kBlurRS]) {
+        const int x = tx0 + c4;
+        if (x >= w) return;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int y = ty0 + r0 + 2 * j;
+            if (y >= h) continue;
+            const uint32_t lo = __builtin_amdgcn_udot4(rows[2 * j], 0x00000101u, __builtin_amdgcn_udot4(rows[2 * j + 1], 0x00000101u, 2u, false), false) >> 2;
+            const uint32_t hi = __builtin_amdgcn_udot4(rows[2 * j], 0x01010000u, __builtin_amdgcn_udot4(rows[2 * j + 1], 0x01010000u, 2u, false), false) >> 2;
+            *reinterpret_cast<uint16_t*>(d + (size_t)(y >> 1) * dst_pitch + (x >> 1)) = (uint16_t)(lo | (hi << 8));
+        }
+    });
 }
 
 // ------------------------------------------------------------------------------------------ ll_angle
@@ -746,40 +775,58 @@ __global__ __launch_bounds__(64) void k_keylines(LinePlanes P, LsdParams lp) {
     if (lane == 0) P.n_all[b] = run;
 }
 
-// ------------------------------------------------------------------------------------------ Sobel
-// cv::Sobel 3x3 (dx and dy, CV_16S, BORDER_REFLECT_101).  Four pixels per thread from aligned dword loads; the two
-// derivatives of a pixel are stored side by side (one 4-byte gather per LBD sample instead of two 2-byte ones).
-// grid = (ceil(w / 256), ceil(h / 4), B), block = 256 (64 x 4)
-__global__ __launch_bounds__(256) void k_sobel3(const uint8_t* __restrict__ src, size_t src_fs, int pitch, short2* __restrict__ dxy,
-                                                int w, int h) {
-    const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
-    if (x >= w || y >= h) return;
-    const uint8_t* s = src + (size_t)b * src_fs;
-    const uint8_t* rows[3] = {s + (size_t)reflect101_l(y - 1, h) * pitch, s + (size_t)y * pitch, s + (size_t)reflect101_l(y + 1, h) * pitch};
-    int p[3][6];   // columns x-1 .. x+4 of the three rows
-    const bool interior = x >= 4 && x + 4 <= w - 1 && x + 8 <= pitch;
+// ------------------------------------------------------------------------------------------ blur5 + Sobel
+// cv::GaussianBlur(5x5, sigma 1) followed by cv::Sobel 3x3 (dx and dy, CV_16S, BORDER_REFLECT_101) in one pass: the blurred image
+// is only ever read by the Sobel filter, so it never goes to HBM.  A workgroup blurs a 128 x 32 tile whose origin lies 4 columns
+// and 1 row before its 120 x 30 block of outputs (blur_tile_core evaluates the blur on the reflected extension of the source, which
+// is the reflected extension of the blurred image: the Sobel border needs nothing else), keeps the bytes in LDS and filters them:
+// a work item makes 4 pixels x 2 rows from 4 rows x 3 aligned dwords.  The two derivatives of a pixel are stored side by side (one
+// 4-byte gather per LBD sample instead of two 2-byte ones).  grid = (tiles, B) through xcd_frame_major, block = 256.
+constexpr int kSobelTW = 120, kSobelTH = 30;
+struct BlurSobelLds { BlurTileLds<2> b; uint32_t bt[kBlurTH * (kBlurTW / 4)]; };
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_blur_sobel(const uint8_t* __restrict__ src, size_t src_fs, int src_pitch,
+                                                                                            short2* __restrict__ dxy, int w, int h, BlurTapsN taps) {
+    __shared__ BlurSobelLds S;
+    const int tiles_x = (w + kSobelTW - 1) / kSobelTW;
+    unsigned t, f;
+    xcd_frame_major(t, f);
+    const int bx0 = ((int)t % tiles_x) * kSobelTW - 4, by0 = ((int)t / tiles_x) * kSobelTH - 1;
+    blur_tile_core<2>(S.b, src + (size_t)f * src_fs, src_pitch, w, h, bx0, by0, taps.k, [&](int r0, int c4, const uint32_t (&rows)[kBlurRS]) {
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        if (interior) {
-            const uint32_t* q = reinterpret_cast<const uint32_t*>(rows[r] + x);
-            const uint32_t L = q[-1], M = q[0], R = q[1];
-            p[r][0] = (int)(L >> 24); p[r][1] = (int)(M & 255u); p[r][2] = (int)((M >> 8) & 255u); p[r][3] = (int)((M >> 16) & 255u);
-            p[r][4] = (int)(M >> 24); p[r][5] = (int)(R & 255u);
-        } else {
+        for (int rr = 0; rr < kBlurRS; ++rr) S.bt[(r0 + rr) * (kBlurTW / 4) + c4 / 4] = rows[rr];
+    });
+    __syncthreads();
+    short2* out_frame = dxy + (size_t)f * w * h;
+    for (int i = threadIdx.x; i < (kSobelTW / 4) * (kSobelTH / 2); i += 256) {
+        const int cgp = i % (kSobelTW / 4), rp = i / (kSobelTW / 4);
+        const int x = bx0 + 4 + 4 * cgp, y = by0 + 1 + 2 * rp;
+        if (x >= w || y >= h) continue;
+        const int cd = 1 + cgp;
+        int d[4][4], sm[4][4];   // per blurred row: right - left and left + 2 mid + right of the 4 pixels
 #pragma unroll
-            for (int k = 0; k < 6; ++k) p[r][k] = rows[r][reflect101_l(min(x - 1 + k, w), w)];
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t* q = &S.bt[(2 * rp + r) * (kBlurTW / 4) + cd];
+            const uint32_t A = q[-1], Bv = q[0], Cv = q[1];
+            const int p[6] = {(int)(A >> 24), (int)(Bv & 255u), (int)((Bv >> 8) & 255u), (int)((Bv >> 16) & 255u), (int)(Bv >> 24), (int)(Cv & 255u)};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { d[r][k] = p[k + 2] - p[k]; sm[r][k] = p[k] + 2 * p[k + 1] + p[k + 2]; }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (y + j >= h) continue;
+            uint32_t out[4];   // (dx, dy) as two s16 in one dword
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                out[k] = ((uint32_t)(d[j][k] + 2 * d[j + 1][k] + d[j + 2][k]) & 0xffffu) | ((uint32_t)(sm[j + 2][k] - sm[j][k]) << 16);
+            const size_t o = (size_t)(y + j) * w + x;
+            uint32_t* dst = reinterpret_cast<uint32_t*>(out_frame + o);
+            if (x + 3 < w && (((size_t)f * w * h + o) & 3) == 0) *reinterpret_cast<uint4*>(dst) = make_uint4(out[0], out[1], out[2], out[3]);
+            else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (x + k < w) dst[k] = out[k];
+            }
         }
     }
-    short2 out[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {   // pixel x + i: xm = p[.][i], centre = p[.][i+1], xp = p[.][i+2]
-        out[i].x = (short)((p[0][i + 2] - p[0][i]) + 2 * (p[1][i + 2] - p[1][i]) + (p[2][i + 2] - p[2][i]));
-        out[i].y = (short)((p[2][i] - p[0][i]) + 2 * (p[2][i + 1] - p[0][i + 1]) + (p[2][i + 2] - p[0][i + 2]));
-    }
-    const size_t o = ((size_t)b * h + y) * w + x;
-    if (x + 3 < w && (o & 3) == 0) *reinterpret_cast<uint4*>(dxy + o) = *reinterpret_cast<const uint4*>(out);
-    else
-        for (int i = 0; i < 4 && x + i < w; ++i) dxy[o + i] = out[i];
 }
 
 // ------------------------------------------------------------------------------------------ LBD
@@ -961,19 +1008,22 @@ void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp,
     hipStream_t st2 = fork ? side->stream : st;
     const size_t plane_fs = (size_t)P.pitch * P.H, splane_fs = (size_t)P.spitch * P.sh;
     const int tiles = ((P.W + 127) / 128) * ((P.H + kBlurTH - 1) / kBlurTH);
+    const int sobel_tiles = ((P.W + kSobelTW - 1) / kSobelTW) * ((P.H + kSobelTH - 1) / kSobelTH);
     mark(0);
     if (fork) {
         (void)hipEventRecord(side->fork, st);
         (void)hipStreamWaitEvent(st2, side->fork, 0);
-        hipLaunchKernelGGL(k_blur_plane<2>, dim3(tiles, B), dim3(256), 0, st2, P.img, P.img_frame_stride, P.img_pitch, P.blur5, plane_fs,
-                           P.pitch, P.W, P.H, t5);
-        hipLaunchKernelGGL(k_sobel3, dim3((P.W + 255) / 256, (P.H + 3) / 4, B), dim3(256), 0, st2, P.blur5, plane_fs, P.pitch, P.dxy, P.W, P.H);
+        hipLaunchKernelGGL(k_blur_sobel, dim3(sobel_tiles, B), dim3(256), 0, st2, P.img, P.img_frame_stride, P.img_pitch, P.dxy, P.W, P.H, t5);
         (void)hipEventRecord(side->join, st2);
     }
-    hipLaunchKernelGGL(k_blur_plane<5>, dim3(tiles, B), dim3(256), 0, st, P.img, P.img_frame_stride, P.img_pitch, P.blur11, plane_fs,
-                       P.pitch, P.W, P.H, t11);
-    hipLaunchKernelGGL(k_resize_exact, dim3((P.sw + 255) / 256, (P.sh + 3) / 4, B), dim3(64, 4), 0, st, P.blur11, plane_fs, P.pitch,
-                       P.scaled, splane_fs, P.spitch, P.sw, P.sh, rt);
+    if (P.half_exact)
+        hipLaunchKernelGGL(k_blur_half, dim3(tiles, B), dim3(256), 0, st, P.img, P.img_frame_stride, P.img_pitch, P.scaled, splane_fs, P.spitch, P.W, P.H, t11);
+    else {
+        hipLaunchKernelGGL(k_blur_plane<5>, dim3(tiles, B), dim3(256), 0, st, P.img, P.img_frame_stride, P.img_pitch, P.blur11, plane_fs,
+                           P.pitch, P.W, P.H, t11);
+        hipLaunchKernelGGL(k_resize_exact, dim3((P.sw + 255) / 256, (P.sh + 3) / 4, B), dim3(64, 4), 0, st, P.blur11, plane_fs, P.pitch,
+                           P.scaled, splane_fs, P.spitch, P.sw, P.sh, rt);
+    }
     mark(1);
     const int n = P.sw * P.sh;
     hipLaunchKernelGGL(k_lsd_gradient, dim3((n + 255) / 256, B), dim3(256), 0, st, P, lp);
@@ -998,9 +1048,7 @@ void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp,
     mark(5);
     if (fork) (void)hipStreamWaitEvent(st, side->join, 0);
     else {
-        hipLaunchKernelGGL(k_blur_plane<2>, dim3(tiles, B), dim3(256), 0, st, P.img, P.img_frame_stride, P.img_pitch, P.blur5, plane_fs,
-                           P.pitch, P.W, P.H, t5);
-        hipLaunchKernelGGL(k_sobel3, dim3((P.W + 255) / 256, (P.H + 3) / 4, B), dim3(256), 0, st, P.blur5, plane_fs, P.pitch, P.dxy, P.W, P.H);
+        hipLaunchKernelGGL(k_blur_sobel, dim3(sobel_tiles, B), dim3(256), 0, st, P.img, P.img_frame_stride, P.img_pitch, P.dxy, P.W, P.H, t5);
     }
     mark(6);
     static const int lbd_blocks = [] { const char* e = getenv("PLP_LBD_BLOCKS"); int r = e ? atoi(e) : 4; return r > 0 ? r : 4; }();   // few resident waves per frame: their 63-row working sets have to stay in L1/L2
