@@ -22,7 +22,7 @@ struct plp_line {
     ResizeExactTab rt{};
     BlurTapsN t11{}, t5{};
     LbdWeightsDev w{};
-    DevBuf tabs, blur11, scaled, pix, g2, maxgrad, undef, order, n_order, reg, raw, n_raw, blur5, dx, dy, all_kl, all_lbd, n_all, status, prof, grow_stats;
+    DevBuf tabs, blur11, scaled, pix, g2, maxgrad, undef, order, n_order, reg, raw, n_raw, dx, dy, all_kl, all_lbd, n_all, status, prof, grow_stats;
     DevBuf l0copy, s_kl, s_lbd, s_fn, s_cnt;   // host-API staging
     DevBuf aligned;                             // aligned copy of odd-pitch device frames
     int s_cap = 0;
@@ -130,7 +130,7 @@ plp_status ensure(plp_line* c, int B) {
     if (B <= c->capB) return PLP_OK;
     LinePlanes& P = c->P;
     const size_t n = (size_t)P.sw * P.sh, nv = (size_t)(P.sw - 1) * (P.sh - 1), full = (size_t)P.W * P.H;
-    PLP_HIP(c->blur11.reserve((size_t)P.pitch * P.H * B)); PLP_HIP(c->blur5.reserve((size_t)P.pitch * P.H * B));
+    if (!P.half_exact) PLP_HIP(c->blur11.reserve((size_t)P.pitch * P.H * B));   // only the two-kernel fallback of the LSD front writes the blurred plane
     PLP_HIP(c->scaled.reserve((size_t)P.spitch * P.sh * B));
     PLP_HIP(c->pix.reserve(n * sizeof(LsdPix) * B));
     PLP_HIP(c->g2.reserve(n * 4 * B)); PLP_HIP(c->n_order.reserve(4 * (size_t)B)); PLP_HIP(c->maxgrad.reserve(4 * ((n + 255) / 256) * (size_t)B)); PLP_HIP(c->undef.reserve((n + 63) / 64 * 8 * B));
@@ -139,7 +139,7 @@ plp_status ensure(plp_line* c, int B) {
     PLP_HIP(c->dx.reserve(full * 4 * B));
     PLP_HIP(c->all_kl.reserve(sizeof(plp_keyline) * kLineCap * B)); PLP_HIP(c->all_lbd.reserve((size_t)32 * kLineCap * B));
     PLP_HIP(c->n_all.reserve(4 * (size_t)B)); PLP_HIP(c->status.reserve(16)); PLP_HIP(c->prof.reserve(64)); PLP_HIP(c->grow_stats.reserve(16 * (size_t)B));
-    P.blur11 = (uint8_t*)c->blur11.p; P.blur5 = (uint8_t*)c->blur5.p; P.scaled = (uint8_t*)c->scaled.p;
+    P.blur11 = (uint8_t*)c->blur11.p; P.scaled = (uint8_t*)c->scaled.p;
     P.pix = (LsdPix*)c->pix.p; P.g2 = (uint32_t*)c->g2.p; P.n_order = (int32_t*)c->n_order.p;
     P.blockmax = (uint32_t*)c->maxgrad.p; P.undef = (unsigned long long*)c->undef.p;
     P.order = (uint32_t*)c->order.p; P.reg = (uint32_t*)c->reg.p; P.raw = (float4*)c->raw.p; P.n_raw = (int32_t*)c->n_raw.p;

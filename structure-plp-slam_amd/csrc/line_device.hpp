@@ -25,7 +25,7 @@ struct LinePlanes {
     int sw, sh;               // LSD working resolution (scale 0.5)
     int pitch, spitch;        // row pitch of the full-res u8 planes / of the scaled u8 plane (64-B multiples)
     const uint8_t* img; size_t img_frame_stride; int img_pitch;   // caller's frames
-    uint8_t* blur11;          // 11-tap sigma 1.2 blur (LSD)          [B][H][pitch]
+    uint8_t* blur11;          // 11-tap sigma 1.2 blur (LSD), only when the blur and the resize run as two kernels  [B][H][pitch]
     uint8_t* scaled;          // INTER_LINEAR_EXACT x0.5              [B][sh][spitch]
     LsdPix* pix;              // per scaled pixel: angle / magnitude^2 / cos,sin, 16 bytes  [B][sh*sw]
     uint32_t* g2;             // gx^2 + gy^2 of the defined pixels, 0 = undefined  [B][sh*sw]
@@ -35,7 +35,6 @@ struct LinePlanes {
     int32_t* n_order;         // number of seeds                      [B]
     uint32_t* reg;            // region point list scratch            [B][sh*sw]
     float4* raw; int32_t* n_raw;          // LSD segments             [B][kLineCap], [B]
-    uint8_t* blur5;           // 5-tap sigma 1 blur (LBD)             [B][H][pitch]
     short2* dxy;              // Sobel 3x3, (dx, dy) per pixel        [B][H][W]
     plp_keyline* all_kl; uint8_t* all_lbd; int32_t* n_all;   // before the length filter  [B][kLineCap]
     int32_t* status;

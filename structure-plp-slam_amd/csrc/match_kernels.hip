@@ -566,6 +566,9 @@ __device__ __forceinline__ bool accept(const MatchProblem& P, unsigned best, int
 }
 
 // grid = (B), block = 256.  LDS: owner[2][n_cap] (dynamic).
+// kSorted: the windowed point modes after k_match_prep (a dry list is rescanned over the window's ranges of the sorted array); the other
+// instantiation rescans through candidate_key() and is the only one that carries its registers (all modes' gates, f64 epipolar tests).
+template <bool kSorted>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_match_resolve(MatchProblem P) {
     extern __shared__ int32_t lds[];
     __shared__ int s_changed, s_num, s_hist[32], s_valid_bin[32], s_full_n, s_claim_tmp[256];
@@ -593,7 +596,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     const int need = (is_last_frame_mode(P.mode) || P.mode == PLP_MATCH_MODE_TRIANGULATION) ? 1 : 2;   // the last-frame matcher has no second-best test
     const bool blocks_always = !has_obs || P.mode == PLP_MATCH_MODE_BRUTE_FORCE || is_group_mode(P.mode);
     const unsigned t_flip = P.mode == PLP_MATCH_MODE_TRIANGULATION ? 0xffffu : 0u;   // that mode orders equal distances by DESCENDING index
-    const bool use_sorted = P.sorted_valid != 0;
+    constexpr bool use_sorted = kSorted;
     const StagedTarget* sorted = P.sorted + (size_t)b * P.n_cap;
     const float* sorted_xr = P.sorted_xr + (size_t)b * P.n_cap;
     const uint16_t* g_cell_start = P.cell_start + (size_t)b * kCellStride;
@@ -607,6 +610,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
           const int q = chunk_start + tid;
           int my_claim = -1;
           for (int t = tid; t < n; t += 256) owner_prev[t] = 0x7fffffff;
+          // the query's best-K list and candidate count: read once per chunk (two 16-byte loads), the iterations work on registers
+          uint32_t e8[kMatchK];
+          int cnt = 0;
+          if (q < m) {
+              cnt = kcount[q];
+              const uint4* kp = reinterpret_cast<const uint4*>(klist + (size_t)q * kMatchK);
+              const uint4 lo = kp[0], hi = kp[1];
+              e8[0] = lo.x; e8[1] = lo.y; e8[2] = lo.z; e8[3] = lo.w; e8[4] = hi.x; e8[5] = hi.y; e8[6] = hi.z; e8[7] = hi.w;
+          }
           for (int inner = 0; inner <= 256; ++inner) {
             if (tid == 0) { s_full_n = 0; s_changed = 0; }
             for (int t = tid; t < n; t += 256) owner_next[t] = 0x7fffffff;
@@ -614,18 +626,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             int new_claim = -1;
             bool decided = false;
             if (q < m) {
-                const int cnt = kcount[q];
                 if (cnt <= 0) decided = true;
                 else {
                     const int have = min(cnt, kMatchK);
                     unsigned best = 256, second = 256;
                     int best_lvl = -1, second_lvl = -1, best_t = -1, found = 0;
-                    uint32_t e8[kMatchK];
-                    {   // the whole best-K list in two 16-byte loads
-                        const uint4* kp = reinterpret_cast<const uint4*>(klist + (size_t)q * kMatchK);
-                        const uint4 lo = kp[0], hi = kp[1];
-                        e8[0] = lo.x; e8[1] = lo.y; e8[2] = lo.z; e8[3] = lo.w; e8[4] = hi.x; e8[5] = hi.y; e8[6] = hi.z; e8[7] = hi.w;
-                    }
 #pragma unroll
                     for (int e = 0; e < kMatchK; ++e) {
                         if (e >= have || found >= need) continue;
@@ -663,7 +668,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                 const uint4* qd = reinterpret_cast<const uint4*>(P.q_desc + ((size_t)b * P.q_desc_stride + fq) * 32);
                 const uint4 q0 = qd[0], q1 = qd[1];
                 unsigned long long k0 = ~0ull, k1 = ~0ull;
-                if (use_sorted) {
+                if constexpr (use_sorted) {
                     if (!c.empty) {
                         const bool check_level = (0 < c.min_level) || (0 <= c.max_level);
                         for (int col = c.min_cx; col <= c.max_cx; ++col) {
@@ -946,13 +951,16 @@ void launch_match(hipStream_t st, const MatchProblem& P, int B) {
         const int gx_full = (P.m_cap + 3) / 4, gx_min = std::max(16, (8192 + B - 1) / B);   // keep >= ~8K workgroups in flight
         hipLaunchKernelGGL(k_match_topk, dim3(std::min(gx_full, gx_min), B), dim3(256), 0, st, P);
     }
-    hipLaunchKernelGGL(k_match_resolve, dim3(B), dim3(256), (size_t)P.n_cap * 12, st, Q);
+    if (Q.sorted_valid) hipLaunchKernelGGL(k_match_resolve<true>, dim3(B), dim3(256), (size_t)P.n_cap * 12, st, Q);
+    else hipLaunchKernelGGL(k_match_resolve<false>, dim3(B), dim3(256), (size_t)P.n_cap * 12, st, Q);
 }
 
 // up to 8192 targets: 96 KB of owner arrays.  The attribute belongs to the function ON THE CURRENT DEVICE: called by
 // plp_matcher_create after hipSetDevice, once per context.
 hipError_t configure_match_kernels() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_match_resolve), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 12);
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_match_resolve<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 12);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_match_resolve<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 12);
 }
 
 void launch_hamming_matrix(hipStream_t st, const uint8_t* q, int nq, const uint8_t* t, int nt, uint16_t* dist) {
