@@ -17,9 +17,12 @@ synth = importlib.import_module("structure-plp-slam_amd.synth")
 def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--frames", type=int, nargs="*", default=[1, 64, 256, 512, 1024, 2048, 3072])
     ap.add_argument("--same-frame", action="store_true", help="every slot of the batch holds the same image (same trip counts everywhere)")
+    ap.add_argument("--transpose", action="store_true", help="transposed frames (480 wide, 640 high): horizontal structures become vertical")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     base = synth.replay(7, 64, 480, 640)
+    if a.transpose:
+        base = np.ascontiguousarray(base.transpose(0, 2, 1))
     lt = plp.LineFeatureTracker()
     for B in a.frames:
         idx = np.zeros(B, np.int64) if a.same_frame else np.arange(B) % len(base)
