@@ -25,8 +25,14 @@ constexpr int kQtKeyCache = 2048;            // ... and share it with the sorted
 struct QtShared {
     uint16_t* cnt;                  // [16 * kQtSegLds] radix counters [digit][segment]      } one 8 KB block
     uint32_t* big;                  // [kQtKeyCache] cell prefix, later the sorted-key cache  }
-    uint16_t *ns[2], *ne[2];
-    uint8_t *nd[2], *nleaf[2];
+    // node records, two generations (ping-pong): start / end of the node's range, depth, leaf flag.  Addressed by arithmetic:
+    // arrays of pointers indexed by the generation had put the whole struct into scratch memory.
+    uint16_t* ns0;                  // ns(0), ne(0), ns(1), ne(1): max_nodes entries each
+    uint8_t* nd0;                   // nd(0), nleaf(0), nd(1), nleaf(1): max_nodes bytes each
+    __device__ __forceinline__ uint16_t* ns(int k) const { return ns0 + (size_t)k * 2 * max_nodes; }
+    __device__ __forceinline__ uint16_t* ne(int k) const { return ns0 + (size_t)k * 2 * max_nodes + max_nodes; }
+    __device__ __forceinline__ uint8_t* nd(int k) const { return nd0 + (size_t)k * 2 * max_nodes; }
+    __device__ __forceinline__ uint8_t* nleaf(int k) const { return nd0 + (size_t)k * 2 * max_nodes + max_nodes; }
     uint16_t *b1, *b2, *b3;
     uint32_t* pk;                   // packed per-entry counts -> exclusive prefixes (lo16 created, hi16 kept)
     uint16_t *pool_pos, *pool_sorted;
@@ -44,11 +50,11 @@ __device__ __forceinline__ QtShared qt_carve(uint8_t* base, int mn) {
     S.pk = reinterpret_cast<uint32_t*>(p); p += 4 * (size_t)mn;
     S.partial = reinterpret_cast<uint32_t*>(p); p += 16;
     S.misc = reinterpret_cast<int*>(p); p += 32;
-    for (int k = 0; k < 2; ++k) { S.ns[k] = reinterpret_cast<uint16_t*>(p); p += 2 * (size_t)mn; S.ne[k] = reinterpret_cast<uint16_t*>(p); p += 2 * (size_t)mn; }
+    S.ns0 = reinterpret_cast<uint16_t*>(p); p += 4 * 2 * (size_t)mn;
     S.b1 = reinterpret_cast<uint16_t*>(p); p += 2 * (size_t)mn; S.b2 = reinterpret_cast<uint16_t*>(p); p += 2 * (size_t)mn;
     S.b3 = reinterpret_cast<uint16_t*>(p); p += 2 * (size_t)mn;
     S.pool_pos = reinterpret_cast<uint16_t*>(p); p += 2 * (size_t)mn; S.pool_sorted = reinterpret_cast<uint16_t*>(p); p += 2 * (size_t)mn;
-    for (int k = 0; k < 2; ++k) { S.nd[k] = p; p += mn; S.nleaf[k] = p; p += mn; }
+    S.nd0 = p; p += 4 * (size_t)mn;
     S.max_nodes = mn;
     return S;
 }
@@ -218,7 +224,7 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelDev* __restrict__ l
             const uint32_t node = K[s] >> (2 * kQtDepth);
             int lo = s, hi = n;
             while (lo < hi) { const int mid = (lo + hi) >> 1; if ((K[mid] >> (2 * kQtDepth)) > node) hi = mid; else lo = mid + 1; }
-            S.ns[0][m] = (uint16_t)s; S.ne[0][m] = (uint16_t)lo; S.nd[0][m] = 0; S.nleaf[0][m] = (lo - s == 1);
+            S.ns(0)[m] = (uint16_t)s; S.ne(0)[m] = (uint16_t)lo; S.nd(0)[m] = 0; S.nleaf(0)[m] = (lo - s == 1);
             ++m; s = lo;
         }
         S.misc[0] = m;
@@ -233,10 +239,10 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelDev* __restrict__ l
         if (tid == 0) S.misc[1] = 0;   // pool size (children with more than one point)
         __syncthreads();
         for (int i = tid; i < m; i += 256) {
-            if (S.nleaf[cur][i]) { S.pk[i] = 1u << 16; continue; }
+            if (S.nleaf(cur)[i]) { S.pk[i] = 1u << 16; continue; }
             int o1, o2, o3;
-            const int s = S.ns[cur][i], e = S.ne[cur][i];
-            const int k = dev_split(K, s, e, S.nd[cur][i], o1, o2, o3);
+            const int s = S.ns(cur)[i], e = S.ne(cur)[i];
+            const int k = dev_split(K, s, e, S.nd(cur)[i], o1, o2, o3);
             S.b1[i] = (uint16_t)o1; S.b2[i] = (uint16_t)o2; S.b3[i] = (uint16_t)o3;
             S.pk[i] = (uint32_t)k;
             const int big = (o1 - s > 1) + (o2 - o1 > 1) + (o3 - o2 > 1) + (e - o3 > 1);
@@ -250,20 +256,20 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelDev* __restrict__ l
         const int nxt = cur ^ 1;
         for (int i = tid; i < m; i += 256) {
             const uint32_t p = S.pk[i];
-            const int s = S.ns[cur][i], e = S.ne[cur][i];
-            if (S.nleaf[cur][i]) {
+            const int s = S.ns(cur)[i], e = S.ne(cur)[i];
+            if (S.nleaf(cur)[i]) {
                 const int pos = T + (int)(p >> 16);
-                S.ns[nxt][pos] = (uint16_t)s; S.ne[nxt][pos] = (uint16_t)e; S.nd[nxt][pos] = S.nd[cur][i]; S.nleaf[nxt][pos] = 1;
+                S.ns(nxt)[pos] = (uint16_t)s; S.ne(nxt)[pos] = (uint16_t)e; S.nd(nxt)[pos] = S.nd(cur)[i]; S.nleaf(nxt)[pos] = 1;
                 continue;
             }
             int q = (int)(p & 0xffff);
             const int b[5] = {s, S.b1[i], S.b2[i], S.b3[i], e};
-            const uint8_t dep = (uint8_t)min((int)S.nd[cur][i] + 1, 255);
+            const uint8_t dep = (uint8_t)min((int)S.nd(cur)[i] + 1, 255);
 #pragma unroll
             for (int c = 0; c < 4; ++c)
                 if (b[c + 1] > b[c]) {
                     const int pos = T - 1 - q;
-                    S.ns[nxt][pos] = (uint16_t)b[c]; S.ne[nxt][pos] = (uint16_t)b[c + 1]; S.nd[nxt][pos] = dep; S.nleaf[nxt][pos] = 0;
+                    S.ns(nxt)[pos] = (uint16_t)b[c]; S.ne(nxt)[pos] = (uint16_t)b[c + 1]; S.nd(nxt)[pos] = dep; S.nleaf(nxt)[pos] = 0;
                     ++q;
                 }
         }
@@ -279,21 +285,21 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelDev* __restrict__ l
     while (!filled && !failed) {
         const int prev = m;
         // pool = entries with more than one point, in list order (ordered compaction)
-        for (int i = tid; i < m; i += 256) S.pk[i] = (uint32_t)(S.ne[cur][i] - S.ns[cur][i] > 1);
+        for (int i = tid; i < m; i += 256) S.pk[i] = (uint32_t)(S.ne(cur)[i] - S.ns(cur)[i] > 1);
         __syncthreads();
         const int p = (int)block_scan_excl(S.pk, m, S.partial);
         for (int i = tid; i < m; i += 256)
-            if (S.ne[cur][i] - S.ns[cur][i] > 1) S.pool_pos[S.pk[i]] = (uint16_t)i;
+            if (S.ne(cur)[i] - S.ns(cur)[i] > 1) S.pool_pos[S.pk[i]] = (uint16_t)i;
         __syncthreads();
         if (p == 0) break;   // nothing left to split
         // order: count descending, then list position ascending (== creation descending)
         for (int a = tid; a < p; a += 256) {
             const int ia = S.pool_pos[a];
-            const uint32_t ka = ((uint32_t)(S.ne[cur][ia] - S.ns[cur][ia]) << 12) | (uint32_t)(4095 - min(ia, 4095));
+            const uint32_t ka = ((uint32_t)(S.ne(cur)[ia] - S.ns(cur)[ia]) << 12) | (uint32_t)(4095 - min(ia, 4095));
             int rank = 0;
             for (int b = 0; b < p; ++b) {
                 const int ib = S.pool_pos[b];
-                const uint32_t kb = ((uint32_t)(S.ne[cur][ib] - S.ns[cur][ib]) << 12) | (uint32_t)(4095 - min(ib, 4095));
+                const uint32_t kb = ((uint32_t)(S.ne(cur)[ib] - S.ns(cur)[ib]) << 12) | (uint32_t)(4095 - min(ib, 4095));
                 rank += kb > ka;
             }
             S.pool_sorted[rank] = (uint16_t)ia;
@@ -303,7 +309,7 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelDev* __restrict__ l
         for (int j = tid; j < p; j += 256) {
             const int i = S.pool_sorted[j];
             int o1, o2, o3;
-            const int k = dev_split(K, S.ns[cur][i], S.ne[cur][i], S.nd[cur][i], o1, o2, o3);
+            const int k = dev_split(K, S.ns(cur)[i], S.ne(cur)[i], S.nd(cur)[i], o1, o2, o3);
             S.b1[j] = (uint16_t)o1; S.b2[j] = (uint16_t)o2; S.b3[j] = (uint16_t)o3;
             S.pk[j] = (uint32_t)k;
         }
@@ -314,7 +320,7 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelDev* __restrict__ l
             const int i = S.pool_sorted[j];
             int k = 1;
             {   // recover k_j from the boundaries
-                const int s = S.ns[cur][i], e = S.ne[cur][i];
+                const int s = S.ns(cur)[i], e = S.ne(cur)[i];
                 k = (S.b1[j] > s) + (S.b2[j] > S.b1[j]) + (S.b3[j] > S.b2[j]) + (e > S.b3[j]);
             }
             const int size_after = m + (int)S.pk[j] + k - (j + 1);   // m + sum_{t<=j} (k_t - 1)
@@ -326,7 +332,7 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelDev* __restrict__ l
         int T;
         {
             const int jl = nsplit - 1, il = S.pool_sorted[jl];
-            const int s = S.ns[cur][il], e = S.ne[cur][il];
+            const int s = S.ns(cur)[il], e = S.ne(cur)[il];
             const int kl = (S.b1[jl] > s) + (S.b2[jl] > S.b1[jl]) + (S.b3[jl] > S.b2[jl]) + (e > S.b3[jl]);
             T = (int)S.pk[jl] + kl;
         }
@@ -338,26 +344,26 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelDev* __restrict__ l
         for (int j = tid; j < nsplit; j += 256) {
             const int i = S.pool_sorted[j];
             int q = (int)S.pk[j];
-            const int s = S.ns[cur][i], e = S.ne[cur][i];
+            const int s = S.ns(cur)[i], e = S.ne(cur)[i];
             const int b[5] = {s, S.b1[j], S.b2[j], S.b3[j], e};
-            const uint8_t dep = (uint8_t)min((int)S.nd[cur][i] + 1, 255);
+            const uint8_t dep = (uint8_t)min((int)S.nd(cur)[i] + 1, 255);
 #pragma unroll
             for (int c = 0; c < 4; ++c)
                 if (b[c + 1] > b[c]) {
                     const int pos = T - 1 - q;
-                    S.ns[nxt][pos] = (uint16_t)b[c]; S.ne[nxt][pos] = (uint16_t)b[c + 1]; S.nd[nxt][pos] = dep; S.nleaf[nxt][pos] = 0;
+                    S.ns(nxt)[pos] = (uint16_t)b[c]; S.ne(nxt)[pos] = (uint16_t)b[c + 1]; S.nd(nxt)[pos] = dep; S.nleaf(nxt)[pos] = 0;
                     ++q;
                 }
-            S.nleaf[cur][i] |= 2;   // mark erased
+            S.nleaf(cur)[i] |= 2;   // mark erased
         }
         __syncthreads();
-        for (int i = tid; i < m; i += 256) S.pk[i] = (S.nleaf[cur][i] & 2) ? 0u : 1u;
+        for (int i = tid; i < m; i += 256) S.pk[i] = (S.nleaf(cur)[i] & 2) ? 0u : 1u;
         __syncthreads();
         block_scan_excl(S.pk, m, S.partial);
         for (int i = tid; i < m; i += 256)
-            if (!(S.nleaf[cur][i] & 2)) {
+            if (!(S.nleaf(cur)[i] & 2)) {
                 const int pos = T + (int)S.pk[i];
-                S.ns[nxt][pos] = S.ns[cur][i]; S.ne[nxt][pos] = S.ne[cur][i]; S.nd[nxt][pos] = S.nd[cur][i]; S.nleaf[nxt][pos] = S.nleaf[cur][i];
+                S.ns(nxt)[pos] = S.ns(cur)[i]; S.ne(nxt)[pos] = S.ne(cur)[i]; S.nd(nxt)[pos] = S.nd(cur)[i]; S.nleaf(nxt)[pos] = S.nleaf(cur)[i];
             }
         __syncthreads();
         cur = nxt; m = m_new;
@@ -372,7 +378,7 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelDev* __restrict__ l
     const int m_out = min(m, L.sel_cap);
     if (m > L.sel_cap && tid == 0) atomicOr(status, 2);
     for (int i = tid; i < m_out; i += 256) {
-        const int s = S.ns[cur][i], e = S.ne[cur][i];
+        const int s = S.ns(cur)[i], e = S.ne(cur)[i];
         uint32_t best_id = sidx[s];
         uint32_t best_pk = cand[best_id];
         for (int t = s + 1; t < e; ++t) {
