@@ -13,6 +13,7 @@
 //   k_match_topk_lds    brute-force mode: the target descriptors staged in LDS, one wave per query
 //   k_match_topk        generic path (line modes, BoW / triangulation groups, frames beyond the LDS budget): one wave per
 //                       query scans all targets through candidate_key(); waves stride over a frame's queries
+//   k_match_topk_lanes  the same search, one LANE per query: small target sets (key lines) in large batches
 //   k_match_resolve     one workgroup per problem: chunk-wise fixed point of "best free candidate given the claims of
 //                       all EARLIER queries" (2-3 iterations per chunk of 256 queries), an exact wave-wide rescan for a
 //                       query whose truncated list ran dry, then the accept rules, the delta-angle histogram check
@@ -296,6 +297,41 @@ __global__ __launch_bounds__(256) void k_match_topk(MatchProblem P) {
     const int lane = threadIdx.x & 63, b = blockIdx.y;
     const int m = P.q_counts ? min(P.q_counts[b], P.m_cap) : P.m_cap;
     for (int q = blockIdx.x * 4 + (threadIdx.x >> 6); q < m; q += gridDim.x * 4) match_topk_query(P, b, q, lane);
+}
+
+// The same search with ONE LANE per query (each lane scans all targets and keeps its 8 best keys): for small target sets -- the key
+// lines of a frame, ~50 against ~50 -- a wave per query leaves most lanes without a target and spends more on merging the lanes'
+// lists than on the candidates.  grid = (ceil(m_cap / 64), B), block = 64.
+__global__ __launch_bounds__(64) void k_match_topk_lanes(MatchProblem P) {
+    const int b = blockIdx.y, q = blockIdx.x * 64 + threadIdx.x;
+    const int m = P.q_counts ? min(P.q_counts[b], P.m_cap) : P.m_cap;
+    if (q >= m) return;
+    uint32_t* klist = P.klist + ((size_t)b * P.m_cap + q) * kMatchK;
+    int32_t* kcount = P.kcount + (size_t)b * P.m_cap + q;
+    const uint8_t* q_valid = P.q_valid ? P.q_valid + (size_t)b * P.m_cap : nullptr;
+    if (q_valid && !q_valid[q]) { *kcount = -1; return; }
+    const int n = P.t_counts ? min(P.t_counts[b], P.n_cap) : P.n_cap;
+    const plp_keypoint* kps = P.t_kps ? P.t_kps + (size_t)b * P.n_cap : nullptr;
+    const uint8_t* t_desc = P.t_desc + (size_t)b * P.n_cap * 32;
+    const float* t_xr = P.t_x_right ? P.t_x_right + (size_t)b * P.n_cap : nullptr;
+    const uint8_t* t_occ = P.t_occupied ? P.t_occupied + (size_t)b * P.n_cap : nullptr;
+    const QueryCtx c = make_query(P, q, b);
+    const uint4* qd = reinterpret_cast<const uint4*>(P.q_desc + ((size_t)b * P.q_desc_stride + q) * 32);
+    const uint4 q0 = qd[0], q1 = qd[1];
+    unsigned long long top[kMatchK];
+#pragma unroll
+    for (int i = 0; i < kMatchK; ++i) top[i] = ~0ull;
+    int passed = 0;
+    if (!(c.windowed && c.empty))
+        for (int t = 0; t < n; ++t) {
+            const unsigned long long key = candidate_key(P, c, t, kps, t_desc, t_xr, t_occ, q0, q1);
+            if (key == ~0ull) continue;
+            ++passed;
+            topk_insert(top, key);
+        }
+#pragma unroll
+    for (int r = 0; r < kMatchK; ++r) klist[r] = pack_key(top[r]);
+    *kcount = passed;
 }
 
 // Main path.  k_match_prep buckets each frame's free, in-grid targets by grid ROW once (counting sort with LDS
@@ -949,7 +985,8 @@ void launch_match(hipStream_t st, const MatchProblem& P, int B) {
         hipLaunchKernelGGL(k_match_topk_lds, qgrid, dim3(256), staged, st, P);
     } else {
         const int gx_full = (P.m_cap + 3) / 4, gx_min = std::max(16, (8192 + B - 1) / B);   // keep >= ~8K workgroups in flight
-        hipLaunchKernelGGL(k_match_topk, dim3(std::min(gx_full, gx_min), B), dim3(256), 0, st, P);
+        if (P.n_cap <= 512 && B >= 64) hipLaunchKernelGGL(k_match_topk_lanes, dim3((P.m_cap + 63) / 64, B), dim3(64), 0, st, P);   // small target sets, many frames
+        else hipLaunchKernelGGL(k_match_topk, dim3(std::min(gx_full, gx_min), B), dim3(256), 0, st, P);
     }
     if (Q.sorted_valid) hipLaunchKernelGGL(k_match_resolve<true>, dim3(B), dim3(256), (size_t)P.n_cap * 12, st, Q);
     else hipLaunchKernelGGL(k_match_resolve<false>, dim3(B), dim3(256), (size_t)P.n_cap * 12, st, Q);

@@ -173,6 +173,48 @@ def test_line_projection_matchers(seed):
                 assert gn[0] == wn and np.array_equal(got[0], want), (n, m, direction, rgbd)
 
 
+def test_batched_line_matchers_small_target_sets_one_lane_per_query():
+    """64 frames x (<= 120 key lines against <= 200 projected lines): the batch path with one lane per query (k_match_topk_lanes: target
+    capacity <= 512 and >= 64 problems) must equal the per-problem oracle, for both line projection matchers"""
+    import torch
+    rng = np.random.default_rng(77)
+    sf_lsd = np.array([1.0, 2.0], np.float32)
+    B, n_cap, m_cap = 64, 128, 256
+    ts, qs = zip(*[random_line_problem(rng, int(rng.integers(1, 120)), int(rng.integers(1, 200)), words=(0, 3)[b % 2]) for b in range(B)])
+    dev = torch.device("cuda:0")
+
+    def pad(arrs, cap, dt):
+        out = np.zeros((B, cap) + arrs[0].shape[1:], dt)
+        for b, a in enumerate(arrs):
+            out[b, :len(a)] = a
+        return out
+    f = {k: pad([t[k] for t in ts], n_cap, ts[0][k].dtype) for k in ts[0]}
+    f.update({k: pad([q[k] for q in qs], m_cap, qs[0][k].dtype) for k in qs[0]})
+    f["t_counts"] = np.array([len(t["t_kl"]) for t in ts], np.int32)
+    f["q_counts"] = np.array([len(q["q_level"]) for q in qs], np.int32)
+    d = {k: torch.from_numpy(v.view(np.uint8) if v.dtype in (plp.KP_DTYPE, plp.KL_DTYPE) else v).to(dev) for k, v in f.items()}
+    out_match = torch.full((B, n_cap), -7, dtype=torch.int32, device=dev)
+    out_num = torch.zeros(B, dtype=torch.int32, device=dev)
+    plp.matcher(0.8, False).match_device(plp.MODE_LANDMARKS_LINE, n_cap, m_cap, d, out_match, out_num, margin=12.0, scale_factors=sf_lsd, B=B)
+    torch.cuda.synchronize()
+    om, on = out_match.cpu().numpy(), out_num.cpu().numpy()
+    for b in range(B):
+        t, q = ts[b], qs[b]
+        want, wn = O.match_frame_and_landmarks_line(t["t_kl"], t["t_desc"], t["t_kp_octave"], t["t_occupied"], sf_lsd, q["q_valid"], q["q_reproj"],
+                                                    q["q_reproj2"], q["q_level"], q["q_desc"], q["q_has_obs"], 12.0, 0.8)
+        assert on[b] == wn and np.array_equal(om[b, :len(want)], want), b
+    plp.matcher(0.9, True).match_device(plp.MODE_LAST_FRAME_LINE, n_cap, m_cap, {**d, "is_rgbd": 1, "num_levels_lsd": 1}, out_match, out_num, margin=12.0,
+                                        direction=0, scale_factors=sf_lsd, B=B)
+    torch.cuda.synchronize()
+    om, on = out_match.cpu().numpy(), out_num.cpu().numpy()
+    for b in range(B):
+        t, q = ts[b], qs[b]
+        want, wn = O.match_current_and_last_line(t["t_kl"], t["t_desc"], np.stack([t["t_x_right"], t["t_x_right2"]], 1), t["t_occupied"], sf_lsd, 1,
+                                                 q["q_valid"], q["q_reproj"], q["q_reproj2"], q["q_x_right"], q["q_x_right2"], q["q_level"], q["q_desc"],
+                                                 q["q_has_obs"], 12.0, 0, 1)
+        assert on[b] == wn and np.array_equal(om[b, :len(want)], want), b
+
+
 # ---------------------------------------------------------------------------------------- BoW-guided, fuse, area
 @pytest.mark.parametrize("seed", range(3))
 def test_bow_guided_matcher(seed):
