@@ -136,7 +136,7 @@ plp_status ensure(plp_line* c, int B) {
     PLP_HIP(c->g2.reserve(n * 4 * B)); PLP_HIP(c->n_order.reserve(4 * (size_t)B)); PLP_HIP(c->maxgrad.reserve(4 * ((n + 255) / 256) * (size_t)B)); PLP_HIP(c->undef.reserve((n + 63) / 64 * 8 * B));
     PLP_HIP(c->order.reserve(nv * 4 * B)); PLP_HIP(c->reg.reserve(n * 4 * B));
     PLP_HIP(c->raw.reserve(sizeof(float4) * kLineCap * B)); PLP_HIP(c->n_raw.reserve(4 * (size_t)B));
-    PLP_HIP(c->dx.reserve(full * 4 * B));
+    PLP_HIP(c->dx.reserve(dxy_frame_entries(P.W, P.H) * 4 * B));
     PLP_HIP(c->all_kl.reserve(sizeof(plp_keyline) * kLineCap * B)); PLP_HIP(c->all_lbd.reserve((size_t)32 * kLineCap * B));
     PLP_HIP(c->n_all.reserve(4 * (size_t)B)); PLP_HIP(c->status.reserve(16)); PLP_HIP(c->prof.reserve(64)); PLP_HIP(c->grow_stats.reserve(16 * (size_t)B));
     P.blur11 = (uint8_t*)c->blur11.p; P.scaled = (uint8_t*)c->scaled.p;
@@ -342,10 +342,13 @@ plp_status plp_line_debug_read(plp_line* c, plp_line_debug_id what, int32_t fram
         case PLP_LINE_DBG_SOBEL_DY:
             if (dst_bytes < full * 2) return set_error(PLP_ERR_CAPACITY, "dst too small");
             {   // the device plane interleaves (dx, dy)
-                std::vector<int16_t> both(full * 2);
-                PLP_HIP(hipMemcpy(both.data(), P.dxy + (size_t)frame * full, full * 4, hipMemcpyDeviceToHost));
+                const size_t ent = dxy_frame_entries(P.W, P.H);
+                std::vector<int16_t> both(ent * 2);
+                PLP_HIP(hipMemcpy(both.data(), P.dxy + (size_t)frame * ent, ent * 4, hipMemcpyDeviceToHost));
                 int16_t* d16 = (int16_t*)dst;
-                for (size_t i = 0; i < full; ++i) d16[i] = both[2 * i + (what == PLP_LINE_DBG_SOBEL_DY ? 1 : 0)];
+                const int tiles8 = (P.W + 7) / 8;
+                for (int y = 0; y < P.H; ++y)
+                    for (int x = 0; x < P.W; ++x) d16[(size_t)y * P.W + x] = both[2 * (size_t)dxy_index(x, y, tiles8) + (what == PLP_LINE_DBG_SOBEL_DY ? 1 : 0)];
             }
             *n_out = (int64_t)full; return PLP_OK;
     }

@@ -35,13 +35,18 @@ struct LinePlanes {
     int32_t* n_order;         // number of seeds                      [B]
     uint32_t* reg;            // region point list scratch            [B][sh*sw]
     float4* raw; int32_t* n_raw;          // LSD segments             [B][kLineCap], [B]
-    short2* dxy;              // Sobel 3x3, (dx, dy) per pixel        [B][H][W]
+    short2* dxy;              // Sobel 3x3, (dx, dy) per pixel, in tiles of 8 x 4 pixels = one 128-byte line (dxy_index)  [B][dxy_frame_entries(W, H)]
     plp_keyline* all_kl; uint8_t* all_lbd; int32_t* n_all;   // before the length filter  [B][kLineCap]
     int32_t* status;
     int half_exact;           // 1: every INTER_LINEAR_EXACT table entry is (2d, 128): blur11 and the x0.5 resize run as one kernel
     int32_t* grow_stats;      // per frame {regions grown, pixels accepted, exact (in-band) decisions of the angle test, 0}: the USED map's history in three numbers  [B][4]
     long long* prof;          // optional diagnostics of frame 0: cycles {total, grow, rect, refine}, seeds grown, pixels grown
 };
+
+// The Sobel plane is stored in tiles of 8 pixels x 4 rows (128 bytes): the band of a key line covers 63 rows x its length, and the
+// LBD kernel's gathers (lane = band row) then touch a quarter of the cache lines for a line that runs along the image rows.
+__host__ __device__ inline size_t dxy_frame_entries(int W, int H) { return (size_t)((W + 7) / 8) * ((H + 3) / 4) * 32; }
+__host__ __device__ inline int dxy_index(int x, int y, int tiles_x) { return (((y >> 2) * tiles_x + (x >> 3)) << 5) + ((y & 3) << 3) + (x & 7); }
 
 struct LsdParams {
     double prec, p, rho, density_th, scale;

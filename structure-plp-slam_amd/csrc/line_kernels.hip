@@ -796,7 +796,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         for (int rr = 0; rr < kBlurRS; ++rr) S.bt[(r0 + rr) * (kBlurTW / 4) + c4 / 4] = rows[rr];
     });
     __syncthreads();
-    short2* out_frame = dxy + (size_t)f * w * h;
+    short2* out_frame = dxy + (size_t)f * dxy_frame_entries(w, h);
+    const int tiles8 = (w + 7) / 8;
     for (int i = threadIdx.x; i < (kSobelTW / 4) * (kSobelTH / 2); i += 256) {
         const int cgp = i % (kSobelTW / 4), rp = i / (kSobelTW / 4);
         const int x = bx0 + 4 + 4 * cgp, y = by0 + 1 + 2 * rp;
@@ -818,13 +819,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 out[k] = ((uint32_t)(d[j][k] + 2 * d[j + 1][k] + d[j + 2][k]) & 0xffffu) | ((uint32_t)(sm[j + 2][k] - sm[j][k]) << 16);
-            const size_t o = (size_t)(y + j) * w + x;
-            uint32_t* dst = reinterpret_cast<uint32_t*>(out_frame + o);
-            if (x + 3 < w && (((size_t)f * w * h + o) & 3) == 0) *reinterpret_cast<uint4*>(dst) = make_uint4(out[0], out[1], out[2], out[3]);
-            else {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) if (x + k < w) dst[k] = out[k];
-            }
+            // x is a multiple of 4: the four pixels are one aligned 16-byte piece of a tile row (pixels beyond the image edge land in the tile's padding)
+            *reinterpret_cast<uint4*>(out_frame + dxy_index(x, y + j, tiles8)) = make_uint4(out[0], out[1], out[2], out[3]);
         }
     }
 }
@@ -843,8 +839,8 @@ __global__ __launch_bounds__(256) void k_lbd(LinePlanes P, LbdWeightsDev W) {
     const int n_lines = P.n_all[b];
     for (int li = blockIdx.x * 4 + wv; li < n_lines; li += gridDim.x * 4) {   // a few resident waves walk the frame's lines
     const plp_keyline kl = P.all_kl[(size_t)b * kLineCap + li];
-    const short2* dxyImg = P.dxy + (size_t)b * P.W * P.H;
-    const int realWidth = P.W;
+    const short2* dxyImg = P.dxy + (size_t)b * dxy_frame_entries(P.W, P.H);
+    const int tiles8 = (P.W + 7) / 8;
     const short imageWidth = (short)(P.W - 1), imageHeight = (short)(P.H - 1);
     const short lengthOfLSP = (short)kl.numOfPixels;
     const short halfWidth = (short)((lengthOfLSP - 1) / 2), halfHeight = 31;
@@ -869,7 +865,7 @@ __global__ __launch_bounds__(256) void k_lbd(LinePlanes P, LbdWeightsDev W) {
                 const short xCor = (t < 0) ? 0 : (t > imageWidth) ? imageWidth : t;
                 t = (short)roundf(sCorY);
                 const short yCor = (t < 0) ? 0 : (t > imageHeight) ? imageHeight : t;
-                off[u] = yCor * realWidth + xCor;
+                off[u] = dxy_index(xCor, yCor, tiles8);
                 sCorX = __fadd_rn(sCorX, dL0);
                 sCorY = __fadd_rn(sCorY, dL1);
             }
