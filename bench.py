@@ -391,7 +391,7 @@ def main():
                    "frames_per_rank_per_step": B, "keypoints_mean": round(mean_kp, 1), "lines_mean": round(mean_lines, 1),
                    "matches_mean": [round(float(n1.float().mean().item()), 1), round(float(n2.float().mean().item()), 1)] + ([] if args.orb_only else [round(float(n3.float().mean().item()), 1)]),
                    "match_rescans_rounds": (match_dbg if not args.orb_only else None),
-                   "sharding": "contiguous frame blocks per rank; RCCL all-gather of the 2-frame feature halo for the matchers"},
+                   "sharding": "contiguous frame blocks per rank; one packed RCCL send/recv per rank (ring) of the 2-frame feature halo for the matchers"},
         "roofline": roofline,
     }
     out.update(extras)
