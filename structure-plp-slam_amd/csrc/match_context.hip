@@ -14,7 +14,7 @@ using namespace plp;
 struct plp_matcher {
     int device = 0;
     hipStream_t stream = nullptr;
-    DevBuf klist, kcount, claim, full_list, sorted, sorted_xr, row_start, dbg;  // scratch of the device path
+    DevBuf klist, klist2, kcount, claim, full_list, sorted, sorted_xr, row_start, dbg;  // scratch of the device path
     DevBuf stage;                            // one slab for the host-pointer path
     std::mutex mu;
 };
@@ -61,6 +61,7 @@ plp_status run_device(plp_matcher* c, const plp_match_args* a, hipStream_t st) {
     PLP_HIP(hipSetDevice(c->device));
     const size_t qn = (size_t)a->B * a->m_cap;
     PLP_HIP(c->klist.reserve(qn * kMatchK * 4));
+    PLP_HIP(c->klist2.reserve(qn * kMatchK * 4));
     PLP_HIP(c->kcount.reserve(qn * 4));
     PLP_HIP(c->claim.reserve(qn * 4));
     PLP_HIP(c->full_list.reserve(qn * 4));
@@ -86,7 +87,7 @@ plp_status run_device(plp_matcher* c, const plp_match_args* a, hipStream_t st) {
     for (int i = 0; i < 16; ++i) P.scale_factors[i] = (a->scale_factors && i < a->num_levels) ? a->scale_factors[i] : 1.0f;
     P.grid_min_x = a->grid.min_x; P.grid_min_y = a->grid.min_y; P.inv_cell_w = a->grid.inv_cell_width; P.inv_cell_h = a->grid.inv_cell_height;
     P.grid_cols = a->grid.cols; P.grid_rows = a->grid.rows;
-    P.klist = (uint32_t*)c->klist.p; P.kcount = (int32_t*)c->kcount.p; P.claim = (int32_t*)c->claim.p; P.full_list = (int32_t*)c->full_list.p;
+    P.klist = (uint32_t*)c->klist.p; P.klist2 = (uint32_t*)c->klist2.p; P.kcount = (int32_t*)c->kcount.p; P.claim = (int32_t*)c->claim.p; P.full_list = (int32_t*)c->full_list.p;
     P.sorted = (StagedTarget*)c->sorted.p; P.sorted_xr = (float*)c->sorted_xr.p; P.cell_start = (uint16_t*)c->row_start.p; P.dbg = (int32_t*)c->dbg.p;
     P.out_match = a->out_match; P.out_num = a->out_num;
     launch_match(st, P, a->B);

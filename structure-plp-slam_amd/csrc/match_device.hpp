@@ -54,6 +54,7 @@ struct MatchProblem {
     int grid_cols, grid_rows;
     // scratch + outputs
     uint32_t* klist;                 // B x m_cap x kMatchK, packed distance<<20 | octave<<16 | target (sorted)
+    uint32_t* klist2;                // B x m_cap x kMatchK: ranks kMatchK+1 .. 2 kMatchK of a query with more than kMatchK candidates (k_match_topk_cells only)
     int32_t* kcount;                 // B x m_cap
     int32_t* claim;                  // B x m_cap
     int32_t* full_list;              // B x m_cap

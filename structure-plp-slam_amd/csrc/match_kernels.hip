@@ -472,9 +472,9 @@ __global__ __launch_bounds__(256) void k_match_topk_cells(MatchProblem P, int qp
     const int q_end = min(m, q_begin + qpb);
     for (int q = q_begin + tid; q < q_end; q += 256) {
         const bool active = !(q_valid && !q_valid[q]);
-        uint32_t top[kMatchK];
+        uint32_t top[kMatchK], ovf[kMatchK];   // the 8 best keys, and the next 8: what falls out of (or never reaches) the first list
 #pragma unroll
-        for (int i = 0; i < kMatchK; ++i) top[i] = 0xffffffffu;
+        for (int i = 0; i < kMatchK; ++i) { top[i] = 0xffffffffu; ovf[i] = 0xffffffffu; }
         int passed = 0;
         if (active) {
             const QueryCtx c = make_query(P, q, b);
@@ -499,12 +499,20 @@ __global__ __launch_bounds__(256) void k_match_topk_cells(MatchProblem P, int qp
 #pragma unroll
                     for (int k = 0; k < kLaneCand; ++k)
                         if (k < nc) {
-                            const uint32_t key = (hamming256(q0, q1, d0[k], d1[k]) << 16) | (uint32_t)my[k];
+                            uint32_t key = (hamming256(q0, q1, d0[k], d1[k]) << 16) | (uint32_t)my[k];
                             if (key < top[kMatchK - 1]) {
+                                const uint32_t out = top[kMatchK - 1];
                                 top[kMatchK - 1] = key;
 #pragma unroll
                                 for (int e = kMatchK - 1; e > 0; --e)
                                     if (top[e] < top[e - 1]) { const uint32_t w = top[e]; top[e] = top[e - 1]; top[e - 1] = w; }
+                                key = out;
+                            }
+                            if (key < ovf[kMatchK - 1]) {
+                                ovf[kMatchK - 1] = key;
+#pragma unroll
+                                for (int e = kMatchK - 1; e > 0; --e)
+                                    if (ovf[e] < ovf[e - 1]) { const uint32_t w = ovf[e]; ovf[e] = ovf[e - 1]; ovf[e - 1] = w; }
                             }
                         }
                     passed += nc;
@@ -545,6 +553,19 @@ __global__ __launch_bounds__(256) void k_match_topk_cells(MatchProblem P, int qp
         out[0] = make_uint4(e[0], e[1], e[2], e[3]);
         out[1] = make_uint4(e[4], e[5], e[6], e[7]);
         P.kcount[(size_t)b * P.m_cap + q] = active ? passed : -1;
+        if (passed > kMatchK) {   // ranks 9..16 for the resolver: a first list whose entries are all taken rarely needs an exact rescan then
+#pragma unroll
+            for (int k = 0; k < kMatchK; ++k) {
+                e[k] = 0xffffffffu;
+                if (ovf[k] != 0xffffffffu) {
+                    const uint32_t to = sto[ovf[k] & 0xffffu];
+                    e[k] = ((ovf[k] >> 16) << 20) | (((to >> 16) & 15u) << 16) | (to & 0xffffu);
+                }
+            }
+            uint4* out2 = reinterpret_cast<uint4*>(P.klist2 + ((size_t)b * P.m_cap + q) * kMatchK);
+            out2[0] = make_uint4(e[0], e[1], e[2], e[3]);
+            out2[1] = make_uint4(e[4], e[5], e[6], e[7]);
+        }
     }
 }
 
@@ -647,13 +668,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
           int my_claim = -1;
           for (int t = tid; t < n; t += 256) owner_prev[t] = 0x7fffffff;
           // the query's best-K list and candidate count: read once per chunk (two 16-byte loads), the iterations work on registers
-          uint32_t e8[kMatchK];
+          constexpr int kList = kSorted ? 2 * kMatchK : kMatchK;   // k_match_topk_cells also leaves ranks 9..16 of a crowded window
+          uint32_t e8[kList];
           int cnt = 0;
           if (q < m) {
               cnt = kcount[q];
               const uint4* kp = reinterpret_cast<const uint4*>(klist + (size_t)q * kMatchK);
               const uint4 lo = kp[0], hi = kp[1];
               e8[0] = lo.x; e8[1] = lo.y; e8[2] = lo.z; e8[3] = lo.w; e8[4] = hi.x; e8[5] = hi.y; e8[6] = hi.z; e8[7] = hi.w;
+              if constexpr (kSorted) {
+#pragma unroll
+                  for (int k = kMatchK; k < kList; ++k) e8[k] = 0xffffffffu;
+                  if (cnt > kMatchK) {
+                      const uint4* kp2 = reinterpret_cast<const uint4*>(P.klist2 + ((size_t)b * P.m_cap + q) * kMatchK);
+                      const uint4 lo2 = kp2[0], hi2 = kp2[1];
+                      e8[8] = lo2.x; e8[9] = lo2.y; e8[10] = lo2.z; e8[11] = lo2.w; e8[12] = hi2.x; e8[13] = hi2.y; e8[14] = hi2.z; e8[15] = hi2.w;
+                  }
+              }
           }
           for (int inner = 0; inner <= 256; ++inner) {
             if (tid == 0) { s_full_n = 0; s_changed = 0; }
@@ -664,11 +695,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             if (q < m) {
                 if (cnt <= 0) decided = true;
                 else {
-                    const int have = min(cnt, kMatchK);
+                    const int have = min(cnt, kList);
                     unsigned best = 256, second = 256;
                     int best_lvl = -1, second_lvl = -1, best_t = -1, found = 0;
 #pragma unroll
-                    for (int e = 0; e < kMatchK; ++e) {
+                    for (int e = 0; e < kList; ++e) {
                         if (e >= have || found >= need) continue;
                         const int t = (int)((e8[e] & 0xffff) ^ t_flip);
                         if (taken(t, q, chunk_start)) continue;
@@ -680,9 +711,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                     // candidates.  Whatever lies beyond the list is at least as far as its last entry, d8 -- often that alone
                     // decides: no acceptable best exists beyond it (d8 above the mode's distance threshold), or the best that was
                     // found passes (or fails) its test against ANY second-best >= d8.  Only the rest needs the exact rescan.
-                    bool rescan = found < need && cnt > kMatchK;
+                    bool rescan = found < need && cnt > kList;
                     if (rescan && P.mode != PLP_MATCH_MODE_TRIANGULATION) {
-                        const unsigned d8 = e8[kMatchK - 1] >> 20;
+                        const unsigned d8 = e8[kList - 1] >> 20;   // the distance of the list's last entry: nothing beyond it is closer
                         const bool lm = P.mode == PLP_MATCH_MODE_LANDMARKS || P.mode == PLP_MATCH_MODE_LANDMARKS_LINE;
                         const unsigned thr = (lm || is_last_frame_mode(P.mode)) ? (is_last_frame_mode(P.mode) && P.hamm_dist_thr > 0 ? (unsigned)P.hamm_dist_thr : 100u) : 50u;
                         if (found == 0) { if (d8 > thr) rescan = false; }                       // nothing acceptable is left: no claim
