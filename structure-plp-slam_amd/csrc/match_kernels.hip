@@ -504,15 +504,13 @@ __global__ __launch_bounds__(256) void k_match_topk_cells(MatchProblem P, int qp
                                 const uint32_t out = top[kMatchK - 1];
                                 top[kMatchK - 1] = key;
 #pragma unroll
-                                for (int e = kMatchK - 1; e > 0; --e)
-                                    if (top[e] < top[e - 1]) { const uint32_t w = top[e]; top[e] = top[e - 1]; top[e - 1] = w; }
+                                for (int e = kMatchK - 1; e > 0; --e) { const uint32_t lo = min(top[e], top[e - 1]), hi = max(top[e], top[e - 1]); top[e - 1] = lo; top[e] = hi; }
                                 key = out;
                             }
                             if (key < ovf[kMatchK - 1]) {
                                 ovf[kMatchK - 1] = key;
 #pragma unroll
-                                for (int e = kMatchK - 1; e > 0; --e)
-                                    if (ovf[e] < ovf[e - 1]) { const uint32_t w = ovf[e]; ovf[e] = ovf[e - 1]; ovf[e - 1] = w; }
+                                for (int e = kMatchK - 1; e > 0; --e) { const uint32_t lo = min(ovf[e], ovf[e - 1]), hi = max(ovf[e], ovf[e - 1]); ovf[e - 1] = lo; ovf[e] = hi; }
                             }
                         }
                     passed += nc;
