@@ -201,6 +201,10 @@ typedef enum plp_line_debug_id { PLP_LINE_DBG_SCALED = 0, PLP_LINE_DBG_ORDER = 1
                                  PLP_LINE_DBG_ALL_LBD = 4, PLP_LINE_DBG_SOBEL_DX = 5, PLP_LINE_DBG_SOBEL_DY = 6,
                                  PLP_LINE_DBG_GROW_STATS = 7 /* int32[4]: regions grown, pixels accepted, exact (in-band) decisions, 0 */ } plp_line_debug_id;
 plp_status plp_line_debug_read(plp_line* ctx, plp_line_debug_id what, int32_t frame, void* dst, size_t dst_bytes, int64_t* n_out);
+/* Host model of the bin ranking of match::angle_checker (the reference sorts its 30 histogram bins by size with std::sort,
+ * src/PLPSLAM/match/angle_checker.h:165-176; the kernels reproduce libstdc++'s algorithm so that ties fall as in a reference built with
+ * GCC): idx = the indices 0..n-1, n <= 64, in that order.  depth_limit < 0 = the library's recursion budget.  No GPU needed. */
+int32_t plp_model_index_sort_host(const int32_t* sizes, int32_t n, int32_t depth_limit, uint32_t* idx);
 /* Host model of the LSD gradient kernel's (float)cos((double)a), (float)sin((double)a) fast path (csrc/sincos_ziv.hpp): proven[i] = 0 marks the
  * arguments for which the kernel falls back to the general f64 routine.  Returns the number of proven arguments.  No GPU needed. */
 int32_t plp_model_sincos_host(const float* a, int64_t n, float* c, float* s, uint8_t* proven);

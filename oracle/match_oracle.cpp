@@ -59,9 +59,9 @@ inline unsigned hamming64(const uint8_t* a, const uint8_t* b) {  // base.h:70-92
 // comparator (angle_checker.h:165-176), so which of several EQUALLY full bins makes the top 3 is
 // unspecified there.  Deliberate definition (oracle and HIP path alike): equally full bins keep
 // ascending bin order (a stable sort).
-// set by AngleChecker::collect: the thr-th and (thr+1)-th fullest bins held equally many (> 0) matches, i.e. the reference's
-// unstable std::sort (angle_checker.h:165-176) decides which of them is kept (definition D3); read by tests through
-// oracle_angle_checker_last_tie() to tell a D3 case from a real difference
+// set by AngleChecker::collect: the thr-th and (thr+1)-th fullest bins held equally many (> 0) matches, i.e. the order std::sort
+// gives equal elements (angle_checker.h:165-176) decides which of them is kept (D3); read through oracle_angle_checker_last_tie()
+// by tests that want to know how often that happens
 static int g_angle_tie = 0;
 struct AngleChecker {
     std::vector<std::vector<int>> hist;
@@ -77,7 +77,9 @@ struct AngleChecker {
     std::vector<unsigned> order() const {
         std::vector<unsigned> idx(hist.size());
         std::iota(idx.begin(), idx.end(), 0);
-        std::stable_sort(idx.begin(), idx.end(), [&](unsigned a, unsigned b) { return hist.at(a).size() > hist.at(b).size(); });
+        // std::sort, as the reference (angle_checker.h:165-176): among equally full bins the library's algorithm decides.  The HIP
+        // path reproduces libstdc++'s std::sort (csrc/libstdcxx_sort.hpp), so both equal a reference built with GCC's library.
+        std::sort(idx.begin(), idx.end(), [&](unsigned a, unsigned b) { return hist.at(a).size() > hist.at(b).size(); });
         return idx;
     }
     std::vector<int> collect(bool valid) const {
@@ -150,6 +152,13 @@ using namespace oracle;
 extern "C" {
 
 int oracle_angle_checker_last_tie() { return g_angle_tie; }
+// index_sort_by_size of the reference (std::sort of the bin indices by bin size, descending) for given bin sizes
+void oracle_index_sort_by_size(const int* sizes, int n, unsigned* idx) {
+    std::vector<unsigned> v(n);
+    std::iota(v.begin(), v.end(), 0u);
+    std::sort(v.begin(), v.end(), [&](unsigned a, unsigned b) { return sizes[a] > sizes[b]; });
+    for (int i = 0; i < n; ++i) idx[i] = v[i];
+}
 unsigned oracle_hamming32(const uint8_t* a, const uint8_t* b) { return hamming32(a, b); }
 unsigned oracle_hamming64(const uint8_t* a, const uint8_t* b) { return hamming64(a, b); }
 

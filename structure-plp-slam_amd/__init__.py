@@ -69,6 +69,7 @@ _API = [
     ("plp_orb_debug_read", C.c_int, [_VP, C.c_int, _I32, _I32, _VP, _SZ, _VP]),
     ("plp_model_quadtree_host", _I32, [_VP, _I32, _I32, _I32, C.c_uint32, _VP]),
     ("plp_model_sincos_host", _I32, [_VP, C.c_int64, _VP, _VP, _VP]),
+    ("plp_model_index_sort_host", _I32, [_VP, _I32, _I32, _VP]),
     ("plp_line_create", C.c_int, [C.c_int, _VP]),
     ("plp_line_destroy", None, [_VP]),
     ("plp_line_extract", C.c_int, [_VP, _VP, _I32, _I32, _SZ, _VP, _VP, _VP, _I32, _VP]),
@@ -150,6 +151,14 @@ def model_quadtree(xys, level_w, level_h, quota):
     out = np.zeros(max(len(xys), 1), np.int32)
     m = lib().plp_model_quadtree_host(_p(xys), len(xys), level_w, level_h, quota, _p(out))
     return out[:m].copy()
+
+
+def model_index_sort(sizes, depth_limit=-1):
+    """Host model of the matchers' bin ranking (libstdc++ std::sort order of the indices by size, descending); no GPU needed"""
+    sz = np.ascontiguousarray(sizes, np.int32)
+    idx = np.zeros(len(sz), np.uint32)
+    assert lib().plp_model_index_sort_host(_p(sz), len(sz), int(depth_limit), _p(idx)) == len(sz)
+    return idx
 
 
 def model_sincos(a):

@@ -6,6 +6,7 @@
 #include <mutex>
 #include <vector>
 
+#include "libstdcxx_sort.hpp"
 #include "match_device.hpp"
 #include "plp_common.hpp"
 
@@ -557,6 +558,15 @@ plp_status plp_hamming_matrix_host(plp_matcher* c, const uint8_t* q, int32_t nq,
     PLP_HIP(hipMemcpyAsync(dist, base + bq + bt, (size_t)nq * nt * 2, hipMemcpyDeviceToHost, c->stream));
     PLP_HIP(hipStreamSynchronize(c->stream));
     return PLP_OK;
+}
+
+// Host model of the bin ranking inside the matchers' orientation check (csrc/libstdcxx_sort.hpp), callable without a GPU: the
+// indices 0..n-1 (n <= 64) as std::sort orders them by bin size, descending.  depth_limit < 0: the library's own recursion budget.
+int32_t plp_model_index_sort_host(const int32_t* sizes, int32_t n, int32_t depth_limit, uint32_t* idx) {
+    if (!sizes || !idx || n < 0 || n > 64) return -1;
+    int ws[48];
+    plp::libstdcxx::index_sort_by_size(sizes, n, idx, ws, depth_limit);
+    return n;
 }
 
 }  // extern "C"

@@ -26,6 +26,7 @@
 #include <stdint.h>
 #include <cstdlib>
 
+#include "libstdcxx_sort.hpp"
 #include "match_device.hpp"
 #include "xcd_map.hpp"
 
@@ -626,7 +627,8 @@ __device__ __forceinline__ bool accept(const MatchProblem& P, unsigned best, int
 template <bool kSorted>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_match_resolve(MatchProblem P) {
     extern __shared__ int32_t lds[];
-    __shared__ int s_changed, s_num, s_hist[32], s_valid_bin[32], s_full_n, s_claim_tmp[256];
+    __shared__ int s_changed, s_num, s_hist[32], s_valid_bin[32], s_full_n, s_claim_tmp[256], s_sort_ws[48];
+    __shared__ unsigned s_sort_idx[32];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.x;
     const int m = P.q_counts ? min(P.q_counts[b], P.m_cap) : P.m_cap;
     const int n = P.t_counts ? min(P.t_counts[b], P.n_cap) : P.n_cap;
@@ -829,12 +831,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     if (my) atomicAdd(&s_num, my);
     __syncthreads();
     if (angle_check) {
-        if (tid == 0) {   // the 3 fullest of 30 bins; equally full bins keep ascending bin order
-            for (int r = 0; r < 3; ++r) {
-                int bi = -1, bv = -1;
-                for (int i = 0; i < 30; ++i) if (!s_valid_bin[i] && s_hist[i] > bv) { bv = s_hist[i]; bi = i; }
-                s_valid_bin[bi] = 1;
-            }
+        if (tid == 0) {   // the first 3 of the 30 bins as the reference's std::sort by size orders them (angle_checker.h:165-176), ties included
+            libstdcxx::index_sort_by_size(s_hist, 30, s_sort_idx, s_sort_ws);
+            for (int r = 0; r < 3; ++r) s_valid_bin[s_sort_idx[r]] = 1;
         }
         __syncthreads();
         int bad = 0;
@@ -911,7 +910,8 @@ __global__ __launch_bounds__(256) void k_match_fuse(MatchProblem P) {
 // replayed literally: one wave per problem walks frame 1 in order, its 64 lanes scan frame 2.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_match_area(AreaArgs A) {
-    __shared__ int hist[32], valid_bin[32];
+    __shared__ int hist[32], valid_bin[32], sort_ws[48];
+    __shared__ unsigned sort_idx[32];
     const int lane = threadIdx.x;
     uint32_t* mdist = A.scratch;            // matched_dists_in_frm_2
     int32_t* m1in2 = reinterpret_cast<int32_t*>(A.scratch + A.n2);   // matched_indices_1_in_frm_2
@@ -972,11 +972,8 @@ __global__ __launch_bounds__(64) void k_match_area(AreaArgs A) {
     }
     // num_matches = matches still standing; the orientation check removes the ones outside the 3 fullest bins
     if (A.check_orientation && lane == 0) {
-        for (int r = 0; r < 3; ++r) {
-            int bi = -1, bv = -1;
-            for (int i = 0; i < 30; ++i) if (!valid_bin[i] && hist[i] > bv) { bv = hist[i]; bi = i; }
-            valid_bin[bi] = 1;
-        }
+        libstdcxx::index_sort_by_size(hist, 30, sort_idx, sort_ws);   // the reference's std::sort of the bins by size, ties included
+        for (int r = 0; r < 3; ++r) valid_bin[sort_idx[r]] = 1;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();

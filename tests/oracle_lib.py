@@ -740,6 +740,14 @@ def ref_robust_match_frame_and_keyframe(desc1, angle1, desc2, angle2, valid2, lo
     return out[:n1].copy(), num
 
 
+def index_sort_by_size(sizes):
+    """the reference's index_sort_by_size (std::sort of the bin indices by size, descending) with this machine's C++ library"""
+    sz = np.ascontiguousarray(sizes, np.int32)
+    idx = np.zeros(len(sz), np.uint32)
+    _load().oracle_index_sort_by_size(_p(sz), len(sz), _p(idx))
+    return idx
+
+
 def angle_checker_last_tie():
     """1 if the oracle's last orientation check met equally full bins at the cut (definition D3: the reference's unstable std::sort decides)"""
     return int(_load().oracle_angle_checker_last_tie())

@@ -108,6 +108,20 @@ def test_sincos_fast_path_equals_libm_on_every_gradient_angle():
     assert np.array_equal(c[ok], want_c[ok]) and np.array_equal(s[ok], want_s[ok])
 
 
+def test_bin_ranking_model_equals_std_sort():
+    """csrc/libstdcxx_sort.hpp (the matchers' orientation check ranks the 30 histogram bins as the reference's std::sort does) against
+    the real std::sort of this machine's library: random bin sizes with many ties, sorted / reversed / organ-pipe shapes, other
+    lengths up to 64."""
+    rng = np.random.default_rng(3)
+    for trial in range(20000):
+        n = 30 if trial % 4 else int(rng.integers(1, 65))
+        sizes = rng.integers(0, (2, 3, 5, 50, 1000)[trial % 5], n).astype(np.int32)
+        if trial % 7 == 4: sizes = np.sort(sizes)
+        if trial % 7 == 5: sizes = np.sort(sizes)[::-1].copy()
+        if trial % 7 == 6: sizes = np.concatenate([np.sort(sizes[:n // 2]), np.sort(sizes[n // 2:])[::-1]]).astype(np.int32)
+        assert np.array_equal(plp.model_index_sort(sizes), O.index_sort_by_size(sizes)), (trial, sizes)
+
+
 def test_facade_check_programs_are_built_and_load():
     """The C++ facade check programs (oracle/facade_*_check, oracle/_ref/facade_orb_check) are compiled by build(); without
     arguments they only print nothing and return 2, which proves that they link against libplp_front.so / liboracle.so."""

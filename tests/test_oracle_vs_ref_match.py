@@ -6,9 +6,9 @@ Eigen / DBoW2 / json headers (oracle/ref_shadow), driven through array-form entr
 the signatures of the oracle's.  Every reference-owned line of these paths is pinned here; the OpenCV primitives underneath
 (LSD proper, GaussianBlur, Sobel, remap, resize) are the same restatement on both sides and stay unpinned.
 
-Two places where the reference itself is implementation-defined are excluded by construction, not hidden:
-  D3  angle_checker ranks the histogram bins with an unstable std::sort: an orientation-checked problem whose cut falls between
-      equally full bins is compared without the check (oracle_angle_checker_last_tie reports those).
+D3: angle_checker ranks its histogram bins with std::sort and a size-only comparator; the oracle calls std::sort too (same library as
+the reference build), so orientation-checked problems are compared as they are, ties at the cut included (they are counted).
+One place where the reference itself is undefined is excluded by construction, not hidden:
   MIH BinaryDescriptorMatcher::match reads uninitialised memory for a query with no train descriptor inside the search reach
       (binary_descriptor_matcher.cpp:236-243): those queries (oracle: index -1) are not compared.
 Runs wherever the prebuilt library is present (built here, where /root/reference is mounted; it travels to the GPU box)."""
@@ -31,7 +31,7 @@ def same(a, b):
 
 
 def compare_case(label, fn, args):
-    """returns 'equal' or 'd3' (equal without the orientation check, tie at the cut); asserts otherwise"""
+    """returns 'equal' or 'tie' (equal, and the orientation check's cut fell between equally full bins); asserts otherwise"""
     want = getattr(O, fn)(*args)
     checked = isinstance(args[-1], (bool, np.bool_)) and bool(args[-1])
     tie = O.angle_checker_last_tie() if checked else 0
@@ -41,15 +41,8 @@ def compare_case(label, fn, args):
         ok = want[0] >= 0
         assert np.array_equal(want[0][ok], got[0][ok]) and np.array_equal(want[1][ok], got[1][ok]), label
         return "equal"
-    if same(want, got):
-        return "equal"
-    assert checked and tie, f"{label}: oracle and reference build differ"
-    args2 = args[:-1] + (False,)
-    want2 = getattr(O, fn)(*args2)
-    with O.reference():
-        got2 = getattr(O, fn)(*args2)
-    assert same(want2, got2), f"{label}: oracle and reference build differ without the orientation check"
-    return "d3"
+    assert same(want, got), f"{label}: oracle and reference build differ"
+    return "tie" if tie else "equal"
 
 
 @pytest.mark.parametrize("block", range(10))
@@ -61,7 +54,7 @@ def test_matchers_equal_the_reference_build_on_random_problems(block):
         for label, fn, args in MC.matcher_cases(rng, 0.35):
             r = compare_case(label, fn, args)
             counts[(label, r)] = counts.get((label, r), 0) + 1
-    assert all(counts.get((label, "equal"), 0) >= 60 for label in {k[0] for k in counts}), counts
+    assert all(counts.get((label, "equal"), 0) + counts.get((label, "tie"), 0) >= 100 for label in {k[0] for k in counts}), counts
 
 
 @pytest.mark.parametrize("seed", range(6))
