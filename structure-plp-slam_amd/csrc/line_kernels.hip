@@ -200,17 +200,25 @@ __global__ __launch_bounds__(256) void k_lsd_order(LinePlanes P, LsdParams lp, i
     const int ngroups = (n + 63) / 64, gper = (ngroups + 3) / 4, g0 = q * gper, g1 = min(ngroups, g0 + gper);
     uint32_t* comp = P.reg + (size_t)b * n + (size_t)g0 * 64;
     int ncomp = 0;
-    for (int g = g0; g < g1; ++g) {
-        const int pix = g * 64 + lane;
-        const uint32_t v = pix < n ? g2[pix] : 0u;
-        const unsigned long long defm = __ballot(v != 0);
-        if (!defm) continue;
-        if (v) {
-            const uint32_t bin = (uint32_t)(int)(sqrt((double)v / 4.0) * bin_coef);
-            atomicAdd(&cnt[q][bin], 1u);
-            comp[ncomp + __popcll(defm & ((1ull << lane) - 1ull))] = (uint32_t)pix | (bin << 17);
+    for (int gb = g0; gb < g1; gb += 4) {   // four groups per trip: their loads are in flight together (a wave walks ~300 groups, one frame per workgroup)
+        uint32_t v4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int pix = (gb + u) * 64 + lane;
+            v4[u] = (gb + u < g1 && pix < n) ? g2[pix] : 0u;
         }
-        ncomp += __popcll(defm);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t v = v4[u];
+            const unsigned long long defm = __ballot(v != 0);
+            if (!defm) continue;
+            if (v) {
+                const uint32_t bin = (uint32_t)(int)(sqrt((double)v / 4.0) * bin_coef);
+                atomicAdd(&cnt[q][bin], 1u);
+                comp[ncomp + __popcll(defm & ((1ull << lane) - 1ull))] = (uint32_t)((gb + u) * 64 + lane) | (bin << 17);
+            }
+            ncomp += __popcll(defm);
+        }
     }
     __syncthreads();
     {   // thread t owns bins 1023-4t .. 1020-4t (descending)
