@@ -242,9 +242,16 @@ __global__ __launch_bounds__(256) void k_lsd_order(LinePlanes P, LsdParams lp, i
         if (tid == 255) P.n_order[b] = (int32_t)run;
     }
     __syncthreads();
-    for (int i0 = 0; i0 < ncomp; i0 += 64) {
+    for (int ib = 0; ib < ncomp; ib += 256) {   // four groups of entries loaded together, ranked one after the other
+    uint32_t e4[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) e4[u] = ib + 64 * u + lane < ncomp ? comp[ib + 64 * u + lane] : 0u;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int i0 = ib + 64 * u;
+        if (i0 >= ncomp) break;
         const bool valid = i0 + lane < ncomp;
-        const uint32_t e = valid ? comp[i0 + lane] : 0u;
+        const uint32_t e = e4[u];
         const unsigned v = e >> 17;
         unsigned long long peers = __ballot(valid);
 #pragma unroll
@@ -259,6 +266,7 @@ __global__ __launch_bounds__(256) void k_lsd_order(LinePlanes P, LsdParams lp, i
         __builtin_amdgcn_wave_barrier();
         if (valid && (peers & ((1ull << lane) - 1ull)) == 0) cnt[q][v] += (uint32_t)__popcll(peers);   // one leader per bin
         __builtin_amdgcn_wave_barrier();
+    }
     }
 }
 
