@@ -14,6 +14,7 @@
 using namespace plp;
 
 struct plp_line {
+    HostPinned pin;            // staging of the host-pointer entry point's image
     int device = 0;
     hipStream_t stream = nullptr;
     int rows = 0, cols = 0, capB = 0;
@@ -244,7 +245,9 @@ plp_status plp_line_extract(plp_line* c, const uint8_t* img, int32_t rows, int32
         PLP_HIP(c->s_fn.reserve((size_t)24 * kLineCap)); PLP_HIP(c->s_cnt.reserve(16));
         c->s_cap = kLineCap;
     }
-    PLP_HIP(hipMemcpy2DAsync(c->l0copy.p, pitch, img, step, cols, rows, hipMemcpyHostToDevice, st));
+    PLP_HIP(c->pin.reserve((size_t)rows * cols));   // the caller's pageable image never meets a DMA engine (plp_common.hpp HostPinned)
+    c->pin.pack(0, img, step, rows, cols);
+    PLP_HIP(hipMemcpy2DAsync(c->l0copy.p, pitch, c->pin.p, cols, cols, rows, hipMemcpyHostToDevice, st));
     PLP_TRY(run(c, (const uint8_t*)c->l0copy.p, 1, rows, cols, pitch, (size_t)pitch * rows, (plp_keyline*)c->s_kl.p, (uint8_t*)c->s_lbd.p,
                 (double*)c->s_fn.p, kLineCap, (int32_t*)c->s_cnt.p, st));
     int32_t n = 0;
@@ -253,10 +256,15 @@ plp_status plp_line_extract(plp_line* c, const uint8_t* img, int32_t rows, int32
     *n_out = n;
     if (n > cap) return set_error(PLP_ERR_CAPACITY, "caller buffers too small");
     if (n > 0) {
-        PLP_HIP(hipMemcpyAsync(kl, c->s_kl.p, sizeof(plp_keyline) * (size_t)n, hipMemcpyDeviceToHost, st));
-        PLP_HIP(hipMemcpyAsync(lbd, c->s_lbd.p, 32 * (size_t)n, hipMemcpyDeviceToHost, st));
-        PLP_HIP(hipMemcpyAsync(linefn, c->s_fn.p, 24 * (size_t)n, hipMemcpyDeviceToHost, st));
+        // results come back through the page-locked buffer as well
+        const size_t b_kl = sizeof(plp_keyline) * (size_t)n, b_lbd = 32 * (size_t)n, b_fn = 24 * (size_t)n;
+        PLP_HIP(c->pin.reserve(b_kl + b_lbd + b_fn));
+        uint8_t* hp = static_cast<uint8_t*>(c->pin.p);
+        PLP_HIP(hipMemcpyAsync(hp, c->s_kl.p, b_kl, hipMemcpyDeviceToHost, st));
+        PLP_HIP(hipMemcpyAsync(hp + b_kl, c->s_lbd.p, b_lbd, hipMemcpyDeviceToHost, st));
+        PLP_HIP(hipMemcpyAsync(hp + b_kl + b_lbd, c->s_fn.p, b_fn, hipMemcpyDeviceToHost, st));
         PLP_HIP(hipStreamSynchronize(st));
+        memcpy(kl, hp, b_kl); memcpy(lbd, hp + b_kl, b_lbd); memcpy(linefn, hp + b_kl + b_lbd, b_fn);
     }
     int32_t s[4];
     PLP_HIP(hipMemcpy(s, c->status.p, 16, hipMemcpyDeviceToHost));

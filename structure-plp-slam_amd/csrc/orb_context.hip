@@ -25,6 +25,7 @@ size_t quadtree_scratch_bytes_per_frame(const LevelDev* h_lv, int n_levels);
 using namespace plp;
 
 struct plp_orb {
+    HostPinned pin;            // staging of the host-pointer entry point's image and mask
     plp_orb_params p{};
     std::vector<float> rects;
     int device = 0;
@@ -201,7 +202,12 @@ plp_status run_batch(plp_orb* c, const uint8_t* d_imgs, int B, int rows, int col
     const int nl = g.n_levels;
 
     const bool prof = c->profiling;
-    auto mark = [&](int i) { if (prof) (void)hipEventRecord(c->ev[i], st); };
+    // PLP_TRACE=1 (diagnostic): every stage boundary waits for the stream and is logged, so that a device fault names its stage
+    static const bool trace = getenv("PLP_TRACE") != nullptr;
+    auto mark = [&](int i) {
+        if (prof) (void)hipEventRecord(c->ev[i], st);
+        if (trace) { const hipError_t e = hipStreamSynchronize(st); fprintf(stderr, "plp_orb: stage boundary %d reached (%dx%d, B=%d)%s\n", i, cols, rows, B, e == hipSuccess ? "" : " ERROR"); fflush(stderr); }
+    };
     mark(0);
     OrbPlanes pl{};
     pl.pyr = (uint8_t*)c->pyr.p; pl.pyr_frame_stride = g.frame_plane_bytes;
@@ -244,6 +250,7 @@ plp_status run_batch(plp_orb* c, const uint8_t* d_imgs, int B, int rows, int col
     launch_orient_rbrief(st, pl, (const uint8_t*)c->blur.p, g.frame_plane_bytes, (const LevelDev*)c->d_lv.p, nl, (const int32_t*)c->sel.p,
                          (const int32_t*)c->sel_count.p, g.total_sel_cap, um, d_kps, d_desc, cap, d_counts, (int32_t*)c->status.p, B);
     PLP_HIP(hipGetLastError());
+    if (trace) { const hipError_t e = hipStreamSynchronize(st); fprintf(stderr, "plp_orb: batch done%s\n", e == hipSuccess ? "" : " ERROR"); fflush(stderr); }
     if (prof) {
         mark(6);
         PLP_HIP(hipEventSynchronize(c->ev[6]));
@@ -350,6 +357,7 @@ plp_status plp_orb_last_batch_status(plp_orb* c) {
     PLP_HIP(hipMemcpyAsync(s, c->status.p, 16, hipMemcpyDeviceToHost, c->last_stream));
     PLP_HIP(hipStreamSynchronize(c->last_stream));
     if (s[0] & 1) return set_error(PLP_ERR_CAPACITY, "a frame produced more key points than `cap`; output truncated");
+    if (s[0] & 8) return set_error(PLP_ERR_HIP, "internal consistency check failed in the ORB kernels (please report the frame)");
     if (s[0] & 2) return set_error(PLP_ERR_OVERFLOW, "per-level candidate scratch overflow");
     return PLP_OK;
 }
@@ -371,12 +379,16 @@ plp_status plp_orb_extract(plp_orb* c, const uint8_t* img, int32_t rows, int32_t
         PLP_HIP(c->s_counts.reserve(16));
         c->s_cap = need;
     }
-    // H2D straight into the aligned level-0 plane
-    PLP_HIP(hipMemcpy2DAsync(c->l0copy.p, c->geo.lv[0].pitch, img, step, cols, rows, hipMemcpyHostToDevice, st));
+    // image (and mask) through the page-locked staging buffer into the aligned level-0 plane
+    const size_t img_bytes = (size_t)rows * cols;
+    PLP_HIP(c->pin.reserve(img_bytes * (mask ? 2 : 1)));
+    c->pin.pack(0, img, step, rows, cols);
+    PLP_HIP(hipMemcpy2DAsync(c->l0copy.p, c->geo.lv[0].pitch, c->pin.p, cols, cols, rows, hipMemcpyHostToDevice, st));
     const uint8_t* d_mask = nullptr;
     if (mask) {
-        PLP_HIP(c->d_mask.reserve((size_t)rows * cols));
-        PLP_HIP(hipMemcpy2DAsync(c->d_mask.p, cols, mask, mask_step, cols, rows, hipMemcpyHostToDevice, st));
+        PLP_HIP(c->d_mask.reserve(img_bytes));
+        c->pin.pack(img_bytes, mask, mask_step, rows, cols);
+        PLP_HIP(hipMemcpyAsync(c->d_mask.p, static_cast<const uint8_t*>(c->pin.p) + img_bytes, img_bytes, hipMemcpyHostToDevice, st));
         d_mask = (const uint8_t*)c->d_mask.p;
     }
     PLP_TRY(run_batch(c, (const uint8_t*)c->l0copy.p, 1, rows, cols, c->geo.lv[0].pitch, c->l0copy_frame_stride, d_mask, cols, 0,
@@ -387,12 +399,18 @@ plp_status plp_orb_extract(plp_orb* c, const uint8_t* img, int32_t rows, int32_t
     *n_out = n;
     if (n > cap) return set_error(PLP_ERR_CAPACITY, "caller buffers too small");
     if (n > 0) {
-        PLP_HIP(hipMemcpyAsync(kps, c->s_kps.p, sizeof(plp_keypoint) * (size_t)n, hipMemcpyDeviceToHost, st));
-        PLP_HIP(hipMemcpyAsync(desc, c->s_desc.p, 32 * (size_t)n, hipMemcpyDeviceToHost, st));
+        // results come back through the page-locked buffer as well
+        const size_t b_kps = sizeof(plp_keypoint) * (size_t)n, b_desc = 32 * (size_t)n;
+        PLP_HIP(c->pin.reserve(b_kps + b_desc));
+        uint8_t* hp = static_cast<uint8_t*>(c->pin.p);
+        PLP_HIP(hipMemcpyAsync(hp, c->s_kps.p, b_kps, hipMemcpyDeviceToHost, st));
+        PLP_HIP(hipMemcpyAsync(hp + b_kps, c->s_desc.p, b_desc, hipMemcpyDeviceToHost, st));
         PLP_HIP(hipStreamSynchronize(st));
+        memcpy(kps, hp, b_kps); memcpy(desc, hp + b_kps, b_desc);
     }
     int32_t s[4];
     PLP_HIP(hipMemcpy(s, c->status.p, 16, hipMemcpyDeviceToHost));
+    if (s[0] & 8) return set_error(PLP_ERR_HIP, "internal consistency check failed in the ORB kernels (please report the frame)");
     if (s[0] & 2) return set_error(PLP_ERR_OVERFLOW, "per-level candidate scratch overflow");
     return PLP_OK;
 }

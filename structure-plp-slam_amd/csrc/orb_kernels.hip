@@ -347,7 +347,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             m &= m - 1;
             // border-relative position: ROI coordinate + cell index * 64 (orb_extractor.cc:426-427)
             const uint32_t v = score[(lane + 1) * kScoreW + tx + 1];
-            out[pos++] = (uint32_t)(tx + 3 + cd.cx * kCellSize) | (y << 12) | (v << 24);
+            if (pos < kCellCap) out[pos] = (uint32_t)(tx + 3 + cd.cx * kCellSize) | (y << 12) | (v << 24);
+            ++pos;
         }
         if (lane == 63) cell_count[out_slot] = inc;
         return;
@@ -512,6 +513,10 @@ __global__ __launch_bounds__(256) void k_orient_rbrief(OrbPlanes pl, const uint8
     const uint32_t pk = (uint32_t)sel[(size_t)frame * total_sel_cap + g];
     const int cx = (int)(pk & 0xfff) + kOrbBorder, cy = (int)((pk >> 12) & 0xfff) + kOrbBorder;   // level pixel
     const int resp = (int)(pk >> 24);
+    if (cx < kOrbBorder || cy < kOrbBorder || cx > L.w - 1 - kOrbBorder || cy > L.h - 1 - kOrbBorder) {   // cannot happen: a selected point is a FAST corner
+        if (sub == 0) atomicOr(status, 8);
+        return;
+    }
 
     // Both patches of a key point go through LDS (s_patch: 37 rows x 48 bytes per key point): the 16 lanes fetch them with 16-byte
     // loads, neighbouring lanes taking neighbouring pieces of a row, so that one load instruction touches ~20 cache lines instead

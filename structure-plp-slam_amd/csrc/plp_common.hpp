@@ -1,5 +1,6 @@
 // Error plumbing and small RAII helpers shared by the host drivers.
 #pragma once
+#include <cstring>
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -44,6 +45,32 @@ struct DevBuf {
         hipError_t e = reserve(n);
         if (e != hipSuccess) return e;
         return hipMemcpyAsync(p, src, n, hipMemcpyHostToDevice, st);
+    }
+};
+
+// Page-locked bounce buffer of a context for the host-pointer entry points: the caller's image is copied into it by the CPU and
+// goes to the device from there, so that no DMA / blit ever addresses the caller's pageable memory (whose pages the caller may
+// unmap right after the call; a randomised sweep that allocated a fresh image per call hit rare GPU page faults otherwise).
+struct HostPinned {
+    void* p = nullptr;
+    size_t bytes = 0;
+    HostPinned() = default;
+    HostPinned(const HostPinned&) = delete;
+    HostPinned& operator=(const HostPinned&) = delete;
+    ~HostPinned() { if (p) (void)hipHostFree(p); }
+    hipError_t reserve(size_t n) {
+        if (n <= bytes && p) return hipSuccess;
+        if (p) { hipError_t e = hipHostFree(p); p = nullptr; bytes = 0; if (e != hipSuccess) return e; }
+        if (n == 0) n = 16;
+        hipError_t e = hipHostMalloc(&p, n, hipHostMallocDefault);
+        if (e == hipSuccess) bytes = n; else p = nullptr;
+        return e;
+    }
+    // rows x cols bytes from a pitched host image into the buffer at byte offset off, densely packed (pitch = cols)
+    void pack(size_t off, const uint8_t* src, size_t step, int rows, int cols) {
+        uint8_t* d = static_cast<uint8_t*>(p) + off;
+        if (step == (size_t)cols) memcpy(d, src, (size_t)rows * cols);
+        else for (int y = 0; y < rows; ++y) memcpy(d + (size_t)y * cols, src + (size_t)y * step, (size_t)cols);
     }
 };
 

@@ -379,10 +379,14 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelDev* __restrict__ l
     if (m > L.sel_cap && tid == 0) atomicOr(status, 2);
     for (int i = tid; i < m_out; i += 256) {
         const int s = S.ns(cur)[i], e = S.ne(cur)[i];
+        if (s >= n || e > n || s >= e) { atomicOr(status, 8); out_sel[i] = 0; continue; }   // cannot happen: node ranges partition [0, n)
         uint32_t best_id = sidx[s];
+        if (best_id >= (uint32_t)n) { atomicOr(status, 8); best_id = (uint32_t)(n - 1); }   // cannot happen: the sort permutes [0, n)
         uint32_t best_pk = cand[best_id];
         for (int t = s + 1; t < e; ++t) {
-            const uint32_t id = sidx[t], pk = cand[id];
+            uint32_t id = sidx[t];
+            if (id >= (uint32_t)n) { atomicOr(status, 8); id = (uint32_t)(n - 1); }
+            const uint32_t pk = cand[id];
             const uint32_t sa = pk >> 24, sb = best_pk >> 24;
             if (sa > sb || (sa == sb && id < best_id)) { best_id = id; best_pk = pk; }
         }

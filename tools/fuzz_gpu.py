@@ -113,6 +113,7 @@ def main():
         ini = int(rng.integers(8, 40)); mn = int(rng.integers(2, ini + 1))
         img = rand_image(rng, h, w)
         mask = None
+        if os.environ.get("PLP_FUZZ_VERBOSE"): print("orb case", n, h, w, K, sfac, nl, ini, mn, flush=True)
         if rng.uniform() < 0.25:
             mask = np.full((h, w), 255, np.uint8); x0 = int(rng.integers(0, w - 20)); mask[:, x0:x0 + int(rng.integers(10, w // 2))] = 0
         try:
