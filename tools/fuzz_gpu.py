@@ -116,6 +116,7 @@ def main():
         if os.environ.get("PLP_FUZZ_VERBOSE"): print("orb case", n, h, w, K, sfac, nl, ini, mn, flush=True)
         if rng.uniform() < 0.25:
             mask = np.full((h, w), 255, np.uint8); x0 = int(rng.integers(0, w - 20)); mask[:, x0:x0 + int(rng.integers(10, w // 2))] = 0
+            if os.environ.get("PLP_FUZZ_NOMASK"): mask = None   # bisection aid: same random sequence, no image masks
         try:
             ex = plp.orb_extractor(K, sfac, nl, ini, mn)
             got = ex.extract(img, mask)
