@@ -62,7 +62,9 @@ struct HostPinned {
         if (n <= bytes && p) return hipSuccess;
         if (p) { hipError_t e = hipHostFree(p); p = nullptr; bytes = 0; if (e != hipSuccess) return e; }
         if (n == 0) n = 16;
-        hipError_t e = hipHostMalloc(&p, n, hipHostMallocDefault);
+        // one page of slack behind the payload: a copy engine / blit kernel that fetches its source in 16-byte (or wider) pieces may
+        // touch a few bytes past the last requested one, and the page after a host allocation need not be mapped
+        hipError_t e = hipHostMalloc(&p, n + 4096, hipHostMallocDefault);
         if (e == hipSuccess) bytes = n; else p = nullptr;
         return e;
     }
