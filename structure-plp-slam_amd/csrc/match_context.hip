@@ -17,6 +17,7 @@ struct plp_matcher {
     hipStream_t stream = nullptr;
     DevBuf klist, klist2, kcount, claim, full_list, sorted, sorted_xr, row_start, dbg;  // scratch of the device path
     DevBuf stage;                            // one slab for the host-pointer path
+    HostPinned pin;                          // page-locked staging of host images (post-extract depth)
     std::mutex mu;
 };
 
@@ -364,7 +365,11 @@ plp_status plp_post_extract_host(plp_matcher* c, const plp_camera* cam, const pl
             PLP_HIP(hipMemcpyAsync(base + o_ld, kl_depths, (size_t)n_kl * 8, hipMemcpyHostToDevice, st));     // skipped lines keep the caller's values
             PLP_HIP(hipMemcpyAsync(base + o_lx, kl_x_right, (size_t)n_kl * 8, hipMemcpyHostToDevice, st));
         }
-        if (depth) PLP_HIP(hipMemcpy2DAsync(base + o_img, (size_t)cols * 4, depth, depth_step, (size_t)cols * 4, rows, hipMemcpyHostToDevice, st));
+        if (depth) {   // the depth image through a page-locked buffer with slack (plp_common.hpp HostPinned): no 2-D copy reads the caller's pageable memory
+            PLP_HIP(c->pin.reserve((size_t)rows * cols * 4));
+            c->pin.pack(0, reinterpret_cast<const uint8_t*>(depth), depth_step, rows, cols * 4);
+            PLP_HIP(hipMemcpyAsync(base + o_img, c->pin.p, (size_t)rows * cols * 4, hipMemcpyHostToDevice, st));
+        }
         PostArgs A = post_args(cam);
         A.kps = n ? (const plp_keypoint*)(base + o_k) : nullptr; A.counts = nullptr; A.cap = n;
         A.depth = depth ? (const float*)(base + o_img) : nullptr; A.depth_step = (size_t)cols * 4; A.depth_frame_stride = 0;
