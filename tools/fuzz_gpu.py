@@ -101,13 +101,15 @@ def aux_families(rng, seconds):
 
 def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--seconds", type=float, default=120); ap.add_argument("--seed", type=int, default=0); ap.add_argument("--aux-seconds", type=float, default=0.0)
+    ap.add_argument("--only", choices=["orb", "lines", "match"], default=None, help="spend all of --seconds on one family")
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     budget = a.seconds / 3
+    share = lambda fam: (a.seconds if a.only == fam else 0.0) if a.only else budget
     bad = 0
     # ---- ORB
     t0, n = time.time(), 0
-    while time.time() - t0 < budget:
+    while time.time() - t0 < share("orb"):
         h, w = int(rng.integers(120, 720)), int(rng.integers(160, 1300))
         K = int(rng.choice([100, 500, 1000, 2000, 4000])); sfac = float(rng.choice([1.2, 1.2, 1.1, 1.5])); nl = int(rng.integers(1, 9))
         ini = int(rng.integers(8, 40)); mn = int(rng.integers(2, ini + 1))
@@ -133,7 +135,7 @@ def main():
     # ---- lines
     t0, n = time.time(), 0
     lt = plp.LineFeatureTracker()
-    while time.time() - t0 < budget:
+    while time.time() - t0 < share("lines"):
         h, w = int(rng.integers(200, 600)), int(rng.integers(240, 900))
         img = rand_image(rng, h, w)
         kl, lbd, fn = lt.extract_LSD_LBD(img)
@@ -147,7 +149,7 @@ def main():
     t0, n = time.time(), 0
     grid = plp.make_grid(640, 480)
     SF = (np.float32(1.2) ** np.arange(8)).astype(np.float32)
-    while time.time() - t0 < budget:
+    while time.time() - t0 < share("match"):
         nt, m = int(rng.integers(1, 2500)), int(rng.integers(1, 3000))
         t, q = MC.random_problem(rng, nt, m, n_words=int(rng.choice([0, 0, 3, 20])), stereo=bool(rng.integers(0, 2)))
         margin, ratio = float(rng.uniform(2, 40)), float(rng.choice([0.6, 0.75, 0.9]))
