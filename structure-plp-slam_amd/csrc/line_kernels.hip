@@ -356,6 +356,9 @@ __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed
     }
     __builtin_amdgcn_wave_barrier();
     const int slot = lane / 9, k9 = lane - slot * 9;   // slot 0..6 (lane 63: slot 7, idle)
+    // the band thresholds as scalars for the hand-scheduled block; a tolerance without a band (c_pass = 2) never enters it
+    const bool banded = c_pass <= 1.f;
+    const int s_cpass = __builtin_amdgcn_readfirstlane(__float_as_int(c_pass)), s_cfail = __builtin_amdgcn_readfirstlane(__float_as_int(c_fail));
     const int ddx = k9 % 3 - 1, ddy = k9 / 3 - 1;
     for (int i = 0; i < nreg;) {
         const int nb = min(7, nreg - i);
@@ -384,6 +387,66 @@ __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed
         // unit only evaluates the two compares of the guard-banded test
         unsigned long long candmask = __builtin_amdgcn_ballot_w64(cand), gt = ~0ull;
         while (true) {
+            // ---- the certain decisions, hand-scheduled: 28 instructions per acceptance where the compiler's rendering of the
+            // same loop took 40 (a "continue" flag kept as a lane mask, wait states for packed f32 results, the test for "band
+            // pixel before the first certain one").  The block decides lanes only while NO eligible lane is inside the guard
+            // band; otherwise (`careful`) one decision is taken by the C++ below and the block is entered again.  Its test uses
+            // fused multiply-adds: the band covers every rounding of either form, so a lane that is certain here is certain.
+            // The sum itself is accumulated with plain f32 additions in acceptance order (bit-exact with the reference).
+            // Hazards honoured by hand (the compiler does not look into the block): two VALU between v_rsq and its consumer;
+            // lane selects of v_readlane come from the scalar unit; trailing s_nop before the compiler's code resumes.
+            int careful = 1;
+            if (banded) {
+                const int n0 = nreg;
+                float ta, tb;
+                unsigned long long t_elig, t_p, t_f, t_bit;
+                int t_k, t_ap, t_rx, t_ry;
+                asm volatile(
+                    "Lgrow_top_%=:\n\t"
+                    "s_and_b64 %[elig], %[cand], %[gt]\n\t"
+                    "s_cbranch_scc0 Lgrow_done_%=\n\t"
+                    "v_mul_f32 %[a], %[sx], %[sx]\n\t"
+                    "v_fmac_f32 %[a], %[sy], %[sy]\n\t"
+                    "v_rsq_f32 %[a], %[a]\n\t"
+                    "v_mul_f32 %[b], %[cx], %[sx]\n\t"
+                    "v_fmac_f32 %[b], %[cy], %[sy]\n\t"
+                    "v_mul_f32 %[a], %[b], %[a]\n\t"
+                    "v_cmp_le_f32 vcc, %[cp], %[a]\n\t"
+                    "v_cmp_gt_f32 %[f], %[cf], %[a]\n\t"
+                    "s_or_b64 %[f], %[f], vcc\n\t"
+                    "s_andn2_b64 %[f], %[elig], %[f]\n\t"
+                    "s_cbranch_scc1 Lgrow_band_%=\n\t"
+                    "s_and_b64 %[p], vcc, %[elig]\n\t"
+                    "s_cbranch_scc0 Lgrow_done_%=\n\t"
+                    "s_ff1_i32_b64 %[k], %[p]\n\t"
+                    "v_readlane_b32 %[ap], %[np], %[k]\n\t"
+                    "v_readlane_b32 %[rx], %[cx], %[k]\n\t"
+                    "v_readlane_b32 %[ry], %[cy], %[k]\n\t"
+                    "s_lshl_b64 %[bit], 1, %[k]\n\t"
+                    "v_cmp_eq_u32 vcc, %[ap], %[np]\n\t"
+                    "s_or_b64 %[acc], %[acc], %[bit]\n\t"
+                    "s_add_i32 %[nreg], %[nreg], 1\n\t"
+                    "v_add_f32 %[sx], %[rx], %[sx]\n\t"
+                    "v_add_f32 %[sy], %[ry], %[sy]\n\t"
+                    "s_lshl_b64 %[gt], -2, %[k]\n\t"
+                    "s_andn2_b64 %[cand], %[cand], vcc\n\t"
+                    "s_branch Lgrow_top_%=\n"
+                    "Lgrow_band_%=:\n\t"
+                    "s_mov_b32 %[careful], 1\n\t"
+                    "s_branch Lgrow_end_%=\n"
+                    "Lgrow_done_%=:\n\t"
+                    "s_mov_b32 %[careful], 0\n"
+                    "Lgrow_end_%=:\n\t"
+                    "s_nop 4"
+                    : [sx] "+v"(sumdx), [sy] "+v"(sumdy), [cand] "+s"(candmask), [gt] "+s"(gt), [acc] "+s"(acc), [nreg] "+s"(nreg),
+                      [careful] "=&s"(careful), [a] "=&v"(ta), [b] "=&v"(tb), [elig] "=&s"(t_elig), [p] "=&s"(t_p), [f] "=&s"(t_f),
+                      [bit] "=&s"(t_bit), [k] "=&s"(t_k), [ap] "=&s"(t_ap), [rx] "=&s"(t_rx), [ry] "=&s"(t_ry)
+                    : [cx] "v"(ncs.x), [cy] "v"(ncs.y), [np] "v"(np), [cp] "s"(s_cpass), [cf] "s"(s_cfail)
+                    : "vcc", "scc");
+                if (nreg != n0) theta_valid = false;
+            }
+            if (!careful) break;
+            // ---- one decision the careful way (an eligible pixel is inside the band, or the tolerance has no band)
             const unsigned long long elig = candmask & gt;
             if (!elig) break;
             const float inv = __builtin_amdgcn_rsqf(sumdx * sumdx + sumdy * sumdy);   // |sum| >= 0.9: no denormal care needed
