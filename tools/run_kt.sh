@@ -1,11 +1,14 @@
+# Short round-end check: bench line without the CPU leg, then a kernel trace.  Usage (GPU box): bash tools/run_kt.sh <tag>
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/kt1
+T=${1:-kt1}
+O=$R/gpurun_out/$T
 mkdir -p $O
+cd $R && timeout 40 python bench.py --no-cpu-baseline > $O/${T}_bench.json 2> $O/bench.err
+cat $O/${T}_bench.json
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/kt.log 2>&1
+timeout 50 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/kt.log 2>&1
 cd $R
-python tools/rocpd_summary.py $O/kt/kt_results.db "kt1" > $O/kt1_kernel_stats.md
-python tools/rocpd_isolated.py $O/kt/kt_results.db "kt1" > $O/kt1_isolated.md 2>&1
+python tools/rocpd_summary.py $O/kt/kt_results.db "$T (bench.py --steps 3 --warmup 1)" > $O/${T}_full_kernel_stats.md
 rm -rf $O/kt
-cat $O/kt1_isolated.md | head -60
+head -12 $O/${T}_full_kernel_stats.md
