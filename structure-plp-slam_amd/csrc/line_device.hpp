@@ -57,6 +57,11 @@ struct LsdParams {
     uint32_t g2_def_min;      // smallest gx^2 + gy^2 whose magnitude sqrt(g2 / 4.0) exceeds rho (the pixel's angle is defined)
 };
 constexpr double kLsdAngleBand = 3.5e-4;   // rad (0.02 deg) >= 2x the largest error of cv::fastAtan2 (0.0096 deg) + f32 rounding
+// The cosine form of the test resolves an angle step d near the tolerance t as sin(t) * d; its own f32 roundings are worth up to
+// ~4e-7 in the cosine, and 1.8e-4 rad of the band is what the error of fastAtan2 leaves.  Below t = 0.01 rad that is no longer a
+// safe margin (tests/test_angle_band_model.py finds wrong "certain" decisions at t = 0.0009), above 1.5 rad t + band passes
+// pi/2: outside [kLsdBandMinPrec, kLsdBandMaxPrec) every decision takes the exact path.
+constexpr double kLsdBandMinPrec = 0.01, kLsdBandMaxPrec = 1.5;
 
 struct ResizeExactTab { const int16_t *xo, *xc, *yo, *yc; };   // offsets + 8.8 weights (-1/-2: border sample)
 struct BlurTapsN { int k[11]; };

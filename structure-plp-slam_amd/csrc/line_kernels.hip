@@ -744,7 +744,7 @@ __global__ __launch_bounds__(256) void k_lsd_grow(LinePlanes P, LsdParams lp, in
                     const double tau = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / (double)nn + mean_angle * mean_angle);
                     // guard band of the angle test for this tolerance (disabled = every test takes the exact path)
                     float cp = 2.f, cf = -2.f;
-                    if (tau > 2 * kLsdAngleBand && tau < 1.5) { cp = (float)cos(tau - kLsdAngleBand); cf = (float)cos(tau + kLsdAngleBand); }
+                    if (tau >= kLsdBandMinPrec && tau < kLsdBandMaxPrec) { cp = (float)cos(tau - kLsdAngleBand); cf = (float)cos(tau + kLsdAngleBand); }
                     nreg = region_grow(g, (int)(c0 >> 16) * g.sw + (int)(c0 & 0xffff), false, 0.f, nullptr, tau, cp, cf, reg_angle);
                     region_list_fence();
                     if (nreg < 2) keep = false;

@@ -324,6 +324,11 @@ def brute_force_match(desc1, angle1, desc2, angle2, valid2, lowe_ratio, check_or
     return out[:n1].copy(), num
 
 
+def fast_atan2(y, x):
+    """cv::fastAtan2 (degrees, f32) as the oracle restates it (oracle/cv_restated.hpp fast_atan2f_deg)"""
+    return float(lib().oracle_fast_atan2(float(y), float(x)))
+
+
 def f_cos_sin(a):
     """D2: (float)cos((double)a), (float)sin((double)a) with this machine's libm (lsd_restated.hpp f_cos / f_sin)"""
     a = np.ascontiguousarray(a, np.float32)
