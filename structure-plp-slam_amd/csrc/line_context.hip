@@ -130,7 +130,7 @@ plp_status build(plp_line* c, int rows, int cols) {
 plp_status ensure(plp_line* c, int B) {
     if (B <= c->capB) return PLP_OK;
     LinePlanes& P = c->P;
-    const size_t n = (size_t)P.sw * P.sh, nv = (size_t)(P.sw - 1) * (P.sh - 1), full = (size_t)P.W * P.H;
+    const size_t n = (size_t)P.sw * P.sh, nv = (size_t)(P.sw - 1) * (P.sh - 1);
     if (!P.half_exact) PLP_HIP(c->blur11.reserve((size_t)P.pitch * P.H * B));   // only the two-kernel fallback of the LSD front writes the blurred plane
     PLP_HIP(c->scaled.reserve((size_t)P.spitch * P.sh * B));
     PLP_HIP(c->pix.reserve(n * sizeof(LsdPix) * B));
