@@ -394,7 +394,9 @@ __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed
             // fused multiply-adds: the band covers every rounding of either form, so a lane that is certain here is certain.
             // The sum itself is accumulated with plain f32 additions in acceptance order (bit-exact with the reference).
             // Hazards honoured by hand (the compiler does not look into the block): two VALU between v_rsq and its consumer;
-            // lane selects of v_readlane come from the scalar unit; trailing s_nop before the compiler's code resumes.
+            // lane selects of v_readlane come from the scalar unit (never from a VALU-written SGPR); an SGPR written by
+            // v_readlane is read by the VALU three or more instructions later; trailing s_nop before the compiler's code
+            // resumes.  EXEC is all ones here: every branch around this point is wave-uniform.
             int careful = 1;
             if (banded) {
                 const int n0 = nreg;
