@@ -12,6 +12,9 @@ One "step" = one pass of the hot path over one batch of `--batch` frames that ar
   match_current_and_last_frames  (frame b against frame b-1, margin 20, orientation check)
   match_frame_and_landmarks      (frame b against the key points of frames b-1 and b-2 as ~2K local landmarks, margin 10)
   match_current_and_last_frames_line (frame b's key lines against frame b-1's, margin 20)
+  match_frame_and_landmarks_line (frame b's key lines against those of frames b-1 and b-2 as local line landmarks, margin 10)
+The step itself lives in structure-plp-slam_amd/replay_step.py (class tracker_step) so that tests/test_gpu_bench_step.py checks, frame by
+frame against the oracle, exactly the code that is timed here; `--verify N` repeats that check on N frames of the last timed step.
 Steps are software-pipelined (stream C matches step n while A/B extract step n+1); every step's work is inside the timed
 region.  Frames shard across ranks in contiguous blocks, the only exchange being that halo (weak scaling: every rank
 owns its own batch); the timed region is bracketed by a barrier + synchronize and the max over ranks is used.  Rank 0
@@ -80,6 +83,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the PCIe-inclusive pass and the single-frame latency pass (profiling runs)")
     ap.add_argument("--orb-only", action="store_true", help="time the ORB extractor alone (config 1 shape)")
+    ap.add_argument("--verify", type=int, default=64, help="after the timed region: re-derive N frames of the last step (features and the four matcher "
+                    "results) with the CPU oracle and compare (0 = off; rank 0, N = 1 only)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -107,105 +112,25 @@ def main():
     d_frames = torch.from_numpy(frames_np).to(dev)
     if uniq < B:
         d_frames = d_frames.repeat((B + uniq - 1) // uniq, 1, 1)[:B].contiguous()
-    cap, lcap = 2 * K + 64, 512
-    # NBUF sets of outputs: the matchers of step n read set n % NBUF while the extractors of the next steps fill the others
-    NBUF = max(2, int(os.environ.get("PLP_BENCH_NBUF", "2")))
-    HALO = 2    # the matchers of frame b read frames b-1 and b-2: rows 0..HALO-1 of every feature array hold the predecessor rank's tail
-    full = lambda shape, dt, zero=False: (torch.zeros if zero else torch.empty)((HALO + B,) + shape, dtype=dt, device=dev)
-    kps2 = [full((cap, 28), torch.uint8) for _ in range(NBUF)]
-    desc2 = [full((cap, 32), torch.uint8) for _ in range(NBUF)]
-    cnt2 = [full((), torch.int32, True) for _ in range(NBUF)]
-    kl2 = [full((lcap, 68), torch.uint8, True) for _ in range(NBUF)]
-    lbd2 = [full((lcap, 32), torch.uint8, True) for _ in range(NBUF)]
-    fn2 = [torch.empty((B, lcap, 3), dtype=torch.float64, device=dev) for _ in range(NBUF)]
-    lcnt2 = [full((), torch.int32, True) for _ in range(NBUF)]
+    rs = importlib.import_module("structure-plp-slam_amd.replay_step")
+    HALO = rs.HALO
+    serial = bool(os.environ.get("PLP_BENCH_SERIAL"))                            # diagnostic: one stream for everything
+    ts = rs.tracker_step(plp, B, K, args.rows, args.cols, device_index=local_rank, orb_only=args.orb_only,
+                         n_line=int(os.environ.get("PLP_BENCH_LINE_SPLIT", "2")), nbuf=int(os.environ.get("PLP_BENCH_NBUF", "2")), serial=serial,
+                         shift=(SHIFT_X, 0.0), parts=os.environ.get("PLP_BENCH_PARTS", "orb,lines,match"))   # PLP_BENCH_PARTS: diagnostic, time a subset of the step
+    cap, lcap, NBUF = ts.cap, ts.lcap, ts.NBUF
+    kps2, desc2, cnt2, kl2, lbd2, fn2, lcnt2 = ts.kps2, ts.desc2, ts.cnt2, ts.kl2, ts.lbd2, ts.fn2, ts.lcnt2
     d_kps, d_desc, d_cnt = kps2[0][HALO:], desc2[0][HALO:], cnt2[0][HALO:]
     d_kl, d_lbd, d_fn, d_lcnt = kl2[0][HALO:], lbd2[0][HALO:], fn2[0], lcnt2[0][HALO:]
-    m3 = torch.empty((B, lcap), dtype=torch.int32, device=dev); n3 = torch.zeros(B, dtype=torch.int32, device=dev)
-    m1 = torch.empty((B, cap), dtype=torch.int32, device=dev); n1 = torch.zeros(B, dtype=torch.int32, device=dev)
-    m2 = torch.empty((B, cap), dtype=torch.int32, device=dev); n2 = torch.zeros(B, dtype=torch.int32, device=dev)
-    ex = plp.orb_extractor(K, device=local_rank)
-    lt = plp.LineFeatureTracker(device=local_rank)
-    # The line path is one long dependent chain per launch (region growing is a single wave per frame), so
-    # the batch is cut into n_line contiguous sub-blocks, each with its own context (scratch planes) and HIP stream.
-    n_line = max(1, int(os.environ.get("PLP_BENCH_LINE_SPLIT", "2")))
-    while B % n_line:
-        n_line -= 1
-    lts = [lt] + [plp.LineFeatureTracker(device=local_rank) for _ in range(n_line - 1)]
-    mt_last = plp.matcher(0.9, True, device=local_rank)     # motion_based_track: match::projection(0.9, true)
-    mt_lm = plp.matcher(0.8, True, device=local_rank)       # search_local_landmarks: match::projection(0.8)
-    mt_line = plp.matcher(0.9, True, device=local_rank)     # motion_based_track, lines: match_current_and_last_frames_line
-    sf_lsd = np.ones(1, np.float32)                         # LineFeatureTracker: one LSD level (line_extractor.cc:34-35)
-    grid = plp.make_grid(args.cols, args.rows)
-    sf = ex.get_scale_factors()
-    cur = torch.cuda.current_stream(dev)
-    sA = torch.cuda.Stream(dev)
-    serial = bool(os.environ.get("PLP_BENCH_SERIAL"))                            # diagnostic: one stream for everything
-    sB = sA if serial else torch.cuda.Stream(dev)
-    sBs = [sB] + [sA if serial else torch.cuda.Stream(dev) for _ in range(n_line - 1)]
-    
-    replay = importlib.import_module("structure-plp-slam_amd.replay")
-    pq = replay.point_queries(plp, B, cap, dev)
-    lq = replay.line_queries(plp, B, lcap, dev)
-    shift = (SHIFT_X, 0.0)
-
-    def match_stage(buf=0, st=None, before_lines=None):
-        """the tracker's three matcher calls for every frame of the step held in feature set `buf`, on stream st"""
-        st = st or sA
-        kps, desc, cnt = kps2[buf], desc2[buf], cnt2[buf]
-        # the two frames preceding this rank's block come from the previous rank: one packed exchange into rows 0..HALO-1
-        replay.exchange_halo_into([kps, desc, cnt], halo=HALO)
-        pq.build(kps, cnt, HALO, shift, st)       # reprojections / levels / angles / validity of the queries: one launch
-        t = dict(t_kps=kps[HALO:], t_desc=desc[HALO:], t_counts=cnt[HALO:])
-        # descriptors are read in place: the queries of frame b are rows (b + HALO - 1) resp. (b + HALO - 2 .. b + HALO - 1) of `desc`
-        q1 = dict(q_reproj=pq.q1_reproj, q_level=pq.q1_level, q_angle=pq.q1_angle, q_counts=pq.q1_counts, q_desc=desc[HALO - 1:], q_desc_stride=cap)
-        mt_last.match_device(plp.MODE_LAST_FRAME, cap, cap, {**t, **q1}, m1, n1, margin=20.0, direction=0, scale_factors=sf, grid=grid, B=B, stream=st)
-        q2 = dict(q_reproj=pq.q2_reproj, q_level=pq.q2_level, q_valid=pq.q2_valid, q_desc=desc[HALO - 2:], q_desc_stride=cap)
-        mt_lm.match_device(plp.MODE_LANDMARKS, cap, 2 * cap, {**t, **q2}, m2, n2, margin=10.0, scale_factors=sf, grid=grid, B=B, stream=st)
-        if args.orb_only:
-            return
-        if before_lines is not None:
-            before_lines()          # the point matchers only needed the ORB stream; the line matcher waits for the line streams here
-        kl, lbd, lcnt = kl2[buf], lbd2[buf], lcnt2[buf]
-        replay.exchange_halo_into([kl, lbd, lcnt], halo=HALO)
-        lq.build(kl, lcnt, HALO, shift, st)       # key lines of the previous frame, both end points moved by the pan
-        q3 = dict(q_reproj=lq.q_sp, q_reproj2=lq.q_ep, q_level=lq.q_level, q_counts=lq.q_counts, q_desc=lbd[HALO - 1:], q_desc_stride=lcap, is_rgbd=0, num_levels_lsd=1)
-        mt_line.match_device(plp.MODE_LAST_FRAME_LINE, lcap, lcap, {**dict(t_kl=kl[HALO:], t_desc=lbd[HALO:], t_counts=lcnt[HALO:]), **q3}, m3, n3, margin=20.0,
-                             direction=0, scale_factors=sf_lsd, B=B, stream=st)
-
-    # One step = ORB (stream A) || LSD+LBD (stream B), then the halo exchange and the two matchers (stream C) on that
-    # step's features.  Steps are software-pipelined: stream C works on step n while A and B already extract step n + 1
-    # (no stage fills the chip on its own, see profiles/r01i_sq_counters.md); all K steps' work, matchers
-    # included, is inside the timed region because the closing barrier synchronises the device.
-    sC = sA if serial else torch.cuda.Stream(dev)
-    done_match = [None] * NBUF
-    step_no = [0]
+    m1, n1, m2, n2, m3, n3, m4, n4 = ts.m1, ts.n1, ts.m2, ts.n2, ts.m3, ts.n3, ts.m4, ts.n4
+    ex, lts = ts.ex, ts.lts
+    lt = lts[0] if lts else None
+    mt_last, mt_lm = ts.mt_last, ts.mt_lm
+    grid, sf, cur, sA, sBs = ts.grid, ts.sf, ts.cur, ts.sA, ts.sBs
+    match_stage = ts.match_stage
 
     def step():
-        n = step_no[0]; step_no[0] += 1
-        buf = n % NBUF
-        if done_match[buf] is not None:
-            sA.wait_event(done_match[buf])          # the matchers of step n - 2 have read this set
-        parts = os.environ.get("PLP_BENCH_PARTS", "orb,lines,match")   # diagnostic: time a subset of the step
-        if "orb" in parts:
-            ex.extract_batch(d_frames, kps2[buf][HALO:], desc2[buf][HALO:], cnt2[buf][HALO:], stream=sA)
-        ready = torch.cuda.Event(); ready.record(sA)
-        if not args.orb_only:
-            bs = B // n_line
-            line_ready = []
-            for i, (lti, sbi) in enumerate(zip(lts, sBs)):
-                sl = slice(i * bs, (i + 1) * bs)
-                if done_match[buf] is not None:
-                    sbi.wait_event(done_match[buf])     # the line matcher of step n - 2 has read this set
-                if "lines" in parts:
-                    lti.extract_batch(d_frames[sl], kl2[buf][HALO:][sl], lbd2[buf][HALO:][sl], fn2[buf][sl], lcnt2[buf][HALO:][sl], stream=sbi)
-                ev = torch.cuda.Event(); ev.record(sbi); line_ready.append(ev)
-            if "match" not in parts:
-                return
-            sC.wait_event(ready)
-            with torch.cuda.stream(sC):
-                match_stage(buf, sC, before_lines=lambda: [sC.wait_event(ev) for ev in line_ready])
-                done_match[buf] = torch.cuda.Event(); done_match[buf].record(sC)
+        return ts.step(d_frames)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -213,21 +138,32 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    sA.wait_stream(cur)
-    for sbi in sBs:
-        sbi.wait_stream(cur)
     for _ in range(args.warmup):
         step()
     barrier()
     t0 = time.perf_counter()
+    last_buf = 0
     for _ in range(args.steps):
-        step()
+        last_buf = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    ex.last_batch_status()
-    if not args.orb_only:
-        for lti in lts:
-            lti.last_batch_status()
+    ts.last_batch_status()
+    # ---- parity of the timed step itself: N frames of the LAST timed step (features + the four matcher results) against the CPU oracle.
+    # After the timed region; the oracle is the checker here, never part of what is measured (tests/bench_step_check.py).
+    verified = None
+    if args.verify > 0 and rank == 0 and world == 1 and uniq >= 3:
+        import bench_step_check as BC
+        n_ver = min(args.verify, B)
+        ids = np.unique(np.concatenate([[0, 1], np.linspace(0, B - 1, n_ver).astype(np.int64)]))[:max(n_ver, 2)]   # frames 0 and 1 read the circular halo
+        h = BC.fetch(ts, last_buf)
+        g6 = BC.O.grid6(ts.grid)
+        bad = []
+        for b in ids:
+            bad += BC.check_frame(h, int(b), K, g6, ts.shift, sf, frames_np[int(b) % uniq], args.orb_only)
+        if bad:
+            print(json.dumps({"error": "bench.py --verify: the timed step differs from the oracle", "mismatches": bad[:8]}), file=sys.stderr)
+            sys.exit(3)
+        verified = int(len(ids))
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -264,32 +200,37 @@ def main():
                 match_stage()
             e1.record(sA)
         torch.cuda.synchronize(dev)
-        stage_ms["match_2x"] = e0.elapsed_time(e1) / n_prof
+        stage_ms["match_4x"] = e0.elapsed_time(e1) / n_prof
         match_dbg = {"last_frame": mt_last.debug_counters()[:2].tolist(), "landmarks": mt_lm.debug_counters()[:2].tolist()}
     nl = ex.get_num_scale_levels()
     mean_cand = float(sum(len(ex.debug_read(ex.DBG_CANDIDATES, l, 0)) for l in range(nl)))
     per_frame = algorithmic_bytes(args.rows, args.cols, nl, mean_kp, mean_cand, mean_lines, mean_len, mean_raw)
-    n_match_q = 3 * mean_kp
-    per_frame["match_2x"] = n_match_q * 32 + n_match_q * 15 * (32 + 28)   # 32*M + 60*C, ~15 candidates per query
+    n_match_q = 3 * mean_kp + 3 * mean_lines            # last-frame + 2 x landmark queries, points and lines
+    per_frame["match_4x"] = n_match_q * 32 + n_match_q * 15 * (32 + 28)   # 32*M + 60*C, ~15 candidates per query
     kern = {k: v for k, v in stage_ms.items() if k in per_frame and v > 0}
     dominant = max(kern, key=kern.get)
-    launches = {"pyramid": 7, "lsd_blur11_resize": 2, "lsd_gradient_bins": 2, "lbd_blur5_sobel": 2, "match_2x": 4}.get(dominant, 1)
+    launches = {"pyramid": 7, "lsd_blur11_resize": 2, "lsd_gradient_bins": 2, "lbd_blur5_sobel": 2, "match_4x": 8}.get(dominant, 1)
     dom_bytes = per_frame[dominant] * B
     achieved = dom_bytes / (kern[dominant] * 1e-3) / 1e9
     # HBM-side bytes per launch from the committed rocprofv3 PMC passes (tools/pmc_traffic.py; separate FETCH_SIZE /
     # WRITE_SIZE runs of this same command at the same batch).  Only quoted when the batch matches.
-    traffic = None
+    traffic = traffic_source = None
     stage_kernel = {"lsd_grow": "plp::k_lsd_grow", "fast_cells": "plp::k_fast_cells", "quadtree": "plp::k_quadtree", "lbd": "plp::k_lbd",
                     "orient_rbrief": "plp::k_orient_rbrief", "blur7": "plp::k_blur7", "pyramid": "plp::k_resize_linear",
-                    "lsd_order": "plp::k_lsd_order", "match_2x": "plp::k_match_topk_lds"}
+                    "lsd_order": "plp::k_lsd_order", "match_4x": "plp::k_match_topk_lds"}
     try:
         pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")))
         if pmc.get("batch") == B and dominant in stage_kernel:
             traffic = pmc["traffic_bytes_per_launch"].get(stage_kernel[dominant])
+            traffic_source = pmc.get("source", "profiles/pmc_traffic.json") if traffic is not None else None
     except (OSError, ValueError):
         pass
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                # `traffic` is NOT measured by this run: it is the PMC figure of the committed profile named here (same command, same batch)
+                "traffic_source": traffic_source,
+                # whole path: algorithmic bytes of one frame through all stages x frames/s / peak
+                "path_bytes_per_frame": int(sum(per_frame.values())), "path_frac": round(sum(per_frame.values()) * fps / world / 1e9 / HBM_PEAK_GBS, 6),
                 "launch_ms": round(kern[dominant] / launches, 4), "bytes_per_launch": int(dom_bytes / launches),
                 "stage_ms_per_batch": {k: round(v, 4) for k, v in stage_ms.items()},
                 "stage_GBps": {k: round(per_frame[k] * B / (kern[k] * 1e-3) / 1e9, 1) for k in kern}}
@@ -304,7 +245,7 @@ def main():
         stage = [torch.empty_like(d_frames) for _ in range(2)]
         outs = [[t[HALO:] for t in kps2], [t[HALO:] for t in desc2], [t[HALO:] for t in cnt2], [t[HALO:] for t in kl2], [t[HALO:] for t in lbd2], fn2, [t[HALO:] for t in lcnt2]]
         h_out = [[torch.empty(t[0].shape, dtype=t[0].dtype, pin_memory=True) for t in outs] for _ in range(NBUF)]
-        h_m = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in (m1, n1, m2, n2, m3, n3)]
+        h_m = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in (m1, n1, m2, n2, m3, n3, m4, n4)]
         sH, sD = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
         stage_free = [None, None]; down_done = [None] * NBUF
         frames_default = d_frames
@@ -319,7 +260,7 @@ def main():
                 ev = torch.cuda.Event(); ev.record(sH)
             for s_ in [sA] + sBs:
                 s_.wait_event(ev)
-            buf = step_no[0] % NBUF
+            buf = ts.step_no % NBUF
             if down_done[buf] is not None:
                 sA.wait_event(down_done[buf])
                 for s_ in sBs:
@@ -327,14 +268,14 @@ def main():
             d_frames = stage[sb]
             step()
             d_frames = frames_default
-            sD.wait_event(done_match[buf])
+            sD.wait_event(ts.done_match[buf])
             with torch.cuda.stream(sD):                                      # D2H of this step's features and matches
                 for h, t in zip(h_out[buf], outs):
                     h.copy_(t[buf], non_blocking=True)
-                for h, t in zip(h_m, (m1, n1, m2, n2, m3, n3)):
+                for h, t in zip(h_m, (m1, n1, m2, n2, m3, n3, m4, n4)):
                     h.copy_(t, non_blocking=True)
                 down_done[buf] = torch.cuda.Event(); down_done[buf].record(sD)
-            stage_free[sb] = done_match[buf]
+            stage_free[sb] = ts.done_match[buf]
         for n in range(2):
             host_step(n)
         barrier()
@@ -380,19 +321,22 @@ def main():
         extras["latency_ms_median_mean"] = lat
         extras["latency_note"] = f"{n_lat} synchronous single-frame calls each through the host-pointer C ABI (plp_orb_extract, plp_line_extract, plp_match_host), {uniq} distinct frames"
 
-    what = "ORB extract only" if args.orb_only else "ORB extract || LSD+LBD extract, then match_current_and_last_frames + match_frame_and_landmarks (~2K landmarks) + match_current_and_last_frames_line"
+    what = ("ORB extract only" if args.orb_only else
+            "ORB extract || LSD+LBD extract, then match_current_and_last_frames + match_frame_and_landmarks (~2K landmarks) + match_current_and_last_frames_line + match_frame_and_landmarks_line")
     out = {
         "metric": "frames/sec ORB+LSD extract+match, 640x480 TUM-RGBD, 1/2/4/8 GPU",
         "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": f"TUM-RGBD-shaped replay {args.cols}x{args.rows} (BASELINE configs[1]): {what}; K={K}, 8 levels, 1.2; "
-                               "+ match_current_and_last_frames_line on the key lines; BoW matchers not included",
+                               "BoW matchers not included",
                    "frames_per_rank_per_step": B, "keypoints_mean": round(mean_kp, 1), "lines_mean": round(mean_lines, 1),
-                   "matches_mean": [round(float(n1.float().mean().item()), 1), round(float(n2.float().mean().item()), 1)] + ([] if args.orb_only else [round(float(n3.float().mean().item()), 1)]),
+                   "matches_mean": [round(float(n1.float().mean().item()), 1), round(float(n2.float().mean().item()), 1)] + ([] if args.orb_only else [round(float(n3.float().mean().item()), 1), round(float(n4.float().mean().item()), 1)]),
                    "match_rescans_rounds": (match_dbg if not args.orb_only else None),
                    "sharding": "contiguous frame blocks per rank; one packed RCCL send/recv per rank (ring) of the 2-frame feature halo for the matchers"},
         "roofline": roofline,
+        # frames of the LAST TIMED step whose features and four matcher results were recomputed by the CPU oracle and found identical
+        "verified_frames": verified,
     }
     out.update(extras)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # the CPU baseline is reported at N = 1 only

@@ -362,9 +362,17 @@ plp_status plp_match_host(plp_matcher* ctx, const plp_match_args* a);
 plp_status plp_replay_point_queries_device(const plp_keypoint* feat_kps, const int32_t* feat_counts, int32_t halo, int32_t B, int32_t cap, float shift_x,
                                            float shift_y, float* q1_reproj, int32_t* q1_level, float* q1_angle, int32_t* q1_counts, float* q2_reproj,
                                            int32_t* q2_level, uint8_t* q2_valid, void* hip_stream);
-/* key lines of frame b-1, both end points moved by the shift: q_sp / q_ep [B][cap][2], q_level [B][cap] (KeyLine::octave), q_counts [B] */
+/* key lines of frame b-1, both end points moved by the shift: q_sp / q_ep [B][cap][2], q_level [B][cap] (KeyLine::octave), q_counts [B].
+ * Optional (all four or none, halo >= 2): the local LINE landmarks of frame b for projection::match_frame_and_landmarks_line
+ * (match/projection.cc:124-212, called per frame from tracking_module.cc:1060) = key lines of frame b-2 moved by 2 x shift, then those of
+ * frame b-1 moved by 1 x shift: q2_sp / q2_ep [B][2 cap][2], q2_level [B][2 cap], q2_valid [B][2 cap]; their LBD rows are read in place
+ * (q_desc = feat_lbd + (halo - 2) * cap * 32, q_desc_stride = cap).
+ * Optional: t_kp_octave [B][cap] = frame b's undist_keypts_[i].octave for i < cap (the key POINT octave that matcher reads with a LINE
+ * index, projection.cc:187,192) from feat_kps [halo + B][kp_cap] / feat_kp_counts [halo + B]. */
 plp_status plp_replay_line_queries_device(const plp_keyline* feat_kl, const int32_t* feat_counts, int32_t halo, int32_t B, int32_t cap, float shift_x,
-                                          float shift_y, float* q_sp, float* q_ep, int32_t* q_level, int32_t* q_counts, void* hip_stream);
+                                          float shift_y, float* q_sp, float* q_ep, int32_t* q_level, int32_t* q_counts, float* q2_sp, float* q2_ep,
+                                          int32_t* q2_level, uint8_t* q2_valid, const plp_keypoint* feat_kps, const int32_t* feat_kp_counts, int32_t kp_cap,
+                                          int32_t* t_kp_octave, void* hip_stream);
 
 /* area::match_in_consistent_area(frm_1, frm_2, prev_matched_pts, matched_indices_2_in_frm_1, margin)
  * (src/PLPSLAM/match/area.cc:33-153; monocular initialisation, module/initializer.cc:191-192).  Host pointers, one

@@ -85,14 +85,29 @@ int main(int argc, char** argv) {
         std::fwrite(sf.data(), 4, sf.size(), o); std::fwrite(isq.data(), 4, isq.size(), o);
         std::fwrite(kps.data(), sizeof(cv::KeyPoint), kps.size(), o);
         for (int i = 0; i < n; ++i) std::fwrite(desc.ptr<unsigned char>(i), 1, 32, o);
+        std::vector<unsigned> sums;
+        auto level_sum = [](const cv::Mat& m) { unsigned s = 0; for (int y = 0; y < m.rows; ++y) for (int x = 0; x < m.cols; ++x) s += m.at<unsigned char>(y, x); return s; };
         for (int l = 0; l < nl; ++l) {                                  // the public pyramid (match::stereo reads it)
             const cv::Mat& m = ex.image_pyramid_.at(l);
             std::fwrite(&m.rows, 4, 1, o); std::fwrite(&m.cols, 4, 1, o);
-            unsigned sum = 0;
-            for (int y = 0; y < m.rows; ++y) for (int x = 0; x < m.cols; ++x) sum += m.at<unsigned char>(y, x);
+            const unsigned sum = level_sum(m);
+            sums.push_back(sum);
             std::fwrite(&sum, 4, 1, o);
         }
         std::fclose(o);
+        // the other ways into the lazily downloaded pyramid: after a fresh extract (levels 1.. stale again) each must fetch first
+        const auto& cex = ex;
+        for (int way = 0; way < 5; ++way) {
+            ex.extract(cv::_InputArray(img), cv::_InputArray(), kps, cv::_OutputArray(desc));
+            if (way == 4) ex.set_eager_pyramid(true), ex.extract(cv::_InputArray(img), cv::_InputArray(), kps, cv::_OutputArray(desc));
+            const std::vector<cv::Mat>& plain = way == 0 ? cex.host_pyramid() : static_cast<const std::vector<cv::Mat>&>(cex.image_pyramid_);
+            const cv::Mat* first = way == 1 ? &cex.image_pyramid_.front() : way == 2 ? cex.image_pyramid_.data() : way == 3 ? &*(cex.image_pyramid_.end() - nl) : &plain[0];
+            const cv::Mat& last = way == 1 ? cex.image_pyramid_.back() : first[nl - 1];
+            if (nl > 1 && (level_sum(last) != sums[nl - 1] || level_sum(first[1]) != sums[1] || level_sum(plain[nl - 1]) != sums[nl - 1])) {
+                std::fprintf(stderr, "facade_orb_check: pyramid accessor %d sees stale levels\n", way);
+                return 5;
+            }
+        }
     } catch (const std::exception& e) {
         std::fprintf(stderr, "facade_orb_check: %s\n", e.what());
         return 1;

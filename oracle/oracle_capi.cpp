@@ -160,7 +160,7 @@ double oracle_orb_time_frames(const uint8_t* frames, int n_frames, int rows, int
 }  // extern "C"
 
 // ---- CPU baseline of the whole front-end (bench.py cpu_baseline leg only): per frame ORB extract + LSD/LBD
-// extract + match_current_and_last_frames[_line] + match_frame_and_landmarks against the two previous frames,
+// extract + match_current_and_last_frames[_line] + match_frame_and_landmarks[_line] against the two previous frames,
 // the same work bench.py times on the GPU.  Frame-parallel over n_threads workers; returns wall seconds.
 namespace oracle { struct LineResult; }
 extern "C" {
@@ -174,6 +174,10 @@ unsigned oracle_match_current_and_last_line(const CapiKeyLine* kl, const uint8_t
                                             const float* ep, const float* lxr_sp, const float* lxr_ep, const int* loctave,
                                             const uint8_t* ldesc, const uint8_t* l_has_obs, int m, float margin, int direction, int is_rgbd,
                                             int* line_last);
+unsigned oracle_match_frame_and_landmarks_line(const CapiKeyLine* kl, const uint8_t* lbd, const int* kp_octave, const uint8_t* occupied, int n,
+                                               const float* scale_factors_lsd, const uint8_t* lm_valid, const float* lm_sp,
+                                               const float* lm_ep, const int* lm_level, const uint8_t* lm_desc,
+                                               const uint8_t* lm_has_obs, int m, float margin, float lowe_ratio, int* line_landmark);
 unsigned oracle_match_frame_and_landmarks(const double* grid6, const KeyPoint* kps, const uint8_t* desc, const float* x_right,
                                           const uint8_t* occupied, int n, const float* scale_factors, const uint8_t* lm_valid,
                                           const float* lm_reproj, const float* lm_x_right, const int* lm_level,
@@ -206,9 +210,9 @@ double oracle_front_time_frames2(const uint8_t* frames, int n_frames, int rows, 
             const int per = (n_frames + n_threads - 1) / n_threads, f0 = t * per, f1 = std::min(n_frames, f0 + per);
             std::vector<KeyPoint> k[3];
             std::vector<uint8_t> d[3];
-            std::vector<CapiKeyLine> kl[2];
-            std::vector<uint8_t> lbd[2];
-            int have_lines[2] = {-1, -1};
+            std::vector<CapiKeyLine> kl[3];
+            std::vector<uint8_t> lbd[3];
+            int have_lines[3] = {-1, -1, -1};
             for (int f = f0; f < f1; ++f) {
                 const int cur = f % 3;
                 Image im = wrap(frames + (size_t)f * rows * cols, rows, cols, cols);
@@ -232,13 +236,15 @@ double oracle_front_time_frames2(const uint8_t* frames, int n_frames, int rows, 
                 kp[t] += (long)k[cur].size();
                 const int nl = oracle_line_count(lh, 0);
                 ln[t] += nl;
-                kl[f & 1].assign((size_t)nl, CapiKeyLine{}); lbd[f & 1].assign((size_t)nl * 32, 0);
-                oracle_line_get(lh, 0, kl[f & 1].data(), lbd[f & 1].data(), nullptr, nullptr);
+                kl[cur].assign((size_t)nl, CapiKeyLine{}); lbd[cur].assign((size_t)nl * 32, 0);
+                oracle_line_get(lh, 0, kl[cur].data(), lbd[cur].data(), nullptr, nullptr);
                 oracle_line_free(lh);
-                have_lines[f & 1] = f;
+                have_lines[cur] = f;
+                const int p1 = (f + 2) % 3, p2 = (f + 1) % 3;   // frames f - 1 and f - 2
+                const float sf_lsd[1] = {1.f};
                 // match_current_and_last_frames_line: the previous frame's key lines, both end points moved by the pan
-                if (f > f0 && have_lines[(f & 1) ^ 1] == f - 1 && nl > 0) {
-                    const auto& pk = kl[(f & 1) ^ 1];
+                if (f > f0 && have_lines[p1] == f - 1 && nl > 0) {
+                    const auto& pk = kl[p1];
                     const int m = (int)pk.size();
                     std::vector<float> sp(2 * (size_t)m), ep(2 * (size_t)m), lxr((size_t)m, -1.f), xrp(2 * (size_t)nl, -1.f);
                     std::vector<int> loct((size_t)m), lout((size_t)nl);
@@ -248,10 +254,31 @@ double oracle_front_time_frames2(const uint8_t* frames, int n_frames, int rows, 
                         ep[2 * i] = pk[i].f[6] + shift_x; ep[2 * i + 1] = pk[i].f[7];
                         loct[i] = pk[i].octave;
                     }
-                    const float sf_lsd[1] = {1.f};
-                    mt[t] += oracle_match_current_and_last_line(kl[f & 1].data(), lbd[f & 1].data(), xrp.data(), occl.data(), nl, sf_lsd, 1,
+                    mt[t] += oracle_match_current_and_last_line(kl[cur].data(), lbd[cur].data(), xrp.data(), occl.data(), nl, sf_lsd, 1,
                                                                 one.data(), sp.data(), ep.data(), lxr.data(), lxr.data(), loct.data(),
-                                                                lbd[(f & 1) ^ 1].data(), one.data(), m, 20.f, 0, 0, lout.data());
+                                                                lbd[p1].data(), one.data(), m, 20.f, 0, 0, lout.data());
+                }
+                // match_frame_and_landmarks_line: the key lines of frames f - 2 and f - 1 as local line landmarks (tracking_module.cc:1060)
+                if (f - f0 >= 2 && have_lines[p1] == f - 1 && have_lines[p2] == f - 2 && nl > 0) {
+                    std::vector<float> sp, ep;
+                    std::vector<int> lvl, lout((size_t)nl), kpo((size_t)nl, 0);
+                    std::vector<uint8_t> qd;
+                    for (int which = 0; which < 2; ++which) {
+                        const auto& pk = kl[which ? p1 : p2];
+                        const float sx = which ? shift_x : 2 * shift_x;
+                        for (size_t i = 0; i < pk.size(); ++i) {
+                            sp.push_back(pk[i].f[4] + sx); sp.push_back(pk[i].f[5]);
+                            ep.push_back(pk[i].f[6] + sx); ep.push_back(pk[i].f[7]);
+                            lvl.push_back(pk[i].octave);
+                        }
+                        qd.insert(qd.end(), lbd[which ? p1 : p2].begin(), lbd[which ? p1 : p2].end());
+                    }
+                    const int m = (int)lvl.size();
+                    std::vector<uint8_t> one((size_t)std::max(m, 1), 1), occl((size_t)nl, 0);
+                    for (int i = 0; i < nl && i < (int)k[cur].size(); ++i) kpo[i] = k[cur][i].octave;   // the key POINT octave read with a line index (projection.cc:187)
+                    if (m > 0)
+                        mt[t] += oracle_match_frame_and_landmarks_line(kl[cur].data(), lbd[cur].data(), kpo.data(), occl.data(), nl, sf_lsd, one.data(), sp.data(),
+                                                                       ep.data(), lvl.data(), qd.data(), one.data(), m, 10.f, 0.8f, lout.data());
                 }
                 const int n = (int)k[cur].size();
                 if (f - f0 < 2 || n == 0) continue;

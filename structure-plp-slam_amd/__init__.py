@@ -38,7 +38,7 @@ class orb_params_c(C.Structure):
 
 def build(verbose=False):
     """Compile libplp_front.so for gfx950 (hipcc cross-compiles without a GPU)."""
-    r = subprocess.run(["make", "-C", str(_PKG / "csrc")], capture_output=not verbose, text=True)
+    r = subprocess.run(["make", "-j", str(min(8, os.cpu_count() or 1)), "-C", str(_PKG / "csrc")], capture_output=not verbose, text=True)
     if r.returncode != 0:
         raise RuntimeError("building libplp_front.so failed:\n" + (r.stdout or "") + (r.stderr or ""))
     return LIB_PATH
@@ -107,7 +107,7 @@ _API = [
     ("plp_hamming_matrix_device", C.c_int, [_VP, _VP, _I32, _VP, _I32, _VP, _VP]),
     ("plp_hamming_matrix_host", C.c_int, [_VP, _VP, _I32, _VP, _I32, _VP]),
     ("plp_replay_point_queries_device", C.c_int, [_VP, _VP, _I32, _I32, _I32, C.c_float, C.c_float, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
-    ("plp_replay_line_queries_device", C.c_int, [_VP, _VP, _I32, _I32, _I32, C.c_float, C.c_float, _VP, _VP, _VP, _VP, _VP]),
+    ("plp_replay_line_queries_device", C.c_int, [_VP, _VP, _I32, _I32, _I32, C.c_float, C.c_float, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _VP, _VP]),
 ]
 
 

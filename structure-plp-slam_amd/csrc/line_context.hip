@@ -76,8 +76,8 @@ plp_status build(plp_line* c, int rows, int cols) {
     LinePlanes& P = c->P;
     P.W = cols; P.H = rows;
     P.sw = (int)std::nearbyint(cols * 0.5); P.sh = (int)std::nearbyint(rows * 0.5);   // cvRound(ssize * scale)
-    if (P.sw >= 65536 || P.sh >= 65536 || (((size_t)P.sw * P.sh + 31) / 32 + 256) * 4 > 65536)
-        return set_error(PLP_ERR_UNSUPPORTED, "frame too large for the LSD region-growing kernel (scaled image must stay below ~131k pixels)");
+    if (P.sw >= 65536 || P.sh >= 65536 || (size_t)P.sw * P.sh > kLsdMaxScaledPixels)
+        return set_error(PLP_ERR_UNSUPPORTED, "frame too large for the LSD region-growing kernel (the half-resolution image must not exceed 516,065 pixels)");
     P.pitch = (cols + 63) / 64 * 64; P.spitch = (P.sw + 63) / 64 * 64;
     // LSD constants (line_extractor.cc:113-122, lsd.cpp flsd)
     LsdParams& lp = c->lp;

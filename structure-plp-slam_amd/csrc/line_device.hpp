@@ -9,6 +9,15 @@ namespace plp {
 
 constexpr int kLineCap = 2048;        // raw LSD segments / key lines kept per frame (a 640x480 frame yields ~400)
 constexpr double kLsdNotDef = -1024.0;
+// k_lsd_order packs a seed as (pixel | bin << kLsdSeedPixBits): 10 bits of bin above kLsdSeedPixBits bits of pixel index.  The
+// host refuses a scaled image with more pixels than either this field or the region-growing kernel's LDS bitmap can hold
+// (line_context.hip build(): one constant for the check, the error text and the kernel).
+constexpr int kLsdSeedPixBits = 20;
+constexpr uint32_t kLsdSeedPixMask = (1u << kLsdSeedPixBits) - 1u;
+constexpr size_t kLsdGrowLdsBytes = 65536;                                    // k_lsd_grow: USED bitmap (1 bit per scaled pixel) + 1 KB of ring / scratch
+constexpr size_t kLsdMaxScaledPixels = (kLsdGrowLdsBytes / 4 - 256) * 32 - 31;   // 516,065: the bitmap bound, the tighter of the two
+static_assert(kLsdMaxScaledPixels <= (size_t)kLsdSeedPixMask + 1, "seed packing of k_lsd_order must hold every admitted pixel index");
+static_assert(kLsdSeedPixBits + 10 <= 32, "10 bits of gradient bin above the pixel field");
 
 // Everything region growing needs about one pixel of the scaled image in 16 bytes (two pixels per 32-byte HBM sector):
 //   deg  cv::fastAtan2(gx, -gy) in degrees; the level-line angle of lsd.cpp is (double)deg * (pi / 180)

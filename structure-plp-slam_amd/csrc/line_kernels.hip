@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void k_lsd_gradient(LinePlanes P, LsdParams lp
 // One workgroup per frame; wave q owns the q-th quarter of the row-major pixel sequence.
 //   1  frame maximum from the gradient kernel's per-workgroup values -> bin_coef
 //   2  per 64 pixels: bin = (int)(magnitude * bin_coef) for the defined ones, per-wave histogram (LDS atomics), the defined
-//      pixels compacted as (pixel | bin << 17) into the frame's region-list scratch (free until region growing)
+//      pixels compacted as (pixel | bin << kLsdSeedPixBits) into the frame's region-list scratch (free until region growing)
 //   3  exclusive scan over (bin descending, wave ascending): 4 bins per thread, shuffles, one LDS hop across waves
 //   4  per 64 compacted entries: rank among equal bins by 10 ballots (stable), scatter
 __global__ __launch_bounds__(256) void k_lsd_order(LinePlanes P, LsdParams lp, int n_grad_blocks) {
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void k_lsd_order(LinePlanes P, LsdParams lp, i
             if (v) {
                 const uint32_t bin = (uint32_t)(int)(sqrt((double)v / 4.0) * bin_coef);
                 atomicAdd(&cnt[q][bin], 1u);
-                comp[ncomp + __popcll(defm & ((1ull << lane) - 1ull))] = (uint32_t)((gb + u) * 64 + lane) | (bin << 17);
+                comp[ncomp + __popcll(defm & ((1ull << lane) - 1ull))] = (uint32_t)((gb + u) * 64 + lane) | (bin << kLsdSeedPixBits);
             }
             ncomp += __popcll(defm);
         }
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void k_lsd_order(LinePlanes P, LsdParams lp, i
         if (i0 >= ncomp) break;
         const bool valid = i0 + lane < ncomp;
         const uint32_t e = e4[u];
-        const unsigned v = e >> 17;
+        const unsigned v = e >> kLsdSeedPixBits;
         unsigned long long peers = __ballot(valid);
 #pragma unroll
         for (int bit = 0; bit < 10; ++bit) {
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void k_lsd_order(LinePlanes P, LsdParams lp, i
         }
         if (valid) {
             const int rank = __popcll(peers & ((1ull << lane) - 1ull));
-            order[cnt[q][v] + rank] = e & 0x1ffffu;
+            order[cnt[q][v] + rank] = e & kLsdSeedPixMask;
         }
         __builtin_amdgcn_wave_barrier();
         if (valid && (peers & ((1ull << lane) - 1ull)) == 0) cnt[q][v] += (uint32_t)__popcll(peers);   // one leader per bin
@@ -335,6 +335,9 @@ __device__ __forceinline__ void set_used(const GrowCtx& g, int p) { atomicOr(&g.
 // only for a pixel inside the band that could be the next one accepted, and once when the region is complete.
 // seed_cs: (float)cos / (float)sin of the seed's f64 angle when the caller has them (it evaluates them for 64 seeds in
 // one go: a sincos here runs with 64 lanes computing the same value), else NULL.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "region_grow's hand-scheduled acceptance block (wait states, wave64, v_readlane hazards) is verified for gfx950 only: port it before building for another target"
+#endif
 __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed_deg, const float2* seed_cs, double prec, float c_pass,
                            float c_fail, double& reg_angle, int* n_exact_tests = nullptr) {
     const int lane = g.lane;

@@ -32,18 +32,43 @@ __global__ __launch_bounds__(256) void k_replay_point_queries(const plp_keypoint
     q2_level[o2 + cap + i] = k1.octave; q2_valid[o2 + cap + i] = i < c1;
 }
 
+// q2_* (optional): the local line landmarks of frame b = the key lines of frame b-2 (two shifts away), then those of frame b-1,
+// the line counterpart of the point kernel's q2 (tracking_module.cc:975-1060 search_local_landmarks_line).  t_kp_octave (optional):
+// undist_keypts_.at(i).octave of frame b for i < cap, the key POINT octave match_frame_and_landmarks_line reads with a LINE index
+// (projection.cc:187,192); 0 where frame b has fewer key points than i (the reference's .at() would throw there).
 __global__ __launch_bounds__(256) void k_replay_line_queries(const plp_keyline* __restrict__ kl, const int32_t* __restrict__ counts, int halo, int cap, float sx, float sy,
                                                              float2* __restrict__ q_sp, float2* __restrict__ q_ep, int32_t* __restrict__ q_level,
-                                                             int32_t* __restrict__ q_counts) {
+                                                             int32_t* __restrict__ q_counts, float2* __restrict__ q2_sp, float2* __restrict__ q2_ep,
+                                                             int32_t* __restrict__ q2_level, uint8_t* __restrict__ q2_valid, const plp_keypoint* __restrict__ kps,
+                                                             const int32_t* __restrict__ kp_counts, int kp_cap, int32_t* __restrict__ t_kp_octave) {
     const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
     if (i >= cap) return;
     const int f1 = halo + b - 1;
     const plp_keyline k = kl[(size_t)f1 * cap + i];
     const size_t o = (size_t)b * cap + i;
-    q_sp[o] = make_float2(__fadd_rn(k.startPointX, sx), __fadd_rn(k.startPointY, sy));
-    q_ep[o] = make_float2(__fadd_rn(k.endPointX, sx), __fadd_rn(k.endPointY, sy));
+    const float2 sp1 = make_float2(__fadd_rn(k.startPointX, sx), __fadd_rn(k.startPointY, sy));
+    const float2 ep1 = make_float2(__fadd_rn(k.endPointX, sx), __fadd_rn(k.endPointY, sy));
+    const int c1 = min(max(counts[f1], 0), cap);
+    q_sp[o] = sp1; q_ep[o] = ep1;
     q_level[o] = k.octave;
-    if (i == 0) q_counts[b] = min(max(counts[f1], 0), cap);
+    if (i == 0) q_counts[b] = c1;
+    if (q2_sp) {
+        const int f2 = halo + b - 2;
+        const plp_keyline k2 = kl[(size_t)f2 * cap + i];
+        const int c2 = min(max(counts[f2], 0), cap);
+        const size_t o2 = (size_t)b * 2 * cap;
+        const float sx2 = __fmul_rn(2.f, sx), sy2 = __fmul_rn(2.f, sy);
+        q2_sp[o2 + i] = make_float2(__fadd_rn(k2.startPointX, sx2), __fadd_rn(k2.startPointY, sy2));
+        q2_ep[o2 + i] = make_float2(__fadd_rn(k2.endPointX, sx2), __fadd_rn(k2.endPointY, sy2));
+        q2_level[o2 + i] = k2.octave; q2_valid[o2 + i] = i < c2;
+        q2_sp[o2 + cap + i] = sp1; q2_ep[o2 + cap + i] = ep1;
+        q2_level[o2 + cap + i] = k.octave; q2_valid[o2 + cap + i] = i < c1;
+    }
+    if (t_kp_octave) {
+        const int f0 = halo + b;
+        const int nk = min(max(kp_counts[f0], 0), kp_cap);
+        t_kp_octave[o] = i < nk ? kps[(size_t)f0 * kp_cap + i].octave : 0;
+    }
 }
 
 }  // namespace plp
@@ -65,11 +90,17 @@ plp_status plp_replay_point_queries_device(const plp_keypoint* feat_kps, const i
 }
 
 plp_status plp_replay_line_queries_device(const plp_keyline* feat_kl, const int32_t* feat_counts, int32_t halo, int32_t B, int32_t cap, float shift_x,
-                                          float shift_y, float* q_sp, float* q_ep, int32_t* q_level, int32_t* q_counts, void* hip_stream) {
+                                          float shift_y, float* q_sp, float* q_ep, int32_t* q_level, int32_t* q_counts, float* q2_sp, float* q2_ep,
+                                          int32_t* q2_level, uint8_t* q2_valid, const plp_keypoint* feat_kps, const int32_t* feat_kp_counts, int32_t kp_cap,
+                                          int32_t* t_kp_octave, void* hip_stream) {
     if (!feat_kl || !feat_counts || !q_sp || !q_ep || !q_level || !q_counts) return set_error(PLP_ERR_INVALID_ARG, "NULL argument");
-    if (halo < 1 || B <= 0 || cap <= 0) return set_error(PLP_ERR_INVALID_ARG, "halo must be >= 1, B and cap positive");
+    const bool lm = q2_sp || q2_ep || q2_level || q2_valid;
+    if (lm && !(q2_sp && q2_ep && q2_level && q2_valid)) return set_error(PLP_ERR_INVALID_ARG, "q2_sp, q2_ep, q2_level and q2_valid go together");
+    if (t_kp_octave && (!feat_kps || !feat_kp_counts || kp_cap <= 0)) return set_error(PLP_ERR_INVALID_ARG, "t_kp_octave needs feat_kps, feat_kp_counts and kp_cap");
+    if (halo < (lm ? 2 : 1) || B <= 0 || cap <= 0) return set_error(PLP_ERR_INVALID_ARG, "halo must be >= 1 (>= 2 with the landmark queries), B and cap positive");
     hipLaunchKernelGGL(k_replay_line_queries, dim3((cap + 255) / 256, B), dim3(256), 0, (hipStream_t)hip_stream, feat_kl, feat_counts, halo, cap, shift_x, shift_y,
-                       reinterpret_cast<float2*>(q_sp), reinterpret_cast<float2*>(q_ep), q_level, q_counts);
+                       reinterpret_cast<float2*>(q_sp), reinterpret_cast<float2*>(q_ep), q_level, q_counts, reinterpret_cast<float2*>(q2_sp),
+                       reinterpret_cast<float2*>(q2_ep), q2_level, q2_valid, feat_kps, feat_kp_counts, kp_cap, t_kp_octave);
     PLP_HIP(hipGetLastError());
     return PLP_OK;
 }

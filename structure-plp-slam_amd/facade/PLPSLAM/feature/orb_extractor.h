@@ -65,6 +65,7 @@ public:
         // host code actually looks at them (lazy_pyramid below): 0.64 MB of D2H per frame that mono / RGB-D tracking never needs.
         image_pyramid_.raw(0) = image;
         image_pyramid_.mark_stale();
+        if (eager_pyramid_) image_pyramid_.front();
     }
 
     unsigned int get_max_num_keypoints() const { return static_cast<unsigned int>(get(PLP_ORB_MAX_NUM_KEYPOINTS)); }
@@ -95,7 +96,16 @@ public:
         const cv::Mat& operator[](size_t i) const { fetch(); return base::operator[](i); }
         base::iterator begin() { fetch(); return base::begin(); }
         base::const_iterator begin() const { fetch(); return base::begin(); }
+        base::iterator end() { fetch(); return base::end(); }
+        base::const_iterator end() const { fetch(); return base::end(); }
+        base::const_iterator cbegin() const { fetch(); return base::cbegin(); }
+        base::const_iterator cend() const { fetch(); return base::cend(); }
+        cv::Mat& front() { fetch(); return base::front(); }
+        const cv::Mat& front() const { fetch(); return base::front(); }
         cv::Mat& back() { fetch(); return base::back(); }
+        const cv::Mat& back() const { fetch(); return base::back(); }
+        cv::Mat* data() { fetch(); return base::data(); }
+        const cv::Mat* data() const { fetch(); return base::data(); }
         cv::Mat& raw(size_t i) { return base::at(i); }
         void mark_stale() { stale_ = true; }
         const orb_extractor* owner_ = nullptr;
@@ -109,6 +119,12 @@ public:
     };
     //! Image pyramid (public in the reference, orb_extractor.h:101)
     lazy_pyramid image_pyramid_;
+    //! Every level on the host, as a plain vector: the accessor for host code that binds `const std::vector<cv::Mat>&` (a reference
+    //! to the base class bypasses the lazy accessors above; this one cannot be bypassed).
+    const std::vector<cv::Mat>& host_pyramid() const { image_pyramid_.front(); return image_pyramid_; }
+    //! Opt-in: download levels 1.. after every extract (the reference's behaviour, 0.64 MB of D2H per 640 x 480 frame), for host code
+    //! that reads image_pyramid_ through a base-class reference.  Also switched on by the environment variable PLP_EAGER_PYRAMID=1.
+    void set_eager_pyramid(bool on) { eager_pyramid_ = on; }
 
 private:
     friend class lazy_pyramid;
@@ -135,6 +151,7 @@ private:
     }
     orb_params orb_params_;
     plp_orb* ctx_ = nullptr;
+    bool eager_pyramid_ = [] { const char* e = std::getenv("PLP_EAGER_PYRAMID"); return e && e[0] == '1'; }();
 };
 
 }  // namespace feature

@@ -57,10 +57,14 @@ def exchange_halo(tensors, halo=2, group=None, mode="ring"):
 def exchange_halo_into(buffers, halo=2, group=None, mode="ring"):
     """buffers: feature tensors laid out [halo + B, ...] -- rows halo.. hold this rank's block (the extractors write there), rows
     0..halo-1 receive the predecessor's tail.  Same single exchange as exchange_halo, without re-concatenating the block: the
-    matchers then read `buffer[halo - 1 + b]` as frame b's predecessor straight from the array the extractor filled."""
+    matchers then read `buffer[halo - 1 + b]` as frame b's predecessor straight from the array the extractor filled.
+    Stream order is the CALLER's: the exchange runs on the current stream and waits for nothing else, so the current stream must already
+    be ordered after the extractor streams that fill `buffers` (bench.py / replay_step: stream C waits for the extractors' events first)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         for t in buffers:
-            t[:halo].copy_(t[-halo:])          # single rank: circular replay inside the block
+            # single rank: circular replay inside the block.  With fewer than `halo` frames in the block the tail overlaps the
+            # head rows (rows B..B+halo-1 vs 0..halo-1): copy through a temporary, copy_ on overlapping views is undefined.
+            t[:halo].copy_(t[-halo:].clone() if t.shape[0] < 2 * halo else t[-halo:])
         return
     tails = exchange_halo([t[halo:] for t in buffers], halo=halo, group=group, mode=mode)
     for t, tail in zip(buffers, tails):
@@ -86,16 +90,30 @@ class point_queries:
 
 
 class line_queries:
-    def __init__(self, plp, B, cap, device):
+    """Device-side builder of the line queries (plp_replay_line_queries_device): the previous frame's key lines for
+    match_current_and_last_frames_line and -- with landmarks=True -- the key lines of the two previous frames as local line landmarks for
+    match_frame_and_landmarks_line, plus the key-point octaves that matcher reads with a line index."""
+
+    def __init__(self, plp, B, cap, device, landmarks=False):
         import torch
-        self.plp, self.B, self.cap = plp, B, cap
+        self.plp, self.B, self.cap, self.landmarks = plp, B, cap, landmarks
         z = lambda shape, dt: torch.empty(shape, dtype=dt, device=device)
         self.q_sp, self.q_ep, self.q_level, self.q_counts = z((B, cap, 2), torch.float32), z((B, cap, 2), torch.float32), z((B, cap), torch.int32), z((B,), torch.int32)
+        if landmarks:
+            self.q2_sp, self.q2_ep, self.q2_level, self.q2_valid = z((B, 2 * cap, 2), torch.float32), z((B, 2 * cap, 2), torch.float32), z((B, 2 * cap), torch.int32), z((B, 2 * cap), torch.uint8)
+            self.t_kp_octave = z((B, cap), torch.int32)
 
-    def build(self, feat_kl, feat_counts, halo, shift, stream):
+    def build(self, feat_kl, feat_counts, halo, shift, stream, feat_kps=None, feat_kp_counts=None):
+        """feat_kl: uint8 [halo + B, cap, 68]; feat_counts: int32 [halo + B]; with landmarks also feat_kps uint8 [halo + B, kp_cap, 28] and
+        feat_kp_counts int32 [halo + B] of the same frames"""
+        p = lambda t: t.data_ptr() if t is not None else None
+        lm = self.landmarks
+        kp_cap = feat_kps.shape[1] if lm else 0
         self.plp._check(self.plp.lib().plp_replay_line_queries_device(feat_kl.data_ptr(), feat_counts.data_ptr(), halo, self.B, self.cap, float(shift[0]), float(shift[1]),
                                                                       self.q_sp.data_ptr(), self.q_ep.data_ptr(), self.q_level.data_ptr(), self.q_counts.data_ptr(),
-                                                                      stream.cuda_stream))
+                                                                      p(self.q2_sp) if lm else None, p(self.q2_ep) if lm else None, p(self.q2_level) if lm else None,
+                                                                      p(self.q2_valid) if lm else None, p(feat_kps) if lm else None, p(feat_kp_counts) if lm else None,
+                                                                      kp_cap, p(self.t_kp_octave) if lm else None, stream.cuda_stream))
 
 
 def with_halo(t, halo_t):

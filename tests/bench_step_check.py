@@ -1,0 +1,112 @@
+"""Checker of one benchmarked step (structure-plp-slam_amd/replay_step.py) against the CPU oracle.  TEST INFRASTRUCTURE: imported by
+tests/test_gpu_bench_step.py and by `bench.py --verify N` after its timed region, never by the product path.
+
+For every checked frame b of a step's feature set (frames b-1 / b-2 are the rows before it in the [HALO + B] feature arrays: the rank's own
+frames, or the halo rows 0..HALO-1 that exchange_halo_into filled) the oracle repeats the tracker's per-frame sequence:
+
+  features   orb_extractor::extract / LineFeatureTracker::extract_LSD_LBD of the frame's pixels       (oracle/orb_oracle.cpp, line_oracle.cpp)
+  m1, n1     projection::match_current_and_last_frames       match/projection.cc:214-358   queries = key points of b-1 + shift
+  m2, n2     projection::match_frame_and_landmarks           match/projection.cc:37-121    queries = key points of b-2 + 2 shift, then b-1 + shift
+                                                                                          (the order replay_kernels.hip lists them in; the matcher is order dependent)
+  m3, n3     projection::match_current_and_last_frames_line  match/projection.cc:361-527   queries = key lines of b-1 + shift
+  m4, n4     projection::match_frame_and_landmarks_line      match/projection.cc:124-212   queries = key lines of b-2 + 2 shift, then b-1 + shift;
+                                                                                          t_kp_octave = the frame's key-POINT octaves (the :187,192 quirk)
+and every array must be identical (integer work: bit-exact).
+"""
+import numpy as np
+
+import oracle_lib as O
+
+HALO = 2
+
+
+def _f32(a):
+    return np.asarray(a, np.float32)
+
+
+def fetch(ts, buf):
+    """host copies of feature set `buf` (halo rows included) and of the four match arrays of the step that filled it"""
+    c = lambda t: t.cpu().numpy()
+    return dict(kps=c(ts.kps2[buf]).view(O.KP_DTYPE).reshape(HALO + ts.B, ts.cap), desc=c(ts.desc2[buf]), cnt=c(ts.cnt2[buf]),
+                kl=c(ts.kl2[buf]).view(O.KL_DTYPE).reshape(HALO + ts.B, ts.lcap), lbd=c(ts.lbd2[buf]), lcnt=c(ts.lcnt2[buf]), fn=c(ts.fn2[buf]),
+                m=[c(ts.m1), c(ts.m2)] + ([] if ts.orb_only else [c(ts.m3), c(ts.m4)]),
+                n=[c(ts.n1), c(ts.n2)] + ([] if ts.orb_only else [c(ts.n3), c(ts.n4)]))
+
+
+def check_frame(h, b, K, g6, shift, sf, frame=None, orb_only=False):
+    """h: fetch() result; b: frame of the block; frame: its pixels (uint8 rows x cols) to check the extraction too, or None.
+    Returns a list of mismatch descriptions (empty = frame verified)."""
+    bad = []
+    sx, sy = np.float32(shift[0]), np.float32(shift[1])
+    r0, r1, r2 = HALO + b, HALO + b - 1, HALO + b - 2
+    c0, c1, c2 = int(h["cnt"][r0]), int(h["cnt"][r1]), int(h["cnt"][r2])
+    kp0, d0 = h["kps"][r0][:c0], h["desc"][r0][:c0]
+    cap = h["kps"].shape[1]
+    if frame is not None:
+        ok, od = O.OrbOracle(K).extract(frame)
+        if len(ok) != c0 or not np.array_equal(ok, kp0) or not np.array_equal(od, d0):
+            bad.append(f"frame {b}: ORB key points / descriptors differ from the oracle ({len(ok)} vs {c0})")
+    neg = lambda n: np.full(n, -1, np.float32)
+    # m1: match_current_and_last_frames, margin 20, ratio 0.9, orientation check, no direction
+    p1 = h["kps"][r1][:c1]
+    reproj1 = np.stack([_f32(p1["x"]) + sx, _f32(p1["y"]) + sy], 1).astype(np.float32)
+    want, wn = O.match_current_and_last(g6, kp0, d0, neg(c0), np.zeros(c0, np.uint8), sf, np.ones(c1, np.uint8), reproj1, neg(c1), p1["octave"], p1["angle"],
+                                        h["desc"][r1][:c1], np.ones(c1, np.uint8), 20.0, 0, True)
+    if wn != h["n"][0][b] or not np.array_equal(want, h["m"][0][b][:c0]):
+        bad.append(f"frame {b}: match_current_and_last_frames differs (oracle {wn} matches, device {h['n'][0][b]})")
+    # m2: match_frame_and_landmarks over [b-2 | b-1], 2 * cap query slots with validity flags, margin 10, ratio 0.8
+    two = np.float32(2.0)
+    q_kp = np.concatenate([h["kps"][r2], h["kps"][r1]])
+    q_re = np.concatenate([np.stack([_f32(h["kps"][r2]["x"]) + two * sx, _f32(h["kps"][r2]["y"]) + two * sy], 1),
+                           np.stack([_f32(h["kps"][r1]["x"]) + sx, _f32(h["kps"][r1]["y"]) + sy], 1)]).astype(np.float32)
+    q_valid = np.concatenate([np.arange(cap) < c2, np.arange(cap) < c1]).astype(np.uint8)
+    q_desc = np.concatenate([h["desc"][r2], h["desc"][r1]])
+    q_re = np.where(q_valid[:, None].astype(bool), q_re, np.float32(0))      # slots past a frame's count hold stale bytes; the matcher skips them
+    q_lvl = np.where(q_valid.astype(bool), q_kp["octave"], 0).astype(np.int32)
+    want, wn = O.match_frame_and_landmarks(g6, kp0, d0, neg(c0), np.zeros(c0, np.uint8), sf, q_valid, q_re, neg(2 * cap), q_lvl, q_desc, np.ones(2 * cap, np.uint8),
+                                           10.0, 0.8)
+    if wn != h["n"][1][b] or not np.array_equal(want, h["m"][1][b][:c0]):
+        bad.append(f"frame {b}: match_frame_and_landmarks differs (oracle {wn} matches, device {h['n'][1][b]})")
+    if orb_only:
+        return bad
+    l0, l1, l2 = int(h["lcnt"][r0]), int(h["lcnt"][r1]), int(h["lcnt"][r2])
+    kl0, lb0 = h["kl"][r0][:l0], h["lbd"][r0][:l0]
+    lcap = h["kl"].shape[1]
+    if frame is not None:
+        ora = O.LineOracle(frame)
+        if len(ora.keylsd) != l0 or not np.array_equal(ora.keylsd, kl0) or not np.array_equal(ora.lbd, lb0) or not np.array_equal(ora.linefn, h["fn"][b][:l0]):
+            bad.append(f"frame {b}: key lines / LBD / line functions differ from the oracle ({len(ora.keylsd)} vs {l0})")
+    sf_lsd = np.ones(1, np.float32)
+    pl = h["kl"][r1][:l1]
+    sp = np.stack([_f32(pl["startPointX"]) + sx, _f32(pl["startPointY"]) + sy], 1).astype(np.float32)
+    ep = np.stack([_f32(pl["endPointX"]) + sx, _f32(pl["endPointY"]) + sy], 1).astype(np.float32)
+    want, wn = O.match_current_and_last_line(kl0, lb0, np.full((l0, 2), -1, np.float32), np.zeros(l0, np.uint8), sf_lsd, 1, np.ones(l1, np.uint8), sp, ep, neg(l1), neg(l1),
+                                             pl["octave"], h["lbd"][r1][:l1], np.ones(l1, np.uint8), 20.0, 0, 0)
+    if wn != h["n"][2][b] or not np.array_equal(want, h["m"][2][b][:l0]):
+        bad.append(f"frame {b}: match_current_and_last_frames_line differs (oracle {wn} matches, device {h['n'][2][b]})")
+    ql = np.concatenate([h["kl"][r2], h["kl"][r1]])
+    lv = np.concatenate([np.arange(lcap) < l2, np.arange(lcap) < l1])
+    mul = np.concatenate([np.full(lcap, 2.0, np.float32), np.ones(lcap, np.float32)])
+    sp2 = np.stack([_f32(ql["startPointX"]) + mul * sx, _f32(ql["startPointY"]) + mul * sy], 1).astype(np.float32)
+    ep2 = np.stack([_f32(ql["endPointX"]) + mul * sx, _f32(ql["endPointY"]) + mul * sy], 1).astype(np.float32)
+    sp2 = np.where(lv[:, None], sp2, np.float32(0)); ep2 = np.where(lv[:, None], ep2, np.float32(0))
+    lvl2 = np.where(lv, ql["octave"], 0).astype(np.int32)
+    kp_oct = np.zeros(l0, np.int32)
+    kp_oct[:min(l0, c0)] = kp0["octave"][:min(l0, c0)]
+    want, wn = O.match_frame_and_landmarks_line(kl0, lb0, kp_oct, np.zeros(l0, np.uint8), sf_lsd, lv.astype(np.uint8), sp2, ep2, lvl2, np.concatenate([h["lbd"][r2], h["lbd"][r1]]),
+                                                np.ones(2 * lcap, np.uint8), 10.0, 0.8)
+    if wn != h["n"][3][b] or not np.array_equal(want, h["m"][3][b][:l0]):
+        bad.append(f"frame {b}: match_frame_and_landmarks_line differs (oracle {wn} matches, device {h['n'][3][b]})")
+    return bad
+
+
+def verify(ts, buf, frame_ids, frames_np=None, sf=None):
+    """check the frames `frame_ids` of the step that filled feature set `buf` of tracker_step `ts` (the device must be idle);
+    frames_np: [B, rows, cols] pixels of the block (None = matchers only).  Returns (n_verified, list of mismatches)."""
+    h = fetch(ts, buf)
+    sf = ts.sf if sf is None else sf
+    g6 = O.grid6(ts.grid)
+    bad = []
+    for b in frame_ids:
+        bad += check_frame(h, int(b), ts.K, g6, ts.shift, sf, None if frames_np is None else frames_np[int(b)], ts.orb_only)
+    return len(frame_ids), bad

@@ -51,7 +51,7 @@ def test_line_front_matches_oracle_on_fixture_frames(golden_dir):
     assert total > 50
 
 
-@pytest.mark.parametrize("shape", [(480, 752), (376, 1241), (240, 320), (333, 517)])
+@pytest.mark.parametrize("shape", [(480, 752), (376, 1241), (240, 320), (333, 517), (720, 1280), (724, 728)])   # the last two: scaled image above 2^17 pixels (seed packing of k_lsd_order)
 def test_other_geometries(shape):
     compare(synth.canvas(3 + shape[0], shape[0], shape[1]))
 

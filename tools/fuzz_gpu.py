@@ -102,8 +102,38 @@ def aux_families(rng, seconds):
 def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--seconds", type=float, default=120); ap.add_argument("--seed", type=int, default=0); ap.add_argument("--aux-seconds", type=float, default=0.0)
     ap.add_argument("--only", choices=["orb", "lines", "match"], default=None, help="spend all of --seconds on one family")
+    ap.add_argument("--soak-calls", type=int, default=0, help="robustness soak instead of a parity sweep: N plp_orb_extract calls, each with a fresh context, a freshly "
+                    "allocated random image of a random size and (half of the calls) a fresh mask, no oracle in between -- the pattern that hit the rare GPU "
+                    "page fault of round 2 (DESIGN.md section 5); every 16th call is also compared with the oracle")
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
+    if a.soak_calls:
+        t0, checked, bad = time.time(), 0, 0
+        for n in range(a.soak_calls):
+            h, w = int(rng.integers(120, 720)), int(rng.integers(160, 1300))
+            K = int(rng.choice([100, 500, 1000, 2000])); sfac = float(rng.choice([1.2, 1.1, 1.1, 1.5])); nl = int(rng.integers(1, 9))
+            base = rng.integers(0, 256, (h // 4 + 1, w // 4 + 1), dtype=np.uint8)
+            img = np.repeat(np.repeat(base, 4, 0), 4, 1)[:h, :w].copy()          # fresh allocation per call
+            mask = None
+            if n & 1:
+                mask = np.full((h, w), 255, np.uint8); x0 = int(rng.integers(0, w - 20)); mask[:, x0:x0 + int(rng.integers(10, w // 2))] = 0
+            try:
+                ex = plp.orb_extractor(K, sfac, nl, 20, 7)
+                got = ex.extract(img, mask)
+            except Exception as e:
+                if "limits" not in str(e) and "too small" not in str(e) and "overflow" not in str(e):
+                    raise
+                continue
+            if n % 16 == 0:
+                want = O.OrbOracle(K, sfac, nl, 20, 7).extract(img, mask)
+                checked += 1
+                if not (np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])):
+                    bad += 1; print("ORB MISMATCH (soak)", h, w, K, sfac, nl)
+            del ex, img, mask
+            if (n + 1) % 5000 == 0:
+                print(f"soak: {n + 1} calls, {time.time() - t0:.0f} s", flush=True)
+        print(f"soak: {a.soak_calls} plp_orb_extract calls with fresh contexts / images / masks in {time.time() - t0:.0f} s, no fault; {checked} compared with the oracle, {bad} mismatches")
+        sys.exit(1 if bad else 0)
     budget = a.seconds / 3
     share = lambda fam: (a.seconds if a.only == fam else 0.0) if a.only else budget
     bad = 0
