@@ -188,6 +188,11 @@ plp_status plp_line_last_batch_status(plp_line* ctx);
  * gradient + bins, seed order, region growing, key lines, 5-tap blur + Sobel, LBD, finalize, whole batch}. */
 plp_status plp_line_set_profiling(plp_line* ctx, int32_t enable);
 plp_status plp_line_get_stage_times(plp_line* ctx, double* ms9, int64_t* n_batches);
+/* Tuning / parity tests: waves that share one frame in LSD region growing.  0 (default) = automatic: a workgroup of up to 8 waves per
+ * frame (one sequential main wave, helpers that grow regions of later seeds speculatively and hand them over, k_lsd_grow_mw) for batches
+ * of at most 256 frames -- the single-frame call of data/frame.cc:1146-1163 --, one wave per frame for larger batches; 1 = always one wave
+ * per frame; 2..8 = that many waves for every batch of at most 512 frames.  The results are identical whichever is used. */
+plp_status plp_line_set_grow_waves(plp_line* ctx, int32_t waves);
 
 /* Stage read-back for parity tests (synchronous, host destination, frame of the last call):
  *   SCALED   u8 sh x sw dense (the 11-tap blur + x0.5 image LSD works on)

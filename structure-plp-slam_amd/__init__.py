@@ -76,6 +76,7 @@ _API = [
     ("plp_line_extract_batch_device", C.c_int, [_VP, _VP, _I32, _I32, _I32, _SZ, _SZ, _VP, _VP, _VP, _I32, _VP, _VP]),
     ("plp_line_last_batch_status", C.c_int, [_VP]),
     ("plp_line_set_profiling", C.c_int, [_VP, _I32]),
+    ("plp_line_set_grow_waves", C.c_int, [_VP, _I32]),
     ("plp_line_get_stage_times", C.c_int, [_VP, _VP, _VP]),
     ("plp_line_debug_read", C.c_int, [_VP, C.c_int, _I32, _VP, _SZ, _VP]),
     ("plp_line_scaled_size", C.c_int, [_VP, _VP, _VP]),
@@ -340,6 +341,10 @@ class LineFeatureTracker:
         n = C.c_int32(0)
         _check(lib().plp_line_extract(self._h, _p(img), img.shape[0], img.shape[1], img.strides[0], _p(kl), _p(lbd), _p(fn), LINE_CAP, C.byref(n)))
         return kl[:n.value].copy(), lbd[:n.value].copy(), fn[:n.value].copy()
+
+    def set_grow_waves(self, waves):
+        """0 = automatic, 1 = one wave per frame in LSD region growing, 2..8 = that many waves per frame (plp_line_set_grow_waves)"""
+        _check(lib().plp_line_set_grow_waves(self._h, int(waves)))
 
     def extract_batch(self, d_imgs, d_kl, d_lbd, d_fn, d_counts, stream=None):
         """d_imgs torch uint8 [B,H,W]; d_kl uint8 [B,cap,68]; d_lbd uint8 [B,cap,32]; d_fn float64 [B,cap,3]; d_counts int32 [B]"""

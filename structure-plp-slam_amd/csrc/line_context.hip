@@ -18,12 +18,13 @@ struct plp_line {
     int device = 0;
     hipStream_t stream = nullptr;
     int rows = 0, cols = 0, capB = 0;
+    int grow_waves = 0;   // plp_line_set_grow_waves
     LinePlanes P{};
     LsdParams lp{};
     ResizeExactTab rt{};
     BlurTapsN t11{}, t5{};
     LbdWeightsDev w{};
-    DevBuf tabs, blur11, scaled, pix, g2, maxgrad, undef, order, n_order, reg, raw, n_raw, dx, dy, all_kl, all_lbd, n_all, status, prof, grow_stats;
+    DevBuf tabs, blur11, scaled, pix, g2, maxgrad, undef, order, n_order, reg, mw_heap, raw, n_raw, dx, dy, all_kl, all_lbd, n_all, status, prof, grow_stats;
     DevBuf l0copy, s_kl, s_lbd, s_fn, s_cnt;   // host-API staging
     DevBuf aligned;                             // aligned copy of odd-pitch device frames
     int s_cap = 0;
@@ -135,7 +136,13 @@ plp_status ensure(plp_line* c, int B) {
     PLP_HIP(c->scaled.reserve((size_t)P.spitch * P.sh * B));
     PLP_HIP(c->pix.reserve(n * sizeof(LsdPix) * B));
     PLP_HIP(c->g2.reserve(n * 4 * B)); PLP_HIP(c->n_order.reserve(4 * (size_t)B)); PLP_HIP(c->maxgrad.reserve(4 * ((n + 255) / 256) * (size_t)B)); PLP_HIP(c->undef.reserve((n + 63) / 64 * 8 * B));
-    PLP_HIP(c->order.reserve(nv * 4 * B)); PLP_HIP(c->reg.reserve(n * 4 * B));
+    // region lists: two per frame (several waves per frame, k_lsd_grow_mw, write the refinement's regrowth behind the first growth), and
+    // the helper waves' lists for as many frames as that path is used for (small batches: kLsdMwMaxFrames)
+    P.reg_frame_stride = 2 * n;
+    P.mw_heap_frame_stride = (size_t)(kMwMaxWaves - 1) * 2 * kMwHeap;
+    PLP_HIP(c->order.reserve(nv * 4 * B)); PLP_HIP(c->reg.reserve(P.reg_frame_stride * 4 * B));
+    PLP_HIP(c->mw_heap.reserve(P.mw_heap_frame_stride * 4 * (size_t)std::min(B, kLsdMwMaxFrames)));
+    P.mw_heap = (uint32_t*)c->mw_heap.p;
     PLP_HIP(c->raw.reserve(sizeof(float4) * kLineCap * B)); PLP_HIP(c->n_raw.reserve(4 * (size_t)B));
     PLP_HIP(c->dx.reserve(dxy_frame_entries(P.W, P.H) * 4 * B));
     PLP_HIP(c->all_kl.reserve(sizeof(plp_keyline) * kLineCap * B)); PLP_HIP(c->all_lbd.reserve((size_t)32 * kLineCap * B));
@@ -166,7 +173,7 @@ plp_status run(plp_line* c, const uint8_t* d_imgs, int B, int rows, int cols, si
     }
     PLP_HIP(hipMemsetAsync(c->status.p, 0, 16, st));
     launch_line_front(st, c->P, c->lp, c->rt, c->t11, c->t5, c->w, d_kl, d_lbd, d_fn, cap, d_counts, B, c->profiling ? c->ev : nullptr,
-                      c->side.stream ? &c->side : nullptr);
+                      c->side.stream ? &c->side : nullptr, c->grow_waves);
     PLP_HIP(hipGetLastError());
     if (c->profiling) {
         PLP_HIP(hipEventSynchronize(c->ev[8]));
@@ -228,6 +235,7 @@ plp_status plp_line_last_batch_status(plp_line* c) {
     PLP_HIP(hipStreamSynchronize(c->last_stream));
     if (s[0] & 1) return set_error(PLP_ERR_CAPACITY, "a frame produced more lines than `cap`; output truncated");
     if (s[0] & 4) return set_error(PLP_ERR_OVERFLOW, "more LSD segments than the per-frame capacity");
+    if (s[0] & 16) return set_error(PLP_ERR_HIP, "region growing with several waves per frame timed out in a wait (protocol error, please report the frame)");
     return PLP_OK;
 }
 
@@ -269,6 +277,7 @@ plp_status plp_line_extract(plp_line* c, const uint8_t* img, int32_t rows, int32
     int32_t s[4];
     PLP_HIP(hipMemcpy(s, c->status.p, 16, hipMemcpyDeviceToHost));
     if (s[0] & 4) return set_error(PLP_ERR_OVERFLOW, "more LSD segments than the per-frame capacity");
+    if (s[0] & 16) return set_error(PLP_ERR_HIP, "region growing with several waves per frame timed out in a wait (protocol error, please report the frame)");
     return PLP_OK;
 }
 
@@ -281,6 +290,14 @@ plp_status plp_line_debug_grow_profile(plp_line* c, int64_t* out6) {
     long long v[8] = {0};
     PLP_HIP(hipMemcpy(v, c->prof.p, 48, hipMemcpyDeviceToHost));
     for (int i = 0; i < 6; ++i) out6[i] = v[i];
+    return PLP_OK;
+}
+
+plp_status plp_line_set_grow_waves(plp_line* c, int32_t waves) {
+    if (!c) return set_error(PLP_ERR_INVALID_ARG, "ctx is NULL");
+    if (waves < 0 || waves > kMwMaxWaves) return set_error(PLP_ERR_INVALID_ARG, "waves must be 0 (automatic) .. 8");
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->grow_waves = waves;
     return PLP_OK;
 }
 

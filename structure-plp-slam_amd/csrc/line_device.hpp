@@ -7,6 +7,9 @@
 
 namespace plp {
 
+constexpr int kMwHeap = 8192;        // k_lsd_grow_mw: list entries per helper wave and group buffer
+constexpr int kMwMaxWaves = 8;       // k_lsd_grow_mw: waves per frame (one main + helpers)
+constexpr int kLsdMwMaxFrames = 512; // batches up to this many frames get the buffers of the several-waves-per-frame path
 constexpr int kLineCap = 2048;        // raw LSD segments / key lines kept per frame (a 640x480 frame yields ~400)
 constexpr double kLsdNotDef = -1024.0;
 // k_lsd_order packs a seed as (pixel | bin << kLsdSeedPixBits): 10 bits of bin above kLsdSeedPixBits bits of pixel index.  The
@@ -42,7 +45,9 @@ struct LinePlanes {
     unsigned long long* undef;     // NOTDEF bitmask, 1 bit per scaled pixel          [B][ceil(sh*sw/64)]
     uint32_t* order;          // seed order (pixel index y*sw+x), defined pixels only  [B][(sh-1)*(sw-1)]
     int32_t* n_order;         // number of seeds                      [B]
-    uint32_t* reg;            // region point list scratch            [B][sh*sw]
+    uint32_t* reg; size_t reg_frame_stride;   // region point list scratch [B][reg_frame_stride]: sh*sw entries (the seed sort's scratch as well), 2*sh*sw when
+                              // several waves share a frame (the refinement's second list then follows the first instead of replacing it)
+    uint32_t* mw_heap; size_t mw_heap_frame_stride;   // lists of the speculating waves (k_lsd_grow_mw)  [B][helpers][2][kMwHeap]
     float4* raw; int32_t* n_raw;          // LSD segments             [B][kLineCap], [B]
     short2* dxy;              // Sobel 3x3, (dx, dy) per pixel, in tiles of 8 x 4 pixels = one 128-byte line (dxy_index)  [B][dxy_frame_entries(W, H)]
     plp_keyline* all_kl; uint8_t* all_lbd; int32_t* n_all;   // before the length filter  [B][kLineCap]
@@ -82,6 +87,6 @@ struct LineSideStream { hipStream_t stream; hipEvent_t fork, join; };   // optio
 // blur5+sobel, LBD, finalize}
 void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp, const ResizeExactTab& rt, const BlurTapsN& t11,
                        const BlurTapsN& t5, const LbdWeightsDev& w, plp_keyline* out_kl, uint8_t* out_lbd, double* out_fn, int cap,
-                       int32_t* out_counts, int B, hipEvent_t* ev, const LineSideStream* side);
+                       int32_t* out_counts, int B, hipEvent_t* ev, const LineSideStream* side, int grow_waves);
 
 }  // namespace plp

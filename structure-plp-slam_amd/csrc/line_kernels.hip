@@ -24,6 +24,7 @@
 
 #include "blur_tile.hpp"
 #include "line_device.hpp"
+#include "plp_common.hpp"
 #include "sincos_ziv.hpp"
 #include "xcd_map.hpp"
 
@@ -106,6 +107,7 @@ __global__ __launch_bounds__(256) void k_resize_exact(const uint8_t* __restrict_
 // k_blur_plane<5> + k_resize_exact otherwise.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_blur_half(const uint8_t* __restrict__ src, size_t src_fs, int src_pitch,
                                                                                            uint8_t* __restrict__ dst, size_t dst_fs, int dst_pitch, int w, int h, BlurTapsN taps) {
+    corun_priority();
     __shared__ BlurTileLds<5> S;
     const int tiles_x = (w + kBlurTW - 1) / kBlurTW;
     unsigned t, f;
@@ -132,6 +134,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 // (LsdParams::g2_def_min, same f64 operations).  Only defined pixels get a record (nothing ever reads the others);
 // the g2 plane holds g2 for defined pixels and 0 otherwise -- the seed sort works from it.
 __global__ __launch_bounds__(256) void k_lsd_gradient(LinePlanes P, LsdParams lp) {
+    corun_priority();
     const int b = blockIdx.y;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int n = P.sw * P.sh;
@@ -181,6 +184,7 @@ __global__ __launch_bounds__(256) void k_lsd_gradient(LinePlanes P, LsdParams lp
 //   3  exclusive scan over (bin descending, wave ascending): 4 bins per thread, shuffles, one LDS hop across waves
 //   4  per 64 compacted entries: rank among equal bins by 10 ballots (stable), scatter
 __global__ __launch_bounds__(256) void k_lsd_order(LinePlanes P, LsdParams lp, int n_grad_blocks) {
+    corun_priority();
     __shared__ uint32_t cnt[4][1024];
     __shared__ uint32_t s_red[4], s_wsum[4];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(256) void k_lsd_order(LinePlanes P, LsdParams lp, i
     const uint32_t* g2 = P.g2 + (size_t)b * n;
     uint32_t* order = P.order + (size_t)b * nv;
     const int ngroups = (n + 63) / 64, gper = (ngroups + 3) / 4, g0 = q * gper, g1 = min(ngroups, g0 + gper);
-    uint32_t* comp = P.reg + (size_t)b * n + (size_t)g0 * 64;
+    uint32_t* comp = P.reg + (size_t)b * P.reg_frame_stride + (size_t)g0 * 64;
     int ncomp = 0;
     for (int gb = g0; gb < g1; gb += 4) {   // four groups per trip: their loads are in flight together (a wave walks ~300 groups, one frame per workgroup)
         uint32_t v4[4];
@@ -304,14 +308,26 @@ __device__ __forceinline__ double bcast_d(double v, int src) {
 
 struct GrowCtx {
     const LsdPix* pix;
-    uint32_t* reg; uint32_t* used;   // used: LDS bitmap
+    uint32_t* reg; uint32_t* used;   // used: LDS bitmap (one wave per frame: the USED map; several waves per frame: this wave's OWN marks)
     uint32_t* ring;                  // LDS: the last kRing region points (the breadth-first frontier lives here)
     int sw, sh, lane, ring_mask;
+    // several waves per frame (k_lsd_grow_mw) only:
+    const uint32_t* comm;            // LDS: the COMMITTED USED map -- read here, written by the main wave when a region is final
+    uint32_t* tent;                  // LDS: pixels marked by unfinished speculations of any helper wave; NULL for the main wave
+    int reg_cap;                     // entries the list at `reg` can take
 };
 struct Rect { double x1, y1, x2, y2, width; };
 
 __device__ __forceinline__ bool is_used(const GrowCtx& g, int p) { return (g.used[p >> 5] >> (p & 31)) & 1u; }
 __device__ __forceinline__ void set_used(const GrowCtx& g, int p) { atomicOr(&g.used[p >> 5], 1u << (p & 31)); }   // fire-and-forget ds_or
+template <bool MW> __device__ __forceinline__ bool is_used_t(const GrowCtx& g, int p) {
+    if (MW) return ((g.used[p >> 5] | g.comm[p >> 5]) >> (p & 31)) & 1u;   // mine, or committed by the main wave
+    return is_used(g, p);
+}
+template <bool MW> __device__ __forceinline__ void set_used_t(const GrowCtx& g, int p) {
+    set_used(g, p);
+    if (MW && g.tent) atomicOr(&g.tent[p >> 5], 1u << (p & 31));
+}
 
 // region_grow (lsd.cpp).  The region list is processed breadth-first, SEVEN region points at a time: lanes
 // 9c..9c+8 hold the 3x3 neighbourhood of the c-th point of the batch (63 lanes), so one round of gathers serves
@@ -338,6 +354,11 @@ __device__ __forceinline__ void set_used(const GrowCtx& g, int p) { atomicOr(&g.
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
 #error "region_grow's hand-scheduled acceptance block (wait states, wave64, v_readlane hazards) is verified for gfx950 only: port it before building for another target"
 #endif
+// MW (several waves per frame): "used" = this wave's marks | the committed map; a speculating wave (g.tent != NULL) also marks what it
+// accepts in the tentative map and GIVES UP when the pixel it is about to accept carries another speculation's mark (which of the two
+// regions gets it depends on the seed order: only the main wave knows), or when the list outgrows its space.  Giving up returns
+// -1 - (number of list entries written and marked so far); tests/test_spec_grow_model.py is the model of the protocol.
+template <bool MW>
 __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed_deg, const float2* seed_cs, double prec, float c_pass,
                            float c_fail, double& reg_angle, int* n_exact_tests = nullptr) {
     const int lane = g.lane;
@@ -355,7 +376,7 @@ __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed
     if (lane == 0) {
         const uint32_t c = (uint32_t)sx | ((uint32_t)sy << 16);
         g.reg[0] = c; g.ring[0] = c;
-        set_used(g, seed);
+        set_used_t<MW>(g, seed);
     }
     __builtin_amdgcn_wave_barrier();
     const int slot = lane / 9, k9 = lane - slot * 9;   // slot 0..6 (lane 63: slot 7, idle)
@@ -363,7 +384,9 @@ __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed
     const bool banded = c_pass <= 1.f;
     const int s_cpass = __builtin_amdgcn_readfirstlane(__float_as_int(c_pass)), s_cfail = __builtin_amdgcn_readfirstlane(__float_as_int(c_fail));
     const int ddx = k9 % 3 - 1, ddy = k9 / 3 - 1;
-    for (int i = 0; i < nreg;) {
+    bool gave_up = false;
+    const int list_cap = MW ? __builtin_amdgcn_readfirstlane(g.reg_cap) : 0;   // wave-uniform, and said so (the block below keeps nreg in a scalar register)
+    for (int i = 0; i < nreg && !(MW && gave_up);) {
         const int nb = min(7, nreg - i);
         bool cand = slot < nb;
         int nx = 0, ny = 0, np = 0;
@@ -378,7 +401,9 @@ __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed
         }
         cand = cand && nx >= 0 && ny >= 0 && nx < g.sw && ny < g.sh;
         np = ny * g.sw + nx;
-        if (cand) cand = !is_used(g, np);
+        if (cand) cand = !is_used_t<MW>(g, np);
+        bool foreign = false;   // marked by another wave's unfinished speculation
+        if (MW) { if (g.tent && cand) foreign = (g.tent[np >> 5] >> (np & 31)) & 1u; }
         if (cand) { const LsdPix px = g.pix[np]; deg = px.deg; ncs = px.cs; }   // 16 bytes per live neighbour
         // ---- acceptances in order.  Accepted lanes are strictly increasing, so the set of accepted lanes (a bit mask)
         // already is the order: the list append and the USED bits are written by the accepted lanes themselves after
@@ -478,16 +503,20 @@ __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed
             gt = ~((2ull << k) - 1ull);                                       // lanes above k
             candmask &= ~__builtin_amdgcn_ballot_w64(np == ap);              // the same pixel seen from a later point of the batch
         }
+        if (MW) {   // give up before anything of this round is written or marked
+            if ((g.tent && (acc & __builtin_amdgcn_ballot_w64(foreign))) || nreg > list_cap) { gave_up = true; nreg = n_before; acc = 0; }
+        }
         if ((acc >> lane) & 1ull) {
             const int pos = n_before + __popcll(acc & ((1ull << lane) - 1ull));
             const uint32_t c = (uint32_t)nx | ((uint32_t)ny << 16);
             g.ring[pos & g.ring_mask] = c;
-            set_used(g, np);
+            set_used_t<MW>(g, np);
             __hip_atomic_store(&g.reg[pos], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // HBM copy of the list
         }
         __builtin_amdgcn_wave_barrier();   // LDS operations of one wave complete in order: the next round's reads see these writes
         i += nb;
     }
+    if (MW && gave_up) return -1 - nreg;
     if (!theta_valid) reg_angle = (double)fast_atan2_deg_l(sumdy, sumdx) * (3.14159265358979323846 / 180);
     return nreg;
 }
@@ -647,15 +676,19 @@ __device__ void centroid_sums(const GrowCtx& g, int nreg, double cen[3]) {
 
 // grid = (ceil(B / wpb)), block = 64 * wpb: wave w of a block handles frame wpb*blockIdx.x + w (wpb = waves whose
 // USED bitmap + frontier ring fit 64 KB of LDS together, at most 4).
-__global__ __launch_bounds__(256) void k_lsd_grow(LinePlanes P, LsdParams lp, int B, int wpb, int ring) {
+#ifndef PLP_GROW_MIN_WAVES      // experiment knob: waves per SIMD the register allocation must allow (4 = at most 128 VGPRs)
+#define PLP_GROW_MIN_WAVES 1
+#endif
+__global__ __launch_bounds__(256, PLP_GROW_MIN_WAVES) void k_lsd_grow(LinePlanes P, LsdParams lp, int B, int wpb, int ring) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_bits[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int b = blockIdx.x * wpb + wv;
     if (b >= B) return;
     const int n = P.sw * P.sh, nwords = (n + 31) / 32, nv = (P.sw - 1) * (P.sh - 1);
     GrowCtx g;
+    g.comm = nullptr; g.tent = nullptr; g.reg_cap = n;
     g.pix = P.pix + (size_t)b * n;
-    g.reg = P.reg + (size_t)b * n; const int nw_al = (nwords + 1) & ~1;   // the ring doubles as f64 scratch: 8-byte aligned
+    g.reg = P.reg + (size_t)b * P.reg_frame_stride; const int nw_al = (nwords + 1) & ~1;   // the ring doubles as f64 scratch: 8-byte aligned
     g.used = s_bits + (size_t)wv * (nw_al + ring); g.ring = g.used + nw_al; g.ring_mask = ring - 1;
     g.sw = P.sw; g.sh = P.sh; g.lane = lane;
     // USED map starts as the NOTDEF mask: an undefined pixel is never a seed and never aligned, so
@@ -698,7 +731,7 @@ __global__ __launch_bounds__(256) void k_lsd_grow(LinePlanes P, LsdParams lp, in
             double reg_angle, cen[3];
             long long t0 = tick();
             const float2 seed_cs = make_float2(bcast_f(s_cs.x, t), bcast_f(s_cs.y, t));
-            int nreg = region_grow(g, seed, true, bcast_f(s_deg, t), &seed_cs, lp.prec, lp.c_pass, lp.c_fail, reg_angle, &n_exact_tests);
+            int nreg = region_grow<false>(g, seed, true, bcast_f(s_deg, t), &seed_cs, lp.prec, lp.c_pass, lp.c_fail, reg_angle, &n_exact_tests);
             t_grow += tick() - t0; ++n_seed; n_pix += nreg;
             if (nreg < lp.min_reg_size) continue;
             Rect rec;
@@ -750,7 +783,7 @@ __global__ __launch_bounds__(256) void k_lsd_grow(LinePlanes P, LsdParams lp, in
                     // guard band of the angle test for this tolerance (disabled = every test takes the exact path)
                     float cp = 2.f, cf = -2.f;
                     if (tau >= kLsdBandMinPrec && tau < kLsdBandMaxPrec) { cp = (float)cos(tau - kLsdAngleBand); cf = (float)cos(tau + kLsdAngleBand); }
-                    nreg = region_grow(g, (int)(c0 >> 16) * g.sw + (int)(c0 & 0xffff), false, 0.f, nullptr, tau, cp, cf, reg_angle);
+                    nreg = region_grow<false>(g, (int)(c0 >> 16) * g.sw + (int)(c0 & 0xffff), false, 0.f, nullptr, tau, cp, cf, reg_angle);
                     region_list_fence();
                     if (nreg < 2) keep = false;
                     else {
@@ -811,9 +844,380 @@ __global__ __launch_bounds__(256) void k_lsd_grow(LinePlanes P, LsdParams lp, in
     }
 }
 
+// ------------------------------------------------------------------------------------------ region growing, several waves per frame
+// The latency path (plp_line_extract brings ONE frame, data/frame.cc:1146-1163): k_lsd_grow's single wave is a sequential scan over the
+// seeds; here a workgroup of W waves shares a frame.  Wave 0 (MAIN) is that sequential scan and the only writer of the committed USED map
+// C and of the output; waves 1.. (HELPERS) claim groups of 64 seeds ahead of it and grow their regions SPECULATIVELY: they read C, keep
+// their own marks in a private map O and set them in a shared tentative map T, and leave per region {the list of every pixel they ever
+// accepted, the final list, the rectangle}.  When main reaches such a seed it takes the result iff none of the ever-accepted pixels is
+// committed by then -- C only grows, and a helper that read C(x) = 0 where the sequential scan would see USED(x) = 1 differs from it only
+// if it ACCEPTED x (a rejected pixel leaves no trace), so this is exactly the condition under which the sequential scan grows the same
+// region -- and otherwise grows the region itself.  A helper about to accept a pixel that carries another unfinished speculation's mark
+// gives up (which region gets it depends on the seed order).  Because main never publishes tentative marks (a refinement un-marks and
+// regrows: its pixels reach C only when the region is final), C is monotone.  Model with random interleavings: tests/test_spec_grow_model.py.
+// Results equal k_lsd_grow's bit for bit (tests/test_gpu_line.py runs both).
+// kMwHeap (line_device.hpp): list entries per helper and group buffer (first + second list of all its regions of one group)
+constexpr int kMwEntries = 16;       // results per helper and group buffer
+constexpr int kMwInline = 12;        // list entries of a small region kept in the LDS entry itself (main then never touches HBM for it)
+struct MwResult { int n1, n2, nfinal; bool second, keep; float4 line; };
+struct alignas(16) MwEntry { int pos, n1, n2, nfinal; uint32_t flags, off, pad0, pad1; float4 line; uint32_t inl[kMwInline]; };   // flags: 1 keep, 2 final list = second
+static_assert(sizeof(MwEntry) == 96, "MwEntry layout");
+struct MwLayout { int waves, ring, nw_al, n_groups_cap, lookahead; };   // LDS (words): C | T | waves x (O | ring) | control | owner bytes | entries
+
+// control words are read by all lanes from one address: the value is wave-uniform, and said so (readfirstlane) -- the hand-scheduled
+// block of region_grow wants its loop state in scalar registers, which the compiler only grants to values it can prove uniform
+__device__ __forceinline__ int lds_ld(const int* p) { return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)); }
+__device__ __forceinline__ void lds_st(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ uint32_t heap_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int pix_of(uint32_t c, int sw) { return (int)(c >> 16) * sw + (int)(c & 0xffff); }
+
+// clear bits of `map` for list[0..n) (lists written by this wave: call region_list_fence() first)
+__device__ __forceinline__ void mw_clear(uint32_t* map, const uint32_t* list, int n, int sw, int lane) {
+    for (int j = lane; j < n; j += 64) { const int p = pix_of(heap_ld(list + j), sw); atomicAnd(&map[p >> 5], ~(1u << (p & 31))); }
+}
+
+// One seed through region_grow -> rectangle -> refinement (k_lsd_grow's per-seed body) with TWO lists: the refinement's regrowth is
+// written behind the first growth's list instead of over it, and reduce_region_radius swaps a removed point with the last one instead
+// of overwriting it, so that list 1 [0, n1) and list 2 [n1, n1 + n2) together hold every pixel this attempt ever accepted.
+// Returns false when the speculation gave up (r.n1 / r.n2 = entries marked so far in either list).
+__device__ bool mw_process_seed(const GrowCtx& g, const LsdParams& lp, int seed, float seed_deg, float2 seed_cs, MwResult& r) {
+    const int lane = g.lane;
+    double reg_angle, cen[3];
+    r.n2 = 0; r.second = false; r.keep = false;
+    int nreg = region_grow<true>(g, seed, true, seed_deg, &seed_cs, lp.prec, lp.c_pass, lp.c_fail, reg_angle);
+    if (nreg < 0) { r.n1 = -1 - nreg; r.nfinal = 0; return false; }
+    r.n1 = r.nfinal = nreg;
+    if (nreg < lp.min_reg_size) return true;
+    Rect rec;
+    const int ring_cap = g.ring_mask + 1 >= 256 ? 256 : 0;
+    if (nreg <= ring_cap) rect_from_ring(g, nreg, reg_angle, lp.prec, rec);
+    else {
+        region_list_fence();
+        centroid_sums(g, nreg, cen);
+        region2rect(g, nreg, reg_angle, lp.prec, cen, rec);
+    }
+    bool keep = true;
+    if (lp.refine > 0) {
+        double density = rect_density(nreg, rec);
+        if (density < lp.density_th) {
+            region_list_fence();
+            const uint32_t c0 = g.reg[0];
+            const double xc = (double)(int)(c0 & 0xffff), yc = (double)(int)(c0 >> 16);
+            const double ang_c = pix_ang(g.pix[pix_of(c0, g.sw)]);
+            double sum = 0, s_sum = 0;
+            int nn = 0;
+            for (int rb = 0; rb < nreg; rb += 64) {
+                const int j = rb + lane;
+                double a = 0;
+                bool near = false;
+                if (j < nreg) {
+                    const uint32_t c = g.reg[j];
+                    const int px = (int)(c & 0xffff), py = (int)(c >> 16);
+                    atomicAnd(&g.used[(py * g.sw + px) >> 5], ~(1u << ((py * g.sw + px) & 31)));   // own marks only: the tentative mark stays
+                    const double ddx = (double)px - xc, ddy = (double)py - yc;
+                    near = sqrt(ddx * ddx + ddy * ddy) < rec.width;
+                    a = pix_ang(g.pix[py * g.sw + px]);
+                }
+                const double my_d = near ? angle_diff_signed(a, ang_c) : 0.0;
+                const double my_d2 = my_d * my_d;
+                unsigned long long nb = __ballot(near);
+                while (nb) {
+                    const int u = __ffsll((long long)nb) - 1;
+                    nb &= nb - 1;
+                    sum += bcast_d(my_d, u); s_sum += bcast_d(my_d2, u); ++nn;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            const double mean_angle = sum / (double)nn;
+            const double tau = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / (double)nn + mean_angle * mean_angle);
+            float cp = 2.f, cf = -2.f;
+            if (tau >= kLsdBandMinPrec && tau < kLsdBandMaxPrec) { cp = (float)cos(tau - kLsdAngleBand); cf = (float)cos(tau + kLsdAngleBand); }
+            GrowCtx g2 = g;
+            g2.reg = g.reg + r.n1; g2.reg_cap = g.reg_cap - r.n1;
+            r.second = true;
+            nreg = region_grow<true>(g2, pix_of(c0, g.sw), false, 0.f, nullptr, tau, cp, cf, reg_angle);
+            if (nreg < 0) { r.n2 = -1 - nreg; r.nfinal = 0; return false; }
+            r.n2 = r.nfinal = nreg;
+            region_list_fence();
+            if (nreg < 2) keep = false;
+            else {
+                if (nreg <= ring_cap) rect_from_ring(g2, nreg, reg_angle, lp.prec, rec);
+                else {
+                    centroid_sums(g2, nreg, cen);
+                    region2rect(g2, nreg, reg_angle, lp.prec, cen, rec);
+                }
+                density = rect_density(nreg, rec);
+                if (density < lp.density_th) {
+                    const double r1 = (rec.x1 - xc) * (rec.x1 - xc) + (rec.y1 - yc) * (rec.y1 - yc);
+                    const double r2 = (rec.x2 - xc) * (rec.x2 - xc) + (rec.y2 - yc) * (rec.y2 - yc);
+                    double radSq = r1 > r2 ? r1 : r2;
+                    while (density < lp.density_th) {
+                        radSq *= 0.75 * 0.75;
+                        if (lane == 0) {   // swap-with-last removal is order dependent: one lane, region order
+                            int m = nreg;
+                            for (int i = 0; i < m; ++i) {
+                                const uint32_t c = __hip_atomic_load(&g2.reg[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                                const int px = (int)(c & 0xffff), py = (int)(c >> 16);
+                                const double ddx = (double)px - xc, ddy = (double)py - yc;
+                                if (ddx * ddx + ddy * ddy > radSq) {
+                                    g2.used[(py * g.sw + px) >> 5] &= ~(1u << ((py * g.sw + px) & 31));
+                                    const uint32_t lastv = __hip_atomic_load(&g2.reg[m - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                                    __hip_atomic_store(&g2.reg[i], lastv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                                    __hip_atomic_store(&g2.reg[m - 1], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   // kept behind the live part: list 2 stays a permutation
+                                    --m; --i;
+                                }
+                            }
+                            nreg = m;
+                        }
+                        nreg = __shfl(nreg, 0);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                        __builtin_amdgcn_wave_barrier();
+                        if (nreg < 2) { keep = false; break; }
+                        centroid_sums(g2, nreg, cen);
+                        region2rect(g2, nreg, reg_angle, lp.prec, cen, rec);
+                        density = rect_density(nreg, rec);
+                    }
+                    r.nfinal = nreg;
+                }
+            }
+        }
+    }
+    if (!keep) return true;
+    rec.x1 += 0.5; rec.y1 += 0.5; rec.x2 += 0.5; rec.y2 += 0.5;
+    if (lp.scale != 1) { rec.x1 /= lp.scale; rec.y1 /= lp.scale; rec.x2 /= lp.scale; rec.y2 /= lp.scale; }
+    r.keep = true;
+    r.line = make_float4((float)rec.x1, (float)rec.y1, (float)rec.x2, (float)rec.y2);
+    return true;
+}
+
+// grid = B, block = 64 * L.waves, dynamic LDS per MwLayout (host: mw_layout()).
+__global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, LsdParams lp, MwLayout L) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_mw[];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), b = blockIdx.x;
+    const int n = P.sw * P.sh, nwords = (n + 31) / 32, nv = (P.sw - 1) * (P.sh - 1);
+    const int W = L.waves;
+    uint32_t* C = s_mw;
+    uint32_t* T = C + L.nw_al;
+    uint32_t* O = T + L.nw_al + (size_t)wv * (L.nw_al + L.ring);
+    int* ctrl = reinterpret_cast<int*>(T + L.nw_al + (size_t)W * (L.nw_al + L.ring));
+    // control words: 0 next_group, 1 main_group, 2 done, 3 abort (watchdog), 4.. hstate[NH], then buf_group[NH][2], buf_n[NH][2]
+    int* next_group = ctrl; int* main_group = ctrl + 1; int* done = ctrl + 2; int* wd_abort = ctrl + 3;
+    int* hstate = ctrl + 4; int* buf_group = hstate + kMwMaxWaves; int* buf_n = buf_group + 2 * kMwMaxWaves;
+    uint8_t* owner = reinterpret_cast<uint8_t*>(buf_n + 2 * kMwMaxWaves);                       // [n_groups_cap]: 0 unpublished, 1 main, 2 + (h * 2 + k)
+    MwEntry* entries = reinterpret_cast<MwEntry*>((reinterpret_cast<uintptr_t>(owner + ((L.n_groups_cap + 15) & ~15)) + 15) & ~(uintptr_t)15);   // [helpers][2][kMwEntries]
+    const int n_ord = P.n_order[b];
+    const int n_groups = (n_ord + 63) / 64;
+    {   // C = NOTDEF mask (an undefined pixel is never a seed and never aligned), T = 0, every O = 0
+        const uint32_t* u32 = reinterpret_cast<const uint32_t*>(P.undef + (size_t)b * ((n + 63) / 64));
+        for (int i = threadIdx.x; i < nwords; i += blockDim.x) { C[i] = u32[i]; T[i] = 0; }
+        for (int i = lane; i < L.nw_al; i += 64) O[i] = 0;
+        for (int i = threadIdx.x; i < L.n_groups_cap; i += blockDim.x) owner[i] = 0;
+        if (threadIdx.x < 4 + 5 * kMwMaxWaves) ctrl[threadIdx.x] = threadIdx.x >= 4 + kMwMaxWaves && threadIdx.x < 4 + 3 * kMwMaxWaves ? -1 : 0;   // buf_group = -1 (free)
+    }
+    __syncthreads();
+    const bool is_main = wv == 0;
+    const int h = wv - 1;
+    GrowCtx g;
+    g.pix = P.pix + (size_t)b * n; g.used = O; g.ring = O + L.nw_al; g.ring_mask = L.ring - 1;
+    g.sw = P.sw; g.sh = P.sh; g.lane = lane; g.comm = C; g.tent = is_main ? nullptr : T;
+    uint32_t* const my_heap = is_main ? P.reg + (size_t)b * P.reg_frame_stride : P.mw_heap + (size_t)b * P.mw_heap_frame_stride + (size_t)h * 2 * kMwHeap;
+    g.reg = my_heap; g.reg_cap = is_main ? 2 * n : kMwHeap;
+    const uint32_t* order = P.order + (size_t)b * nv;
+    float4* raw = P.raw + (size_t)b * kLineCap;
+    auto committed = [&](int p) -> bool { return (C[p >> 5] >> (p & 31)) & 1u; };
+    auto tentative = [&](int p) -> bool { return (T[p >> 5] >> (p & 31)) & 1u; };
+    // a spin that lasts longer than any legitimate wait (tens of milliseconds) is a protocol error: every wave leaves, the batch reports it
+    long long wd_t0 = 0;
+    auto spin = [&]() -> bool {
+        __builtin_amdgcn_s_sleep(4);
+        if (wd_t0 == 0) wd_t0 = (long long)clock64();
+        if ((long long)clock64() - wd_t0 > 400000000ll) { lds_st(wd_abort, 1); if (lane == 0) atomicOr(P.status, 16); }
+        return lds_ld(wd_abort) == 0;
+    };
+    // state of the group this wave works on
+    int grp = -1, own = 0, kbuf = 0, hoff = 0, nent = 0, n_lines = 0;
+    uint32_t mine = 0; float s_deg = 0.f; float2 s_cs = make_float2(0.f, 0.f);
+    unsigned long long todo = 0;
+    auto load_group = [&](int gi) {   // seeds of group gi, the angle records of those not yet committed (64 at once)
+        const bool in_range = gi * 64 + lane < n_ord;
+        mine = in_range ? order[gi * 64 + lane] : 0u;
+        const bool fresh = in_range && !committed((int)mine);
+        todo = __ballot(fresh);
+        s_deg = fresh ? g.pix[mine].deg : 0.f;
+        if (fresh) { double sn, cs; sincos((double)s_deg * (3.14159265358979323846 / 180), &sn, &cs); s_cs = make_float2((float)cs, (float)sn); }
+    };
+    for (;;) {
+        int t = -1;
+        wd_t0 = 0;
+        if (is_main) {
+            for (;;) {
+                if (lds_ld(wd_abort)) break;
+                if (!todo) {
+                    if (++grp >= n_groups) break;
+                    lds_st(main_group, grp);
+                    // whose group is it?  unclaimed (next_group == grp): take it; else wait until its helper has said so
+                    own = 0;
+                    while (!own) {
+                        own = __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&owner[grp], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+                        if (own) break;
+                        int expect = grp;
+                        if (lds_ld(next_group) == grp) {
+                            int okc = 0;
+                            if (lane == 0) okc = __hip_atomic_compare_exchange_strong(next_group, &expect, grp + 1, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1 : 0;
+                            if (__builtin_amdgcn_readfirstlane(okc)) {
+                                if (lane == 0) __hip_atomic_store(&owner[grp], (uint8_t)1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                own = 1; break;
+                            }
+                        }
+                        if (!spin()) break;
+                    }
+                    if (!own) break;
+                    wd_t0 = 0;
+                    load_group(grp);
+                    continue;
+                }
+                const int tt = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const int seed = bcast_i((int)mine, tt);
+                if (committed(seed)) continue;
+                if (own > 1) {
+                    const int hh = (own - 2) >> 1, kk = (own - 2) & 1;
+                    bool alive = true;
+                    for (;;) {   // until the helper has dealt with position tt
+                        const int st = lds_ld(&hstate[hh]);
+                        if ((st >> 8) > grp || ((st >> 8) == grp && (st & 255) > tt)) break;
+                        if (!(alive = spin())) break;
+                    }
+                    if (!alive) break;
+                    wd_t0 = 0;
+                    const int ne = lds_ld(&buf_n[hh * 2 + kk]);
+                    const MwEntry* eb = entries + (size_t)(hh * 2 + kk) * kMwEntries;
+                    const unsigned long long hit = __ballot(lane < ne && eb[min(lane, kMwEntries - 1)].pos == tt);
+                    if (hit) {
+                        const MwEntry* e = eb + (__ffsll((long long)hit) - 1);
+                        const int n1 = e->n1, n2 = e->n2, nf = e->nfinal, tot = n1 + n2;
+                        const uint32_t fl = e->flags;
+                        const uint32_t* hl = P.mw_heap + (size_t)b * P.mw_heap_frame_stride + (size_t)(hh * 2 + kk) * kMwHeap + e->off;
+                        bool bad = false;
+                        for (int j0 = 0; j0 < tot; j0 += 64) {
+                            const int j = j0 + lane;
+                            if (j < tot) bad |= committed(pix_of(tot <= kMwInline ? e->inl[j] : heap_ld(hl + j), g.sw));
+                        }
+                        if (!__ballot(bad)) {   // the sequential scan grows exactly this region here: commit it
+                            const int fb = (fl & 2u) ? n1 : 0;
+                            for (int j0 = 0; j0 < nf; j0 += 64) {
+                                const int j = j0 + lane;
+                                if (j < nf) { const int p = pix_of(tot <= kMwInline ? e->inl[fb + j] : heap_ld(hl + fb + j), g.sw); atomicOr(&C[p >> 5], 1u << (p & 31)); }
+                            }
+                            if (fl & 1u) {
+                                if (n_lines < kLineCap) { if (lane == 0) raw[n_lines] = e->line; }
+                                else if (lane == 0) atomicOr(P.status, 4);
+                                ++n_lines;
+                            }
+                            __builtin_amdgcn_wave_barrier();
+                            continue;
+                        }
+                    }
+                }
+                t = tt;
+                break;
+            }
+        } else {
+            for (;;) {
+                if (lds_ld(done) || lds_ld(wd_abort)) break;
+                if (grp >= 0 && todo) {
+                    const int tt = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1;
+                    const int seed = bcast_i((int)mine, tt);
+                    if (committed(seed) || tentative(seed)) { lds_st(&hstate[h], (grp << 8) | (tt + 1)); continue; }
+                    if (nent >= kMwEntries || kMwHeap - hoff < 256) { todo = 0; continue; }   // out of room: main does the rest of the group
+                    t = tt;
+                    break;
+                }
+                if (grp >= 0) {   // group finished
+                    lds_st(&hstate[h], (grp << 8) | 64);
+                    grp = -1;
+                }
+                // recycle: a buffer whose group main has left gives its tentative marks back
+                const int mg = lds_ld(main_group);
+                int free_k = -1;
+                for (int k = 0; k < 2; ++k) {
+                    const int bg = lds_ld(&buf_group[h * 2 + k]);
+                    if (bg >= 0 && bg < mg) {
+                        const int ne = lds_ld(&buf_n[h * 2 + k]);
+                        const MwEntry* eb = entries + (size_t)(h * 2 + k) * kMwEntries;
+                        for (int i = 0; i < ne; ++i) mw_clear(T, my_heap + (size_t)k * kMwHeap + eb[i].off, eb[i].n1 + eb[i].n2, g.sw, lane);
+                        __builtin_amdgcn_wave_barrier();
+                        lds_st(&buf_n[h * 2 + k], 0);
+                        lds_st(&buf_group[h * 2 + k], -1);
+                        free_k = k;
+                    } else if (bg < 0) free_k = k;
+                }
+                const int ng = lds_ld(next_group);
+                if (ng >= n_groups) { if (!spin()) break; wd_t0 = 0; continue; }          // nothing left to claim: wait for `done`
+                if (free_k < 0 || ng >= mg + L.lookahead) { if (!spin()) break; wd_t0 = 0; continue; }
+                int gi = 0;
+                if (lane == 0) gi = __hip_atomic_fetch_add(next_group, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+                gi = __builtin_amdgcn_readfirstlane(gi);
+                if (gi >= n_groups) continue;
+                grp = gi; kbuf = free_k; nent = 0; hoff = 0;
+                lds_st(&hstate[h], grp << 8);
+                lds_st(&buf_n[h * 2 + kbuf], 0);
+                lds_st(&buf_group[h * 2 + kbuf], grp);
+                if (lane == 0) __hip_atomic_store(&owner[grp], (uint8_t)(2 + h * 2 + kbuf), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                load_group(grp);
+            }
+        }
+        t = __builtin_amdgcn_readfirstlane(t);
+        if (t < 0) break;
+        // ---- one region (the only call site of the per-seed code)
+        const int seed = bcast_i((int)mine, t);
+        if (!is_main) { g.reg = my_heap + (size_t)kbuf * kMwHeap + hoff; g.reg_cap = kMwHeap - hoff; }
+        MwResult r;
+        const bool ok = mw_process_seed(g, lp, seed, bcast_f(s_deg, t), make_float2(bcast_f(s_cs.x, t), bcast_f(s_cs.y, t)), r);
+        region_list_fence();
+        const int tot = r.n1 + r.n2;
+        if (is_main) {
+            const int fb = r.second ? r.n1 : 0;
+            for (int j = lane; j < r.nfinal; j += 64) { const int p = pix_of(heap_ld(g.reg + fb + j), g.sw); atomicOr(&C[p >> 5], 1u << (p & 31)); }
+            mw_clear(O, g.reg, tot, g.sw, lane);
+            if (r.keep) {
+                if (n_lines < kLineCap) { if (lane == 0) raw[n_lines] = r.line; }
+                else if (lane == 0) atomicOr(P.status, 4);
+                ++n_lines;
+            }
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            mw_clear(O, g.reg, tot, g.sw, lane);
+            if (ok) {
+                MwEntry* e = entries + (size_t)(h * 2 + kbuf) * kMwEntries + nent;
+                if (lane == 0) {
+                    e->pos = t; e->n1 = r.n1; e->n2 = r.n2; e->nfinal = r.nfinal; e->flags = (r.keep ? 1u : 0u) | (r.second ? 2u : 0u); e->off = (uint32_t)hoff;
+                    e->line = r.line;
+                }
+                if (tot <= kMwInline && lane < tot) e->inl[lane] = heap_ld(g.reg + lane);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the lists in HBM are complete before the entry is announced
+                __builtin_amdgcn_wave_barrier();
+                ++nent; hoff += (tot + 1) & ~1;
+                lds_st(&buf_n[h * 2 + kbuf], nent);
+            } else mw_clear(T, g.reg, tot, g.sw, lane);
+            __builtin_amdgcn_wave_barrier();
+            lds_st(&hstate[h], (grp << 8) | (t + 1));
+        }
+    }
+    if (is_main) {
+        if (lane == 0) {
+            P.n_raw[b] = min(n_lines, kLineCap);
+            int32_t* gs = P.grow_stats + (size_t)b * 4; gs[0] = gs[1] = gs[2] = 0; gs[3] = W;
+        }
+        lds_st(done, 1);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ KeyLine assembly
 // LSDDetector_custom.cpp:262-303 (octave 0).  One wave per frame; class_id = running index of kept lines.
 __global__ __launch_bounds__(64) void k_keylines(LinePlanes P, LsdParams lp) {
+    corun_priority();
     const int b = blockIdx.x, lane = threadIdx.x;
     const int n = P.n_raw[b];
     const float4* raw = P.raw + (size_t)b * kLineCap;
@@ -870,6 +1274,7 @@ constexpr int kSobelTW = 120, kSobelTH = 30;
 struct BlurSobelLds { BlurTileLds<2> b; uint32_t bt[kBlurTH * (kBlurTW / 4)]; };
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_blur_sobel(const uint8_t* __restrict__ src, size_t src_fs, int src_pitch,
                                                                                             short2* __restrict__ dxy, int w, int h, BlurTapsN taps) {
+    corun_priority();
     __shared__ BlurSobelLds S;
     const int tiles_x = (w + kSobelTW - 1) / kSobelTW;
     unsigned t, f;
@@ -917,6 +1322,7 @@ __constant__ int c_comb[32][2] = {{0, 1}, {0, 2}, {0, 3}, {0, 4}, {0, 5}, {0, 6}
 // grid = (4, B), block = 256: one wave per line, 16 lines of a frame in flight (more waves thrash L1/L2: every wave
 // keeps 63 image rows live).
 __global__ __launch_bounds__(256) void k_lbd(LinePlanes P, LbdWeightsDev W) {
+    corun_priority();
     __shared__ float s_row[4][63][8];   // per row: pgdL, ngdL, pgdL2, ngdL2, pgdO, ngdO, pgdO2, ngdO2 (after the global weight)
     __shared__ float s_des[4][72], s_des2[4][72], s_norm[4][4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, b = blockIdx.y;
@@ -1048,6 +1454,7 @@ __global__ __launch_bounds__(256) void k_lbd(LinePlanes P, LbdWeightsDev W) {
 __global__ __launch_bounds__(64) void k_line_finalize(LinePlanes P, LsdParams lp, plp_keyline* __restrict__ out_kl,
                                                       uint8_t* __restrict__ out_lbd, double* __restrict__ out_fn, int cap,
                                                       int32_t* __restrict__ out_counts) {
+    corun_priority();
     const int b = blockIdx.x, lane = threadIdx.x;
     const int n = P.n_all[b];
     int run = 0;
@@ -1080,7 +1487,7 @@ __global__ __launch_bounds__(64) void k_line_finalize(LinePlanes P, LsdParams lp
 // ------------------------------------------------------------------------------------------ launch sequence
 void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp, const ResizeExactTab& rt, const BlurTapsN& t11,
                        const BlurTapsN& t5, const LbdWeightsDev& w, plp_keyline* out_kl, uint8_t* out_lbd, double* out_fn, int cap,
-                       int32_t* out_counts, int B, hipEvent_t* ev, const LineSideStream* side) {
+                       int32_t* out_counts, int B, hipEvent_t* ev, const LineSideStream* side, int grow_waves) {
     auto mark = [&](int i) { if (ev) (void)hipEventRecord(ev[i], st); };
     // The LBD image pass (5-tap blur + Sobel) does not depend on LSD: when a side stream is given (and no per-stage
     // timing is requested) it runs beside the LSD chain and joins before k_lbd.
@@ -1121,8 +1528,29 @@ void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp,
     // the k-th launch; the later stages then chew on the previous launch's segments
     static const int skip_after = [] { const char* e = getenv("PLP_LSD_SKIP_GROW"); return e ? atoi(e) : -1; }();
     static int n_launch = 0;
-    if (skip_after < 0 || n_launch++ < skip_after)
-        hipLaunchKernelGGL(k_lsd_grow, dim3((B + wpb - 1) / wpb), dim3(64 * wpb), per_wave * wpb, st, P, lp, B, wpb, ring);
+    // Few frames (plp_line_extract brings one): a workgroup of several waves per frame (k_lsd_grow_mw: one main wave + helpers that
+    // speculate ahead); many frames: one wave per frame, the chip is full of independent scans anyway.
+    static const int mw_max_b = [] { const char* e = getenv("PLP_LSD_MW_MAX_B"); return std::min(e ? atoi(e) : 256, kLsdMwMaxFrames); }();   // 256 = one workgroup per CU
+    static const int mw_waves = [] { const char* e = getenv("PLP_LSD_MW_WAVES"); int r = e ? atoi(e) : kMwMaxWaves; return std::min(std::max(r, 0), kMwMaxWaves); }();
+    MwLayout L{};
+    size_t mw_bytes = 0;
+    const int want_waves = grow_waves > 0 ? std::min(grow_waves, kMwMaxWaves) : mw_waves;          // plp_line_set_grow_waves overrides the automatic choice
+    if (B <= (grow_waves > 1 ? kLsdMwMaxFrames : mw_max_b) && want_waves >= 2 && P.mw_heap && P.reg_frame_stride >= 2 * (size_t)n) {
+        const int nw_al = (((n + 31) / 32 + 1) & ~1), groups_cap = ((P.sw - 1) * (P.sh - 1) + 63) / 64 + 1;
+        for (int w = want_waves; w >= 2; --w) {
+            const size_t bytes = (size_t)(2 + w) * nw_al * 4 + (size_t)w * 256 * 4 + (4 + 5 * kMwMaxWaves) * 4 + ((groups_cap + 15) & ~15) + 16 +
+                                 (size_t)(w - 1) * 2 * kMwEntries * sizeof(MwEntry);
+            if (bytes <= 160 * 1024) { L.waves = w; L.ring = 256; L.nw_al = nw_al; L.n_groups_cap = groups_cap; L.lookahead = 2 * (w - 1); mw_bytes = bytes; break; }
+        }
+    }
+    if (skip_after < 0 || n_launch++ < skip_after) {
+        if (L.waves >= 2) {
+            static size_t attr_set = 0;
+            if (mw_bytes > attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lsd_grow_mw), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)); attr_set = 160 * 1024; }
+            hipLaunchKernelGGL(k_lsd_grow_mw, dim3(B), dim3(64 * L.waves), mw_bytes, st, P, lp, L);
+        } else
+            hipLaunchKernelGGL(k_lsd_grow, dim3((B + wpb - 1) / wpb), dim3(64 * wpb), per_wave * wpb, st, P, lp, B, wpb, ring);
+    }
     mark(4);
     hipLaunchKernelGGL(k_keylines, dim3(B), dim3(64), 0, st, P, lp);
     mark(5);

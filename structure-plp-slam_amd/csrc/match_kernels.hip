@@ -28,6 +28,7 @@
 
 #include "libstdcxx_sort.hpp"
 #include "match_device.hpp"
+#include "plp_common.hpp"
 #include "xcd_map.hpp"
 
 namespace plp {
@@ -295,6 +296,7 @@ __device__ __forceinline__ void match_topk_query(const MatchProblem& P, int b, i
 // grid = (gx, B) with gx <= ceil(m_cap / 4): the waves of a frame stride over its queries, so a batch of frames with few
 // queries each (key lines: ~50 of a 512 capacity) does not launch hundreds of thousands of workgroups that only exit.
 __global__ __launch_bounds__(256) void k_match_topk(MatchProblem P) {
+    corun_priority();
     const int lane = threadIdx.x & 63, b = blockIdx.y;
     const int m = P.q_counts ? min(P.q_counts[b], P.m_cap) : P.m_cap;
     for (int q = blockIdx.x * 4 + (threadIdx.x >> 6); q < m; q += gridDim.x * 4) match_topk_query(P, b, q, lane);
@@ -304,6 +306,7 @@ __global__ __launch_bounds__(256) void k_match_topk(MatchProblem P) {
 // lines of a frame, ~50 against ~50 -- a wave per query leaves most lanes without a target and spends more on merging the lanes'
 // lists than on the candidates.  grid = (ceil(m_cap / 64), B), block = 64.
 __global__ __launch_bounds__(64) void k_match_topk_lanes(MatchProblem P) {
+    corun_priority();
     const int b = blockIdx.y, q = blockIdx.x * 64 + threadIdx.x;
     const int m = P.q_counts ? min(P.q_counts[b], P.m_cap) : P.m_cap;
     if (q >= m) return;
@@ -350,6 +353,7 @@ constexpr int kCellStride = 4104;  // cell_start[cols * rows + 1] per frame (<= 
 // order is simply its position in this array (16 bits), and a window is one contiguous range per grid column.
 // grid = (B), block = 256.
 __global__ __launch_bounds__(256) void k_match_prep(MatchProblem P) {
+    corun_priority();
     __shared__ int cnt[4096];
     __shared__ uint16_t start[4098];
     __shared__ uint16_t tmp_t[8192];
@@ -438,6 +442,7 @@ __device__ __forceinline__ int row16_sum_i32(int v) {
 // Consecutive queries sit on the same pyramid level (key points are stored by level), so the lanes of a wave run similar trip counts.
 // grid = (ceil(m_cap / kQueriesPerBlock), B), block = 256, dynamic LDS = n_cap * 20 + 2 * kCellStride bytes.
 __global__ __launch_bounds__(256) void k_match_topk_cells(MatchProblem P, int qpb) {
+    corun_priority();
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     unsigned uqb, ub;
     xcd_frame_major(uqb, ub);   // the query blocks of a frame all stage the same sorted target array
@@ -571,6 +576,7 @@ __global__ __launch_bounds__(256) void k_match_topk_cells(MatchProblem P, int qp
 // Brute-force mode: the frame's 32-byte descriptors are staged in LDS, one wave per query scans them all.
 // grid = (ceil(m_cap / kQueriesPerBlock), B), block = 256, dynamic LDS = n_cap * 32 bytes.
 __global__ __launch_bounds__(256) void k_match_topk_lds(MatchProblem P) {
+    corun_priority();
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.y;
     const int m = P.q_counts ? min(P.q_counts[b], P.m_cap) : P.m_cap;
@@ -626,6 +632,7 @@ __device__ __forceinline__ bool accept(const MatchProblem& P, unsigned best, int
 // instantiation rescans through candidate_key() and is the only one that carries its registers (all modes' gates, f64 epipolar tests).
 template <bool kSorted>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_match_resolve(MatchProblem P) {
+    corun_priority();
     extern __shared__ int32_t lds[];
     __shared__ int s_changed, s_num, s_hist[32], s_valid_bin[32], s_full_n, s_claim_tmp[256], s_sort_ws[48];
     __shared__ unsigned s_sort_idx[32];

@@ -64,7 +64,11 @@ struct HostPinned {
         if (n == 0) n = 16;
         // one page of slack behind the payload: a copy engine / blit kernel that fetches its source in 16-byte (or wider) pieces may
         // touch a few bytes past the last requested one, and the page after a host allocation need not be mapped
+#ifdef PLP_NO_STAGING_SLACK      // diagnostic build only (tools/build_variant.sh): the exactly-sized staging buffer of early round 2
+        hipError_t e = hipHostMalloc(&p, n, hipHostMallocDefault);
+#else
         hipError_t e = hipHostMalloc(&p, n + 4096, hipHostMallocDefault);
+#endif
         if (e == hipSuccess) bytes = n; else p = nullptr;
         return e;
     }
@@ -75,5 +79,17 @@ struct HostPinned {
         else for (int y = 0; y < rows; ++y) memcpy(d + (size_t)y * cols, src + (size_t)y * step, (size_t)cols);
     }
 };
+
+// Wave priority of the kernels that run BESIDE region growing (bench step: ORB chain, line front, matchers on their own streams).
+// k_lsd_grow is a dependent-latency chain that issues a third of its cycles; a SIMD that hosts two of its waves should hand its
+// issue slots to the streaming kernel first (s_setprio: 0 = default ... 3 = highest; arbitration among the waves of one SIMD).
+#ifndef PLP_CORUN_PRIO
+#define PLP_CORUN_PRIO 0
+#endif
+__device__ __forceinline__ void corun_priority() {
+#if PLP_CORUN_PRIO > 0
+    __builtin_amdgcn_s_setprio(PLP_CORUN_PRIO);
+#endif
+}
 
 }  // namespace plp

@@ -37,6 +37,7 @@ def check_frame(h, b, K, g6, shift, sf, frame=None, orb_only=False):
     """h: fetch() result; b: frame of the block; frame: its pixels (uint8 rows x cols) to check the extraction too, or None.
     Returns a list of mismatch descriptions (empty = frame verified)."""
     bad = []
+    np.seterr(invalid="ignore", over="ignore")      # slots past a frame's count hold uninitialised bytes; they are masked out below
     sx, sy = np.float32(shift[0]), np.float32(shift[1])
     r0, r1, r2 = HALO + b, HALO + b - 1, HALO + b - 2
     c0, c1, c2 = int(h["cnt"][r0]), int(h["cnt"][r1]), int(h["cnt"][r2])

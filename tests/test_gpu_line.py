@@ -19,9 +19,18 @@ def defined_seed(scaled):
     return d.ravel()
 
 
-def compare(img):
+def compare(img, grow_waves=(0, 1, 3)):
+    """every stage against the oracle, for each way region growing can be run: several waves per frame (0 = automatic: 8 for a single
+    frame; 3 = one main wave + two speculating helpers) and one wave per frame (1); the results must not depend on it"""
     ora = O.LineOracle(img)
+    for w in grow_waves:
+        kl = compare_one(img, ora, w)
+    return kl
+
+
+def compare_one(img, ora, waves):
     lt = plp.LineFeatureTracker()
+    lt.set_grow_waves(waves)
     kl, lbd, fn = lt.extract_LSD_LBD(img)
     assert np.array_equal(lt.debug_read(lt.DBG_SCALED), ora.scaled), "11-tap blur + x0.5 INTER_LINEAR_EXACT"
     assert np.array_equal(lt.debug_read(lt.DBG_ORDER), ora.order[defined_seed(ora.scaled)[ora.order]]), "seed order (pixels with a defined angle: the others never start a region)"

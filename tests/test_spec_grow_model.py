@@ -1,0 +1,223 @@
+"""Model of the multi-wave region growing of k_lsd_grow_mw (csrc/line_kernels.hip): one MAIN wave walks the seeds in order and is the only
+writer of the committed USED map C; HELPER waves run ahead, grow regions of later seeds speculatively (reading C, marking their own pixels in
+a private map O and in the shared tentative map T) and hand the results over; main accepts a result iff none of the pixels it EVER accepted
+(first growth or refinement) is committed at its turn, else grows the region itself.
+
+Why that rule is exact: C only grows, and a helper that read C(x) = 0 where the sequential algorithm would see USED(x) = 1 differs from it only
+if it then ACCEPTS x (a pixel that is tested and rejected leaves no trace) -- so "no accepted pixel is committed at my turn" is precisely the
+condition under which the sequential algorithm grows the same region from the same seed.  A helper that is about to accept a pixel another
+unfinished speculation has marked (T) gives up: which of the two gets it depends on an order it cannot know.
+
+The model runs the protocol on toy images with a toy order-dependent region_grow (running mean angle, refinement that un-marks and regrows with
+a tighter tolerance, radius reduction) under random interleavings of the waves, and requires the sequence of committed regions and the final
+USED map to equal the sequential run.  It checks the protocol, not the arithmetic (tests/test_gpu_line.py does that on the GPU)."""
+import random
+
+import numpy as np
+import pytest
+
+GROUP = 8          # seeds per group (64 on the device)
+LOOKAHEAD = 6      # groups a helper may be ahead of main
+ENTRIES = 3        # results a helper keeps per group before it leaves the rest of the group to main
+
+
+def neighbours(p, W, H):
+    x, y = p % W, p // W
+    for dy in (-1, 0, 1):
+        for dx in (-1, 0, 1):
+            nx, ny = x + dx, y + dy
+            if 0 <= nx < W and 0 <= ny < H:
+                yield ny * W + nx
+
+
+class Abort(Exception):
+    pass
+
+
+def grow(img, seed, tol, is_used, mark, poison=None, tick=None):
+    """toy region_grow: breadth first over the list, running mean `angle`, acceptance depends on the order of acceptances"""
+    W, H, ang = img
+    reg, s = [seed], float(ang[seed])
+    mark(seed)
+    i = 0
+    while i < len(reg):
+        for q in neighbours(reg[i], W, H):
+            if tick:
+                yield from tick()
+            if is_used(q):
+                continue
+            if abs(ang[q] - s / len(reg)) <= tol:
+                if poison and poison(q):
+                    raise Abort()
+                reg.append(q); s += float(ang[q]); mark(q)
+        i += 1
+    return reg
+
+
+def process_seed(img, seed, is_used, mark, unmark, poison=None, tick=None):
+    """grow -> (maybe) refine: un-mark everything, regrow tighter -> (maybe) reduce: drop far pixels.  Returns (final list, every pixel ever
+    accepted, line or None)"""
+    W, H, ang = img
+    first = yield from grow(img, seed, 0.30, is_used, mark, poison, tick)
+    ever = list(first)
+    final = first
+    if len(first) >= 3 and (np.ptp(ang[first]) > 0.35):          # "density too low": refine
+        for q in first:
+            unmark(q)
+        final = yield from grow(img, seed, 0.12, is_used, mark, poison, tick)
+        ever += final
+        if len(final) > 4 and np.ptp(ang[final]) > 0.15:         # reduce_region_radius: keep the points near the seed
+            sx, sy = seed % W, seed // W
+            keep = [q for q in final if abs(q % W - sx) + abs(q // W - sy) <= 2]
+            for q in final:
+                if q not in keep:
+                    unmark(q)
+            final = keep
+    line = (seed, len(final), float(np.sum(ang[final]))) if len(final) >= 3 else None
+    return final, ever, line
+
+
+def run_gen(g):
+    try:
+        while True:
+            next(g)
+    except StopIteration as e:
+        return e.value
+
+
+def sequential(img, order):
+    used = set()
+    out = []
+    for seed in order:
+        if seed in used:
+            continue
+        own = set()
+        final, ever, line = run_gen(process_seed(img, seed, lambda q: q in used or q in own, own.add, own.discard))
+        used.update(final)
+        out.append((seed, tuple(final), line))
+    return out, used
+
+
+def concurrent(img, order, n_helpers, rng):
+    C, T = set(), set()
+    n_groups = (len(order) + GROUP - 1) // GROUP
+    owner = [None] * n_groups          # None / "main" / helper id
+    progress = [0] * n_groups          # positions of the group the owner has dealt with (published after the entry, if any)
+    entries = [[] for _ in range(n_groups)]
+    state = {"main_group": 0, "next_group": 0, "done": False, "wasted": 0, "used_spec": 0}
+    out = []
+
+    def tick():
+        yield
+
+    def helper(hid):
+        pending = []        # groups whose T marks this helper still has to clear (after main is through with them)
+        while not state["done"]:
+            for g in [g for g in pending if state["main_group"] > g]:
+                for e in entries[g]:
+                    T.difference_update(e["ever"])
+                pending.remove(g)
+            g = state["next_group"]
+            if g >= n_groups:
+                yield
+                if not pending:
+                    return
+                continue
+            if g >= state["main_group"] + LOOKAHEAD or len(pending) >= 2:
+                yield
+                continue
+            if owner[g] is not None:            # claimed meanwhile (the device does this with one atomic)
+                state["next_group"] = max(state["next_group"], g + 1)
+                continue
+            owner[g] = hid; state["next_group"] = g + 1
+            pending.append(g)
+            for k, seed in enumerate(order[g * GROUP:(g + 1) * GROUP]):
+                yield
+                if len(entries[g]) >= ENTRIES:
+                    break                       # out of result slots: main does the rest of this group itself
+                if seed in C or seed in T:
+                    progress[g] = k + 1
+                    continue
+                own, marked = set(), []
+
+                def mark(q, own=own, marked=marked):
+                    own.add(q); T.add(q); marked.append(q)
+                try:
+                    final, ever, line = yield from process_seed(img, seed, lambda q: q in C or q in own, mark, own.discard,
+                                                                poison=lambda q: q in T and q not in own, tick=tick)
+                    entries[g].append(dict(pos=k, seed=seed, final=final, ever=ever, line=line))
+                except Abort:
+                    T.difference_update(marked)     # every pixel this attempt ever marked (the device walks its two lists)
+                progress[g] = k + 1
+            progress[g] = GROUP
+
+    def main():
+        for g in range(n_groups):
+            state["main_group"] = g
+            if owner[g] is None:
+                owner[g] = "main"
+                state["next_group"] = max(state["next_group"], g + 1)
+            seeds = order[g * GROUP:(g + 1) * GROUP]
+            for k, seed in enumerate(seeds):
+                yield
+                if seed in C:
+                    continue
+                e = None
+                if owner[g] != "main":
+                    while progress[g] <= k and not (entries[g] and entries[g][-1]["pos"] >= k):
+                        yield                   # the helper is still busy with (or before) this position
+                    e = next((x for x in entries[g] if x["pos"] == k), None)
+                if e is not None and not any(q in C for q in e["ever"]):
+                    final, line = e["final"], e["line"]
+                    state["used_spec"] += 1
+                else:
+                    if e is not None:
+                        state["wasted"] += 1
+                    own = set()
+                    final, ever, line = yield from process_seed(img, seed, lambda q: q in C or q in own, own.add, own.discard, tick=tick)
+                C.update(final)
+                out.append((seed, tuple(final), line))
+        state["main_group"] = n_groups
+        state["done"] = True
+
+    waves = [main()] + [helper(h) for h in range(n_helpers)]
+    alive = list(range(len(waves)))
+    steps = 0
+    while alive:
+        w = rng.choice(alive) if rng.random() < 0.8 else alive[0]
+        try:
+            next(waves[w])
+        except StopIteration:
+            alive.remove(w)
+        steps += 1
+        assert steps < 5_000_000, "the protocol does not terminate"
+    return out, C, state
+
+
+def toy_image(seed, W=20, H=14):
+    r = np.random.default_rng(seed)
+    ang = r.uniform(0, 1, W * H)
+    # a few coherent "edges": rows / columns / blocks of nearly equal angle, so that regions are long and seeds of one edge are neighbours in the order
+    for _ in range(10):
+        a = r.uniform(0, 1)
+        if r.uniform() < 0.5:
+            y, x0, x1 = int(r.integers(0, H)), int(r.integers(0, W // 2)), int(r.integers(W // 2, W))
+            ang[y * W + x0:y * W + x1] = a + r.normal(0, 0.03, x1 - x0)
+        else:
+            x, y0, y1 = int(r.integers(0, W)), int(r.integers(0, H // 2)), int(r.integers(H // 2, H))
+            ang[x + W * np.arange(y0, y1)] = a + r.normal(0, 0.05, y1 - y0)
+    order = list(np.argsort(-ang, kind="stable"))          # "gradient bins descending": neighbours on an edge are close in the order
+    return (W, H, ang), [int(p) for p in order]
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_speculative_protocol_equals_the_sequential_scan(seed):
+    img, order = toy_image(seed)
+    want, want_used = sequential(img, order)
+    assert len(want) > 20
+    for n_helpers in (1, 3, 7):
+        rng = random.Random(1000 * seed + n_helpers)
+        got, used, st = concurrent(img, order, n_helpers, rng)
+        assert got == want, (seed, n_helpers)
+        assert used == want_used
+    assert st["used_spec"] > 0          # the helpers did contribute

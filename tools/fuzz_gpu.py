@@ -168,6 +168,7 @@ def main():
     while time.time() - t0 < share("lines"):
         h, w = int(rng.integers(200, 600)), int(rng.integers(240, 900))
         img = rand_image(rng, h, w)
+        lt.set_grow_waves((0, 1, 3, 5)[n % 4])          # several waves per frame (automatic / 3 / 5) and one wave per frame: same results
         kl, lbd, fn = lt.extract_LSD_LBD(img)
         o = O.LineOracle(img)
         ok = len(kl) == len(o.keylsd) and np.array_equal(lbd, o.lbd) and np.array_equal(kl, o.keylsd) and np.array_equal(fn, o.linefn)
