@@ -313,7 +313,9 @@ struct GrowCtx {
     int sw, sh, lane, ring_mask;
     // several waves per frame (k_lsd_grow_mw) only:
     const uint32_t* comm;            // LDS: the COMMITTED USED map -- read here, written by the main wave when a region is final
-    uint32_t* tent;                  // LDS: pixels marked by unfinished speculations of any helper wave; NULL for the main wave
+    uint32_t* tent;                  // LDS: 4 bits per pixel, the helper wave (1..) whose unfinished speculation marked it last, 0 = none; NULL for the main wave
+    const int* tent_pos;             // LDS: per helper, the seed position (rank in the seed order) of its latest attempt
+    int tent_id, my_pos;             // this helper's id (1..) and the seed position of the attempt it is growing
     int reg_cap;                     // entries the list at `reg` can take
 };
 struct Rect { double x1, y1, x2, y2, width; };
@@ -326,7 +328,11 @@ template <bool MW> __device__ __forceinline__ bool is_used_t(const GrowCtx& g, i
 }
 template <bool MW> __device__ __forceinline__ void set_used_t(const GrowCtx& g, int p) {
     set_used(g, p);
-    if (MW && g.tent) atomicOr(&g.tent[p >> 5], 1u << (p & 31));
+    if (MW && g.tent) {   // the owner nibble becomes mine (two atomics: the transient 0 only hides a mark for a moment, which costs nothing but a wasted attempt)
+        const unsigned sh = (unsigned)(p & 7) * 4u;
+        atomicAnd(&g.tent[p >> 3], ~(15u << sh));
+        atomicOr(&g.tent[p >> 3], (unsigned)g.tent_id << sh);
+    }
 }
 
 // region_grow (lsd.cpp).  The region list is processed breadth-first, SEVEN region points at a time: lanes
@@ -354,10 +360,13 @@ template <bool MW> __device__ __forceinline__ void set_used_t(const GrowCtx& g, 
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
 #error "region_grow's hand-scheduled acceptance block (wait states, wave64, v_readlane hazards) is verified for gfx950 only: port it before building for another target"
 #endif
-// MW (several waves per frame): "used" = this wave's marks | the committed map; a speculating wave (g.tent != NULL) also marks what it
-// accepts in the tentative map and GIVES UP when the pixel it is about to accept carries another speculation's mark (which of the two
-// regions gets it depends on the seed order: only the main wave knows), or when the list outgrows its space.  Giving up returns
-// -1 - (number of list entries written and marked so far); tests/test_spec_grow_model.py is the model of the protocol.
+// MW (several waves per frame): "used" = this wave's marks | the committed map; a speculating wave (g.tent != NULL) also writes its id
+// over the tentative-owner nibble of what it accepts, and when the pixel it is about to accept carries ANOTHER helper's id it looks at
+// that helper's seed position: an EARLIER seed has precedence in the sequential scan and will most likely take the pixel (and this seed
+// with it) -- the wave GIVES UP, cheaply; a LATER seed's claim is ignored and overwritten (that speculation will be found invalid when its
+// turn comes, by the one rule that decides validity: none of its pixels may be committed by then).  So the earliest unfinished region
+// never yields and the critical path keeps moving in a helper, not in the main wave.  It also gives up when the list outgrows its space.
+// Giving up returns -1 - (number of list entries written and marked so far); tests/test_spec_grow_model.py is the model of the protocol.
 template <bool MW>
 __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed_deg, const float2* seed_cs, double prec, float c_pass,
                            float c_fail, double& reg_angle, int* n_exact_tests = nullptr) {
@@ -403,7 +412,12 @@ __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed
         np = ny * g.sw + nx;
         if (cand) cand = !is_used_t<MW>(g, np);
         bool foreign = false;   // marked by another wave's unfinished speculation
-        if (MW) { if (g.tent && cand) foreign = (g.tent[np >> 5] >> (np & 31)) & 1u; }
+        if (MW) {
+            if (g.tent && cand) {
+                const int owner = (int)((g.tent[np >> 3] >> ((unsigned)(np & 7) * 4u)) & 15u);
+                if (owner != 0 && owner != g.tent_id) foreign = g.tent_pos[owner - 1] < g.my_pos;   // an earlier seed's claim: yield to it
+            }
+        }
         if (cand) { const LsdPix px = g.pix[np]; deg = px.deg; ncs = px.cs; }   // 16 bytes per live neighbour
         // ---- acceptances in order.  Accepted lanes are strictly increasing, so the set of accepted lanes (a bit mask)
         // already is the order: the list append and the USED bits are written by the accepted lanes themselves after
@@ -686,7 +700,7 @@ __global__ __launch_bounds__(256, PLP_GROW_MIN_WAVES) void k_lsd_grow(LinePlanes
     if (b >= B) return;
     const int n = P.sw * P.sh, nwords = (n + 31) / 32, nv = (P.sw - 1) * (P.sh - 1);
     GrowCtx g;
-    g.comm = nullptr; g.tent = nullptr; g.reg_cap = n;
+    g.comm = nullptr; g.tent = nullptr; g.tent_pos = nullptr; g.tent_id = 0; g.my_pos = 0; g.reg_cap = n;
     g.pix = P.pix + (size_t)b * n;
     g.reg = P.reg + (size_t)b * P.reg_frame_stride; const int nw_al = (nwords + 1) & ~1;   // the ring doubles as f64 scratch: 8-byte aligned
     g.used = s_bits + (size_t)wv * (nw_al + ring); g.ring = g.used + nw_al; g.ring_mask = ring - 1;
@@ -862,7 +876,7 @@ constexpr int kMwInline = 12;        // list entries of a small region kept in t
 struct MwResult { int n1, n2, nfinal; bool second, keep; float4 line; };
 struct alignas(16) MwEntry { int pos, n1, n2, nfinal; uint32_t flags, off, pad0, pad1; float4 line; uint32_t inl[kMwInline]; };   // flags: 1 keep, 2 final list = second
 static_assert(sizeof(MwEntry) == 96, "MwEntry layout");
-struct MwLayout { int waves, ring, nw_al, n_groups_cap, lookahead; };   // LDS (words): C | T | waves x (O | ring) | control | owner bytes | entries
+struct MwLayout { int waves, ring, nw_al, n_groups_cap, lookahead; };   // LDS (words): C | T (4 bits per pixel) | waves x (O | ring) | control | owner bytes | entries
 
 // control words are read by all lanes from one address: the value is wave-uniform, and said so (readfirstlane) -- the hand-scheduled
 // block of region_grow wants its loop state in scalar registers, which the compiler only grants to values it can prove uniform
@@ -871,6 +885,14 @@ __device__ __forceinline__ void lds_st(int* p, int v) { __hip_atomic_store(p, v,
 __device__ __forceinline__ uint32_t heap_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int pix_of(uint32_t c, int sw) { return (int)(c >> 16) * sw + (int)(c & 0xffff); }
 
+// give back the tentative-owner nibbles of list[0..n) that still carry this helper's id (a later helper may have taken a pixel over)
+__device__ __forceinline__ void mw_clear_owner(uint32_t* tw, const uint32_t* list, int n, int sw, int lane, int me) {
+    for (int j = lane; j < n; j += 64) {
+        const int p = pix_of(heap_ld(list + j), sw);
+        const unsigned sh = (unsigned)(p & 7) * 4u;
+        if (((tw[p >> 3] >> sh) & 15u) == (unsigned)me) atomicAnd(&tw[p >> 3], ~(15u << sh));
+    }
+}
 // clear bits of `map` for list[0..n) (lists written by this wave: call region_list_fence() first)
 __device__ __forceinline__ void mw_clear(uint32_t* map, const uint32_t* list, int n, int sw, int lane) {
     for (int j = lane; j < n; j += 64) { const int p = pix_of(heap_ld(list + j), sw); atomicAnd(&map[p >> 5], ~(1u << (p & 31))); }
@@ -998,21 +1020,24 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
     const int W = L.waves;
     uint32_t* C = s_mw;
     uint32_t* T = C + L.nw_al;
-    uint32_t* O = T + L.nw_al + (size_t)wv * (L.nw_al + L.ring);
-    int* ctrl = reinterpret_cast<int*>(T + L.nw_al + (size_t)W * (L.nw_al + L.ring));
+    uint32_t* O = T + 4 * L.nw_al + (size_t)wv * (L.nw_al + L.ring);
+    int* ctrl = reinterpret_cast<int*>(T + 4 * L.nw_al + (size_t)W * (L.nw_al + L.ring));
     // control words: 0 next_group, 1 main_group, 2 done, 3 abort (watchdog), 4.. hstate[NH], then buf_group[NH][2], buf_n[NH][2]
     int* next_group = ctrl; int* main_group = ctrl + 1; int* done = ctrl + 2; int* wd_abort = ctrl + 3;
     int* hstate = ctrl + 4; int* buf_group = hstate + kMwMaxWaves; int* buf_n = buf_group + 2 * kMwMaxWaves;
-    uint8_t* owner = reinterpret_cast<uint8_t*>(buf_n + 2 * kMwMaxWaves);                       // [n_groups_cap]: 0 unpublished, 1 main, 2 + (h * 2 + k)
+    int* hcount = buf_n + 2 * kMwMaxWaves;                                                          // diagnostics: helper attempts, give-ups
+    int* cur_pos = hcount + 4;                                                                      // [helpers]: seed position of each helper's latest attempt
+    uint8_t* owner = reinterpret_cast<uint8_t*>(cur_pos + kMwMaxWaves);                       // [n_groups_cap]: 0 unpublished, 1 main, 2 + (h * 2 + k)
     MwEntry* entries = reinterpret_cast<MwEntry*>((reinterpret_cast<uintptr_t>(owner + ((L.n_groups_cap + 15) & ~15)) + 15) & ~(uintptr_t)15);   // [helpers][2][kMwEntries]
     const int n_ord = P.n_order[b];
     const int n_groups = (n_ord + 63) / 64;
     {   // C = NOTDEF mask (an undefined pixel is never a seed and never aligned), T = 0, every O = 0
         const uint32_t* u32 = reinterpret_cast<const uint32_t*>(P.undef + (size_t)b * ((n + 63) / 64));
-        for (int i = threadIdx.x; i < nwords; i += blockDim.x) { C[i] = u32[i]; T[i] = 0; }
+        for (int i = threadIdx.x; i < nwords; i += blockDim.x) C[i] = u32[i];
+        for (int i = threadIdx.x; i < 4 * L.nw_al; i += blockDim.x) T[i] = 0;
         for (int i = lane; i < L.nw_al; i += 64) O[i] = 0;
         for (int i = threadIdx.x; i < L.n_groups_cap; i += blockDim.x) owner[i] = 0;
-        if (threadIdx.x < 4 + 5 * kMwMaxWaves) ctrl[threadIdx.x] = threadIdx.x >= 4 + kMwMaxWaves && threadIdx.x < 4 + 3 * kMwMaxWaves ? -1 : 0;   // buf_group = -1 (free)
+        if (threadIdx.x < 8 + 6 * kMwMaxWaves) ctrl[threadIdx.x] = threadIdx.x >= 4 + kMwMaxWaves && threadIdx.x < 4 + 3 * kMwMaxWaves ? -1 : 0;   // buf_group = -1 (free)
     }
     __syncthreads();
     const bool is_main = wv == 0;
@@ -1020,12 +1045,13 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
     GrowCtx g;
     g.pix = P.pix + (size_t)b * n; g.used = O; g.ring = O + L.nw_al; g.ring_mask = L.ring - 1;
     g.sw = P.sw; g.sh = P.sh; g.lane = lane; g.comm = C; g.tent = is_main ? nullptr : T;
+    g.tent_pos = cur_pos; g.tent_id = wv; g.my_pos = 0;
     uint32_t* const my_heap = is_main ? P.reg + (size_t)b * P.reg_frame_stride : P.mw_heap + (size_t)b * P.mw_heap_frame_stride + (size_t)h * 2 * kMwHeap;
     g.reg = my_heap; g.reg_cap = is_main ? 2 * n : kMwHeap;
     const uint32_t* order = P.order + (size_t)b * nv;
     float4* raw = P.raw + (size_t)b * kLineCap;
     auto committed = [&](int p) -> bool { return (C[p >> 5] >> (p & 31)) & 1u; };
-    auto tentative = [&](int p) -> bool { return (T[p >> 5] >> (p & 31)) & 1u; };
+    auto tentative_owner = [&](int p) -> int { return __builtin_amdgcn_readfirstlane((int)((T[p >> 3] >> ((unsigned)(p & 7) * 4u)) & 15u)); };
     // a spin that lasts longer than any legitimate wait (tens of milliseconds) is a protocol error: every wave leaves, the batch reports it
     long long wd_t0 = 0;
     auto spin = [&]() -> bool {
@@ -1036,15 +1062,22 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
     };
     // state of the group this wave works on
     int grp = -1, own = 0, kbuf = 0, hoff = 0, nent = 0, n_lines = 0;
+    int n_self = 0, n_spec_ok = 0, n_spec_bad = 0;           // main: regions it grew itself, results it took / had to reject
+    long long c_wait = 0, c_self = 0;                        // main: cycles spent waiting for helpers / growing regions itself
+    const long long c_begin = (long long)clock64();
     uint32_t mine = 0; float s_deg = 0.f; float2 s_cs = make_float2(0.f, 0.f);
     unsigned long long todo = 0;
-    auto load_group = [&](int gi) {   // seeds of group gi, the angle records of those not yet committed (64 at once)
+    bool have_cs = false;
+    auto load_group = [&](int gi, bool with_angles) {   // seeds of group gi and (with_angles) the angle records of those not yet committed, 64 at once
         const bool in_range = gi * 64 + lane < n_ord;
         mine = in_range ? order[gi * 64 + lane] : 0u;
         const bool fresh = in_range && !committed((int)mine);
         todo = __ballot(fresh);
-        s_deg = fresh ? g.pix[mine].deg : 0.f;
-        if (fresh) { double sn, cs; sincos((double)s_deg * (3.14159265358979323846 / 180), &sn, &cs); s_cs = make_float2((float)cs, (float)sn); }
+        have_cs = with_angles;
+        if (with_angles) {
+            s_deg = fresh ? g.pix[mine].deg : 0.f;
+            if (fresh) { double sn, cs; sincos((double)s_deg * (3.14159265358979323846 / 180), &sn, &cs); s_cs = make_float2((float)cs, (float)sn); }
+        }
     };
     for (;;) {
         int t = -1;
@@ -1073,7 +1106,7 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
                     }
                     if (!own) break;
                     wd_t0 = 0;
-                    load_group(grp);
+                    load_group(grp, own == 1);   // a helper's group: main grows few of its seeds itself, their angles are fetched when that happens
                     continue;
                 }
                 const int tt = __ffsll((long long)todo) - 1;
@@ -1083,6 +1116,7 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
                 if (own > 1) {
                     const int hh = (own - 2) >> 1, kk = (own - 2) & 1;
                     bool alive = true;
+                    const long long cw0 = (long long)clock64();
                     for (;;) {   // until the helper has dealt with position tt
                         const int st = lds_ld(&hstate[hh]);
                         if ((st >> 8) > grp || ((st >> 8) == grp && (st & 255) > tt)) break;
@@ -1090,6 +1124,7 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
                     }
                     if (!alive) break;
                     wd_t0 = 0;
+                    c_wait += (long long)clock64() - cw0;
                     const int ne = lds_ld(&buf_n[hh * 2 + kk]);
                     const MwEntry* eb = entries + (size_t)(hh * 2 + kk) * kMwEntries;
                     const unsigned long long hit = __ballot(lane < ne && eb[min(lane, kMwEntries - 1)].pos == tt);
@@ -1115,8 +1150,10 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
                                 ++n_lines;
                             }
                             __builtin_amdgcn_wave_barrier();
+                            ++n_spec_ok;
                             continue;
                         }
+                        ++n_spec_bad;
                     }
                 }
                 t = tt;
@@ -1129,7 +1166,10 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
                     const int tt = __ffsll((long long)todo) - 1;
                     todo &= todo - 1;
                     const int seed = bcast_i((int)mine, tt);
-                    if (committed(seed) || tentative(seed)) { lds_st(&hstate[h], (grp << 8) | (tt + 1)); continue; }
+                    // committed, or claimed by an earlier seed's unfinished region (mine included): it will most likely be swallowed -- skip;
+                    // a LATER seed's claim does not count (that speculation yields to this one)
+                    const int ow = tentative_owner(seed);
+                    if (committed(seed) || (ow != 0 && (ow == wv || lds_ld(&cur_pos[ow - 1]) < grp * 64 + tt))) { lds_st(&hstate[h], (grp << 8) | (tt + 1)); continue; }
                     if (nent >= kMwEntries || kMwHeap - hoff < 256) { todo = 0; continue; }   // out of room: main does the rest of the group
                     t = tt;
                     break;
@@ -1146,7 +1186,7 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
                     if (bg >= 0 && bg < mg) {
                         const int ne = lds_ld(&buf_n[h * 2 + k]);
                         const MwEntry* eb = entries + (size_t)(h * 2 + k) * kMwEntries;
-                        for (int i = 0; i < ne; ++i) mw_clear(T, my_heap + (size_t)k * kMwHeap + eb[i].off, eb[i].n1 + eb[i].n2, g.sw, lane);
+                        for (int i = 0; i < ne; ++i) mw_clear_owner(T, my_heap + (size_t)k * kMwHeap + eb[i].off, eb[i].n1 + eb[i].n2, g.sw, lane, wv);
                         __builtin_amdgcn_wave_barrier();
                         lds_st(&buf_n[h * 2 + k], 0);
                         lds_st(&buf_group[h * 2 + k], -1);
@@ -1165,17 +1205,32 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
                 lds_st(&buf_n[h * 2 + kbuf], 0);
                 lds_st(&buf_group[h * 2 + kbuf], grp);
                 if (lane == 0) __hip_atomic_store(&owner[grp], (uint8_t)(2 + h * 2 + kbuf), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                load_group(grp);
+                load_group(grp, true);
             }
         }
         t = __builtin_amdgcn_readfirstlane(t);
         if (t < 0) break;
         // ---- one region (the only call site of the per-seed code)
         const int seed = bcast_i((int)mine, t);
-        if (!is_main) { g.reg = my_heap + (size_t)kbuf * kMwHeap + hoff; g.reg_cap = kMwHeap - hoff; }
+        if (!is_main) {
+            g.reg = my_heap + (size_t)kbuf * kMwHeap + hoff; g.reg_cap = kMwHeap - hoff;
+            g.my_pos = grp * 64 + t;
+            lds_st(&cur_pos[h], g.my_pos);
+        }
         MwResult r;
-        const bool ok = mw_process_seed(g, lp, seed, bcast_f(s_deg, t), make_float2(bcast_f(s_cs.x, t), bcast_f(s_cs.y, t)), r);
+        const long long cs0 = (long long)clock64();
+        float seed_deg; float2 seed_cs;
+        if (have_cs) { seed_deg = bcast_f(s_deg, t); seed_cs = make_float2(bcast_f(s_cs.x, t), bcast_f(s_cs.y, t)); }
+        else {
+            seed_deg = g.pix[seed].deg;
+            double sn, cs;
+            sincos((double)seed_deg * (3.14159265358979323846 / 180), &sn, &cs);
+            seed_cs = make_float2((float)cs, (float)sn);
+        }
+        const bool ok = mw_process_seed(g, lp, seed, seed_deg, seed_cs, r);
         region_list_fence();
+        if (is_main) { c_self += (long long)clock64() - cs0; ++n_self; }
+        else if (lane == 0) { atomicAdd(&hcount[0], 1); if (!ok) atomicAdd(&hcount[1], 1); }
         const int tot = r.n1 + r.n2;
         if (is_main) {
             const int fb = r.second ? r.n1 : 0;
@@ -1200,7 +1255,7 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
                 __builtin_amdgcn_wave_barrier();
                 ++nent; hoff += (tot + 1) & ~1;
                 lds_st(&buf_n[h * 2 + kbuf], nent);
-            } else mw_clear(T, g.reg, tot, g.sw, lane);
+            } else mw_clear_owner(T, g.reg, tot, g.sw, lane, wv);
             __builtin_amdgcn_wave_barrier();
             lds_st(&hstate[h], (grp << 8) | (t + 1));
         }
@@ -1208,7 +1263,11 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
     if (is_main) {
         if (lane == 0) {
             P.n_raw[b] = min(n_lines, kLineCap);
-            int32_t* gs = P.grow_stats + (size_t)b * 4; gs[0] = gs[1] = gs[2] = 0; gs[3] = W;
+            int32_t* gs = P.grow_stats + (size_t)b * 4; gs[0] = n_self; gs[1] = n_spec_ok; gs[2] = n_spec_bad; gs[3] = W;
+            if (P.prof && b == 0) {   // diagnostics of frame 0: cycles {total, waiting for helpers, growing itself}, helper attempts | give-ups << 32, regions grown by main, results taken
+                P.prof[0] = (long long)clock64() - c_begin; P.prof[1] = c_wait; P.prof[2] = c_self;
+                P.prof[3] = (long long)hcount[0] | ((long long)hcount[1] << 32); P.prof[4] = n_self; P.prof[5] = n_spec_ok;
+            }
         }
         lds_st(done, 1);
     }
@@ -1489,9 +1548,14 @@ void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp,
                        const BlurTapsN& t5, const LbdWeightsDev& w, plp_keyline* out_kl, uint8_t* out_lbd, double* out_fn, int cap,
                        int32_t* out_counts, int B, hipEvent_t* ev, const LineSideStream* side, int grow_waves) {
     auto mark = [&](int i) { if (ev) (void)hipEventRecord(ev[i], st); };
-    // The LBD image pass (5-tap blur + Sobel) does not depend on LSD: when a side stream is given (and no per-stage
-    // timing is requested) it runs beside the LSD chain and joins before k_lbd.
-    const bool fork = side && !ev;
+    // The LBD image pass (5-tap blur + Sobel) does not depend on LSD.  Unless per-stage timing is requested it is launched FIRST, on the
+    // same stream: it then overlaps whatever the other streams of the caller run, and nothing has to join before k_lbd.  (A side
+    // stream per context did this until round 3: with two line contexts, the ORB stream and the matcher stream that made six streams
+    // on the runtime's four hardware queues, and a context's Sobel pass queued behind 8 ms of matcher kernels of an unrelated stream
+    // while its k_lbd waited for it -- profiles/r03c_step_timeline.md.  PLP_LINE_SIDE_STREAM=1 brings the side stream back.)
+    static const bool use_side = [] { const char* e = getenv("PLP_LINE_SIDE_STREAM"); return e && e[0] == '1'; }();
+    const bool fork = side && !ev && use_side;
+    const bool sobel_first = !ev && !fork;
     hipStream_t st2 = fork ? side->stream : st;
     const size_t plane_fs = (size_t)P.pitch * P.H, splane_fs = (size_t)P.spitch * P.sh;
     const int tiles = ((P.W + 127) / 128) * ((P.H + kBlurTH - 1) / kBlurTH);
@@ -1503,6 +1567,7 @@ void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp,
         hipLaunchKernelGGL(k_blur_sobel, dim3(sobel_tiles, B), dim3(256), 0, st2, P.img, P.img_frame_stride, P.img_pitch, P.dxy, P.W, P.H, t5);
         (void)hipEventRecord(side->join, st2);
     }
+    if (sobel_first) hipLaunchKernelGGL(k_blur_sobel, dim3(sobel_tiles, B), dim3(256), 0, st, P.img, P.img_frame_stride, P.img_pitch, P.dxy, P.W, P.H, t5);
     if (P.half_exact)
         hipLaunchKernelGGL(k_blur_half, dim3(tiles, B), dim3(256), 0, st, P.img, P.img_frame_stride, P.img_pitch, P.scaled, splane_fs, P.spitch, P.W, P.H, t11);
     else {
@@ -1538,7 +1603,7 @@ void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp,
     if (B <= (grow_waves > 1 ? kLsdMwMaxFrames : mw_max_b) && want_waves >= 2 && P.mw_heap && P.reg_frame_stride >= 2 * (size_t)n) {
         const int nw_al = (((n + 31) / 32 + 1) & ~1), groups_cap = ((P.sw - 1) * (P.sh - 1) + 63) / 64 + 1;
         for (int w = want_waves; w >= 2; --w) {
-            const size_t bytes = (size_t)(2 + w) * nw_al * 4 + (size_t)w * 256 * 4 + (4 + 5 * kMwMaxWaves) * 4 + ((groups_cap + 15) & ~15) + 16 +
+            const size_t bytes = (size_t)(5 + w) * nw_al * 4 + (size_t)w * 256 * 4 + (8 + 6 * kMwMaxWaves) * 4 + ((groups_cap + 15) & ~15) + 16 +
                                  (size_t)(w - 1) * 2 * kMwEntries * sizeof(MwEntry);
             if (bytes <= 160 * 1024) { L.waves = w; L.ring = 256; L.nw_al = nw_al; L.n_groups_cap = groups_cap; L.lookahead = 2 * (w - 1); mw_bytes = bytes; break; }
         }
@@ -1555,7 +1620,7 @@ void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp,
     hipLaunchKernelGGL(k_keylines, dim3(B), dim3(64), 0, st, P, lp);
     mark(5);
     if (fork) (void)hipStreamWaitEvent(st, side->join, 0);
-    else {
+    else if (!sobel_first) {
         hipLaunchKernelGGL(k_blur_sobel, dim3(sobel_tiles, B), dim3(256), 0, st, P.img, P.img_frame_stride, P.img_pitch, P.dxy, P.W, P.H, t5);
     }
     mark(6);

@@ -66,8 +66,12 @@ class tracker_step:
         self.grid = plp.make_grid(cols, rows)
         self.sf = self.ex.get_scale_factors()
         self.cur = torch.cuda.current_stream(dev)
+        # Four streams = the runtime's four hardware queues (GPU_MAX_HW_QUEUES): a fifth would share a queue with one of these and its
+        # kernels would wait behind that stream's.  The line streams carry the step's longest dependent chain (region growing is ~15 ms
+        # however few frames it gets): line_prio < 0 gives them the higher stream priority, so their kernels are dispatched first.
+        line_prio = int(os.environ.get("PLP_BENCH_LINE_PRIO", "0"))
         self.sA = torch.cuda.Stream(dev)
-        self.sBs = [self.sA if serial else torch.cuda.Stream(dev) for _ in range(n_line)]
+        self.sBs = [self.sA if serial else torch.cuda.Stream(dev, priority=line_prio) for _ in range(n_line)]
         self.sC = self.sA if serial else torch.cuda.Stream(dev)
         self.pq = self.replay.point_queries(plp, B, cap, dev)
         self.lq = None if orb_only else self.replay.line_queries(plp, B, lcap, dev, landmarks=True)

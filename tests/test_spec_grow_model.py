@@ -5,8 +5,10 @@ a private map O and in the shared tentative map T) and hand the results over; ma
 
 Why that rule is exact: C only grows, and a helper that read C(x) = 0 where the sequential algorithm would see USED(x) = 1 differs from it only
 if it then ACCEPTS x (a pixel that is tested and rejected leaves no trace) -- so "no accepted pixel is committed at my turn" is precisely the
-condition under which the sequential algorithm grows the same region from the same seed.  A helper that is about to accept a pixel another
-unfinished speculation has marked (T) gives up: which of the two gets it depends on an order it cannot know.
+condition under which the sequential algorithm grows the same region from the same seed.  A helper that is about to accept a pixel which
+another helper's unfinished speculation has marked looks at that helper's seed position: an EARLIER seed has precedence in the sequential
+scan, so this one gives up; a LATER seed's mark is ignored and overwritten (that speculation will be found invalid at its turn).  Whatever
+the helpers decide among themselves only changes how much speculation is wasted: the rule above alone decides what is committed.
 
 The model runs the protocol on toy images with a toy order-dependent region_grow (running mean angle, refinement that un-marks and regrows with
 a tighter tolerance, radius reduction) under random interleavings of the waves, and requires the sequence of committed regions and the final
@@ -99,7 +101,8 @@ def sequential(img, order):
 
 
 def concurrent(img, order, n_helpers, rng):
-    C, T = set(), set()
+    C, T = set(), {}                     # T: pixel -> helper that marked it last (the tentative-owner nibbles of the device)
+    cur_pos = [0] * n_helpers            # seed position of each helper's latest attempt
     n_groups = (len(order) + GROUP - 1) // GROUP
     owner = [None] * n_groups          # None / "main" / helper id
     progress = [0] * n_groups          # positions of the group the owner has dealt with (published after the entry, if any)
@@ -115,7 +118,9 @@ def concurrent(img, order, n_helpers, rng):
         while not state["done"]:
             for g in [g for g in pending if state["main_group"] > g]:
                 for e in entries[g]:
-                    T.difference_update(e["ever"])
+                    for q in e["ever"]:
+                        if T.get(q) == hid:         # a later helper may have taken the pixel over
+                            del T[q]
                 pending.remove(g)
             g = state["next_group"]
             if g >= n_groups:
@@ -135,19 +140,27 @@ def concurrent(img, order, n_helpers, rng):
                 yield
                 if len(entries[g]) >= ENTRIES:
                     break                       # out of result slots: main does the rest of this group itself
-                if seed in C or seed in T:
+                my_pos = g * GROUP + k
+                ow = T.get(seed)
+                if seed in C or (ow is not None and (ow == hid or cur_pos[ow] < my_pos)):     # committed, or claimed by an EARLIER seed's unfinished region
                     progress[g] = k + 1
                     continue
+                cur_pos[hid] = my_pos
                 own, marked = set(), []
 
                 def mark(q, own=own, marked=marked):
-                    own.add(q); T.add(q); marked.append(q)
+                    own.add(q); T[q] = hid; marked.append(q)       # a later seed's claim is simply overwritten
+
+                def poison(q, my_pos=my_pos):                       # about to accept q: yield to an earlier seed's claim
+                    o = T.get(q)
+                    return o is not None and o != hid and cur_pos[o] < my_pos
                 try:
-                    final, ever, line = yield from process_seed(img, seed, lambda q: q in C or q in own, mark, own.discard,
-                                                                poison=lambda q: q in T and q not in own, tick=tick)
+                    final, ever, line = yield from process_seed(img, seed, lambda q: q in C or q in own, mark, own.discard, poison=poison, tick=tick)
                     entries[g].append(dict(pos=k, seed=seed, final=final, ever=ever, line=line))
                 except Abort:
-                    T.difference_update(marked)     # every pixel this attempt ever marked (the device walks its two lists)
+                    for q in marked:                # every pixel this attempt ever marked (the device walks its two lists), where still its own
+                        if T.get(q) == hid:
+                            del T[q]
                 progress[g] = k + 1
             progress[g] = GROUP
 
