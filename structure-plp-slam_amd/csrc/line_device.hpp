@@ -7,7 +7,7 @@
 
 namespace plp {
 
-constexpr int kMwHeap = 8192;        // k_lsd_grow_mw: list entries per helper wave and group buffer
+constexpr int kMwHeap = 16384;       // k_lsd_grow_mw: list entries per helper wave and group buffer
 constexpr int kMwMaxWaves = 8;       // k_lsd_grow_mw: waves per frame (one main + helpers)
 constexpr int kLsdMwMaxFrames = 512; // batches up to this many frames get the buffers of the several-waves-per-frame path
 constexpr int kLineCap = 2048;        // raw LSD segments / key lines kept per frame (a 640x480 frame yields ~400)

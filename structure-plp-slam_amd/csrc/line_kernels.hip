@@ -313,26 +313,33 @@ struct GrowCtx {
     int sw, sh, lane, ring_mask;
     // several waves per frame (k_lsd_grow_mw) only:
     const uint32_t* comm;            // LDS: the COMMITTED USED map -- read here, written by the main wave when a region is final
-    uint32_t* tent;                  // LDS: 4 bits per pixel, the helper wave (1..) whose unfinished speculation marked it last, 0 = none; NULL for the main wave
+    uint32_t* tent;                  // LDS: 4 bits per pixel, who holds the pixel: 0 nobody; h = 1..7 the region helper h is growing; 7 + h a finished
+                                     // region of helper h that waits for its turn; kMwMainId the region the main wave is growing
     const int* tent_pos;             // LDS: per helper, the seed position (rank in the seed order) of its latest attempt
-    int tent_id, my_pos;             // this helper's id (1..) and the seed position of the attempt it is growing
+    int tent_id, my_pos;             // this wave's id and the seed position of the region it is growing
     int reg_cap;                     // entries the list at `reg` can take
+    uint32_t* assumed; int assumed_cap;   // LDS: pixels this attempt treated as USED because an earlier seed's unfinished region holds them
 };
+constexpr int kMwMainId = 15, kMwPending = 7;   // owner ids: helpers 1..7, their finished-but-uncommitted regions 8..14, main 15
 struct Rect { double x1, y1, x2, y2, width; };
 
 __device__ __forceinline__ bool is_used(const GrowCtx& g, int p) { return (g.used[p >> 5] >> (p & 31)) & 1u; }
 __device__ __forceinline__ void set_used(const GrowCtx& g, int p) { atomicOr(&g.used[p >> 5], 1u << (p & 31)); }   // fire-and-forget ds_or
-template <bool MW> __device__ __forceinline__ bool is_used_t(const GrowCtx& g, int p) {
-    if (MW) return ((g.used[p >> 5] | g.comm[p >> 5]) >> (p & 31)) & 1u;   // mine, or committed by the main wave
-    return is_used(g, p);
+__device__ __forceinline__ int tent_owner(const GrowCtx& g, int p) { return (int)((g.tent[p >> 3] >> ((unsigned)(p & 7) * 4u)) & 15u); }
+__device__ __forceinline__ void tent_release(const GrowCtx& g, int p, int id) {   // give the pixel back if it still carries `id`
+    const unsigned sh = (unsigned)(p & 7) * 4u;
+    if (((g.tent[p >> 3] >> sh) & 15u) == (unsigned)id) atomicAnd(&g.tent[p >> 3], ~(15u << sh));
+}
+__device__ __forceinline__ void tent_retag(const GrowCtx& g, int p, int from, int to) {
+    const unsigned sh = (unsigned)(p & 7) * 4u;
+    if (((g.tent[p >> 3] >> sh) & 15u) == (unsigned)from) { atomicAnd(&g.tent[p >> 3], ~(15u << sh)); atomicOr(&g.tent[p >> 3], (unsigned)to << sh); }
 }
 template <bool MW> __device__ __forceinline__ void set_used_t(const GrowCtx& g, int p) {
-    set_used(g, p);
-    if (MW && g.tent) {   // the owner nibble becomes mine (two atomics: the transient 0 only hides a mark for a moment, which costs nothing but a wasted attempt)
+    if (MW) {   // the owner nibble becomes mine (two atomics: the transient 0 only hides a claim for a moment, which costs nothing but a wasted attempt)
         const unsigned sh = (unsigned)(p & 7) * 4u;
         atomicAnd(&g.tent[p >> 3], ~(15u << sh));
         atomicOr(&g.tent[p >> 3], (unsigned)g.tent_id << sh);
-    }
+    } else set_used(g, p);
 }
 
 // region_grow (lsd.cpp).  The region list is processed breadth-first, SEVEN region points at a time: lanes
@@ -360,13 +367,14 @@ template <bool MW> __device__ __forceinline__ void set_used_t(const GrowCtx& g, 
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
 #error "region_grow's hand-scheduled acceptance block (wait states, wave64, v_readlane hazards) is verified for gfx950 only: port it before building for another target"
 #endif
-// MW (several waves per frame): "used" = this wave's marks | the committed map; a speculating wave (g.tent != NULL) also writes its id
-// over the tentative-owner nibble of what it accepts, and when the pixel it is about to accept carries ANOTHER helper's id it looks at
-// that helper's seed position: an EARLIER seed has precedence in the sequential scan and will most likely take the pixel (and this seed
-// with it) -- the wave GIVES UP, cheaply; a LATER seed's claim is ignored and overwritten (that speculation will be found invalid when its
-// turn comes, by the one rule that decides validity: none of its pixels may be committed by then).  So the earliest unfinished region
-// never yields and the critical path keeps moving in a helper, not in the main wave.  It also gives up when the list outgrows its space.
-// Giving up returns -1 - (number of list entries written and marked so far); tests/test_spec_grow_model.py is the model of the protocol.
+// MW (several waves per frame, k_lsd_grow_mw): a pixel is used when it is COMMITTED (g.comm, written by the main wave only) or part of
+// the region this wave is growing (its id in the pixel's owner nibble, g.tent).  A pixel held by somebody else -- the main wave, another
+// helper's growing region if that helper's seed comes EARLIER in the seed order, any finished region that waits for its turn (this
+// helper's own earlier ones included) -- will most likely be used by the time this seed's turn comes: it is treated as used and
+// written to the `assumed` list, which the main wave checks at this seed's turn (every assumed pixel must be committed by then).  The
+// claim of a helper that grows a LATER seed is ignored and overwritten on acceptance (that speculation will be found invalid at its
+// turn).  The main wave ignores every claim: it IS the sequential scan.  Gives up (returns -1 - entries written and marked so far) when
+// a list outgrows its space.  Model of the protocol: tests/test_spec_grow_model.py.
 template <bool MW>
 __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed_deg, const float2* seed_cs, double prec, float c_pass,
                            float c_fail, double& reg_angle, int* n_exact_tests = nullptr) {
@@ -410,14 +418,30 @@ __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed
         }
         cand = cand && nx >= 0 && ny >= 0 && nx < g.sw && ny < g.sh;
         np = ny * g.sw + nx;
-        if (cand) cand = !is_used_t<MW>(g, np);
-        bool foreign = false;   // marked by another wave's unfinished speculation
         if (MW) {
-            if (g.tent && cand) {
-                const int owner = (int)((g.tent[np >> 3] >> ((unsigned)(np & 7) * 4u)) & 15u);
-                if (owner != 0 && owner != g.tent_id) foreign = g.tent_pos[owner - 1] < g.my_pos;   // an earlier seed's claim: yield to it
+            bool assume = false;
+            if (cand) {
+                const int owner = tent_owner(g, np);
+                bool used = ((g.comm[np >> 5] >> (np & 31)) & 1u) || owner == g.tent_id;
+                if (!used && owner != 0 && g.tent_id != kMwMainId) {   // somebody else's claim
+                    const bool earlier = owner > kMwPending || g.tent_pos[owner - 1] < g.my_pos;   // main / a finished region / an earlier seed's growing region
+                    if (earlier) { assume = true; used = true; }
+                }
+                cand = !used;
             }
-        }
+            const unsigned long long am = __builtin_amdgcn_ballot_w64(assume);
+            if (am) {   // rare: regions of different waves touch
+                // the fill count lives in LDS behind the list (g.assumed[g.assumed_cap]): read back as a wave-uniform value, so that nothing
+                // per-lane flows into the give-up decision (the hand-scheduled block wants its loop state in scalar registers)
+                const int na = __builtin_amdgcn_readfirstlane((int)g.assumed[g.assumed_cap]);
+                if (na + __popcll(am) > g.assumed_cap) gave_up = true;
+                else {
+                    if (assume) g.assumed[na + __popcll(am & ((1ull << lane) - 1ull))] = (uint32_t)nx | ((uint32_t)ny << 16);
+                    if (lane == 0) g.assumed[g.assumed_cap] = (uint32_t)(na + __popcll(am));
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        } else if (cand) cand = !is_used(g, np);
         if (cand) { const LsdPix px = g.pix[np]; deg = px.deg; ncs = px.cs; }   // 16 bytes per live neighbour
         // ---- acceptances in order.  Accepted lanes are strictly increasing, so the set of accepted lanes (a bit mask)
         // already is the order: the list append and the USED bits are written by the accepted lanes themselves after
@@ -518,7 +542,7 @@ __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed
             candmask &= ~__builtin_amdgcn_ballot_w64(np == ap);              // the same pixel seen from a later point of the batch
         }
         if (MW) {   // give up before anything of this round is written or marked
-            if ((g.tent && (acc & __builtin_amdgcn_ballot_w64(foreign))) || nreg > list_cap) { gave_up = true; nreg = n_before; acc = 0; }
+            if (gave_up || nreg > list_cap) { gave_up = true; nreg = n_before; acc = 0; }
         }
         if ((acc >> lane) & 1ull) {
             const int pos = n_before + __popcll(acc & ((1ull << lane) - 1ull));
@@ -700,7 +724,7 @@ __global__ __launch_bounds__(256, PLP_GROW_MIN_WAVES) void k_lsd_grow(LinePlanes
     if (b >= B) return;
     const int n = P.sw * P.sh, nwords = (n + 31) / 32, nv = (P.sw - 1) * (P.sh - 1);
     GrowCtx g;
-    g.comm = nullptr; g.tent = nullptr; g.tent_pos = nullptr; g.tent_id = 0; g.my_pos = 0; g.reg_cap = n;
+    g.comm = nullptr; g.tent = nullptr; g.tent_pos = nullptr; g.tent_id = 0; g.my_pos = 0; g.reg_cap = n; g.assumed = nullptr; g.assumed_cap = 0;
     g.pix = P.pix + (size_t)b * n;
     g.reg = P.reg + (size_t)b * P.reg_frame_stride; const int nw_al = (nwords + 1) & ~1;   // the ring doubles as f64 scratch: 8-byte aligned
     g.used = s_bits + (size_t)wv * (nw_al + ring); g.ring = g.used + nw_al; g.ring_mask = ring - 1;
@@ -861,22 +885,24 @@ __global__ __launch_bounds__(256, PLP_GROW_MIN_WAVES) void k_lsd_grow(LinePlanes
 // ------------------------------------------------------------------------------------------ region growing, several waves per frame
 // The latency path (plp_line_extract brings ONE frame, data/frame.cc:1146-1163): k_lsd_grow's single wave is a sequential scan over the
 // seeds; here a workgroup of W waves shares a frame.  Wave 0 (MAIN) is that sequential scan and the only writer of the committed USED map
-// C and of the output; waves 1.. (HELPERS) claim groups of 64 seeds ahead of it and grow their regions SPECULATIVELY: they read C, keep
-// their own marks in a private map O and set them in a shared tentative map T, and leave per region {the list of every pixel they ever
-// accepted, the final list, the rectangle}.  When main reaches such a seed it takes the result iff none of the ever-accepted pixels is
-// committed by then -- C only grows, and a helper that read C(x) = 0 where the sequential scan would see USED(x) = 1 differs from it only
-// if it ACCEPTED x (a rejected pixel leaves no trace), so this is exactly the condition under which the sequential scan grows the same
-// region -- and otherwise grows the region itself.  A helper about to accept a pixel that carries another unfinished speculation's mark
-// gives up (which region gets it depends on the seed order).  Because main never publishes tentative marks (a refinement un-marks and
-// regrows: its pixels reach C only when the region is final), C is monotone.  Model with random interleavings: tests/test_spec_grow_model.py.
-// Results equal k_lsd_grow's bit for bit (tests/test_gpu_line.py runs both).
-// kMwHeap (line_device.hpp): list entries per helper and group buffer (first + second list of all its regions of one group)
+// C and of the output; waves 1.. (HELPERS) claim groups of 64 seeds ahead of it and grow their regions SPECULATIVELY: they read C, write
+// their id into the owner nibble (map T) of every pixel they accept, and leave per region {every pixel they ever accepted, the pixels
+// they ASSUMED used because an earlier seed's unfinished region held them, the final list, the rectangle}.  When main reaches such a
+// seed it takes the result iff none of the ever-accepted pixels is committed by then and every assumed pixel is -- C only grows, and a
+// helper that read C(x) = 0 where the sequential scan would see USED(x) = 1 differs from it only if it ACCEPTED x (a rejected pixel
+// leaves no trace), while one that skipped x as used is right iff x is used at its turn; so this is exactly the condition under which the
+// sequential scan grows the same region -- and otherwise grows the region itself.  Because main publishes a region's pixels only when the
+// region is final (a refinement un-marks and regrows), C is monotone.  Whatever the helpers decide among themselves (whose claim to
+// respect) only changes how much speculation is wasted.  Model with random interleavings: tests/test_spec_grow_model.py.  Results equal
+// k_lsd_grow's bit for bit (tests/test_gpu_line.py runs both).
+// kMwHeap (line_device.hpp): list entries per helper and group buffer (both lists + the assumed pixels of all its regions of one group)
 constexpr int kMwEntries = 16;       // results per helper and group buffer
 constexpr int kMwInline = 12;        // list entries of a small region kept in the LDS entry itself (main then never touches HBM for it)
-struct MwResult { int n1, n2, nfinal; bool second, keep; float4 line; };
-struct alignas(16) MwEntry { int pos, n1, n2, nfinal; uint32_t flags, off, pad0, pad1; float4 line; uint32_t inl[kMwInline]; };   // flags: 1 keep, 2 final list = second
+constexpr int kMwAssumed = 192;      // assumed-used pixels per attempt (a pixel is listed once per time it is looked at: up to 8 times)
+struct MwResult { int n1, n2, nfinal, na; bool second, keep; float4 line; };
+struct alignas(16) MwEntry { int pos, n1, n2, nfinal; uint32_t flags, off; int na; uint32_t pad1; float4 line; uint32_t inl[kMwInline]; };   // flags: 1 keep, 2 final list = second
 static_assert(sizeof(MwEntry) == 96, "MwEntry layout");
-struct MwLayout { int waves, ring, nw_al, n_groups_cap, lookahead; };   // LDS (words): C | T (4 bits per pixel) | waves x (O | ring) | control | owner bytes | entries
+struct MwLayout { int waves, ring, nw_al, n_groups_cap, lookahead; };   // LDS (words): C | T (4 bits per pixel) | waves x (ring | assumed) | control | owner bytes | entries
 
 // control words are read by all lanes from one address: the value is wave-uniform, and said so (readfirstlane) -- the hand-scheduled
 // block of region_grow wants its loop state in scalar registers, which the compiler only grants to values it can prove uniform
@@ -885,17 +911,9 @@ __device__ __forceinline__ void lds_st(int* p, int v) { __hip_atomic_store(p, v,
 __device__ __forceinline__ uint32_t heap_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int pix_of(uint32_t c, int sw) { return (int)(c >> 16) * sw + (int)(c & 0xffff); }
 
-// give back the tentative-owner nibbles of list[0..n) that still carry this helper's id (a later helper may have taken a pixel over)
-__device__ __forceinline__ void mw_clear_owner(uint32_t* tw, const uint32_t* list, int n, int sw, int lane, int me) {
-    for (int j = lane; j < n; j += 64) {
-        const int p = pix_of(heap_ld(list + j), sw);
-        const unsigned sh = (unsigned)(p & 7) * 4u;
-        if (((tw[p >> 3] >> sh) & 15u) == (unsigned)me) atomicAnd(&tw[p >> 3], ~(15u << sh));
-    }
-}
-// clear bits of `map` for list[0..n) (lists written by this wave: call region_list_fence() first)
-__device__ __forceinline__ void mw_clear(uint32_t* map, const uint32_t* list, int n, int sw, int lane) {
-    for (int j = lane; j < n; j += 64) { const int p = pix_of(heap_ld(list + j), sw); atomicAnd(&map[p >> 5], ~(1u << (p & 31))); }
+// give back the owner nibbles of list[0..n) that still carry `id` (another wave may have taken a pixel over)
+__device__ __forceinline__ void mw_release(const GrowCtx& g, const uint32_t* list, int n, int id) {
+    for (int j = g.lane; j < n; j += 64) tent_release(g, pix_of(heap_ld(list + j), g.sw), id);
 }
 
 // One seed through region_grow -> rectangle -> refinement (k_lsd_grow's per-seed body) with TWO lists: the refinement's regrowth is
@@ -906,7 +924,11 @@ __device__ bool mw_process_seed(const GrowCtx& g, const LsdParams& lp, int seed,
     const int lane = g.lane;
     double reg_angle, cen[3];
     r.n2 = 0; r.second = false; r.keep = false;
+    if (lane == 0) g.assumed[g.assumed_cap] = 0;   // fill count of the assumed-used list
+    __builtin_amdgcn_wave_barrier();
+    auto n_assumed = [&]() -> int { return __builtin_amdgcn_readfirstlane((int)g.assumed[g.assumed_cap]); };
     int nreg = region_grow<true>(g, seed, true, seed_deg, &seed_cs, lp.prec, lp.c_pass, lp.c_fail, reg_angle);
+    r.na = n_assumed();
     if (nreg < 0) { r.n1 = -1 - nreg; r.nfinal = 0; return false; }
     r.n1 = r.nfinal = nreg;
     if (nreg < lp.min_reg_size) return true;
@@ -935,7 +957,7 @@ __device__ bool mw_process_seed(const GrowCtx& g, const LsdParams& lp, int seed,
                 if (j < nreg) {
                     const uint32_t c = g.reg[j];
                     const int px = (int)(c & 0xffff), py = (int)(c >> 16);
-                    atomicAnd(&g.used[(py * g.sw + px) >> 5], ~(1u << ((py * g.sw + px) & 31)));   // own marks only: the tentative mark stays
+                    tent_release(g, py * g.sw + px, g.tent_id);   // *(reg[i].used) = NOTUSED
                     const double ddx = (double)px - xc, ddy = (double)py - yc;
                     near = sqrt(ddx * ddx + ddy * ddy) < rec.width;
                     a = pix_ang(g.pix[py * g.sw + px]);
@@ -958,6 +980,7 @@ __device__ bool mw_process_seed(const GrowCtx& g, const LsdParams& lp, int seed,
             g2.reg = g.reg + r.n1; g2.reg_cap = g.reg_cap - r.n1;
             r.second = true;
             nreg = region_grow<true>(g2, pix_of(c0, g.sw), false, 0.f, nullptr, tau, cp, cf, reg_angle);
+            r.na = n_assumed();
             if (nreg < 0) { r.n2 = -1 - nreg; r.nfinal = 0; return false; }
             r.n2 = r.nfinal = nreg;
             region_list_fence();
@@ -982,7 +1005,7 @@ __device__ bool mw_process_seed(const GrowCtx& g, const LsdParams& lp, int seed,
                                 const int px = (int)(c & 0xffff), py = (int)(c >> 16);
                                 const double ddx = (double)px - xc, ddy = (double)py - yc;
                                 if (ddx * ddx + ddy * ddy > radSq) {
-                                    g2.used[(py * g.sw + px) >> 5] &= ~(1u << ((py * g.sw + px) & 31));
+                                    tent_release(g2, py * g.sw + px, g.tent_id);
                                     const uint32_t lastv = __hip_atomic_load(&g2.reg[m - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                                     __hip_atomic_store(&g2.reg[i], lastv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                                     __hip_atomic_store(&g2.reg[m - 1], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   // kept behind the live part: list 2 stays a permutation
@@ -1012,7 +1035,7 @@ __device__ bool mw_process_seed(const GrowCtx& g, const LsdParams& lp, int seed,
     return true;
 }
 
-// grid = B, block = 64 * L.waves, dynamic LDS per MwLayout (host: mw_layout()).
+// grid = B, block = 64 * L.waves, dynamic LDS per MwLayout (host: launch_line_front).
 __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, LsdParams lp, MwLayout L) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_mw[];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), b = blockIdx.x;
@@ -1020,22 +1043,21 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
     const int W = L.waves;
     uint32_t* C = s_mw;
     uint32_t* T = C + L.nw_al;
-    uint32_t* O = T + 4 * L.nw_al + (size_t)wv * (L.nw_al + L.ring);
-    int* ctrl = reinterpret_cast<int*>(T + 4 * L.nw_al + (size_t)W * (L.nw_al + L.ring));
-    // control words: 0 next_group, 1 main_group, 2 done, 3 abort (watchdog), 4.. hstate[NH], then buf_group[NH][2], buf_n[NH][2]
+    uint32_t* my_ring = T + 4 * L.nw_al + (size_t)wv * (L.ring + kMwAssumed + 2);
+    int* ctrl = reinterpret_cast<int*>(T + 4 * L.nw_al + (size_t)W * (L.ring + kMwAssumed + 2));
+    // control words: 0 next_group, 1 main_group, 2 done, 3 abort (watchdog), then per-wave arrays
     int* next_group = ctrl; int* main_group = ctrl + 1; int* done = ctrl + 2; int* wd_abort = ctrl + 3;
     int* hstate = ctrl + 4; int* buf_group = hstate + kMwMaxWaves; int* buf_n = buf_group + 2 * kMwMaxWaves;
     int* hcount = buf_n + 2 * kMwMaxWaves;                                                          // diagnostics: helper attempts, give-ups
     int* cur_pos = hcount + 4;                                                                      // [helpers]: seed position of each helper's latest attempt
-    uint8_t* owner = reinterpret_cast<uint8_t*>(cur_pos + kMwMaxWaves);                       // [n_groups_cap]: 0 unpublished, 1 main, 2 + (h * 2 + k)
+    uint8_t* owner = reinterpret_cast<uint8_t*>(cur_pos + kMwMaxWaves);                          // [n_groups_cap]: 0 unpublished, 1 main, 2 + (h * 2 + k)
     MwEntry* entries = reinterpret_cast<MwEntry*>((reinterpret_cast<uintptr_t>(owner + ((L.n_groups_cap + 15) & ~15)) + 15) & ~(uintptr_t)15);   // [helpers][2][kMwEntries]
     const int n_ord = P.n_order[b];
     const int n_groups = (n_ord + 63) / 64;
-    {   // C = NOTDEF mask (an undefined pixel is never a seed and never aligned), T = 0, every O = 0
+    {   // C = NOTDEF mask (an undefined pixel is never a seed and never aligned), no pixel held by anybody
         const uint32_t* u32 = reinterpret_cast<const uint32_t*>(P.undef + (size_t)b * ((n + 63) / 64));
         for (int i = threadIdx.x; i < nwords; i += blockDim.x) C[i] = u32[i];
         for (int i = threadIdx.x; i < 4 * L.nw_al; i += blockDim.x) T[i] = 0;
-        for (int i = lane; i < L.nw_al; i += 64) O[i] = 0;
         for (int i = threadIdx.x; i < L.n_groups_cap; i += blockDim.x) owner[i] = 0;
         if (threadIdx.x < 8 + 6 * kMwMaxWaves) ctrl[threadIdx.x] = threadIdx.x >= 4 + kMwMaxWaves && threadIdx.x < 4 + 3 * kMwMaxWaves ? -1 : 0;   // buf_group = -1 (free)
     }
@@ -1043,19 +1065,19 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
     const bool is_main = wv == 0;
     const int h = wv - 1;
     GrowCtx g;
-    g.pix = P.pix + (size_t)b * n; g.used = O; g.ring = O + L.nw_al; g.ring_mask = L.ring - 1;
-    g.sw = P.sw; g.sh = P.sh; g.lane = lane; g.comm = C; g.tent = is_main ? nullptr : T;
-    g.tent_pos = cur_pos; g.tent_id = wv; g.my_pos = 0;
+    g.pix = P.pix + (size_t)b * n; g.used = nullptr; g.ring = my_ring; g.ring_mask = L.ring - 1;
+    g.sw = P.sw; g.sh = P.sh; g.lane = lane; g.comm = C; g.tent = T;
+    g.tent_pos = cur_pos; g.tent_id = is_main ? kMwMainId : wv; g.my_pos = 0;
+    g.assumed = my_ring + L.ring; g.assumed_cap = kMwAssumed;
     uint32_t* const my_heap = is_main ? P.reg + (size_t)b * P.reg_frame_stride : P.mw_heap + (size_t)b * P.mw_heap_frame_stride + (size_t)h * 2 * kMwHeap;
     g.reg = my_heap; g.reg_cap = is_main ? 2 * n : kMwHeap;
     const uint32_t* order = P.order + (size_t)b * nv;
     float4* raw = P.raw + (size_t)b * kLineCap;
     auto committed = [&](int p) -> bool { return (C[p >> 5] >> (p & 31)) & 1u; };
-    auto tentative_owner = [&](int p) -> int { return __builtin_amdgcn_readfirstlane((int)((T[p >> 3] >> ((unsigned)(p & 7) * 4u)) & 15u)); };
     // a spin that lasts longer than any legitimate wait (tens of milliseconds) is a protocol error: every wave leaves, the batch reports it
     long long wd_t0 = 0;
     auto spin = [&]() -> bool {
-        __builtin_amdgcn_s_sleep(4);
+        __builtin_amdgcn_s_sleep(2);
         if (wd_t0 == 0) wd_t0 = (long long)clock64();
         if ((long long)clock64() - wd_t0 > 400000000ll) { lds_st(wd_abort, 1); if (lane == 0) atomicOr(P.status, 16); }
         return lds_ld(wd_abort) == 0;
@@ -1065,12 +1087,12 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
     int n_self = 0, n_spec_ok = 0, n_spec_bad = 0;           // main: regions it grew itself, results it took / had to reject
     long long c_wait = 0, c_self = 0;                        // main: cycles spent waiting for helpers / growing regions itself
     const long long c_begin = (long long)clock64();
-    uint32_t mine = 0; float s_deg = 0.f; float2 s_cs = make_float2(0.f, 0.f);
+    uint32_t mine = 0, mine_next = 0; float s_deg = 0.f; float2 s_cs = make_float2(0.f, 0.f);
     unsigned long long todo = 0;
     bool have_cs = false;
-    auto load_group = [&](int gi, bool with_angles) {   // seeds of group gi and (with_angles) the angle records of those not yet committed, 64 at once
+    auto load_group = [&](int gi, bool with_angles, bool prefetched) {   // seeds of group gi and (with_angles) the angle records of those not yet committed, 64 at once
         const bool in_range = gi * 64 + lane < n_ord;
-        mine = in_range ? order[gi * 64 + lane] : 0u;
+        mine = prefetched ? mine_next : (in_range ? order[gi * 64 + lane] : 0u);
         const bool fresh = in_range && !committed((int)mine);
         todo = __ballot(fresh);
         have_cs = with_angles;
@@ -1079,6 +1101,17 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
             if (fresh) { double sn, cs; sincos((double)s_deg * (3.14159265358979323846 / 180), &sn, &cs); s_cs = make_float2((float)cs, (float)sn); }
         }
     };
+    // main's view of the helper that owns the current group: progress inside the group, entries announced, their positions (lane i: entry i)
+    int prog = 0, ne = 0, pos_vec = -1;
+    const MwEntry* eb = entries;
+    auto refresh = [&](int hh, int kk) {
+        const int st = lds_ld(&hstate[hh]);
+        prog = (st >> 8) > grp ? 64 : ((st >> 8) == grp ? (st & 255) : 0);
+        ne = lds_ld(&buf_n[hh * 2 + kk]);
+        eb = entries + (size_t)(hh * 2 + kk) * kMwEntries;
+        pos_vec = lane < ne ? eb[min(lane, kMwEntries - 1)].pos : -1;
+    };
+    if (is_main) mine_next = lane < n_ord ? order[lane] : 0u;
     for (;;) {
         int t = -1;
         wd_t0 = 0;
@@ -1106,7 +1139,9 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
                     }
                     if (!own) break;
                     wd_t0 = 0;
-                    load_group(grp, own == 1);   // a helper's group: main grows few of its seeds itself, their angles are fetched when that happens
+                    load_group(grp, own == 1, true);   // a helper's group: main grows few of its seeds itself, their angles are fetched when that happens
+                    mine_next = (grp + 1) * 64 + lane < n_ord ? order[(grp + 1) * 64 + lane] : 0u;   // the next group's seeds are on their way while this one is dealt with
+                    if (own > 1) refresh((own - 2) >> 1, (own - 2) & 1);
                     continue;
                 }
                 const int tt = __ffsll((long long)todo) - 1;
@@ -1115,28 +1150,28 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
                 if (committed(seed)) continue;
                 if (own > 1) {
                     const int hh = (own - 2) >> 1, kk = (own - 2) & 1;
-                    bool alive = true;
-                    const long long cw0 = (long long)clock64();
-                    for (;;) {   // until the helper has dealt with position tt
-                        const int st = lds_ld(&hstate[hh]);
-                        if ((st >> 8) > grp || ((st >> 8) == grp && (st & 255) > tt)) break;
-                        if (!(alive = spin())) break;
+                    if (prog <= tt) {   // until the helper has dealt with position tt
+                        bool alive = true;
+                        const long long cw0 = (long long)clock64();
+                        for (;;) {
+                            refresh(hh, kk);
+                            if (prog > tt) break;
+                            if (!(alive = spin())) break;
+                        }
+                        if (!alive) break;
+                        wd_t0 = 0;
+                        c_wait += (long long)clock64() - cw0;
                     }
-                    if (!alive) break;
-                    wd_t0 = 0;
-                    c_wait += (long long)clock64() - cw0;
-                    const int ne = lds_ld(&buf_n[hh * 2 + kk]);
-                    const MwEntry* eb = entries + (size_t)(hh * 2 + kk) * kMwEntries;
-                    const unsigned long long hit = __ballot(lane < ne && eb[min(lane, kMwEntries - 1)].pos == tt);
+                    const unsigned long long hit = __ballot(pos_vec == tt);
                     if (hit) {
                         const MwEntry* e = eb + (__ffsll((long long)hit) - 1);
-                        const int n1 = e->n1, n2 = e->n2, nf = e->nfinal, tot = n1 + n2;
+                        const int n1 = e->n1, n2 = e->n2, nf = e->nfinal, na = e->na, acc_n = n1 + n2, tot = acc_n + na;
                         const uint32_t fl = e->flags;
                         const uint32_t* hl = P.mw_heap + (size_t)b * P.mw_heap_frame_stride + (size_t)(hh * 2 + kk) * kMwHeap + e->off;
-                        bool bad = false;
+                        bool bad = false;   // an accepted pixel that is committed by now, or an assumed-used one that is not
                         for (int j0 = 0; j0 < tot; j0 += 64) {
                             const int j = j0 + lane;
-                            if (j < tot) bad |= committed(pix_of(tot <= kMwInline ? e->inl[j] : heap_ld(hl + j), g.sw));
+                            if (j < tot) bad |= committed(pix_of(tot <= kMwInline ? e->inl[j] : heap_ld(hl + j), g.sw)) != (j >= acc_n);
                         }
                         if (!__ballot(bad)) {   // the sequential scan grows exactly this region here: commit it
                             const int fb = (fl & 2u) ? n1 : 0;
@@ -1166,11 +1201,12 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
                     const int tt = __ffsll((long long)todo) - 1;
                     todo &= todo - 1;
                     const int seed = bcast_i((int)mine, tt);
-                    // committed, or claimed by an earlier seed's unfinished region (mine included): it will most likely be swallowed -- skip;
-                    // a LATER seed's claim does not count (that speculation yields to this one)
-                    const int ow = tentative_owner(seed);
-                    if (committed(seed) || (ow != 0 && (ow == wv || lds_ld(&cur_pos[ow - 1]) < grp * 64 + tt))) { lds_st(&hstate[h], (grp << 8) | (tt + 1)); continue; }
-                    if (nent >= kMwEntries || kMwHeap - hoff < 256) { todo = 0; continue; }   // out of room: main does the rest of the group
+                    // committed, or held by an earlier seed's unfinished region (mine included): it will most likely be swallowed -- skip;
+                    // a LATER seed's claim does not count
+                    const int ow = __builtin_amdgcn_readfirstlane(tent_owner(g, seed));
+                    const int owh = ow > kMwPending ? ow - kMwPending : ow;   // the helper behind the claim (8 for main: never read)
+                    if (committed(seed) || (ow != 0 && (ow == kMwMainId || owh == wv || lds_ld(&cur_pos[owh - 1]) < grp * 64 + tt))) { lds_st(&hstate[h], (grp << 8) | (tt + 1)); continue; }
+                    if (nent >= kMwEntries || kMwHeap - hoff < 512 + kMwAssumed) { todo = 0; continue; }   // out of room: main does the rest of the group
                     t = tt;
                     break;
                 }
@@ -1178,15 +1214,15 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
                     lds_st(&hstate[h], (grp << 8) | 64);
                     grp = -1;
                 }
-                // recycle: a buffer whose group main has left gives its tentative marks back
+                // recycle: a buffer whose group main has left gives its claims back
                 const int mg = lds_ld(main_group);
                 int free_k = -1;
                 for (int k = 0; k < 2; ++k) {
                     const int bg = lds_ld(&buf_group[h * 2 + k]);
                     if (bg >= 0 && bg < mg) {
-                        const int ne = lds_ld(&buf_n[h * 2 + k]);
-                        const MwEntry* eb = entries + (size_t)(h * 2 + k) * kMwEntries;
-                        for (int i = 0; i < ne; ++i) mw_clear_owner(T, my_heap + (size_t)k * kMwHeap + eb[i].off, eb[i].n1 + eb[i].n2, g.sw, lane, wv);
+                        const int nek = lds_ld(&buf_n[h * 2 + k]);
+                        const MwEntry* ek = entries + (size_t)(h * 2 + k) * kMwEntries;
+                        for (int i = 0; i < nek; ++i) mw_release(g, my_heap + (size_t)k * kMwHeap + ek[i].off, ek[i].n1 + ek[i].n2, wv + kMwPending);
                         __builtin_amdgcn_wave_barrier();
                         lds_st(&buf_n[h * 2 + k], 0);
                         lds_st(&buf_group[h * 2 + k], -1);
@@ -1205,7 +1241,7 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
                 lds_st(&buf_n[h * 2 + kbuf], 0);
                 lds_st(&buf_group[h * 2 + kbuf], grp);
                 if (lane == 0) __hip_atomic_store(&owner[grp], (uint8_t)(2 + h * 2 + kbuf), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                load_group(grp, true);
+                load_group(grp, true, false);
             }
         }
         t = __builtin_amdgcn_readfirstlane(t);
@@ -1213,7 +1249,7 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
         // ---- one region (the only call site of the per-seed code)
         const int seed = bcast_i((int)mine, t);
         if (!is_main) {
-            g.reg = my_heap + (size_t)kbuf * kMwHeap + hoff; g.reg_cap = kMwHeap - hoff;
+            g.reg = my_heap + (size_t)kbuf * kMwHeap + hoff; g.reg_cap = kMwHeap - hoff - kMwAssumed;
             g.my_pos = grp * 64 + t;
             lds_st(&cur_pos[h], g.my_pos);
         }
@@ -1231,11 +1267,11 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
         region_list_fence();
         if (is_main) { c_self += (long long)clock64() - cs0; ++n_self; }
         else if (lane == 0) { atomicAdd(&hcount[0], 1); if (!ok) atomicAdd(&hcount[1], 1); }
-        const int tot = r.n1 + r.n2;
+        const int acc_n = r.n1 + r.n2;
         if (is_main) {
             const int fb = r.second ? r.n1 : 0;
             for (int j = lane; j < r.nfinal; j += 64) { const int p = pix_of(heap_ld(g.reg + fb + j), g.sw); atomicOr(&C[p >> 5], 1u << (p & 31)); }
-            mw_clear(O, g.reg, tot, g.sw, lane);
+            mw_release(g, g.reg, acc_n, kMwMainId);
             if (r.keep) {
                 if (n_lines < kLineCap) { if (lane == 0) raw[n_lines] = r.line; }
                 else if (lane == 0) atomicOr(P.status, 4);
@@ -1243,19 +1279,26 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
             }
             __builtin_amdgcn_wave_barrier();
         } else {
-            mw_clear(O, g.reg, tot, g.sw, lane);
             if (ok) {
+                const int tot = acc_n + r.na;
+                // the region is finished: its pixels change from "helper h is growing this" to "a finished region of helper h" -- the next
+                // attempts of this helper treat them like anybody else's finished region (assumed used, and checked at their turn)
+                for (int j = lane; j < r.nfinal; j += 64) tent_retag(g, pix_of(heap_ld(g.reg + (r.second ? r.n1 : 0) + j), g.sw), wv, wv + kMwPending);
+                for (int j = lane; j < r.na; j += 64) __hip_atomic_store(g.reg + acc_n + j, g.assumed[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the assumed-used pixels follow the two lists
                 MwEntry* e = entries + (size_t)(h * 2 + kbuf) * kMwEntries + nent;
                 if (lane == 0) {
                     e->pos = t; e->n1 = r.n1; e->n2 = r.n2; e->nfinal = r.nfinal; e->flags = (r.keep ? 1u : 0u) | (r.second ? 2u : 0u); e->off = (uint32_t)hoff;
-                    e->line = r.line;
+                    e->na = r.na; e->line = r.line;
                 }
-                if (tot <= kMwInline && lane < tot) e->inl[lane] = heap_ld(g.reg + lane);
+                if (tot <= kMwInline) {
+                    if (lane < acc_n) e->inl[lane] = heap_ld(g.reg + lane);
+                    else if (lane < tot) e->inl[lane] = g.assumed[lane - acc_n];
+                }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the lists in HBM are complete before the entry is announced
                 __builtin_amdgcn_wave_barrier();
                 ++nent; hoff += (tot + 1) & ~1;
                 lds_st(&buf_n[h * 2 + kbuf], nent);
-            } else mw_clear_owner(T, g.reg, tot, g.sw, lane, wv);
+            } else mw_release(g, g.reg, acc_n, wv);
             __builtin_amdgcn_wave_barrier();
             lds_st(&hstate[h], (grp << 8) | (t + 1));
         }
@@ -1603,7 +1646,7 @@ void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp,
     if (B <= (grow_waves > 1 ? kLsdMwMaxFrames : mw_max_b) && want_waves >= 2 && P.mw_heap && P.reg_frame_stride >= 2 * (size_t)n) {
         const int nw_al = (((n + 31) / 32 + 1) & ~1), groups_cap = ((P.sw - 1) * (P.sh - 1) + 63) / 64 + 1;
         for (int w = want_waves; w >= 2; --w) {
-            const size_t bytes = (size_t)(5 + w) * nw_al * 4 + (size_t)w * 256 * 4 + (8 + 6 * kMwMaxWaves) * 4 + ((groups_cap + 15) & ~15) + 16 +
+            const size_t bytes = (size_t)5 * nw_al * 4 + (size_t)w * (256 + kMwAssumed + 2) * 4 + (8 + 6 * kMwMaxWaves) * 4 + ((groups_cap + 15) & ~15) + 16 +
                                  (size_t)(w - 1) * 2 * kMwEntries * sizeof(MwEntry);
             if (bytes <= 160 * 1024) { L.waves = w; L.ring = 256; L.nw_al = nw_al; L.n_groups_cap = groups_cap; L.lookahead = 2 * (w - 1); mw_bytes = bytes; break; }
         }

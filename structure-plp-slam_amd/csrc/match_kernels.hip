@@ -631,7 +631,7 @@ __device__ __forceinline__ bool accept(const MatchProblem& P, unsigned best, int
 // kSorted: the windowed point modes after k_match_prep (a dry list is rescanned over the window's ranges of the sorted array); the other
 // instantiation rescans through candidate_key() and is the only one that carries its registers (all modes' gates, f64 epipolar tests).
 template <bool kSorted>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_match_resolve(MatchProblem P) {
+__device__ __forceinline__ void match_resolve_body(const MatchProblem& P) {
     corun_priority();
     extern __shared__ int32_t lds[];
     __shared__ int s_changed, s_num, s_hist[32], s_valid_bin[32], s_full_n, s_claim_tmp[256], s_sort_ws[48];
@@ -854,6 +854,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     }
     if (tid == 0) P.out_num[b] = s_num;
 }
+// two kernels around the one body: the sorted instantiation is the hot one (point matchers of every frame) and is held to 128 registers
+// (4 waves per SIMD beside its 24 KB of LDS); the generic one carries every mode's gates and takes the registers it needs instead of spilling
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_match_resolve_sorted(MatchProblem P) { match_resolve_body<true>(P); }
+__global__ __launch_bounds__(256) void k_match_resolve_generic(MatchProblem P) { match_resolve_body<false>(P); }
 
 // ------------------------------------------------------------------------------------------
 // K16  full Hamming matrix: dist[q][t] (u16), 64 x 64 tile per workgroup, descriptors staged in LDS.
@@ -1021,16 +1025,16 @@ void launch_match(hipStream_t st, const MatchProblem& P, int B) {
         if (P.n_cap <= 512 && B >= 64) hipLaunchKernelGGL(k_match_topk_lanes, dim3((P.m_cap + 63) / 64, B), dim3(64), 0, st, P);   // small target sets, many frames
         else hipLaunchKernelGGL(k_match_topk, dim3(std::min(gx_full, gx_min), B), dim3(256), 0, st, P);
     }
-    if (Q.sorted_valid) hipLaunchKernelGGL(k_match_resolve<true>, dim3(B), dim3(256), (size_t)P.n_cap * 12, st, Q);
-    else hipLaunchKernelGGL(k_match_resolve<false>, dim3(B), dim3(256), (size_t)P.n_cap * 12, st, Q);
+    if (Q.sorted_valid) hipLaunchKernelGGL(k_match_resolve_sorted, dim3(B), dim3(256), (size_t)P.n_cap * 12, st, Q);
+    else hipLaunchKernelGGL(k_match_resolve_generic, dim3(B), dim3(256), (size_t)P.n_cap * 12, st, Q);
 }
 
 // up to 8192 targets: 96 KB of owner arrays.  The attribute belongs to the function ON THE CURRENT DEVICE: called by
 // plp_matcher_create after hipSetDevice, once per context.
 hipError_t configure_match_kernels() {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_match_resolve<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 12);
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_match_resolve_sorted), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 12);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_match_resolve<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 12);
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_match_resolve_generic), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 12);
 }
 
 void launch_hamming_matrix(hipStream_t st, const uint8_t* q, int nq, const uint8_t* t, int nt, uint16_t* dist) {

@@ -1,14 +1,14 @@
 """Model of the multi-wave region growing of k_lsd_grow_mw (csrc/line_kernels.hip): one MAIN wave walks the seeds in order and is the only
 writer of the committed USED map C; HELPER waves run ahead, grow regions of later seeds speculatively (reading C, marking their own pixels in
-a private map O and in the shared tentative map T) and hand the results over; main accepts a result iff none of the pixels it EVER accepted
-(first growth or refinement) is committed at its turn, else grows the region itself.
+the shared owner map T) and hand the results over; main accepts a result iff none of the pixels it EVER accepted (first growth or
+refinement) is committed at its turn AND every pixel it assumed used (because somebody else held it) is, else grows the region itself.
 
 Why that rule is exact: C only grows, and a helper that read C(x) = 0 where the sequential algorithm would see USED(x) = 1 differs from it only
 if it then ACCEPTS x (a pixel that is tested and rejected leaves no trace) -- so "no accepted pixel is committed at my turn" is precisely the
-condition under which the sequential algorithm grows the same region from the same seed.  A helper that is about to accept a pixel which
-another helper's unfinished speculation has marked looks at that helper's seed position: an EARLIER seed has precedence in the sequential
-scan, so this one gives up; a LATER seed's mark is ignored and overwritten (that speculation will be found invalid at its turn).  Whatever
-the helpers decide among themselves only changes how much speculation is wasted: the rule above alone decides what is committed.
+condition under which the sequential algorithm grows the same region from the same seed; and a helper that skipped x as used is right iff
+x is used at its turn.  Which claims a helper respects (the main wave's growing region, any finished region that waits for its turn, the
+growing region of a helper whose seed comes EARLIER) and which it overrides (a LATER seed's growing region) only changes how much
+speculation is wasted: the two checks above alone decide what is committed.
 
 The model runs the protocol on toy images with a toy order-dependent region_grow (running mean angle, refinement that un-marks and regrows with
 a tighter tolerance, radius reduction) under random interleavings of the waves, and requires the sequence of committed regions and the final
@@ -119,7 +119,7 @@ def concurrent(img, order, n_helpers, rng):
             for g in [g for g in pending if state["main_group"] > g]:
                 for e in entries[g]:
                     for q in e["ever"]:
-                        if T.get(q) == hid:         # a later helper may have taken the pixel over
+                        if T.get(q) == (hid, "pending"):     # another wave may have taken the pixel over
                             del T[q]
                 pending.remove(g)
             g = state["next_group"]
@@ -141,26 +141,39 @@ def concurrent(img, order, n_helpers, rng):
                 if len(entries[g]) >= ENTRIES:
                     break                       # out of result slots: main does the rest of this group itself
                 my_pos = g * GROUP + k
-                ow = T.get(seed)
-                if seed in C or (ow is not None and (ow == hid or cur_pos[ow] < my_pos)):     # committed, or claimed by an EARLIER seed's unfinished region
-                    progress[g] = k + 1
+                ow = T.get(seed)        # (holder, state): holder = helper id or "main", state = "growing" | "pending"
+                if seed in C or (ow is not None and (ow[0] == "main" or ow[0] == hid or cur_pos[ow[0]] < my_pos)):
+                    progress[g] = k + 1     # committed, or held by a region that will most likely swallow it
                     continue
                 cur_pos[hid] = my_pos
-                own, marked = set(), []
+                marked, assumed = [], []
 
-                def mark(q, own=own, marked=marked):
-                    own.add(q); T[q] = hid; marked.append(q)       # a later seed's claim is simply overwritten
+                def mark(q, marked=marked):
+                    T[q] = (hid, "growing"); marked.append(q)       # a later seed's claim is simply overwritten
 
-                def poison(q, my_pos=my_pos):                       # about to accept q: yield to an earlier seed's claim
+                def unmark(q):
+                    if T.get(q) == (hid, "growing"):
+                        del T[q]
+
+                def is_used(q, my_pos=my_pos, assumed=assumed):
+                    if q in C or T.get(q) == (hid, "growing"):
+                        return True
                     o = T.get(q)
-                    return o is not None and o != hid and cur_pos[o] < my_pos
+                    if o is not None and (o[0] == "main" or o[1] == "pending" or cur_pos[o[0]] < my_pos):
+                        assumed.append(q)                           # somebody else's claim: assumed used, checked at this seed's turn
+                        return True
+                    return False
                 try:
-                    final, ever, line = yield from process_seed(img, seed, lambda q: q in C or q in own, mark, own.discard, poison=poison, tick=tick)
-                    entries[g].append(dict(pos=k, seed=seed, final=final, ever=ever, line=line))
+                    if len(marked) > 10_000:
+                        raise Abort()
+                    final, ever, line = yield from process_seed(img, seed, is_used, mark, unmark, tick=tick)
+                    for q in final:                                 # finished: "helper is growing this" -> "a finished region that waits for its turn"
+                        if T.get(q) == (hid, "growing"):
+                            T[q] = (hid, "pending")
+                    entries[g].append(dict(pos=k, seed=seed, final=final, ever=ever, line=line, assumed=assumed))
                 except Abort:
-                    for q in marked:                # every pixel this attempt ever marked (the device walks its two lists), where still its own
-                        if T.get(q) == hid:
-                            del T[q]
+                    for q in marked:
+                        unmark(q)
                 progress[g] = k + 1
             progress[g] = GROUP
 
@@ -180,14 +193,26 @@ def concurrent(img, order, n_helpers, rng):
                     while progress[g] <= k and not (entries[g] and entries[g][-1]["pos"] >= k):
                         yield                   # the helper is still busy with (or before) this position
                     e = next((x for x in entries[g] if x["pos"] == k), None)
-                if e is not None and not any(q in C for q in e["ever"]):
+                if e is not None and not any(q in C for q in e["ever"]) and all(q in C for q in e["assumed"]):
                     final, line = e["final"], e["line"]
                     state["used_spec"] += 1
                 else:
                     if e is not None:
                         state["wasted"] += 1
                     own = set()
-                    final, ever, line = yield from process_seed(img, seed, lambda q: q in C or q in own, own.add, own.discard, tick=tick)
+
+                    def m_mark(q, own=own):
+                        own.add(q); T[q] = ("main", "growing")      # the helpers see what main is growing; main itself ignores every claim
+
+                    def m_unmark(q, own=own):
+                        own.discard(q)
+                        if T.get(q) == ("main", "growing"):
+                            del T[q]
+                    final, ever, line = yield from process_seed(img, seed, lambda q: q in C or q in own, m_mark, m_unmark, tick=tick)
+                    C.update(final)
+                    for q in ever:
+                        if T.get(q) == ("main", "growing"):
+                            del T[q]
                 C.update(final)
                 out.append((seed, tuple(final), line))
         state["main_group"] = n_groups
