@@ -379,6 +379,15 @@ plp_status plp_replay_line_queries_device(const plp_keyline* feat_kl, const int3
                                           int32_t* q2_level, uint8_t* q2_valid, const plp_keypoint* feat_kps, const int32_t* feat_kp_counts, int32_t kp_cap,
                                           int32_t* t_kp_octave, void* hip_stream);
 
+/* Host boundary of the batched replay: the live rows of a padded per-frame array packed back to back, so that the device-to-host copy
+ * moves the features that exist instead of the capacity they were allotted (the std::vector<cv::KeyPoint> / cv::Mat rows that
+ * orb_extractor::extract and extract_LSD_LBD hand back hold exactly that many entries, feature/orb_extractor.cc:124-132).
+ * dst[offsets[b] + i] = src[b][i] for i < min(counts[b], cap), rows of row_bytes bytes (a multiple of 4); offsets [B + 1] = exclusive
+ * prefix sum of the clamped counts, offsets[B] = total rows.  compute_offsets != 0 computes them first; pass 0 to reuse the offsets of an
+ * earlier call with the same counts (key points + descriptors + matches share one set).  Asynchronous on hip_stream. */
+plp_status plp_pack_rows_device(const void* src, const int32_t* counts, int32_t B, int32_t cap, int32_t row_bytes, void* dst, int64_t* offsets,
+                                int32_t compute_offsets, void* hip_stream);
+
 /* area::match_in_consistent_area(frm_1, frm_2, prev_matched_pts, matched_indices_2_in_frm_1, margin)
  * (src/PLPSLAM/match/area.cc:33-153; monocular initialisation, module/initializer.cc:191-192).  Host pointers, one
  * problem, synchronous.  kps_1/kps_2 = undist_keypts_ of the two frames, prev_matched_pts = n1 x 2 floats (updated in

@@ -108,6 +108,7 @@ _API = [
     ("plp_hamming_matrix_device", C.c_int, [_VP, _VP, _I32, _VP, _I32, _VP, _VP]),
     ("plp_hamming_matrix_host", C.c_int, [_VP, _VP, _I32, _VP, _I32, _VP]),
     ("plp_replay_point_queries_device", C.c_int, [_VP, _VP, _I32, _I32, _I32, C.c_float, C.c_float, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    ("plp_pack_rows_device", C.c_int, [_VP, _VP, _I32, _I32, _I32, _VP, _VP, _I32, _VP]),
     ("plp_replay_line_queries_device", C.c_int, [_VP, _VP, _I32, _I32, _I32, C.c_float, C.c_float, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _VP, _VP]),
 ]
 

@@ -313,8 +313,9 @@ struct GrowCtx {
     int sw, sh, lane, ring_mask;
     // several waves per frame (k_lsd_grow_mw) only:
     const uint32_t* comm;            // LDS: the COMMITTED USED map -- read here, written by the main wave when a region is final
-    uint32_t* tent;                  // LDS: 4 bits per pixel, who holds the pixel: 0 nobody; h = 1..7 the region helper h is growing; 7 + h a finished
-                                     // region of helper h that waits for its turn; kMwMainId the region the main wave is growing
+    uint32_t* tent;                  // LDS: 4 bits per pixel, who CLAIMS the pixel (advisory: a claim can be overwritten; what a wave itself holds is in
+                                     // its private map `used`): 0 nobody; h = 1..7 the region helper h is growing; 7 + h a finished region of helper
+                                     // h that waits for its turn; kMwMainId the region the main wave is growing
     const int* tent_pos;             // LDS: per helper, the seed position (rank in the seed order) of its latest attempt
     int tent_id, my_pos;             // this wave's id and the seed position of the region it is growing
     int reg_cap;                     // entries the list at `reg` can take
@@ -335,11 +336,17 @@ __device__ __forceinline__ void tent_retag(const GrowCtx& g, int p, int from, in
     if (((g.tent[p >> 3] >> sh) & 15u) == (unsigned)from) { atomicAnd(&g.tent[p >> 3], ~(15u << sh)); atomicOr(&g.tent[p >> 3], (unsigned)to << sh); }
 }
 template <bool MW> __device__ __forceinline__ void set_used_t(const GrowCtx& g, int p) {
-    if (MW) {   // the owner nibble becomes mine (two atomics: the transient 0 only hides a claim for a moment, which costs nothing but a wasted attempt)
+    set_used(g, p);
+    if (MW) {   // and the claim nibble becomes mine (two atomics: the transient 0 only hides a claim for a moment, which costs nothing but a wasted attempt)
         const unsigned sh = (unsigned)(p & 7) * 4u;
         atomicAnd(&g.tent[p >> 3], ~(15u << sh));
         atomicOr(&g.tent[p >> 3], (unsigned)g.tent_id << sh);
-    } else set_used(g, p);
+    }
+}
+// un-mark (refinement, radius reduction): out of this wave's own map, and the claim is given back if it is still this wave's
+__device__ __forceinline__ void mw_unmark(const GrowCtx& g, int p) {
+    atomicAnd(&g.used[p >> 5], ~(1u << (p & 31)));
+    tent_release(g, p, g.tent_id);
 }
 
 // region_grow (lsd.cpp).  The region list is processed breadth-first, SEVEN region points at a time: lanes
@@ -368,7 +375,7 @@ template <bool MW> __device__ __forceinline__ void set_used_t(const GrowCtx& g, 
 #error "region_grow's hand-scheduled acceptance block (wait states, wave64, v_readlane hazards) is verified for gfx950 only: port it before building for another target"
 #endif
 // MW (several waves per frame, k_lsd_grow_mw): a pixel is used when it is COMMITTED (g.comm, written by the main wave only) or part of
-// the region this wave is growing (its id in the pixel's owner nibble, g.tent).  A pixel held by somebody else -- the main wave, another
+// the region this wave is growing (its private map g.used).  A pixel CLAIMED by somebody else (the claim nibbles, g.tent) -- the main wave, another
 // helper's growing region if that helper's seed comes EARLIER in the seed order, any finished region that waits for its turn (this
 // helper's own earlier ones included) -- will most likely be used by the time this seed's turn comes: it is treated as used and
 // written to the `assumed` list, which the main wave checks at this seed's turn (every assumed pixel must be committed by then).  The
@@ -421,9 +428,9 @@ __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed
         if (MW) {
             bool assume = false;
             if (cand) {
+                bool used = ((g.comm[np >> 5] | g.used[np >> 5]) >> (np & 31)) & 1u;
                 const int owner = tent_owner(g, np);
-                bool used = ((g.comm[np >> 5] >> (np & 31)) & 1u) || owner == g.tent_id;
-                if (!used && owner != 0 && g.tent_id != kMwMainId) {   // somebody else's claim
+                if (!used && owner != 0 && owner != g.tent_id && g.tent_id != kMwMainId) {   // somebody else's claim
                     const bool earlier = owner > kMwPending || g.tent_pos[owner - 1] < g.my_pos;   // main / a finished region / an earlier seed's growing region
                     if (earlier) { assume = true; used = true; }
                 }
@@ -902,7 +909,7 @@ constexpr int kMwAssumed = 192;      // assumed-used pixels per attempt (a pixel
 struct MwResult { int n1, n2, nfinal, na; bool second, keep; float4 line; };
 struct alignas(16) MwEntry { int pos, n1, n2, nfinal; uint32_t flags, off; int na; uint32_t pad1; float4 line; uint32_t inl[kMwInline]; };   // flags: 1 keep, 2 final list = second
 static_assert(sizeof(MwEntry) == 96, "MwEntry layout");
-struct MwLayout { int waves, ring, nw_al, n_groups_cap, lookahead; };   // LDS (words): C | T (4 bits per pixel) | waves x (ring | assumed) | control | owner bytes | entries
+struct MwLayout { int waves, ring, nw_al, n_groups_cap, lookahead; };   // LDS (words): C | T (4 bits per pixel) | waves x (O | ring | assumed) | control | owner bytes | entries
 
 // control words are read by all lanes from one address: the value is wave-uniform, and said so (readfirstlane) -- the hand-scheduled
 // block of region_grow wants its loop state in scalar registers, which the compiler only grants to values it can prove uniform
@@ -911,9 +918,17 @@ __device__ __forceinline__ void lds_st(int* p, int v) { __hip_atomic_store(p, v,
 __device__ __forceinline__ uint32_t heap_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int pix_of(uint32_t c, int sw) { return (int)(c >> 16) * sw + (int)(c & 0xffff); }
 
-// give back the owner nibbles of list[0..n) that still carry `id` (another wave may have taken a pixel over)
+// give back the claim nibbles of list[0..n) that still carry `id` (another wave may have taken a pixel over)
 __device__ __forceinline__ void mw_release(const GrowCtx& g, const uint32_t* list, int n, int id) {
     for (int j = g.lane; j < n; j += 64) tent_release(g, pix_of(heap_ld(list + j), g.sw), id);
+}
+// the attempt is over: its pixels leave this wave's own map (and, release_id != 0, its claims are given back)
+__device__ __forceinline__ void mw_forget(const GrowCtx& g, const uint32_t* list, int n, int release_id) {
+    for (int j = g.lane; j < n; j += 64) {
+        const int p = pix_of(heap_ld(list + j), g.sw);
+        atomicAnd(&g.used[p >> 5], ~(1u << (p & 31)));
+        if (release_id) tent_release(g, p, release_id);
+    }
 }
 
 // One seed through region_grow -> rectangle -> refinement (k_lsd_grow's per-seed body) with TWO lists: the refinement's regrowth is
@@ -957,7 +972,7 @@ __device__ bool mw_process_seed(const GrowCtx& g, const LsdParams& lp, int seed,
                 if (j < nreg) {
                     const uint32_t c = g.reg[j];
                     const int px = (int)(c & 0xffff), py = (int)(c >> 16);
-                    tent_release(g, py * g.sw + px, g.tent_id);   // *(reg[i].used) = NOTUSED
+                    mw_unmark(g, py * g.sw + px);   // *(reg[i].used) = NOTUSED
                     const double ddx = (double)px - xc, ddy = (double)py - yc;
                     near = sqrt(ddx * ddx + ddy * ddy) < rec.width;
                     a = pix_ang(g.pix[py * g.sw + px]);
@@ -1005,7 +1020,7 @@ __device__ bool mw_process_seed(const GrowCtx& g, const LsdParams& lp, int seed,
                                 const int px = (int)(c & 0xffff), py = (int)(c >> 16);
                                 const double ddx = (double)px - xc, ddy = (double)py - yc;
                                 if (ddx * ddx + ddy * ddy > radSq) {
-                                    tent_release(g2, py * g.sw + px, g.tent_id);
+                                    mw_unmark(g2, py * g.sw + px);
                                     const uint32_t lastv = __hip_atomic_load(&g2.reg[m - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                                     __hip_atomic_store(&g2.reg[i], lastv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                                     __hip_atomic_store(&g2.reg[m - 1], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   // kept behind the live part: list 2 stays a permutation
@@ -1043,8 +1058,9 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
     const int W = L.waves;
     uint32_t* C = s_mw;
     uint32_t* T = C + L.nw_al;
-    uint32_t* my_ring = T + 4 * L.nw_al + (size_t)wv * (L.ring + kMwAssumed + 2);
-    int* ctrl = reinterpret_cast<int*>(T + 4 * L.nw_al + (size_t)W * (L.ring + kMwAssumed + 2));
+    uint32_t* O = T + 4 * L.nw_al + (size_t)wv * (L.nw_al + L.ring + kMwAssumed + 2);   // this wave's own marks (private: a claim nibble can be overwritten)
+    uint32_t* my_ring = O + L.nw_al;
+    int* ctrl = reinterpret_cast<int*>(T + 4 * L.nw_al + (size_t)W * (L.nw_al + L.ring + kMwAssumed + 2));
     // control words: 0 next_group, 1 main_group, 2 done, 3 abort (watchdog), then per-wave arrays
     int* next_group = ctrl; int* main_group = ctrl + 1; int* done = ctrl + 2; int* wd_abort = ctrl + 3;
     int* hstate = ctrl + 4; int* buf_group = hstate + kMwMaxWaves; int* buf_n = buf_group + 2 * kMwMaxWaves;
@@ -1058,6 +1074,7 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
         const uint32_t* u32 = reinterpret_cast<const uint32_t*>(P.undef + (size_t)b * ((n + 63) / 64));
         for (int i = threadIdx.x; i < nwords; i += blockDim.x) C[i] = u32[i];
         for (int i = threadIdx.x; i < 4 * L.nw_al; i += blockDim.x) T[i] = 0;
+        for (int i = lane; i < L.nw_al; i += 64) O[i] = 0;
         for (int i = threadIdx.x; i < L.n_groups_cap; i += blockDim.x) owner[i] = 0;
         if (threadIdx.x < 8 + 6 * kMwMaxWaves) ctrl[threadIdx.x] = threadIdx.x >= 4 + kMwMaxWaves && threadIdx.x < 4 + 3 * kMwMaxWaves ? -1 : 0;   // buf_group = -1 (free)
     }
@@ -1065,7 +1082,7 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
     const bool is_main = wv == 0;
     const int h = wv - 1;
     GrowCtx g;
-    g.pix = P.pix + (size_t)b * n; g.used = nullptr; g.ring = my_ring; g.ring_mask = L.ring - 1;
+    g.pix = P.pix + (size_t)b * n; g.used = O; g.ring = my_ring; g.ring_mask = L.ring - 1;
     g.sw = P.sw; g.sh = P.sh; g.lane = lane; g.comm = C; g.tent = T;
     g.tent_pos = cur_pos; g.tent_id = is_main ? kMwMainId : wv; g.my_pos = 0;
     g.assumed = my_ring + L.ring; g.assumed_cap = kMwAssumed;
@@ -1271,7 +1288,7 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
         if (is_main) {
             const int fb = r.second ? r.n1 : 0;
             for (int j = lane; j < r.nfinal; j += 64) { const int p = pix_of(heap_ld(g.reg + fb + j), g.sw); atomicOr(&C[p >> 5], 1u << (p & 31)); }
-            mw_release(g, g.reg, acc_n, kMwMainId);
+            mw_forget(g, g.reg, acc_n, kMwMainId);
             if (r.keep) {
                 if (n_lines < kLineCap) { if (lane == 0) raw[n_lines] = r.line; }
                 else if (lane == 0) atomicOr(P.status, 4);
@@ -1298,7 +1315,8 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
                 __builtin_amdgcn_wave_barrier();
                 ++nent; hoff += (tot + 1) & ~1;
                 lds_st(&buf_n[h * 2 + kbuf], nent);
-            } else mw_release(g, g.reg, acc_n, wv);
+                mw_forget(g, g.reg, acc_n, 0);
+            } else mw_forget(g, g.reg, acc_n, wv);
             __builtin_amdgcn_wave_barrier();
             lds_st(&hstate[h], (grp << 8) | (t + 1));
         }
@@ -1309,7 +1327,7 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
             int32_t* gs = P.grow_stats + (size_t)b * 4; gs[0] = n_self; gs[1] = n_spec_ok; gs[2] = n_spec_bad; gs[3] = W;
             if (P.prof && b == 0) {   // diagnostics of frame 0: cycles {total, waiting for helpers, growing itself}, helper attempts | give-ups << 32, regions grown by main, results taken
                 P.prof[0] = (long long)clock64() - c_begin; P.prof[1] = c_wait; P.prof[2] = c_self;
-                P.prof[3] = (long long)hcount[0] | ((long long)hcount[1] << 32); P.prof[4] = n_self; P.prof[5] = n_spec_ok;
+                P.prof[3] = (long long)hcount[0] | ((long long)hcount[1] << 32); P.prof[4] = n_self; P.prof[5] = (long long)n_spec_ok | ((long long)n_spec_bad << 32);
             }
         }
         lds_st(done, 1);
@@ -1646,7 +1664,7 @@ void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp,
     if (B <= (grow_waves > 1 ? kLsdMwMaxFrames : mw_max_b) && want_waves >= 2 && P.mw_heap && P.reg_frame_stride >= 2 * (size_t)n) {
         const int nw_al = (((n + 31) / 32 + 1) & ~1), groups_cap = ((P.sw - 1) * (P.sh - 1) + 63) / 64 + 1;
         for (int w = want_waves; w >= 2; --w) {
-            const size_t bytes = (size_t)5 * nw_al * 4 + (size_t)w * (256 + kMwAssumed + 2) * 4 + (8 + 6 * kMwMaxWaves) * 4 + ((groups_cap + 15) & ~15) + 16 +
+            const size_t bytes = (size_t)5 * nw_al * 4 + (size_t)w * (nw_al + 256 + kMwAssumed + 2) * 4 + (8 + 6 * kMwMaxWaves) * 4 + ((groups_cap + 15) & ~15) + 16 +
                                  (size_t)(w - 1) * 2 * kMwEntries * sizeof(MwEntry);
             if (bytes <= 160 * 1024) { L.waves = w; L.ring = 256; L.nw_al = nw_al; L.n_groups_cap = groups_cap; L.lookahead = 2 * (w - 1); mw_bytes = bytes; break; }
         }

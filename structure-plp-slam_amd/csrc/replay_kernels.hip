@@ -73,6 +73,49 @@ __global__ __launch_bounds__(256) void k_replay_line_queries(const plp_keyline* 
     }
 }
 
+// ---- live rows of a padded per-frame array, packed back to back (the host boundary of the batched replay: what crosses PCIe is the
+// features that exist, not the capacity they were allotted; SURVEY.md 8(d) "PCIe-inclusive rate")
+// one workgroup: offsets[0..B] = exclusive prefix sum of min(max(counts, 0), cap)
+__global__ __launch_bounds__(1024) void k_pack_offsets(const int32_t* __restrict__ counts, int B, int cap, long long* __restrict__ offsets) {
+    __shared__ long long s_wave[16];
+    __shared__ long long s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < B; base += 1024) {
+        const int i = base + tid;
+        const long long v = i < B ? (long long)min(max(counts[i], 0), cap) : 0;
+        long long inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const long long up = ((long long)__shfl_up((int)(inc >> 32), o) << 32) | (unsigned)__shfl_up((int)(unsigned)inc, o);
+            if (lane >= o) inc += up;
+        }
+        if (lane == 63) s_wave[wv] = inc;
+        __syncthreads();
+        long long before = s_carry;
+        for (int k = 0; k < wv; ++k) before += s_wave[k];
+        if (i < B) offsets[i] = before + inc - v;
+        __syncthreads();
+        if (tid == 1023) s_carry = before + inc;
+        __syncthreads();
+    }
+    if (tid == 0) offsets[B] = s_carry;
+}
+
+// grid = (ceil(cap * row_words / 1024), B), block = 256: 4 dwords per thread
+__global__ __launch_bounds__(256) void k_pack_rows(const uint32_t* __restrict__ src, const int32_t* __restrict__ counts, int cap, int row_words,
+                                                   const long long* __restrict__ offsets, uint32_t* __restrict__ dst) {
+    const int b = blockIdx.y;
+    const long long words = (long long)min(max(counts[b], 0), cap) * row_words;
+    const uint32_t* s = src + (size_t)b * cap * row_words;
+    uint32_t* d = dst + offsets[b] * row_words;
+    const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (i0 + k < words) d[i0 + k] = s[i0 + k];
+}
+
 }  // namespace plp
 
 using namespace plp;
@@ -103,6 +146,20 @@ plp_status plp_replay_line_queries_device(const plp_keyline* feat_kl, const int3
     hipLaunchKernelGGL(k_replay_line_queries, dim3((cap + 255) / 256, B), dim3(256), 0, (hipStream_t)hip_stream, feat_kl, feat_counts, halo, cap, shift_x, shift_y,
                        reinterpret_cast<float2*>(q_sp), reinterpret_cast<float2*>(q_ep), q_level, q_counts, reinterpret_cast<float2*>(q2_sp),
                        reinterpret_cast<float2*>(q2_ep), q2_level, q2_valid, feat_kps, feat_kp_counts, kp_cap, t_kp_octave);
+    PLP_HIP(hipGetLastError());
+    return PLP_OK;
+}
+
+plp_status plp_pack_rows_device(const void* src, const int32_t* counts, int32_t B, int32_t cap, int32_t row_bytes, void* dst, int64_t* offsets,
+                                int32_t compute_offsets, void* hip_stream) {
+    if (!src || !counts || !dst || !offsets) return set_error(PLP_ERR_INVALID_ARG, "NULL argument");
+    if (B <= 0 || cap <= 0 || row_bytes <= 0 || (row_bytes & 3)) return set_error(PLP_ERR_INVALID_ARG, "B, cap positive; row_bytes a positive multiple of 4");
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (compute_offsets) hipLaunchKernelGGL(k_pack_offsets, dim3(1), dim3(1024), 0, st, counts, B, cap, reinterpret_cast<long long*>(offsets));
+    const int row_words = row_bytes / 4;
+    const long long per_frame = (long long)cap * row_words;
+    hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)((per_frame + 1023) / 1024), B), dim3(256), 0, st, reinterpret_cast<const uint32_t*>(src), counts, cap, row_words,
+                       reinterpret_cast<const long long*>(offsets), reinterpret_cast<uint32_t*>(dst));
     PLP_HIP(hipGetLastError());
     return PLP_OK;
 }

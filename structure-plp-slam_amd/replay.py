@@ -116,6 +116,16 @@ class line_queries:
                                                                       kp_cap, p(self.t_kp_octave) if lm else None, stream.cuda_stream))
 
 
+def pack_rows(plp, src, counts, dst, offsets, compute_offsets, stream):
+    """src: torch tensor [B, cap, ...] (rows of a multiple of 4 bytes); counts int32 [B]; dst: flat uint8 tensor with room for B * cap rows;
+    offsets int64 [B + 1].  dst gets the live rows back to back (plp_pack_rows_device); offsets[B] = number of rows packed."""
+    B, cap = src.shape[0], src.shape[1]
+    row_bytes = src[0, 0].numel() * src.element_size()
+    plp._check(plp.lib().plp_pack_rows_device(src.data_ptr(), counts.data_ptr(), B, cap, row_bytes, dst.data_ptr(), offsets.data_ptr(), int(bool(compute_offsets)),
+                                              stream.cuda_stream))
+    return row_bytes
+
+
 def with_halo(t, halo_t):
     """[halo + B, ...]: predecessor frames in front, so frame b's predecessors are rows b+halo-1, b+halo-2."""
     return torch.cat([halo_t, t], 0)

@@ -146,20 +146,21 @@ def concurrent(img, order, n_helpers, rng):
                     progress[g] = k + 1     # committed, or held by a region that will most likely swallow it
                     continue
                 cur_pos[hid] = my_pos
-                marked, assumed = [], []
+                own, marked, assumed = set(), [], []        # own: this wave's private map; T only carries CLAIMS, which others may overwrite
 
-                def mark(q, marked=marked):
-                    T[q] = (hid, "growing"); marked.append(q)       # a later seed's claim is simply overwritten
+                def mark(q, own=own, marked=marked):
+                    own.add(q); T[q] = (hid, "growing"); marked.append(q)       # a later seed's claim is simply overwritten
 
-                def unmark(q):
+                def unmark(q, own=own):
+                    own.discard(q)
                     if T.get(q) == (hid, "growing"):
                         del T[q]
 
-                def is_used(q, my_pos=my_pos, assumed=assumed):
-                    if q in C or T.get(q) == (hid, "growing"):
+                def is_used(q, my_pos=my_pos, assumed=assumed, own=own):
+                    if q in C or q in own:
                         return True
                     o = T.get(q)
-                    if o is not None and (o[0] == "main" or o[1] == "pending" or cur_pos[o[0]] < my_pos):
+                    if o is not None and o != (hid, "growing") and (o[0] == "main" or o[1] == "pending" or cur_pos[o[0]] < my_pos):
                         assumed.append(q)                           # somebody else's claim: assumed used, checked at this seed's turn
                         return True
                     return False
