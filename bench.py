@@ -243,12 +243,41 @@ def main():
         h_frames = torch.empty((B, args.rows, args.cols), dtype=torch.uint8, pin_memory=True)
         h_frames.copy_(d_frames.cpu())
         stage = [torch.empty_like(d_frames) for _ in range(2)]
-        outs = [[t[HALO:] for t in kps2], [t[HALO:] for t in desc2], [t[HALO:] for t in cnt2], [t[HALO:] for t in kl2], [t[HALO:] for t in lbd2], fn2, [t[HALO:] for t in lcnt2]]
-        h_out = [[torch.empty(t[0].shape, dtype=t[0].dtype, pin_memory=True) for t in outs] for _ in range(NBUF)]
-        h_m = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in (m1, n1, m2, n2, m3, n3, m4, n4)]
-        sH, sD = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
-        stage_free = [None, None]; down_done = [None] * NBUF
+        # What comes back: the features that exist, not the capacity they were allotted (the reference's extract() hands back vectors of exactly
+        # that many entries).  Per step the live rows of every padded array are packed on the device (plp_pack_rows_device: offsets = prefix
+        # sum of the per-frame counts) and the device-to-host copies move exactly offsets[B] rows; their sizes are known on the host one
+        # step later (the offsets come back first), so the bulk copy of step n is issued after step n + 1 has been enqueued.
+        rp = ts.replay
+        pt_arrays = lambda buf: [(kps2[buf][HALO:], 28), (desc2[buf][HALO:], 32), (m1.view(B, cap, 1), 4), (m2.view(B, cap, 1), 4)]
+        ln_arrays = lambda buf: [(kl2[buf][HALO:], 68), (lbd2[buf][HALO:], 32), (fn2[buf], 24), (m3.view(B, lcap, 1), 4), (m4.view(B, lcap, 1), 4)]
+        flat = lambda nbytes, **kw: torch.empty(nbytes, dtype=torch.uint8, **kw)
+        d_pk = [[flat(B * (cap if i < 4 else lcap) * rb, device=dev) for i, (_, rb) in enumerate(pt_arrays(0) + ln_arrays(0))] for _ in range(NBUF)]
+        h_pk = [[flat(t.numel(), pin_memory=True) for t in d_pk[0]] for _ in range(NBUF)]
+        d_off = [torch.empty((2, B + 1), dtype=torch.int64, device=dev) for _ in range(NBUF)]
+        h_off = [torch.empty((2, B + 1), dtype=torch.int64, pin_memory=True) for _ in range(NBUF)]
+        small = lambda buf: [cnt2[buf][HALO:], lcnt2[buf][HALO:], n1, n2, n3, n4]
+        h_small = [[torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in small(0)] for _ in range(NBUF)]
+        sH, sD, sD2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        stage_free = [None, None]; down_done = [None] * NBUF; ev_off = [None] * NBUF
         frames_default = d_frames
+        d2h_bytes = []
+
+        def finish_download(buf):
+            """the bulk device-to-host copy of the step that filled set `buf`: its sizes are on the host once the offsets have arrived"""
+            ev_off[buf].synchronize()
+            tot_pt, tot_ln = int(h_off[buf][0, B]), int(h_off[buf][1, B])
+            nbytes = 0
+            with torch.cuda.stream(sD2):
+                sD2.wait_event(ev_off[buf])
+                for i, (_, rb) in enumerate(pt_arrays(buf) + ln_arrays(buf)):
+                    nb = (tot_pt if i < 4 else tot_ln) * rb
+                    if nb:
+                        h_pk[buf][i][:nb].copy_(d_pk[buf][i][:nb], non_blocking=True)
+                    nbytes += nb
+                down_done[buf] = torch.cuda.Event(); down_done[buf].record(sD2)
+            d2h_bytes.append(nbytes + h_off[buf].numel() * 8 + sum(t.numel() * t.element_size() for t in h_small[buf]))
+
+        pending = []
 
         def host_step(n):
             nonlocal d_frames
@@ -269,25 +298,44 @@ def main():
             step()
             d_frames = frames_default
             sD.wait_event(ts.done_match[buf])
-            with torch.cuda.stream(sD):                                      # D2H of this step's features and matches
-                for h, t in zip(h_out[buf], outs):
-                    h.copy_(t[buf], non_blocking=True)
-                for h, t in zip(h_m, (m1, n1, m2, n2, m3, n3, m4, n4)):
+            with torch.cuda.stream(sD):                                      # pack this step's live rows; offsets, counts and match counts go first
+                for i, (t, rb) in enumerate(pt_arrays(buf)):
+                    rp.pack_rows(plp, t, cnt2[buf][HALO:], d_pk[buf][i], d_off[buf][0], i == 0, sD)
+                for i, (t, rb) in enumerate(ln_arrays(buf)):
+                    rp.pack_rows(plp, t, lcnt2[buf][HALO:], d_pk[buf][4 + i], d_off[buf][1], i == 0, sD)
+                h_off[buf].copy_(d_off[buf], non_blocking=True)
+                for h, t in zip(h_small[buf], small(buf)):
                     h.copy_(t, non_blocking=True)
-                down_done[buf] = torch.cuda.Event(); down_done[buf].record(sD)
+                ev_off[buf] = torch.cuda.Event(); ev_off[buf].record(sD)
             stage_free[sb] = ts.done_match[buf]
+            while pending:                                                   # the previous step's bulk copy, now that this step keeps the GPU busy
+                finish_download(pending.pop(0))
+            pending.append(buf)
         for n in range(2):
             host_step(n)
+        while pending:
+            finish_download(pending.pop(0))
         barrier()
+        d2h_bytes.clear()
         t0 = time.perf_counter()
         for n in range(args.steps):
             host_step(n)
+        while pending:
+            finish_download(pending.pop(0))
         barrier()
         el = time.perf_counter() - t0
         extras["pcie_inclusive_value"] = round(B * args.steps / el, 1)
         extras["pcie_inclusive_ms_per_step"] = round(1e3 * el / args.steps, 4)
-        extras["pcie_bytes_per_step"] = {"h2d": int(h_frames.numel()), "d2h": int(sum(h.numel() * h.element_size() for h in h_out[0]) + sum(h.numel() * h.element_size() for h in h_m))}
-        del h_frames, stage, h_out
+        extras["pcie_bytes_per_step"] = {"h2d": int(h_frames.numel()), "d2h": int(np.mean(d2h_bytes)) if d2h_bytes else 0,
+                                         "d2h_padded_arrays_would_be": int(sum(t.numel() for t in d_pk[0]) + 6 * B * 4)}
+        # the packed copy of the last step against the padded arrays (frame 0 and the last frame): the packing moves what it should
+        lb = (ts.step_no - 1) % NBUF
+        o = h_off[lb][0]
+        k_first = kps2[lb][HALO].cpu().numpy()[:int(o[1])]
+        assert np.array_equal(h_pk[lb][0][:int(o[1]) * 28].numpy().reshape(-1, 28), k_first), "packed key points differ from the padded array"
+        d_last = desc2[lb][HALO + B - 1].cpu().numpy()[:int(o[B] - o[B - 1])]
+        assert np.array_equal(h_pk[lb][1][int(o[B - 1]) * 32:int(o[B]) * 32].numpy().reshape(-1, 32), d_last), "packed descriptors differ from the padded array"
+        del h_frames, stage, h_pk, d_pk
         # single-frame latency, 256 calls each, the host-pointer entry points on one frame at a time
         lat = {}
         n_lat = 256

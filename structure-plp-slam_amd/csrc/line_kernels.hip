@@ -375,13 +375,16 @@ __device__ __forceinline__ void mw_unmark(const GrowCtx& g, int p) {
 #error "region_grow's hand-scheduled acceptance block (wait states, wave64, v_readlane hazards) is verified for gfx950 only: port it before building for another target"
 #endif
 // MW (several waves per frame, k_lsd_grow_mw): a pixel is used when it is COMMITTED (g.comm, written by the main wave only) or part of
-// the region this wave is growing (its private map g.used).  A pixel CLAIMED by somebody else (the claim nibbles, g.tent) -- the main wave, another
-// helper's growing region if that helper's seed comes EARLIER in the seed order, any finished region that waits for its turn (this
-// helper's own earlier ones included) -- will most likely be used by the time this seed's turn comes: it is treated as used and
-// written to the `assumed` list, which the main wave checks at this seed's turn (every assumed pixel must be committed by then).  The
-// claim of a helper that grows a LATER seed is ignored and overwritten on acceptance (that speculation will be found invalid at its
-// turn).  The main wave ignores every claim: it IS the sequential scan.  Gives up (returns -1 - entries written and marked so far) when
-// a list outgrows its space.  Model of the protocol: tests/test_spec_grow_model.py.
+// the region this wave is growing (its private map g.used).  A pixel CLAIMED by somebody else (the claim nibbles, g.tent):
+//   by a FINISHED region that waits for its turn (this helper's own earlier ones included): its pixels are known and will most likely be
+//     committed by the time this seed's turn comes -- treated as used and written to the `assumed` list, which the main wave checks at
+//     this seed's turn (every assumed pixel must be committed by then);
+//   by a region still GROWING from an earlier seed (the main wave's always is): the sequential scan gives that region precedence and it
+//     will most likely take this seed's pixels too -- when such a pixel is about to be accepted the wave GIVES UP, cheaply;
+//   by a region growing from a LATER seed: ignored, and overwritten on acceptance (that speculation will be found invalid at its turn).
+// The main wave ignores every claim: it IS the sequential scan.  Giving up (also when a list outgrows its space) returns
+// -1 - (entries written and marked so far).  Model of the protocol: tests/test_spec_grow_model.py.  Measured alternatives
+// (profiles/r03_lsd_grow_mw.md): yielding to every earlier claim, and assuming every earlier claim used.
 template <bool MW>
 __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed_deg, const float2* seed_cs, double prec, float c_pass,
                            float c_fail, double& reg_angle, int* n_exact_tests = nullptr) {
@@ -425,14 +428,15 @@ __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed
         }
         cand = cand && nx >= 0 && ny >= 0 && nx < g.sw && ny < g.sh;
         np = ny * g.sw + nx;
+        bool foreign = false;   // claimed by the growing region of an earlier seed (or of the main wave)
         if (MW) {
             bool assume = false;
             if (cand) {
                 bool used = ((g.comm[np >> 5] | g.used[np >> 5]) >> (np & 31)) & 1u;
                 const int owner = tent_owner(g, np);
                 if (!used && owner != 0 && owner != g.tent_id && g.tent_id != kMwMainId) {   // somebody else's claim
-                    const bool earlier = owner > kMwPending || g.tent_pos[owner - 1] < g.my_pos;   // main / a finished region / an earlier seed's growing region
-                    if (earlier) { assume = true; used = true; }
+                    if (owner > kMwPending && owner != kMwMainId) { assume = true; used = true; }   // a FINISHED region that waits for its turn: its pixels are known
+                    else foreign = owner == kMwMainId || g.tent_pos[owner - 1] < g.my_pos;       // a region still growing from an earlier seed; a later seed's claim is ignored
                 }
                 cand = !used;
             }
@@ -549,7 +553,7 @@ __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed
             candmask &= ~__builtin_amdgcn_ballot_w64(np == ap);              // the same pixel seen from a later point of the batch
         }
         if (MW) {   // give up before anything of this round is written or marked
-            if (gave_up || nreg > list_cap) { gave_up = true; nreg = n_before; acc = 0; }
+            if (gave_up || nreg > list_cap || (acc & __builtin_amdgcn_ballot_w64(foreign))) { gave_up = true; nreg = n_before; acc = 0; }
         }
         if ((acc >> lane) & 1ull) {
             const int pos = n_before + __popcll(acc & ((1ull << lane) - 1ull));
@@ -1203,6 +1207,7 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
                             }
                             __builtin_amdgcn_wave_barrier();
                             ++n_spec_ok;
+                            todo &= __ballot(!committed((int)mine));   // the seeds this region covers leave the list together
                             continue;
                         }
                         ++n_spec_bad;
@@ -1289,6 +1294,7 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
             const int fb = r.second ? r.n1 : 0;
             for (int j = lane; j < r.nfinal; j += 64) { const int p = pix_of(heap_ld(g.reg + fb + j), g.sw); atomicOr(&C[p >> 5], 1u << (p & 31)); }
             mw_forget(g, g.reg, acc_n, kMwMainId);
+            todo &= __ballot(!committed((int)mine));
             if (r.keep) {
                 if (n_lines < kLineCap) { if (lane == 0) raw[n_lines] = r.line; }
                 else if (lane == 0) atomicOr(P.status, 4);
@@ -1318,6 +1324,12 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
                 mw_forget(g, g.reg, acc_n, 0);
             } else mw_forget(g, g.reg, acc_n, wv);
             __builtin_amdgcn_wave_barrier();
+            {   // the seeds of this group that the new region (or anybody's) covers or claims leave the list together (same rule as one by one above)
+                const int p = (int)mine;
+                const int ow = tent_owner(g, p), owh = ow > kMwPending ? ow - kMwPending : ow;
+                const bool skip = committed(p) || (ow != 0 && (ow == kMwMainId || owh == wv || cur_pos[min(owh, kMwMaxWaves) - 1] < grp * 64 + lane));
+                todo &= __ballot(!skip);
+            }
             lds_st(&hstate[h], (grp << 8) | (t + 1));
         }
     }

@@ -6,9 +6,9 @@ refinement) is committed at its turn AND every pixel it assumed used (because so
 Why that rule is exact: C only grows, and a helper that read C(x) = 0 where the sequential algorithm would see USED(x) = 1 differs from it only
 if it then ACCEPTS x (a pixel that is tested and rejected leaves no trace) -- so "no accepted pixel is committed at my turn" is precisely the
 condition under which the sequential algorithm grows the same region from the same seed; and a helper that skipped x as used is right iff
-x is used at its turn.  Which claims a helper respects (the main wave's growing region, any finished region that waits for its turn, the
-growing region of a helper whose seed comes EARLIER) and which it overrides (a LATER seed's growing region) only changes how much
-speculation is wasted: the two checks above alone decide what is committed.
+x is used at its turn.  What a helper does about other waves' claims (a finished region that waits for its turn: assumed used; a region
+still growing from an EARLIER seed or by the main wave: the helper gives up when it is about to accept such a pixel; a region growing from a
+LATER seed: overridden) only changes how much speculation is wasted: the two checks above alone decide what is committed.
 
 The model runs the protocol on toy images with a toy order-dependent region_grow (running mean angle, refinement that un-marks and regrows with
 a tighter tolerance, radius reduction) under random interleavings of the waves, and requires the sequence of committed regions and the final
@@ -160,14 +160,18 @@ def concurrent(img, order, n_helpers, rng):
                     if q in C or q in own:
                         return True
                     o = T.get(q)
-                    if o is not None and o != (hid, "growing") and (o[0] == "main" or o[1] == "pending" or cur_pos[o[0]] < my_pos):
-                        assumed.append(q)                           # somebody else's claim: assumed used, checked at this seed's turn
+                    if o is not None and o[1] == "pending":         # a FINISHED region that waits for its turn: assumed used, checked at this seed's turn
+                        assumed.append(q)
                         return True
                     return False
+
+                def poison(q, my_pos=my_pos):                       # about to accept q: yield to a region still growing from an earlier seed (main's always is)
+                    o = T.get(q)
+                    return o is not None and o[1] == "growing" and o[0] != hid and (o[0] == "main" or cur_pos[o[0]] < my_pos)
                 try:
                     if len(marked) > 10_000:
                         raise Abort()
-                    final, ever, line = yield from process_seed(img, seed, is_used, mark, unmark, tick=tick)
+                    final, ever, line = yield from process_seed(img, seed, is_used, mark, unmark, poison=poison, tick=tick)
                     for q in final:                                 # finished: "helper is growing this" -> "a finished region that waits for its turn"
                         if T.get(q) == (hid, "growing"):
                             T[q] = (hid, "pending")
