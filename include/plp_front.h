@@ -214,8 +214,11 @@ int32_t plp_model_index_sort_host(const int32_t* sizes, int32_t n, int32_t depth
  * arguments for which the kernel falls back to the general f64 routine.  Returns the number of proven arguments.  No GPU needed. */
 int32_t plp_model_sincos_host(const float* a, int64_t n, float* c, float* s, uint8_t* proven);
 plp_status plp_line_scaled_size(const plp_line* ctx, int32_t* rows, int32_t* cols);
-/* Diagnostics of frame 0 of the last batch: shader cycles {whole wave, region_grow, region2rect, refine}, regions grown, pixels grown. */
-plp_status plp_line_debug_grow_profile(plp_line* ctx, int64_t* out6);
+/* Diagnostics of frame 0 of the last batch, 12 values.  One wave per frame: shader cycles {whole wave, region_grow, region2rect, refine},
+ * regions grown, pixels grown, 0 x 6.  Several waves per frame, the main wave's view: cycles {whole, waiting for helpers, growing regions
+ * itself}, helper attempts | give-ups << 32, regions it grew itself, results taken | rejected << 32, cycles {taking results, publishing its
+ * own regions, group set-up}, 0 x 3. */
+plp_status plp_line_debug_grow_profile(plp_line* ctx, int64_t* out12);
 
 /* ------------------------------------------------------------------------------------------
  * Hamming matchers, array form — replace the inner loops of the reference's src/PLPSLAM/match directory.

@@ -371,9 +371,11 @@ class LineFeatureTracker:
         return {k: float(v) / nb for k, v in zip(self.STAGES, ms)}, n.value
 
     def grow_profile(self):
-        v = np.zeros(6, np.int64)
+        v = np.zeros(12, np.int64)
         _check(lib().plp_line_debug_grow_profile(self._h, _p(v)))
-        return dict(zip(("cycles_total", "cycles_grow", "cycles_rect", "cycles_refine", "regions", "pixels"), v.tolist()))
+        d = dict(zip(("cycles_total", "cycles_grow", "cycles_rect", "cycles_refine", "regions", "pixels"), v[:6].tolist()))
+        d["more"] = v[6:].tolist()
+        return d
 
     def debug_read(self, what, frame=0):
         r, c = C.c_int32(), C.c_int32()

@@ -146,7 +146,7 @@ plp_status ensure(plp_line* c, int B) {
     PLP_HIP(c->raw.reserve(sizeof(float4) * kLineCap * B)); PLP_HIP(c->n_raw.reserve(4 * (size_t)B));
     PLP_HIP(c->dx.reserve(dxy_frame_entries(P.W, P.H) * 4 * B));
     PLP_HIP(c->all_kl.reserve(sizeof(plp_keyline) * kLineCap * B)); PLP_HIP(c->all_lbd.reserve((size_t)32 * kLineCap * B));
-    PLP_HIP(c->n_all.reserve(4 * (size_t)B)); PLP_HIP(c->status.reserve(16)); PLP_HIP(c->prof.reserve(64)); PLP_HIP(c->grow_stats.reserve(16 * (size_t)B));
+    PLP_HIP(c->n_all.reserve(4 * (size_t)B)); PLP_HIP(c->status.reserve(16)); PLP_HIP(c->prof.reserve(128)); PLP_HIP(c->grow_stats.reserve(16 * (size_t)B));
     P.blur11 = (uint8_t*)c->blur11.p; P.scaled = (uint8_t*)c->scaled.p;
     P.pix = (LsdPix*)c->pix.p; P.g2 = (uint32_t*)c->g2.p; P.n_order = (int32_t*)c->n_order.p;
     P.blockmax = (uint32_t*)c->maxgrad.p; P.undef = (unsigned long long*)c->undef.p;
@@ -281,15 +281,16 @@ plp_status plp_line_extract(plp_line* c, const uint8_t* img, int32_t rows, int32
     return PLP_OK;
 }
 
-plp_status plp_line_debug_grow_profile(plp_line* c, int64_t* out6) {
+plp_status plp_line_debug_grow_profile(plp_line* c, int64_t* out12) {
+    int64_t* out6 = out12;
     if (!c || !out6) return set_error(PLP_ERR_INVALID_ARG, "NULL argument");
     std::lock_guard<std::mutex> lk(c->mu);
     if (!c->last_B) return set_error(PLP_ERR_INVALID_ARG, "no batch yet");
     PLP_HIP(hipSetDevice(c->device));
     PLP_HIP(hipStreamSynchronize(c->last_stream));
-    long long v[8] = {0};
-    PLP_HIP(hipMemcpy(v, c->prof.p, 48, hipMemcpyDeviceToHost));
-    for (int i = 0; i < 6; ++i) out6[i] = v[i];
+    long long v[12] = {0};
+    PLP_HIP(hipMemcpy(v, c->prof.p, 96, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 12; ++i) out6[i] = v[i];
     return PLP_OK;
 }
 

@@ -316,7 +316,9 @@ struct GrowCtx {
     uint32_t* tent;                  // LDS: 4 bits per pixel, who CLAIMS the pixel (advisory: a claim can be overwritten; what a wave itself holds is in
                                      // its private map `used`): 0 nobody; h = 1..7 the region helper h is growing; 7 + h a finished region of helper
                                      // h that waits for its turn; kMwMainId the region the main wave is growing
-    const int* tent_pos;             // LDS: per helper, the seed position (rank in the seed order) of its latest attempt
+    const int* tent_pos;             // LDS: per helper, the seed position (rank in the seed order) of its latest attempt, then [kMwMaxWaves ..) the lowest
+                                     // and [2 kMwMaxWaves ..) the highest seed position among its finished regions that still wait for their turn
+    int policy;                      // 0: a finished region's claim is judged like a growing one's; 1: by the position range of that helper's finished regions
     int tent_id, my_pos;             // this wave's id and the seed position of the region it is growing
     int reg_cap;                     // entries the list at `reg` can take
     uint32_t* assumed; int assumed_cap;   // LDS: pixels this attempt treated as USED because an earlier seed's unfinished region holds them
@@ -435,8 +437,12 @@ __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed
                 bool used = ((g.comm[np >> 5] | g.used[np >> 5]) >> (np & 31)) & 1u;
                 const int owner = tent_owner(g, np);
                 if (!used && owner != 0 && owner != g.tent_id && g.tent_id != kMwMainId) {   // somebody else's claim
-                    if (owner > kMwPending && owner != kMwMainId) { assume = true; used = true; }   // a FINISHED region that waits for its turn: its pixels are known
-                    else foreign = owner == kMwMainId || g.tent_pos[owner - 1] < g.my_pos;       // a region still growing from an earlier seed; a later seed's claim is ignored
+                    if (owner > kMwPending && owner != kMwMainId) {   // a FINISHED region that waits for its turn: its pixels are known
+                        const int x = owner - kMwPending - 1;
+                        if (g.policy == 0) foreign = g.tent_pos[x] < g.my_pos;
+                        else if (g.tent_pos[2 * kMwMaxWaves + x] < g.my_pos) { assume = true; used = true; }   // all of that helper's finished regions come earlier: used by my turn
+                        else foreign = !(g.tent_pos[kMwMaxWaves + x] > g.my_pos);                              // all later: ignore the claim; mixed: yield
+                    } else foreign = owner == kMwMainId || g.tent_pos[owner - 1] < g.my_pos;   // a region still growing from an earlier seed; a later seed's claim is ignored
                 }
                 cand = !used;
             }
@@ -735,7 +741,7 @@ __global__ __launch_bounds__(256, PLP_GROW_MIN_WAVES) void k_lsd_grow(LinePlanes
     if (b >= B) return;
     const int n = P.sw * P.sh, nwords = (n + 31) / 32, nv = (P.sw - 1) * (P.sh - 1);
     GrowCtx g;
-    g.comm = nullptr; g.tent = nullptr; g.tent_pos = nullptr; g.tent_id = 0; g.my_pos = 0; g.reg_cap = n; g.assumed = nullptr; g.assumed_cap = 0;
+    g.comm = nullptr; g.tent = nullptr; g.tent_pos = nullptr; g.tent_id = 0; g.my_pos = 0; g.reg_cap = n; g.assumed = nullptr; g.assumed_cap = 0; g.policy = 0;
     g.pix = P.pix + (size_t)b * n;
     g.reg = P.reg + (size_t)b * P.reg_frame_stride; const int nw_al = (nwords + 1) & ~1;   // the ring doubles as f64 scratch: 8-byte aligned
     g.used = s_bits + (size_t)wv * (nw_al + ring); g.ring = g.used + nw_al; g.ring_mask = ring - 1;
@@ -913,7 +919,7 @@ constexpr int kMwAssumed = 192;      // assumed-used pixels per attempt (a pixel
 struct MwResult { int n1, n2, nfinal, na; bool second, keep; float4 line; };
 struct alignas(16) MwEntry { int pos, n1, n2, nfinal; uint32_t flags, off; int na; uint32_t pad1; float4 line; uint32_t inl[kMwInline]; };   // flags: 1 keep, 2 final list = second
 static_assert(sizeof(MwEntry) == 96, "MwEntry layout");
-struct MwLayout { int waves, ring, nw_al, n_groups_cap, lookahead; };   // LDS (words): C | T (4 bits per pixel) | waves x (O | ring | assumed) | control | owner bytes | entries
+struct MwLayout { int waves, ring, nw_al, n_groups_cap, lookahead, policy; };   // LDS (words): C | T (4 bits per pixel) | waves x (O | ring | assumed) | control | owner bytes | entries
 
 // control words are read by all lanes from one address: the value is wave-uniform, and said so (readfirstlane) -- the hand-scheduled
 // block of region_grow wants its loop state in scalar registers, which the compiler only grants to values it can prove uniform
@@ -1070,7 +1076,8 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
     int* hstate = ctrl + 4; int* buf_group = hstate + kMwMaxWaves; int* buf_n = buf_group + 2 * kMwMaxWaves;
     int* hcount = buf_n + 2 * kMwMaxWaves;                                                          // diagnostics: helper attempts, give-ups
     int* cur_pos = hcount + 4;                                                                      // [helpers]: seed position of each helper's latest attempt
-    uint8_t* owner = reinterpret_cast<uint8_t*>(cur_pos + kMwMaxWaves);                          // [n_groups_cap]: 0 unpublished, 1 main, 2 + (h * 2 + k)
+    int* pend_lo = cur_pos + kMwMaxWaves; int* pend_hi = pend_lo + kMwMaxWaves;                      // [helpers]: lowest / highest seed position among its finished, waiting regions
+    uint8_t* owner = reinterpret_cast<uint8_t*>(pend_hi + kMwMaxWaves);                          // [n_groups_cap]: 0 unpublished, 1 main, 2 + (h * 2 + k)
     MwEntry* entries = reinterpret_cast<MwEntry*>((reinterpret_cast<uintptr_t>(owner + ((L.n_groups_cap + 15) & ~15)) + 15) & ~(uintptr_t)15);   // [helpers][2][kMwEntries]
     const int n_ord = P.n_order[b];
     const int n_groups = (n_ord + 63) / 64;
@@ -1080,7 +1087,10 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
         for (int i = threadIdx.x; i < 4 * L.nw_al; i += blockDim.x) T[i] = 0;
         for (int i = lane; i < L.nw_al; i += 64) O[i] = 0;
         for (int i = threadIdx.x; i < L.n_groups_cap; i += blockDim.x) owner[i] = 0;
-        if (threadIdx.x < 8 + 6 * kMwMaxWaves) ctrl[threadIdx.x] = threadIdx.x >= 4 + kMwMaxWaves && threadIdx.x < 4 + 3 * kMwMaxWaves ? -1 : 0;   // buf_group = -1 (free)
+        if (threadIdx.x < 8 + 8 * kMwMaxWaves) {   // buf_group = -1 (free); no finished region waits: lowest = "infinity", highest = -1
+            const int i = threadIdx.x;
+            ctrl[i] = (i >= 4 + kMwMaxWaves && i < 4 + 3 * kMwMaxWaves) ? -1 : (i >= 8 + 6 * kMwMaxWaves && i < 8 + 7 * kMwMaxWaves) ? 0x7fffffff : (i >= 8 + 7 * kMwMaxWaves) ? -1 : 0;
+        }
     }
     __syncthreads();
     const bool is_main = wv == 0;
@@ -1088,7 +1098,7 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
     GrowCtx g;
     g.pix = P.pix + (size_t)b * n; g.used = O; g.ring = my_ring; g.ring_mask = L.ring - 1;
     g.sw = P.sw; g.sh = P.sh; g.lane = lane; g.comm = C; g.tent = T;
-    g.tent_pos = cur_pos; g.tent_id = is_main ? kMwMainId : wv; g.my_pos = 0;
+    g.tent_pos = cur_pos; g.tent_id = is_main ? kMwMainId : wv; g.my_pos = 0; g.policy = L.policy;
     g.assumed = my_ring + L.ring; g.assumed_cap = kMwAssumed;
     uint32_t* const my_heap = is_main ? P.reg + (size_t)b * P.reg_frame_stride : P.mw_heap + (size_t)b * P.mw_heap_frame_stride + (size_t)h * 2 * kMwHeap;
     g.reg = my_heap; g.reg_cap = is_main ? 2 * n : kMwHeap;
@@ -1106,7 +1116,7 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
     // state of the group this wave works on
     int grp = -1, own = 0, kbuf = 0, hoff = 0, nent = 0, n_lines = 0;
     int n_self = 0, n_spec_ok = 0, n_spec_bad = 0;           // main: regions it grew itself, results it took / had to reject
-    long long c_wait = 0, c_self = 0;                        // main: cycles spent waiting for helpers / growing regions itself
+    long long c_wait = 0, c_self = 0, c_commit = 0, c_pub = 0, c_grp = 0;   // main: cycles waiting for helpers / growing regions itself / taking results / publishing its own / group set-up
     const long long c_begin = (long long)clock64();
     uint32_t mine = 0, mine_next = 0; float s_deg = 0.f; float2 s_cs = make_float2(0.f, 0.f);
     unsigned long long todo = 0;
@@ -1122,15 +1132,17 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
             if (fresh) { double sn, cs; sincos((double)s_deg * (3.14159265358979323846 / 180), &sn, &cs); s_cs = make_float2((float)cs, (float)sn); }
         }
     };
-    // main's view of the helper that owns the current group: progress inside the group, entries announced, their positions (lane i: entry i)
-    int prog = 0, ne = 0, pos_vec = -1;
+    // main's view of the helper that owns the current group: progress inside the group, entries announced and their headers (lane i: entry i)
+    int prog = 0, ne = 0, pos_vec = -1, hv_n1 = 0, hv_n2 = 0, hv_nf = 0, hv_na = 0, hv_fl = 0, hv_off = 0;
     const MwEntry* eb = entries;
     auto refresh = [&](int hh, int kk) {
         const int st = lds_ld(&hstate[hh]);
         prog = (st >> 8) > grp ? 64 : ((st >> 8) == grp ? (st & 255) : 0);
         ne = lds_ld(&buf_n[hh * 2 + kk]);
         eb = entries + (size_t)(hh * 2 + kk) * kMwEntries;
-        pos_vec = lane < ne ? eb[min(lane, kMwEntries - 1)].pos : -1;
+        const MwEntry* e = eb + min(lane, kMwEntries - 1);
+        pos_vec = lane < ne ? e->pos : -1;
+        hv_n1 = e->n1; hv_n2 = e->n2; hv_nf = e->nfinal; hv_na = e->na; hv_fl = (int)e->flags; hv_off = (int)e->off;   // one round trip for all of them
     };
     if (is_main) mine_next = lane < n_ord ? order[lane] : 0u;
     for (;;) {
@@ -1141,6 +1153,7 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
                 if (lds_ld(wd_abort)) break;
                 if (!todo) {
                     if (++grp >= n_groups) break;
+                    const long long cg0 = (long long)clock64();
                     lds_st(main_group, grp);
                     // whose group is it?  unclaimed (next_group == grp): take it; else wait until its helper has said so
                     own = 0;
@@ -1163,6 +1176,7 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
                     load_group(grp, own == 1, true);   // a helper's group: main grows few of its seeds itself, their angles are fetched when that happens
                     mine_next = (grp + 1) * 64 + lane < n_ord ? order[(grp + 1) * 64 + lane] : 0u;   // the next group's seeds are on their way while this one is dealt with
                     if (own > 1) refresh((own - 2) >> 1, (own - 2) & 1);
+                    c_grp += (long long)clock64() - cg0;
                     continue;
                 }
                 const int tt = __ffsll((long long)todo) - 1;
@@ -1184,22 +1198,33 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
                         c_wait += (long long)clock64() - cw0;
                     }
                     const unsigned long long hit = __ballot(pos_vec == tt);
+                    const long long cc0 = (long long)clock64();
                     if (hit) {
-                        const MwEntry* e = eb + (__ffsll((long long)hit) - 1);
-                        const int n1 = e->n1, n2 = e->n2, nf = e->nfinal, na = e->na, acc_n = n1 + n2, tot = acc_n + na;
-                        const uint32_t fl = e->flags;
-                        const uint32_t* hl = P.mw_heap + (size_t)b * P.mw_heap_frame_stride + (size_t)(hh * 2 + kk) * kMwHeap + e->off;
+                        const int ei = __ffsll((long long)hit) - 1;
+                        const MwEntry* e = eb + ei;
+                        const int n1 = bcast_i(hv_n1, ei), n2 = bcast_i(hv_n2, ei), nf = bcast_i(hv_nf, ei), na = bcast_i(hv_na, ei), acc_n = n1 + n2, tot = acc_n + na;
+                        const uint32_t fl = (uint32_t)bcast_i(hv_fl, ei);
+                        const int fb = (fl & 2u) ? n1 : 0;
                         bool bad = false;   // an accepted pixel that is committed by now, or an assumed-used one that is not
-                        for (int j0 = 0; j0 < tot; j0 += 64) {
-                            const int j = j0 + lane;
-                            if (j < tot) bad |= committed(pix_of(tot <= kMwInline ? e->inl[j] : heap_ld(hl + j), g.sw)) != (j >= acc_n);
-                        }
-                        if (!__ballot(bad)) {   // the sequential scan grows exactly this region here: commit it
-                            const int fb = (fl & 2u) ? n1 : 0;
-                            for (int j0 = 0; j0 < nf; j0 += 64) {
+                        if (tot <= kMwInline) {   // a small region: its pixels are in the entry, one LDS round trip each for the list and for the committed bits
+                            int p = 0;
+                            if (lane < tot) { p = pix_of(e->inl[lane], g.sw); bad = committed(p) != (lane >= acc_n); }
+                            if (!__ballot(bad)) { if (lane >= fb && lane < fb + nf) atomicOr(&C[p >> 5], 1u << (p & 31)); }
+                            else bad = true;
+                        } else {
+                            const uint32_t* hl = P.mw_heap + (size_t)b * P.mw_heap_frame_stride + (size_t)(hh * 2 + kk) * kMwHeap + bcast_i(hv_off, ei);
+                            for (int j0 = 0; j0 < tot; j0 += 64) {
                                 const int j = j0 + lane;
-                                if (j < nf) { const int p = pix_of(tot <= kMwInline ? e->inl[fb + j] : heap_ld(hl + fb + j), g.sw); atomicOr(&C[p >> 5], 1u << (p & 31)); }
+                                if (j < tot) bad |= committed(pix_of(heap_ld(hl + j), g.sw)) != (j >= acc_n);
                             }
+                            if (!__ballot(bad)) {
+                                for (int j0 = 0; j0 < nf; j0 += 64) {
+                                    const int j = j0 + lane;
+                                    if (j < nf) { const int p = pix_of(heap_ld(hl + fb + j), g.sw); atomicOr(&C[p >> 5], 1u << (p & 31)); }
+                                }
+                            }
+                        }
+                        if (!__ballot(bad)) {   // the sequential scan grows exactly this region here: it is committed
                             if (fl & 1u) {
                                 if (n_lines < kLineCap) { if (lane == 0) raw[n_lines] = e->line; }
                                 else if (lane == 0) atomicOr(P.status, 4);
@@ -1207,10 +1232,12 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
                             }
                             __builtin_amdgcn_wave_barrier();
                             ++n_spec_ok;
-                            todo &= __ballot(!committed((int)mine));   // the seeds this region covers leave the list together
+                            if (nf > 1) todo &= __ballot(!committed((int)mine));   // the seeds this region covers leave the list together
+                            c_commit += (long long)clock64() - cc0;
                             continue;
                         }
                         ++n_spec_bad;
+                        c_commit += (long long)clock64() - cc0;
                     }
                 }
                 t = tt;
@@ -1249,6 +1276,10 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
                         lds_st(&buf_n[h * 2 + k], 0);
                         lds_st(&buf_group[h * 2 + k], -1);
                         free_k = k;
+                        // what still waits is in the other buffer (entries in increasing position), or nothing
+                        const int og = lds_ld(&buf_group[h * 2 + (k ^ 1)]), on = lds_ld(&buf_n[h * 2 + (k ^ 1)]);
+                        if (og >= 0 && on > 0) lds_st(&pend_lo[h], og * 64 + entries[(size_t)(h * 2 + (k ^ 1)) * kMwEntries].pos);
+                        else { lds_st(&pend_lo[h], 0x7fffffff); lds_st(&pend_hi[h], -1); }
                     } else if (bg < 0) free_k = k;
                 }
                 const int ng = lds_ld(next_group);
@@ -1291,10 +1322,12 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
         else if (lane == 0) { atomicAdd(&hcount[0], 1); if (!ok) atomicAdd(&hcount[1], 1); }
         const int acc_n = r.n1 + r.n2;
         if (is_main) {
+            const long long cp0 = (long long)clock64();
             const int fb = r.second ? r.n1 : 0;
             for (int j = lane; j < r.nfinal; j += 64) { const int p = pix_of(heap_ld(g.reg + fb + j), g.sw); atomicOr(&C[p >> 5], 1u << (p & 31)); }
             mw_forget(g, g.reg, acc_n, kMwMainId);
             todo &= __ballot(!committed((int)mine));
+            c_pub += (long long)clock64() - cp0;
             if (r.keep) {
                 if (n_lines < kLineCap) { if (lane == 0) raw[n_lines] = r.line; }
                 else if (lane == 0) atomicOr(P.status, 4);
@@ -1320,6 +1353,8 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the lists in HBM are complete before the entry is announced
                 __builtin_amdgcn_wave_barrier();
                 ++nent; hoff += (tot + 1) & ~1;
+                if (lds_ld(&pend_hi[h]) < 0) lds_st(&pend_lo[h], g.my_pos);
+                lds_st(&pend_hi[h], g.my_pos);
                 lds_st(&buf_n[h * 2 + kbuf], nent);
                 mw_forget(g, g.reg, acc_n, 0);
             } else mw_forget(g, g.reg, acc_n, wv);
@@ -1340,6 +1375,7 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
             if (P.prof && b == 0) {   // diagnostics of frame 0: cycles {total, waiting for helpers, growing itself}, helper attempts | give-ups << 32, regions grown by main, results taken
                 P.prof[0] = (long long)clock64() - c_begin; P.prof[1] = c_wait; P.prof[2] = c_self;
                 P.prof[3] = (long long)hcount[0] | ((long long)hcount[1] << 32); P.prof[4] = n_self; P.prof[5] = (long long)n_spec_ok | ((long long)n_spec_bad << 32);
+                P.prof[6] = c_commit; P.prof[7] = c_pub; P.prof[8] = c_grp; P.prof[9] = P.prof[10] = P.prof[11] = 0;
             }
         }
         lds_st(done, 1);
@@ -1670,15 +1706,16 @@ void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp,
     // speculate ahead); many frames: one wave per frame, the chip is full of independent scans anyway.
     static const int mw_max_b = [] { const char* e = getenv("PLP_LSD_MW_MAX_B"); return std::min(e ? atoi(e) : 256, kLsdMwMaxFrames); }();   // 256 = one workgroup per CU
     static const int mw_waves = [] { const char* e = getenv("PLP_LSD_MW_WAVES"); int r = e ? atoi(e) : kMwMaxWaves; return std::min(std::max(r, 0), kMwMaxWaves); }();
+    static const int mw_policy = [] { const char* e = getenv("PLP_LSD_MW_POLICY"); return e ? atoi(e) : 0; }();   // how helpers treat the claims of finished regions (region_grow)
     MwLayout L{};
     size_t mw_bytes = 0;
     const int want_waves = grow_waves > 0 ? std::min(grow_waves, kMwMaxWaves) : mw_waves;          // plp_line_set_grow_waves overrides the automatic choice
     if (B <= (grow_waves > 1 ? kLsdMwMaxFrames : mw_max_b) && want_waves >= 2 && P.mw_heap && P.reg_frame_stride >= 2 * (size_t)n) {
         const int nw_al = (((n + 31) / 32 + 1) & ~1), groups_cap = ((P.sw - 1) * (P.sh - 1) + 63) / 64 + 1;
         for (int w = want_waves; w >= 2; --w) {
-            const size_t bytes = (size_t)5 * nw_al * 4 + (size_t)w * (nw_al + 256 + kMwAssumed + 2) * 4 + (8 + 6 * kMwMaxWaves) * 4 + ((groups_cap + 15) & ~15) + 16 +
+            const size_t bytes = (size_t)5 * nw_al * 4 + (size_t)w * (nw_al + 256 + kMwAssumed + 2) * 4 + (8 + 8 * kMwMaxWaves) * 4 + ((groups_cap + 15) & ~15) + 16 +
                                  (size_t)(w - 1) * 2 * kMwEntries * sizeof(MwEntry);
-            if (bytes <= 160 * 1024) { L.waves = w; L.ring = 256; L.nw_al = nw_al; L.n_groups_cap = groups_cap; L.lookahead = 2 * (w - 1); mw_bytes = bytes; break; }
+            if (bytes <= 160 * 1024) { L.waves = w; L.ring = 256; L.nw_al = nw_al; L.n_groups_cap = groups_cap; L.lookahead = 2 * (w - 1); L.policy = mw_policy; mw_bytes = bytes; break; }
         }
     }
     if (skip_after < 0 || n_launch++ < skip_after) {

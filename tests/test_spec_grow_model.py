@@ -6,9 +6,9 @@ refinement) is committed at its turn AND every pixel it assumed used (because so
 Why that rule is exact: C only grows, and a helper that read C(x) = 0 where the sequential algorithm would see USED(x) = 1 differs from it only
 if it then ACCEPTS x (a pixel that is tested and rejected leaves no trace) -- so "no accepted pixel is committed at my turn" is precisely the
 condition under which the sequential algorithm grows the same region from the same seed; and a helper that skipped x as used is right iff
-x is used at its turn.  What a helper does about other waves' claims (a finished region that waits for its turn: assumed used; a region
-still growing from an EARLIER seed or by the main wave: the helper gives up when it is about to accept such a pixel; a region growing from a
-LATER seed: overridden) only changes how much speculation is wasted: the two checks above alone decide what is committed.
+x is used at its turn.  What a helper does about other waves' claims (a region growing from an EARLIER seed or by the main wave: the helper
+gives up when it is about to accept such a pixel; from a LATER seed: overridden; a finished region that waits for its turn: judged the same
+way (policy 0) or assumed used (policy 1)) only changes how much speculation is wasted: the two checks above alone decide what is committed.
 
 The model runs the protocol on toy images with a toy order-dependent region_grow (running mean angle, refinement that un-marks and regrows with
 a tighter tolerance, radius reduction) under random interleavings of the waves, and requires the sequence of committed regions and the final
@@ -100,7 +100,7 @@ def sequential(img, order):
     return out, used
 
 
-def concurrent(img, order, n_helpers, rng):
+def concurrent(img, order, n_helpers, rng, policy=0):
     C, T = set(), {}                     # T: pixel -> helper that marked it last (the tentative-owner nibbles of the device)
     cur_pos = [0] * n_helpers            # seed position of each helper's latest attempt
     n_groups = (len(order) + GROUP - 1) // GROUP
@@ -160,14 +160,16 @@ def concurrent(img, order, n_helpers, rng):
                     if q in C or q in own:
                         return True
                     o = T.get(q)
-                    if o is not None and o[1] == "pending":         # a FINISHED region that waits for its turn: assumed used, checked at this seed's turn
+                    if policy == 1 and o is not None and o[1] == "pending":     # a FINISHED region that waits for its turn: assumed used, checked at this seed's turn
                         assumed.append(q)
                         return True
                     return False
 
-                def poison(q, my_pos=my_pos):                       # about to accept q: yield to a region still growing from an earlier seed (main's always is)
+                def poison(q, my_pos=my_pos):       # about to accept q: yield to the claim of a region growing from an earlier seed (main's always is)
                     o = T.get(q)
-                    return o is not None and o[1] == "growing" and o[0] != hid and (o[0] == "main" or cur_pos[o[0]] < my_pos)
+                    if o is None or o == (hid, "growing") or (policy == 1 and o[1] == "pending"):
+                        return False
+                    return o[0] == "main" or (o[0] != hid and cur_pos[o[0]] < my_pos)       # policy 0: a finished region's claim is judged like a growing one's
                 try:
                     if len(marked) > 10_000:
                         raise Abort()
@@ -259,8 +261,9 @@ def test_speculative_protocol_equals_the_sequential_scan(seed):
     want, want_used = sequential(img, order)
     assert len(want) > 20
     for n_helpers in (1, 3, 7):
-        rng = random.Random(1000 * seed + n_helpers)
-        got, used, st = concurrent(img, order, n_helpers, rng)
-        assert got == want, (seed, n_helpers)
-        assert used == want_used
+        for policy in (0, 1):      # what the helpers make of a finished region's claim (MwLayout.policy on the device)
+            rng = random.Random(1000 * seed + 10 * n_helpers + policy)
+            got, used, st = concurrent(img, order, n_helpers, rng, policy)
+            assert got == want, (seed, n_helpers, policy)
+            assert used == want_used
     assert st["used_spec"] > 0          # the helpers did contribute
