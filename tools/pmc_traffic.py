@@ -30,6 +30,7 @@ def main():
     ap.add_argument("fetch_db"); ap.add_argument("write_db")
     ap.add_argument("--batch", type=int, default=2048)
     ap.add_argument("--md"); ap.add_argument("--json")
+    ap.add_argument("--source", default=None, help="the committed file this json is a digest of (bench.py quotes it as roofline.traffic_source)")
     a = ap.parse_args()
     f, w = per_kernel(a.fetch_db, "FETCH_SIZE"), per_kernel(a.write_db, "WRITE_SIZE")
     rows = []
@@ -49,7 +50,7 @@ def main():
                               "traffic = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B: FETCH_SIZE on gfx950 counts half of a wide coalesced read "
                               "(guide: MI355X_MICROARCH.md, HBM); gather-heavy kernels may be over-corrected by up to 2x on the read side.\n\n" + text + "\n")
     if a.json:
-        json.dump({"batch": a.batch, "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024", "traffic_bytes_per_launch": {k: tr for k, _, _, _, tr in rows}},
+        json.dump({"batch": a.batch, "source": a.source or a.md, "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024", "traffic_bytes_per_launch": {k: tr for k, _, _, _, tr in rows}},
                   open(a.json, "w"), indent=1)
 
 
