@@ -28,6 +28,10 @@
 #include "sincos_ziv.hpp"
 #include "xcd_map.hpp"
 
+#ifndef PLP_CHAIN_BATCH         // addends per LDS round trip in the rectangle fit's sequential sums (rect_from_ring); 0 / 4 / 8 / 16 measured: profiles/r03_lsd_grow.md
+#define PLP_CHAIN_BATCH 8
+#endif
+
 namespace plp {
 
 __device__ __forceinline__ int reflect101_l(int p, int len) {
@@ -668,7 +672,31 @@ __device__ void rect_from_ring(const GrowCtx& g, int nreg, double reg_angle, dou
             }
             __builtin_amdgcn_wave_barrier();
             const int cnt = min(32, nreg - 32 * c);
-            if (lane < 3) for (int t = 0; t < cnt; ++t) acc += sc[3 * t + lane];
+            if (lane < 3) {   // PLP_CHAIN_BATCH addends are fetched together, then added one after the other: the chain is the additions, not one LDS
+                int t = 0;        // round trip per point (the loop used to be ds_read -> wait -> add per point: ~130 cycles each, a sixth of the kernel)
+#if PLP_CHAIN_BATCH >= 16
+                for (; t + 16 <= cnt; t += 16) {
+                    double v[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) v[u] = sc[3 * (t + u) + lane];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) acc += v[u];
+                }
+#endif
+#if PLP_CHAIN_BATCH >= 8
+                for (; t + 8 <= cnt; t += 8) {
+                    const double v0 = sc[3 * t + lane], v1 = sc[3 * t + 3 + lane], v2 = sc[3 * t + 6 + lane], v3 = sc[3 * t + 9 + lane];
+                    const double v4 = sc[3 * t + 12 + lane], v5 = sc[3 * t + 15 + lane], v6 = sc[3 * t + 18 + lane], v7 = sc[3 * t + 21 + lane];
+                    acc += v0; acc += v1; acc += v2; acc += v3; acc += v4; acc += v5; acc += v6; acc += v7;
+                }
+#elif PLP_CHAIN_BATCH >= 4
+                for (; t + 4 <= cnt; t += 4) {
+                    const double v0 = sc[3 * t + lane], v1 = sc[3 * t + 3 + lane], v2 = sc[3 * t + 6 + lane], v3 = sc[3 * t + 9 + lane];
+                    acc += v0; acc += v1; acc += v2; acc += v3;
+                }
+#endif
+                for (; t < cnt; ++t) acc += sc[3 * t + lane];
+            }
             __builtin_amdgcn_wave_barrier();
         }
         return acc;
@@ -764,9 +792,11 @@ __global__ __launch_bounds__(256, PLP_GROW_MIN_WAVES) void k_lsd_grow(LinePlanes
     const bool prof_on = P.prof != nullptr && b == 0;
     auto tick = [&]() -> long long { return prof_on ? clock64() : 0ll; };
     const long long t_begin = tick();
+    uint32_t mine_next = lane < n_ord ? order[lane] : 0u;
     for (int base = 0; base < n_ord; base += 64) {
         const bool in_range = base + lane < n_ord;
-        const uint32_t mine = in_range ? order[base + lane] : 0u;
+        const uint32_t mine = mine_next;
+        mine_next = base + 64 + lane < n_ord ? order[base + 64 + lane] : 0u;   // the next group's seeds are on their way while this group's regions grow
         // most seeds are already inside an earlier region: test the 64 USED bits in parallel, visit the rest in order
         const bool fresh = in_range && !is_used(g, (int)mine);
         unsigned long long todo = __ballot(fresh);
