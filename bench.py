@@ -282,8 +282,8 @@ def main():
         def host_step(n):
             nonlocal d_frames
             sb = n % 2
-            if stage_free[sb] is not None:
-                sH.wait_event(stage_free[sb])                                # the step that last read this staging buffer has been matched
+            for ev_ in stage_free[sb] or ():
+                sH.wait_event(ev_)                                           # the extractors that last read this staging buffer are through (the matchers never read pixels)
             with torch.cuda.stream(sH):
                 stage[sb].copy_(h_frames, non_blocking=True)                 # H2D of this step's frames
                 ev = torch.cuda.Event(); ev.record(sH)
@@ -307,7 +307,7 @@ def main():
                 for h, t in zip(h_small[buf], small(buf)):
                     h.copy_(t, non_blocking=True)
                 ev_off[buf] = torch.cuda.Event(); ev_off[buf].record(sD)
-            stage_free[sb] = ts.done_match[buf]
+            stage_free[sb] = list(ts.extract_events)
             while pending:                                                   # the previous step's bulk copy, now that this step keeps the GPU busy
                 finish_download(pending.pop(0))
             pending.append(buf)

@@ -76,6 +76,7 @@ class tracker_step:
         self.pq = self.replay.point_queries(plp, B, cap, dev)
         self.lq = None if orb_only else self.replay.line_queries(plp, B, lcap, dev, landmarks=True)
         self.done_match = [None] * NBUF
+        self.extract_events = []
         self.step_no = 0
         self.sA.wait_stream(self.cur)
         for s in self.sBs:
@@ -132,6 +133,7 @@ class tracker_step:
                 if "lines" in parts:
                     lti.extract_batch(d_frames[sl], self.kl2[buf][HALO:][sl], self.lbd2[buf][HALO:][sl], self.fn2[buf][sl], self.lcnt2[buf][HALO:][sl], stream=sbi)
                 ev = torch.cuda.Event(); ev.record(sbi); line_ready.append(ev)
+        self.extract_events = [ready] + line_ready      # once these have passed, d_frames has been read (the matchers never look at pixels)
         if "match" not in parts:
             return buf
         sC.wait_event(ready)
