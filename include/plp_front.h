@@ -204,7 +204,8 @@ plp_status plp_line_set_grow_waves(plp_line* ctx, int32_t waves);
  *   SOBEL_DX / SOBEL_DY  int16 rows x cols */
 typedef enum plp_line_debug_id { PLP_LINE_DBG_SCALED = 0, PLP_LINE_DBG_ORDER = 1, PLP_LINE_DBG_RAW = 2, PLP_LINE_DBG_ALL_KL = 3,
                                  PLP_LINE_DBG_ALL_LBD = 4, PLP_LINE_DBG_SOBEL_DX = 5, PLP_LINE_DBG_SOBEL_DY = 6,
-                                 PLP_LINE_DBG_GROW_STATS = 7 /* int32[4]: regions grown, pixels accepted, exact (in-band) decisions, 0 */ } plp_line_debug_id;
+                                 PLP_LINE_DBG_GROW_STATS = 7 /* int32[4]; one wave per frame: regions grown, pixels accepted, exact (in-band) decisions, 0;
+                                    several waves per frame: regions the main wave grew itself, helper results taken, rejected, number of waves */ } plp_line_debug_id;
 plp_status plp_line_debug_read(plp_line* ctx, plp_line_debug_id what, int32_t frame, void* dst, size_t dst_bytes, int64_t* n_out);
 /* Host model of the bin ranking of match::angle_checker (the reference sorts its 30 histogram bins by size with std::sort,
  * src/PLPSLAM/match/angle_checker.h:165-176; the kernels reproduce libstdc++'s algorithm so that ties fall as in a reference built with
