@@ -191,7 +191,7 @@ plp_status plp_line_get_stage_times(plp_line* ctx, double* ms9, int64_t* n_batch
 /* Tuning / parity tests: waves that share one frame in LSD region growing.  0 (default) = automatic: a workgroup of up to 8 waves per
  * frame (one sequential main wave, helpers that grow regions of later seeds speculatively and hand them over, k_lsd_grow_mw) for batches
  * of at most 256 frames -- the single-frame call of data/frame.cc:1146-1163 --, one wave per frame for larger batches; 1 = always one wave
- * per frame; 2..8 = that many waves for every batch of at most 512 frames.  The results are identical whichever is used. */
+ * per frame; 2..8 = that many waves for every batch of at most 256 frames.  The results are identical whichever is used. */
 plp_status plp_line_set_grow_waves(plp_line* ctx, int32_t waves);
 
 /* Stage read-back for parity tests (synchronous, host destination, frame of the last call):

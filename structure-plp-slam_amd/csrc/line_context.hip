@@ -139,7 +139,7 @@ plp_status ensure(plp_line* c, int B) {
     // region lists: two per frame (several waves per frame, k_lsd_grow_mw, write the refinement's regrowth behind the first growth), and
     // the helper waves' lists for as many frames as that path is used for (small batches: kLsdMwMaxFrames)
     P.reg_frame_stride = 2 * n;
-    P.mw_heap_frame_stride = (size_t)(kMwMaxWaves - 1) * 2 * kMwHeap;
+    P.mw_heap_frame_stride = (size_t)(kMwMaxWaves - 1) * kMwHeapBufs * kMwHeap;
     PLP_HIP(c->order.reserve(nv * 4 * B)); PLP_HIP(c->reg.reserve(P.reg_frame_stride * 4 * B));
     PLP_HIP(c->mw_heap.reserve(P.mw_heap_frame_stride * 4 * (size_t)std::min(B, kLsdMwMaxFrames)));
     P.mw_heap = (uint32_t*)c->mw_heap.p;

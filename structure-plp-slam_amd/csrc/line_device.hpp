@@ -8,8 +8,9 @@
 namespace plp {
 
 constexpr int kMwHeap = 16384;       // k_lsd_grow_mw: list entries per helper wave and group buffer
+constexpr int kMwHeapBufs = 8;       // k_lsd_grow_mw: group buffers per helper wave
 constexpr int kMwMaxWaves = 8;       // k_lsd_grow_mw: waves per frame (one main + helpers)
-constexpr int kLsdMwMaxFrames = 512; // batches up to this many frames get the buffers of the several-waves-per-frame path
+constexpr int kLsdMwMaxFrames = 256; // batches up to this many frames get the buffers of the several-waves-per-frame path
 constexpr int kLineCap = 2048;        // raw LSD segments / key lines kept per frame (a 640x480 frame yields ~400)
 constexpr double kLsdNotDef = -1024.0;
 // k_lsd_order packs a seed as (pixel | bin << kLsdSeedPixBits): 10 bits of bin above kLsdSeedPixBits bits of pixel index.  The
@@ -47,7 +48,7 @@ struct LinePlanes {
     int32_t* n_order;         // number of seeds                      [B]
     uint32_t* reg; size_t reg_frame_stride;   // region point list scratch [B][reg_frame_stride]: sh*sw entries (the seed sort's scratch as well), 2*sh*sw when
                               // several waves share a frame (the refinement's second list then follows the first instead of replacing it)
-    uint32_t* mw_heap; size_t mw_heap_frame_stride;   // lists of the speculating waves (k_lsd_grow_mw)  [B][helpers][2][kMwHeap]
+    uint32_t* mw_heap; size_t mw_heap_frame_stride;   // lists of the speculating waves (k_lsd_grow_mw)  [B][helpers][kMwHeapBufs][kMwHeap]
     float4* raw; int32_t* n_raw;          // LSD segments             [B][kLineCap], [B]
     short2* dxy;              // Sobel 3x3, (dx, dy) per pixel, in tiles of 8 x 4 pixels = one 128-byte line (dxy_index)  [B][dxy_frame_entries(W, H)]
     plp_keyline* all_kl; uint8_t* all_lbd; int32_t* n_all;   // before the length filter  [B][kLineCap]

@@ -942,13 +942,25 @@ __global__ __launch_bounds__(256, PLP_GROW_MIN_WAVES) void k_lsd_grow(LinePlanes
 // region is final (a refinement un-marks and regrows), C is monotone.  Whatever the helpers decide among themselves (whose claim to
 // respect) only changes how much speculation is wasted.  Model with random interleavings: tests/test_spec_grow_model.py.  Results equal
 // k_lsd_grow's bit for bit (tests/test_gpu_line.py runs both).
-// kMwHeap (line_device.hpp): list entries per helper and group buffer (both lists + the assumed pixels of all its regions of one group)
-constexpr int kMwEntries = 16;       // results per helper and group buffer
-constexpr int kMwInline = 12;        // list entries of a small region kept in the LDS entry itself (main then never touches HBM for it)
+// kMwHeap (line_device.hpp): list entries per helper and group buffer (both lists + the assumed pixels of all its regions of one group); kMwBufs buffers per helper
+#ifndef PLP_MW_GROUP      // tuning knobs of the several-waves path (tools/build_variant.sh; measured: profiles/r03_lsd_grow.md)
+#define PLP_MW_GROUP 64
+#endif
+#ifndef PLP_MW_BUFS
+#define PLP_MW_BUFS 2
+#endif
+#ifndef PLP_MW_ENTRIES
+#define PLP_MW_ENTRIES 16
+#endif
+constexpr int kMwGroup = PLP_MW_GROUP;   // seeds per ownership unit (a helper claims a group, main walks them in order; its own loads are 64 seeds)
+static_assert(PLP_MW_BUFS <= kMwHeapBufs && 64 % PLP_MW_GROUP == 0 && PLP_MW_ENTRIES <= 64, "line_device.hpp");
+constexpr int kMwBufs = PLP_MW_BUFS;         // group buffers per helper: groups it may have finished before main has walked through them
+constexpr int kMwEntries = PLP_MW_ENTRIES;      // results per group buffer (a group of 16 seeds yields 0.4 regions on average; beyond 4 the rest of the group is main's)
+constexpr int kMwInline = 8;         // list entries of a small region kept in the LDS entry itself (main then never touches HBM for it)
 constexpr int kMwAssumed = 192;      // assumed-used pixels per attempt (a pixel is listed once per time it is looked at: up to 8 times)
 struct MwResult { int n1, n2, nfinal, na; bool second, keep; float4 line; };
 struct alignas(16) MwEntry { int pos, n1, n2, nfinal; uint32_t flags, off; int na; uint32_t pad1; float4 line; uint32_t inl[kMwInline]; };   // flags: 1 keep, 2 final list = second
-static_assert(sizeof(MwEntry) == 96, "MwEntry layout");
+static_assert(sizeof(MwEntry) == 80, "MwEntry layout");
 struct MwLayout { int waves, ring, nw_al, n_groups_cap, lookahead, policy; };   // LDS (words): C | T (4 bits per pixel) | waves x (O | ring | assumed) | control | owner bytes | entries
 
 // control words are read by all lanes from one address: the value is wave-uniform, and said so (readfirstlane) -- the hand-scheduled
@@ -1103,23 +1115,24 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
     int* ctrl = reinterpret_cast<int*>(T + 4 * L.nw_al + (size_t)W * (L.nw_al + L.ring + kMwAssumed + 2));
     // control words: 0 next_group, 1 main_group, 2 done, 3 abort (watchdog), then per-wave arrays
     int* next_group = ctrl; int* main_group = ctrl + 1; int* done = ctrl + 2; int* wd_abort = ctrl + 3;
-    int* hstate = ctrl + 4; int* buf_group = hstate + kMwMaxWaves; int* buf_n = buf_group + 2 * kMwMaxWaves;
-    int* hcount = buf_n + 2 * kMwMaxWaves;                                                          // diagnostics: helper attempts, give-ups
+    int* hstate = ctrl + 4; int* buf_group = hstate + kMwMaxWaves; int* buf_n = buf_group + kMwBufs * kMwMaxWaves;
+    int* hcount = buf_n + kMwBufs * kMwMaxWaves;                                                       // diagnostics: helper attempts, give-ups
     int* cur_pos = hcount + 4;                                                                      // [helpers]: seed position of each helper's latest attempt
     int* pend_lo = cur_pos + kMwMaxWaves; int* pend_hi = pend_lo + kMwMaxWaves;                      // [helpers]: lowest / highest seed position among its finished, waiting regions
-    uint8_t* owner = reinterpret_cast<uint8_t*>(pend_hi + kMwMaxWaves);                          // [n_groups_cap]: 0 unpublished, 1 main, 2 + (h * 2 + k)
-    MwEntry* entries = reinterpret_cast<MwEntry*>((reinterpret_cast<uintptr_t>(owner + ((L.n_groups_cap + 15) & ~15)) + 15) & ~(uintptr_t)15);   // [helpers][2][kMwEntries]
+    uint8_t* owner = reinterpret_cast<uint8_t*>(pend_hi + kMwMaxWaves);                          // [n_groups_cap]: 0 unpublished, 1 main, 2 + (h * kMwBufs + k)
+    MwEntry* entries = reinterpret_cast<MwEntry*>((reinterpret_cast<uintptr_t>(owner + ((L.n_groups_cap + 15) & ~15)) + 15) & ~(uintptr_t)15);   // [helpers][kMwBufs][kMwEntries]
     const int n_ord = P.n_order[b];
-    const int n_groups = (n_ord + 63) / 64;
+    const int n_groups = (n_ord + kMwGroup - 1) / kMwGroup;   // ownership units: kMwGroup consecutive seeds
     {   // C = NOTDEF mask (an undefined pixel is never a seed and never aligned), no pixel held by anybody
         const uint32_t* u32 = reinterpret_cast<const uint32_t*>(P.undef + (size_t)b * ((n + 63) / 64));
         for (int i = threadIdx.x; i < nwords; i += blockDim.x) C[i] = u32[i];
         for (int i = threadIdx.x; i < 4 * L.nw_al; i += blockDim.x) T[i] = 0;
         for (int i = lane; i < L.nw_al; i += 64) O[i] = 0;
         for (int i = threadIdx.x; i < L.n_groups_cap; i += blockDim.x) owner[i] = 0;
-        if (threadIdx.x < 8 + 8 * kMwMaxWaves) {   // buf_group = -1 (free); no finished region waits: lowest = "infinity", highest = -1
-            const int i = threadIdx.x;
-            ctrl[i] = (i >= 4 + kMwMaxWaves && i < 4 + 3 * kMwMaxWaves) ? -1 : (i >= 8 + 6 * kMwMaxWaves && i < 8 + 7 * kMwMaxWaves) ? 0x7fffffff : (i >= 8 + 7 * kMwMaxWaves) ? -1 : 0;
+        constexpr int kCtrl = 8 + (4 + 2 * kMwBufs) * kMwMaxWaves;
+        for (int i = threadIdx.x; i < kCtrl; i += blockDim.x) {   // buf_group = -1 (free); no finished region waits: lowest = "infinity", highest = -1
+            const int* pi = ctrl + i;
+            ctrl[i] = (pi >= buf_group && pi < buf_n) ? -1 : (pi >= pend_lo && pi < pend_hi) ? 0x7fffffff : (pi >= pend_hi) ? -1 : 0;
         }
     }
     __syncthreads();
@@ -1130,7 +1143,7 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
     g.sw = P.sw; g.sh = P.sh; g.lane = lane; g.comm = C; g.tent = T;
     g.tent_pos = cur_pos; g.tent_id = is_main ? kMwMainId : wv; g.my_pos = 0; g.policy = L.policy;
     g.assumed = my_ring + L.ring; g.assumed_cap = kMwAssumed;
-    uint32_t* const my_heap = is_main ? P.reg + (size_t)b * P.reg_frame_stride : P.mw_heap + (size_t)b * P.mw_heap_frame_stride + (size_t)h * 2 * kMwHeap;
+    uint32_t* const my_heap = is_main ? P.reg + (size_t)b * P.reg_frame_stride : P.mw_heap + (size_t)b * P.mw_heap_frame_stride + (size_t)h * kMwBufs * kMwHeap;
     g.reg = my_heap; g.reg_cap = is_main ? 2 * n : kMwHeap;
     const uint32_t* order = P.order + (size_t)b * nv;
     float4* raw = P.raw + (size_t)b * kLineCap;
@@ -1143,33 +1156,25 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
         if ((long long)clock64() - wd_t0 > 400000000ll) { lds_st(wd_abort, 1); if (lane == 0) atomicOr(P.status, 16); }
         return lds_ld(wd_abort) == 0;
     };
-    // state of the group this wave works on
-    int grp = -1, own = 0, kbuf = 0, hoff = 0, nent = 0, n_lines = 0;
+    // state of the group this wave works on (main: `mine` holds 64 seeds = four groups, `sub` is the one it is in; helpers: lanes 0..kMwGroup-1)
+    constexpr int kSubs = 64 / kMwGroup;
+    constexpr unsigned long long kGroupMask = kMwGroup == 64 ? ~0ull : ((1ull << kMwGroup) - 1ull);
+    int grp = -1, own = 0, kbuf = 0, hoff = 0, nent = 0, n_lines = 0, ld = -1, sub = kSubs - 1;
     int n_self = 0, n_spec_ok = 0, n_spec_bad = 0;           // main: regions it grew itself, results it took / had to reject
     long long c_wait = 0, c_self = 0, c_commit = 0, c_pub = 0, c_grp = 0;   // main: cycles waiting for helpers / growing regions itself / taking results / publishing its own / group set-up
     const long long c_begin = (long long)clock64();
     uint32_t mine = 0, mine_next = 0; float s_deg = 0.f; float2 s_cs = make_float2(0.f, 0.f);
-    unsigned long long todo = 0;
+    unsigned long long todo = 0;      // helpers: the group's seeds still to look at; main: those of its 64-seed load
+    unsigned long long bits = 0;      // main: those of the current group
     bool have_cs = false;
-    auto load_group = [&](int gi, bool with_angles, bool prefetched) {   // seeds of group gi and (with_angles) the angle records of those not yet committed, 64 at once
-        const bool in_range = gi * 64 + lane < n_ord;
-        mine = prefetched ? mine_next : (in_range ? order[gi * 64 + lane] : 0u);
-        const bool fresh = in_range && !committed((int)mine);
-        todo = __ballot(fresh);
-        have_cs = with_angles;
-        if (with_angles) {
-            s_deg = fresh ? g.pix[mine].deg : 0.f;
-            if (fresh) { double sn, cs; sincos((double)s_deg * (3.14159265358979323846 / 180), &sn, &cs); s_cs = make_float2((float)cs, (float)sn); }
-        }
-    };
     // main's view of the helper that owns the current group: progress inside the group, entries announced and their headers (lane i: entry i)
     int prog = 0, ne = 0, pos_vec = -1, hv_n1 = 0, hv_n2 = 0, hv_nf = 0, hv_na = 0, hv_fl = 0, hv_off = 0;
     const MwEntry* eb = entries;
-    auto refresh = [&](int hh, int kk) {
+    auto refresh = [&](int hh, int hk) {   // hk = helper * kMwBufs + buffer
         const int st = lds_ld(&hstate[hh]);
-        prog = (st >> 8) > grp ? 64 : ((st >> 8) == grp ? (st & 255) : 0);
-        ne = lds_ld(&buf_n[hh * 2 + kk]);
-        eb = entries + (size_t)(hh * 2 + kk) * kMwEntries;
+        prog = (st >> 8) > grp ? kMwGroup : ((st >> 8) == grp ? (st & 255) : 0);
+        ne = lds_ld(&buf_n[hk]);
+        eb = entries + (size_t)hk * kMwEntries;
         const MwEntry* e = eb + min(lane, kMwEntries - 1);
         pos_vec = lane < ne ? e->pos : -1;
         hv_n1 = e->n1; hv_n2 = e->n2; hv_nf = e->nfinal; hv_na = e->na; hv_fl = (int)e->flags; hv_off = (int)e->off;   // one round trip for all of them
@@ -1181,45 +1186,55 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
         if (is_main) {
             for (;;) {
                 if (lds_ld(wd_abort)) break;
-                if (!todo) {
-                    if (++grp >= n_groups) break;
+                if (!bits) {   // on to the next group that still has a seed to look at
+                    if (++sub >= kSubs) {
+                        if (++ld * 64 >= n_ord) break;
+                        mine = mine_next;
+                        mine_next = (ld + 1) * 64 + lane < n_ord ? order[(ld + 1) * 64 + lane] : 0u;   // the next load's seeds are on their way while this one is dealt with
+                        todo = __ballot(ld * 64 + lane < n_ord && !committed((int)mine));
+                        sub = 0;
+                    }
+                    bits = (todo >> (kMwGroup * sub)) & kGroupMask;
+                    if (!bits) continue;
                     const long long cg0 = (long long)clock64();
+                    grp = ld * kSubs + sub;
                     lds_st(main_group, grp);
-                    // whose group is it?  unclaimed (next_group == grp): take it; else wait until its helper has said so
+                    // whose group is it?  unclaimed (nobody's fetch-and-add has reached it): take it (and every skipped one before it); else wait
+                    // until its helper has said so
                     own = 0;
                     while (!own) {
                         own = __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&owner[grp], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
                         if (own) break;
-                        int expect = grp;
-                        if (lds_ld(next_group) == grp) {
+                        int nu = lds_ld(next_group);
+                        if (nu <= grp) {
                             int okc = 0;
-                            if (lane == 0) okc = __hip_atomic_compare_exchange_strong(next_group, &expect, grp + 1, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1 : 0;
+                            if (lane == 0) okc = __hip_atomic_compare_exchange_strong(next_group, &nu, grp + 1, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1 : 0;
                             if (__builtin_amdgcn_readfirstlane(okc)) {
                                 if (lane == 0) __hip_atomic_store(&owner[grp], (uint8_t)1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                                 own = 1; break;
                             }
+                            continue;
                         }
                         if (!spin()) break;
                     }
                     if (!own) break;
                     wd_t0 = 0;
-                    load_group(grp, own == 1, true);   // a helper's group: main grows few of its seeds itself, their angles are fetched when that happens
-                    mine_next = (grp + 1) * 64 + lane < n_ord ? order[(grp + 1) * 64 + lane] : 0u;   // the next group's seeds are on their way while this one is dealt with
-                    if (own > 1) refresh((own - 2) >> 1, (own - 2) & 1);
+                    have_cs = false;   // main grows few seeds itself: their angles are fetched when that happens
+                    if (own > 1) refresh((own - 2) / kMwBufs, own - 2);
                     c_grp += (long long)clock64() - cg0;
                     continue;
                 }
-                const int tt = __ffsll((long long)todo) - 1;
-                todo &= todo - 1;
-                const int seed = bcast_i((int)mine, tt);
+                const int tt = __ffsll((long long)bits) - 1;
+                bits &= bits - 1;
+                const int seed = bcast_i((int)mine, kMwGroup * sub + tt);
                 if (committed(seed)) continue;
                 if (own > 1) {
-                    const int hh = (own - 2) >> 1, kk = (own - 2) & 1;
+                    const int hk = own - 2, hh = hk / kMwBufs;
                     if (prog <= tt) {   // until the helper has dealt with position tt
                         bool alive = true;
                         const long long cw0 = (long long)clock64();
                         for (;;) {
-                            refresh(hh, kk);
+                            refresh(hh, hk);
                             if (prog > tt) break;
                             if (!(alive = spin())) break;
                         }
@@ -1242,7 +1257,7 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
                             if (!__ballot(bad)) { if (lane >= fb && lane < fb + nf) atomicOr(&C[p >> 5], 1u << (p & 31)); }
                             else bad = true;
                         } else {
-                            const uint32_t* hl = P.mw_heap + (size_t)b * P.mw_heap_frame_stride + (size_t)(hh * 2 + kk) * kMwHeap + bcast_i(hv_off, ei);
+                            const uint32_t* hl = P.mw_heap + (size_t)b * P.mw_heap_frame_stride + (size_t)hk * kMwHeap + bcast_i(hv_off, ei);
                             for (int j0 = 0; j0 < tot; j0 += 64) {
                                 const int j = j0 + lane;
                                 if (j < tot) bad |= committed(pix_of(heap_ld(hl + j), g.sw)) != (j >= acc_n);
@@ -1262,7 +1277,10 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
                             }
                             __builtin_amdgcn_wave_barrier();
                             ++n_spec_ok;
-                            if (nf > 1) todo &= __ballot(!committed((int)mine));   // the seeds this region covers leave the list together
+                            if (nf > 1) {   // the seeds this region covers leave the list together
+                                todo &= __ballot(!committed((int)mine));
+                                bits &= (todo >> (kMwGroup * sub)) & kGroupMask;
+                            }
                             c_commit += (long long)clock64() - cc0;
                             continue;
                         }
@@ -1270,7 +1288,7 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
                         c_commit += (long long)clock64() - cc0;
                     }
                 }
-                t = tt;
+                t = kMwGroup * sub + tt;
                 break;
             }
         } else {
@@ -1284,47 +1302,56 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
                     // a LATER seed's claim does not count
                     const int ow = __builtin_amdgcn_readfirstlane(tent_owner(g, seed));
                     const int owh = ow > kMwPending ? ow - kMwPending : ow;   // the helper behind the claim (8 for main: never read)
-                    if (committed(seed) || (ow != 0 && (ow == kMwMainId || owh == wv || lds_ld(&cur_pos[owh - 1]) < grp * 64 + tt))) { lds_st(&hstate[h], (grp << 8) | (tt + 1)); continue; }
+                    if (committed(seed) || (ow != 0 && (ow == kMwMainId || owh == wv || lds_ld(&cur_pos[owh - 1]) < grp * kMwGroup + tt))) {
+                        lds_st(&hstate[h], (grp << 8) | (tt + 1));
+                        continue;
+                    }
                     if (nent >= kMwEntries || kMwHeap - hoff < 512 + kMwAssumed) { todo = 0; continue; }   // out of room: main does the rest of the group
                     t = tt;
                     break;
                 }
                 if (grp >= 0) {   // group finished
-                    lds_st(&hstate[h], (grp << 8) | 64);
+                    lds_st(&hstate[h], (grp << 8) | kMwGroup);
                     grp = -1;
                 }
                 // recycle: a buffer whose group main has left gives its claims back
                 const int mg = lds_ld(main_group);
-                int free_k = -1;
-                for (int k = 0; k < 2; ++k) {
-                    const int bg = lds_ld(&buf_group[h * 2 + k]);
+                int free_k = -1, lo = 0x7fffffff;
+                for (int k = 0; k < kMwBufs; ++k) {
+                    const int bg = lds_ld(&buf_group[h * kMwBufs + k]);
                     if (bg >= 0 && bg < mg) {
-                        const int nek = lds_ld(&buf_n[h * 2 + k]);
-                        const MwEntry* ek = entries + (size_t)(h * 2 + k) * kMwEntries;
+                        const int nek = lds_ld(&buf_n[h * kMwBufs + k]);
+                        const MwEntry* ek = entries + (size_t)(h * kMwBufs + k) * kMwEntries;
                         for (int i = 0; i < nek; ++i) mw_release(g, my_heap + (size_t)k * kMwHeap + ek[i].off, ek[i].n1 + ek[i].n2, wv + kMwPending);
                         __builtin_amdgcn_wave_barrier();
-                        lds_st(&buf_n[h * 2 + k], 0);
-                        lds_st(&buf_group[h * 2 + k], -1);
+                        lds_st(&buf_n[h * kMwBufs + k], 0);
+                        lds_st(&buf_group[h * kMwBufs + k], -1);
                         free_k = k;
-                        // what still waits is in the other buffer (entries in increasing position), or nothing
-                        const int og = lds_ld(&buf_group[h * 2 + (k ^ 1)]), on = lds_ld(&buf_n[h * 2 + (k ^ 1)]);
-                        if (og >= 0 && on > 0) lds_st(&pend_lo[h], og * 64 + entries[(size_t)(h * 2 + (k ^ 1)) * kMwEntries].pos);
-                        else { lds_st(&pend_lo[h], 0x7fffffff); lds_st(&pend_hi[h], -1); }
                     } else if (bg < 0) free_k = k;
+                    else if (lds_ld(&buf_n[h * kMwBufs + k]) > 0) lo = min(lo, bg * kMwGroup + entries[(size_t)(h * kMwBufs + k) * kMwEntries].pos);
                 }
+                if (lo != lds_ld(&pend_lo[h])) { lds_st(&pend_lo[h], lo); if (lo == 0x7fffffff) lds_st(&pend_hi[h], -1); }   // what still waits for its turn
                 const int ng = lds_ld(next_group);
                 if (ng >= n_groups) { if (!spin()) break; wd_t0 = 0; continue; }          // nothing left to claim: wait for `done`
                 if (free_k < 0 || ng >= mg + L.lookahead) { if (!spin()) break; wd_t0 = 0; continue; }
                 int gi = 0;
                 if (lane == 0) gi = __hip_atomic_fetch_add(next_group, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
                 gi = __builtin_amdgcn_readfirstlane(gi);
-                if (gi >= n_groups) continue;
+                if (gi >= n_groups || gi < lds_ld(main_group)) continue;   // past the end, or main has gone past it already (it skips groups without an open seed)
                 grp = gi; kbuf = free_k; nent = 0; hoff = 0;
                 lds_st(&hstate[h], grp << 8);
-                lds_st(&buf_n[h * 2 + kbuf], 0);
-                lds_st(&buf_group[h * 2 + kbuf], grp);
-                if (lane == 0) __hip_atomic_store(&owner[grp], (uint8_t)(2 + h * 2 + kbuf), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                load_group(grp, true, false);
+                lds_st(&buf_n[h * kMwBufs + kbuf], 0);
+                lds_st(&buf_group[h * kMwBufs + kbuf], grp);
+                if (lane == 0) __hip_atomic_store(&owner[grp], (uint8_t)(2 + h * kMwBufs + kbuf), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                {   // the group's seeds and the angle records of those not yet committed, all at once
+                    const bool in_range = lane < kMwGroup && grp * kMwGroup + lane < n_ord;
+                    mine = in_range ? order[grp * kMwGroup + lane] : 0u;
+                    const bool fresh = in_range && !committed((int)mine);
+                    todo = __ballot(fresh);
+                    have_cs = true;
+                    s_deg = fresh ? g.pix[mine].deg : 0.f;
+                    if (fresh) { double sn, cs; sincos((double)s_deg * (3.14159265358979323846 / 180), &sn, &cs); s_cs = make_float2((float)cs, (float)sn); }
+                }
             }
         }
         t = __builtin_amdgcn_readfirstlane(t);
@@ -1333,7 +1360,7 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
         const int seed = bcast_i((int)mine, t);
         if (!is_main) {
             g.reg = my_heap + (size_t)kbuf * kMwHeap + hoff; g.reg_cap = kMwHeap - hoff - kMwAssumed;
-            g.my_pos = grp * 64 + t;
+            g.my_pos = grp * kMwGroup + t;
             lds_st(&cur_pos[h], g.my_pos);
         }
         MwResult r;
@@ -1357,6 +1384,7 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
             for (int j = lane; j < r.nfinal; j += 64) { const int p = pix_of(heap_ld(g.reg + fb + j), g.sw); atomicOr(&C[p >> 5], 1u << (p & 31)); }
             mw_forget(g, g.reg, acc_n, kMwMainId);
             todo &= __ballot(!committed((int)mine));
+            bits &= (todo >> (kMwGroup * sub)) & kGroupMask;
             c_pub += (long long)clock64() - cp0;
             if (r.keep) {
                 if (n_lines < kLineCap) { if (lane == 0) raw[n_lines] = r.line; }
@@ -1371,7 +1399,7 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
                 // attempts of this helper treat them like anybody else's finished region (assumed used, and checked at their turn)
                 for (int j = lane; j < r.nfinal; j += 64) tent_retag(g, pix_of(heap_ld(g.reg + (r.second ? r.n1 : 0) + j), g.sw), wv, wv + kMwPending);
                 for (int j = lane; j < r.na; j += 64) __hip_atomic_store(g.reg + acc_n + j, g.assumed[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the assumed-used pixels follow the two lists
-                MwEntry* e = entries + (size_t)(h * 2 + kbuf) * kMwEntries + nent;
+                MwEntry* e = entries + (size_t)(h * kMwBufs + kbuf) * kMwEntries + nent;
                 if (lane == 0) {
                     e->pos = t; e->n1 = r.n1; e->n2 = r.n2; e->nfinal = r.nfinal; e->flags = (r.keep ? 1u : 0u) | (r.second ? 2u : 0u); e->off = (uint32_t)hoff;
                     e->na = r.na; e->line = r.line;
@@ -1385,14 +1413,14 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
                 ++nent; hoff += (tot + 1) & ~1;
                 if (lds_ld(&pend_hi[h]) < 0) lds_st(&pend_lo[h], g.my_pos);
                 lds_st(&pend_hi[h], g.my_pos);
-                lds_st(&buf_n[h * 2 + kbuf], nent);
+                lds_st(&buf_n[h * kMwBufs + kbuf], nent);
                 mw_forget(g, g.reg, acc_n, 0);
             } else mw_forget(g, g.reg, acc_n, wv);
             __builtin_amdgcn_wave_barrier();
             {   // the seeds of this group that the new region (or anybody's) covers or claims leave the list together (same rule as one by one above)
                 const int p = (int)mine;
                 const int ow = tent_owner(g, p), owh = ow > kMwPending ? ow - kMwPending : ow;
-                const bool skip = committed(p) || (ow != 0 && (ow == kMwMainId || owh == wv || cur_pos[min(owh, kMwMaxWaves) - 1] < grp * 64 + lane));
+                const bool skip = committed(p) || (ow != 0 && (ow == kMwMainId || owh == wv || cur_pos[min(owh, kMwMaxWaves) - 1] < grp * kMwGroup + lane));
                 todo &= __ballot(!skip);
             }
             lds_st(&hstate[h], (grp << 8) | (t + 1));
@@ -1741,11 +1769,11 @@ void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp,
     size_t mw_bytes = 0;
     const int want_waves = grow_waves > 0 ? std::min(grow_waves, kMwMaxWaves) : mw_waves;          // plp_line_set_grow_waves overrides the automatic choice
     if (B <= (grow_waves > 1 ? kLsdMwMaxFrames : mw_max_b) && want_waves >= 2 && P.mw_heap && P.reg_frame_stride >= 2 * (size_t)n) {
-        const int nw_al = (((n + 31) / 32 + 1) & ~1), groups_cap = ((P.sw - 1) * (P.sh - 1) + 63) / 64 + 1;
+        const int nw_al = (((n + 31) / 32 + 1) & ~1), groups_cap = ((P.sw - 1) * (P.sh - 1) + kMwGroup - 1) / kMwGroup + 64 / kMwGroup;
         for (int w = want_waves; w >= 2; --w) {
-            const size_t bytes = (size_t)5 * nw_al * 4 + (size_t)w * (nw_al + 256 + kMwAssumed + 2) * 4 + (8 + 8 * kMwMaxWaves) * 4 + ((groups_cap + 15) & ~15) + 16 +
-                                 (size_t)(w - 1) * 2 * kMwEntries * sizeof(MwEntry);
-            if (bytes <= 160 * 1024) { L.waves = w; L.ring = 256; L.nw_al = nw_al; L.n_groups_cap = groups_cap; L.lookahead = 2 * (w - 1); L.policy = mw_policy; mw_bytes = bytes; break; }
+            const size_t bytes = (size_t)5 * nw_al * 4 + (size_t)w * (nw_al + 256 + kMwAssumed + 2) * 4 + (8 + (4 + 2 * kMwBufs) * kMwMaxWaves) * 4 + ((groups_cap + 15) & ~15) + 16 +
+                                 (size_t)(w - 1) * kMwBufs * kMwEntries * sizeof(MwEntry);
+            if (bytes <= 160 * 1024) { L.waves = w; L.ring = 256; L.nw_al = nw_al; L.n_groups_cap = groups_cap; L.lookahead = kMwBufs * (w - 1); L.policy = mw_policy; mw_bytes = bytes; break; }
         }
     }
     if (skip_after < 0 || n_launch++ < skip_after) {

@@ -1,5 +1,5 @@
 # GPU session 9 of round 3: helper policy A/B of the several-waves-per-frame region growing
-O=gpurun_out/r03k; mkdir -p $O
+O=gpurun_out/r03q; mkdir -p $O
 for pol in 0; do
 unset PLP_LSD_MW_POLICY
 timeout 200 python -m pytest tests/test_gpu_line.py tests/test_gpu_golden_ref.py -m gpu -x -q 2>&1 | tail -2
