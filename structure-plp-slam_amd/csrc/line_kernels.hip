@@ -955,7 +955,7 @@ __global__ __launch_bounds__(256, PLP_GROW_MIN_WAVES) void k_lsd_grow(LinePlanes
 constexpr int kMwGroup = PLP_MW_GROUP;   // seeds per ownership unit (a helper claims a group, main walks them in order; its own loads are 64 seeds)
 static_assert(PLP_MW_BUFS <= kMwHeapBufs && 64 % PLP_MW_GROUP == 0 && PLP_MW_ENTRIES <= 64, "line_device.hpp");
 constexpr int kMwBufs = PLP_MW_BUFS;         // group buffers per helper: groups it may have finished before main has walked through them
-constexpr int kMwEntries = PLP_MW_ENTRIES;      // results per group buffer (a group of 16 seeds yields 0.4 regions on average; beyond 4 the rest of the group is main's)
+constexpr int kMwEntries = PLP_MW_ENTRIES;      // results per group buffer; beyond them the rest of the group is main's (16 / 32 / 64 seeds x 8 / 4 / 2 buffers x 4 / 8 / 16 entries measured)
 constexpr int kMwInline = 8;         // list entries of a small region kept in the LDS entry itself (main then never touches HBM for it)
 constexpr int kMwAssumed = 192;      // assumed-used pixels per attempt (a pixel is listed once per time it is looked at: up to 8 times)
 struct MwResult { int n1, n2, nfinal, na; bool second, keep; float4 line; };
