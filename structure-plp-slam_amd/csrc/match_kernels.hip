@@ -415,7 +415,15 @@ __global__ __launch_bounds__(256) void k_match_prep(MatchProblem P) {
     for (int i = tid; i <= ncell; i += 256) P.cell_start[(size_t)b * kCellStride + i] = start[min(i, 4096)];
 }
 
-constexpr int kLaneCand = 6;   // candidate positions a lane collects before it fetches their descriptors
+#ifndef PLP_MATCH_LANE_CAND      // 6: most descriptor fetches in flight per lane (97 VGPRs); 3 / 4 with the register cap (72 / 80 VGPRs): two waves per SIMD
+#define PLP_MATCH_LANE_CAND 3    // instead of one beside two region-growing waves (profiles/r03_lsd_grow.md section 3); measured: profiles/r03_scheduling_experiments.md
+#endif
+#if PLP_MATCH_LANE_CAND <= 4
+#define PLP_TOPK_CELLS_BOUNDS __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8)))
+#else
+#define PLP_TOPK_CELLS_BOUNDS __launch_bounds__(256)
+#endif
+constexpr int kLaneCand = PLP_MATCH_LANE_CAND;   // candidate positions a lane collects before it fetches their descriptors
 
 // 16-lane (DPP row) reductions: four queries share a wave
 __device__ __forceinline__ uint32_t row16_min_u32(uint32_t v) {
@@ -441,7 +449,7 @@ __device__ __forceinline__ int row16_sum_i32(int v) {
 // its lanes idle and spent more instructions merging the lanes' lists (8 DPP row minima per query) than finding candidates.
 // Consecutive queries sit on the same pyramid level (key points are stored by level), so the lanes of a wave run similar trip counts.
 // grid = (ceil(m_cap / kQueriesPerBlock), B), block = 256, dynamic LDS = n_cap * 20 + 2 * kCellStride bytes.
-__global__ __launch_bounds__(256) void k_match_topk_cells(MatchProblem P, int qpb) {
+__global__ PLP_TOPK_CELLS_BOUNDS void k_match_topk_cells(MatchProblem P, int qpb) {
     corun_priority();
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     unsigned uqb, ub;
