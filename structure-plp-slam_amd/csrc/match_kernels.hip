@@ -354,10 +354,12 @@ constexpr int kCellStride = 4104;  // cell_start[cols * rows + 1] per frame (<= 
 // grid = (B), block = 256.
 __global__ __launch_bounds__(256) void k_match_prep(MatchProblem P) {
     corun_priority();
-    __shared__ int cnt[4096];
+    // 33 KB of LDS: two of these workgroups fit beside the 85 KB that region growing holds on a CU (with 32-bit cell counters it was 41 KB and
+    // one).  Cell counts (at most 8192 targets per frame) are 16-bit halves of 32-bit words: cell c lives in word c >> 1, half c & 1.
+    __shared__ uint32_t cnt2[2048];
     __shared__ uint16_t start[4098];
     __shared__ uint16_t tmp_t[8192];
-    __shared__ int part[256];
+    __shared__ int part[4];
     const int tid = threadIdx.x, b = blockIdx.x;
     const int n = P.t_counts ? min(P.t_counts[b], P.n_cap) : P.n_cap;
     const int ncell = P.grid_cols * P.grid_rows;
@@ -366,7 +368,8 @@ __global__ __launch_bounds__(256) void k_match_prep(MatchProblem P) {
     const uint8_t* t_occ = P.t_occupied ? P.t_occupied + (size_t)b * P.n_cap : nullptr;
     StagedTarget* st = P.sorted + (size_t)b * P.n_cap;
     float* sxr = P.sorted_xr + (size_t)b * P.n_cap;
-    for (int i = tid; i < 4096; i += 256) cnt[i] = 0;
+    auto cnt_inc = [&](int c) -> int { return (int)((atomicAdd(&cnt2[c >> 1], 1u << (16 * (c & 1))) >> (16 * (c & 1))) & 0xffffu); };   // the count before
+    for (int i = tid; i < 2048; i += 256) cnt2[i] = 0;
     __syncthreads();
     auto cell_of = [&](const plp_keypoint& k, int t, int& cx, int& cy) -> bool {
         cx = floor_d((double)__fsub_rn(k.x, P.grid_min_x) * P.inv_cell_w);
@@ -375,27 +378,33 @@ __global__ __launch_bounds__(256) void k_match_prep(MatchProblem P) {
     };
     for (int t = tid; t < n; t += 256) {   // pass 1: cell sizes
         int cx, cy;
-        if (cell_of(kps[t], t, cx, cy)) atomicAdd(&cnt[cx * P.grid_rows + cy], 1);
+        if (cell_of(kps[t], t, cx, cy)) cnt_inc(cx * P.grid_rows + cy);
     }
     __syncthreads();
-    {   // exclusive scan over the cells: 16 cells per thread + a scan of the 256 partial sums
-        int sum = 0;
-        for (int i = 0; i < 16; ++i) sum += cnt[tid * 16 + i];
-        part[tid] = sum;
+    {   // exclusive scan over the cells: 16 cells per thread, a shuffle scan inside the wave, four wave totals through LDS
+        const int lane = tid & 63, wv = tid >> 6;
+        int c16[16], sum = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const uint32_t w = cnt2[tid * 8 + i]; c16[2 * i] = (int)(w & 0xffffu); c16[2 * i + 1] = (int)(w >> 16); sum += c16[2 * i] + c16[2 * i + 1]; }
+        int inc = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(inc, o); if (lane >= o) inc += up; }
+        if (lane == 63) part[wv] = inc;
         __syncthreads();
-        int base = 0;
-        for (int i = 0; i < tid; ++i) base += part[i];
-        for (int i = 0; i < 16; ++i) { start[tid * 16 + i] = (uint16_t)base; base += cnt[tid * 16 + i]; }
+        int base = inc - sum;
+        for (int k = 0; k < wv; ++k) base += part[k];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { start[tid * 16 + i] = (uint16_t)base; base += c16[i]; }
         if (tid == 255) { start[4096] = (uint16_t)base; start[4097] = (uint16_t)base; }
         __syncthreads();
-        for (int i = tid; i < 4096; i += 256) cnt[i] = 0;
+        for (int i = tid; i < 2048; i += 256) cnt2[i] = 0;
         __syncthreads();
     }
     for (int t = tid; t < n; t += 256) {   // pass 2: unordered placement inside the cell
         int cx, cy;
         if (!cell_of(kps[t], t, cx, cy)) continue;
         const int cell = cx * P.grid_rows + cy;
-        tmp_t[start[cell] + atomicAdd(&cnt[cell], 1)] = (uint16_t)t;
+        tmp_t[start[cell] + cnt_inc(cell)] = (uint16_t)t;
     }
     __syncthreads();
     const int used = start[4096];
