@@ -24,7 +24,7 @@ struct plp_line {
     ResizeExactTab rt{};
     BlurTapsN t11{}, t5{};
     LbdWeightsDev w{};
-    DevBuf tabs, blur11, scaled, pix_cs, pix_deg, g2, maxgrad, undef, order, n_order, reg, mw_heap, raw, n_raw, dx, dy, all_kl, all_lbd, n_all, status, prof, grow_stats;
+    DevBuf tabs, blur11, scaled, pix, g2, maxgrad, undef, order, n_order, reg, mw_heap, raw, n_raw, dx, dy, all_kl, all_lbd, n_all, status, prof, grow_stats;
     DevBuf l0copy, s_kl, s_lbd, s_fn, s_cnt;   // host-API staging
     DevBuf aligned;                             // aligned copy of odd-pitch device frames
     int s_cap = 0;
@@ -134,7 +134,7 @@ plp_status ensure(plp_line* c, int B) {
     const size_t n = (size_t)P.sw * P.sh, nv = (size_t)(P.sw - 1) * (P.sh - 1);
     if (!P.half_exact) PLP_HIP(c->blur11.reserve((size_t)P.pitch * P.H * B));   // only the two-kernel fallback of the LSD front writes the blurred plane
     PLP_HIP(c->scaled.reserve((size_t)P.spitch * P.sh * B));
-    PLP_HIP(c->pix_cs.reserve(n * sizeof(float2) * B)); PLP_HIP(c->pix_deg.reserve(n * sizeof(float) * B));
+    PLP_HIP(c->pix.reserve(n * sizeof(LsdPix) * B));
     PLP_HIP(c->g2.reserve(n * 4 * B)); PLP_HIP(c->n_order.reserve(4 * (size_t)B)); PLP_HIP(c->maxgrad.reserve(4 * ((n + 255) / 256) * (size_t)B)); PLP_HIP(c->undef.reserve((n + 63) / 64 * 8 * B));
     // region lists: two per frame (several waves per frame, k_lsd_grow_mw, write the refinement's regrowth behind the first growth), and
     // the helper waves' lists for as many frames as that path is used for (small batches: kLsdMwMaxFrames)
@@ -148,7 +148,7 @@ plp_status ensure(plp_line* c, int B) {
     PLP_HIP(c->all_kl.reserve(sizeof(plp_keyline) * kLineCap * B)); PLP_HIP(c->all_lbd.reserve((size_t)32 * kLineCap * B));
     PLP_HIP(c->n_all.reserve(4 * (size_t)B)); PLP_HIP(c->status.reserve(16)); PLP_HIP(c->prof.reserve(128)); PLP_HIP(c->grow_stats.reserve(16 * (size_t)B));
     P.blur11 = (uint8_t*)c->blur11.p; P.scaled = (uint8_t*)c->scaled.p;
-    P.pix_cs = (float2*)c->pix_cs.p; P.pix_deg = (float*)c->pix_deg.p; P.g2 = (uint32_t*)c->g2.p; P.n_order = (int32_t*)c->n_order.p;
+    P.pix = (LsdPix*)c->pix.p; P.g2 = (uint32_t*)c->g2.p; P.n_order = (int32_t*)c->n_order.p;
     P.blockmax = (uint32_t*)c->maxgrad.p; P.undef = (unsigned long long*)c->undef.p;
     P.order = (uint32_t*)c->order.p; P.reg = (uint32_t*)c->reg.p; P.raw = (float4*)c->raw.p; P.n_raw = (int32_t*)c->n_raw.p;
     P.dxy = (short2*)c->dx.p; P.all_kl = (plp_keyline*)c->all_kl.p; P.all_lbd = (uint8_t*)c->all_lbd.p;

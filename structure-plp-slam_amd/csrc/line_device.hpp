@@ -23,15 +23,14 @@ constexpr size_t kLsdMaxScaledPixels = (kLsdGrowLdsBytes / 4 - 256) * 32 - 31;  
 static_assert(kLsdMaxScaledPixels <= (size_t)kLsdSeedPixMask + 1, "seed packing of k_lsd_order must hold every admitted pixel index");
 static_assert(kLsdSeedPixBits + 10 <= 32, "10 bits of gradient bin above the pixel field");
 
-// What region growing needs about a pixel of the scaled image, in planes by how hot it is (round 3: one 16-byte record per pixel had
-// cost a 32-byte sector per gathered neighbour for 8 hot bytes; HBM traffic of k_lsd_grow 1.7 x its algorithmic bytes):
-//   cs   (float)cos / (float)sin of float(angle): the ONLY thing the neighbour gather of region_grow reads, 8 bytes
-//   deg  cv::fastAtan2(gx, -gy) in degrees (the level-line angle of lsd.cpp is (double)deg * (pi / 180)): seeds, the rare in-band
-//        decisions of the angle test, the refinement's statistics
-//   g2   gx^2 + gy^2 (the gradient magnitude is sqrt((double)g2 / 4.0)): the rectangle fits; the plane the seed sort reads anyway
-// Undefined pixels (magnitude <= rho) are marked in the `undef` bit mask; their cs / deg are never read, their g2 is 0.
-__device__ __forceinline__ double deg_to_ang(float deg) { return (double)deg * (3.14159265358979323846 / 180); }
-__device__ __forceinline__ double g2_to_mod(uint32_t g2) { return sqrt((double)g2 / 4.0); }
+// Everything region growing needs about one pixel of the scaled image in 16 bytes (two pixels per 32-byte HBM sector):
+//   deg  cv::fastAtan2(gx, -gy) in degrees; the level-line angle of lsd.cpp is (double)deg * (pi / 180)
+//   g2   gx^2 + gy^2; the gradient magnitude is sqrt((double)g2 / 4.0)
+//   cs   (float)cos / (float)sin of float(angle)
+// Undefined pixels (magnitude <= rho) are marked in the `undef` bit mask and never read.
+struct alignas(16) LsdPix { float deg; uint32_t g2; float2 cs; };
+__device__ __forceinline__ double pix_ang(const LsdPix& p) { return (double)p.deg * (3.14159265358979323846 / 180); }
+__device__ __forceinline__ double pix_mod(const LsdPix& p) { return sqrt((double)p.g2 / 4.0); }
 
 // Per-frame geometry + HBM planes of the line path.  All planes are B frames back to back.
 struct LinePlanes {
@@ -41,8 +40,7 @@ struct LinePlanes {
     const uint8_t* img; size_t img_frame_stride; int img_pitch;   // caller's frames
     uint8_t* blur11;          // 11-tap sigma 1.2 blur (LSD), only when the blur and the resize run as two kernels  [B][H][pitch]
     uint8_t* scaled;          // INTER_LINEAR_EXACT x0.5              [B][sh][spitch]
-    float2* pix_cs;           // per DEFINED scaled pixel: cos / sin of the level-line angle  [B][sh*sw]
-    float* pix_deg;           // per DEFINED scaled pixel: the angle in degrees (cv::fastAtan2)  [B][sh*sw]
+    LsdPix* pix;              // per scaled pixel: angle / magnitude^2 / cos,sin, 16 bytes  [B][sh*sw]
     uint32_t* g2;             // gx^2 + gy^2 of the defined pixels, 0 = undefined  [B][sh*sw]
     uint32_t* blockmax;       // per gradient workgroup: max g2 over its defined pixels   [B][ceil(sh*sw/256)]
     unsigned long long* undef;     // NOTDEF bitmask, 1 bit per scaled pixel          [B][ceil(sh*sw/64)]

@@ -153,12 +153,12 @@ __global__ __launch_bounds__(256) void k_lsd_gradient(LinePlanes P, LsdParams lp
             const uint32_t g2 = (uint32_t)(gx * gx + gy * gy);
             if (g2 >= lp.g2_def_min) {
                 g2_def = g2;
-                const float deg = fast_atan2_deg_l((float)gx, (float)-gy);
-                const float fa = (float)((double)deg * (3.14159265358979323846 / 180));
-                float2 cs;
-                if (!sincos_ziv(fa, &cs.x, &cs.y)) cs = make_float2((float)cos((double)fa), (float)sin((double)fa));   // ~1 pixel in a million
-                P.pix_cs[(size_t)b * n + idx] = cs;
-                P.pix_deg[(size_t)b * n + idx] = deg;
+                LsdPix px;
+                px.deg = fast_atan2_deg_l((float)gx, (float)-gy);
+                px.g2 = g2;
+                const float fa = (float)((double)px.deg * (3.14159265358979323846 / 180));
+                if (!sincos_ziv(fa, &px.cs.x, &px.cs.y)) px.cs = make_float2((float)cos((double)fa), (float)sin((double)fa));   // ~1 pixel in a million
+                P.pix[(size_t)b * n + idx] = px;
             }
         }
         P.g2[(size_t)b * n + idx] = g2_def;
@@ -311,7 +311,7 @@ __device__ __forceinline__ double bcast_d(double v, int src) {
 }
 
 struct GrowCtx {
-    const float2* cs; const float* deg; const uint32_t* g2;   // per-pixel planes of this frame (line_device.hpp)
+    const LsdPix* pix;
     uint32_t* reg; uint32_t* used;   // used: LDS bitmap (one wave per frame: the USED map; several waves per frame: this wave's OWN marks)
     uint32_t* ring;                  // LDS: the last kRing region points (the breadth-first frontier lives here)
     int sw, sh, lane, ring_mask;
@@ -397,7 +397,7 @@ __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed
     const int lane = g.lane;
     int nreg = 1;
     const int sx = seed % g.sw, sy = seed / g.sw;
-    reg_angle = (double)(have_deg ? seed_deg : g.deg[seed]) * (3.14159265358979323846 / 180);
+    reg_angle = (double)(have_deg ? seed_deg : g.pix[seed].deg) * (3.14159265358979323846 / 180);
     float sumdx, sumdy;
     if (seed_cs) { sumdx = seed_cs->x; sumdy = seed_cs->y; }
     else {
@@ -423,6 +423,7 @@ __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed
         const int nb = min(7, nreg - i);
         bool cand = slot < nb;
         int nx = 0, ny = 0, np = 0;
+        float deg = 0.f;
         float2 ncs = make_float2(0.f, 0.f);
         {
             uint32_t c = 0;
@@ -462,7 +463,7 @@ __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed
                 __builtin_amdgcn_wave_barrier();
             }
         } else if (cand) cand = !is_used(g, np);
-        if (cand) ncs = g.cs[np];   // 8 bytes per live neighbour
+        if (cand) { const LsdPix px = g.pix[np]; deg = px.deg; ncs = px.cs; }   // 16 bytes per live neighbour
         // ---- acceptances in order.  Accepted lanes are strictly increasing, so the set of accepted lanes (a bit mask)
         // already is the order: the list append and the USED bits are written by the accepted lanes themselves after
         // the loop, in parallel (the loop used to hand every acceptance to lane 0: two more broadcasts and a
@@ -547,7 +548,6 @@ __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed
             if (U & before) {
                 if (n_exact_tests) ++*n_exact_tests;
                 if (!theta_valid) { reg_angle = (double)fast_atan2_deg_l(sumdy, sumdx) * (3.14159265358979323846 / 180); theta_valid = true; }
-                const float deg = cand ? g.deg[np] : 0.f;   // the exact test needs the pixel's own angle: fetched here, a dozen times per frame
                 bal = __builtin_amdgcn_ballot_w64(aligned_to((double)deg * (3.14159265358979323846 / 180), reg_angle, prec)) & elig;
             }
             if (!bal) break;
@@ -596,7 +596,7 @@ __device__ void region2rect(const GrowCtx& g, int nreg, double reg_angle, double
         double txx = 0, tyy = 0, txy = 0;   // this lane's addends (same roundings as the reference's per-point products)
         if (j < nreg) {
             const uint32_t c = g.reg[j];
-            const double w = g2_to_mod(g.g2[(int)(c >> 16) * g.sw + (int)(c & 0xffff)]);
+            const double w = pix_mod(g.pix[(int)(c >> 16) * g.sw + (int)(c & 0xffff)]);
             const double dx = (double)(int)(c & 0xffff) - x, dy = (double)(int)(c >> 16) - y;
             txx = dy * dy * w; tyy = dx * dx * w; txy = dx * dy * w;
         }
@@ -650,7 +650,7 @@ __device__ void rect_from_ring(const GrowCtx& g, int nreg, double reg_angle, dou
         if (j < nreg) {
             const uint32_t c = g.ring[j & g.ring_mask];
             px[u] = (int)(c & 0xffff); py[u] = (int)(c >> 16);
-            w[u] = g2_to_mod(g.g2[py[u] * g.sw + px[u]]);
+            w[u] = pix_mod(g.pix[py[u] * g.sw + px[u]]);
         }
     }
     // The three running sums of a pass are three lanes of one loop: the addends go through LDS (3 doubles per point,
@@ -749,7 +749,7 @@ __device__ void centroid_sums(const GrowCtx& g, int nreg, double cen[3]) {
         double tx = 0, ty = 0, w = 0;
         if (j < nreg) {
             const uint32_t c = g.reg[j];
-            w = g2_to_mod(g.g2[(int)(c >> 16) * g.sw + (int)(c & 0xffff)]);
+            w = pix_mod(g.pix[(int)(c >> 16) * g.sw + (int)(c & 0xffff)]);
             tx = (double)(int)(c & 0xffff) * w; ty = (double)(int)(c >> 16) * w;
         }
         const int cnt = min(64, nreg - base);
@@ -770,7 +770,7 @@ __global__ __launch_bounds__(256, PLP_GROW_MIN_WAVES) void k_lsd_grow(LinePlanes
     const int n = P.sw * P.sh, nwords = (n + 31) / 32, nv = (P.sw - 1) * (P.sh - 1);
     GrowCtx g;
     g.comm = nullptr; g.tent = nullptr; g.tent_pos = nullptr; g.tent_id = 0; g.my_pos = 0; g.reg_cap = n; g.assumed = nullptr; g.assumed_cap = 0; g.policy = 0;
-    g.cs = P.pix_cs + (size_t)b * n; g.deg = P.pix_deg + (size_t)b * n; g.g2 = P.g2 + (size_t)b * n;
+    g.pix = P.pix + (size_t)b * n;
     g.reg = P.reg + (size_t)b * P.reg_frame_stride; const int nw_al = (nwords + 1) & ~1;   // the ring doubles as f64 scratch: 8-byte aligned
     g.used = s_bits + (size_t)wv * (nw_al + ring); g.ring = g.used + nw_al; g.ring_mask = ring - 1;
     g.sw = P.sw; g.sh = P.sh; g.lane = lane;
@@ -801,7 +801,7 @@ __global__ __launch_bounds__(256, PLP_GROW_MIN_WAVES) void k_lsd_grow(LinePlanes
         const bool fresh = in_range && !is_used(g, (int)mine);
         unsigned long long todo = __ballot(fresh);
         // every still-unused seed of this group of 64 fetches its own record now: one round trip for up to 64 regions
-        const float s_deg = fresh ? g.deg[mine] : 0.f;
+        const float s_deg = fresh ? g.pix[mine].deg : 0.f;
         float2 s_cs = make_float2(0.f, 0.f);
         if (fresh) {   // (float)cos / (float)sin of the f64 seed angle, 64 seeds per evaluation
             double sn, cs;
@@ -838,7 +838,7 @@ __global__ __launch_bounds__(256, PLP_GROW_MIN_WAVES) void k_lsd_grow(LinePlanes
                     region_list_fence();
                     const uint32_t c0 = g.reg[0];
                     const double xc = (double)(int)(c0 & 0xffff), yc = (double)(int)(c0 >> 16);
-                    const double ang_c = deg_to_ang(g.deg[(int)(c0 >> 16) * g.sw + (int)(c0 & 0xffff)]);
+                    const double ang_c = pix_ang(g.pix[(int)(c0 >> 16) * g.sw + (int)(c0 & 0xffff)]);
                     double sum = 0, s_sum = 0;
                     int nn = 0;
                     for (int rb = 0; rb < nreg; rb += 64) {
@@ -851,7 +851,7 @@ __global__ __launch_bounds__(256, PLP_GROW_MIN_WAVES) void k_lsd_grow(LinePlanes
                             atomicAnd(&g.used[(py * g.sw + px) >> 5], ~(1u << ((py * g.sw + px) & 31)));   // *(reg[i].used) = NOTUSED
                             const double ddx = (double)px - xc, ddy = (double)py - yc;
                             near = sqrt(ddx * ddx + ddy * ddy) < rec.width;
-                            a = deg_to_ang(g.deg[py * g.sw + px]);
+                            a = pix_ang(g.pix[py * g.sw + px]);
                         }
                         const double my_d = near ? angle_diff_signed(a, ang_c) : 0.0;
                         const double my_d2 = my_d * my_d;
@@ -1014,7 +1014,7 @@ __device__ bool mw_process_seed(const GrowCtx& g, const LsdParams& lp, int seed,
             region_list_fence();
             const uint32_t c0 = g.reg[0];
             const double xc = (double)(int)(c0 & 0xffff), yc = (double)(int)(c0 >> 16);
-            const double ang_c = deg_to_ang(g.deg[pix_of(c0, g.sw)]);
+            const double ang_c = pix_ang(g.pix[pix_of(c0, g.sw)]);
             double sum = 0, s_sum = 0;
             int nn = 0;
             for (int rb = 0; rb < nreg; rb += 64) {
@@ -1027,7 +1027,7 @@ __device__ bool mw_process_seed(const GrowCtx& g, const LsdParams& lp, int seed,
                     mw_unmark(g, py * g.sw + px);   // *(reg[i].used) = NOTUSED
                     const double ddx = (double)px - xc, ddy = (double)py - yc;
                     near = sqrt(ddx * ddx + ddy * ddy) < rec.width;
-                    a = deg_to_ang(g.deg[py * g.sw + px]);
+                    a = pix_ang(g.pix[py * g.sw + px]);
                 }
                 const double my_d = near ? angle_diff_signed(a, ang_c) : 0.0;
                 const double my_d2 = my_d * my_d;
@@ -1139,7 +1139,7 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
     const bool is_main = wv == 0;
     const int h = wv - 1;
     GrowCtx g;
-    g.cs = P.pix_cs + (size_t)b * n; g.deg = P.pix_deg + (size_t)b * n; g.g2 = P.g2 + (size_t)b * n; g.used = O; g.ring = my_ring; g.ring_mask = L.ring - 1;
+    g.pix = P.pix + (size_t)b * n; g.used = O; g.ring = my_ring; g.ring_mask = L.ring - 1;
     g.sw = P.sw; g.sh = P.sh; g.lane = lane; g.comm = C; g.tent = T;
     g.tent_pos = cur_pos; g.tent_id = is_main ? kMwMainId : wv; g.my_pos = 0; g.policy = L.policy;
     g.assumed = my_ring + L.ring; g.assumed_cap = kMwAssumed;
@@ -1158,7 +1158,7 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
     };
     // state of the group this wave works on (main: `mine` holds 64 seeds = four groups, `sub` is the one it is in; helpers: lanes 0..kMwGroup-1)
     constexpr int kSubs = 64 / kMwGroup;
-    constexpr unsigned long long kGroupMask = kMwGroup >= 64 ? ~0ull : ((1ull << (kMwGroup & 63)) - 1ull);
+    constexpr unsigned long long kGroupMask = kMwGroup == 64 ? ~0ull : ((1ull << kMwGroup) - 1ull);
     int grp = -1, own = 0, kbuf = 0, hoff = 0, nent = 0, n_lines = 0, ld = -1, sub = kSubs - 1;
     int n_self = 0, n_spec_ok = 0, n_spec_bad = 0;           // main: regions it grew itself, results it took / had to reject
     long long c_wait = 0, c_self = 0, c_commit = 0, c_pub = 0, c_grp = 0;   // main: cycles waiting for helpers / growing regions itself / taking results / publishing its own / group set-up
@@ -1349,7 +1349,7 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
                     const bool fresh = in_range && !committed((int)mine);
                     todo = __ballot(fresh);
                     have_cs = true;
-                    s_deg = fresh ? g.deg[mine] : 0.f;
+                    s_deg = fresh ? g.pix[mine].deg : 0.f;
                     if (fresh) { double sn, cs; sincos((double)s_deg * (3.14159265358979323846 / 180), &sn, &cs); s_cs = make_float2((float)cs, (float)sn); }
                 }
             }
@@ -1368,7 +1368,7 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
         float seed_deg; float2 seed_cs;
         if (have_cs) { seed_deg = bcast_f(s_deg, t); seed_cs = make_float2(bcast_f(s_cs.x, t), bcast_f(s_cs.y, t)); }
         else {
-            seed_deg = g.deg[seed];
+            seed_deg = g.pix[seed].deg;
             double sn, cs;
             sincos((double)seed_deg * (3.14159265358979323846 / 180), &sn, &cs);
             seed_cs = make_float2((float)cs, (float)sn);
