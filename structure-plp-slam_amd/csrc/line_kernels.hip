@@ -640,19 +640,24 @@ __device__ void region2rect(const GrowCtx& g, int nreg, double reg_angle, double
 // list.  Same additions in the same order as centroid_sums() + region2rect().
 __device__ void rect_from_ring(const GrowCtx& g, int nreg, double reg_angle, double prec, Rect& rec) {
     const int lane = g.lane;
-    int px[4], py[4];
+    // per lane up to four points, kept small across the two sequential passes (this function is the kernel's register peak, and what
+    // two of these waves leave of a SIMD's registers decides how many waves of the neighbouring kernels fit): coordinates stay packed as
+    // in the list
+    uint32_t pc[4];
     double w[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int j = lane + 64 * u;
-        px[u] = 0; py[u] = 0; w[u] = 0;
+        pc[u] = 0; w[u] = 0;
         if (64 * u >= nreg) continue;   // uniform: most fitted regions have fewer than 64 points
         if (j < nreg) {
-            const uint32_t c = g.ring[j & g.ring_mask];
-            px[u] = (int)(c & 0xffff); py[u] = (int)(c >> 16);
-            w[u] = pix_mod(g.pix[py[u] * g.sw + px[u]]);
+            pc[u] = g.ring[j & g.ring_mask];
+            w[u] = pix_mod(g.pix[(int)(pc[u] >> 16) * g.sw + (int)(pc[u] & 0xffff)]);
         }
     }
+    auto PX = [&](int u) -> int { return (int)(pc[u] & 0xffff); };
+    auto PY = [&](int u) -> int { return (int)(pc[u] >> 16); };
+    auto WT = [&](int u) -> double { return w[u]; };
     // The three running sums of a pass are three lanes of one loop: the addends go through LDS (3 doubles per point,
     // 32 points at a time), lane k adds stream k in region order -- 2 instructions per point instead of 9 broadcasts and
     // adds.  The scratch is the frontier ring itself: its coordinates are in registers by now and the next region_grow
@@ -701,12 +706,12 @@ __device__ void rect_from_ring(const GrowCtx& g, int nreg, double reg_angle, dou
         }
         return acc;
     };
-    double acc = chain3([&](int u, int k) -> double { return k == 0 ? (double)px[u] * w[u] : k == 1 ? (double)py[u] * w[u] : w[u]; });
+    double acc = chain3([&](int u, int k) -> double { const double w = WT(u); return k == 0 ? (double)PX(u) * w : k == 1 ? (double)PY(u) * w : w; });
     const double sx = bcast_d(acc, 0), sy = bcast_d(acc, 1), sw = bcast_d(acc, 2);
     const double x = sx / sw, y = sy / sw;
     acc = chain3([&](int u, int k) -> double {
-        const double dx = (double)px[u] - x, dy = (double)py[u] - y;
-        return k == 0 ? dy * dy * w[u] : k == 1 ? dx * dx * w[u] : -(dx * dy * w[u]);   // Ixy -= v  ==  Ixy += -v
+        const double dx = (double)PX(u) - x, dy = (double)PY(u) - y, w = WT(u);
+        return k == 0 ? dy * dy * w : k == 1 ? dx * dx * w : -(dx * dy * w);   // Ixy -= v  ==  Ixy += -v
     });
     const double Ixx = bcast_d(acc, 0), Iyy = bcast_d(acc, 1), Ixy = bcast_d(acc, 2);
     const double lambda = 0.5 * (Ixx + Iyy - sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
@@ -720,7 +725,7 @@ __device__ void rect_from_ring(const GrowCtx& g, int nreg, double reg_angle, dou
 #pragma unroll
     for (int u = 0; u < 4; ++u)
         if (lane + 64 * u < nreg) {
-            const double rdx = (double)px[u] - x, rdy = (double)py[u] - y;
+            const double rdx = (double)PX(u) - x, rdy = (double)PY(u) - y;
             const double l = rdx * dx + rdy * dy, ww = -rdx * dy + rdy * dx;
             l_max = fmax(l_max, l); l_min = fmin(l_min, l);
             w_max = fmax(w_max, ww); w_min = fmin(w_min, ww);
@@ -1750,10 +1755,11 @@ void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp,
     hipLaunchKernelGGL(k_lsd_order, dim3(B), dim3(256), 0, st, P, lp, (n + 255) / 256);
     mark(3);
     // per wave: USED bitmap + frontier ring (a power of two; the HBM copy of the region list backs larger frontiers).
-    // One wave per workgroup keeps the LDS footprint small (~10.6 KB), so LDS never limits how many frames a CU hosts;
-    // at 2048 frames every SIMD carries two of these instruction-bound waves (profiles/r01i_sq_counters.md).
+    // ~10.6 KB of LDS per wave; at 2048 frames every SIMD carries two of these latency-bound waves.
     static const int ring = [] { const char* e = getenv("PLP_LSD_RING"); int r = e ? atoi(e) : 256; return (r >= 64 && (r & (r - 1)) == 0) ? r : 256; }();
-    static const int wpb_env = [] { const char* e = getenv("PLP_LSD_WPB"); return e ? atoi(e) : 1; }();
+    // four waves per workgroup = one per SIMD of the CU that takes the workgroup: with 147 registers three of these waves fit a SIMD, and 2048
+    // one-wave workgroups had spread unevenly (13.2 -> 14.2 ms); profiles/r03_lsd_grow.md section 2
+    static const int wpb_env = [] { const char* e = getenv("PLP_LSD_WPB"); return e ? atoi(e) : 4; }();
     const size_t per_wave = (size_t)((((n + 31) / 32 + 1) & ~1) + ring) * 4;
     const int wpb = (int)std::max<size_t>(1, std::min<size_t>(std::min(4, std::max(1, wpb_env)), 65536 / per_wave));
     // diagnostic only (what the rest of a step costs without region growing): PLP_LSD_SKIP_GROW=k leaves the kernel out after
