@@ -279,14 +279,24 @@ def main():
 
         pending = []
 
-        def host_step(n):
-            nonlocal d_frames
+        uploaded = {}
+
+        def upload(n):
+            """enqueue the host-to-device copy of step n's frames (once): it starts as soon as the extractors that last read this staging buffer are through"""
+            if n in uploaded:
+                return
             sb = n % 2
             for ev_ in stage_free[sb] or ():
-                sH.wait_event(ev_)                                           # the extractors that last read this staging buffer are through (the matchers never read pixels)
+                sH.wait_event(ev_)                                           # (the matchers never read pixels)
             with torch.cuda.stream(sH):
-                stage[sb].copy_(h_frames, non_blocking=True)                 # H2D of this step's frames
-                ev = torch.cuda.Event(); ev.record(sH)
+                stage[sb].copy_(h_frames, non_blocking=True)
+                uploaded[n] = torch.cuda.Event(); uploaded[n].record(sH)
+
+        def host_step(n, last=False):
+            nonlocal d_frames
+            sb = n % 2
+            upload(n)
+            ev = uploaded.pop(n)
             for s_ in [sA] + sBs:
                 s_.wait_event(ev)
             buf = ts.step_no % NBUF
@@ -308,18 +318,20 @@ def main():
                     h.copy_(t, non_blocking=True)
                 ev_off[buf] = torch.cuda.Event(); ev_off[buf].record(sD)
             stage_free[sb] = list(ts.extract_events)
+            if not last:
+                upload(n + 1)                                                # before the host blocks below: the next step's frames travel while this step computes
             while pending:                                                   # the previous step's bulk copy, now that this step keeps the GPU busy
                 finish_download(pending.pop(0))
             pending.append(buf)
         for n in range(2):
-            host_step(n)
+            host_step(n, last=n == 1)
         while pending:
             finish_download(pending.pop(0))
         barrier()
         d2h_bytes.clear()
         t0 = time.perf_counter()
         for n in range(args.steps):
-            host_step(n)
+            host_step(n, last=n == args.steps - 1)                           # exactly args.steps uploads inside the timed region
         while pending:
             finish_download(pending.pop(0))
         barrier()

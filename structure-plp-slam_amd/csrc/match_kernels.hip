@@ -69,16 +69,32 @@ __device__ __forceinline__ bool is_line_mode(int mode) { return mode == PLP_MATC
 __device__ __forceinline__ bool is_group_mode(int mode) { return mode == PLP_MATCH_MODE_BOW || mode == PLP_MATCH_MODE_TRIANGULATION; }
 __device__ __forceinline__ bool is_last_frame_mode(int mode) { return mode == PLP_MATCH_MODE_LAST_FRAME || mode == PLP_MATCH_MODE_LAST_FRAME_LINE; }
 
+// The generic kernels (k_match_topk, k_match_topk_lanes, k_match_resolve_generic) are instantiated per FAMILY of modes: written against
+// every mode at once they kept all modes' pointers and gates live (81-125 scalar registers spilled, a scratch frame per wave).  An
+// instantiation reads the mode through fam_mode<FAM>(): a select over the constants of its family, so every test for another family's
+// mode folds away at compile time and that family's arguments are never loaded.  launch_match() picks the instantiation from the same value.
+enum MatchFamily { kFamAny = 0, kFamLine = 1, kFamGroup = 2, kFamPoint = 3, kFamGrid = 4 };   // kFamGrid: the two windowed point modes after k_match_prep
+template <int FAM>
+__device__ __forceinline__ int fam_mode(int m) {
+    if constexpr (FAM == kFamLine) return m == PLP_MATCH_MODE_LANDMARKS_LINE ? PLP_MATCH_MODE_LANDMARKS_LINE : PLP_MATCH_MODE_LAST_FRAME_LINE;
+    else if constexpr (FAM == kFamGroup) return m == PLP_MATCH_MODE_BOW ? PLP_MATCH_MODE_BOW : PLP_MATCH_MODE_TRIANGULATION;
+    else if constexpr (FAM == kFamPoint) return m == PLP_MATCH_MODE_LANDMARKS ? PLP_MATCH_MODE_LANDMARKS : m == PLP_MATCH_MODE_LAST_FRAME ? PLP_MATCH_MODE_LAST_FRAME : PLP_MATCH_MODE_BRUTE_FORCE;
+    else if constexpr (FAM == kFamGrid) return m == PLP_MATCH_MODE_LANDMARKS ? PLP_MATCH_MODE_LANDMARKS : PLP_MATCH_MODE_LAST_FRAME;
+    else return m;
+}
+
+template <int FAM = kFamAny>
 __device__ __forceinline__ QueryCtx make_query(const MatchProblem& P, int q, int b) {
+    const int mode = fam_mode<FAM>(P.mode);
     const size_t qoff = (size_t)b * P.m_cap;
     const float* reproj = P.q_reproj ? P.q_reproj + qoff * 2 : nullptr;
     const float* q_xr = P.q_x_right ? P.q_x_right + qoff : nullptr;
     const int32_t* q_level = P.q_level ? P.q_level + qoff : nullptr;
     QueryCtx c{};
-    c.windowed = P.mode != PLP_MATCH_MODE_BRUTE_FORCE && !is_group_mode(P.mode);
-    c.line = is_line_mode(P.mode);
-    if (is_group_mode(P.mode)) c.group = P.q_group[qoff + q];
-    if (P.mode == PLP_MATCH_MODE_TRIANGULATION) {
+    c.windowed = mode != PLP_MATCH_MODE_BRUTE_FORCE && !is_group_mode(mode);
+    c.line = is_line_mode(mode);
+    if (is_group_mode(mode)) c.group = P.q_group[qoff + q];
+    if (mode == PLP_MATCH_MODE_TRIANGULATION) {
         const double* bq = P.q_bearing + (qoff + q) * 3;
         c.b1x = bq[0]; c.b1y = bq[1]; c.b1z = bq[2];
         c.stereo = q_xr && 0 <= q_xr[q];
@@ -93,7 +109,7 @@ __device__ __forceinline__ QueryCtx make_query(const MatchProblem& P, int q, int
     if (c.line) {   // data::get_keylines_in_cell (common.cc:315-363) + the level windows of projection.cc:138-144, :429-450
         c.mg = __fmul_rn(P.margin, P.scale_factors[lvl_tab]);
         double x1, y1, x2, y2;
-        if (P.mode == PLP_MATCH_MODE_FUSE_LINE) {   // the f64 reprojections are narrowed to float by the call (fuse.cc:420-422)
+        if (mode == PLP_MATCH_MODE_FUSE_LINE) {   // the f64 reprojections are narrowed to float by the call (fuse.cc:420-422)
             const double* a = P.q_reproj_d + (qoff + q) * 2; const double* e = P.q_reproj2_d + (qoff + q) * 2;
             x1 = (float)a[0]; y1 = (float)a[1]; x2 = (float)e[0]; y2 = (float)e[1];
             c.g0 = a[1] * 1.0 - 1.0 * e[1]; c.g1 = 1.0 * e[0] - a[0] * 1.0; c.g2 = a[0] * e[1] - a[1] * e[0];
@@ -106,8 +122,8 @@ __device__ __forceinline__ QueryCtx make_query(const MatchProblem& P, int q, int
         c.lden = sqrt(c.l0 * c.l0 + c.l1 * c.l1);
         c.xr = q_xr ? q_xr[q] : -1.f;
         c.xr2 = P.q_x_right2 ? P.q_x_right2[qoff + q] : -1.f;
-        if (P.mode == PLP_MATCH_MODE_FUSE_LINE) { c.min_level = -1; c.max_level = -1; }
-        else if (P.mode == PLP_MATCH_MODE_LANDMARKS_LINE || P.level_window == 1) { c.min_level = lvl - 1; c.max_level = lvl; }
+        if (mode == PLP_MATCH_MODE_FUSE_LINE) { c.min_level = -1; c.max_level = -1; }
+        else if (mode == PLP_MATCH_MODE_LANDMARKS_LINE || P.level_window == 1) { c.min_level = lvl - 1; c.max_level = lvl; }
         else if (P.level_window == 2) { c.min_level = lvl - 1; c.max_level = lvl + 1; }
         else if (P.direction == 1) { c.min_level = lvl; c.max_level = P.num_levels_lsd; }
         else if (P.direction == 2) { c.min_level = 0; c.max_level = lvl + 1; }
@@ -115,7 +131,7 @@ __device__ __forceinline__ QueryCtx make_query(const MatchProblem& P, int q, int
         c.empty = false;
         return c;
     }
-    if (P.mode == PLP_MATCH_MODE_FUSE) {   // get_keypoints_in_cell(reproj(0), reproj(1), margin * scale) takes the f64 reprojection as float
+    if (mode == PLP_MATCH_MODE_FUSE) {   // get_keypoints_in_cell(reproj(0), reproj(1), margin * scale) takes the f64 reprojection as float
         const double* rd = P.q_reproj_d + qoff * 2;
         c.rdx = rd[2 * q]; c.rdy = rd[2 * q + 1];
         c.rx = (float)c.rdx; c.ry = (float)c.rdy;
@@ -123,8 +139,8 @@ __device__ __forceinline__ QueryCtx make_query(const MatchProblem& P, int q, int
     } else { c.rx = reproj[2 * q]; c.ry = reproj[2 * q + 1]; }
     c.mg = __fmul_rn(P.margin, P.scale_factors[lvl_tab]);
     c.xr = q_xr ? q_xr[q] : -1.f;
-    if (P.mode == PLP_MATCH_MODE_LANDMARKS || (P.mode == PLP_MATCH_MODE_LAST_FRAME && P.level_window == 1)) { c.min_level = lvl - 1; c.max_level = lvl; }
-    else if (P.mode == PLP_MATCH_MODE_FUSE) { c.min_level = -1; c.max_level = -1; }
+    if (mode == PLP_MATCH_MODE_LANDMARKS || (mode == PLP_MATCH_MODE_LAST_FRAME && P.level_window == 1)) { c.min_level = lvl - 1; c.max_level = lvl; }
+    else if (mode == PLP_MATCH_MODE_FUSE) { c.min_level = -1; c.max_level = -1; }
     else if (P.level_window == 2) { c.min_level = lvl - 1; c.max_level = lvl + 1; }
     else if (P.direction == 1) { c.min_level = lvl; c.max_level = P.num_levels - 1; }
     else if (P.direction == 2) { c.min_level = 0; c.max_level = lvl; }
@@ -137,19 +153,21 @@ __device__ __forceinline__ QueryCtx make_query(const MatchProblem& P, int q, int
     c.max_cy = min(P.grid_rows - 1, ceil_d((double)__fadd_rn(__fsub_rn(c.ry, P.grid_min_y), c.mg) * P.inv_cell_h));
     c.empty = P.grid_cols <= c.min_cx || c.max_cx < 0 || P.grid_rows <= c.min_cy || c.max_cy < 0;
     // match_by_Sim3_transform tests `scale_level < pred - 1 || pred < scale_level` on unsigned values (projection.cc:862)
-    if (P.mode == PLP_MATCH_MODE_LAST_FRAME && (P.flags & PLP_MATCH_FLAG_UNSIGNED_LEVEL) && lvl == 0) c.empty = true;
+    if (mode == PLP_MATCH_MODE_LAST_FRAME && (P.flags & PLP_MATCH_FLAG_UNSIGNED_LEVEL) && lvl == 0) c.empty = true;
     return c;
 }
 
+template <int FAM = kFamAny>
 __device__ __forceinline__ unsigned long long candidate_key(const MatchProblem& P, const QueryCtx& c, int t, const plp_keypoint* kps,
                                                            const uint8_t* t_desc, const float* t_xr, const uint8_t* t_occ,
                                                            const uint4& q0, const uint4& q1) {
+    const int mode = fam_mode<FAM>(P.mode);
     unsigned order = (unsigned)t, oct = 0;
-    if (is_group_mode(P.mode)) {
+    if (is_group_mode(mode)) {
         const size_t tb = (size_t)(t_desc - P.t_desc) / 32;
         if (P.t_group[tb + t] != c.group) return ~0ull;
         if (t_occ && t_occ[t]) return ~0ull;
-        if (P.mode == PLP_MATCH_MODE_TRIANGULATION) {
+        if (mode == PLP_MATCH_MODE_TRIANGULATION) {
             const uint4* d = reinterpret_cast<const uint4*>(t_desc + 32 * (size_t)t);
             const unsigned dist = hamming256(q0, q1, d[0], d[1]);
             if (50u < dist) return ~0ull;                                       // HAMMING_DIST_THR_LOW (robust.cc:124)
@@ -174,7 +192,7 @@ __device__ __forceinline__ unsigned long long candidate_key(const MatchProblem& 
         const float dsp = (float)(((double)kl.startPointX * c.l0 + (double)kl.startPointY * c.l1 + c.l2) / c.lden);
         const float dep = (float)(((double)kl.endPointX * c.l0 + (double)kl.endPointY * c.l1 + c.l2) / c.lden);
         if (fabsf(dsp) > c.mg || fabsf(dep) > c.mg) return ~0ull;
-        if (P.mode == PLP_MATCH_MODE_FUSE_LINE) {   // fuse.cc:440-451, f64
+        if (mode == PLP_MATCH_MODE_FUSE_LINE) {   // fuse.cc:440-451, f64
             const double e_sp = ((double)kl.startPointX * c.g0 + (double)kl.startPointY * c.g1 + c.g2) / c.gden;
             const double e_ep = ((double)kl.endPointX * c.g0 + (double)kl.endPointY * c.g1 + c.g2) / c.gden;
             if ((double)5.99146f < (e_sp * e_sp + e_ep * e_ep) * (double)P.inv_level_sigma_sq[(unsigned)kl.octave & 15]) return ~0ull;
@@ -187,7 +205,7 @@ __device__ __forceinline__ unsigned long long candidate_key(const MatchProblem& 
             if (c.max_level > 0 && kl.octave > c.max_level) return ~0ull;   // `max_level > 0` as the reference (common.cc:354)
         }
         if (t_occ && t_occ[t]) return ~0ull;
-        if (P.mode == PLP_MATCH_MODE_LAST_FRAME_LINE && P.is_rgbd && t_xr && P.t_x_right2) {
+        if (mode == PLP_MATCH_MODE_LAST_FRAME_LINE && P.is_rgbd && t_xr && P.t_x_right2) {
             const float a = t_xr[t], b2 = P.t_x_right2[tb + t];
             if (a > 0 && b2 > 0 && (c.mg < fabsf(__fsub_rn(c.xr, a)) || c.mg < fabsf(__fsub_rn(c.xr2, b2)))) return ~0ull;
         }
@@ -204,7 +222,7 @@ __device__ __forceinline__ unsigned long long candidate_key(const MatchProblem& 
             if (0 <= c.max_level && c.max_level < k.octave) return ~0ull;
         }
         if (!(fabsf(__fsub_rn(k.x, c.rx)) < c.mg && fabsf(__fsub_rn(k.y, c.ry)) < c.mg)) return ~0ull;
-        if (P.mode == PLP_MATCH_MODE_FUSE) {   // fuse.cc:230-262: octave window in unsigned arithmetic + chi-square gates in f64
+        if (mode == PLP_MATCH_MODE_FUSE) {   // fuse.cc:230-262: octave window in unsigned arithmetic + chi-square gates in f64
             const unsigned sl = (unsigned)k.octave;
             if (P.flags & PLP_MATCH_FLAG_SIGNED_LEVEL) { if (k.octave < (int)c.pred - 1 || (int)c.pred < k.octave) return ~0ull; }
             else if (sl < c.pred - 1u || c.pred < sl) return ~0ull;
@@ -263,6 +281,7 @@ __device__ __forceinline__ void topk_merge_store(unsigned long long (&top)[kMatc
 
 // Fallback for frames with more key points than the LDS staging of k_match_topk_lds holds:
 // grid = (ceil(m_cap / 4), B), block = 256: one wave per query, targets read from HBM/L2.
+template <int FAM = kFamAny>
 __device__ __forceinline__ void match_topk_query(const MatchProblem& P, int b, int q, int lane) {
     uint32_t* klist = P.klist + ((size_t)b * P.m_cap + q) * kMatchK;
     int32_t* kcount = P.kcount + (size_t)b * P.m_cap + q;
@@ -273,7 +292,7 @@ __device__ __forceinline__ void match_topk_query(const MatchProblem& P, int b, i
     const uint8_t* t_desc = P.t_desc + (size_t)b * P.n_cap * 32;
     const float* t_xr = P.t_x_right ? P.t_x_right + (size_t)b * P.n_cap : nullptr;
     const uint8_t* t_occ = P.t_occupied ? P.t_occupied + (size_t)b * P.n_cap : nullptr;
-    const QueryCtx c = make_query(P, q, b);
+    const QueryCtx c = make_query<FAM>(P, q, b);
     const uint4* qd = reinterpret_cast<const uint4*>(P.q_desc + ((size_t)b * P.q_desc_stride + q) * 32);
     const uint4 q0 = qd[0], q1 = qd[1];
     unsigned long long top[kMatchK];
@@ -282,7 +301,7 @@ __device__ __forceinline__ void match_topk_query(const MatchProblem& P, int b, i
     int passed = 0;
     if (!(c.windowed && c.empty))
         for (int t = lane; t < n; t += 64) {
-            const unsigned long long key = candidate_key(P, c, t, kps, t_desc, t_xr, t_occ, q0, q1);
+            const unsigned long long key = candidate_key<FAM>(P, c, t, kps, t_desc, t_xr, t_occ, q0, q1);
             if (key == ~0ull) continue;
             ++passed;
             topk_insert(top, key);
@@ -295,16 +314,18 @@ __device__ __forceinline__ void match_topk_query(const MatchProblem& P, int b, i
 
 // grid = (gx, B) with gx <= ceil(m_cap / 4): the waves of a frame stride over its queries, so a batch of frames with few
 // queries each (key lines: ~50 of a 512 capacity) does not launch hundreds of thousands of workgroups that only exit.
+template <int FAM>
 __global__ __launch_bounds__(256) void k_match_topk(MatchProblem P) {
     corun_priority();
     const int lane = threadIdx.x & 63, b = blockIdx.y;
     const int m = P.q_counts ? min(P.q_counts[b], P.m_cap) : P.m_cap;
-    for (int q = blockIdx.x * 4 + (threadIdx.x >> 6); q < m; q += gridDim.x * 4) match_topk_query(P, b, q, lane);
+    for (int q = blockIdx.x * 4 + (threadIdx.x >> 6); q < m; q += gridDim.x * 4) match_topk_query<FAM>(P, b, q, lane);
 }
 
 // The same search with ONE LANE per query (each lane scans all targets and keeps its 8 best keys): for small target sets -- the key
 // lines of a frame, ~50 against ~50 -- a wave per query leaves most lanes without a target and spends more on merging the lanes'
 // lists than on the candidates.  grid = (ceil(m_cap / 64), B), block = 64.
+template <int FAM>
 __global__ __launch_bounds__(64) void k_match_topk_lanes(MatchProblem P) {
     corun_priority();
     const int b = blockIdx.y, q = blockIdx.x * 64 + threadIdx.x;
@@ -319,7 +340,7 @@ __global__ __launch_bounds__(64) void k_match_topk_lanes(MatchProblem P) {
     const uint8_t* t_desc = P.t_desc + (size_t)b * P.n_cap * 32;
     const float* t_xr = P.t_x_right ? P.t_x_right + (size_t)b * P.n_cap : nullptr;
     const uint8_t* t_occ = P.t_occupied ? P.t_occupied + (size_t)b * P.n_cap : nullptr;
-    const QueryCtx c = make_query(P, q, b);
+    const QueryCtx c = make_query<FAM>(P, q, b);
     const uint4* qd = reinterpret_cast<const uint4*>(P.q_desc + ((size_t)b * P.q_desc_stride + q) * 32);
     const uint4 q0 = qd[0], q1 = qd[1];
     unsigned long long top[kMatchK];
@@ -328,7 +349,7 @@ __global__ __launch_bounds__(64) void k_match_topk_lanes(MatchProblem P) {
     int passed = 0;
     if (!(c.windowed && c.empty))
         for (int t = 0; t < n; ++t) {
-            const unsigned long long key = candidate_key(P, c, t, kps, t_desc, t_xr, t_occ, q0, q1);
+            const unsigned long long key = candidate_key<FAM>(P, c, t, kps, t_desc, t_xr, t_occ, q0, q1);
             if (key == ~0ull) continue;
             ++passed;
             topk_insert(top, key);
@@ -631,14 +652,16 @@ __global__ __launch_bounds__(256) void k_match_topk_lds(MatchProblem P) {
 }
 
 // accept rules of the three matchers; best/second are (distance, octave) of the two best free candidates
+template <int FAM = kFamAny>
 __device__ __forceinline__ bool accept(const MatchProblem& P, unsigned best, int best_lvl, unsigned second, int second_lvl) {
-    if (P.mode == PLP_MATCH_MODE_LANDMARKS || P.mode == PLP_MATCH_MODE_LANDMARKS_LINE) {
+    const int mode = fam_mode<FAM>(P.mode);
+    if (mode == PLP_MATCH_MODE_LANDMARKS || mode == PLP_MATCH_MODE_LANDMARKS_LINE) {
         if (!(best <= 100u)) return false;
         if (best_lvl == second_lvl && (float)best > __fmul_rn(P.lowe_ratio, (float)second)) return false;
         return true;
     }
-    if (is_last_frame_mode(P.mode)) return best <= (P.hamm_dist_thr > 0 ? (unsigned)P.hamm_dist_thr : 100u);
-    if (P.mode == PLP_MATCH_MODE_TRIANGULATION) return true;                 // every gate is part of the candidate test
+    if (is_last_frame_mode(mode)) return best <= (P.hamm_dist_thr > 0 ? (unsigned)P.hamm_dist_thr : 100u);
+    if (mode == PLP_MATCH_MODE_TRIANGULATION) return true;                 // every gate is part of the candidate test
     if (50u < best) return false;                                            // brute force: HAMMING_DIST_THR_LOW
     if (__fmul_rn(P.lowe_ratio, (float)second) < (float)best) return false;
     return true;
@@ -647,8 +670,9 @@ __device__ __forceinline__ bool accept(const MatchProblem& P, unsigned best, int
 // grid = (B), block = 256.  LDS: owner[2][n_cap] (dynamic).
 // kSorted: the windowed point modes after k_match_prep (a dry list is rescanned over the window's ranges of the sorted array); the other
 // instantiation rescans through candidate_key() and is the only one that carries its registers (all modes' gates, f64 epipolar tests).
-template <bool kSorted>
+template <bool kSorted, int FAM = kFamAny>
 __device__ __forceinline__ void match_resolve_body(const MatchProblem& P) {
+    const int mode = fam_mode<FAM>(P.mode);
     corun_priority();
     extern __shared__ int32_t lds[];
     __shared__ int s_changed, s_num, s_hist[32], s_valid_bin[32], s_full_n, s_claim_tmp[256], s_sort_ws[48];
@@ -674,9 +698,9 @@ __device__ __forceinline__ void match_resolve_body(const MatchProblem& P) {
     __syncthreads();
 
     int32_t* full_list = P.full_list + (size_t)b * P.m_cap;   // queries whose truncated best-K list ran dry
-    const int need = (is_last_frame_mode(P.mode) || P.mode == PLP_MATCH_MODE_TRIANGULATION) ? 1 : 2;   // the last-frame matcher has no second-best test
-    const bool blocks_always = !has_obs || P.mode == PLP_MATCH_MODE_BRUTE_FORCE || is_group_mode(P.mode);
-    const unsigned t_flip = P.mode == PLP_MATCH_MODE_TRIANGULATION ? 0xffffu : 0u;   // that mode orders equal distances by DESCENDING index
+    const int need = (is_last_frame_mode(mode) || mode == PLP_MATCH_MODE_TRIANGULATION) ? 1 : 2;   // the last-frame matcher has no second-best test
+    const bool blocks_always = !has_obs || mode == PLP_MATCH_MODE_BRUTE_FORCE || is_group_mode(mode);
+    const unsigned t_flip = mode == PLP_MATCH_MODE_TRIANGULATION ? 0xffffu : 0u;   // that mode orders equal distances by DESCENDING index
     constexpr bool use_sorted = kSorted;
     const StagedTarget* sorted = P.sorted + (size_t)b * P.n_cap;
     const float* sorted_xr = P.sorted_xr + (size_t)b * P.n_cap;
@@ -736,17 +760,17 @@ __device__ __forceinline__ void match_resolve_body(const MatchProblem& P) {
                     // decides: no acceptable best exists beyond it (d8 above the mode's distance threshold), or the best that was
                     // found passes (or fails) its test against ANY second-best >= d8.  Only the rest needs the exact rescan.
                     bool rescan = found < need && cnt > kList;
-                    if (rescan && P.mode != PLP_MATCH_MODE_TRIANGULATION) {
+                    if (rescan && mode != PLP_MATCH_MODE_TRIANGULATION) {
                         const unsigned d8 = e8[kList - 1] >> 20;   // the distance of the list's last entry: nothing beyond it is closer
-                        const bool lm = P.mode == PLP_MATCH_MODE_LANDMARKS || P.mode == PLP_MATCH_MODE_LANDMARKS_LINE;
-                        const unsigned thr = (lm || is_last_frame_mode(P.mode)) ? (is_last_frame_mode(P.mode) && P.hamm_dist_thr > 0 ? (unsigned)P.hamm_dist_thr : 100u) : 50u;
+                        const bool lm = mode == PLP_MATCH_MODE_LANDMARKS || mode == PLP_MATCH_MODE_LANDMARKS_LINE;
+                        const unsigned thr = (lm || is_last_frame_mode(mode)) ? (is_last_frame_mode(mode) && P.hamm_dist_thr > 0 ? (unsigned)P.hamm_dist_thr : 100u) : 50u;
                         if (found == 0) { if (d8 > thr) rescan = false; }                       // nothing acceptable is left: no claim
                         else if (best > thr) rescan = false;                                      // (found == 1, need == 2) rejected whatever the second is
                         else if (lm) { if (!((float)best > __fmul_rn(P.lowe_ratio, (float)d8))) { rescan = false; second = d8; second_lvl = -2; } }
                         else if (!(__fmul_rn(P.lowe_ratio, (float)d8) < (float)best)) { rescan = false; second = d8; }
                     }
                     if (rescan) full_list[atomicAdd(&s_full_n, 1)] = q;   // exact rescan below
-                    else { decided = true; if (found > 0 && accept(P, best, best_lvl, second, second_lvl)) new_claim = best_t; }
+                    else { decided = true; if (found > 0 && accept<FAM>(P, best, best_lvl, second, second_lvl)) new_claim = best_t; }
                 }
             }
             __syncthreads();
@@ -755,7 +779,7 @@ __device__ __forceinline__ void match_resolve_body(const MatchProblem& P) {
             if (tid == 0 && P.dbg && nf) atomicAdd(&P.dbg[0], nf);
             for (int f = wv; f < nf; f += 4) {
                 const int fq = full_list[f];
-                const QueryCtx c = make_query(P, fq, b);
+                const QueryCtx c = make_query<FAM>(P, fq, b);
                 const uint4* qd = reinterpret_cast<const uint4*>(P.q_desc + ((size_t)b * P.q_desc_stride + fq) * 32);
                 const uint4 q0 = qd[0], q1 = qd[1];
                 unsigned long long k0 = ~0ull, k1 = ~0ull;
@@ -788,7 +812,7 @@ __device__ __forceinline__ void match_resolve_body(const MatchProblem& P) {
                 } else if (!(c.windowed && c.empty)) {
                     for (int t = lane; t < n; t += 64) {
                         if (taken(t, fq, chunk_start)) continue;
-                        const unsigned long long key = candidate_key(P, c, t, kps, t_desc, t_xr, t_occ, q0, q1);
+                        const unsigned long long key = candidate_key<FAM>(P, c, t, kps, t_desc, t_xr, t_occ, q0, q1);
                         if (key < k0) { k1 = k0; k0 = key; } else if (key < k1) k1 = key;
                     }
                 }
@@ -799,7 +823,7 @@ __device__ __forceinline__ void match_resolve_body(const MatchProblem& P) {
                     if (g0 != ~0ull) {
                         const unsigned second = g1 != ~0ull ? (unsigned)(g1 >> 32) : 256u;
                         const int second_lvl = g1 != ~0ull ? (int)(g1 & 15) : -1;
-                        if (accept(P, (unsigned)(g0 >> 32), (int)(g0 & 15), second, second_lvl))
+                        if (accept<FAM>(P, (unsigned)(g0 >> 32), (int)(g0 & 15), second, second_lvl))
                             nc = use_sorted ? (int)sorted[(g0 >> 4) & 0xffff].t : (int)(((g0 >> 4) & 0xffff) ^ t_flip);
                     }
                     s_claim_tmp[fq - chunk_start] = nc;
@@ -831,12 +855,12 @@ __device__ __forceinline__ void match_resolve_body(const MatchProblem& P) {
     if (tid == 0) s_num = 0;
     for (int i = tid; i < 32; i += 256) { s_hist[i] = 0; s_valid_bin[i] = 0; }
     __syncthreads();
-    const bool angle_check = P.check_orientation && (P.mode == PLP_MATCH_MODE_LAST_FRAME || P.mode == PLP_MATCH_MODE_BRUTE_FORCE || is_group_mode(P.mode));
+    const bool angle_check = P.check_orientation && (mode == PLP_MATCH_MODE_LAST_FRAME || mode == PLP_MATCH_MODE_BRUTE_FORCE || is_group_mode(mode));
     const float* q_angle = P.q_angle ? P.q_angle + (size_t)b * P.m_cap : nullptr;
     const float* t_angle = P.t_angle ? P.t_angle + (size_t)b * P.n_cap : nullptr;
     auto bin_of = [&](int q, int t) -> int {
         const float ta = kps ? kps[t].angle : t_angle[t];
-        float delta = (P.mode == PLP_MATCH_MODE_LAST_FRAME || is_group_mode(P.mode)) ? __fsub_rn(q_angle[q], ta) : __fsub_rn(ta, q_angle[q]);
+        float delta = (mode == PLP_MATCH_MODE_LAST_FRAME || is_group_mode(mode)) ? __fsub_rn(q_angle[q], ta) : __fsub_rn(ta, q_angle[q]);
         if (delta < 0.0) delta = (float)((double)delta + 360.0);
         if (360.0 <= delta) delta = (float)((double)delta - 360.0);
         // angles outside [0, 360) can leave delta negative: the reference throws there (angle_histogram_.at(bin)); here such a
@@ -873,8 +897,9 @@ __device__ __forceinline__ void match_resolve_body(const MatchProblem& P) {
 }
 // two kernels around the one body: the sorted instantiation is the hot one (point matchers of every frame) and is held to 128 registers
 // (4 waves per SIMD beside its 24 KB of LDS); the generic one carries every mode's gates and takes the registers it needs instead of spilling
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_match_resolve_sorted(MatchProblem P) { match_resolve_body<true>(P); }
-__global__ __launch_bounds__(256) void k_match_resolve_generic(MatchProblem P) { match_resolve_body<false>(P); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_match_resolve_sorted(MatchProblem P) { match_resolve_body<true, kFamGrid>(P); }
+template <int FAM>
+__global__ __launch_bounds__(256) void k_match_resolve_generic(MatchProblem P) { match_resolve_body<false, FAM>(P); }
 
 // ------------------------------------------------------------------------------------------
 // K16  full Hamming matrix: dist[q][t] (u16), 64 x 64 tile per workgroup, descriptors staged in LDS.
@@ -1028,6 +1053,7 @@ void launch_match(hipStream_t st, const MatchProblem& P, int B) {
     Q.sorted_valid = 0;
     const bool windowed = P.mode == PLP_MATCH_MODE_LANDMARKS || P.mode == PLP_MATCH_MODE_LAST_FRAME;
     const bool line = is_line_mode_host(P.mode) || P.mode == PLP_MATCH_MODE_BOW || P.mode == PLP_MATCH_MODE_TRIANGULATION;
+    const int fam = is_line_mode_host(P.mode) ? kFamLine : (P.mode == PLP_MATCH_MODE_BOW || P.mode == PLP_MATCH_MODE_TRIANGULATION) ? kFamGroup : kFamPoint;
     const size_t staged = windowed ? (size_t)P.n_cap * (P.t_x_right ? 16 : 12) + 2 * kCellStride : (size_t)P.n_cap * 32;
     const dim3 qgrid((P.m_cap + kQueriesPerBlock - 1) / kQueriesPerBlock, B);
     if (!line && windowed && staged <= 64 * 1024 && P.grid_cols <= 255 && P.grid_rows <= 255) {
@@ -1039,11 +1065,23 @@ void launch_match(hipStream_t st, const MatchProblem& P, int B) {
         hipLaunchKernelGGL(k_match_topk_lds, qgrid, dim3(256), staged, st, P);
     } else {
         const int gx_full = (P.m_cap + 3) / 4, gx_min = std::max(16, (8192 + B - 1) / B);   // keep >= ~8K workgroups in flight
-        if (P.n_cap <= 512 && B >= 64) hipLaunchKernelGGL(k_match_topk_lanes, dim3((P.m_cap + 63) / 64, B), dim3(64), 0, st, P);   // small target sets, many frames
-        else hipLaunchKernelGGL(k_match_topk, dim3(std::min(gx_full, gx_min), B), dim3(256), 0, st, P);
+        if (P.n_cap <= 512 && B >= 64) {   // small target sets, many frames
+            const dim3 g((P.m_cap + 63) / 64, B);
+            if (fam == kFamLine) hipLaunchKernelGGL(k_match_topk_lanes<kFamLine>, g, dim3(64), 0, st, P);
+            else if (fam == kFamGroup) hipLaunchKernelGGL(k_match_topk_lanes<kFamGroup>, g, dim3(64), 0, st, P);
+            else hipLaunchKernelGGL(k_match_topk_lanes<kFamPoint>, g, dim3(64), 0, st, P);
+        } else {
+            const dim3 g(std::min(gx_full, gx_min), B);
+            if (fam == kFamLine) hipLaunchKernelGGL(k_match_topk<kFamLine>, g, dim3(256), 0, st, P);
+            else if (fam == kFamGroup) hipLaunchKernelGGL(k_match_topk<kFamGroup>, g, dim3(256), 0, st, P);
+            else hipLaunchKernelGGL(k_match_topk<kFamPoint>, g, dim3(256), 0, st, P);
+        }
     }
-    if (Q.sorted_valid) hipLaunchKernelGGL(k_match_resolve_sorted, dim3(B), dim3(256), (size_t)P.n_cap * 12, st, Q);
-    else hipLaunchKernelGGL(k_match_resolve_generic, dim3(B), dim3(256), (size_t)P.n_cap * 12, st, Q);
+    const size_t owners = (size_t)P.n_cap * 12;
+    if (Q.sorted_valid) hipLaunchKernelGGL(k_match_resolve_sorted, dim3(B), dim3(256), owners, st, Q);
+    else if (fam == kFamLine) hipLaunchKernelGGL(k_match_resolve_generic<kFamLine>, dim3(B), dim3(256), owners, st, Q);
+    else if (fam == kFamGroup) hipLaunchKernelGGL(k_match_resolve_generic<kFamGroup>, dim3(B), dim3(256), owners, st, Q);
+    else hipLaunchKernelGGL(k_match_resolve_generic<kFamPoint>, dim3(B), dim3(256), owners, st, Q);
 }
 
 // up to 8192 targets: 96 KB of owner arrays.  The attribute belongs to the function ON THE CURRENT DEVICE: called by
@@ -1051,7 +1089,12 @@ void launch_match(hipStream_t st, const MatchProblem& P, int B) {
 hipError_t configure_match_kernels() {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_match_resolve_sorted), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 12);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_match_resolve_generic), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 12);
+    for (const void* f : {reinterpret_cast<const void*>(k_match_resolve_generic<kFamLine>), reinterpret_cast<const void*>(k_match_resolve_generic<kFamGroup>),
+                          reinterpret_cast<const void*>(k_match_resolve_generic<kFamPoint>)}) {
+        const hipError_t e2 = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 12);
+        if (e2 != hipSuccess) return e2;
+    }
+    return hipSuccess;
 }
 
 void launch_hamming_matrix(hipStream_t st, const uint8_t* q, int nq, const uint8_t* t, int nt, uint16_t* dist) {

@@ -1,0 +1,66 @@
+"""What the compiler allotted to every kernel of libplp_front.so (csrc/build/*.remarks, written by the Makefile with
+-Rpass-analysis=kernel-resource-usage): no kernel of the library may use scratch memory (the generic matcher kernels kept
+a 36 / 68-byte frame and spilled 81-125 scalar registers until they were instantiated per family of modes), and the register / LDS
+footprints that DESIGN.md section 6 argues with (how many waves of a kernel fit beside two region growers per SIMD) are what the build has."""
+import glob
+import os
+import re
+
+import pytest
+
+BUILD = os.path.join(os.path.dirname(__file__), "..", "structure-plp-slam_amd", "csrc", "build")
+
+
+def kernels():
+    out = {}
+    for path in glob.glob(os.path.join(BUILD, "*.remarks")):
+        name = None
+        for line in open(path, errors="replace"):
+            m = re.search(r"remark: (?:[^:]+:\d+:\d+: )?\s*Function Name: (\S+)", line) or re.search(r"Function Name: (\S+)", line)
+            if m:
+                name = m.group(1)
+                out[name] = {"file": os.path.basename(path)}
+                continue
+            m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", line)
+            if m and name:
+                out[name][m.group(1).strip()] = int(m.group(2))
+    return out
+
+
+K = kernels()
+needs_build = pytest.mark.skipif(not K, reason="csrc/build/*.remarks absent: run __graft_entry__.build() (make) first")
+
+
+def find(sub):
+    hits = [v for k, v in K.items() if sub in k]
+    assert hits, sub
+    return hits
+
+
+@needs_build
+def test_every_kernel_was_seen_and_none_uses_scratch():
+    assert len(K) >= 45, sorted(K)
+    bad = {k: v["ScratchSize"] for k, v in K.items() if v.get("ScratchSize", 0) != 0}
+    assert not bad, bad
+    assert not {k: v["VGPRs Spill"] for k, v in K.items() if v.get("VGPRs Spill", 0)}, "vector registers spilled"
+
+
+@needs_build
+def test_footprints_the_design_argues_with():
+    # beside two growers per SIMD (2 x 147 -> 2 x 152 allotted of 512 VGPRs): 208 registers left
+    (grow,) = find("k_lsd_growENS")
+    assert grow["VGPRs"] <= 152, grow
+    (mw,) = find("k_lsd_grow_mw")
+    assert mw["VGPRs"] <= 176, mw                 # eight waves of a workgroup on four SIMDs: 2 x 176 <= 512
+    (cells,) = find("k_match_topk_cells")
+    assert cells["VGPRs"] <= 72, cells            # two waves beside the growers (was 97: one)
+    (prep,) = find("k_match_prep")
+    assert prep["LDS Size"] <= 34 * 1024, prep    # two workgroups in the 75 KB the growers leave on a CU (was 41 KB: one)
+    (srt,) = find("k_match_resolve_sorted")
+    assert srt["VGPRs"] <= 128, srt
+    for name in ("k_fast_cells", "k_blur7", "k_orient_rbrief", "k_quadtree", "k_lbd"):
+        for k in find(name):
+            assert k["VGPRs"] <= 80, (name, k)
+    # the per-family instantiations of the generic matcher kernels exist (line, group, point)
+    for name in ("k_match_topk_lanesILi", "k_match_topkILi", "k_match_resolve_genericILi"):
+        assert len(find(name)) == 3, name
