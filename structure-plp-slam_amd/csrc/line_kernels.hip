@@ -767,7 +767,13 @@ __device__ void centroid_sums(const GrowCtx& g, int nreg, double cen[3]) {
 #ifndef PLP_GROW_MIN_WAVES      // experiment knob: waves per SIMD the register allocation must allow (4 = at most 128 VGPRs)
 #define PLP_GROW_MIN_WAVES 1
 #endif
+#ifndef PLP_GROW_PRIO           // wave priority of the region growers (s_setprio 0..3): their dependent chains are the critical path of the line streams
+#define PLP_GROW_PRIO 0
+#endif
 __global__ __launch_bounds__(256, PLP_GROW_MIN_WAVES) void k_lsd_grow(LinePlanes P, LsdParams lp, int B, int wpb, int ring) {
+#if PLP_GROW_PRIO > 0
+    __builtin_amdgcn_s_setprio(PLP_GROW_PRIO);
+#endif
     extern __shared__ __attribute__((aligned(16))) uint32_t s_bits[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int b = blockIdx.x * wpb + wv;

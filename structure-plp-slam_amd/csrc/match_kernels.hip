@@ -157,6 +157,28 @@ __device__ __forceinline__ QueryCtx make_query(const MatchProblem& P, int q, int
     return c;
 }
 
+// What the two projection line matchers test of a target key line (data::get_keylines_in_cell, common.cc:315-363, + projection.cc:138-144,
+// :429-450), on the target's fields alone: candidate_key() fills them from memory, k_match_topk_lanes from a register broadcast.
+struct LineTarget { float sx, sy, ex, ey; int octave; bool occ; float xr, xr2; unsigned kp_oct; };
+template <int FAM = kFamAny>
+__device__ __forceinline__ bool line_gate(const MatchProblem& P, const QueryCtx& c, const LineTarget& T, bool has_xr) {
+    const int mode = fam_mode<FAM>(P.mode);
+    const float dsp = (float)(((double)T.sx * c.l0 + (double)T.sy * c.l1 + c.l2) / c.lden);
+    const float dep = (float)(((double)T.ex * c.l0 + (double)T.ey * c.l1 + c.l2) / c.lden);
+    if (fabsf(dsp) > c.mg || fabsf(dep) > c.mg) return false;
+    const bool check_level = (0 < c.min_level) || (0 <= c.max_level);
+    if (check_level) {
+        if (T.octave < c.min_level) return false;
+        if (c.max_level > 0 && T.octave > c.max_level) return false;   // `max_level > 0` as the reference (common.cc:354)
+    }
+    if (T.occ) return false;
+    if (mode == PLP_MATCH_MODE_LAST_FRAME_LINE && P.is_rgbd && has_xr && P.t_x_right2) {
+        const float a = T.xr, b2 = T.xr2;
+        if (a > 0 && b2 > 0 && (c.mg < fabsf(__fsub_rn(c.xr, a)) || c.mg < fabsf(__fsub_rn(c.xr2, b2)))) return false;
+    }
+    return true;
+}
+
 template <int FAM = kFamAny>
 __device__ __forceinline__ unsigned long long candidate_key(const MatchProblem& P, const QueryCtx& c, int t, const plp_keypoint* kps,
                                                            const uint8_t* t_desc, const float* t_xr, const uint8_t* t_occ,
@@ -186,30 +208,29 @@ __device__ __forceinline__ unsigned long long candidate_key(const MatchProblem& 
             if (!(residual_rad < c.thr)) return ~0ull;
             return ((unsigned long long)dist << 32) | ((unsigned long long)(0xffffu - (unsigned)t) << 4);   // ties: the later candidate
         }
+    } else if (c.line && mode != PLP_MATCH_MODE_FUSE_LINE) {
+        const size_t tb = (size_t)(t_desc - P.t_desc) / 32;   // per-problem target offset
+        const plp_keyline kl = P.t_kl[tb + t];
+        LineTarget T;
+        T.sx = kl.startPointX; T.sy = kl.startPointY; T.ex = kl.endPointX; T.ey = kl.endPointY; T.octave = kl.octave;
+        T.occ = t_occ && t_occ[t];
+        T.xr = t_xr ? t_xr[t] : 0.f; T.xr2 = P.t_x_right2 ? P.t_x_right2[tb + t] : 0.f;
+        T.kp_oct = P.t_kp_octave ? ((unsigned)P.t_kp_octave[tb + t] & 15u) : 0u;
+        if (!line_gate<FAM>(P, c, T, t_xr != nullptr)) return ~0ull;
+        oct = T.kp_oct;
     } else if (c.line) {
         const size_t tb = (size_t)(t_desc - P.t_desc) / 32;   // per-problem target offset
         const plp_keyline kl = P.t_kl[tb + t];
         const float dsp = (float)(((double)kl.startPointX * c.l0 + (double)kl.startPointY * c.l1 + c.l2) / c.lden);
         const float dep = (float)(((double)kl.endPointX * c.l0 + (double)kl.endPointY * c.l1 + c.l2) / c.lden);
         if (fabsf(dsp) > c.mg || fabsf(dep) > c.mg) return ~0ull;
-        if (mode == PLP_MATCH_MODE_FUSE_LINE) {   // fuse.cc:440-451, f64
+        {   // fuse.cc:440-451, f64
             const double e_sp = ((double)kl.startPointX * c.g0 + (double)kl.startPointY * c.g1 + c.g2) / c.gden;
             const double e_ep = ((double)kl.endPointX * c.g0 + (double)kl.endPointY * c.g1 + c.g2) / c.gden;
             if ((double)5.99146f < (e_sp * e_sp + e_ep * e_ep) * (double)P.inv_level_sigma_sq[(unsigned)kl.octave & 15]) return ~0ull;
             const uint4* d = reinterpret_cast<const uint4*>(t_desc + 32 * (size_t)t);
             return ((unsigned long long)hamming256(q0, q1, d[0], d[1]) << 32) | ((unsigned long long)(unsigned)t << 4);
         }
-        const bool check_level = (0 < c.min_level) || (0 <= c.max_level);
-        if (check_level) {
-            if (kl.octave < c.min_level) return ~0ull;
-            if (c.max_level > 0 && kl.octave > c.max_level) return ~0ull;   // `max_level > 0` as the reference (common.cc:354)
-        }
-        if (t_occ && t_occ[t]) return ~0ull;
-        if (mode == PLP_MATCH_MODE_LAST_FRAME_LINE && P.is_rgbd && t_xr && P.t_x_right2) {
-            const float a = t_xr[t], b2 = P.t_x_right2[tb + t];
-            if (a > 0 && b2 > 0 && (c.mg < fabsf(__fsub_rn(c.xr, a)) || c.mg < fabsf(__fsub_rn(c.xr2, b2)))) return ~0ull;
-        }
-        oct = P.t_kp_octave ? ((unsigned)P.t_kp_octave[tb + t] & 15u) : 0u;
     } else if (c.windowed) {
         const plp_keypoint k = kps[t];
         const int cx = floor_d((double)__fsub_rn(k.x, P.grid_min_x) * P.inv_cell_w);
@@ -330,30 +351,73 @@ __global__ __launch_bounds__(64) void k_match_topk_lanes(MatchProblem P) {
     corun_priority();
     const int b = blockIdx.y, q = blockIdx.x * 64 + threadIdx.x;
     const int m = P.q_counts ? min(P.q_counts[b], P.m_cap) : P.m_cap;
-    if (q >= m) return;
+    if ((int)blockIdx.x * 64 >= m) return;   // the whole wave
+    // a lane without a query stays (the line family's loop below has every lane fetch one TARGET per chunk): `active` gates its query work
+    bool active = q < m;
     uint32_t* klist = P.klist + ((size_t)b * P.m_cap + q) * kMatchK;
     int32_t* kcount = P.kcount + (size_t)b * P.m_cap + q;
     const uint8_t* q_valid = P.q_valid ? P.q_valid + (size_t)b * P.m_cap : nullptr;
-    if (q_valid && !q_valid[q]) { *kcount = -1; return; }
+    if (active && q_valid && !q_valid[q]) { *kcount = -1; active = false; }
+    if constexpr (FAM != kFamLine) { if (!active) return; }
     const int n = P.t_counts ? min(P.t_counts[b], P.n_cap) : P.n_cap;
     const plp_keypoint* kps = P.t_kps ? P.t_kps + (size_t)b * P.n_cap : nullptr;
     const uint8_t* t_desc = P.t_desc + (size_t)b * P.n_cap * 32;
     const float* t_xr = P.t_x_right ? P.t_x_right + (size_t)b * P.n_cap : nullptr;
     const uint8_t* t_occ = P.t_occupied ? P.t_occupied + (size_t)b * P.n_cap : nullptr;
-    const QueryCtx c = make_query<FAM>(P, q, b);
-    const uint4* qd = reinterpret_cast<const uint4*>(P.q_desc + ((size_t)b * P.q_desc_stride + q) * 32);
-    const uint4 q0 = qd[0], q1 = qd[1];
+    QueryCtx c{};
+    uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0;
+    if (active) {
+        c = make_query<FAM>(P, q, b);
+        const uint4* qd = reinterpret_cast<const uint4*>(P.q_desc + ((size_t)b * P.q_desc_stride + q) * 32);
+        q0 = qd[0]; q1 = qd[1];
+    }
     unsigned long long top[kMatchK];
 #pragma unroll
     for (int i = 0; i < kMatchK; ++i) top[i] = ~0ull;
     int passed = 0;
-    if (!(c.windowed && c.empty))
+    if constexpr (FAM == kFamLine) {
+        // The gates read ~9 fields of the target key line: fetched inside the loop they were five DEPENDENT scalar round trips per target
+        // (start point -> end point -> octave -> occupancy -> descriptor ...), ~2 us each beside a busy chip.  Here lane j fetches the
+        // fields of target base + j once (all loads of a lane in flight together), and the loop over the targets hands them to all lanes
+        // with v_readlane (t is uniform): no memory access per target except the descriptor of one that passed the gates.
+        const size_t tb = (size_t)b * P.n_cap;
+        const int lane = threadIdx.x;
+        for (int base = 0; base < n; base += 64) {
+            const int tj = base + lane;
+            float f_sx = 0.f, f_sy = 0.f, f_ex = 0.f, f_ey = 0.f, f_xr = 0.f, f_xr2 = 0.f;
+            int f_misc = 0;                                   // octave << 8 | occupied << 4 | key-point octave
+            if (tj < n) {
+                const plp_keyline* kl = P.t_kl + tb + tj;
+                f_sx = kl->startPointX; f_sy = kl->startPointY; f_ex = kl->endPointX; f_ey = kl->endPointY;
+                const int occ = t_occ && t_occ[tj];
+                const unsigned kpo = P.t_kp_octave ? ((unsigned)P.t_kp_octave[tb + tj] & 15u) : 0u;
+                f_misc = (int)(((unsigned)kl->octave << 8) | ((unsigned)occ << 4) | kpo);
+                if (t_xr) f_xr = t_xr[tj];
+                if (P.t_x_right2) f_xr2 = P.t_x_right2[tb + tj];
+            }
+            const int m_chunk = min(64, n - base);
+            for (int u = 0; u < m_chunk; ++u) {
+                auto bc_f = [&](float v) -> float { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), u)); };
+                LineTarget T;
+                T.sx = bc_f(f_sx); T.sy = bc_f(f_sy); T.ex = bc_f(f_ex); T.ey = bc_f(f_ey); T.xr = bc_f(f_xr); T.xr2 = bc_f(f_xr2);
+                const int misc = __builtin_amdgcn_readlane(f_misc, u);
+                T.octave = misc >> 8; T.occ = (misc >> 4) & 1; T.kp_oct = (unsigned)misc & 15u;   // octave: arithmetic shift keeps the sign
+                if (!active || !line_gate<FAM>(P, c, T, t_xr != nullptr)) continue;
+                const int t = base + u;
+                const uint4* d = reinterpret_cast<const uint4*>(t_desc + 32 * (size_t)t);
+                const unsigned dist = hamming256(q0, q1, d[0], d[1]);
+                ++passed;
+                topk_insert(top, ((unsigned long long)dist << 32) | ((unsigned long long)(unsigned)t << 4) | T.kp_oct);
+            }
+        }
+    } else if (!(c.windowed && c.empty))
         for (int t = 0; t < n; ++t) {
             const unsigned long long key = candidate_key<FAM>(P, c, t, kps, t_desc, t_xr, t_occ, q0, q1);
             if (key == ~0ull) continue;
             ++passed;
             topk_insert(top, key);
         }
+    if (!active) return;
 #pragma unroll
     for (int r = 0; r < kMatchK; ++r) klist[r] = pack_key(top[r]);
     *kcount = passed;

@@ -9,6 +9,7 @@
 //   4. per node: maximum score, ties to the smallest candidate index
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 
 #include "orb_device.hpp"
 #include "plp_common.hpp"
@@ -194,11 +195,14 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelDev* __restrict__ l
             unsigned d = 16;
             uint32_t id = 0;
             if (i < n) { id = first ? (uint32_t)i : src[i]; d = (key[id] >> shift) & 15u; }
-            unsigned long long mybal = 0;
+            // the lanes holding the same digit as this one (d = 16: the lanes past the end), from one ballot per BIT of d; selecting the
+            // lane's own of sixteen per-value ballots had cost 30 registers for their copies (the kernel's register peak)
+            unsigned long long mybal = ~0ull;
 #pragma unroll
-            for (unsigned v = 0; v < 16; ++v) {
-                const unsigned long long bal = __ballot(d == v);
-                if (d == v) mybal = bal;
+            for (unsigned bit = 0; bit < 5; ++bit) {
+                const bool one = (d >> bit) & 1u;
+                const unsigned long long bal = __ballot(one);
+                mybal &= one ? bal : ~bal;
             }
             if (i < n) dst[(uint32_t)CNT[d * nseg + seg] + (uint32_t)__popcll(mybal & ((1ull << lane) - 1ull))] = id;
         }
@@ -406,8 +410,9 @@ size_t quadtree_scratch_bytes_per_frame(const LevelDev* h_lv, int n_levels) {
 void launch_quadtree(hipStream_t st, const LevelDev* d_lv, int n_levels, int n_cells_total, const uint32_t* cell_cand,
                      const int32_t* cell_count, int32_t* sel, int32_t* sel_count, int total_sel_cap, uint32_t* qt_scratch,
                      size_t qt_scratch_frame_stride, int32_t* status, int B, int max_quota) {
-    int mn = 256;
-    while (mn < 3 * max_quota + 8 && mn < kQtMaxNodes) mn *= 2;
+    // node arrays for 3 * quota + 8 entries (the bound of the lists, see QtShared), rounded to 8: at K = 1000 (quota 217) 25.5 KB, so that THREE
+    // workgroups fit the 77 KB two region-growing workgroups leave on a CU (rounded to a power of two it was 34.9 KB: two)
+    const int mn = std::min(kQtMaxNodes, std::max(256, (3 * max_quota + 8 + 7) / 8 * 8));
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)qt_lds_bytes(kQtMaxNodes)); attr_set = true; }
     hipLaunchKernelGGL(k_quadtree, dim3(n_levels, B), dim3(256), qt_lds_bytes(mn), st, d_lv, n_cells_total, cell_cand, cell_count, sel,
