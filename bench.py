@@ -34,6 +34,9 @@ for p in (str(ROOT), str(ROOT / "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# A hardware queue per stream (the runtime's default is four; the PCIe-inclusive pass drives seven streams, the resident step four: the resident
+# number does not move with this setting, profiles/r03_scheduling_experiments.md).  Read by the HIP runtime when it initialises: set before torch.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import numpy as np
 import torch
 
@@ -82,6 +85,7 @@ def main():
     ap.add_argument("--cols", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the PCIe-inclusive pass and the single-frame latency pass (profiling runs)")
+    ap.add_argument("--no-latency", action="store_true", help="two calls instead of 256 in the single-frame latency pass")
     ap.add_argument("--orb-only", action="store_true", help="time the ORB extractor alone (config 1 shape)")
     ap.add_argument("--verify", type=int, default=64, help="after the timed region: re-derive N frames of the last step (features and the four matcher "
                     "results) with the CPU oracle and compare (0 = off; rank 0, N = 1 only)")
@@ -242,7 +246,8 @@ def main():
     if not args.no_extras and not args.orb_only and world == 1:
         h_frames = torch.empty((B, args.rows, args.cols), dtype=torch.uint8, pin_memory=True)
         h_frames.copy_(d_frames.cpu())
-        stage = [torch.empty_like(d_frames) for _ in range(2)]
+        n_stage = max(2, int(os.environ.get("PLP_BENCH_STAGES", "2")))
+        stage = [torch.empty_like(d_frames) for _ in range(n_stage)]
         # What comes back: the features that exist, not the capacity they were allotted (the reference's extract() hands back vectors of exactly
         # that many entries).  Per step the live rows of every padded array are packed on the device (plp_pack_rows_device: offsets = prefix
         # sum of the per-frame counts) and the device-to-host copies move exactly offsets[B] rows; their sizes are known on the host one
@@ -258,7 +263,7 @@ def main():
         small = lambda buf: [cnt2[buf][HALO:], lcnt2[buf][HALO:], n1, n2, n3, n4]
         h_small = [[torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in small(0)] for _ in range(NBUF)]
         sH, sD, sD2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev)
-        stage_free = [None, None]; down_done = [None] * NBUF; ev_off = [None] * NBUF
+        stage_free = [None] * n_stage; down_done = [None] * NBUF; ev_off = [None] * NBUF
         frames_default = d_frames
         d2h_bytes = []
 
@@ -279,13 +284,18 @@ def main():
 
         pending = []
 
+        # The next step's upload is enqueued before the host waits for this step's offsets (PLP_BENCH_PREFETCH=0: at the start of its own step).
+        # This pass drives seven streams: on the runtime's default of four hardware queues an 11 ms copy queued early sits in front of another
+        # stream's kernels and the early upload LOSES (31.8 against 28.7 ms per step); with a queue per stream (GPU_MAX_HW_QUEUES=8, set at the top of
+        # this file) it wins (27.7 ms).  profiles/r03_pcie.md
+        prefetch = os.environ.get("PLP_BENCH_PREFETCH", "1") == "1"
         uploaded = {}
 
         def upload(n):
             """enqueue the host-to-device copy of step n's frames (once): it starts as soon as the extractors that last read this staging buffer are through"""
             if n in uploaded:
                 return
-            sb = n % 2
+            sb = n % n_stage
             for ev_ in stage_free[sb] or ():
                 sH.wait_event(ev_)                                           # (the matchers never read pixels)
             with torch.cuda.stream(sH):
@@ -294,7 +304,7 @@ def main():
 
         def host_step(n, last=False):
             nonlocal d_frames
-            sb = n % 2
+            sb = n % n_stage
             upload(n)
             ev = uploaded.pop(n)
             for s_ in [sA] + sBs:
@@ -318,7 +328,7 @@ def main():
                     h.copy_(t, non_blocking=True)
                 ev_off[buf] = torch.cuda.Event(); ev_off[buf].record(sD)
             stage_free[sb] = list(ts.extract_events)
-            if not last:
+            if prefetch and not last:
                 upload(n + 1)                                                # before the host blocks below: the next step's frames travel while this step computes
             while pending:                                                   # the previous step's bulk copy, now that this step keeps the GPU busy
                 finish_download(pending.pop(0))
@@ -367,7 +377,7 @@ def main():
         del h_frames, stage, h_pk, d_pk
         # single-frame latency, 256 calls each, the host-pointer entry points on one frame at a time
         lat = {}
-        n_lat = 256
+        n_lat = 2 if args.no_latency else 256      # --no-latency: a token pass (A/B runs of the PCIe arrangement)
         imgs = [np.ascontiguousarray(frames_np[i % uniq]) for i in range(n_lat)]
 
         def timed(fn):

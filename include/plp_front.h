@@ -354,6 +354,11 @@ typedef struct plp_match_args {
      * frames before it: with q_desc_stride = the per-frame capacity, q_desc may point INTO the batch's own descriptor array (one
      * frame back, m_cap = cap; or two frames back, m_cap = 2 cap: overlapping windows) and no descriptor is copied. */
     int32_t q_desc_stride;
+    /* Performance hint for the windowed point modes (LANDMARKS, LAST_FRAME), 0 = none: an upper bound the caller EXPECTS for t_counts[b]
+     * (a tracker knows its extractor's max_num_keypoints; the arrays are usually strided by a larger capacity n_cap).  The matcher then
+     * keeps only that many targets of a frame in LDS -- more of its workgroups fit a compute unit -- and reads the targets of a frame that
+     * has more from memory: results never depend on the hint. */
+    int32_t t_count_hint;
 } plp_match_args;
 
 /* All array pointers in `a` are DEVICE pointers (except scale_factors); asynchronous on hip_stream. */

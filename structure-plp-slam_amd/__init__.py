@@ -428,7 +428,7 @@ class match_args_c(C.Structure):
                 ("q_group", _VP), ("t_group", _VP), ("q_reproj_d", _VP), ("inv_level_sigma_sq", _VP), ("out_query_best", _VP),
                 ("hamm_dist_thr", C.c_int32), ("level_window", C.c_int32), ("flags", C.c_int32),
                 ("q_reproj2_d", _VP), ("q_bearing", _VP), ("t_bearing", _VP), ("epipolar", _VP),
-                ("out_match", _VP), ("out_num", _VP), ("q_desc_stride", C.c_int32)]
+                ("out_match", _VP), ("out_num", _VP), ("q_desc_stride", C.c_int32), ("t_count_hint", C.c_int32)]
 
 
 MODE_LANDMARKS, MODE_LAST_FRAME, MODE_BRUTE_FORCE, MODE_LANDMARKS_LINE, MODE_LAST_FRAME_LINE, MODE_BOW, MODE_FUSE, MODE_FUSE_LINE, MODE_TRIANGULATION = 0, 1, 2, 3, 4, 5, 6, 7, 8
@@ -464,7 +464,7 @@ class matcher:
         a = match_args_c()
         a.mode, a.B, a.n_cap, a.m_cap = mode, B, n_cap, m_cap
         for k, v in fields.items():
-            if k in ("is_rgbd", "num_levels_lsd", "hamm_dist_thr", "level_window", "flags", "q_desc_stride"):
+            if k in ("is_rgbd", "num_levels_lsd", "hamm_dist_thr", "level_window", "flags", "q_desc_stride", "t_count_hint"):
                 setattr(a, k, int(v))
             elif k == "inv_level_sigma_sq":
                 arr = np.ascontiguousarray(v, np.float32)

@@ -92,6 +92,7 @@ plp_status run_device(plp_matcher* c, const plp_match_args* a, hipStream_t st) {
     P.klist = (uint32_t*)c->klist.p; P.klist2 = (uint32_t*)c->klist2.p; P.kcount = (int32_t*)c->kcount.p; P.claim = (int32_t*)c->claim.p; P.full_list = (int32_t*)c->full_list.p;
     P.sorted = (StagedTarget*)c->sorted.p; P.sorted_xr = (float*)c->sorted_xr.p; P.cell_start = (uint16_t*)c->row_start.p; P.dbg = (int32_t*)c->dbg.p;
     P.out_match = a->out_match; P.out_num = a->out_num;
+    P.lds_targets = a->t_count_hint > 0 ? std::min(a->t_count_hint, a->n_cap) : a->n_cap;
     launch_match(st, P, a->B);
     PLP_HIP(hipGetLastError());
     return PLP_OK;

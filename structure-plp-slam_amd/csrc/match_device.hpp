@@ -62,6 +62,7 @@ struct MatchProblem {
     float* sorted_xr;                // B x n_cap
     uint16_t* cell_start;            // B x 4104: first position of every grid cell in `sorted`
     int sorted_valid;                // set by launch_match when k_match_prep ran
+    int lds_targets;                 // targets of a frame k_match_topk_cells holds in LDS (<= n_cap; plp_match_args.t_count_hint), the rest is read from `sorted`
     int32_t* dbg;                    // 4 counters: exact rescans, resolve rounds (accumulated)
     int32_t* out_match;              // B x n_cap: query index per key point, -1 = none
     int32_t* out_num;                // B

@@ -509,9 +509,9 @@ __global__ __launch_bounds__(256) void k_match_prep(MatchProblem P) {
     for (int i = tid; i <= ncell; i += 256) P.cell_start[(size_t)b * kCellStride + i] = start[min(i, 4096)];
 }
 
-#ifndef PLP_MATCH_LANE_CAND      // 6: most descriptor fetches in flight per lane (97 VGPRs); 3 / 4 with the register cap (72 / 80 VGPRs): two waves per SIMD
-#define PLP_MATCH_LANE_CAND 3    // instead of one beside two region-growing waves (profiles/r03_lsd_grow.md section 3); measured: profiles/r03_scheduling_experiments.md
-#endif
+#ifndef PLP_MATCH_LANE_CAND      // candidates a lane collects before it fetches their descriptors = descriptor fetches in flight per lane.  6: 97 VGPRs, one wave
+#define PLP_MATCH_LANE_CAND 1    // per SIMD beside two region growers; 3: 72, two; 1: 54, three -- and alone the kernel is FASTER with one (the four matcher calls
+#endif                           // 3.84 -> 3.52 ms): its occupancy, not its memory-level parallelism per lane, is what it runs on.  profiles/r03_scheduling_experiments.md
 #if PLP_MATCH_LANE_CAND <= 4
 #define PLP_TOPK_CELLS_BOUNDS __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8)))
 #else
@@ -555,27 +555,35 @@ __global__ PLP_TOPK_CELLS_BOUNDS void k_match_topk_cells(MatchProblem P, int qpb
     const int ncell = P.grid_cols * P.grid_rows, rows = P.grid_rows;
     const uint8_t* t_desc = P.t_desc + (size_t)b * P.n_cap * 32;
     // LDS (12 or 16 bytes per target: beside region growing's 85 KB per CU a 50 KB workgroup fitted only once per CU):
-    //   sxy[n_cap] position, sto[n_cap] = index | octave << 16, sxr[n_cap] stereo coordinate (only if given), cell index
+    //   sxy[nb] position, sto[nb] = index | octave << 16, sxr[nb] stereo coordinate (only if given), cell index
     const bool has_xr = P.t_x_right != nullptr;
+    // The first nb sorted targets of the frame live in LDS (nb = the caller's expected bound of the frame's target count, plp_match_args.
+    // t_count_hint, at most the array capacity n_cap): sized by the capacity -- 2064 slots for frames of ~1000 key points -- the workgroup held
+    // 33 KB and two of them fitted beside the region growers.  A frame with more targets than nb reads the rest from the sorted array in memory.
+    const int nb = P.lds_targets;
     float2* sxy = reinterpret_cast<float2*>(smem);
-    uint32_t* sto = reinterpret_cast<uint32_t*>(smem + (size_t)P.n_cap * 8);
-    float* sxr = reinterpret_cast<float*>(smem + (size_t)P.n_cap * 12);
-    uint16_t* cs = reinterpret_cast<uint16_t*>(smem + (size_t)P.n_cap * (has_xr ? 16 : 12));
+    uint32_t* sto = reinterpret_cast<uint32_t*>(smem + (size_t)nb * 8);
+    float* sxr = reinterpret_cast<float*>(smem + (size_t)nb * 12);
+    uint16_t* cs = reinterpret_cast<uint16_t*>(smem + (size_t)nb * (has_xr ? 16 : 12));
     __shared__ uint16_t s_cand[256 * kLaneCand];
+    const uint4* g_sorted = reinterpret_cast<const uint4*>(P.sorted + (size_t)b * P.n_cap);   // {x, y, octave | cell, index}
+    const float* g_sorted_xr = P.sorted_xr + (size_t)b * P.n_cap;
     {
         const uint16_t* gcs = P.cell_start + (size_t)b * kCellStride;
-        const int used = gcs[ncell];
-        const uint4* src = reinterpret_cast<const uint4*>(P.sorted + (size_t)b * P.n_cap);
+        const int used = min((int)gcs[ncell], nb);
         for (int i = tid; i < used; i += 256) {
-            const uint4 r = src[i];   // {x, y, octave | cell, index}
+            const uint4 r = g_sorted[i];
             sxy[i] = make_float2(__uint_as_float(r.x), __uint_as_float(r.y));
             sto[i] = (r.w & 0xffffu) | ((r.z & 0xffu) << 16);
         }
-        if (has_xr) for (int i = tid; i < used; i += 256) sxr[i] = P.sorted_xr[(size_t)b * P.n_cap + i];
+        if (has_xr) for (int i = tid; i < used; i += 256) sxr[i] = g_sorted_xr[i];
         const uint32_t* g32 = reinterpret_cast<const uint32_t*>(gcs);
         for (int i = tid; i < (ncell + 2) / 2; i += 256) reinterpret_cast<uint32_t*>(cs)[i] = g32[i];
     }
     __syncthreads();
+    auto t_xy = [&](int i) -> float2 { if (i < nb) return sxy[i]; const uint4 r = g_sorted[i]; return make_float2(__uint_as_float(r.x), __uint_as_float(r.y)); };
+    auto t_to = [&](int i) -> uint32_t { if (i < nb) return sto[i]; const uint4 r = g_sorted[i]; return (r.w & 0xffffu) | ((r.z & 0xffu) << 16); };   // index | octave << 16
+    auto t_xr = [&](int i) -> float { return i < nb ? sxr[i] : g_sorted_xr[i]; };
     const uint8_t* q_valid = P.q_valid ? P.q_valid + (size_t)b * P.m_cap : nullptr;
     const int q_end = min(m, q_begin + qpb);
     for (int q = q_begin + tid; q < q_end; q += 256) {
@@ -601,7 +609,7 @@ __global__ PLP_TOPK_CELLS_BOUNDS void k_match_topk_cells(MatchProblem P, int qpb
 #pragma unroll
                     for (int k = 0; k < kLaneCand; ++k)
                         if (k < nc) {
-                            const uint4* d = reinterpret_cast<const uint4*>(t_desc + 32 * (size_t)(sto[my[k]] & 0xffffu));
+                            const uint4* d = reinterpret_cast<const uint4*>(t_desc + 32 * (size_t)(t_to(my[k]) & 0xffffu));
                             d0[k] = d[0]; d1[k] = d[1];
                         }
 #pragma unroll
@@ -627,15 +635,15 @@ __global__ PLP_TOPK_CELLS_BOUNDS void k_match_topk_cells(MatchProblem P, int qpb
                 for (int col = c.min_cx; col <= c.max_cx; ++col) {
                     const int i0 = cs[col * rows + c.min_cy], i1 = cs[col * rows + c.max_cy + 1];
                     for (int i = i0; i < i1; ++i) {
-                        const float2 sp = sxy[i];
+                        const float2 sp = t_xy(i);
                         if (check_level) {
-                            const int oct = (int)(sto[i] >> 16);
+                            const int oct = (int)(t_to(i) >> 16);
                             if (oct < c.min_level) continue;
                             if (0 <= c.max_level && c.max_level < oct) continue;
                         }
                         if (!(fabsf(__fsub_rn(sp.x, c.rx)) < c.mg && fabsf(__fsub_rn(sp.y, c.ry)) < c.mg)) continue;
                         if (has_xr) {
-                            const float xr = sxr[i];
+                            const float xr = t_xr(i);
                             if (0 < xr && c.mg < fabsf(__fsub_rn(c.xr, xr))) continue;
                         }
                         my[nc++] = (uint16_t)i;
@@ -650,7 +658,7 @@ __global__ PLP_TOPK_CELLS_BOUNDS void k_match_topk_cells(MatchProblem P, int qpb
         for (int k = 0; k < kMatchK; ++k) {
             e[k] = 0xffffffffu;
             if (top[k] != 0xffffffffu) {
-                const uint32_t to = sto[top[k] & 0xffffu];
+                const uint32_t to = t_to((int)(top[k] & 0xffffu));
                 e[k] = ((top[k] >> 16) << 20) | (((to >> 16) & 15u) << 16) | (to & 0xffffu);
             }
         }
@@ -664,7 +672,7 @@ __global__ PLP_TOPK_CELLS_BOUNDS void k_match_topk_cells(MatchProblem P, int qpb
             for (int k = 0; k < kMatchK; ++k) {
                 e[k] = 0xffffffffu;
                 if (ovf[k] != 0xffffffffu) {
-                    const uint32_t to = sto[ovf[k] & 0xffffu];
+                    const uint32_t to = t_to((int)(ovf[k] & 0xffffu));
                     e[k] = ((ovf[k] >> 16) << 20) | (((to >> 16) & 15u) << 16) | (to & 0xffffu);
                 }
             }
@@ -1118,7 +1126,7 @@ void launch_match(hipStream_t st, const MatchProblem& P, int B) {
     const bool windowed = P.mode == PLP_MATCH_MODE_LANDMARKS || P.mode == PLP_MATCH_MODE_LAST_FRAME;
     const bool line = is_line_mode_host(P.mode) || P.mode == PLP_MATCH_MODE_BOW || P.mode == PLP_MATCH_MODE_TRIANGULATION;
     const int fam = is_line_mode_host(P.mode) ? kFamLine : (P.mode == PLP_MATCH_MODE_BOW || P.mode == PLP_MATCH_MODE_TRIANGULATION) ? kFamGroup : kFamPoint;
-    const size_t staged = windowed ? (size_t)P.n_cap * (P.t_x_right ? 16 : 12) + 2 * kCellStride : (size_t)P.n_cap * 32;
+    const size_t staged = windowed ? (size_t)P.lds_targets * (P.t_x_right ? 16 : 12) + 2 * kCellStride : (size_t)P.n_cap * 32;
     const dim3 qgrid((P.m_cap + kQueriesPerBlock - 1) / kQueriesPerBlock, B);
     if (!line && windowed && staged <= 64 * 1024 && P.grid_cols <= 255 && P.grid_rows <= 255) {
         hipLaunchKernelGGL(k_match_prep, dim3(B), dim3(256), 0, st, P);

@@ -138,14 +138,6 @@ constexpr int kTileW = 76;            // LDS row pitch of the u8 ROI tile (>= 70
 constexpr int kScoreW = 68;           // 64 tested + 2 zero border, padded
 
 __device__ __forceinline__ int min3(int a, int b, int c) { return min(a, min(b, c)); }
-// OR over the 16 lanes of a DPP row (all lanes active)
-__device__ __forceinline__ uint32_t row16_or(uint32_t v) {
-    v |= (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xf, 0xf, false);   // row_ror:8
-    v |= (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x124, 0xf, 0xf, false);   // row_ror:4
-    v |= (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x122, 0xf, 0xf, false);   // row_ror:2
-    v |= (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x121, 0xf, 0xf, false);   // row_ror:1
-    return v;
-}
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fast_cells(OrbPlanes pl, const CellDesc* __restrict__ cells,
                                                     const LevelDev* __restrict__ lv, int ini_thr, int min_thr,
@@ -193,32 +185,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     {
         const int a0 = cd.min_x - 1;                 // image column of tile column 0
         const int sh = a0 & 3;
-        const int ndw = (w + 2 + 3) >> 2;            // tile columns 0 .. w + 1: at most 19 dwords
+        const int ndw = (w + 2 + 3) >> 2;            // tile columns 0 .. w + 1
         const uint8_t* row0 = img + (size_t)cd.min_y * pitch + (a0 - sh);
-        // thread = (dword column tid & 31, rows tid >> 5 + 8 k): no division, and all of a thread's loads are issued before its first LDS
-        // write (a loop of load -> shift -> store had five dependent round trips to HBM / L2 at the head of every workgroup)
-        const int c = tid & 31, r0 = tid >> 5;
-        const bool col = c < ndw;
-        const uint32_t off0 = (uint32_t)(r0 * pitch + 4 * c), step = (uint32_t)(8 * pitch);   // 32-bit offsets from the uniform row0
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {       // two batches (5 + 4 rows): nine loads in flight cost more registers than the kernel has
-            constexpr int NR = 5;
-            uint32_t lo[NR], hi[NR];
-#pragma unroll
-            for (int k = 0; k < NR; ++k) {
-                const int kk = NR * half + k, r = r0 + 8 * kk;
-                lo[k] = 0; hi[k] = 0;
-                if (kk < 9 && col && r < h) {
-                    const uint32_t* g = reinterpret_cast<const uint32_t*>(row0 + (off0 + (uint32_t)kk * step));
-                    lo[k] = g[0];
-                    if (sh) hi[k] = g[1];
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < NR; ++k) {
-                const int kk = NR * half + k, r = r0 + 8 * kk;
-                if (kk < 9 && col && r < h) *reinterpret_cast<uint32_t*>(&tile[r * kTileW + 4 * c]) = sh ? __builtin_amdgcn_alignbyte(hi[k], lo[k], (uint32_t)sh) : lo[k];
-            }
+        for (int i = tid; i < ndw * h; i += 256) {
+            const int r = i / ndw, c = i - r * ndw;
+            const uint32_t* g = reinterpret_cast<const uint32_t*>(row0 + (size_t)r * pitch + 4 * c);
+            const uint32_t lo = g[0];
+            const uint32_t v = sh ? __builtin_amdgcn_alignbyte(g[1], lo, (uint32_t)sh) : lo;
+            *reinterpret_cast<uint32_t*>(&tile[r * kTileW + 4 * c]) = v;
         }
     }
     const int tw = w - 6, th = h - 6;   // tested interior (ROI x,y in [3, w-3) x [3, h-3))
@@ -229,114 +203,64 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     for (int attempt = 0; attempt < 2; ++attempt) {
         thr = attempt == 0 ? ini_thr : min_thr;
         for (int i = tid; i < 66 * kScoreW / 4; i += 256) reinterpret_cast<uint32_t*>(score)[i] = 0;
-        if (tid < 64) { keepbits[tid] = 0ull; bits2[tid] = 0ull; }   // bits1: pass 1 stores every row
+        if (tid < 64) { keepbits[tid] = 0ull; bits1[tid] = 0ull; bits2[tid] = 0ull; }
         if (tid == 0) { q_count = 0; q2_count = 0; n_ini = 0; run_base = 0; }
         __syncthreads();
-        // pass 1: every arc of 9 contains two neighbouring compass pixels (0, 4, 8, 12): five dword reads serve four positions and reject
-        // most of them.  The four positions are tested at once as two pairs of 16-bit lanes (gfx950 has packed i16 arithmetic, no packed
-        // compares): bytes 0 / 2 of a dword go to the "even" pair, bytes 1 / 3 to the "odd" pair (one v_perm each); p > v + thr is the sign
-        // of (v + thr) - p, p < v - thr the sign of p - (v - thr); the signs are OR-ed / AND-ed as whole words.  Survivors are NOT pushed one
-        // by one (that was two LDS atomics per survivor, 32 divergent bodies per thread and ~500 same-address atomics per cell): a row's
-        // 64-bit mask is the OR over the 16 lanes that own the row (DPP, plain store), and the queue slots of a wave's survivors of all four
-        // rounds come from ONE atomic add per wave (lane prefix sums from five ballots of the per-lane counts).
-        {
-            typedef short v2s __attribute__((ext_vector_type(2)));
-            const v2s thr2 = {(short)thr, (short)thr};
-            uint32_t f16 = 0;                        // bit 4 * round + k: position k of this thread's group of that round survives
-#pragma unroll 1   // unrolled, the four rounds' addresses were hoisted out of the attempt loop and lived (spilled) through pass 3
-            for (int it = 0; it < 4; ++it) {         // 64 rows x 16 groups of 4 positions = 4 rounds of 256 threads
-                const int i = tid + 256 * it;
-                const int ty = i >> 4, tx4 = (i & 15) * 4;
-                // rows ty, ty + 3, ty + 6 <= 69 and dwords up to byte 71 are inside the tile array for every i; what lies outside the
-                // ROI is masked below
-                const uint32_t* rowc = reinterpret_cast<const uint32_t*>(&tile[(ty + 3) * kTileW]) + (tx4 >> 2);
-                const uint32_t C = rowc[1], Lw = rowc[0], Rw = rowc[2];
-                const uint32_t Lq = __builtin_amdgcn_alignbyte(C, Lw, 1u);     // columns -3 of the four positions
-                const uint32_t Rq = __builtin_amdgcn_alignbyte(Rw, C, 3u);     // columns +3
-                const uint32_t U = *(reinterpret_cast<const uint32_t*>(&tile[ty * kTileW]) + (tx4 >> 2) + 1);          // row -3
-                const uint32_t D = *(reinterpret_cast<const uint32_t*>(&tile[(ty + 6) * kTileW]) + (tx4 >> 2) + 1);    // row +3
-                uint32_t flags[2];
+        // pass 1: every arc of 9 contains two neighbouring compass pixels (0, 4, 8, 12): five dword reads serve four
+        // positions and reject most of them
+        for (int i = tid; i < 1024; i += 256) {   // 64 rows x 16 groups of 4 positions
+            const int ty = i >> 4, tx4 = (i & 15) * 4;
+            if (tx4 >= tw || ty >= th) continue;
+            const uint32_t* rowc = reinterpret_cast<const uint32_t*>(&tile[(ty + 3) * kTileW]) + (tx4 >> 2);
+            const uint32_t C = rowc[1], Lw = rowc[0], Rw = rowc[2];
+            const uint32_t Lq = __builtin_amdgcn_alignbyte(C, Lw, 1u);     // columns -3 of the four positions
+            const uint32_t Rq = __builtin_amdgcn_alignbyte(Rw, C, 3u);     // columns +3
+            const uint32_t U = *(reinterpret_cast<const uint32_t*>(&tile[ty * kTileW]) + (tx4 >> 2) + 1);          // row -3
+            const uint32_t D = *(reinterpret_cast<const uint32_t*>(&tile[(ty + 6) * kTileW]) + (tx4 >> 2) + 1);    // row +3
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const uint32_t sel = half ? 0x0c030c01u : 0x0c020c00u;     // bytes {1, 3} or {0, 2} of the source, zero-extended to 16 bits
-                    auto lanes = [&](uint32_t x) -> v2s { return __builtin_bit_cast(v2s, __builtin_amdgcn_perm(0u, x, sel)); };
-                    auto bits = [](v2s x) -> uint32_t { return __builtin_bit_cast(uint32_t, x); };
-                    const v2s v = lanes(C), hi = v + thr2, lo = v - thr2;
-                    const v2s p0 = lanes(D), p4 = lanes(Rq), p8 = lanes(U), p12 = lanes(Lq);
-                    const uint32_t b08 = bits(hi - p0) | bits(hi - p8), b412 = bits(hi - p4) | bits(hi - p12);
-                    const uint32_t d08 = bits(p0 - lo) | bits(p8 - lo), d412 = bits(p4 - lo) | bits(p12 - lo);
-                    flags[half] = (b08 & b412) | (d08 & d412);                // bit 15 / bit 31: the 16-bit lane's position survives
+            for (int k = 0; k < 4; ++k) {
+                if (tx4 + k >= tw) break;
+                const int v = (int)((C >> (8 * k)) & 255u);
+                const int hi = v + thr, lo = v - thr;
+                const int p0 = (int)((D >> (8 * k)) & 255u), p4 = (int)((Rq >> (8 * k)) & 255u), p8 = (int)((U >> (8 * k)) & 255u),
+                          p12 = (int)((Lq >> (8 * k)) & 255u);
+                const bool b0 = p0 > hi, b4 = p4 > hi, b8 = p8 > hi, b12 = p12 > hi;
+                const bool d0 = p0 < lo, d4 = p4 < lo, d8 = p8 < lo, d12 = p12 < lo;
+                if (((b0 | b8) & (b4 | b12)) | ((d0 | d8) & (d4 | d12))) {
+                    atomicOr(&bits1[ty], 1ull << (tx4 + k));
+                    const int slot = atomicAdd(&q_count, 1);
+                    if (slot < kFastQ1) queue[slot] = (uint16_t)((ty << 6) | (tx4 + k));
                 }
-                uint32_t m = ((flags[0] >> 15) & 1u) | ((flags[1] >> 14) & 2u) | ((flags[0] >> 29) & 4u) | ((flags[1] >> 28) & 8u);
-                const int nvalid = ty < th ? min(4, max(0, tw - tx4)) : 0;   // positions of the group inside the tested interior
-                m &= (1u << nvalid) - 1u;
-                uint32_t rlo = tx4 < 32 ? m << tx4 : 0u, rhi = tx4 >= 32 ? m << (tx4 - 32) : 0u;
-                rlo = row16_or(rlo); rhi = row16_or(rhi);
-                if ((tid & 15) == 0) bits1[ty] = (unsigned long long)rlo | ((unsigned long long)rhi << 32);
-                f16 |= m << (4 * it);
-            }
-            const int lane = tid & 63;
-            const int cnt = __popc(f16);             // <= 16
-            int pre = 0, tot = 0;
-#pragma unroll
-            for (int bit = 0; bit < 5; ++bit) {
-                const unsigned long long mk = __ballot((cnt >> bit) & 1);
-                pre += __popcll(mk & ((1ull << lane) - 1ull)) << bit;
-                tot += __popcll(mk) << bit;
-            }
-            int base = 0;
-            if (lane == 0 && tot) base = atomicAdd(&q_count, tot);
-            int slot = __builtin_amdgcn_readfirstlane(base) + pre;
-            while (f16) {
-                const int bp = __builtin_ctz(f16);
-                f16 &= f16 - 1;
-                const int i = tid + 256 * (bp >> 2);
-                if (slot < kFastQ1) queue[slot] = (uint16_t)(((i >> 4) << 6) | ((i & 15) * 4 + (bp & 3)));
-                ++slot;
             }
         }
         __syncthreads();
         // pass 2: 16-bit brighter / darker masks of the survivors -> "has an arc of 9" -> second queue
         const int nq1 = q_count;
         const bool dense1 = nq1 <= kFastQ1;
-        const int lim1 = dense1 ? nq1 : 4096;
-        for (int j0 = 0; j0 < lim1; j0 += 256) {   // every wave runs every round: the pushes below are wave-wide
-            const int j = j0 + tid;
-            bool live = j < lim1;
-            const int i = live ? (dense1 ? (int)queue[j] : j) : 0;
+        for (int j = tid; j < (dense1 ? nq1 : 4096); j += 256) {
+            const int i = dense1 ? (int)queue[j] : j;
             const int ty = i >> 6, tx = i & 63;
-            if (live && !dense1 && !((bits1[ty] >> tx) & 1ull)) live = false;
-            bool corner = false;
-            if (live) {
-                const uint8_t* c = &tile[(ty + 3) * kTileW + tx + 4];
-                const int v = c[0];
-                const int hi = v + thr, lo = v - thr;
-                uint32_t B = 0, D = 0;
-                // ring positions 15 .. 0, each shifted in from the right: no 16 different bit constants to keep in registers
-#define PLP_T(dx, dy) { const int p = c[(dy) * kTileW + (dx)]; B = (B << 1) | (uint32_t)(p > hi); D = (D << 1) | (uint32_t)(p < lo); }
-                PLP_T(-1, 3) PLP_T(-2, 2) PLP_T(-3, 1) PLP_T(-3, 0) PLP_T(-3, -1) PLP_T(-2, -2) PLP_T(-1, -3) PLP_T(0, -3)
-                PLP_T(1, -3) PLP_T(2, -2) PLP_T(3, -1) PLP_T(3, 0) PLP_T(3, 1) PLP_T(2, 2) PLP_T(1, 3) PLP_T(0, 3)
+            if (!dense1 && !((bits1[ty] >> tx) & 1ull)) continue;
+            const uint8_t* c = &tile[(ty + 3) * kTileW + tx + 4];
+            const int v = c[0];
+            const int hi = v + thr, lo = v - thr;
+            uint32_t B = 0, D = 0;
+#define PLP_T(k, dx, dy) { const int p = c[(dy) * kTileW + (dx)]; B |= (uint32_t)(p > hi) << k; D |= (uint32_t)(p < lo) << k; }
+            PLP_T(0, 0, 3) PLP_T(1, 1, 3) PLP_T(2, 2, 2) PLP_T(3, 3, 1) PLP_T(4, 3, 0) PLP_T(5, 3, -1) PLP_T(6, 2, -2) PLP_T(7, 1, -3)
+            PLP_T(8, 0, -3) PLP_T(9, -1, -3) PLP_T(10, -2, -2) PLP_T(11, -3, -1) PLP_T(12, -3, 0) PLP_T(13, -3, 1) PLP_T(14, -2, 2) PLP_T(15, -1, 3)
 #undef PLP_T
-                auto arc9 = [](uint32_t m) -> bool {
-                    m |= m << 16;
-                    uint32_t x = m & (m >> 1);
-                    x &= x >> 2;
-                    x &= x >> 4;
-                    x &= m >> 8;
-                    return (x & 0xffffu) != 0;
-                };
-                corner = arc9(B) || arc9(D);
-            }
-            const unsigned long long cm = __ballot(corner);
-            if (cm) {   // wave-uniform
-                const int lane = tid & 63;
-                int base = 0;
-                if (lane == 0) base = atomicAdd(&q2_count, __popcll(cm));
-                const int slot = __builtin_amdgcn_readfirstlane(base) + __popcll(cm & ((1ull << lane) - 1ull));
-                if (corner) {
-                    atomicOr(&bits2[ty], 1ull << tx);          // read only if the queue overflows
-                    if (slot < kFastQ2) queue2[slot] = (uint16_t)i;
-                }
+            auto arc9 = [](uint32_t m) -> bool {
+                m |= m << 16;
+                uint32_t x = m & (m >> 1);
+                x &= x >> 2;
+                x &= x >> 4;
+                x &= m >> 8;
+                return (x & 0xffffu) != 0;
+            };
+            if (arc9(B) || arc9(D)) {
+                atomicOr(&bits2[ty], 1ull << tx);
+                const int slot = atomicAdd(&q2_count, 1);
+                if (slot < kFastQ2) queue2[slot] = (uint16_t)i;
             }
         }
         __syncthreads();
@@ -561,10 +485,7 @@ __global__ __launch_bounds__(256) void k_orient_rbrief(OrbPlanes pl, const uint8
     corun_priority();
     __shared__ uint32_t s_w0[16][8], s_w1[16][8];   // per |v|: byte weights 1 / (u + 15) inside the disc, 0 outside
     __shared__ uint32_t s_pat[256];                 // the 256 test pairs (ax, ay, bx, by as int8)
-    // per key point: the disc of the level (31 rows x 32 bytes), then the patch of the blurred level (37 rows x 40 bytes).  25.9 KB with the
-    // tables above: THREE of these workgroups fit the 77 KB that two region-growing workgroups leave on a CU (with 48-byte rows: 30.5 KB, two)
-    constexpr int kDiscPitch = 32, kPatchPitch = 40, kPatchBytes = (37 * kPatchPitch + 15) / 16 * 16;
-    __shared__ __attribute__((aligned(16))) uint8_t s_patch[16 * kPatchBytes];
+    __shared__ __attribute__((aligned(16))) uint8_t s_patch[16 * 37 * 48];   // per key point: the disc of the level, then the patch of the blurred level
     unsigned ublk, uframe;
     xcd_frame_major(ublk, uframe);   // a frame's patches (two planes, ~2.6 MB) stay in one L2
     const int tid = threadIdx.x, sub = tid & 15, frame = (int)uframe;
@@ -605,7 +526,7 @@ __global__ __launch_bounds__(256) void k_orient_rbrief(OrbPlanes pl, const uint8
     // Both patches of a key point go through LDS (s_patch: 37 rows x 48 bytes per key point): the 16 lanes fetch them with 16-byte
     // loads, neighbouring lanes taking neighbouring pieces of a row, so that one load instruction touches ~20 cache lines instead
     // of 64 -- the kernel used to be bound by L1 tag look-ups (32 single-byte gathers per lane for the test pairs alone).
-    uint8_t* patch = s_patch + (tid >> 4) * kPatchBytes;
+    uint8_t* patch = s_patch + (tid >> 4) * (37 * 48);
     // intensity centroid over the radius-15 disc (key points keep 19 pixels from the border: every load is inside)
     const uint8_t* img = pl.level_ptr(frame, level, L);
     const int pitch = pl.level_pitch(level, L);
@@ -614,7 +535,7 @@ __global__ __launch_bounds__(256) void k_orient_rbrief(OrbPlanes pl, const uint8
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int item = sub + 16 * it, row = item >> 1, half = item & 1;
-            if (row < 31) *reinterpret_cast<uint4*>(patch + row * kDiscPitch + 16 * half) = load_u128_unaligned(p0 + (size_t)row * pitch + 16 * half);
+            if (row < 31) *reinterpret_cast<uint4*>(patch + row * 48 + 16 * half) = load_u128_unaligned(p0 + (size_t)row * pitch + 16 * half);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -622,22 +543,17 @@ __global__ __launch_bounds__(256) void k_orient_rbrief(OrbPlanes pl, const uint8
     int m10 = 0, m01 = 0;
     {
         const int vA = sub - 15, vB = sub + 1;   // rows -15..0 and 1..15 (lane 15 has no second row)
+        const uint4* pA = reinterpret_cast<const uint4*>(patch + (vA + 15) * 48);
+        const uint4* pB = reinterpret_cast<const uint4*>(patch + (min(vB, 15) + 15) * 48);
+        const uint4 a0 = pA[0], a1 = pA[1], b0 = pB[0], b1 = pB[1];
+        const uint32_t dA[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, dB[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
         uint32_t sA = 0, tA = 0, sB = 0, tB = 0;   // s = sum I, t = sum (u + 15) I
-        // one disc row at a time: a row's pixels and both weight rows are 48 registers in flight, and the scheduler had fetched both rows at
-        // once (the kernel's register peak, 70: two waves per SIMD beside two region growers where 64 registers make it three)
-        auto row_sums = [&](int v_row, int a_row, uint32_t& s_out, uint32_t& t_out) {
-            const uint4* pr = reinterpret_cast<const uint4*>(patch + (v_row + 15) * kDiscPitch);
-            const uint4 a0 = pr[0], a1 = pr[1];
-            const uint32_t d[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-            uint32_t sv = 0, tv = 0;
+        const int aA = -vA, aB = min(vB, 15);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { sv = __builtin_amdgcn_udot4(d[j], s_w0[a_row][j], sv, false); tv = __builtin_amdgcn_udot4(d[j], s_w1[a_row][j], tv, false); }
-            s_out = sv; t_out = tv;
-        };
-        row_sums(vA, -vA, sA, tA);
-        int rowB = min(vB, 15);
-        asm volatile("" : "+v"(rowB) : "v"(tA));   // the second row's loads are issued after the first row's sums exist
-        row_sums(rowB, rowB, sB, tB);
+        for (int j = 0; j < 8; ++j) {
+            sA = __builtin_amdgcn_udot4(dA[j], s_w0[aA][j], sA, false); tA = __builtin_amdgcn_udot4(dA[j], s_w1[aA][j], tA, false);
+            sB = __builtin_amdgcn_udot4(dB[j], s_w0[aB][j], sB, false); tB = __builtin_amdgcn_udot4(dB[j], s_w1[aB][j], tB, false);
+        }
         if (vB > 15) { sB = 0; tB = 0; }
         m10 = (int)tA - 15 * (int)sA + (int)tB - 15 * (int)sB;
         m01 = vA * (int)sA + vB * (int)sB;
@@ -645,7 +561,7 @@ __global__ __launch_bounds__(256) void k_orient_rbrief(OrbPlanes pl, const uint8
     m10 = row16_sum(m10); m01 = row16_sum(m01);
     const float angle = fast_atan2_deg((float)m01, (float)m10);
 
-    // rBRIEF on the blurred level: rows cy-18 .. cy+18, columns cx-18 .. cx+21 (the rotated pattern stays within +-18)
+    // rBRIEF on the blurred level: rows cy-18 .. cy+18, columns cx-18 .. cx+29 (the rotated pattern stays within +-18)
     const float arad = (float)((double)angle * 3.14159265358979323846 / 180.0);
     const float ca = ref_cos(arad), sa = ref_sin(arad);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -654,26 +570,17 @@ __global__ __launch_bounds__(256) void k_orient_rbrief(OrbPlanes pl, const uint8
         const uint8_t* b0 = blur_base + (size_t)frame * blur_frame_stride + L.off + (size_t)(cy - 18) * L.pitch + cx - 18;
 #pragma unroll
         for (int it = 0; it < 7; ++it) {
-            const int item = sub + 16 * it, row = item / 3, seg = item - 3 * row;   // a row = 16 + 16 + 8 bytes
-            if (row < 37) {
-                const uint8_t* gsrc = b0 + (size_t)row * L.pitch + 16 * seg;
-                uint8_t* ldst = patch + row * kPatchPitch + 16 * seg;              // 8-byte aligned
-                if (seg < 2) { const uint4 v = load_u128_unaligned(gsrc); uint2 lo2 = make_uint2(v.x, v.y), hi2 = make_uint2(v.z, v.w);
-                               reinterpret_cast<uint2*>(ldst)[0] = lo2; reinterpret_cast<uint2*>(ldst)[1] = hi2; }
-                else { uint2 v; __builtin_memcpy(&v, gsrc, 8); *reinterpret_cast<uint2*>(ldst) = v; }
-            }
+            const int item = sub + 16 * it, row = item / 3, seg = item - 3 * row;
+            if (row < 37) *reinterpret_cast<uint4*>(patch + row * 48 + 16 * seg) = load_u128_unaligned(b0 + (size_t)row * L.pitch + 16 * seg);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    const uint8_t* bl = patch + 18 * kPatchPitch + 18;
+    const uint8_t* bl = patch + 18 * 48 + 18;
     uint32_t bits = 0;
+    int ta[16], tb[16];
 #pragma unroll
-    for (int r0 = 0; r0 < 16; r0 += 8) {   // eight pairs = sixteen LDS byte gathers in flight (all sixteen pairs: 32 registers the kernels beside the growers do not have)
-    int ta[8], tb[8];
-#pragma unroll
-    for (int r8 = 0; r8 < 8; ++r8) {
-        const int r = r0 + r8;
+    for (int r = 0; r < 16; ++r) {
         const uint32_t pt = s_pat[16 * sub + r];
         const float ax = (float)(int8_t)(pt & 0xff), ay = (float)(int8_t)((pt >> 8) & 0xff), bx = (float)(int8_t)((pt >> 16) & 0xff),
                     by = (float)(int8_t)(pt >> 24);
@@ -681,11 +588,10 @@ __global__ __launch_bounds__(256) void k_orient_rbrief(OrbPlanes pl, const uint8
         const int ac = __float2int_rn(__fsub_rn(__fmul_rn(ax, ca), __fmul_rn(ay, sa)));
         const int br = __float2int_rn(__fadd_rn(__fmul_rn(bx, sa), __fmul_rn(by, ca)));
         const int bc = __float2int_rn(__fsub_rn(__fmul_rn(bx, ca), __fmul_rn(by, sa)));
-        ta[r8] = bl[ar * kPatchPitch + ac]; tb[r8] = bl[br * kPatchPitch + bc];
+        ta[r] = bl[ar * 48 + ac]; tb[r] = bl[br * 48 + bc];
     }
 #pragma unroll
-    for (int r8 = 0; r8 < 8; ++r8) bits |= (uint32_t)(ta[r8] < tb[r8]) << (r0 + r8);
-    }
+    for (int r = 0; r < 16; ++r) bits |= (uint32_t)(ta[r] < tb[r]) << r;
     reinterpret_cast<uint16_t*>(out_desc + ((size_t)frame * cap + out_idx) * 32)[sub] = (uint16_t)bits;
     if (sub == 0) {
         plp_keypoint k;

@@ -93,6 +93,8 @@ class tracker_step:
         pq = self.pq
         t = dict(t_kps=kps[HALO:], t_desc=desc[HALO:], t_counts=cnt[HALO:])
         # descriptors are read in place: the queries of frame b are rows (b + HALO - 1) resp. (b + HALO - 2 .. b + HALO - 1) of `desc`
+        # the feature arrays are strided by cap = 2 K + 64, a frame holds about K key points: the matchers size their LDS for the expected count
+        t["t_count_hint"] = self.K + max(64, self.K // 8)
         q1 = dict(q_reproj=pq.q1_reproj, q_level=pq.q1_level, q_angle=pq.q1_angle, q_counts=pq.q1_counts, q_desc=desc[HALO - 1:], q_desc_stride=cap)
         self.mt_last.match_device(plp.MODE_LAST_FRAME, cap, cap, {**t, **q1}, self.m1, self.n1, margin=20.0, direction=0, scale_factors=self.sf, grid=self.grid, B=B, stream=st)
         q2 = dict(q_reproj=pq.q2_reproj, q_level=pq.q2_level, q_valid=pq.q2_valid, q_desc=desc[HALO - 2:], q_desc_stride=cap)

@@ -18,7 +18,17 @@ def run_landmarks(t, q, margin, ratio, grid):
     got, gn = mt.match_host(plp.MODE_LANDMARKS, len(t["t_kps"]), len(q["q_level"]), {**t, **q}, margin=margin, scale_factors=SF, grid=grid)
     assert gn[0] == wn
     assert np.array_equal(got[0], want)
+    same_with_a_count_hint(mt, plp.MODE_LANDMARKS, t, q, want, wn, margin=margin, scale_factors=SF, grid=grid)
     return wn
+
+
+def same_with_a_count_hint(mt, mode, t, q, want, wn, **kw):
+    """plp_match_args.t_count_hint sizes the LDS copy of a frame's targets; a frame with MORE targets than the hint reads the rest from memory:
+    the hint (too small by a lot, too small by one, larger than needed) never changes a result"""
+    n = len(t["t_kps"])
+    for hint in sorted({max(1, n // 3), max(1, n - 1), n + 40}):
+        got, gn = mt.match_host(mode, n, len(q["q_level"]), {**t, **q, "t_count_hint": hint}, **kw)
+        assert gn[0] == wn and np.array_equal(got[0], want), hint
 
 
 def run_last(t, q, margin, direction, check, grid):
@@ -30,6 +40,7 @@ def run_last(t, q, margin, direction, check, grid):
                             scale_factors=SF, grid=grid)
     assert gn[0] == wn
     assert np.array_equal(got[0], want)
+    same_with_a_count_hint(mt, plp.MODE_LAST_FRAME, t, q, want, wn, margin=margin, direction=direction, scale_factors=SF, grid=grid)
     if check:
         # PLP_MATCH_FLAG_MARK_INVALIDATED: -2 exactly where the orientation check removed a match (projection.cc:350-354)
         raw, _ = O.match_current_and_last(O.grid6(grid), t["t_kps"], t["t_desc"], t["t_x_right"], t["t_occupied"], SF, q["q_valid"],
