@@ -24,7 +24,7 @@ struct plp_line {
     ResizeExactTab rt{};
     BlurTapsN t11{}, t5{};
     LbdWeightsDev w{};
-    DevBuf tabs, blur11, scaled, pix, g2, maxgrad, undef, order, n_order, reg, mw_heap, raw, n_raw, dx, dy, all_kl, all_lbd, n_all, status, prof, grow_stats;
+    DevBuf tabs, blur11, scaled, pix, g2, maxgrad, undef, order, n_order, reg, mw_heap, raw, n_raw, dx, dy, all_kl, all_kl_dir, all_lbd, n_all, status, prof, grow_stats;
     DevBuf l0copy, s_kl, s_lbd, s_fn, s_cnt;   // host-API staging
     DevBuf aligned;                             // aligned copy of odd-pitch device frames
     int s_cap = 0;
@@ -77,6 +77,8 @@ plp_status build(plp_line* c, int rows, int cols) {
     LinePlanes& P = c->P;
     P.W = cols; P.H = rows;
     P.sw = (int)std::nearbyint(cols * 0.5); P.sh = (int)std::nearbyint(rows * 0.5);   // cvRound(ssize * scale)
+    // idx / sw as mulhi(idx, ceil(2^32 / sw)): exact while idx * sw < 2^32, i.e. (idx < sw * sh <= kLsdMaxScaledPixels < 2^19) for sw <= 8192; 0 = divide
+    P.sw_magic = (P.sw >= 2 && P.sw <= 8192) ? (uint32_t)(((1ull << 32) + (uint64_t)P.sw - 1) / (uint64_t)P.sw) : 0u;
     if (P.sw >= 65536 || P.sh >= 65536 || (size_t)P.sw * P.sh > kLsdMaxScaledPixels)
         return set_error(PLP_ERR_UNSUPPORTED, "frame too large for the LSD region-growing kernel (the half-resolution image must not exceed 516,065 pixels)");
     P.pitch = (cols + 63) / 64 * 64; P.spitch = (P.sw + 63) / 64 * 64;
@@ -145,13 +147,13 @@ plp_status ensure(plp_line* c, int B) {
     P.mw_heap = (uint32_t*)c->mw_heap.p;
     PLP_HIP(c->raw.reserve(sizeof(float4) * kLineCap * B)); PLP_HIP(c->n_raw.reserve(4 * (size_t)B));
     PLP_HIP(c->dx.reserve(dxy_frame_entries(P.W, P.H) * 4 * B));
-    PLP_HIP(c->all_kl.reserve(sizeof(plp_keyline) * kLineCap * B)); PLP_HIP(c->all_lbd.reserve((size_t)32 * kLineCap * B));
+    PLP_HIP(c->all_kl.reserve(sizeof(plp_keyline) * kLineCap * B)); PLP_HIP(c->all_kl_dir.reserve(sizeof(float2) * kLineCap * B)); PLP_HIP(c->all_lbd.reserve((size_t)32 * kLineCap * B));
     PLP_HIP(c->n_all.reserve(4 * (size_t)B)); PLP_HIP(c->status.reserve(16)); PLP_HIP(c->prof.reserve(128)); PLP_HIP(c->grow_stats.reserve(16 * (size_t)B));
     P.blur11 = (uint8_t*)c->blur11.p; P.scaled = (uint8_t*)c->scaled.p;
     P.pix = (LsdPix*)c->pix.p; P.g2 = (uint32_t*)c->g2.p; P.n_order = (int32_t*)c->n_order.p;
     P.blockmax = (uint32_t*)c->maxgrad.p; P.undef = (unsigned long long*)c->undef.p;
     P.order = (uint32_t*)c->order.p; P.reg = (uint32_t*)c->reg.p; P.raw = (float4*)c->raw.p; P.n_raw = (int32_t*)c->n_raw.p;
-    P.dxy = (short2*)c->dx.p; P.all_kl = (plp_keyline*)c->all_kl.p; P.all_lbd = (uint8_t*)c->all_lbd.p;
+    P.dxy = (short2*)c->dx.p; P.all_kl = (plp_keyline*)c->all_kl.p; P.all_kl_dir = (float2*)c->all_kl_dir.p; P.all_lbd = (uint8_t*)c->all_lbd.p;
     P.n_all = (int32_t*)c->n_all.p; P.status = (int32_t*)c->status.p; P.prof = (long long*)c->prof.p; P.grow_stats = (int32_t*)c->grow_stats.p;
     c->capB = B;
     return PLP_OK;

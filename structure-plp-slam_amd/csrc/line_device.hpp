@@ -36,6 +36,7 @@ __device__ __forceinline__ double pix_mod(const LsdPix& p) { return sqrt((double
 struct LinePlanes {
     int W, H;                 // full-resolution frame
     int sw, sh;               // LSD working resolution (scale 0.5)
+    uint32_t sw_magic;        // ceil(2^32 / sw) when idx / sw = mulhi(idx, sw_magic) is exact for every pixel index, else 0 (k_lsd_gradient)
     int pitch, spitch;        // row pitch of the full-res u8 planes / of the scaled u8 plane (64-B multiples)
     const uint8_t* img; size_t img_frame_stride; int img_pitch;   // caller's frames
     uint8_t* blur11;          // 11-tap sigma 1.2 blur (LSD), only when the blur and the resize run as two kernels  [B][H][pitch]
@@ -52,6 +53,7 @@ struct LinePlanes {
     float4* raw; int32_t* n_raw;          // LSD segments             [B][kLineCap], [B]
     short2* dxy;              // Sobel 3x3, (dx, dy) per pixel, in tiles of 8 x 4 pixels = one 128-byte line (dxy_index)  [B][dxy_frame_entries(W, H)]
     plp_keyline* all_kl; uint8_t* all_lbd; int32_t* n_all;   // before the length filter  [B][kLineCap]
+    float2* all_kl_dir;                                       // (cos, sin) of all_kl[.].angle as floats: the LBD's line direction
     int32_t* status;
     int half_exact;           // 1: every INTER_LINEAR_EXACT table entry is (2d, 128): blur11 and the x0.5 resize run as one kernel
     int32_t* grow_stats;      // per frame {regions grown, pixels accepted, exact (in-band) decisions of the angle test, 0}: the USED map's history in three numbers  [B][4]

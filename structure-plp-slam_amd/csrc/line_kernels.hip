@@ -139,43 +139,58 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 // the g2 plane holds g2 for defined pixels and 0 otherwise -- the seed sort works from it.
 __global__ __launch_bounds__(256) void k_lsd_gradient(LinePlanes P, LsdParams lp) {
     corun_priority();
-    const int b = blockIdx.y;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    // About a third of a frame's pixels are "defined" and need the angle, its cosine and sine (~100 instructions); one pixel per lane, every
+    // wave paid them for its few defined lanes.  The workgroup's defined pixels are compacted through LDS first (position in the block + the two
+    // 10-bit gradient components: one dword), then dense lanes do the arithmetic: about a third of the heavy instructions.
+    __shared__ uint32_t s_list[256];
+    __shared__ uint32_t s_max[4], s_cnt[4];
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int idx = blockIdx.x * 256 + tid;
     const int n = P.sw * P.sh;
-    uint32_t g2_def = 0;
+    uint32_t g2_def = 0, packed = 0;
     if (idx < n) {
-        const int y = idx / P.sw, x = idx - y * P.sw;
+        const int y = P.sw_magic ? (int)__umulhi((uint32_t)idx, P.sw_magic) : idx / P.sw, x = idx - y * P.sw;   // idx / sw (line_context.hip: when the product form is exact)
         if (x < P.sw - 1 && y < P.sh - 1) {
             const uint8_t* s = P.scaled + ((size_t)b * P.sh + y) * P.spitch + x;
             const int DA = (int)s[P.spitch + 1] - (int)s[0];
             const int BC = (int)s[1] - (int)s[P.spitch];
-            const int gx = DA + BC, gy = DA - BC;
+            const int gx = DA + BC, gy = DA - BC;                  // each in [-510, 510]
             const uint32_t g2 = (uint32_t)(gx * gx + gy * gy);
             if (g2 >= lp.g2_def_min) {
                 g2_def = g2;
-                LsdPix px;
-                px.deg = fast_atan2_deg_l((float)gx, (float)-gy);
-                px.g2 = g2;
-                const float fa = (float)((double)px.deg * (3.14159265358979323846 / 180));
-                if (!sincos_ziv(fa, &px.cs.x, &px.cs.y)) px.cs = make_float2((float)cos((double)fa), (float)sin((double)fa));   // ~1 pixel in a million
-                P.pix[(size_t)b * n + idx] = px;
+                packed = (uint32_t)tid | ((uint32_t)(gx + 512) << 8) | ((uint32_t)(gy + 512) << 18);
             }
         }
         P.g2[(size_t)b * n + idx] = g2_def;
     }
-    // max magnitude over the defined pixels = max of g2 (the magnitude is monotone in it).  One plain store per
-    // workgroup; k_lsd_order reduces the per-workgroup values (2.4 M same-line atomics per launch had made this kernel
-    // wait 86 % of its time).
     // one 64-bit word per wave: pixels that can never seed or join a region (angle NOTDEF)
     const unsigned long long undef = __ballot(g2_def == 0);
-    if ((threadIdx.x & 63) == 0 && blockIdx.x * 256 + (int)threadIdx.x < ((n + 63) / 64) * 64)
-        P.undef[(size_t)b * ((n + 63) / 64) + (blockIdx.x * 256 + threadIdx.x) / 64] = undef;
+    if (lane == 0 && blockIdx.x * 256 + tid < ((n + 63) / 64) * 64) P.undef[(size_t)b * ((n + 63) / 64) + (blockIdx.x * 256 + tid) / 64] = undef;
+    const unsigned long long defm = ~undef;
+    const int rank = __popcll(defm & ((1ull << lane) - 1ull));
+    // max magnitude over the defined pixels = max of g2 (the magnitude is monotone in it).  One plain store per workgroup; k_lsd_order
+    // reduces the per-workgroup values (2.4 M same-line atomics per launch had made this kernel wait 86 % of its time).
+    uint32_t mx = g2_def;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) g2_def = max(g2_def, (uint32_t)__shfl_xor((int)g2_def, o));
-    __shared__ uint32_t s_max[4];
-    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = g2_def;
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+    if (lane == 0) { s_max[wv] = mx; s_cnt[wv] = (uint32_t)__popcll(defm); }
     __syncthreads();
-    if (threadIdx.x == 0) P.blockmax[(size_t)b * gridDim.x + blockIdx.x] = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+    const uint32_t c0 = s_cnt[0], c1 = s_cnt[1], c2 = s_cnt[2], c3 = s_cnt[3];
+    const int base = (wv > 0 ? (int)c0 : 0) + (wv > 1 ? (int)c1 : 0) + (wv > 2 ? (int)c2 : 0);
+    if (g2_def) s_list[base + rank] = packed;
+    if (tid == 0) P.blockmax[(size_t)b * gridDim.x + blockIdx.x] = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+    __syncthreads();
+    const int total = (int)(c0 + c1 + c2 + c3);
+    if (tid < total) {
+        const uint32_t e = s_list[tid];
+        const int gx = (int)((e >> 8) & 1023u) - 512, gy = (int)(e >> 18) - 512;
+        LsdPix px;
+        px.deg = fast_atan2_deg_l((float)gx, (float)-gy);
+        px.g2 = (uint32_t)(gx * gx + gy * gy);
+        const float fa = (float)((double)px.deg * (3.14159265358979323846 / 180));
+        if (!sincos_ziv(fa, &px.cs.x, &px.cs.y)) px.cs = make_float2((float)cos((double)fa), (float)sin((double)fa));   // ~1 pixel in a million
+        P.pix[(size_t)b * n + blockIdx.x * 256 + (int)(e & 255u)] = px;
+    }
 }
 
 // ------------------------------------------------------------------------------------------ seed ordering
@@ -1494,6 +1509,9 @@ __global__ __launch_bounds__(64) void k_keylines(LinePlanes P, LsdParams lp) {
         if (keep) {
             kl.class_id = run + __popcll(bal & ((1ull << lane) - 1ull));
             out[kl.class_id] = kl;
+            // the band descriptor's direction (binary_descriptor_custom.cpp:1126-1127), here with one line per LANE: in k_lbd, one line per wave,
+            // the f64 cos / sin (64 lanes computing one value) was that kernel's register peak
+            P.all_kl_dir[(size_t)b * kLineCap + kl.class_id] = make_float2((float)cos((double)kl.angle), (float)sin((double)kl.angle));
         }
         run += __popcll(bal);
     }
@@ -1508,18 +1526,22 @@ __global__ __launch_bounds__(64) void k_keylines(LinePlanes P, LsdParams lp) {
 // a work item makes 4 pixels x 2 rows from 4 rows x 3 aligned dwords.  The two derivatives of a pixel are stored side by side (one
 // 4-byte gather per LBD sample instead of two 2-byte ones).  grid = (tiles, B) through xcd_frame_major, block = 256.
 constexpr int kSobelTW = 120, kSobelTH = 30;
-struct BlurSobelLds { BlurTileLds<2> b; uint32_t bt[kBlurTH * (kBlurTW / 4)]; };
+// The blurred tile (4 KB) takes the place of the staged input rows (5 KB): nobody reads those after the horizontal pass, and the barrier between
+// the two passes of blur_tile_core lies before the first blurred byte is written.  14.4 instead of 18.5 KB: five workgroups instead of four in the
+// 77 KB two region-growing workgroups leave on a CU.
+static_assert(sizeof(BlurTileLds<2>::in) >= kBlurTH * (kBlurTW / 4) * 4, "the blurred tile must fit the input rows it replaces");
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_blur_sobel(const uint8_t* __restrict__ src, size_t src_fs, int src_pitch,
                                                                                             short2* __restrict__ dxy, int w, int h, BlurTapsN taps) {
     corun_priority();
-    __shared__ BlurSobelLds S;
+    __shared__ __attribute__((aligned(16))) BlurTileLds<2> Sb;
+    uint32_t* const bt = reinterpret_cast<uint32_t*>(Sb.in);
     const int tiles_x = (w + kSobelTW - 1) / kSobelTW;
     unsigned t, f;
     xcd_frame_major(t, f);
     const int bx0 = ((int)t % tiles_x) * kSobelTW - 4, by0 = ((int)t / tiles_x) * kSobelTH - 1;
-    blur_tile_core<2>(S.b, src + (size_t)f * src_fs, src_pitch, w, h, bx0, by0, taps.k, [&](int r0, int c4, const uint32_t (&rows)[kBlurRS]) {
+    blur_tile_core<2>(Sb, src + (size_t)f * src_fs, src_pitch, w, h, bx0, by0, taps.k, [&](int r0, int c4, const uint32_t (&rows)[kBlurRS]) {
 #pragma unroll
-        for (int rr = 0; rr < kBlurRS; ++rr) S.bt[(r0 + rr) * (kBlurTW / 4) + c4 / 4] = rows[rr];
+        for (int rr = 0; rr < kBlurRS; ++rr) bt[(r0 + rr) * (kBlurTW / 4) + c4 / 4] = rows[rr];
     });
     __syncthreads();
     short2* out_frame = dxy + (size_t)f * dxy_frame_entries(w, h);
@@ -1532,7 +1554,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         int d[4][4], sm[4][4];   // per blurred row: right - left and left + 2 mid + right of the 4 pixels
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const uint32_t* q = &S.bt[(2 * rp + r) * (kBlurTW / 4) + cd];
+            const uint32_t* q = &bt[(2 * rp + r) * (kBlurTW / 4) + cd];
             const uint32_t A = q[-1], Bv = q[0], Cv = q[1];
             const int p[6] = {(int)(A >> 24), (int)(Bv & 255u), (int)((Bv >> 8) & 255u), (int)((Bv >> 16) & 255u), (int)(Bv >> 24), (int)(Cv & 255u)};
 #pragma unroll
@@ -1573,7 +1595,8 @@ __global__ __launch_bounds__(256) void k_lbd(LinePlanes P, LbdWeightsDev W) {
     const short halfWidth = (short)((lengthOfLSP - 1) / 2), halfHeight = 31;
     const float midX = (float)(0.5 * (double)__fadd_rn(kl.sPointInOctaveX, kl.ePointInOctaveX));
     const float midY = (float)(0.5 * (double)__fadd_rn(kl.sPointInOctaveY, kl.ePointInOctaveY));
-    const float dL0 = (float)cos((double)kl.angle), dL1 = (float)sin((double)kl.angle);
+    const float2 dir = P.all_kl_dir[(size_t)b * kLineCap + li];   // ((float)cos((double)kl.angle), (float)sin((double)kl.angle)), from k_keylines
+    const float dL0 = dir.x, dL1 = dir.y;
     const float dO0 = -dL1, dO1 = dL0;
     if (lane < 63) {
         // start corner of row hID = lane: the reference steps it row by row (sCorX0 -= dL1; sCorY0 += dL0)
