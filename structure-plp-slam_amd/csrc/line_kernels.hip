@@ -111,7 +111,6 @@ __global__ __launch_bounds__(256) void k_resize_exact(const uint8_t* __restrict_
 // k_blur_plane<5> + k_resize_exact otherwise.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_blur_half(const uint8_t* __restrict__ src, size_t src_fs, int src_pitch,
                                                                                            uint8_t* __restrict__ dst, size_t dst_fs, int dst_pitch, int w, int h, BlurTapsN taps) {
-    corun_priority();
     __shared__ BlurTileLds<5> S;
     const int tiles_x = (w + kBlurTW - 1) / kBlurTW;
     unsigned t, f;
@@ -138,7 +137,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 // (LsdParams::g2_def_min, same f64 operations).  Only defined pixels get a record (nothing ever reads the others);
 // the g2 plane holds g2 for defined pixels and 0 otherwise -- the seed sort works from it.
 __global__ __launch_bounds__(256) void k_lsd_gradient(LinePlanes P, LsdParams lp) {
-    corun_priority();
     // About a third of a frame's pixels are "defined" and need the angle, its cosine and sine (~100 instructions); one pixel per lane, every
     // wave paid them for its few defined lanes.  The workgroup's defined pixels are compacted through LDS first (position in the block + the two
     // 10-bit gradient components: one dword), then dense lanes do the arithmetic: about a third of the heavy instructions.
@@ -203,7 +201,6 @@ __global__ __launch_bounds__(256) void k_lsd_gradient(LinePlanes P, LsdParams lp
 //   3  exclusive scan over (bin descending, wave ascending): 4 bins per thread, shuffles, one LDS hop across waves
 //   4  per 64 compacted entries: rank among equal bins by 10 ballots (stable), scatter
 __global__ __launch_bounds__(256) void k_lsd_order(LinePlanes P, LsdParams lp, int n_grad_blocks) {
-    corun_priority();
     __shared__ uint32_t cnt[4][1024];
     __shared__ uint32_t s_red[4], s_wsum[4];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
@@ -782,13 +779,7 @@ __device__ void centroid_sums(const GrowCtx& g, int nreg, double cen[3]) {
 #ifndef PLP_GROW_MIN_WAVES      // experiment knob: waves per SIMD the register allocation must allow (4 = at most 128 VGPRs)
 #define PLP_GROW_MIN_WAVES 1
 #endif
-#ifndef PLP_GROW_PRIO           // wave priority of the region growers (s_setprio 0..3): their dependent chains are the critical path of the line streams
-#define PLP_GROW_PRIO 0
-#endif
 __global__ __launch_bounds__(256, PLP_GROW_MIN_WAVES) void k_lsd_grow(LinePlanes P, LsdParams lp, int B, int wpb, int ring) {
-#if PLP_GROW_PRIO > 0
-    __builtin_amdgcn_s_setprio(PLP_GROW_PRIO);
-#endif
     extern __shared__ __attribute__((aligned(16))) uint32_t s_bits[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int b = blockIdx.x * wpb + wv;
@@ -1469,7 +1460,6 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
 // ------------------------------------------------------------------------------------------ KeyLine assembly
 // LSDDetector_custom.cpp:262-303 (octave 0).  One wave per frame; class_id = running index of kept lines.
 __global__ __launch_bounds__(64) void k_keylines(LinePlanes P, LsdParams lp) {
-    corun_priority();
     const int b = blockIdx.x, lane = threadIdx.x;
     const int n = P.n_raw[b];
     const float4* raw = P.raw + (size_t)b * kLineCap;
@@ -1532,7 +1522,6 @@ constexpr int kSobelTW = 120, kSobelTH = 30;
 static_assert(sizeof(BlurTileLds<2>::in) >= kBlurTH * (kBlurTW / 4) * 4, "the blurred tile must fit the input rows it replaces");
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_blur_sobel(const uint8_t* __restrict__ src, size_t src_fs, int src_pitch,
                                                                                             short2* __restrict__ dxy, int w, int h, BlurTapsN taps) {
-    corun_priority();
     __shared__ __attribute__((aligned(16))) BlurTileLds<2> Sb;
     uint32_t* const bt = reinterpret_cast<uint32_t*>(Sb.in);
     const int tiles_x = (w + kSobelTW - 1) / kSobelTW;
@@ -1581,7 +1570,6 @@ __constant__ int c_comb[32][2] = {{0, 1}, {0, 2}, {0, 3}, {0, 4}, {0, 5}, {0, 6}
 // grid = (4, B), block = 256: one wave per line, 16 lines of a frame in flight (more waves thrash L1/L2: every wave
 // keeps 63 image rows live).
 __global__ __launch_bounds__(256) void k_lbd(LinePlanes P, LbdWeightsDev W) {
-    corun_priority();
     __shared__ float s_row[4][63][8];   // per row: pgdL, ngdL, pgdL2, ngdL2, pgdO, ngdO, pgdO2, ngdO2 (after the global weight)
     __shared__ float s_des[4][72], s_des2[4][72], s_norm[4][4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, b = blockIdx.y;
@@ -1714,7 +1702,6 @@ __global__ __launch_bounds__(256) void k_lbd(LinePlanes P, LbdWeightsDev W) {
 __global__ __launch_bounds__(64) void k_line_finalize(LinePlanes P, LsdParams lp, plp_keyline* __restrict__ out_kl,
                                                       uint8_t* __restrict__ out_lbd, double* __restrict__ out_fn, int cap,
                                                       int32_t* __restrict__ out_counts) {
-    corun_priority();
     const int b = blockIdx.x, lane = threadIdx.x;
     const int n = P.n_all[b];
     int run = 0;

@@ -337,7 +337,6 @@ __device__ __forceinline__ void match_topk_query(const MatchProblem& P, int b, i
 // queries each (key lines: ~50 of a 512 capacity) does not launch hundreds of thousands of workgroups that only exit.
 template <int FAM>
 __global__ __launch_bounds__(256) void k_match_topk(MatchProblem P) {
-    corun_priority();
     const int lane = threadIdx.x & 63, b = blockIdx.y;
     const int m = P.q_counts ? min(P.q_counts[b], P.m_cap) : P.m_cap;
     for (int q = blockIdx.x * 4 + (threadIdx.x >> 6); q < m; q += gridDim.x * 4) match_topk_query<FAM>(P, b, q, lane);
@@ -348,7 +347,6 @@ __global__ __launch_bounds__(256) void k_match_topk(MatchProblem P) {
 // lists than on the candidates.  grid = (ceil(m_cap / 64), B), block = 64.
 template <int FAM>
 __global__ __launch_bounds__(64) void k_match_topk_lanes(MatchProblem P) {
-    corun_priority();
     const int b = blockIdx.y, q = blockIdx.x * 64 + threadIdx.x;
     const int m = P.q_counts ? min(P.q_counts[b], P.m_cap) : P.m_cap;
     if ((int)blockIdx.x * 64 >= m) return;   // the whole wave
@@ -438,7 +436,6 @@ constexpr int kCellStride = 4104;  // cell_start[cols * rows + 1] per frame (<= 
 // order is simply its position in this array (16 bits), and a window is one contiguous range per grid column.
 // grid = (B), block = 256.
 __global__ __launch_bounds__(256) void k_match_prep(MatchProblem P) {
-    corun_priority();
     // 33 KB of LDS: two of these workgroups fit beside the 85 KB that region growing holds on a CU (with 32-bit cell counters it was 41 KB and
     // one).  Cell counts (at most 8192 targets per frame) are 16-bit halves of 32-bit words: cell c lives in word c >> 1, half c & 1.
     __shared__ uint32_t cnt2[2048];
@@ -544,7 +541,6 @@ __device__ __forceinline__ int row16_sum_i32(int v) {
 // Consecutive queries sit on the same pyramid level (key points are stored by level), so the lanes of a wave run similar trip counts.
 // grid = (ceil(m_cap / kQueriesPerBlock), B), block = 256, dynamic LDS = n_cap * 20 + 2 * kCellStride bytes.
 __global__ PLP_TOPK_CELLS_BOUNDS void k_match_topk_cells(MatchProblem P, int qpb) {
-    corun_priority();
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     unsigned uqb, ub;
     xcd_frame_major(uqb, ub);   // the query blocks of a frame all stage the same sorted target array
@@ -686,7 +682,6 @@ __global__ PLP_TOPK_CELLS_BOUNDS void k_match_topk_cells(MatchProblem P, int qpb
 // Brute-force mode: the frame's 32-byte descriptors are staged in LDS, one wave per query scans them all.
 // grid = (ceil(m_cap / kQueriesPerBlock), B), block = 256, dynamic LDS = n_cap * 32 bytes.
 __global__ __launch_bounds__(256) void k_match_topk_lds(MatchProblem P) {
-    corun_priority();
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.y;
     const int m = P.q_counts ? min(P.q_counts[b], P.m_cap) : P.m_cap;
@@ -746,7 +741,6 @@ __device__ __forceinline__ bool accept(const MatchProblem& P, unsigned best, int
 template <bool kSorted, int FAM = kFamAny, int BS = 256>
 __device__ __forceinline__ void match_resolve_body(const MatchProblem& P) {
     const int mode = fam_mode<FAM>(P.mode);
-    corun_priority();
     extern __shared__ int32_t lds[];
     __shared__ int s_changed, s_num, s_hist[32], s_valid_bin[32], s_full_n, s_claim_tmp[BS], s_sort_ws[48];
     __shared__ unsigned s_sort_idx[32];

@@ -35,7 +35,6 @@ __global__ __launch_bounds__(256) void k_resize_linear(const uint8_t* __restrict
                                                        const int16_t* __restrict__ a0, const int16_t* __restrict__ a1,
                                                        const int16_t* __restrict__ yofs0, const int16_t* __restrict__ yofs1,
                                                        const int16_t* __restrict__ b0, const int16_t* __restrict__ b1) {
-    corun_priority();
     constexpr int ROWS = 8;
     __shared__ __attribute__((aligned(16))) uint8_t tile[kRsRows * kRsPitch];
     const int tid = threadIdx.y * 64 + threadIdx.x;
@@ -144,7 +143,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                                                     const uint8_t* __restrict__ mask, size_t mask_step,
                                                     size_t mask_frame_stride, uint32_t* __restrict__ cell_cand,
                                                     int32_t* __restrict__ cell_count, int n_cells) {
-    corun_priority();
     __shared__ __attribute__((aligned(16))) uint8_t tile[70 * kTileW];
     __shared__ __attribute__((aligned(16))) uint8_t score[66 * kScoreW];   // score map of the tested interior, +1 zero ring
     __shared__ unsigned long long keepbits[64];                            // NMS survivors, one bit per tested position
@@ -389,7 +387,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_blur7(OrbPlanes pl, uint8_t* __restrict__ blur_base, size_t blur_frame_stride,
                                                const LevelDev* __restrict__ lv, int n_levels, BlurTaps taps) {
-    corun_priority();
     __shared__ BlurTileLds<3> S;
     unsigned ut, uf;
     xcd_frame_major(ut, uf);   // all tiles of a frame share halo rows: one L2 per frame
@@ -482,7 +479,6 @@ __global__ __launch_bounds__(256) void k_orient_rbrief(OrbPlanes pl, const uint8
                                                        int total_sel_cap, UMax um, plp_keypoint* __restrict__ out_kps,
                                                        uint8_t* __restrict__ out_desc, int cap, int32_t* __restrict__ out_counts,
                                                        int32_t* __restrict__ status) {
-    corun_priority();
     __shared__ uint32_t s_w0[16][8], s_w1[16][8];   // per |v|: byte weights 1 / (u + 15) inside the disc, 0 outside
     __shared__ uint32_t s_pat[256];                 // the 256 test pairs (ax, ay, bx, by as int8)
     __shared__ __attribute__((aligned(16))) uint8_t s_patch[16 * 37 * 48];   // per key point: the disc of the level, then the patch of the blurred level

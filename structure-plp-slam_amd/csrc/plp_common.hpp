@@ -80,16 +80,4 @@ struct HostPinned {
     }
 };
 
-// Wave priority of the kernels that run BESIDE region growing (bench step: ORB chain, line front, matchers on their own streams).
-// k_lsd_grow is a dependent-latency chain that issues a third of its cycles; a SIMD that hosts two of its waves should hand its
-// issue slots to the streaming kernel first (s_setprio: 0 = default ... 3 = highest; arbitration among the waves of one SIMD).
-#ifndef PLP_CORUN_PRIO
-#define PLP_CORUN_PRIO 0
-#endif
-__device__ __forceinline__ void corun_priority() {
-#if PLP_CORUN_PRIO > 0
-    __builtin_amdgcn_s_setprio(PLP_CORUN_PRIO);
-#endif
-}
-
 }  // namespace plp

@@ -133,7 +133,6 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelDev* __restrict__ l
                                                   int32_t* __restrict__ sel, int32_t* __restrict__ sel_count, int total_sel_cap,
                                                   uint8_t* __restrict__ scratch, size_t scratch_frame_stride,
                                                   int32_t* __restrict__ status, int max_nodes) {
-    corun_priority();
     extern __shared__ __attribute__((aligned(16))) uint8_t qt_smem[];
     const QtShared S = qt_carve(qt_smem, max_nodes);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;

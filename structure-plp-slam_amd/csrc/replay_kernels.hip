@@ -15,7 +15,6 @@ __global__ __launch_bounds__(256) void k_replay_point_queries(const plp_keypoint
                                                               float sy, float2* __restrict__ q1_reproj, int32_t* __restrict__ q1_level, float* __restrict__ q1_angle,
                                                               int32_t* __restrict__ q1_counts, float2* __restrict__ q2_reproj, int32_t* __restrict__ q2_level,
                                                               uint8_t* __restrict__ q2_valid) {
-    corun_priority();
     const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
     if (i >= cap) return;
     const int f1 = halo + b - 1, f2 = halo + b - 2;            // frames b-1 and b-2 in the (halo + B)-frame feature arrays
@@ -42,7 +41,6 @@ __global__ __launch_bounds__(256) void k_replay_line_queries(const plp_keyline* 
                                                              int32_t* __restrict__ q_counts, float2* __restrict__ q2_sp, float2* __restrict__ q2_ep,
                                                              int32_t* __restrict__ q2_level, uint8_t* __restrict__ q2_valid, const plp_keypoint* __restrict__ kps,
                                                              const int32_t* __restrict__ kp_counts, int kp_cap, int32_t* __restrict__ t_kp_octave) {
-    corun_priority();
     const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
     if (i >= cap) return;
     const int f1 = halo + b - 1;
