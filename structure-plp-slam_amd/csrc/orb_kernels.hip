@@ -18,15 +18,17 @@
 namespace plp {
 
 // ------------------------------------------------------------------------------------------
-// K1  bilinear 11-bit fixed-point down-scale.  A workgroup makes a 256 x 32 destination tile: the source rectangle
-// it needs (<= 42 rows x 336 bytes at scale 1.2) is staged in LDS with 16-byte loads, then every thread makes
-// 4 pixels x 8 rows with byte reads from LDS (one u32 store per row).  The first version gathered single bytes
-// from global memory, 16 per output dword, and was bound by the texture addresser (profiles/r01g_sq_counters.md:
-// 50 % issue stalls).  Horizontal sums of a source row are kept for the next destination row (at scale 1.2 five
-// of six destination rows share a source row with their predecessor).
-// grid = (ceil(dw/256), ceil(dh/32), B), block = (64, 4)
+// K1  bilinear 11-bit fixed-point down-scale.  Every WAVE makes a 64 x 32 destination strip on its own: the source rectangle it needs
+// (<= 44 rows x 96 bytes at scale 1.2) is staged in the wave's quarter of the workgroup's LDS with 16-byte loads, then every lane makes
+// 4 pixels x 8 rows with byte reads from LDS (one u32 store per row); lanes 16 k .. 16 k + 15 own rows 8 k .. 8 k + 7 of the strip.
+// Horizontal sums of a source row are kept for the next destination row (at scale 1.2 five of six destination rows share a source row with
+// their predecessor).  History: the first version gathered single bytes from global memory, 16 per output dword, and was bound by the
+// texture addresser (profiles/r01g_sq_counters.md); the second staged a 256 x 32 tile per workgroup, one 256-pixel row of lanes per wave,
+// and left 30 % of its lanes without a pixel on the narrow pyramid levels (257 = 256 + 1 columns at level 5: the second tile column ran
+// for one pixel per row); strips of 64 columns x 32 rows per wave leave 12 %.
+// grid = (ceil(dw / 64), ceil(dh / 128), B), block = 256: the four waves of a workgroup take four vertically adjacent strips.
 // ------------------------------------------------------------------------------------------
-constexpr int kRsRows = 44, kRsPitch = 352;   // staged source tile (scale factors >= 1.1 fit; larger tiles fall back to global reads)
+constexpr int kRsRows = 44, kRsPitch = 96;   // staged source rectangle of one strip (scale factors >= 1.1 fit; larger ones fall back to global reads)
 
 __global__ __launch_bounds__(256) void k_resize_linear(const uint8_t* __restrict__ src_base, size_t src_frame_stride,
                                                        int src_pitch, int sw, uint8_t* __restrict__ dst_base,
@@ -36,31 +38,35 @@ __global__ __launch_bounds__(256) void k_resize_linear(const uint8_t* __restrict
                                                        const int16_t* __restrict__ yofs0, const int16_t* __restrict__ yofs1,
                                                        const int16_t* __restrict__ b0, const int16_t* __restrict__ b1) {
     constexpr int ROWS = 8;
-    __shared__ __attribute__((aligned(16))) uint8_t tile[kRsRows * kRsPitch];
-    const int tid = threadIdx.y * 64 + threadIdx.x;
-    const int tile_x0 = blockIdx.x * 256, tile_y0 = blockIdx.y * 32;
-    const int tile_x1 = min(tile_x0 + 256, dw) - 1, tile_y1 = min(tile_y0 + 32, dh) - 1;
+    __shared__ __attribute__((aligned(16))) uint8_t tiles[4 * kRsRows * kRsPitch];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int strip_x0 = blockIdx.x * 64, strip_y0 = (blockIdx.y * 4 + wv) * 32;
+    if (strip_y0 >= dh) return;   // the whole wave (no workgroup barrier below)
+    uint8_t* tile = tiles + wv * (kRsRows * kRsPitch);
+    const int strip_x1 = min(strip_x0 + 64, dw) - 1, strip_y1 = min(strip_y0 + 32, dh) - 1;
     const uint8_t* src = src_base + (size_t)blockIdx.z * src_frame_stride;
     uint8_t* dst = dst_base + (size_t)blockIdx.z * dst_frame_stride;
-    const int xs = (int)xofs0[tile_x0] & ~15, xe = xofs1[tile_x1];
-    const int ys = yofs0[tile_y0], ye = yofs1[tile_y1];
+    const int xs = (int)xofs0[strip_x0] & ~15, xe = xofs1[strip_x1];
+    const int ys = yofs0[strip_y0], ye = yofs1[strip_y1];
     const int nrows = ye - ys + 1, nchunks = (xe - xs) / 16 + 1;
-    const bool staged = nrows <= kRsRows && nchunks * 16 <= kRsPitch;   // uniform
+    const bool staged = nrows <= kRsRows && nchunks * 16 <= kRsPitch;   // wave-uniform
     if (staged) {
         const bool wide = (((uintptr_t)src | (uintptr_t)src_pitch) & 15) == 0;
-        for (int i = tid; i < nrows * nchunks; i += 256) {
-            const int r = i / nchunks, c = i - r * nchunks;
-            const int x = xs + 16 * c;
-            const uint8_t* g = src + (size_t)(ys + r) * src_pitch + x;
-            uint8_t* t = tile + r * kRsPitch + 16 * c;
-            if (wide && x + 16 <= src_pitch) *reinterpret_cast<uint4*>(t) = *reinterpret_cast<const uint4*>(g);
-            else
-                for (int k = 0; k < 16; ++k) t[k] = x + k < sw ? g[k] : (uint8_t)0;
-        }
+        const int c = lane & 7, r0 = lane >> 3;      // <= 6 chunks of 16 bytes per row, 8 rows per trip
+        if (c < nchunks)
+            for (int r = r0; r < nrows; r += 8) {
+                const int x = xs + 16 * c;
+                const uint8_t* g = src + (size_t)(ys + r) * src_pitch + x;
+                uint8_t* t = tile + r * kRsPitch + 16 * c;
+                if (wide && x + 16 <= src_pitch) *reinterpret_cast<uint4*>(t) = *reinterpret_cast<const uint4*>(g);
+                else
+                    for (int k = 0; k < 16; ++k) t[k] = x + k < sw ? g[k] : (uint8_t)0;
+            }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();   // the strip belongs to this wave alone: its own LDS writes are all it waits for
     }
-    __syncthreads();
-    const int dy0 = tile_y0 + threadIdx.y * ROWS;
-    const int dx0 = tile_x0 + threadIdx.x * 4;
+    const int dy0 = strip_y0 + (lane >> 4) * ROWS;
+    const int dx0 = strip_x0 + (lane & 15) * 4;
     if (dy0 >= dh || dx0 >= dw) return;
     int x0[4], x1[4], wa0[4], wa1[4];
 #pragma unroll
@@ -80,7 +86,7 @@ __global__ __launch_bounds__(256) void k_resize_linear(const uint8_t* __restrict
         for (int r = 0; r < ROWS; ++r) {
             const int dy = dy0 + r;
             if (dy >= dh) break;
-            const int y0 = yofs0[dy], y1 = yofs1[dy];   // wave-uniform
+            const int y0 = yofs0[dy], y1 = yofs1[dy];   // one value per 16 lanes
             const int wb0 = b0[dy], wb1 = b1[dy];
             int h0[4], h1[4];
             if (y0 == cached_row) {
@@ -610,7 +616,7 @@ void launch_resize(hipStream_t st, const OrbPlanes& pl, const LevelDev* h_lv, in
     const uint8_t* src = level - 1 == 0 ? pl.l0 : pl.pyr + S.off;
     const size_t sstride = level - 1 == 0 ? pl.l0_frame_stride : pl.pyr_frame_stride;
     const int spitch = level - 1 == 0 ? pl.l0_pitch : S.pitch;
-    dim3 grid((D.w + 255) / 256, (D.h + 31) / 32, B), block(64, 4);
+    dim3 grid((D.w + 63) / 64, (D.h + 127) / 128, B), block(256);
     hipLaunchKernelGGL(k_resize_linear, grid, block, 0, st, src, sstride, spitch, S.w, pl.pyr + D.off, pl.pyr_frame_stride, D.pitch,
                        D.w, D.h, rs.xofs0 + rs.col_base[level], rs.xofs1 + rs.col_base[level], rs.a0 + rs.col_base[level],
                        rs.a1 + rs.col_base[level], rs.yofs0 + rs.row_base[level], rs.yofs1 + rs.row_base[level],
