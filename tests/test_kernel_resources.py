@@ -52,15 +52,23 @@ def test_footprints_the_design_argues_with():
     assert grow["VGPRs"] <= 152, grow
     (mw,) = find("k_lsd_grow_mw")
     assert mw["VGPRs"] <= 176, mw                 # eight waves of a workgroup on four SIMDs: 2 x 176 <= 512
+    # kernels that run at few waves per SIMD even alone: their footprint is their speed.  Beside two growers per SIMD a kernel of
+    # at most 64 VGPRs gets three waves, of at most 104 two
     (cells,) = find("k_match_topk_cells")
-    assert cells["VGPRs"] <= 72, cells            # two waves beside the growers (was 97: one)
+    assert cells["VGPRs"] <= 64, cells            # 97 at the start of round 3 (one wave beside the growers), 72 (two), now three
     (prep,) = find("k_match_prep")
-    assert prep["LDS Size"] <= 34 * 1024, prep    # two workgroups in the 75 KB the growers leave on a CU (was 41 KB: one)
+    assert prep["LDS Size"] <= 34 * 1024, prep    # two workgroups in the 77 KB the growers leave on a CU (was 41 KB: one)
     (srt,) = find("k_match_resolve_sorted")
     assert srt["VGPRs"] <= 128, srt
-    for name in ("k_fast_cells", "k_blur7", "k_orient_rbrief", "k_quadtree", "k_lbd"):
+    (qt,) = find("k_quadtree")
+    assert qt["VGPRs"] <= 64, qt                  # 68 with the sixteen per-value ballots of the radix ranking
+    (lbd,) = find("k_lbdENS")
+    assert lbd["VGPRs"] <= 64, lbd                # 76 with the f64 cos / sin of the line direction computed by all 64 lanes of the line's wave
+    (sob,) = find("k_blur_sobel")
+    assert sob["LDS Size"] <= 15 * 1024, sob      # five workgroups beside the growers (18.5 KB: four)
+    for name in ("k_fast_cells", "k_blur7", "k_orient_rbrief", "k_resize_linear"):
         for k in find(name):
-            assert k["VGPRs"] <= 80, (name, k)
+            assert k["VGPRs"] <= 72, (name, k)
     # the per-family instantiations of the generic matcher kernels exist (line, group, point)
     for name in ("k_match_topk_lanesILi", "k_match_topkILi", "k_match_resolve_genericILi"):
         assert len(find(name)) == 3, name
