@@ -344,12 +344,12 @@ __global__ __launch_bounds__(256) void k_match_topk(MatchProblem P) {
 
 // The same search with ONE LANE per query (each lane scans all targets and keeps its 8 best keys): for small target sets -- the key
 // lines of a frame, ~50 against ~50 -- a wave per query leaves most lanes without a target and spends more on merging the lanes'
-// lists than on the candidates.  grid = (ceil(m_cap / 64), B), block = 64.
+// lists than on the candidates.  grid = (min(2, ceil(m_cap / 64)), B), block = 64: the one or two waves of a frame walk its blocks of 64
+// queries (a frame has ~50-100 of a capacity of 512-1024: a workgroup per BLOCK of the capacity launched 24 576 waves per call of which
+// 20 000 only found that their block was empty, and the kernel took 0.28 ms for 60 us of work per active wave).
 template <int FAM>
-__global__ __launch_bounds__(64) void k_match_topk_lanes(MatchProblem P) {
-    const int b = blockIdx.y, q = blockIdx.x * 64 + threadIdx.x;
-    const int m = P.q_counts ? min(P.q_counts[b], P.m_cap) : P.m_cap;
-    if ((int)blockIdx.x * 64 >= m) return;   // the whole wave
+__device__ __forceinline__ void match_topk_lanes_block(const MatchProblem& P, int b, int qblock, int m) {
+    const int q = qblock * 64 + (int)threadIdx.x;
     // a lane without a query stays (the line family's loop below has every lane fetch one TARGET per chunk): `active` gates its query work
     bool active = q < m;
     uint32_t* klist = P.klist + ((size_t)b * P.m_cap + q) * kMatchK;
@@ -419,6 +419,12 @@ __global__ __launch_bounds__(64) void k_match_topk_lanes(MatchProblem P) {
 #pragma unroll
     for (int r = 0; r < kMatchK; ++r) klist[r] = pack_key(top[r]);
     *kcount = passed;
+}
+template <int FAM>
+__global__ __launch_bounds__(64) void k_match_topk_lanes(MatchProblem P) {
+    const int b = blockIdx.y;
+    const int m = P.q_counts ? min(P.q_counts[b], P.m_cap) : P.m_cap;
+    for (int qblock = blockIdx.x; qblock * 64 < m; qblock += gridDim.x) match_topk_lanes_block<FAM>(P, b, qblock, m);
 }
 
 // Main path.  k_match_prep buckets each frame's free, in-grid targets by grid ROW once (counting sort with LDS
@@ -1132,14 +1138,16 @@ void launch_match(hipStream_t st, const MatchProblem& P, int B) {
     if (!line && windowed && staged <= 64 * 1024 && P.grid_cols <= 255 && P.grid_rows <= 255) {
         hipLaunchKernelGGL(k_match_prep, dim3(B), dim3(256), 0, st, P);
         Q.sorted_valid = 1;
-        static const int qpb = [] { const char* e = getenv("PLP_MATCH_QPB"); const int v = e ? atoi(e) : 256; return v >= 16 && v % 16 == 0 ? v : 256; }();
+        // queries per workgroup = queries that share one staging of the frame's targets: 512 (alone the kernel is 3 % faster with 256 -- more workgroups
+        // in flight -- but the step is 0.7 % faster with 512, six passes each: half as many stagings beside the region growers)
+        static const int qpb = [] { const char* e = getenv("PLP_MATCH_QPB"); const int v = e ? atoi(e) : 512; return v >= 16 && v % 16 == 0 ? v : 512; }();
         hipLaunchKernelGGL(k_match_topk_cells, dim3((P.m_cap + qpb - 1) / qpb, B), dim3(256), staged, st, P, qpb);
     } else if (!line && !windowed && staged <= 64 * 1024) {
         hipLaunchKernelGGL(k_match_topk_lds, qgrid, dim3(256), staged, st, P);
     } else {
         const int gx_full = (P.m_cap + 3) / 4, gx_min = std::max(16, (8192 + B - 1) / B);   // keep >= ~8K workgroups in flight
         if (P.n_cap <= 512 && B >= 64) {   // small target sets, many frames
-            const dim3 g((P.m_cap + 63) / 64, B);
+            const dim3 g(std::min((P.m_cap + 63) / 64, 2), B);
             if (fam == kFamLine) hipLaunchKernelGGL(k_match_topk_lanes<kFamLine>, g, dim3(64), 0, st, P);
             else if (fam == kFamGroup) hipLaunchKernelGGL(k_match_topk_lanes<kFamGroup>, g, dim3(64), 0, st, P);
             else hipLaunchKernelGGL(k_match_topk_lanes<kFamPoint>, g, dim3(64), 0, st, P);
