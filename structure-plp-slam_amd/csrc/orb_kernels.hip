@@ -491,6 +491,17 @@ __global__ __launch_bounds__(256) void k_orient_rbrief(OrbPlanes pl, const uint8
     unsigned ublk, uframe;
     xcd_frame_major(ublk, uframe);   // a frame's patches (two planes, ~2.6 MB) stay in one L2
     const int tid = threadIdx.x, sub = tid & 15, frame = (int)uframe;
+    // Key point slots are dealt DENSELY: group d of 16 lanes takes the d-th selected key point of the frame (levels in order), which is also its
+    // output row.  The selection array is laid out by level CAPACITY (2032 slots for ~1000 key points at K = 1000): dealt by slot, half of
+    // the 16-lane groups -- the tail of every level's range -- loaded the tables, passed the barrier and left.
+    const int32_t* cnt = sel_count + frame * kMaxLevels;
+    int total = 0;
+    for (int l = 0; l < n_levels; ++l) total += cnt[l];
+    if (ublk == 0 && tid == 0) {
+        out_counts[frame] = min(total, cap);
+        if (total > cap) atomicOr(status, 1);
+    }
+    if ((int)ublk * 16 >= min(total, cap)) return;   // the whole workgroup, before it touches LDS
     if (tid < 128) {
         const int av = tid >> 3, j = tid & 7, half = um.v[av];
         uint32_t w0 = 0, w1 = 0;
@@ -502,20 +513,12 @@ __global__ __launch_bounds__(256) void k_orient_rbrief(OrbPlanes pl, const uint8
     }
     s_pat[tid] = reinterpret_cast<const uint32_t*>(c_pattern)[tid];
     __syncthreads();
-    const int g = (int)ublk * 16 + (tid >> 4);
-    if (g >= total_sel_cap) return;
-    int level = 0;
-    while (level + 1 < n_levels && g >= lv[level + 1].sel_base) ++level;
+    const int out_idx = (int)ublk * 16 + (tid >> 4);
+    if (out_idx >= total || out_idx >= cap) return;   // the 16 lanes of a key point leave together
+    int level = 0, i = out_idx;
+    while (level + 1 < n_levels && i >= cnt[level]) { i -= cnt[level]; ++level; }
     const LevelDev L = lv[level];
-    const int i = g - L.sel_base;
-    const int32_t* cnt = sel_count + frame * kMaxLevels;
-    int out_idx = i, total = 0;
-    for (int l = 0; l < n_levels; ++l) { const int c = cnt[l]; if (l < level) out_idx += c; total += c; }
-    if (g == 0 && sub == 0) {
-        out_counts[frame] = min(total, cap);
-        if (total > cap) atomicOr(status, 1);
-    }
-    if (i >= cnt[level] || out_idx >= cap) return;   // the 16 lanes of a key point leave together
+    const int g = L.sel_base + i;
 
     const uint32_t pk = (uint32_t)sel[(size_t)frame * total_sel_cap + g];
     const int cx = (int)(pk & 0xfff) + kOrbBorder, cy = (int)((pk >> 12) & 0xfff) + kOrbBorder;   // level pixel
