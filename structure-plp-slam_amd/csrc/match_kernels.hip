@@ -1138,9 +1138,11 @@ void launch_match(hipStream_t st, const MatchProblem& P, int B) {
     if (!line && windowed && staged <= 64 * 1024 && P.grid_cols <= 255 && P.grid_rows <= 255) {
         hipLaunchKernelGGL(k_match_prep, dim3(B), dim3(256), 0, st, P);
         Q.sorted_valid = 1;
-        // queries per workgroup = queries that share one staging of the frame's targets: 512 (alone the kernel is 3 % faster with 256 -- more workgroups
-        // in flight -- but the step is 0.7 % faster with 512, six passes each: half as many stagings beside the region growers)
-        static const int qpb = [] { const char* e = getenv("PLP_MATCH_QPB"); const int v = e ? atoi(e) : 512; return v >= 16 && v % 16 == 0 ? v : 512; }();
+        // queries per workgroup = queries that share one staging of the frame's targets.  Batches: 512 (alone the kernel is 3 % faster with 256 -- more
+        // workgroups in flight -- but the step is 0.7 % faster with 512, six passes each: half as many stagings beside the region growers).  A single
+        // frame or a few (the synchronous host-pointer entry): the CHIP is empty, so many small workgroups (PLP_MATCH_QPB overrides both).
+        static const int qpb_env = [] { const char* e = getenv("PLP_MATCH_QPB"); const int v = e ? atoi(e) : 0; return v >= 16 && v % 16 == 0 ? v : 0; }();
+        const int qpb = qpb_env ? qpb_env : (B >= 64 ? 512 : 32);   // one frame: last-frame matcher 0.40 ms with 32, 0.43 with 64, 0.46 with 256, 0.59 with 512
         hipLaunchKernelGGL(k_match_topk_cells, dim3((P.m_cap + qpb - 1) / qpb, B), dim3(256), staged, st, P, qpb);
     } else if (!line && !windowed && staged <= 64 * 1024) {
         hipLaunchKernelGGL(k_match_topk_lds, qgrid, dim3(256), staged, st, P);

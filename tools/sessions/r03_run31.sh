@@ -1,0 +1,10 @@
+# GPU session 31: full GPU suite, round profile (bench line, kernel trace, PMC passes), the other BASELINE configs
+export TMPDIR=/tmp
+O=gpurun_out/r03v; mkdir -p $O
+(timeout 800 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tail -6) > $O/pytest.log; cat $O/pytest.log
+bash tools/run_prof.sh r03v > $O/run_prof.log 2>&1
+tail -3 $O/run_prof.log
+(timeout 300 python tools/bench_configs.py --batch 1024 --steps 3 2>&1 | grep "^{" ) > $O/other_configs.jsonl; cat $O/other_configs.jsonl
+(timeout 200 python tools/fuzz_gpu.py --only lines --seconds 150 --seed 63 2>&1 | grep "lines:") > $O/fuzz.log
+(timeout 260 python tools/fuzz_gpu.py --only orb --seconds 200 --seed 26 2>&1 | grep "orb:") >> $O/fuzz.log
+cat $O/fuzz.log
