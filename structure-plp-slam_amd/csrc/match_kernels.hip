@@ -743,12 +743,11 @@ __device__ __forceinline__ bool accept(const MatchProblem& P, unsigned best, int
 // grid = (B), block = 256.  LDS: owner[2][n_cap] (dynamic).
 // kSorted: the windowed point modes after k_match_prep (a dry list is rescanned over the window's ranges of the sorted array); the other
 // instantiation rescans through candidate_key() and is the only one that carries its registers (all modes' gates, f64 epipolar tests).
-// BS = threads of the workgroup = queries of a chunk (256; 64 for the small problems of the key-line matchers: one wave per frame, no cross-wave barrier)
-template <bool kSorted, int FAM = kFamAny, int BS = 256>
+template <bool kSorted, int FAM = kFamAny>
 __device__ __forceinline__ void match_resolve_body(const MatchProblem& P) {
     const int mode = fam_mode<FAM>(P.mode);
     extern __shared__ int32_t lds[];
-    __shared__ int s_changed, s_num, s_hist[32], s_valid_bin[32], s_full_n, s_claim_tmp[BS], s_sort_ws[48];
+    __shared__ int s_changed, s_num, s_hist[32], s_valid_bin[32], s_full_n, s_claim_tmp[256], s_sort_ws[48];
     __shared__ unsigned s_sort_idx[32];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.x;
     const int m = P.q_counts ? min(P.q_counts[b], P.m_cap) : P.m_cap;
@@ -766,8 +765,8 @@ __device__ __forceinline__ void match_resolve_body(const MatchProblem& P) {
     const uint8_t* t_occ = P.t_occupied ? P.t_occupied + (size_t)b * P.n_cap : nullptr;
     int32_t* out = P.out_match + (size_t)b * P.n_cap;
 
-    for (int t = tid; t < n; t += BS) { owner_final[t] = 0x7fffffff; out[t] = -1; }
-    for (int q = tid; q < m; q += BS) claim[q] = -1;
+    for (int t = tid; t < n; t += 256) { owner_final[t] = 0x7fffffff; out[t] = -1; }
+    for (int q = tid; q < m; q += 256) claim[q] = -1;
     __syncthreads();
 
     int32_t* full_list = P.full_list + (size_t)b * P.m_cap;   // queries whose truncated best-K list ran dry
@@ -784,10 +783,10 @@ __device__ __forceinline__ void match_resolve_body(const MatchProblem& P) {
     // chunks gives the sequential answer.  (The first version iterated whole sweeps over all chunks: ~7 sweeps.)
     auto taken = [&](int t, int q, int) -> bool { return owner_final[t] != 0x7fffffff || owner_prev[t] < q; };
     {
-        for (int chunk_start = 0; chunk_start < m; chunk_start += BS) {
+        for (int chunk_start = 0; chunk_start < m; chunk_start += 256) {
           const int q = chunk_start + tid;
           int my_claim = -1;
-          for (int t = tid; t < n; t += BS) owner_prev[t] = 0x7fffffff;
+          for (int t = tid; t < n; t += 256) owner_prev[t] = 0x7fffffff;
           // the query's best-K list and candidate count: read once per chunk (two 16-byte loads), the iterations work on registers
           constexpr int kList = kSorted ? 2 * kMatchK : kMatchK;   // k_match_topk_cells also leaves ranks 9..16 of a crowded window
           uint32_t e8[kList];
@@ -807,9 +806,9 @@ __device__ __forceinline__ void match_resolve_body(const MatchProblem& P) {
                   }
               }
           }
-          for (int inner = 0; inner <= BS; ++inner) {
+          for (int inner = 0; inner <= 256; ++inner) {
             if (tid == 0) { s_full_n = 0; s_changed = 0; }
-            for (int t = tid; t < n; t += BS) owner_next[t] = 0x7fffffff;
+            for (int t = tid; t < n; t += 256) owner_next[t] = 0x7fffffff;
             __syncthreads();
             int new_claim = -1;
             bool decided = false;
@@ -850,7 +849,7 @@ __device__ __forceinline__ void match_resolve_body(const MatchProblem& P) {
             // rare: exact two-best over the query's whole window with the occupancy filter, one wave per query
             const int nf = s_full_n;
             if (tid == 0 && P.dbg && nf) atomicAdd(&P.dbg[0], nf);
-            for (int f = wv; f < nf; f += BS / 64) {
+            for (int f = wv; f < nf; f += 4) {
                 const int fq = full_list[f];
                 const QueryCtx c = make_query<FAM>(P, fq, b);
                 const uint4* qd = reinterpret_cast<const uint4*>(P.q_desc + ((size_t)b * P.q_desc_stride + fq) * 32);
@@ -926,7 +925,7 @@ __device__ __forceinline__ void match_resolve_body(const MatchProblem& P) {
 
     // ---- results: last writer per key point, number of accepted queries, delta-angle histogram check
     if (tid == 0) s_num = 0;
-    for (int i = tid; i < 32; i += BS) { s_hist[i] = 0; s_valid_bin[i] = 0; }
+    for (int i = tid; i < 32; i += 256) { s_hist[i] = 0; s_valid_bin[i] = 0; }
     __syncthreads();
     const bool angle_check = P.check_orientation && (mode == PLP_MATCH_MODE_LAST_FRAME || mode == PLP_MATCH_MODE_BRUTE_FORCE || is_group_mode(mode));
     const float* q_angle = P.q_angle ? P.q_angle + (size_t)b * P.m_cap : nullptr;
@@ -942,7 +941,7 @@ __device__ __forceinline__ void match_resolve_body(const MatchProblem& P) {
         return (unsigned)bin > 31u ? 31 : bin;
     };
     int my = 0;
-    for (int q = tid; q < m; q += BS) {
+    for (int q = tid; q < m; q += 256) {
         const int t = claim[q];
         if (t < 0) continue;
         ++my;
@@ -958,7 +957,7 @@ __device__ __forceinline__ void match_resolve_body(const MatchProblem& P) {
         }
         __syncthreads();
         int bad = 0;
-        for (int q = tid; q < m; q += BS) {
+        for (int q = tid; q < m; q += 256) {
             const int t = claim[q];
             if (t < 0) continue;
             if (!s_valid_bin[min(bin_of(q, t), 31)]) { out[t] = (P.flags & PLP_MATCH_FLAG_MARK_INVALIDATED) ? -2 : -1; ++bad; }
@@ -976,7 +975,7 @@ __device__ __forceinline__ void match_resolve_body(const MatchProblem& P) {
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_match_resolve_sorted(MatchProblem P) { match_resolve_body<true, kFamGrid>(P); }
 template <int FAM>
 __global__ __launch_bounds__(256) void k_match_resolve_generic(MatchProblem P) { match_resolve_body<false, FAM>(P); }
-// (A 64-thread instantiation for the key-line matchers -- one wave per problem, match_resolve_body<false, FAM, 64> -- runs 0.1 instead of 2.2 ms per
+// (A 64-thread instantiation for the key-line matchers -- one wave per problem -- runs 0.1 instead of 2.2 ms per
 // call INSIDE the step, where the 256-thread workgroups get one slot per CU, but 0.21 instead of 0.075 ms alone, and the step follows the isolated
 // times: measured, not kept; profiles/r03_scheduling_experiments.md.)
 
