@@ -1567,7 +1567,7 @@ __constant__ int c_comb[32][2] = {{0, 1}, {0, 2}, {0, 3}, {0, 4}, {0, 5}, {0, 6}
                                   {2, 3}, {2, 4}, {2, 5}, {2, 6}, {2, 7}, {2, 8}, {3, 4}, {3, 5}, {3, 6}, {3, 7}, {3, 8},
                                   {4, 5}, {4, 6}, {4, 7}, {4, 8}, {5, 6}, {5, 7}, {5, 8}, {6, 7}, {6, 8}, {7, 8}};
 
-// grid = (4, B), block = 256: one wave per line, 16 lines of a frame in flight (more waves thrash L1/L2: every wave
+// grid = (2, B), block = 256: one wave per line, 8 lines of a frame in flight (more waves thrash L1/L2: every wave
 // keeps 63 image rows live).
 __global__ __launch_bounds__(256) void k_lbd(LinePlanes P, LbdWeightsDev W) {
     __shared__ float s_row[4][63][8];   // per row: pgdL, ngdL, pgdL2, ngdL2, pgdO, ngdO, pgdO2, ngdO2 (after the global weight)
@@ -1814,7 +1814,10 @@ void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp,
         hipLaunchKernelGGL(k_blur_sobel, dim3(sobel_tiles, B), dim3(256), 0, st, P.img, P.img_frame_stride, P.img_pitch, P.dxy, P.W, P.H, t5);
     }
     mark(6);
-    static const int lbd_blocks = [] { const char* e = getenv("PLP_LBD_BLOCKS"); int r = e ? atoi(e) : 4; return r > 0 ? r : 4; }();   // few resident waves per frame: their 63-row working sets have to stay in L1/L2
+    // few resident waves per frame: their 63-row working sets have to stay in L1 / L2.  Workgroups of four waves per frame, kernel alone / step: 1: 1.41 ms /
+    // 87.4 k frames/s, 2: 1.37 / 88.0 k, 3: 1.30 / 86.7 k, 4: 1.40 / 87.5 k, 8: 1.64 / 86.8 k, 16: 1.78 / 86.8 k (sessions 35, 36; the step numbers are within
+    // their run-to-run spread of each other below 8)
+    static const int lbd_blocks = [] { const char* e = getenv("PLP_LBD_BLOCKS"); int r = e ? atoi(e) : 2; return r > 0 ? r : 2; }();
     hipLaunchKernelGGL(k_lbd, dim3(lbd_blocks, B), dim3(256), 0, st, P, w);
     mark(7);
     hipLaunchKernelGGL(k_line_finalize, dim3(B), dim3(64), 0, st, P, lp, out_kl, out_lbd, out_fn, cap, out_counts);
