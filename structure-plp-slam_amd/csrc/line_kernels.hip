@@ -1817,7 +1817,8 @@ void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp,
     // few resident waves per frame: their 63-row working sets have to stay in L1 / L2.  Workgroups of four waves per frame, kernel alone / step: 1: 1.41 ms /
     // 87.4 k frames/s, 2: 1.37 / 88.0 k, 3: 1.30 / 86.7 k, 4: 1.40 / 87.5 k, 8: 1.64 / 86.8 k, 16: 1.78 / 86.8 k (sessions 35, 36; the step numbers are within
     // their run-to-run spread of each other below 8)
-    static const int lbd_blocks = [] { const char* e = getenv("PLP_LBD_BLOCKS"); int r = e ? atoi(e) : 2; return r > 0 ? r : 2; }();
+    static const int lbd_blocks_env = [] { const char* e = getenv("PLP_LBD_BLOCKS"); int r = e ? atoi(e) : 0; return r > 0 ? r : 0; }();
+    const int lbd_blocks = lbd_blocks_env ? lbd_blocks_env : (B >= 64 ? 2 : 16);   // a single frame (plp_line_extract): the chip is empty, one wave per line
     hipLaunchKernelGGL(k_lbd, dim3(lbd_blocks, B), dim3(256), 0, st, P, w);
     mark(7);
     hipLaunchKernelGGL(k_line_finalize, dim3(B), dim3(64), 0, st, P, lp, out_kl, out_lbd, out_fn, cap, out_counts);
