@@ -1,0 +1,69 @@
+"""Index arithmetic of three kernels restated in numpy and checked exhaustively / on random inputs (no GPU): the pieces of late round 3 whose
+correctness is a statement about integers, not about the device.
+
+  k_orient_rbrief   groups of 16 lanes take the frame's selected key points DENSELY (group d -> (level, i) through the per-level counts) instead
+                    of by slot of the per-level capacity: the same (selection slot, output row) pairs, in the same output order
+  k_quadtree        radix ranking: a lane's peers (lanes holding the same digit) from one ballot per BIT of the digit = the lane's own of the
+                    sixteen per-VALUE ballots
+  k_lsd_gradient    pixel index / scaled width as mulhi(idx, ceil(2^32 / width)): exact for every index of every admissible frame
+"""
+import numpy as np
+
+
+def test_dense_dealing_of_selected_key_points_equals_dealing_by_capacity_slot():
+    r = np.random.default_rng(3)
+    for trial in range(300):
+        n_levels = int(r.integers(1, 9))
+        caps = r.integers(1, 60, n_levels)
+        cnt = np.array([int(r.integers(0, c + 1)) for c in caps])
+        if trial % 7 == 0:
+            cnt[:] = 0
+        sel_base = np.concatenate([[0], np.cumsum(caps)[:-1]])
+        total_cap, cap_out = int(caps.sum()), int(r.integers(1, caps.sum() + 8))
+        # by slot (the kernel until late round 3): slot g -> level by sel_base, i = g - sel_base, output row = i + counts of the levels before
+        by_slot = []
+        for g in range(total_cap):
+            level = int(np.searchsorted(sel_base, g, side="right") - 1)
+            i = g - sel_base[level]
+            out = i + int(cnt[:level].sum())
+            if i < cnt[level] and out < cap_out:
+                by_slot.append((out, g))
+        # densely: group d = output row; level / i by walking the counts; slot = sel_base + i
+        total = int(cnt.sum())
+        dense = []
+        n_groups = (total_cap + 15) // 16 * 16
+        for d in range(n_groups):
+            if d >= total or d >= cap_out:
+                continue
+            level, i = 0, d
+            while level + 1 < n_levels and i >= cnt[level]:
+                i -= cnt[level]; level += 1
+            dense.append((d, int(sel_base[level] + i)))
+        assert sorted(by_slot) == dense, (caps, cnt, cap_out)
+
+
+def test_peers_from_bit_ballots_equal_the_per_value_ballot():
+    r = np.random.default_rng(4)
+    for trial in range(2000):
+        d = r.integers(0, 17, 64)          # digit 0..15, 16 = the lanes past the end of the array
+        if trial % 5 == 0:
+            d[:] = r.integers(0, 17)
+        lanes = np.arange(64)
+        peers = np.full(64, (1 << 64) - 1, dtype=object)
+        for bit in range(5):
+            ballot = sum(1 << int(l) for l in lanes[(d >> bit) & 1 == 1])
+            for l in lanes:
+                peers[l] &= ballot if (d[l] >> bit) & 1 else ~ballot & ((1 << 64) - 1)
+        for l in lanes:
+            want = sum(1 << int(k) for k in lanes[d == d[l]])
+            assert peers[l] == want
+
+
+def test_magic_division_by_the_scaled_width_is_exact_for_every_admitted_frame():
+    n_max = 516_065                         # kLsdMaxScaledPixels (csrc/line_device.hpp)
+    for sw in list(range(2, 2050)) + [4095, 4096, 8191, 8192]:
+        magic = ((1 << 32) + sw - 1) // sw
+        assert magic < (1 << 32)
+        idx = np.unique(np.concatenate([np.arange(0, min(n_max, 3 * sw + 5)), np.arange(max(0, n_max - 3 * sw - 5), n_max),
+                                        np.arange(0, n_max, max(1, n_max // 4096))])).astype(np.uint64)
+        assert np.array_equal((idx * np.uint64(magic)) >> np.uint64(32), idx // np.uint64(sw)), sw
