@@ -184,6 +184,8 @@ def main():
         nt, m = int(rng.integers(1, 2500)), int(rng.integers(1, 3000))
         t, q = MC.random_problem(rng, nt, m, n_words=int(rng.choice([0, 0, 3, 20])), stereo=bool(rng.integers(0, 2)))
         margin, ratio = float(rng.uniform(2, 40)), float(rng.choice([0.6, 0.75, 0.9]))
+        # the LDS-size hint never changes a result: none / far too small / a little too small / generous, at random
+        t = {**t, "t_count_hint": int(rng.choice([0, max(1, nt // 4), max(1, nt - 1), nt + 100]))}
         want, wn = O.match_frame_and_landmarks(O.grid6(grid), t["t_kps"], t["t_desc"], t["t_x_right"], t["t_occupied"], SF, q["q_valid"], q["q_reproj"],
                                                q["q_x_right"], q["q_level"], q["q_desc"], q["q_has_obs"], margin, ratio)
         got, gn = plp.matcher(ratio, False).match_host(plp.MODE_LANDMARKS, nt, m, {**t, **q}, margin=margin, scale_factors=SF, grid=grid)
