@@ -193,6 +193,16 @@ plp_status plp_line_get_stage_times(plp_line* ctx, double* ms9, int64_t* n_batch
  * of at most 256 frames -- the single-frame call of data/frame.cc:1146-1163 --, one wave per frame for larger batches; 1 = always one wave
  * per frame; 2..8 = that many waves for every batch of at most 256 frames.  The results are identical whichever is used. */
 plp_status plp_line_set_grow_waves(plp_line* ctx, int32_t waves);
+/* The order in which LSD visits its seed pixels.  OpenCV's lsd.cpp (reached from LSDDetector_custom.cpp:244-257) sorts every pixel by
+ * gradient bin with std::sort and a comparator that looks at the bin only: inside a bin the order is whatever the C++ library's
+ * (unstable) algorithm leaves, and region growing depends on it.
+ *   PLP_SEED_ORDER_LIBSTDCXX  the permutation libstdc++'s std::sort produces (introsort replayed on the device, seed_sort_kernels.hip):
+ *                             bit-identical to a reference built with GCC's library
+ *   PLP_SEED_ORDER_STABLE     bin descending, row-major inside a bin (what the LSD paper describes; cheaper: only defined pixels are sorted)
+ * 3.5 % of the key lines differ between the two. */
+typedef enum plp_seed_order { PLP_SEED_ORDER_STABLE = 0, PLP_SEED_ORDER_LIBSTDCXX = 1 } plp_seed_order;
+plp_status plp_line_set_seed_order(plp_line* ctx, int32_t order);
+plp_status plp_line_get_seed_order(const plp_line* ctx, int32_t* order);
 
 /* Stage read-back for parity tests (synchronous, host destination, frame of the last call):
  *   SCALED   u8 sh x sw dense (the 11-tap blur + x0.5 image LSD works on)
@@ -211,6 +221,12 @@ plp_status plp_line_debug_read(plp_line* ctx, plp_line_debug_id what, int32_t fr
  * src/PLPSLAM/match/angle_checker.h:165-176; the kernels reproduce libstdc++'s algorithm so that ties fall as in a reference built with
  * GCC): idx = the indices 0..n-1, n <= 64, in that order.  depth_limit < 0 = the library's recursion budget.  No GPU needed. */
 int32_t plp_model_index_sort_host(const int32_t* sizes, int32_t n, int32_t depth_limit, uint32_t* idx);
+/* Host model of the exact seed sort (csrc/seed_sort_model.hpp): std::__introsort_loop, in place, on n entries whose sort key is bits 20..29
+ * (larger first), computed as the rank-paired partitions the kernel runs; depth_limit < 0 = the library's 2 * floor(log2 n).  No GPU needed.
+ * Returns 0, or -1 for a bad argument. */
+int32_t plp_model_seed_introsort_host(uint32_t* entries, int64_t n, int32_t depth_limit);
+/* Test entry: the KERNEL's introsort loop on caller-made entries (host pointer, in place), one workgroup, chosen recursion budget. */
+plp_status plp_seed_introsort_debug(int32_t device, uint32_t* entries, int64_t n, int32_t depth_limit);
 /* Host model of the LSD gradient kernel's (float)cos((double)a), (float)sin((double)a) fast path (csrc/sincos_ziv.hpp): proven[i] = 0 marks the
  * arguments for which the kernel falls back to the general f64 routine.  Returns the number of proven arguments.  No GPU needed. */
 int32_t plp_model_sincos_host(const float* a, int64_t n, float* c, float* s, uint8_t* proven);

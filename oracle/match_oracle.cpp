@@ -159,6 +159,23 @@ void oracle_index_sort_by_size(const int* sizes, int n, unsigned* idx) {
     std::sort(v.begin(), v.end(), [&](unsigned a, unsigned b) { return sizes[a] > sizes[b]; });
     for (int i = 0; i < n; ++i) idx[i] = v[i];
 }
+// The real thing the exact seed order is measured against (csrc/seed_sort_model.hpp): this machine's std::sort on 32-bit entries compared by
+// bits 20..29, larger first -- the comparator of lsd.cpp's ordered_points (bin only), with the pixel index as payload -- and, to check the
+// intermediate state and forced recursion budgets, libstdc++'s own std::__introsort_loop.
+void oracle_std_sort_entries(unsigned* e, long n) {
+    std::sort(e, e + n, [](unsigned a, unsigned b) { return (a >> 20) > (b >> 20); });
+}
+int oracle_std_introsort_loop_entries(unsigned* e, long n, int depth_limit) {
+#if defined(__GLIBCXX__)
+    auto cmp = [](unsigned a, unsigned b) { return (a >> 20) > (b >> 20); };
+    if (depth_limit < 0) depth_limit = 2 * std::__lg(n);
+    if (n > 0) std::__introsort_loop(e, e + n, (long)depth_limit, __gnu_cxx::__ops::__iter_comp_iter(cmp));
+    return 1;
+#else
+    (void)e; (void)n; (void)depth_limit;
+    return 0;      // another C++ library: its std::sort is another algorithm, nothing to compare the restatement with
+#endif
+}
 unsigned oracle_hamming32(const uint8_t* a, const uint8_t* b) { return hamming32(a, b); }
 unsigned oracle_hamming64(const uint8_t* a, const uint8_t* b) { return hamming64(a, b); }
 

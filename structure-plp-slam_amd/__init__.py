@@ -15,7 +15,7 @@ import numpy as np
 
 _PKG = pathlib.Path(__file__).resolve().parent
 ROOT = _PKG.parent
-LIB_PATH = _PKG / "libplp_front.so"
+LIB_PATH = pathlib.Path(os.environ["PLP_FRONT_LIB"]).resolve() if os.environ.get("PLP_FRONT_LIB") else _PKG / "libplp_front.so"   # PLP_FRONT_LIB: an experiment's build (tools/build_variant.sh)
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
                      ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
@@ -77,6 +77,10 @@ _API = [
     ("plp_line_last_batch_status", C.c_int, [_VP]),
     ("plp_line_set_profiling", C.c_int, [_VP, _I32]),
     ("plp_line_set_grow_waves", C.c_int, [_VP, _I32]),
+    ("plp_line_set_seed_order", C.c_int, [_VP, _I32]),
+    ("plp_line_get_seed_order", C.c_int, [_VP, _VP]),
+    ("plp_model_seed_introsort_host", _I32, [_VP, C.c_int64, _I32]),
+    ("plp_seed_introsort_debug", C.c_int, [_I32, _VP, C.c_int64, _I32]),
     ("plp_line_get_stage_times", C.c_int, [_VP, _VP, _VP]),
     ("plp_line_debug_read", C.c_int, [_VP, C.c_int, _I32, _VP, _SZ, _VP]),
     ("plp_line_scaled_size", C.c_int, [_VP, _VP, _VP]),
@@ -153,6 +157,23 @@ def model_quadtree(xys, level_w, level_h, quota):
     out = np.zeros(max(len(xys), 1), np.int32)
     m = lib().plp_model_quadtree_host(_p(xys), len(xys), level_w, level_h, quota, _p(out))
     return out[:m].copy()
+
+
+SEED_ORDER_STABLE, SEED_ORDER_LIBSTDCXX = 0, 1          # plp_seed_order (include/plp_front.h)
+
+
+def model_seed_introsort(entries, depth_limit=-1):
+    """Host model of the exact seed sort: std::__introsort_loop on entries keyed by bits 20..29 (larger first), as rank-paired partitions; no GPU"""
+    e = np.ascontiguousarray(entries, np.uint32).copy()
+    assert lib().plp_model_seed_introsort_host(_p(e), e.size, int(depth_limit)) == 0
+    return e
+
+
+def seed_introsort_debug(entries, depth_limit=-1, device=0):
+    """The KERNEL's introsort loop on caller-made entries (one workgroup), with a chosen recursion budget"""
+    e = np.ascontiguousarray(entries, np.uint32).copy()
+    _check(lib().plp_seed_introsort_debug(int(device), _p(e), e.size, int(depth_limit)))
+    return e
 
 
 def model_index_sort(sizes, depth_limit=-1):
@@ -342,6 +363,10 @@ class LineFeatureTracker:
         n = C.c_int32(0)
         _check(lib().plp_line_extract(self._h, _p(img), img.shape[0], img.shape[1], img.strides[0], _p(kl), _p(lbd), _p(fn), LINE_CAP, C.byref(n)))
         return kl[:n.value].copy(), lbd[:n.value].copy(), fn[:n.value].copy()
+
+    def set_seed_order(self, order):
+        """SEED_ORDER_LIBSTDCXX: the seed order of a reference built with GCC's library, SEED_ORDER_STABLE: row-major inside a bin (plp_line_set_seed_order)"""
+        _check(lib().plp_line_set_seed_order(self._h, int(order)))
 
     def set_grow_waves(self, waves):
         """0 = automatic, 1 = one wave per frame in LSD region growing, 2..8 = that many waves per frame (plp_line_set_grow_waves)"""

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "line_device.hpp"
+#include "seed_sort_model.hpp"
 #include "sincos_ziv.hpp"
 #include "plp_common.hpp"
 
@@ -19,12 +20,15 @@ struct plp_line {
     hipStream_t stream = nullptr;
     int rows = 0, cols = 0, capB = 0;
     int grow_waves = 0;   // plp_line_set_grow_waves
+    int seed_order = PLP_SEED_ORDER_STABLE;   // plp_line_set_seed_order
+    bool mw_ok = false, seed_sort_ok = false;  // this device accepted the large dynamic-LDS limits of k_lsd_grow_mw / k_lsd_seed_sort
+    int mw_capB = 0, seed_capB = 0;            // frames the lazily allocated buffers of those two paths hold
     LinePlanes P{};
     LsdParams lp{};
     ResizeExactTab rt{};
     BlurTapsN t11{}, t5{};
     LbdWeightsDev w{};
-    DevBuf tabs, blur11, scaled, pix, g2, maxgrad, undef, order, n_order, reg, mw_heap, raw, n_raw, dx, dy, all_kl, all_kl_dir, all_lbd, n_all, status, prof, grow_stats;
+    DevBuf tabs, blur11, scaled, pix, g2, maxgrad, undef, order, n_order, reg, mw_heap, seed_ent, seed_ws, raw, n_raw, dx, dy, all_kl, all_kl_dir, all_lbd, n_all, status, prof, grow_stats;
     DevBuf l0copy, s_kl, s_lbd, s_fn, s_cnt;   // host-API staging
     DevBuf aligned;                             // aligned copy of odd-pitch device frames
     int s_cap = 0;
@@ -126,36 +130,46 @@ plp_status build(plp_line* c, int rows, int cols) {
     PLP_HIP(hipStreamSynchronize(c->stream));
     const int16_t* base = (const int16_t*)c->tabs.p;
     c->rt.xo = base; c->rt.xc = base + P.sw; c->rt.yo = base + 2 * P.sw; c->rt.yc = base + 2 * P.sw + P.sh;
-    c->rows = rows; c->cols = cols; c->capB = 0;
+    c->rows = rows; c->cols = cols; c->capB = 0; c->mw_capB = 0; c->seed_capB = 0;
     return PLP_OK;
 }
 
 plp_status ensure(plp_line* c, int B) {
-    if (B <= c->capB) return PLP_OK;
     LinePlanes& P = c->P;
     const size_t n = (size_t)P.sw * P.sh, nv = (size_t)(P.sw - 1) * (P.sh - 1);
-    if (!P.half_exact) PLP_HIP(c->blur11.reserve((size_t)P.pitch * P.H * B));   // only the two-kernel fallback of the LSD front writes the blurred plane
-    PLP_HIP(c->scaled.reserve((size_t)P.spitch * P.sh * B));
-    PLP_HIP(c->pix.reserve(n * sizeof(LsdPix) * B));
-    PLP_HIP(c->g2.reserve(n * 4 * B)); PLP_HIP(c->n_order.reserve(4 * (size_t)B)); PLP_HIP(c->maxgrad.reserve(4 * ((n + 255) / 256) * (size_t)B)); PLP_HIP(c->undef.reserve((n + 63) / 64 * 8 * B));
-    // region lists: two per frame (several waves per frame, k_lsd_grow_mw, write the refinement's regrowth behind the first growth), and
-    // the helper waves' lists for as many frames as that path is used for (small batches: kLsdMwMaxFrames)
-    P.reg_frame_stride = 2 * n;
+    const int Bmw = std::min(B, kLsdMwMaxFrames);
+    // Region lists: one per frame; two where several waves share a frame (k_lsd_grow_mw writes the refinement's regrowth behind the first growth),
+    // which only batches of at most kLsdMwMaxFrames frames do.  The buffer holds either layout, the stride is chosen per launch.
+    if (B > c->capB) {
+        if (!P.half_exact) PLP_HIP(c->blur11.reserve((size_t)P.pitch * P.H * B));   // only the two-kernel fallback of the LSD front writes the blurred plane
+        PLP_HIP(c->scaled.reserve((size_t)P.spitch * P.sh * B));
+        PLP_HIP(c->pix.reserve(n * sizeof(LsdPix) * B));
+        PLP_HIP(c->g2.reserve(n * 4 * B)); PLP_HIP(c->n_order.reserve(4 * (size_t)B)); PLP_HIP(c->maxgrad.reserve(4 * ((n + 255) / 256) * (size_t)B)); PLP_HIP(c->undef.reserve((n + 63) / 64 * 8 * B));
+        PLP_HIP(c->order.reserve(nv * 4 * B)); PLP_HIP(c->reg.reserve(std::max(n * (size_t)B, 2 * n * (size_t)Bmw) * 4));
+        PLP_HIP(c->raw.reserve(sizeof(float4) * kLineCap * B)); PLP_HIP(c->n_raw.reserve(4 * (size_t)B));
+        PLP_HIP(c->dx.reserve(dxy_frame_entries(P.W, P.H) * 4 * B));
+        PLP_HIP(c->all_kl.reserve(sizeof(plp_keyline) * kLineCap * B)); PLP_HIP(c->all_kl_dir.reserve(sizeof(float2) * kLineCap * B)); PLP_HIP(c->all_lbd.reserve((size_t)32 * kLineCap * B));
+        PLP_HIP(c->n_all.reserve(4 * (size_t)B)); PLP_HIP(c->status.reserve(16)); PLP_HIP(c->prof.reserve(128)); PLP_HIP(c->grow_stats.reserve(16 * (size_t)B));
+        P.blur11 = (uint8_t*)c->blur11.p; P.scaled = (uint8_t*)c->scaled.p;
+        P.pix = (LsdPix*)c->pix.p; P.g2 = (uint32_t*)c->g2.p; P.n_order = (int32_t*)c->n_order.p;
+        P.blockmax = (uint32_t*)c->maxgrad.p; P.undef = (unsigned long long*)c->undef.p;
+        P.order = (uint32_t*)c->order.p; P.reg = (uint32_t*)c->reg.p; P.raw = (float4*)c->raw.p; P.n_raw = (int32_t*)c->n_raw.p;
+        P.dxy = (short2*)c->dx.p; P.all_kl = (plp_keyline*)c->all_kl.p; P.all_kl_dir = (float2*)c->all_kl_dir.p; P.all_lbd = (uint8_t*)c->all_lbd.p;
+        P.n_all = (int32_t*)c->n_all.p; P.status = (int32_t*)c->status.p; P.prof = (long long*)c->prof.p; P.grow_stats = (int32_t*)c->grow_stats.p;
+        c->capB = B;
+    }
+    P.reg_frame_stride = B <= kLsdMwMaxFrames ? 2 * n : n;
+    // the helper waves' lists: only a batch that can take the several-waves path needs them (3.7 MB per frame: not for the 1024-frame contexts of a replay)
     P.mw_heap_frame_stride = (size_t)(kMwMaxWaves - 1) * kMwHeapBufs * kMwHeap;
-    PLP_HIP(c->order.reserve(nv * 4 * B)); PLP_HIP(c->reg.reserve(P.reg_frame_stride * 4 * B));
-    PLP_HIP(c->mw_heap.reserve(P.mw_heap_frame_stride * 4 * (size_t)std::min(B, kLsdMwMaxFrames)));
-    P.mw_heap = (uint32_t*)c->mw_heap.p;
-    PLP_HIP(c->raw.reserve(sizeof(float4) * kLineCap * B)); PLP_HIP(c->n_raw.reserve(4 * (size_t)B));
-    PLP_HIP(c->dx.reserve(dxy_frame_entries(P.W, P.H) * 4 * B));
-    PLP_HIP(c->all_kl.reserve(sizeof(plp_keyline) * kLineCap * B)); PLP_HIP(c->all_kl_dir.reserve(sizeof(float2) * kLineCap * B)); PLP_HIP(c->all_lbd.reserve((size_t)32 * kLineCap * B));
-    PLP_HIP(c->n_all.reserve(4 * (size_t)B)); PLP_HIP(c->status.reserve(16)); PLP_HIP(c->prof.reserve(128)); PLP_HIP(c->grow_stats.reserve(16 * (size_t)B));
-    P.blur11 = (uint8_t*)c->blur11.p; P.scaled = (uint8_t*)c->scaled.p;
-    P.pix = (LsdPix*)c->pix.p; P.g2 = (uint32_t*)c->g2.p; P.n_order = (int32_t*)c->n_order.p;
-    P.blockmax = (uint32_t*)c->maxgrad.p; P.undef = (unsigned long long*)c->undef.p;
-    P.order = (uint32_t*)c->order.p; P.reg = (uint32_t*)c->reg.p; P.raw = (float4*)c->raw.p; P.n_raw = (int32_t*)c->n_raw.p;
-    P.dxy = (short2*)c->dx.p; P.all_kl = (plp_keyline*)c->all_kl.p; P.all_kl_dir = (float2*)c->all_kl_dir.p; P.all_lbd = (uint8_t*)c->all_lbd.p;
-    P.n_all = (int32_t*)c->n_all.p; P.status = (int32_t*)c->status.p; P.prof = (long long*)c->prof.p; P.grow_stats = (int32_t*)c->grow_stats.p;
-    c->capB = B;
+    if (c->mw_ok && B <= kLsdMwMaxFrames && B > c->mw_capB) {
+        PLP_HIP(c->mw_heap.reserve(P.mw_heap_frame_stride * 4 * (size_t)B));
+        c->mw_capB = B;
+    }
+    P.mw_heap = (B <= c->mw_capB) ? (uint32_t*)c->mw_heap.p : nullptr;
+    if (c->seed_order == PLP_SEED_ORDER_LIBSTDCXX && B > c->seed_capB) {
+        PLP_HIP(c->seed_ent.reserve(nv * 4 * (size_t)B)); PLP_HIP(c->seed_ws.reserve(seed_sort_ws_entries(nv) * 4 * (size_t)B));
+        c->seed_capB = B;
+    }
     return PLP_OK;
 }
 
@@ -174,8 +188,12 @@ plp_status run(plp_line* c, const uint8_t* d_imgs, int B, int rows, int cols, si
         c->P.img = (const uint8_t*)c->aligned.p; c->P.img_frame_stride = fs; c->P.img_pitch = c->P.pitch;
     }
     PLP_HIP(hipMemsetAsync(c->status.p, 0, 16, st));
+    if (c->profiling) PLP_HIP(hipMemsetAsync(c->prof.p, 0, 128, st));   // the one-wave kernel writes slots 0..5 only: no stale counts of an earlier several-waves launch
+    const bool exact = c->seed_order == PLP_SEED_ORDER_LIBSTDCXX;
+    c->lp.seed_exact = exact ? 1 : 0;
+    const SeedSortBufs ssb{(uint32_t*)c->seed_ent.p, (uint32_t*)c->seed_ws.p, seed_sort_ws_entries((size_t)(c->P.sw - 1) * (c->P.sh - 1))};
     launch_line_front(st, c->P, c->lp, c->rt, c->t11, c->t5, c->w, d_kl, d_lbd, d_fn, cap, d_counts, B, c->profiling ? c->ev : nullptr,
-                      c->side.stream ? &c->side : nullptr, c->grow_waves);
+                      c->side.stream ? &c->side : nullptr, c->grow_waves, exact ? &ssb : nullptr, c->mw_ok);
     PLP_HIP(hipGetLastError());
     if (c->profiling) {
         PLP_HIP(hipEventSynchronize(c->ev[8]));
@@ -200,6 +218,10 @@ plp_status plp_line_create(int device, plp_line** out) {
     PLP_HIP(hipSetDevice(device));
     plp_line* c = new plp_line();
     c->device = device;
+    // dynamic-LDS limits are per function AND per device: raised here, for this context's device, not once per process
+    c->mw_ok = grow_mw_configure() == hipSuccess;
+    c->seed_sort_ok = seed_sort_configure() == hipSuccess;
+    (void)hipGetLastError();
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return set_error(PLP_ERR_HIP, "hipStreamCreate failed"); }
     if (hipStreamCreateWithFlags(&c->side.stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->side.fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->side.join, hipEventDisableTiming) != hipSuccess) { c->side.stream = nullptr; }   // optional: falls back to one stream
@@ -238,6 +260,7 @@ plp_status plp_line_last_batch_status(plp_line* c) {
     if (s[0] & 1) return set_error(PLP_ERR_CAPACITY, "a frame produced more lines than `cap`; output truncated");
     if (s[0] & 4) return set_error(PLP_ERR_OVERFLOW, "more LSD segments than the per-frame capacity");
     if (s[0] & 16) return set_error(PLP_ERR_HIP, "region growing with several waves per frame timed out in a wait (protocol error, please report the frame)");
+    if (s[0] & 32) return set_error(PLP_ERR_OVERFLOW, "the exact seed sort ran out of queue space (please report the frame)");
     return PLP_OK;
 }
 
@@ -280,6 +303,7 @@ plp_status plp_line_extract(plp_line* c, const uint8_t* img, int32_t rows, int32
     PLP_HIP(hipMemcpy(s, c->status.p, 16, hipMemcpyDeviceToHost));
     if (s[0] & 4) return set_error(PLP_ERR_OVERFLOW, "more LSD segments than the per-frame capacity");
     if (s[0] & 16) return set_error(PLP_ERR_HIP, "region growing with several waves per frame timed out in a wait (protocol error, please report the frame)");
+    if (s[0] & 32) return set_error(PLP_ERR_OVERFLOW, "the exact seed sort ran out of queue space (please report the frame)");
     return PLP_OK;
 }
 
@@ -301,6 +325,21 @@ plp_status plp_line_set_grow_waves(plp_line* c, int32_t waves) {
     if (waves < 0 || waves > kMwMaxWaves) return set_error(PLP_ERR_INVALID_ARG, "waves must be 0 (automatic) .. 8");
     std::lock_guard<std::mutex> lk(c->mu);
     c->grow_waves = waves;
+    return PLP_OK;
+}
+
+plp_status plp_line_set_seed_order(plp_line* c, int32_t order) {
+    if (!c) return set_error(PLP_ERR_INVALID_ARG, "ctx is NULL");
+    if (order != PLP_SEED_ORDER_STABLE && order != PLP_SEED_ORDER_LIBSTDCXX) return set_error(PLP_ERR_INVALID_ARG, "unknown seed order");
+    if (order == PLP_SEED_ORDER_LIBSTDCXX && !c->seed_sort_ok) return set_error(PLP_ERR_UNSUPPORTED, "this device refused the LDS size of the exact seed sort");
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->seed_order = order;
+    return PLP_OK;
+}
+
+plp_status plp_line_get_seed_order(const plp_line* c, int32_t* order) {
+    if (!c || !order) return set_error(PLP_ERR_INVALID_ARG, "NULL argument");
+    *order = c->seed_order;
     return PLP_OK;
 }
 
@@ -389,6 +428,45 @@ int32_t plp_model_sincos_host(const float* a, int64_t n, float* c, float* s, uin
     int32_t n_proven = 0;
     for (int64_t i = 0; i < n; ++i) { proven[i] = plp::sincos_ziv(a[i], c + i, s + i) ? 1 : 0; n_proven += proven[i]; }
     return n_proven;
+}
+
+// Host model of the exact seed sort (seed_sort_model.hpp): std::__introsort_loop on entries whose key is bits 20..29, as the rank-paired
+// partitions the kernel runs.  depth_limit < 0: the library's 2 * floor(log2 n).  Callable without a GPU.
+int32_t plp_model_seed_introsort_host(uint32_t* entries, int64_t n, int32_t depth_limit) {
+    if (!entries || n < 0 || n > (int64_t)kLsdMaxScaledPixels) return -1;
+    plp::seedsort::introsort_loop_model(entries, (int)n, depth_limit);
+    return 0;
+}
+
+// The kernel's introsort loop on caller-made entries (host pointers; one workgroup), with a chosen recursion budget: the tests' way to
+// reach every branch (global partitions, LDS window, wave tasks, lanes, heap sort) on arbitrary key distributions.
+plp_status plp_seed_introsort_debug(int32_t device, uint32_t* entries, int64_t n, int32_t depth_limit) {
+    if (!entries || n < 0 || n > (int64_t)kLsdMaxScaledPixels) return set_error(PLP_ERR_INVALID_ARG, "bad entries");
+    int nd = 0;
+    if (hipGetDeviceCount(&nd) != hipSuccess || nd == 0) return set_error(PLP_ERR_NO_DEVICE, "no HIP device visible");
+    PLP_HIP(hipSetDevice(device));
+    PLP_HIP(seed_sort_configure());
+    if (depth_limit < 0) { int lg = 0; while ((2ll << lg) <= n) ++lg; depth_limit = 2 * lg; }
+    DevBuf ent, ws, st;
+    PLP_HIP(ent.reserve((size_t)std::max<int64_t>(n, 1) * 4)); PLP_HIP(ws.reserve(seed_sort_ws_entries((size_t)n) * 4)); PLP_HIP(st.reserve(16));
+    PLP_HIP(hipMemcpy(ent.p, entries, (size_t)n * 4, hipMemcpyHostToDevice));
+    PLP_HIP(hipMemset(st.p, 0, 16));
+    DevBuf dbg;
+    const char* dflag = getenv("PLP_SEED_SORT_DBG");
+    if (dflag) { PLP_HIP(dbg.reserve(4 * (2 + 6 * 4000))); PLP_HIP(hipMemset(dbg.p, 0, 4 * (2 + 6 * 4000))); int f = atoi(dflag); PLP_HIP(hipMemcpy(dbg.p, &f, 4, hipMemcpyHostToDevice)); }
+    launch_seed_sort_debug(nullptr, (uint32_t*)ent.p, (int)n, depth_limit, (uint32_t*)ws.p, (int32_t*)st.p, dflag ? (int*)dbg.p : nullptr);
+    PLP_HIP(hipGetLastError());
+    PLP_HIP(hipDeviceSynchronize());
+    int32_t s = 0;
+    PLP_HIP(hipMemcpy(&s, st.p, 4, hipMemcpyDeviceToHost));
+    PLP_HIP(hipMemcpy(entries, ent.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (dflag && getenv("PLP_SEED_SORT_DBG_FILE")) {
+        std::vector<int> h(2 + 6 * 4000);
+        PLP_HIP(hipMemcpy(h.data(), dbg.p, h.size() * 4, hipMemcpyDeviceToHost));
+        if (FILE* f = fopen(getenv("PLP_SEED_SORT_DBG_FILE"), "wb")) { fwrite(h.data(), 4, h.size(), f); fclose(f); }
+    }
+    if (s & 32) return set_error(PLP_ERR_OVERFLOW, "the exact seed sort ran out of queue space");
+    return PLP_OK;
 }
 
 }  // extern "C"

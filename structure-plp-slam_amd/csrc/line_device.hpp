@@ -8,7 +8,7 @@
 namespace plp {
 
 constexpr int kMwHeap = 16384;       // k_lsd_grow_mw: list entries per helper wave and group buffer
-constexpr int kMwHeapBufs = 8;       // k_lsd_grow_mw: group buffers per helper wave
+constexpr int kMwHeapBufs = 2;       // k_lsd_grow_mw: group buffers per helper wave (= kMwBufs of line_kernels.hip: the kernel strides a helper's lists by it)
 constexpr int kMwMaxWaves = 8;       // k_lsd_grow_mw: waves per frame (one main + helpers)
 constexpr int kLsdMwMaxFrames = 256; // batches up to this many frames get the buffers of the several-waves-per-frame path
 constexpr int kLineCap = 2048;        // raw LSD segments / key lines kept per frame (a 640x480 frame yields ~400)
@@ -72,6 +72,8 @@ struct LsdParams {
     float keep_length;        // hard filter of line_extractor.cc:136 (60 px)
     float c_pass, c_fail;     // cos(prec - eps), cos(prec + eps): the guard band of the angle test (region_grow)
     uint32_t g2_def_min;      // smallest gx^2 + gy^2 whose magnitude sqrt(g2 / 4.0) exceeds rho (the pixel's angle is defined)
+    int seed_exact;           // plp_line_set_seed_order: 1 = the seed order of std::sort as libstdc++ implements it (seed_sort_kernels.hip); the g2 plane
+                              // then holds gx^2 + gy^2 of EVERY pixel the reference sorts, defined or not
 };
 constexpr double kLsdAngleBand = 3.5e-4;   // rad (0.02 deg) >= 2x the largest error of cv::fastAtan2 (0.0096 deg) + f32 rounding
 // The cosine form of the test resolves an angle step d near the tolerance t as sin(t) * d; its own f32 roundings are worth up to
@@ -86,10 +88,19 @@ struct LbdWeightsDev { float g[63], l[21]; };
 
 struct LineSideStream { hipStream_t stream; hipEvent_t fork, join; };   // optional second stream of a line context
 
+// Seed order of a reference built with libstdc++ (seed_sort_kernels.hip): `ent` = [B][(sw-1)(sh-1)] entries, `ws` = [B][ws_stride] scratch
+struct SeedSortBufs { uint32_t* ent; uint32_t* ws; size_t ws_stride; };
+size_t seed_sort_ws_entries(size_t nv);
+size_t seed_sort_lds_bytes();
+hipError_t seed_sort_configure();   // raises the kernels' dynamic LDS limit on the CURRENT device
+void launch_seed_order_exact(hipStream_t st, const LinePlanes& P, const LsdParams& lp, int B, uint32_t* ent, uint32_t* ws, size_t ws_stride);
+void launch_seed_sort_debug(hipStream_t st, uint32_t* ent, int n, int depth, uint32_t* ws, int32_t* status, int* dbg);
+hipError_t grow_mw_configure();      // the same for k_lsd_grow_mw (line_kernels.hip)
+
 // ev: NULL or 9 events recorded around the 8 stages {blur11+resize, gradient+bins, seed order, region grow, key lines,
 // blur5+sobel, LBD, finalize}
 void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp, const ResizeExactTab& rt, const BlurTapsN& t11,
                        const BlurTapsN& t5, const LbdWeightsDev& w, plp_keyline* out_kl, uint8_t* out_lbd, double* out_fn, int cap,
-                       int32_t* out_counts, int B, hipEvent_t* ev, const LineSideStream* side, int grow_waves);
+                       int32_t* out_counts, int B, hipEvent_t* ev, const LineSideStream* side, int grow_waves, const SeedSortBufs* seed_exact, bool mw_ok);
 
 }  // namespace plp

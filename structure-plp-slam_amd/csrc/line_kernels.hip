@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void k_lsd_gradient(LinePlanes P, LsdParams lp
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int idx = blockIdx.x * 256 + tid;
     const int n = P.sw * P.sh;
-    uint32_t g2_def = 0, packed = 0;
+    uint32_t g2_def = 0, g2_any = 0, packed = 0;
     if (idx < n) {
         const int y = P.sw_magic ? (int)__umulhi((uint32_t)idx, P.sw_magic) : idx / P.sw, x = idx - y * P.sw;   // idx / sw (line_context.hip: when the product form is exact)
         if (x < P.sw - 1 && y < P.sh - 1) {
@@ -154,12 +154,13 @@ __global__ __launch_bounds__(256) void k_lsd_gradient(LinePlanes P, LsdParams lp
             const int BC = (int)s[1] - (int)s[P.spitch];
             const int gx = DA + BC, gy = DA - BC;                  // each in [-510, 510]
             const uint32_t g2 = (uint32_t)(gx * gx + gy * gy);
+            g2_any = g2;
             if (g2 >= lp.g2_def_min) {
                 g2_def = g2;
                 packed = (uint32_t)tid | ((uint32_t)(gx + 512) << 8) | ((uint32_t)(gy + 512) << 18);
             }
         }
-        P.g2[(size_t)b * n + idx] = g2_def;
+        P.g2[(size_t)b * n + idx] = lp.seed_exact ? g2_any : g2_def;   // the exact seed order sorts the undefined pixels too (they have bins)
     }
     // one 64-bit word per wave: pixels that can never seed or join a region (angle NOTDEF)
     const unsigned long long undef = __ballot(g2_def == 0);
@@ -970,7 +971,7 @@ __global__ __launch_bounds__(256, PLP_GROW_MIN_WAVES) void k_lsd_grow(LinePlanes
 #define PLP_MW_ENTRIES 16
 #endif
 constexpr int kMwGroup = PLP_MW_GROUP;   // seeds per ownership unit (a helper claims a group, main walks them in order; its own loads are 64 seeds)
-static_assert(PLP_MW_BUFS <= kMwHeapBufs && 64 % PLP_MW_GROUP == 0 && PLP_MW_ENTRIES <= 64, "line_device.hpp");
+static_assert(PLP_MW_BUFS == kMwHeapBufs && 64 % PLP_MW_GROUP == 0 && PLP_MW_ENTRIES <= 64, "line_device.hpp sizes the helpers' lists by kMwHeapBufs");
 constexpr int kMwBufs = PLP_MW_BUFS;         // group buffers per helper: groups it may have finished before main has walked through them
 constexpr int kMwEntries = PLP_MW_ENTRIES;      // results per group buffer; beyond them the rest of the group is main's (16 / 32 / 64 seeds x 8 / 4 / 2 buffers x 4 / 8 / 16 entries measured)
 constexpr int kMwInline = 8;         // list entries of a small region kept in the LDS entry itself (main then never touches HBM for it)
@@ -1734,7 +1735,7 @@ __global__ __launch_bounds__(64) void k_line_finalize(LinePlanes P, LsdParams lp
 // ------------------------------------------------------------------------------------------ launch sequence
 void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp, const ResizeExactTab& rt, const BlurTapsN& t11,
                        const BlurTapsN& t5, const LbdWeightsDev& w, plp_keyline* out_kl, uint8_t* out_lbd, double* out_fn, int cap,
-                       int32_t* out_counts, int B, hipEvent_t* ev, const LineSideStream* side, int grow_waves) {
+                       int32_t* out_counts, int B, hipEvent_t* ev, const LineSideStream* side, int grow_waves, const SeedSortBufs* seed_exact, bool mw_ok) {
     auto mark = [&](int i) { if (ev) (void)hipEventRecord(ev[i], st); };
     // The LBD image pass (5-tap blur + Sobel) does not depend on LSD.  Unless per-stage timing is requested it is launched FIRST, on the
     // same stream: it then overlaps whatever the other streams of the caller run, and nothing has to join before k_lbd.  (A side
@@ -1768,7 +1769,8 @@ void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp,
     const int n = P.sw * P.sh;
     hipLaunchKernelGGL(k_lsd_gradient, dim3((n + 255) / 256, B), dim3(256), 0, st, P, lp);
     mark(2);
-    hipLaunchKernelGGL(k_lsd_order, dim3(B), dim3(256), 0, st, P, lp, (n + 255) / 256);
+    if (seed_exact) launch_seed_order_exact(st, P, lp, B, seed_exact->ent, seed_exact->ws, seed_exact->ws_stride);
+    else hipLaunchKernelGGL(k_lsd_order, dim3(B), dim3(256), 0, st, P, lp, (n + 255) / 256);
     mark(3);
     // per wave: USED bitmap + frontier ring (a power of two; the HBM copy of the region list backs larger frontiers).
     // ~10.6 KB of LDS per wave; at 2048 frames every SIMD carries two of these latency-bound waves.
@@ -1790,7 +1792,7 @@ void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp,
     MwLayout L{};
     size_t mw_bytes = 0;
     const int want_waves = grow_waves > 0 ? std::min(grow_waves, kMwMaxWaves) : mw_waves;          // plp_line_set_grow_waves overrides the automatic choice
-    if (B <= (grow_waves > 1 ? kLsdMwMaxFrames : mw_max_b) && want_waves >= 2 && P.mw_heap && P.reg_frame_stride >= 2 * (size_t)n) {
+    if (mw_ok && B <= (grow_waves > 1 ? kLsdMwMaxFrames : mw_max_b) && want_waves >= 2 && P.mw_heap && P.reg_frame_stride >= 2 * (size_t)n) {
         const int nw_al = (((n + 31) / 32 + 1) & ~1), groups_cap = ((P.sw - 1) * (P.sh - 1) + kMwGroup - 1) / kMwGroup + 64 / kMwGroup;
         for (int w = want_waves; w >= 2; --w) {
             const size_t bytes = (size_t)5 * nw_al * 4 + (size_t)w * (nw_al + 256 + kMwAssumed + 2) * 4 + (8 + (4 + 2 * kMwBufs) * kMwMaxWaves) * 4 + ((groups_cap + 15) & ~15) + 16 +
@@ -1800,8 +1802,6 @@ void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp,
     }
     if (skip_after < 0 || n_launch++ < skip_after) {
         if (L.waves >= 2) {
-            static size_t attr_set = 0;
-            if (mw_bytes > attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lsd_grow_mw), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)); attr_set = 160 * 1024; }
             hipLaunchKernelGGL(k_lsd_grow_mw, dim3(B), dim3(64 * L.waves), mw_bytes, st, P, lp, L);
         } else
             hipLaunchKernelGGL(k_lsd_grow, dim3((B + wpb - 1) / wpb), dim3(64 * wpb), per_wave * wpb, st, P, lp, B, wpb, ring);
@@ -1823,6 +1823,12 @@ void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp,
     mark(7);
     hipLaunchKernelGGL(k_line_finalize, dim3(B), dim3(64), 0, st, P, lp, out_kl, out_lbd, out_fn, cap, out_counts);
     mark(8);
+}
+
+// The several-waves-per-frame kernel takes up to 160 KB of dynamic LDS: the limit belongs to the function ON THE CURRENT DEVICE, so every context
+// raises it for its own device when it is created (plp_line_create); a context whose device refuses runs one wave per frame.
+hipError_t grow_mw_configure() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_lsd_grow_mw), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
 }
 
 }  // namespace plp

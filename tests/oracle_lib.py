@@ -745,6 +745,20 @@ def ref_robust_match_frame_and_keyframe(desc1, angle1, desc2, angle2, valid2, lo
     return out[:n1].copy(), num
 
 
+def std_sort_entries(entries):
+    """this machine's std::sort on uint32 entries compared by bits 20..29, larger first (lsd.cpp's comparator on the gradient bin, pixel index as payload)"""
+    e = np.ascontiguousarray(entries, np.uint32).copy()
+    _load().oracle_std_sort_entries(_p(e), C.c_long(e.size))
+    return e
+
+
+def std_introsort_loop_entries(entries, depth_limit=-1):
+    """libstdc++'s std::__introsort_loop on such entries (None when the oracle was built against another C++ library)"""
+    e = np.ascontiguousarray(entries, np.uint32).copy()
+    ok = _load().oracle_std_introsort_loop_entries(_p(e), C.c_long(e.size), int(depth_limit))
+    return e if ok else None
+
+
 def index_sort_by_size(sizes):
     """the reference's index_sort_by_size (std::sort of the bin indices by size, descending) with this machine's C++ library"""
     sz = np.ascontiguousarray(sizes, np.int32)

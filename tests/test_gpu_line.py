@@ -21,16 +21,20 @@ def defined_seed(scaled):
 
 def compare(img, grow_waves=(0, 1, 3)):
     """every stage against the oracle, for each way region growing can be run: several waves per frame (0 = automatic: 8 for a single
-    frame; 3 = one main wave + two speculating helpers) and one wave per frame (1); the results must not depend on it"""
-    ora = O.LineOracle(img)
-    for w in grow_waves:
-        kl = compare_one(img, ora, w)
+    frame; 3 = one main wave + two speculating helpers) and one wave per frame (1); the results must not depend on it.  And for both seed
+    orders: the one a reference built with libstdc++ has (the oracle calls std::sort, as lsd.cpp does; the library replays the introsort on
+    the device) and the stable one (definition D1)."""
+    for order, stable in ((plp.SEED_ORDER_LIBSTDCXX, False), (plp.SEED_ORDER_STABLE, True)):
+        ora = O.LineOracle(img, stable_order=stable)
+        for w in (grow_waves if stable else grow_waves[:2]):
+            kl = compare_one(img, ora, w, order)
     return kl
 
 
-def compare_one(img, ora, waves):
+def compare_one(img, ora, waves, order=plp.SEED_ORDER_STABLE):
     lt = plp.LineFeatureTracker()
     lt.set_grow_waves(waves)
+    lt.set_seed_order(order)
     kl, lbd, fn = lt.extract_LSD_LBD(img)
     assert np.array_equal(lt.debug_read(lt.DBG_SCALED), ora.scaled), "11-tap blur + x0.5 INTER_LINEAR_EXACT"
     assert np.array_equal(lt.debug_read(lt.DBG_ORDER), ora.order[defined_seed(ora.scaled)[ora.order]]), "seed order (pixels with a defined angle: the others never start a region)"

@@ -67,3 +67,73 @@ def test_magic_division_by_the_scaled_width_is_exact_for_every_admitted_frame():
         idx = np.unique(np.concatenate([np.arange(0, min(n_max, 3 * sw + 5)), np.arange(max(0, n_max - 3 * sw - 5), n_max),
                                         np.arange(0, n_max, max(1, n_max // 4096))])).astype(np.uint64)
         assert np.array_equal((idx * np.uint64(magic)) >> np.uint64(32), idx // np.uint64(sw)), sw
+
+
+# ---- the exact LSD seed order (csrc/seed_sort_model.hpp: libstdc++'s std::sort as rank-paired partitions) -----------------------------
+def _seed_entries(r, n, kind):
+    """entries = pixel | bin << 20 with the bins of one of several shapes (uniform, image-like with a heavy low end, few values, constant,
+    ramps, blocks of 64 alternating between extremes = whole chunks of stoppers on one side)"""
+    i = np.arange(n, dtype=np.int64)
+    if kind == 0:
+        key = r.integers(0, 1024, n)
+    elif kind == 1:
+        key = np.where(r.random(n) < 0.6, 0, r.integers(0, 40, n))
+    elif kind == 2:
+        key = r.integers(0, 3, n)
+    elif kind == 3:
+        key = np.full(n, 5)
+    elif kind == 4:
+        key = i * 1023 // max(n, 1)
+    elif kind == 5:
+        key = 1023 - i * 1023 // max(n, 1)
+    elif kind == 6:
+        key = np.where((i // 64) % 2 == 1, 0, 1000)
+    else:
+        key = np.minimum(1023, (r.exponential(30.0, n)).astype(np.int64))
+    return (key.astype(np.uint32) << np.uint32(20)) | i.astype(np.uint32)
+
+
+def _seed_sizes(r, trial):
+    edge = [17, 18, 31, 32, 33, 63, 64, 65, 66, 127, 128, 129, 130, 4095, 4096, 4097, 4098, 24575, 24576, 24577, 24578]
+    if trial < len(edge):
+        return edge[trial]
+    return int(r.integers(17, 400)) if trial % 3 == 0 else int(r.integers(400, 9000)) if trial % 3 == 1 else int(r.integers(9000, 60000))
+
+
+def test_seed_sort_model_equals_libstdcxx_introsort_loop_and_std_sort():
+    """The rank-pairing form of the partitions (chunk masks, chunk prefix sums, crossing chunk, bit selection) leaves the array exactly as
+    libstdc++'s std::__introsort_loop does -- with the library's recursion budget and with forced ones that reach the heap sort -- and a
+    stable sort of that array (what the final insertion sort amounts to) is std::sort's result."""
+    import oracle_lib as O
+    plp = __import__("plp").plp
+    r = np.random.default_rng(11)
+    for trial in range(260):
+        n = _seed_sizes(r, trial)
+        e = _seed_entries(r, n, trial % 8)
+        depth = -1 if trial % 4 else int(r.integers(0, 9))
+        want = O.std_introsort_loop_entries(e, depth)
+        if want is None:
+            import pytest
+            pytest.skip("the oracle was not built against libstdc++")
+        got = plp.model_seed_introsort(e, depth)
+        assert np.array_equal(got, want), (trial, n, depth)
+        if depth < 0:
+            final = got[np.argsort(-(got >> np.uint32(20)).astype(np.int64), kind="stable")]
+            assert np.array_equal(final, O.std_sort_entries(e)), (trial, n)
+
+
+def test_seed_sort_model_on_the_bins_of_real_frames(golden_dir):
+    """the same on what lsd.cpp actually sorts: every pixel of the half-resolution fixture frames with its gradient bin"""
+    import oracle_lib as O
+    from PIL import Image
+    plp = __import__("plp").plp
+    for name in ("equirect1_640x480.png", "equirect2_crop_640x480.png"):
+        s = O.LineOracle(np.asarray(Image.open(golden_dir / name)), False).scaled.astype(np.int64)
+        DA, BC = s[1:, 1:] - s[:-1, :-1], s[:-1, 1:] - s[1:, :-1]
+        norm = np.sqrt(((DA + BC) ** 2 + (DA - BC) ** 2) / 4.0)
+        rho = 2.0 / np.sin(np.pi * 22.5 / 180)
+        bins = (norm * (1023.0 / norm[norm > rho].max())).astype(np.int64).ravel()
+        e = (bins.astype(np.uint32) << np.uint32(20)) | np.arange(bins.size, dtype=np.uint32)
+        got = plp.model_seed_introsort(e)
+        assert np.array_equal(got, O.std_introsort_loop_entries(e))
+        assert np.array_equal(got[np.argsort(-(got >> np.uint32(20)).astype(np.int64), kind="stable")], O.std_sort_entries(e))
