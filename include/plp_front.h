@@ -222,11 +222,13 @@ plp_status plp_line_debug_read(plp_line* ctx, plp_line_debug_id what, int32_t fr
  * GCC): idx = the indices 0..n-1, n <= 64, in that order.  depth_limit < 0 = the library's recursion budget.  No GPU needed. */
 int32_t plp_model_index_sort_host(const int32_t* sizes, int32_t n, int32_t depth_limit, uint32_t* idx);
 /* Host model of the exact seed sort (csrc/seed_sort_model.hpp): std::__introsort_loop, in place, on n entries whose sort key is bits 20..29
- * (larger first), computed as the rank-paired partitions the kernel runs; depth_limit < 0 = the library's 2 * floor(log2 n).  No GPU needed.
- * Returns 0, or -1 for a bad argument. */
-int32_t plp_model_seed_introsort_host(uint32_t* entries, int64_t n, int32_t depth_limit);
-/* Test entry: the KERNEL's introsort loop on caller-made entries (host pointer, in place), one workgroup, chosen recursion budget. */
-plp_status plp_seed_introsort_debug(int32_t device, uint32_t* entries, int64_t n, int32_t depth_limit);
+ * (larger first), computed as the rank-paired partitions the kernel runs; depth_limit < 0 = the library's 2 * floor(log2 n).  skip_key > 0:
+ * parts that can only hold keys below it are left as they are, as the kernel leaves the undefined pixels of a frame (they are sorted along
+ * but never seed a region); the order of the entries with keys >= skip_key after a stable sort by key is std::sort's all the same.
+ * No GPU needed.  Returns 0, or -1 for a bad argument. */
+int32_t plp_model_seed_introsort_host(uint32_t* entries, int64_t n, int32_t depth_limit, uint32_t skip_key);
+/* Test entry: the KERNEL's introsort loop on caller-made entries (host pointer, in place), one workgroup, chosen recursion budget and skip key. */
+plp_status plp_seed_introsort_debug(int32_t device, uint32_t* entries, int64_t n, int32_t depth_limit, uint32_t skip_key);
 /* Host model of the LSD gradient kernel's (float)cos((double)a), (float)sin((double)a) fast path (csrc/sincos_ziv.hpp): proven[i] = 0 marks the
  * arguments for which the kernel falls back to the general f64 routine.  Returns the number of proven arguments.  No GPU needed. */
 int32_t plp_model_sincos_host(const float* a, int64_t n, float* c, float* s, uint8_t* proven);

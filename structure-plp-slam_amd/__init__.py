@@ -79,8 +79,8 @@ _API = [
     ("plp_line_set_grow_waves", C.c_int, [_VP, _I32]),
     ("plp_line_set_seed_order", C.c_int, [_VP, _I32]),
     ("plp_line_get_seed_order", C.c_int, [_VP, _VP]),
-    ("plp_model_seed_introsort_host", _I32, [_VP, C.c_int64, _I32]),
-    ("plp_seed_introsort_debug", C.c_int, [_I32, _VP, C.c_int64, _I32]),
+    ("plp_model_seed_introsort_host", _I32, [_VP, C.c_int64, _I32, C.c_uint32]),
+    ("plp_seed_introsort_debug", C.c_int, [_I32, _VP, C.c_int64, _I32, C.c_uint32]),
     ("plp_line_get_stage_times", C.c_int, [_VP, _VP, _VP]),
     ("plp_line_debug_read", C.c_int, [_VP, C.c_int, _I32, _VP, _SZ, _VP]),
     ("plp_line_scaled_size", C.c_int, [_VP, _VP, _VP]),
@@ -162,17 +162,18 @@ def model_quadtree(xys, level_w, level_h, quota):
 SEED_ORDER_STABLE, SEED_ORDER_LIBSTDCXX = 0, 1          # plp_seed_order (include/plp_front.h)
 
 
-def model_seed_introsort(entries, depth_limit=-1):
-    """Host model of the exact seed sort: std::__introsort_loop on entries keyed by bits 20..29 (larger first), as rank-paired partitions; no GPU"""
+def model_seed_introsort(entries, depth_limit=-1, skip_key=0):
+    """Host model of the exact seed sort: std::__introsort_loop on entries keyed by bits 20..29 (larger first), as rank-paired partitions; parts
+    that can only hold keys below skip_key are left alone (include/plp_front.h); no GPU"""
     e = np.ascontiguousarray(entries, np.uint32).copy()
-    assert lib().plp_model_seed_introsort_host(_p(e), e.size, int(depth_limit)) == 0
+    assert lib().plp_model_seed_introsort_host(_p(e), e.size, int(depth_limit), int(skip_key)) == 0
     return e
 
 
-def seed_introsort_debug(entries, depth_limit=-1, device=0):
-    """The KERNEL's introsort loop on caller-made entries (one workgroup), with a chosen recursion budget"""
+def seed_introsort_debug(entries, depth_limit=-1, skip_key=0, device=0):
+    """The KERNEL's introsort loop on caller-made entries (one workgroup), with a chosen recursion budget and skip key"""
     e = np.ascontiguousarray(entries, np.uint32).copy()
-    _check(lib().plp_seed_introsort_debug(int(device), _p(e), e.size, int(depth_limit)))
+    _check(lib().plp_seed_introsort_debug(int(device), _p(e), e.size, int(depth_limit), int(skip_key)))
     return e
 
 

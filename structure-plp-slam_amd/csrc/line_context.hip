@@ -432,15 +432,15 @@ int32_t plp_model_sincos_host(const float* a, int64_t n, float* c, float* s, uin
 
 // Host model of the exact seed sort (seed_sort_model.hpp): std::__introsort_loop on entries whose key is bits 20..29, as the rank-paired
 // partitions the kernel runs.  depth_limit < 0: the library's 2 * floor(log2 n).  Callable without a GPU.
-int32_t plp_model_seed_introsort_host(uint32_t* entries, int64_t n, int32_t depth_limit) {
+int32_t plp_model_seed_introsort_host(uint32_t* entries, int64_t n, int32_t depth_limit, uint32_t skip_key) {
     if (!entries || n < 0 || n > (int64_t)kLsdMaxScaledPixels) return -1;
-    plp::seedsort::introsort_loop_model(entries, (int)n, depth_limit);
+    plp::seedsort::introsort_loop_model(entries, (int)n, depth_limit, skip_key);
     return 0;
 }
 
 // The kernel's introsort loop on caller-made entries (host pointers; one workgroup), with a chosen recursion budget: the tests' way to
 // reach every branch (global partitions, LDS window, wave tasks, lanes, heap sort) on arbitrary key distributions.
-plp_status plp_seed_introsort_debug(int32_t device, uint32_t* entries, int64_t n, int32_t depth_limit) {
+plp_status plp_seed_introsort_debug(int32_t device, uint32_t* entries, int64_t n, int32_t depth_limit, uint32_t skip_key) {
     if (!entries || n < 0 || n > (int64_t)kLsdMaxScaledPixels) return set_error(PLP_ERR_INVALID_ARG, "bad entries");
     int nd = 0;
     if (hipGetDeviceCount(&nd) != hipSuccess || nd == 0) return set_error(PLP_ERR_NO_DEVICE, "no HIP device visible");
@@ -453,15 +453,15 @@ plp_status plp_seed_introsort_debug(int32_t device, uint32_t* entries, int64_t n
     PLP_HIP(hipMemset(st.p, 0, 16));
     DevBuf dbg;
     const char* dflag = getenv("PLP_SEED_SORT_DBG");
-    if (dflag) { PLP_HIP(dbg.reserve(4 * (2 + 6 * 4000))); PLP_HIP(hipMemset(dbg.p, 0, 4 * (2 + 6 * 4000))); int f = atoi(dflag); PLP_HIP(hipMemcpy(dbg.p, &f, 4, hipMemcpyHostToDevice)); }
-    launch_seed_sort_debug(nullptr, (uint32_t*)ent.p, (int)n, depth_limit, (uint32_t*)ws.p, (int32_t*)st.p, dflag ? (int*)dbg.p : nullptr);
+    if (dflag) { PLP_HIP(dbg.reserve(4 * (2 + 6 * 4000 + 48))); PLP_HIP(hipMemset(dbg.p, 0, 4 * (2 + 6 * 4000 + 48))); int f = atoi(dflag); PLP_HIP(hipMemcpy(dbg.p, &f, 4, hipMemcpyHostToDevice)); }
+    launch_seed_sort_debug(nullptr, (uint32_t*)ent.p, (int)n, depth_limit, skip_key, (uint32_t*)ws.p, (int32_t*)st.p, dflag ? (int*)dbg.p : nullptr);
     PLP_HIP(hipGetLastError());
     PLP_HIP(hipDeviceSynchronize());
     int32_t s = 0;
     PLP_HIP(hipMemcpy(&s, st.p, 4, hipMemcpyDeviceToHost));
     PLP_HIP(hipMemcpy(entries, ent.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     if (dflag && getenv("PLP_SEED_SORT_DBG_FILE")) {
-        std::vector<int> h(2 + 6 * 4000);
+        std::vector<int> h(2 + 6 * 4000 + 48);
         PLP_HIP(hipMemcpy(h.data(), dbg.p, h.size() * 4, hipMemcpyDeviceToHost));
         if (FILE* f = fopen(getenv("PLP_SEED_SORT_DBG_FILE"), "wb")) { fwrite(h.data(), 4, h.size(), f); fclose(f); }
     }

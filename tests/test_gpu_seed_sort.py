@@ -40,6 +40,22 @@ def test_kernel_introsort_loop_random_sizes_and_forced_recursion_budgets():
         assert np.array_equal(plp.seed_introsort_debug(e, depth), _want(e, depth)), (trial, n, depth)
 
 
+def test_kernel_leaves_parts_below_the_skip_key_alone_exactly_as_the_model_does():
+    """with a skip key (the bin of the smallest defined gradient magnitude in a frame) the kernel and the host model make the same choices:
+    identical arrays, and the order of the entries at or above the key is std::sort's"""
+    r = np.random.default_rng(9)
+    key = lambda a: (a >> np.uint32(20)).astype(np.int64)
+    for trial in range(64):
+        n = [300, 5000, 24577, 40000, 76241, 100000][trial % 6] + trial
+        e = _seed_entries(r, n, [1, 7, 0, 2, 3, 6, 4, 5][trial % 8])
+        skip = int(r.integers(1, 60)) if trial % 2 else int(r.integers(1, 1024))
+        got = plp.seed_introsort_debug(e, -1, skip)
+        assert np.array_equal(got, plp.model_seed_introsort(e, -1, skip)), (trial, n, skip)
+        fin = got[np.argsort(-key(got), kind="stable")]
+        ref = O.std_sort_entries(e)
+        assert np.array_equal(fin[key(fin) >= skip], ref[key(ref) >= skip]), (trial, n, skip)
+
+
 def test_exact_seed_order_leaves_no_key_line_different_from_std_sort(golden_dir):
     """tests/test_d1_seed_order_cost.py measures 3.5 % of the key lines differing between the stable order and std::sort; in the exact mode
     the library must give the std::sort result on every frame of that measurement: 0 differing key lines, raw segments and LBD rows included"""

@@ -137,3 +137,22 @@ def test_seed_sort_model_on_the_bins_of_real_frames(golden_dir):
         got = plp.model_seed_introsort(e)
         assert np.array_equal(got, O.std_introsort_loop_entries(e))
         assert np.array_equal(got[np.argsort(-(got >> np.uint32(20)).astype(np.int64), kind="stable")], O.std_sort_entries(e))
+
+
+def test_seed_sort_model_may_leave_the_undefined_pixels_alone():
+    """The kernels do not sort parts that can only hold keys below the bin of the smallest defined gradient magnitude (undefined pixels:
+    70 % of a frame; they take part in every partition above but are never seeds).  What the caller sees -- the entries with keys at or
+    above that bin, stably sorted by key -- is std::sort's order all the same."""
+    import oracle_lib as O
+    plp = __import__("plp").plp
+    r = np.random.default_rng(12)
+    for trial in range(120):
+        n = _seed_sizes(r, trial + 40)
+        e = _seed_entries(r, n, trial % 8)
+        skip = int(r.integers(0, 60)) if trial % 8 in (1, 2, 3, 7) else int(r.integers(0, 1024))
+        got = plp.model_seed_introsort(e, -1, skip)
+        assert np.array_equal(np.sort(got), np.sort(e)), "a permutation of the input"
+        key = lambda a: (a >> np.uint32(20)).astype(np.int64)
+        fin = got[np.argsort(-key(got), kind="stable")]
+        ref = O.std_sort_entries(e)
+        assert np.array_equal(fin[key(fin) >= skip], ref[key(ref) >= skip]), (trial, n, skip)
