@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the PCIe-inclusive pass and the single-frame latency pass (profiling runs)")
     ap.add_argument("--no-latency", action="store_true", help="two calls instead of 256 in the single-frame latency pass")
     ap.add_argument("--orb-only", action="store_true", help="time the ORB extractor alone (config 1 shape)")
+    ap.add_argument("--seed-order", choices=("libstdcxx", "stable"), default="libstdcxx", help="LSD seed order: the reference's (std::sort as libstdc++ implements it, replayed on the "
+                    "device; the library's default) or the cheaper stable order (PLP_SEED_ORDER_STABLE); the other one is timed beside it (`other_seed_order`)")
     ap.add_argument("--verify", type=int, default=64, help="after the timed region: re-derive N frames of the last step (features and the four matcher "
                     "results) with the CPU oracle and compare (0 = off; rank 0, N = 1 only)")
     args = ap.parse_args()
@@ -121,7 +123,8 @@ def main():
     serial = bool(os.environ.get("PLP_BENCH_SERIAL"))                            # diagnostic: one stream for everything
     ts = rs.tracker_step(plp, B, K, args.rows, args.cols, device_index=local_rank, orb_only=args.orb_only,
                          n_line=int(os.environ.get("PLP_BENCH_LINE_SPLIT", "2")), nbuf=int(os.environ.get("PLP_BENCH_NBUF", "2")), serial=serial,
-                         shift=(SHIFT_X, 0.0), parts=os.environ.get("PLP_BENCH_PARTS", "orb,lines,match"))   # PLP_BENCH_PARTS: diagnostic, time a subset of the step
+                         shift=(SHIFT_X, 0.0), parts=os.environ.get("PLP_BENCH_PARTS", "orb,lines,match"),   # PLP_BENCH_PARTS: diagnostic, time a subset of the step
+                         seed_order=plp.SEED_ORDER_STABLE if args.seed_order == "stable" else plp.SEED_ORDER_LIBSTDCXX)
     cap, lcap, NBUF = ts.cap, ts.lcap, ts.NBUF
     kps2, desc2, cnt2, kl2, lbd2, fn2, lcnt2 = ts.kps2, ts.desc2, ts.cnt2, ts.kl2, ts.lbd2, ts.fn2, ts.lcnt2
     d_kps, d_desc, d_cnt = kps2[0][HALO:], desc2[0][HALO:], cnt2[0][HALO:]
@@ -163,7 +166,7 @@ def main():
         g6 = BC.O.grid6(ts.grid)
         bad = []
         for b in ids:
-            bad += BC.check_frame(h, int(b), K, g6, ts.shift, sf, frames_np[int(b) % uniq], args.orb_only)
+            bad += BC.check_frame(h, int(b), K, g6, ts.shift, sf, frames_np[int(b) % uniq], args.orb_only, stable_order=args.seed_order == "stable")
         if bad:
             print(json.dumps({"error": "bench.py --verify: the timed step differs from the oracle", "mismatches": bad[:8]}), file=sys.stderr)
             sys.exit(3)
@@ -173,6 +176,29 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     fps = world * B * args.steps / elapsed
+    # ---- the same steps with the OTHER seed order, for the side-by-side figure: same buffers, same streams
+    other = None
+    if not args.orb_only and ts.lts:
+        o_name = "stable" if args.seed_order == "libstdcxx" else "libstdcxx"
+        for l_ in ts.lts:
+            l_.set_seed_order(plp.SEED_ORDER_STABLE if o_name == "stable" else plp.SEED_ORDER_LIBSTDCXX)
+        k2 = max(2, args.steps // 2)
+        for _ in range(2):
+            step()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(k2):
+            step()
+        barrier()
+        e2 = time.perf_counter() - t1
+        if dist is not None:
+            t = torch.tensor([e2], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e2 = float(t.item())
+        other = {"seed_order": o_name, "value": round(world * B * k2 / e2, 1), "ms_per_step": round(1e3 * e2 / k2, 4), "steps": k2}
+        for l_ in ts.lts:
+            l_.set_seed_order(plp.SEED_ORDER_STABLE if args.seed_order == "stable" else plp.SEED_ORDER_LIBSTDCXX)
+        step(); barrier()      # the feature buffers hold the headline mode's results again (the passes below read them)
 
     # ---- per-kernel HIP-event timing (separate, synchronous pass) -> roofline of the dominant kernel
     mean_kp = float(d_cnt.float().mean().item())
@@ -422,6 +448,8 @@ def main():
                    "match_rescans_rounds": (match_dbg if not args.orb_only else None),
                    "sharding": "contiguous frame blocks per rank; one packed RCCL send/recv per rank (ring) of the 2-frame feature halo for the matchers"},
         "roofline": roofline,
+        # LSD seed order of the headline number (the reference's: std::sort as libstdc++ implements it) and the same steps in the other order
+        "seed_order": args.seed_order, "other_seed_order": other,
         # frames of the LAST TIMED step whose features and four matcher results were recomputed by the CPU oracle and found identical
         "verified_frames": verified,
     }

@@ -13,11 +13,13 @@
 // PARITY UNPINNED: the reference has no test for any of this.
 //
 // Deliberate definitions (where the reference itself is implementation-defined):
-//  (D1) LSD visits seed pixels in the order produced by std::sort (unstable) on the gradient bins
-//       (lsd.cpp ll_angle).  The permutation among equal bins depends on the libstdc++ build.  The
-//       oracle (stable_order=1, the default the HIP path is compared with) uses the order the
-//       LSD paper intends: bin descending, then row-major.  stable_order=0 reproduces
-//       std::sort on this machine, to quantify the difference.
+//  (D1, closed in round 4) LSD visits seed pixels in the order produced by std::sort (unstable) on the
+//       gradient bins (lsd.cpp ll_angle); the permutation among equal bins is whatever the C++ library's
+//       algorithm leaves.  stable_order=0 (the default of the tests since round 4) calls std::sort as
+//       lsd.cpp does, i.e. IS a reference built with this machine's libstdc++ -- the HIP path replays
+//       that library's introsort on the device (PLP_SEED_ORDER_LIBSTDCXX, the library's default).
+//       stable_order=1 is the order the LSD paper describes (bin descending, then row-major), the
+//       library's cheaper PLP_SEED_ORDER_STABLE mode and the definition rounds 1-3 used.
 //  (D2) Single-precision libm calls in the reference (cosf/sinf in region_grow and computeLBD,
 //       atan2f for KeyLine::angle) are evaluated here as (float)f((double)x): glibc selects
 //       FMA/non-FMA variants of the float routines at run time, so their last bit is not a

@@ -219,7 +219,7 @@ double oracle_front_time_frames2(const uint8_t* frames, int n_frames, int rows, 
                 void* lh = nullptr;
                 auto ta = now();
                 if (two_threads_per_frame) {
-                    std::thread line_thread([&]() { lh = oracle_line_extract(im.data.data(), rows, cols, cols, 1); });
+                    std::thread line_thread([&]() { lh = oracle_line_extract(im.data.data(), rows, cols, cols, 0); });   // std::sort, as the reference
                     ex.extract(im, nullptr, k[cur], d[cur]);
                     s_orb[t] += secs(ta, now());
                     line_thread.join();
@@ -228,7 +228,7 @@ double oracle_front_time_frames2(const uint8_t* frames, int n_frames, int rows, 
                     ex.extract(im, nullptr, k[cur], d[cur]);
                     auto tb = now();
                     s_orb[t] += secs(ta, tb);
-                    lh = oracle_line_extract(im.data.data(), rows, cols, cols, 1);
+                    lh = oracle_line_extract(im.data.data(), rows, cols, cols, 0);
                     s_line[t] += secs(tb, now());
                 }
                 auto tm = now();

@@ -519,12 +519,14 @@ public:
     int count;
     LineIterator(const Mat&, Point p1, Point p2, int = 8, bool = false) { count = std::max(std::abs(p2.x - p1.x), std::abs(p2.y - p1.y)) + 1; }
 };
-// cv::LineSegmentDetector = the LSD restatement (oracle/lsd_restated.hpp), definition D1 (stable seed order) as everywhere else
+// cv::LineSegmentDetector = the LSD restatement (oracle/lsd_restated.hpp) with lsd.cpp's own seed ordering: std::sort on the gradient bin, i.e.
+// the reference built with THIS toolchain's C++ library (until round 4 the stand-in used the stable order of definition D1 and the golden
+// vectors made from it could not see the one place where library and reference were known to differ)
 class LineSegmentDetector : public Algorithm {
 public:
     explicit LineSegmentDetector(const oracle::LsdOptions& o) : o_(o) {}
     void detect(const Mat& image, std::vector<Vec4f>& lines) {
-        oracle::Lsd lsd(o_, true);
+        oracle::Lsd lsd(o_, /*stable=*/false);
         const auto segs = lsd.detect(to_image(image));
         lines.clear();
         for (const auto& s : segs) lines.emplace_back(s[0], s[1], s[2], s[3]);

@@ -80,7 +80,7 @@ _API = [
     ("plp_line_set_seed_order", C.c_int, [_VP, _I32]),
     ("plp_line_get_seed_order", C.c_int, [_VP, _VP]),
     ("plp_model_seed_introsort_host", _I32, [_VP, C.c_int64, _I32, C.c_uint32]),
-    ("plp_seed_introsort_debug", C.c_int, [_I32, _VP, C.c_int64, _I32, C.c_uint32]),
+    ("plp_seed_introsort_debug", C.c_int, [_I32, _VP, C.c_int64, _I32, C.c_uint32, _I32]),
     ("plp_line_get_stage_times", C.c_int, [_VP, _VP, _VP]),
     ("plp_line_debug_read", C.c_int, [_VP, C.c_int, _I32, _VP, _SZ, _VP]),
     ("plp_line_scaled_size", C.c_int, [_VP, _VP, _VP]),
@@ -170,10 +170,11 @@ def model_seed_introsort(entries, depth_limit=-1, skip_key=0):
     return e
 
 
-def seed_introsort_debug(entries, depth_limit=-1, skip_key=0, device=0):
-    """The KERNEL's introsort loop on caller-made entries (one workgroup), with a chosen recursion budget and skip key"""
+def seed_introsort_debug(entries, depth_limit=-1, skip_key=0, variant=0, device=0):
+    """The KERNEL's introsort loop on caller-made entries (one workgroup), with a chosen recursion budget and skip key; variant 0 / 1: the kernel
+    configuration of large / small batches"""
     e = np.ascontiguousarray(entries, np.uint32).copy()
-    _check(lib().plp_seed_introsort_debug(int(device), _p(e), e.size, int(depth_limit), int(skip_key)))
+    _check(lib().plp_seed_introsort_debug(int(device), _p(e), e.size, int(depth_limit), int(skip_key), int(variant)))
     return e
 
 

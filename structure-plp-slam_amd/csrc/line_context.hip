@@ -20,7 +20,7 @@ struct plp_line {
     hipStream_t stream = nullptr;
     int rows = 0, cols = 0, capB = 0;
     int grow_waves = 0;   // plp_line_set_grow_waves
-    int seed_order = PLP_SEED_ORDER_STABLE;   // plp_line_set_seed_order
+    int seed_order = PLP_SEED_ORDER_LIBSTDCXX;   // plp_line_set_seed_order; the reference's order unless the device refuses the sort's LDS (plp_line_create)
     bool mw_ok = false, seed_sort_ok = false;  // this device accepted the large dynamic-LDS limits of k_lsd_grow_mw / k_lsd_seed_sort
     int mw_capB = 0, seed_capB = 0;            // frames the lazily allocated buffers of those two paths hold
     LinePlanes P{};
@@ -222,6 +222,7 @@ plp_status plp_line_create(int device, plp_line** out) {
     c->mw_ok = grow_mw_configure() == hipSuccess;
     c->seed_sort_ok = seed_sort_configure() == hipSuccess;
     (void)hipGetLastError();
+    if (!c->seed_sort_ok) { delete c; return set_error(PLP_ERR_UNSUPPORTED, "this device refused the dynamic LDS size of the exact seed sort (144 KB per workgroup)"); }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return set_error(PLP_ERR_HIP, "hipStreamCreate failed"); }
     if (hipStreamCreateWithFlags(&c->side.stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->side.fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->side.join, hipEventDisableTiming) != hipSuccess) { c->side.stream = nullptr; }   // optional: falls back to one stream
@@ -440,7 +441,7 @@ int32_t plp_model_seed_introsort_host(uint32_t* entries, int64_t n, int32_t dept
 
 // The kernel's introsort loop on caller-made entries (host pointers; one workgroup), with a chosen recursion budget: the tests' way to
 // reach every branch (global partitions, LDS window, wave tasks, lanes, heap sort) on arbitrary key distributions.
-plp_status plp_seed_introsort_debug(int32_t device, uint32_t* entries, int64_t n, int32_t depth_limit, uint32_t skip_key) {
+plp_status plp_seed_introsort_debug(int32_t device, uint32_t* entries, int64_t n, int32_t depth_limit, uint32_t skip_key, int32_t variant) {
     if (!entries || n < 0 || n > (int64_t)kLsdMaxScaledPixels) return set_error(PLP_ERR_INVALID_ARG, "bad entries");
     int nd = 0;
     if (hipGetDeviceCount(&nd) != hipSuccess || nd == 0) return set_error(PLP_ERR_NO_DEVICE, "no HIP device visible");
@@ -454,7 +455,7 @@ plp_status plp_seed_introsort_debug(int32_t device, uint32_t* entries, int64_t n
     DevBuf dbg;
     const char* dflag = getenv("PLP_SEED_SORT_DBG");
     if (dflag) { PLP_HIP(dbg.reserve(4 * (2 + 6 * 4000 + 48))); PLP_HIP(hipMemset(dbg.p, 0, 4 * (2 + 6 * 4000 + 48))); int f = atoi(dflag); PLP_HIP(hipMemcpy(dbg.p, &f, 4, hipMemcpyHostToDevice)); }
-    launch_seed_sort_debug(nullptr, (uint32_t*)ent.p, (int)n, depth_limit, skip_key, (uint32_t*)ws.p, (int32_t*)st.p, dflag ? (int*)dbg.p : nullptr);
+    launch_seed_sort_debug(nullptr, (uint32_t*)ent.p, (int)n, depth_limit, skip_key, (uint32_t*)ws.p, (int32_t*)st.p, dflag ? (int*)dbg.p : nullptr, variant);
     PLP_HIP(hipGetLastError());
     PLP_HIP(hipDeviceSynchronize());
     int32_t s = 0;

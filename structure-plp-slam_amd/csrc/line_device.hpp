@@ -91,10 +91,9 @@ struct LineSideStream { hipStream_t stream; hipEvent_t fork, join; };   // optio
 // Seed order of a reference built with libstdc++ (seed_sort_kernels.hip): `ent` = [B][(sw-1)(sh-1)] entries, `ws` = [B][ws_stride] scratch
 struct SeedSortBufs { uint32_t* ent; uint32_t* ws; size_t ws_stride; };
 size_t seed_sort_ws_entries(size_t nv);
-size_t seed_sort_lds_bytes();
 hipError_t seed_sort_configure();   // raises the kernels' dynamic LDS limit on the CURRENT device
 void launch_seed_order_exact(hipStream_t st, const LinePlanes& P, const LsdParams& lp, int B, uint32_t* ent, uint32_t* ws, size_t ws_stride);
-void launch_seed_sort_debug(hipStream_t st, uint32_t* ent, int n, int depth, uint32_t skip_key, uint32_t* ws, int32_t* status, int* dbg);
+void launch_seed_sort_debug(hipStream_t st, uint32_t* ent, int n, int depth, uint32_t skip_key, uint32_t* ws, int32_t* status, int* dbg, int variant);
 hipError_t grow_mw_configure();      // the same for k_lsd_grow_mw (line_kernels.hip)
 
 // ev: NULL or 9 events recorded around the 8 stages {blur11+resize, gradient+bins, seed order, region grow, key lines,

@@ -27,7 +27,7 @@ LCAP = 512  # key lines kept per frame (a 640x480 frame yields ~50 after the >= 
 
 
 class tracker_step:
-    def __init__(self, plp, B, K, rows, cols, device_index=0, orb_only=False, n_line=2, nbuf=2, serial=False, shift=(-3.0, 0.0), parts="orb,lines,match", line_grow_waves=0):
+    def __init__(self, plp, B, K, rows, cols, device_index=0, orb_only=False, n_line=2, nbuf=2, serial=False, shift=(-3.0, 0.0), parts="orb,lines,match", line_grow_waves=0, seed_order=None):
         import torch
         self.torch = torch
         self.plp, self.B, self.K, self.rows, self.cols = plp, B, K, rows, cols
@@ -58,6 +58,8 @@ class tracker_step:
         self.lts = [] if orb_only else [plp.LineFeatureTracker(device=device_index) for _ in range(n_line)]
         for lt in self.lts:
             lt.set_grow_waves(line_grow_waves)      # 0 = automatic (several waves per frame only for batches of at most 256 frames)
+            if seed_order is not None:
+                lt.set_seed_order(seed_order)       # None = the library's default: the reference's std::sort order (PLP_SEED_ORDER_LIBSTDCXX)
         self.mt_last = plp.matcher(0.9, True, device=device_index)      # motion_based_track: match::projection(0.9, true)
         self.mt_lm = plp.matcher(0.8, True, device=device_index)        # search_local_landmarks: match::projection(0.8)
         self.mt_line = plp.matcher(0.9, True, device=device_index)      # motion_based_track, lines: match_current_and_last_frames_line

@@ -33,7 +33,7 @@ def fetch(ts, buf):
                 n=[c(ts.n1), c(ts.n2)] + ([] if ts.orb_only else [c(ts.n3), c(ts.n4)]))
 
 
-def check_frame(h, b, K, g6, shift, sf, frame=None, orb_only=False):
+def check_frame(h, b, K, g6, shift, sf, frame=None, orb_only=False, stable_order=False):
     """h: fetch() result; b: frame of the block; frame: its pixels (uint8 rows x cols) to check the extraction too, or None.
     Returns a list of mismatch descriptions (empty = frame verified)."""
     bad = []
@@ -74,7 +74,7 @@ def check_frame(h, b, K, g6, shift, sf, frame=None, orb_only=False):
     kl0, lb0 = h["kl"][r0][:l0], h["lbd"][r0][:l0]
     lcap = h["kl"].shape[1]
     if frame is not None:
-        ora = O.LineOracle(frame)
+        ora = O.LineOracle(frame, stable_order=stable_order)     # False: std::sort seed order = the library's default mode
         if len(ora.keylsd) != l0 or not np.array_equal(ora.keylsd, kl0) or not np.array_equal(ora.lbd, lb0) or not np.array_equal(ora.linefn, h["fn"][b][:l0]):
             bad.append(f"frame {b}: key lines / LBD / line functions differ from the oracle ({len(ora.keylsd)} vs {l0})")
     sf_lsd = np.ones(1, np.float32)

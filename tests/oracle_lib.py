@@ -347,7 +347,9 @@ KL_DTYPE = np.dtype([("angle", "<f4"), ("class_id", "<i4"), ("octave", "<i4"), (
 class LineOracle:
     """one extract_LSD_LBD run of the oracle with its stage outputs"""
 
-    def __init__(self, img, stable_order=True):
+    def __init__(self, img, stable_order=False):
+        """stable_order=False (default): seeds visited in the order std::sort leaves, as OpenCV's lsd.cpp does it (a reference built with this C++
+        library); True: bin descending then row-major, the library's PLP_SEED_ORDER_STABLE mode (definition D1 of rounds 1-3)"""
         img = np.ascontiguousarray(img, np.uint8)
         self.shape = img.shape
         L = lib()

@@ -19,13 +19,15 @@ def _want(e, depth):
     return plp.model_seed_introsort(e, depth) if w is None else w
 
 
+@pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("n", [17, 33, 64, 65, 66, 129, 1000, 4095, 4096, 4097, 4098, 9000, 24575, 24576, 24577, 24578, 30000, 76241, 115753, 229401])
-def test_kernel_introsort_loop_equals_libstdcxx_at_the_size_thresholds(n):
-    """every boundary between the kernel's regimes (lane / wave / workgroup in LDS / workgroup in global memory), on eight key distributions"""
+def test_kernel_introsort_loop_equals_libstdcxx_at_the_size_thresholds(n, variant):
+    """every boundary between the kernel's regimes (lane / wave / workgroup in LDS / workgroup in global memory), on eight key distributions, in both
+    configurations the library launches (variant 0: 4 waves and a 4096-entry window, large batches; 1: 16 waves and 24576 entries, small ones)"""
     r = np.random.default_rng(n)
     for kind in range(8):
         e = _seed_entries(r, n, kind)
-        assert np.array_equal(plp.seed_introsort_debug(e), _want(e, -1)), (n, kind)
+        assert np.array_equal(plp.seed_introsort_debug(e, variant=variant), _want(e, -1)), (n, kind)
 
 
 def test_kernel_introsort_loop_random_sizes_and_forced_recursion_budgets():
@@ -37,7 +39,7 @@ def test_kernel_introsort_loop_random_sizes_and_forced_recursion_budgets():
         depth = -1 if trial % 3 else int(r.integers(0, 9))
         if depth >= 0 and n > 30000:
             n = 30000 + trial; e = e[:n]                      # the heap sort of a long segment is one lane's work
-        assert np.array_equal(plp.seed_introsort_debug(e, depth), _want(e, depth)), (trial, n, depth)
+        assert np.array_equal(plp.seed_introsort_debug(e, depth, variant=trial % 2), _want(e, depth)), (trial, n, depth)
 
 
 def test_kernel_leaves_parts_below_the_skip_key_alone_exactly_as_the_model_does():
@@ -49,7 +51,7 @@ def test_kernel_leaves_parts_below_the_skip_key_alone_exactly_as_the_model_does(
         n = [300, 5000, 24577, 40000, 76241, 100000][trial % 6] + trial
         e = _seed_entries(r, n, [1, 7, 0, 2, 3, 6, 4, 5][trial % 8])
         skip = int(r.integers(1, 60)) if trial % 2 else int(r.integers(1, 1024))
-        got = plp.seed_introsort_debug(e, -1, skip)
+        got = plp.seed_introsort_debug(e, -1, skip, variant=(trial // 2) % 2)
         assert np.array_equal(got, plp.model_seed_introsort(e, -1, skip)), (trial, n, skip)
         fin = got[np.argsort(-key(got), kind="stable")]
         ref = O.std_sort_entries(e)
@@ -76,6 +78,28 @@ def test_exact_seed_order_leaves_no_key_line_different_from_std_sort(golden_dir)
         n_stable_diff += sum(1 for row in a if not (len(b) and (np.abs(b - row).max(1) == 0).any()))
     assert n_lines > 2500
     assert n_stable_diff > 0, "the two orders are known to differ on these frames: the exact mode must not have fallen back to the stable one"
+
+
+def test_exact_seed_order_in_a_large_batch_takes_the_other_kernel_configuration_with_the_same_result():
+    """batches above 256 frames run the 4-wave configuration of the sort, smaller ones the 16-wave one: 288 frames (24 distinct) against the oracle"""
+    import torch
+    uniq = synth.replay(78, 24)
+    dev = torch.device("cuda:0")
+    d = torch.from_numpy(uniq).to(dev).repeat(12, 1, 1).contiguous()
+    B, cap = d.shape[0], 512
+    d_kl = torch.zeros((B, cap, 68), dtype=torch.uint8, device=dev); d_lbd = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_fn = torch.zeros((B, cap, 3), dtype=torch.float64, device=dev); d_cnt = torch.zeros(B, dtype=torch.int32, device=dev)
+    lt = plp.LineFeatureTracker()
+    lt.extract_batch(d, d_kl, d_lbd, d_fn, d_cnt)
+    torch.cuda.synchronize()
+    lt.last_batch_status()
+    cnt = d_cnt.cpu().numpy()
+    kl = d_kl.cpu().numpy().view(plp.KL_DTYPE).reshape(B, cap)
+    lbd = d_lbd.cpu().numpy()
+    for f in range(24):
+        ora = O.LineOracle(uniq[f], stable_order=False)
+        for b in (f, f + 24 * 5, f + 24 * 11):
+            assert cnt[b] == len(ora.keylsd) and np.array_equal(kl[b, :cnt[b]], ora.keylsd) and np.array_equal(lbd[b, :cnt[b]], ora.lbd), (f, b)
 
 
 def test_exact_seed_order_in_a_batch_and_against_the_single_frame_path():
