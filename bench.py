@@ -64,8 +64,10 @@ def algorithmic_bytes(rows, cols, n_levels, mean_kp, mean_cand, mean_lines, mean
         "quadtree": 3 * 4 * mean_cand + 4 * mean_kp,     # candidates in, keys/indices once, selection out
         "orient_rbrief": mean_kp * (749 + 512 + 28 + 32),
         "lsd_blur11_resize": 2 * P0 + 1.25 * P0,         # 11x11 blur r/w + half-res resize
-        "lsd_gradient_bins": 0.25 * P0 * (1 + 8 + 8),    # read u8, write angle + magnitude
-        "lsd_order": 0.25 * P0 * (2 + 4),                # bins in, seed order out
+        "lsd_gradient_bins": 0.25 * P0 * (1 + 8),        # read u8, write f32 angle + f32 norm
+        # SURVEY 8(d) gives "ordering / growing" ONE figure, 0.25 P0 (8 + 1): each pixel read once + its used flag.  It is charged to region growing
+        # (the dominant kernel); the seed ordering -- stable counting sort or the replay of std::sort -- has no bytes of its own in that budget
+        # (its time is in stage_ms_per_batch, its traffic in profiles/), so that the per-stage figures add up to the 8(d) total.
         "lsd_grow": 0.25 * P0 * (8 + 1) + 16 * mean_raw, # each pixel's angle once + used flag, segments out
         "keylines": mean_raw * (16 + 68),
         "lbd_blur5_sobel": 2 * P0 + P0 * (1 + 4),        # 5x5 blur r/w, Sobel read u8 write 2 x s16
@@ -247,7 +249,7 @@ def main():
     traffic = traffic_source = None
     stage_kernel = {"lsd_grow": "plp::k_lsd_grow", "fast_cells": "plp::k_fast_cells", "quadtree": "plp::k_quadtree", "lbd": "plp::k_lbd",
                     "orient_rbrief": "plp::k_orient_rbrief", "blur7": "plp::k_blur7", "pyramid": "plp::k_resize_linear",
-                    "lsd_order": "plp::k_lsd_order", "match_4x": "plp::k_match_topk_lds"}
+                    "match_4x": "plp::k_match_topk_cells"}
     try:
         pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")))
         if pmc.get("batch") == B and dominant in stage_kernel:

@@ -21,6 +21,7 @@ struct plp_line {
     int rows = 0, cols = 0, capB = 0;
     int grow_waves = 0;   // plp_line_set_grow_waves
     int seed_order = PLP_SEED_ORDER_LIBSTDCXX;   // plp_line_set_seed_order; the reference's order unless the device refuses the sort's LDS (plp_line_create)
+    bool grow_on_side = false;                 // PLP_GROW_CUS: region growing on the CU-masked side stream
     bool mw_ok = false, seed_sort_ok = false;  // this device accepted the large dynamic-LDS limits of k_lsd_grow_mw / k_lsd_seed_sort
     int mw_capB = 0, seed_capB = 0;            // frames the lazily allocated buffers of those two paths hold
     LinePlanes P{};
@@ -193,7 +194,7 @@ plp_status run(plp_line* c, const uint8_t* d_imgs, int B, int rows, int cols, si
     c->lp.seed_exact = exact ? 1 : 0;
     const SeedSortBufs ssb{(uint32_t*)c->seed_ent.p, (uint32_t*)c->seed_ws.p, seed_sort_ws_entries((size_t)(c->P.sw - 1) * (c->P.sh - 1))};
     launch_line_front(st, c->P, c->lp, c->rt, c->t11, c->t5, c->w, d_kl, d_lbd, d_fn, cap, d_counts, B, c->profiling ? c->ev : nullptr,
-                      c->side.stream ? &c->side : nullptr, c->grow_waves, exact ? &ssb : nullptr, c->mw_ok);
+                      c->side.stream ? &c->side : nullptr, c->grow_waves, exact ? &ssb : nullptr, c->mw_ok, c->grow_on_side);
     PLP_HIP(hipGetLastError());
     if (c->profiling) {
         PLP_HIP(hipEventSynchronize(c->ev[8]));
@@ -224,8 +225,20 @@ plp_status plp_line_create(int device, plp_line** out) {
     (void)hipGetLastError();
     if (!c->seed_sort_ok) { delete c; return set_error(PLP_ERR_UNSUPPORTED, "this device refused the dynamic LDS size of the exact seed sort (144 KB per workgroup)"); }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return set_error(PLP_ERR_HIP, "hipStreamCreate failed"); }
-    if (hipStreamCreateWithFlags(&c->side.stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->side.fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->side.join, hipEventDisableTiming) != hipSuccess) { c->side.stream = nullptr; }   // optional: falls back to one stream
+    // Experiment (profiles/r04_grow_cu_mask.md): PLP_GROW_CUS=n runs region growing on a stream of its own that may only use n of the CUs
+    // (hipExtStreamCreateWithCUMask; the mask's bits go round the XCDs, so the first n bits are n / 8 CUs of each), the rest of the chip stays free
+    // of the growers' LDS and registers.  The side stream then serves this purpose (PLP_LINE_SIDE_STREAM is ignored).
+    const char* gcu = getenv("PLP_GROW_CUS");
+    const int n_gcu = gcu ? atoi(gcu) : 0;
+    hipError_t side_err;
+    if (n_gcu > 0) {
+        uint32_t mask[16] = {0};
+        for (int i = 0; i < n_gcu && i < 512; ++i) mask[i >> 5] |= 1u << (i & 31);
+        side_err = hipExtStreamCreateWithCUMask(&c->side.stream, 16, mask);
+        c->grow_on_side = side_err == hipSuccess;
+    } else side_err = hipStreamCreateWithFlags(&c->side.stream, hipStreamNonBlocking);
+    if (side_err != hipSuccess || hipEventCreateWithFlags(&c->side.fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->side.join, hipEventDisableTiming) != hipSuccess) { c->side.stream = nullptr; c->grow_on_side = false; }   // optional: falls back to one stream
     *out = c;
     return PLP_OK;
 }

@@ -100,6 +100,6 @@ hipError_t grow_mw_configure();      // the same for k_lsd_grow_mw (line_kernels
 // blur5+sobel, LBD, finalize}
 void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp, const ResizeExactTab& rt, const BlurTapsN& t11,
                        const BlurTapsN& t5, const LbdWeightsDev& w, plp_keyline* out_kl, uint8_t* out_lbd, double* out_fn, int cap,
-                       int32_t* out_counts, int B, hipEvent_t* ev, const LineSideStream* side, int grow_waves, const SeedSortBufs* seed_exact, bool mw_ok);
+                       int32_t* out_counts, int B, hipEvent_t* ev, const LineSideStream* side, int grow_waves, const SeedSortBufs* seed_exact, bool mw_ok, bool grow_on_side = false);
 
 }  // namespace plp

@@ -1735,7 +1735,7 @@ __global__ __launch_bounds__(64) void k_line_finalize(LinePlanes P, LsdParams lp
 // ------------------------------------------------------------------------------------------ launch sequence
 void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp, const ResizeExactTab& rt, const BlurTapsN& t11,
                        const BlurTapsN& t5, const LbdWeightsDev& w, plp_keyline* out_kl, uint8_t* out_lbd, double* out_fn, int cap,
-                       int32_t* out_counts, int B, hipEvent_t* ev, const LineSideStream* side, int grow_waves, const SeedSortBufs* seed_exact, bool mw_ok) {
+                       int32_t* out_counts, int B, hipEvent_t* ev, const LineSideStream* side, int grow_waves, const SeedSortBufs* seed_exact, bool mw_ok, bool grow_on_side) {
     auto mark = [&](int i) { if (ev) (void)hipEventRecord(ev[i], st); };
     // The LBD image pass (5-tap blur + Sobel) does not depend on LSD.  Unless per-stage timing is requested it is launched FIRST, on the
     // same stream: it then overlaps whatever the other streams of the caller run, and nothing has to join before k_lbd.  (A side
@@ -1743,7 +1743,7 @@ void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp,
     // on the runtime's four hardware queues, and a context's Sobel pass queued behind 8 ms of matcher kernels of an unrelated stream
     // while its k_lbd waited for it -- profiles/r03c_step_timeline.md.  PLP_LINE_SIDE_STREAM=1 brings the side stream back.)
     static const bool use_side = [] { const char* e = getenv("PLP_LINE_SIDE_STREAM"); return e && e[0] == '1'; }();
-    const bool fork = side && !ev && use_side;
+    const bool fork = side && !ev && use_side && !grow_on_side;
     const bool sobel_first = !ev && !fork;
     hipStream_t st2 = fork ? side->stream : st;
     const size_t plane_fs = (size_t)P.pitch * P.H, splane_fs = (size_t)P.spitch * P.sh;
@@ -1800,12 +1800,16 @@ void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp,
             if (bytes <= 160 * 1024) { L.waves = w; L.ring = 256; L.nw_al = nw_al; L.n_groups_cap = groups_cap; L.lookahead = kMwBufs * (w - 1); L.policy = mw_policy; mw_bytes = bytes; break; }
         }
     }
+    hipStream_t st_main = st;
+    const bool grow_fork = grow_on_side && side && L.waves < 2;
+    if (grow_fork) { (void)hipEventRecord(side->fork, st); (void)hipStreamWaitEvent(side->stream, side->fork, 0); st = side->stream; }
     if (skip_after < 0 || n_launch++ < skip_after) {
         if (L.waves >= 2) {
             hipLaunchKernelGGL(k_lsd_grow_mw, dim3(B), dim3(64 * L.waves), mw_bytes, st, P, lp, L);
         } else
             hipLaunchKernelGGL(k_lsd_grow, dim3((B + wpb - 1) / wpb), dim3(64 * wpb), per_wave * wpb, st, P, lp, B, wpb, ring);
     }
+    if (grow_fork) { (void)hipEventRecord(side->join, side->stream); st = st_main; (void)hipStreamWaitEvent(st, side->join, 0); }
     mark(4);
     hipLaunchKernelGGL(k_keylines, dim3(B), dim3(64), 0, st, P, lp);
     mark(5);
