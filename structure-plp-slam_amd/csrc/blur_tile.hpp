@@ -41,44 +41,11 @@ __device__ __forceinline__ uint32_t blur_dot2(uint32_t a, uint32_t b, uint32_t c
     return __builtin_amdgcn_udot2(__builtin_bit_cast(blur_us2, a), __builtin_bit_cast(blur_us2, b), c, false);
 }
 
-// Core: stage, horizontal pass, vertical pass; every thread ends with the blurred bytes of its 4 columns x 4 rows (one dword per
-// row, tile-local rows r0..r0+3, columns c4..c4+3) and hands them to emit(r0, c4, rows).  The tile origin may lie outside the image
-// (tx0 a multiple of 4, possibly negative): the blur is then evaluated on the REFLECT_101 extension of the source, which for a
-// symmetric kernel equals the REFLECT_101 extension of the blurred image -- what a following 3x3 filter wants at the border.
-// src: plane base (4-byte aligned, pitch % 4 == 0)
+// horizontal pass, barrier, vertical pass on a staged tile (the caller has synchronised after staging); emit(r0, c4, rows) gets every thread's 4 x 4 bytes
 template <int R, class Emit>
-__device__ __forceinline__ void blur_tile_core(BlurTileLds<R>& S, const uint8_t* __restrict__ src, int src_pitch, int w, int h, int tx0, int ty0,
-                                               const int* __restrict__ taps, Emit emit) {
-    constexpr int K = 2 * R + 1, IW = BlurTileLds<R>::IW, IH = BlurTileLds<R>::IH, DW = IW / 4, NPR = BlurTileLds<R>::NPR;
-    static_assert(IH % 2 == 0 && kBlurRS == 4, "row pairs");
+__device__ __forceinline__ void blur_tile_compute(BlurTileLds<R>& S, const int* __restrict__ taps, Emit emit) {
+    constexpr int K = 2 * R + 1, IW = BlurTileLds<R>::IW, NPR = BlurTileLds<R>::NPR;
     const int tid = threadIdx.x;
-    // ---- stage input rows [ty0-R, ty0+TH+R) x columns [tx0-PAD, tx0+TW+PAD): whole dwords inside the image
-    for (int i = tid; i < IH * DW; i += 256) {
-        const int r = i / DW, d = i - r * DW;
-        const int x = tx0 - kBlurPad + 4 * d;
-        if (x >= 0 && x + 3 < w) {
-            const int y = blur_reflect101(ty0 + r - R, h);
-            *reinterpret_cast<uint32_t*>(&S.in[r * IW + 4 * d]) = *reinterpret_cast<const uint32_t*>(src + (size_t)y * src_pitch + x);
-        }
-    }
-    // dwords outside [0, w) or straddling x = w: the left pad of the first tile column (up to 4 per row), the ones around and
-    // beyond x = w (outputs up to x = w, for a following 3x3 filter, read bytes up to w + R).  Uniform test: interior tiles skip the pass.
-    const int dr0 = (w - 3 - (tx0 - kBlurPad) + 3) >> 2;   // first dword with x + 3 >= w
-    if (tx0 <= 0 || dr0 < DW) {
-        for (int i = tid; i < IH * 8; i += 256) {
-            const int r = i >> 3, slot = i & 7;
-            const int d = slot < 4 ? slot : dr0 + slot - 4;
-            const int x = tx0 - kBlurPad + 4 * d;
-            const bool todo = slot < 4 ? x < 0 : (d >= 0 && d < DW && x <= w + R + 3);
-            if (todo) {
-                const uint8_t* row = src + (size_t)blur_reflect101(ty0 + r - R, h) * src_pitch;
-                const uint32_t v = (uint32_t)row[blur_reflect101(x, w)] | ((uint32_t)row[blur_reflect101(x + 1, w)] << 8) |
-                                   ((uint32_t)row[blur_reflect101(x + 2, w)] << 16) | ((uint32_t)row[blur_reflect101(x + 3, w)] << 24);
-                *reinterpret_cast<uint32_t*>(&S.in[r * IW + 4 * d]) = v;
-            }
-        }
-    }
-    __syncthreads();
     // ---- horizontal
     constexpr int RU = (R + 3) / 4 * 4;           // window start rounded down to a dword: RU - R bytes of slack
     constexpr int OFF = RU - R;                   // byte offset of tap 0 of output 0 inside the first dword
@@ -149,6 +116,47 @@ __device__ __forceinline__ void blur_tile_core(BlurTileLds<R>& S, const uint8_t*
     emit(r0, c4, rows);
 }
 
+// Core: stage, horizontal pass, vertical pass; every thread ends with the blurred bytes of its 4 columns x 4 rows (one dword per
+// row, tile-local rows r0..r0+3, columns c4..c4+3) and hands them to emit(r0, c4, rows).  The tile origin may lie outside the image
+// (tx0 a multiple of 4, possibly negative): the blur is then evaluated on the REFLECT_101 extension of the source, which for a
+// symmetric kernel equals the REFLECT_101 extension of the blurred image -- what a following 3x3 filter wants at the border.
+// src: plane base (4-byte aligned, pitch % 4 == 0)
+template <int R, class Emit>
+__device__ __forceinline__ void blur_tile_core(BlurTileLds<R>& S, const uint8_t* __restrict__ src, int src_pitch, int w, int h, int tx0, int ty0,
+                                               const int* __restrict__ taps, Emit emit) {
+    constexpr int IW = BlurTileLds<R>::IW, IH = BlurTileLds<R>::IH, DW = IW / 4;
+    static_assert(IH % 2 == 0 && kBlurRS == 4, "row pairs");
+    const int tid = threadIdx.x;
+    // ---- stage input rows [ty0-R, ty0+TH+R) x columns [tx0-PAD, tx0+TW+PAD): whole dwords inside the image
+    for (int i = tid; i < IH * DW; i += 256) {
+        const int r = i / DW, d = i - r * DW;
+        const int x = tx0 - kBlurPad + 4 * d;
+        if (x >= 0 && x + 3 < w) {
+            const int y = blur_reflect101(ty0 + r - R, h);
+            *reinterpret_cast<uint32_t*>(&S.in[r * IW + 4 * d]) = *reinterpret_cast<const uint32_t*>(src + (size_t)y * src_pitch + x);
+        }
+    }
+    // dwords outside [0, w) or straddling x = w: the left pad of the first tile column (up to 4 per row), the ones around and
+    // beyond x = w (outputs up to x = w, for a following 3x3 filter, read bytes up to w + R).  Uniform test: interior tiles skip the pass.
+    const int dr0 = (w - 3 - (tx0 - kBlurPad) + 3) >> 2;   // first dword with x + 3 >= w
+    if (tx0 <= 0 || dr0 < DW) {
+        for (int i = tid; i < IH * 8; i += 256) {
+            const int r = i >> 3, slot = i & 7;
+            const int d = slot < 4 ? slot : dr0 + slot - 4;
+            const int x = tx0 - kBlurPad + 4 * d;
+            const bool todo = slot < 4 ? x < 0 : (d >= 0 && d < DW && x <= w + R + 3);
+            if (todo) {
+                const uint8_t* row = src + (size_t)blur_reflect101(ty0 + r - R, h) * src_pitch;
+                const uint32_t v = (uint32_t)row[blur_reflect101(x, w)] | ((uint32_t)row[blur_reflect101(x + 1, w)] << 8) |
+                                   ((uint32_t)row[blur_reflect101(x + 2, w)] << 16) | ((uint32_t)row[blur_reflect101(x + 3, w)] << 24);
+                *reinterpret_cast<uint32_t*>(&S.in[r * IW + 4 * d]) = v;
+            }
+        }
+    }
+    __syncthreads();
+    blur_tile_compute<R>(S, taps, emit);
+}
+
 // The plain blur: the tile's bytes go to the output plane (pitch % 4 == 0, rows padded to a multiple of 4).
 template <int R>
 __device__ __forceinline__ void blur_tile(BlurTileLds<R>& S, const uint8_t* __restrict__ src, int src_pitch, uint8_t* __restrict__ dst,
@@ -162,6 +170,64 @@ __device__ __forceinline__ void blur_tile(BlurTileLds<R>& S, const uint8_t* __re
             if (y < h) *reinterpret_cast<uint32_t*>(dst + (size_t)y * dst_pitch + x) = rows[rr];
         }
     });
+}
+
+
+// ---- the same tile in three pieces, for PERSISTENT workgroups that walk a list of tiles: the global loads of tile n + 1 are
+// issued into registers right after tile n's first barrier and wait there through its two compute phases, so that the memory latency runs beside
+// the arithmetic of the workgroup's own tile instead of being hidden only by other workgroups; no workgroup launch per tile.
+struct BlurJob { const uint8_t* src; uint8_t* dst; int src_pitch, dst_pitch, w, h, tx0, ty0; };   // wave-uniform
+
+template <int R> struct BlurPrefetch {
+    static constexpr int IW = BlurTileLds<R>::IW, IH = BlurTileLds<R>::IH, DW = IW / 4;
+    static constexpr int NPRE = (IH * DW + 255) / 256, NPATCH = (IH * 8 + 255) / 256;
+    uint32_t pre[NPRE], patch[NPATCH];
+};
+// issue the loads of a tile (whole dwords inside the image; the dwords that straddle the image border assembled byte-wise, border tiles only)
+template <int R> __device__ __forceinline__ void blur_prefetch(BlurPrefetch<R>& F, const BlurJob& J) {
+    constexpr int IW = BlurTileLds<R>::IW, IH = BlurTileLds<R>::IH, DW = IW / 4;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < BlurPrefetch<R>::NPRE; ++q) {
+        const int i = tid + 256 * q, r = i / DW, d = i - r * DW, x = J.tx0 - kBlurPad + 4 * d;
+        F.pre[q] = 0u;
+        if (i < IH * DW && x >= 0 && x + 3 < J.w) F.pre[q] = *reinterpret_cast<const uint32_t*>(J.src + (size_t)blur_reflect101(J.ty0 + r - R, J.h) * J.src_pitch + x);
+    }
+    const int dr0 = (J.w - 3 - (J.tx0 - kBlurPad) + 3) >> 2;
+    if (J.tx0 <= 0 || dr0 < DW) {
+#pragma unroll
+        for (int q = 0; q < BlurPrefetch<R>::NPATCH; ++q) {
+            const int i = tid + 256 * q, r = i >> 3, slot = i & 7;
+            const int d = slot < 4 ? slot : dr0 + slot - 4, x = J.tx0 - kBlurPad + 4 * d;
+            const bool todo = i < IH * 8 && (slot < 4 ? x < 0 : (d >= 0 && d < DW && x <= J.w + R + 3));
+            F.patch[q] = 0u;
+            if (todo) {
+                const uint8_t* row = J.src + (size_t)blur_reflect101(J.ty0 + r - R, J.h) * J.src_pitch;
+                F.patch[q] = (uint32_t)row[blur_reflect101(x, J.w)] | ((uint32_t)row[blur_reflect101(x + 1, J.w)] << 8) |
+                             ((uint32_t)row[blur_reflect101(x + 2, J.w)] << 16) | ((uint32_t)row[blur_reflect101(x + 3, J.w)] << 24);
+            }
+        }
+    }
+}
+// the prefetched dwords go to the LDS tile (same slots as blur_tile_core's staging)
+template <int R> __device__ __forceinline__ void blur_stage_prefetched(BlurTileLds<R>& S, const BlurPrefetch<R>& F, const BlurJob& J) {
+    constexpr int IW = BlurTileLds<R>::IW, IH = BlurTileLds<R>::IH, DW = IW / 4;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < BlurPrefetch<R>::NPRE; ++q) {
+        const int i = tid + 256 * q, r = i / DW, d = i - r * DW, x = J.tx0 - kBlurPad + 4 * d;
+        if (i < IH * DW && x >= 0 && x + 3 < J.w) *reinterpret_cast<uint32_t*>(&S.in[r * IW + 4 * d]) = F.pre[q];
+    }
+    const int dr0 = (J.w - 3 - (J.tx0 - kBlurPad) + 3) >> 2;
+    if (J.tx0 <= 0 || dr0 < DW) {
+#pragma unroll
+        for (int q = 0; q < BlurPrefetch<R>::NPATCH; ++q) {
+            const int i = tid + 256 * q, r = i >> 3, slot = i & 7;
+            const int d = slot < 4 ? slot : dr0 + slot - 4, x = J.tx0 - kBlurPad + 4 * d;
+            const bool todo = i < IH * 8 && (slot < 4 ? x < 0 : (d >= 0 && d < DW && x <= J.w + R + 3));
+            if (todo) *reinterpret_cast<uint32_t*>(&S.in[r * IW + 4 * d]) = F.patch[q];
+        }
+    }
 }
 
 }  // namespace plp

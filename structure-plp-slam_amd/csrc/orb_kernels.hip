@@ -406,6 +406,51 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                  L.w, L.h, (t % tiles_x) * kBlurTW, (t / tiles_x) * kBlurTH, taps.k);
 }
 
+// The same blur by PERSISTENT workgroups (PLP_BLUR7_PERSIST=1; profiles/r04_tile_pipelining.md): workgroup g of G walks the tiles g, g + G, ... of the
+// XCD-major tile order, prefetching the next tile's pixels into registers while it computes the current one (blur_tile.hpp).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_blur7p(OrbPlanes pl, uint8_t* __restrict__ blur_base, size_t blur_frame_stride,
+                                               const LevelDev* __restrict__ lv, int n_levels, BlurTaps taps, int tiles_per_frame, int B) {
+    __shared__ BlurTileLds<3> S;
+    const unsigned total = (unsigned)tiles_per_frame * (unsigned)B, G = gridDim.x, g = blockIdx.x;
+    // XCD k (workgroups with g % 8 == k) takes the k-th eighth of the frame-major tile list, as xcd_frame_major does for the one-tile kernel
+    const unsigned per_xcd = (total + 7u) / 8u, xcd = g & 7u, lane_g = g >> 3, stride = G >> 3;
+    auto job_of = [&](unsigned j, BlurJob& J) -> bool {
+        const unsigned logical = xcd * per_xcd + j;
+        if (j >= per_xcd || logical >= total) return false;
+        const int frame = (int)(logical / (unsigned)tiles_per_frame);
+        int t = (int)(logical - (unsigned)frame * (unsigned)tiles_per_frame), level = 0;
+        while (level + 1 < n_levels && t >= lv[level].blur_tiles) { t -= lv[level].blur_tiles; ++level; }
+        const LevelDev L = lv[level];
+        const int tiles_x = (L.w + kBlurTW - 1) / kBlurTW;
+        J.src = pl.level_ptr(frame, level, L); J.src_pitch = pl.level_pitch(level, L);
+        J.dst = blur_base + (size_t)frame * blur_frame_stride + L.off; J.dst_pitch = L.pitch;
+        J.w = L.w; J.h = L.h; J.tx0 = (t % tiles_x) * kBlurTW; J.ty0 = (t / tiles_x) * kBlurTH;
+        return true;
+    };
+    BlurJob J, Jn;
+    BlurPrefetch<3> F;
+    unsigned j = lane_g;
+    bool have = job_of(j, J);
+    if (have) blur_prefetch<3>(F, J);
+    while (have) {
+        blur_stage_prefetched<3>(S, F, J);
+        __syncthreads();
+        j += stride;
+        const bool have_n = job_of(j, Jn);
+        if (have_n) blur_prefetch<3>(F, Jn);                     // in flight through the two compute phases below
+        blur_tile_compute<3>(S, taps.k, [&](int r0, int c4, const uint32_t (&rows)[kBlurRS]) {
+            const int x = J.tx0 + c4;
+            if (x >= J.w) return;
+#pragma unroll
+            for (int rr = 0; rr < kBlurRS; ++rr) {
+                const int y = J.ty0 + r0 + rr;
+                if (y < J.h) *reinterpret_cast<uint32_t*>(J.dst + (size_t)y * J.dst_pitch + x) = rows[rr];
+            }
+        });
+        J = Jn; have = have_n;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // K5+K7  orientation + rBRIEF + KeyPoint assembly, 16 lanes per selected key point (4 key points per wave64).
 // The first version spent a whole wave on one key point: 4.2 M waves of ~300 instructions each, three dependent memory
@@ -635,7 +680,9 @@ void launch_fast(hipStream_t st, const OrbPlanes& pl, const CellDesc* d_cells, i
 
 void launch_blur(hipStream_t st, const OrbPlanes& pl, uint8_t* blur, size_t blur_frame_stride, const LevelDev* d_lv,
                  int n_levels, int total_tiles, int B, const BlurTaps& taps) {
-    hipLaunchKernelGGL(k_blur7, dim3(total_tiles, B), dim3(256), 0, st, pl, blur, blur_frame_stride, d_lv, n_levels, taps);
+    static const int blur_persist = [] { const char* e = getenv("PLP_BLUR7_PERSIST"); return e ? atoi(e) : 0; }();   // experiment: n = workgroups per CU of the persistent form
+    if (blur_persist > 0 && (size_t)total_tiles * B >= 4096) hipLaunchKernelGGL(k_blur7p, dim3(256 * blur_persist), dim3(256), 0, st, pl, blur, blur_frame_stride, d_lv, n_levels, taps, total_tiles, B);
+    else hipLaunchKernelGGL(k_blur7, dim3(total_tiles, B), dim3(256), 0, st, pl, blur, blur_frame_stride, d_lv, n_levels, taps);
 }
 
 void launch_orient_rbrief(hipStream_t st, const OrbPlanes& pl, const uint8_t* blur, size_t blur_frame_stride,
