@@ -23,7 +23,12 @@ constexpr int kBlurRS = kBlurTH / 8;   // output rows per thread in the vertical
 
 __device__ __forceinline__ int blur_reflect101(int p, int len) {
     if (len == 1) return 0;
-    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p;
+    // one reflection at either border covers every index a tile of an image of at least 48 rows / columns asks for: straight-line code (the general
+    // loop below had made every staging load a loop of its own and kept the compiler from issuing a tile's loads together)
+    p = p < 0 ? -p : p;
+    p = p >= len ? 2 * (len - 1) - p : p;
+    if (__builtin_expect(p < 0 || p >= len, 0))
+        while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p;
     return p;
 }
 
@@ -116,63 +121,6 @@ __device__ __forceinline__ void blur_tile_compute(BlurTileLds<R>& S, const int* 
     emit(r0, c4, rows);
 }
 
-// Core: stage, horizontal pass, vertical pass; every thread ends with the blurred bytes of its 4 columns x 4 rows (one dword per
-// row, tile-local rows r0..r0+3, columns c4..c4+3) and hands them to emit(r0, c4, rows).  The tile origin may lie outside the image
-// (tx0 a multiple of 4, possibly negative): the blur is then evaluated on the REFLECT_101 extension of the source, which for a
-// symmetric kernel equals the REFLECT_101 extension of the blurred image -- what a following 3x3 filter wants at the border.
-// src: plane base (4-byte aligned, pitch % 4 == 0)
-template <int R, class Emit>
-__device__ __forceinline__ void blur_tile_core(BlurTileLds<R>& S, const uint8_t* __restrict__ src, int src_pitch, int w, int h, int tx0, int ty0,
-                                               const int* __restrict__ taps, Emit emit) {
-    constexpr int IW = BlurTileLds<R>::IW, IH = BlurTileLds<R>::IH, DW = IW / 4;
-    static_assert(IH % 2 == 0 && kBlurRS == 4, "row pairs");
-    const int tid = threadIdx.x;
-    // ---- stage input rows [ty0-R, ty0+TH+R) x columns [tx0-PAD, tx0+TW+PAD): whole dwords inside the image
-    for (int i = tid; i < IH * DW; i += 256) {
-        const int r = i / DW, d = i - r * DW;
-        const int x = tx0 - kBlurPad + 4 * d;
-        if (x >= 0 && x + 3 < w) {
-            const int y = blur_reflect101(ty0 + r - R, h);
-            *reinterpret_cast<uint32_t*>(&S.in[r * IW + 4 * d]) = *reinterpret_cast<const uint32_t*>(src + (size_t)y * src_pitch + x);
-        }
-    }
-    // dwords outside [0, w) or straddling x = w: the left pad of the first tile column (up to 4 per row), the ones around and
-    // beyond x = w (outputs up to x = w, for a following 3x3 filter, read bytes up to w + R).  Uniform test: interior tiles skip the pass.
-    const int dr0 = (w - 3 - (tx0 - kBlurPad) + 3) >> 2;   // first dword with x + 3 >= w
-    if (tx0 <= 0 || dr0 < DW) {
-        for (int i = tid; i < IH * 8; i += 256) {
-            const int r = i >> 3, slot = i & 7;
-            const int d = slot < 4 ? slot : dr0 + slot - 4;
-            const int x = tx0 - kBlurPad + 4 * d;
-            const bool todo = slot < 4 ? x < 0 : (d >= 0 && d < DW && x <= w + R + 3);
-            if (todo) {
-                const uint8_t* row = src + (size_t)blur_reflect101(ty0 + r - R, h) * src_pitch;
-                const uint32_t v = (uint32_t)row[blur_reflect101(x, w)] | ((uint32_t)row[blur_reflect101(x + 1, w)] << 8) |
-                                   ((uint32_t)row[blur_reflect101(x + 2, w)] << 16) | ((uint32_t)row[blur_reflect101(x + 3, w)] << 24);
-                *reinterpret_cast<uint32_t*>(&S.in[r * IW + 4 * d]) = v;
-            }
-        }
-    }
-    __syncthreads();
-    blur_tile_compute<R>(S, taps, emit);
-}
-
-// The plain blur: the tile's bytes go to the output plane (pitch % 4 == 0, rows padded to a multiple of 4).
-template <int R>
-__device__ __forceinline__ void blur_tile(BlurTileLds<R>& S, const uint8_t* __restrict__ src, int src_pitch, uint8_t* __restrict__ dst,
-                                          int dst_pitch, int w, int h, int tx0, int ty0, const int* __restrict__ taps) {
-    blur_tile_core<R>(S, src, src_pitch, w, h, tx0, ty0, taps, [&](int r0, int c4, const uint32_t (&rows)[kBlurRS]) {
-        const int x = tx0 + c4;
-        if (x >= w) return;
-#pragma unroll
-        for (int rr = 0; rr < kBlurRS; ++rr) {
-            const int y = ty0 + r0 + rr;
-            if (y < h) *reinterpret_cast<uint32_t*>(dst + (size_t)y * dst_pitch + x) = rows[rr];
-        }
-    });
-}
-
-
 // ---- the same tile in three pieces, for PERSISTENT workgroups that walk a list of tiles: the global loads of tile n + 1 are
 // issued into registers right after tile n's first barrier and wait there through its two compute phases, so that the memory latency runs beside
 // the arithmetic of the workgroup's own tile instead of being hidden only by other workgroups; no workgroup launch per tile.
@@ -195,18 +143,20 @@ template <int R> __device__ __forceinline__ void blur_prefetch(BlurPrefetch<R>& 
     }
     const int dr0 = (J.w - 3 - (J.tx0 - kBlurPad) + 3) >> 2;
     if (J.tx0 <= 0 || dr0 < DW) {
+        uint8_t b[BlurPrefetch<R>::NPATCH][4];                   // all byte loads first, the dwords assembled afterwards: one memory round trip
 #pragma unroll
         for (int q = 0; q < BlurPrefetch<R>::NPATCH; ++q) {
             const int i = tid + 256 * q, r = i >> 3, slot = i & 7;
             const int d = slot < 4 ? slot : dr0 + slot - 4, x = J.tx0 - kBlurPad + 4 * d;
-            const bool todo = i < IH * 8 && (slot < 4 ? x < 0 : (d >= 0 && d < DW && x <= J.w + R + 3));
-            F.patch[q] = 0u;
-            if (todo) {
-                const uint8_t* row = J.src + (size_t)blur_reflect101(J.ty0 + r - R, J.h) * J.src_pitch;
-                F.patch[q] = (uint32_t)row[blur_reflect101(x, J.w)] | ((uint32_t)row[blur_reflect101(x + 1, J.w)] << 8) |
-                             ((uint32_t)row[blur_reflect101(x + 2, J.w)] << 16) | ((uint32_t)row[blur_reflect101(x + 3, J.w)] << 24);
-            }
+            // (unconditional: the reflected indices are valid for every slot, and straight-line loads are what lets all eight be in flight together;
+            //  blur_stage_prefetched only uses the slots that are due)
+            const uint8_t* row = J.src + (size_t)blur_reflect101(J.ty0 + r - R, J.h) * J.src_pitch;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) b[q][k] = row[blur_reflect101(x + k, J.w)];
         }
+#pragma unroll
+        for (int q = 0; q < BlurPrefetch<R>::NPATCH; ++q)
+            F.patch[q] = (uint32_t)b[q][0] | ((uint32_t)b[q][1] << 8) | ((uint32_t)b[q][2] << 16) | ((uint32_t)b[q][3] << 24);
     }
 }
 // the prefetched dwords go to the LDS tile (same slots as blur_tile_core's staging)
@@ -229,5 +179,44 @@ template <int R> __device__ __forceinline__ void blur_stage_prefetched(BlurTileL
         }
     }
 }
+
+
+// Core: stage, horizontal pass, vertical pass; every thread ends with the blurred bytes of its 4 columns x 4 rows (one dword per
+// row, tile-local rows r0..r0+3, columns c4..c4+3) and hands them to emit(r0, c4, rows).  The tile origin may lie outside the image
+// (tx0 a multiple of 4, possibly negative): the blur is then evaluated on the REFLECT_101 extension of the source, which for a
+// symmetric kernel equals the REFLECT_101 extension of the blurred image -- what a following 3x3 filter wants at the border.
+// src: plane base (4-byte aligned, pitch % 4 == 0)
+template <int R, class Emit>
+__device__ __forceinline__ void blur_tile_core(BlurTileLds<R>& S, const uint8_t* __restrict__ src, int src_pitch, int w, int h, int tx0, int ty0,
+                                               const int* __restrict__ taps, Emit emit) {
+    static_assert(BlurTileLds<R>::IH % 2 == 0 && kBlurRS == 4, "row pairs");
+    // ---- stage input rows [ty0-R, ty0+TH+R) x columns [tx0-PAD, tx0+TW+PAD): every thread ISSUES all its loads (6 whole dwords inside the image, and
+    // on border tiles 2 dwords assembled byte-wise around x = 0 / x = w), then stores them to LDS.  Until round 4 this was a loop of load -> wait ->
+    // LDS store: six serialized memory round trips per tile, which is what every kernel built on this tile was waiting for (profiles/r04_tile_pipelining.md).
+    {
+        const BlurJob J{src, nullptr, src_pitch, 0, w, h, tx0, ty0};
+        BlurPrefetch<R> F;
+        blur_prefetch<R>(F, J);
+        blur_stage_prefetched<R>(S, F, J);
+    }
+    __syncthreads();
+    blur_tile_compute<R>(S, taps, emit);
+}
+
+// The plain blur: the tile's bytes go to the output plane (pitch % 4 == 0, rows padded to a multiple of 4).
+template <int R>
+__device__ __forceinline__ void blur_tile(BlurTileLds<R>& S, const uint8_t* __restrict__ src, int src_pitch, uint8_t* __restrict__ dst,
+                                          int dst_pitch, int w, int h, int tx0, int ty0, const int* __restrict__ taps) {
+    blur_tile_core<R>(S, src, src_pitch, w, h, tx0, ty0, taps, [&](int r0, int c4, const uint32_t (&rows)[kBlurRS]) {
+        const int x = tx0 + c4;
+        if (x >= w) return;
+#pragma unroll
+        for (int rr = 0; rr < kBlurRS; ++rr) {
+            const int y = ty0 + r0 + rr;
+            if (y < h) *reinterpret_cast<uint32_t*>(dst + (size_t)y * dst_pitch + x) = rows[rr];
+        }
+    });
+}
+
 
 }  // namespace plp

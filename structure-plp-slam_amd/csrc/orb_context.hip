@@ -239,7 +239,7 @@ plp_status run_batch(plp_orb* c, const uint8_t* d_imgs, int B, int rows, int col
                 (int)c->p.min_fast_thr, d_mask, mask_step, mask_frame_stride, (uint32_t*)c->cell_cand.p, (int32_t*)c->cell_count.p);
     mark(3);
     BlurTaps taps{{18, 34, 48, 56, 48, 34, 18}};   // 7 taps, sigma 2, 8.8 fixed point, sum 256
-    launch_blur(st, pl, (uint8_t*)c->blur.p, g.frame_plane_bytes, (const LevelDev*)c->d_lv.p, nl, c->total_blur_tiles, B, taps);
+    launch_blur(st, pl, (uint8_t*)c->blur.p, g.frame_plane_bytes, (const LevelDev*)c->d_lv.p, nl, c->total_blur_tiles, B, taps, c->h_lv.data());
     mark(4);
     launch_quadtree(st, (const LevelDev*)c->d_lv.p, nl, (int)g.cells.size(), (const uint32_t*)c->cell_cand.p,
                     (const int32_t*)c->cell_count.p, (int32_t*)c->sel.p, (int32_t*)c->sel_count.p, g.total_sel_cap,

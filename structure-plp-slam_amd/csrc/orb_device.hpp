@@ -60,7 +60,7 @@ void launch_fast(hipStream_t st, const OrbPlanes& pl, const CellDesc* d_cells, i
                  int ini_thr, int min_thr, const uint8_t* d_mask, size_t mask_step, size_t mask_frame_stride,
                  uint32_t* cell_cand, int32_t* cell_count);
 void launch_blur(hipStream_t st, const OrbPlanes& pl, uint8_t* blur, size_t blur_frame_stride, const LevelDev* d_lv,
-                 int n_levels, int total_tiles, int B, const BlurTaps& taps);
+                 int n_levels, int total_tiles, int B, const BlurTaps& taps, const LevelDev* h_lv = nullptr);
 void launch_orient_rbrief(hipStream_t st, const OrbPlanes& pl, const uint8_t* blur, size_t blur_frame_stride,
                           const LevelDev* d_lv, int n_levels, const int32_t* sel, const int32_t* sel_count,
                           int total_sel_cap, const UMax& um, plp_keypoint* kps, uint8_t* desc, int cap, int32_t* counts,

@@ -406,6 +406,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                  L.w, L.h, (t % tiles_x) * kBlurTW, (t / tiles_x) * kBlurTH, taps.k);
 }
 
+// The same blur with the level table in the KERNEL ARGUMENTS (PLP_BLUR7_TAB=1; profiles/r04_tile_pipelining.md): finding a workgroup's level walks
+// lv[] in global memory -- up to eight dependent scalar loads before the first pixel load can be issued -- and then loads the level's record; here the
+// per-level fields are kernel arguments (one batch of scalar loads at the start) and the level comes from a chain of compares on registers.
+struct BlurLevelTab { int n; int cum[kMaxLevels], w[kMaxLevels], h[kMaxLevels], pitch[kMaxLevels]; unsigned off[kMaxLevels]; };
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_blur7t(OrbPlanes pl, uint8_t* __restrict__ blur_base, size_t blur_frame_stride,
+                                               BlurLevelTab T, BlurTaps taps) {
+    __shared__ BlurTileLds<3> S;
+    unsigned ut, uf;
+    xcd_frame_major(ut, uf);
+    const int tt = (int)ut, frame = (int)uf;
+    int level = 0, cum = 0, w = T.w[0], h = T.h[0], pitch = T.pitch[0];
+    unsigned off = T.off[0];
+#pragma unroll
+    for (int l = 1; l < kMaxLevels; ++l)
+        if (l < T.n && tt >= T.cum[l]) { level = l; cum = T.cum[l]; w = T.w[l]; h = T.h[l]; pitch = T.pitch[l]; off = T.off[l]; }
+    const int t = tt - cum, tiles_x = (w + kBlurTW - 1) / kBlurTW;
+    const uint8_t* src = level == 0 ? pl.l0 + (size_t)frame * pl.l0_frame_stride : pl.pyr + (size_t)frame * pl.pyr_frame_stride + off;
+    blur_tile<3>(S, src, level == 0 ? pl.l0_pitch : pitch, blur_base + (size_t)frame * blur_frame_stride + off, pitch, w, h, (t % tiles_x) * kBlurTW,
+                 (t / tiles_x) * kBlurTH, taps.k);
+}
+
 // The same blur by PERSISTENT workgroups (PLP_BLUR7_PERSIST=1; profiles/r04_tile_pipelining.md): workgroup g of G walks the tiles g, g + G, ... of the
 // XCD-major tile order, prefetching the next tile's pixels into registers while it computes the current one (blur_tile.hpp).
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_blur7p(OrbPlanes pl, uint8_t* __restrict__ blur_base, size_t blur_frame_stride,
@@ -679,7 +700,15 @@ void launch_fast(hipStream_t st, const OrbPlanes& pl, const CellDesc* d_cells, i
 }
 
 void launch_blur(hipStream_t st, const OrbPlanes& pl, uint8_t* blur, size_t blur_frame_stride, const LevelDev* d_lv,
-                 int n_levels, int total_tiles, int B, const BlurTaps& taps) {
+                 int n_levels, int total_tiles, int B, const BlurTaps& taps, const LevelDev* h_lv) {
+    static const int blur_tab = [] { const char* e = getenv("PLP_BLUR7_TAB"); return e ? atoi(e) : 0; }();
+    if (blur_tab && h_lv) {
+        BlurLevelTab T{};
+        T.n = n_levels;
+        for (int l = 0, cum = 0; l < n_levels; ++l) { T.cum[l] = cum; cum += h_lv[l].blur_tiles; T.w[l] = h_lv[l].w; T.h[l] = h_lv[l].h; T.pitch[l] = h_lv[l].pitch; T.off[l] = (unsigned)h_lv[l].off; }
+        hipLaunchKernelGGL(k_blur7t, dim3(total_tiles, B), dim3(256), 0, st, pl, blur, blur_frame_stride, T, taps);
+        return;
+    }
     static const int blur_persist = [] { const char* e = getenv("PLP_BLUR7_PERSIST"); return e ? atoi(e) : 0; }();   // experiment: n = workgroups per CU of the persistent form
     if (blur_persist > 0 && (size_t)total_tiles * B >= 4096) hipLaunchKernelGGL(k_blur7p, dim3(256 * blur_persist), dim3(256), 0, st, pl, blur, blur_frame_stride, d_lv, n_levels, taps, total_tiles, B);
     else hipLaunchKernelGGL(k_blur7, dim3(total_tiles, B), dim3(256), 0, st, pl, blur, blur_frame_stride, d_lv, n_levels, taps);
