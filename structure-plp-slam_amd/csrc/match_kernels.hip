@@ -459,14 +459,21 @@ __global__ __launch_bounds__(256) void k_match_prep(MatchProblem P) {
     auto cnt_inc = [&](int c) -> int { return (int)((atomicAdd(&cnt2[c >> 1], 1u << (16 * (c & 1))) >> (16 * (c & 1))) & 0xffffu); };   // the count before
     for (int i = tid; i < 2048; i += 256) cnt2[i] = 0;
     __syncthreads();
-    auto cell_of = [&](const plp_keypoint& k, int t, int& cx, int& cy) -> bool {
-        cx = floor_d((double)__fsub_rn(k.x, P.grid_min_x) * P.inv_cell_w);
-        cy = floor_d((double)__fsub_rn(k.y, P.grid_min_y) * P.inv_cell_h);
-        return cx >= 0 && cx < P.grid_cols && cy >= 0 && cy < P.grid_rows && !(t_occ && t_occ[t]);
+    // (passes 1 and 2 take four targets per thread and trip and load them together: a trip per target had been a memory round trip per target)
+    auto cell_xy = [&](float x, float y, bool occ, int& cx, int& cy) -> bool {
+        cx = floor_d((double)__fsub_rn(x, P.grid_min_x) * P.inv_cell_w);
+        cy = floor_d((double)__fsub_rn(y, P.grid_min_y) * P.inv_cell_h);
+        return cx >= 0 && cx < P.grid_cols && cy >= 0 && cy < P.grid_rows && !occ;
     };
-    for (int t = tid; t < n; t += 256) {   // pass 1: cell sizes
-        int cx, cy;
-        if (cell_of(kps[t], t, cx, cy)) cnt_inc(cx * P.grid_rows + cy);
+    for (int t0 = tid; t0 < n; t0 += 4 * 256) {   // pass 1: cell sizes
+        float kx[4], ky[4]; bool oc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int t = min(t0 + 256 * u, n - 1); kx[u] = kps[t].x; ky[u] = kps[t].y; oc[u] = t_occ && t_occ[t]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int cx, cy;
+            if (t0 + 256 * u < n && cell_xy(kx[u], ky[u], oc[u], cx, cy)) cnt_inc(cx * P.grid_rows + cy);
+        }
     }
     __syncthreads();
     {   // exclusive scan over the cells: 16 cells per thread, a shuffle scan inside the wave, four wave totals through LDS
@@ -488,26 +495,43 @@ __global__ __launch_bounds__(256) void k_match_prep(MatchProblem P) {
         for (int i = tid; i < 2048; i += 256) cnt2[i] = 0;
         __syncthreads();
     }
-    for (int t = tid; t < n; t += 256) {   // pass 2: unordered placement inside the cell
-        int cx, cy;
-        if (!cell_of(kps[t], t, cx, cy)) continue;
-        const int cell = cx * P.grid_rows + cy;
-        tmp_t[start[cell] + cnt_inc(cell)] = (uint16_t)t;
+    for (int t0 = tid; t0 < n; t0 += 4 * 256) {   // pass 2: unordered placement inside the cell
+        float kx[4], ky[4]; bool oc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int t = min(t0 + 256 * u, n - 1); kx[u] = kps[t].x; ky[u] = kps[t].y; oc[u] = t_occ && t_occ[t]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = t0 + 256 * u;
+            int cx, cy;
+            if (t >= n || !cell_xy(kx[u], ky[u], oc[u], cx, cy)) continue;
+            const int cell = cx * P.grid_rows + cy;
+            tmp_t[start[cell] + cnt_inc(cell)] = (uint16_t)t;
+        }
     }
     __syncthreads();
     const int used = start[4096];
-    for (int p = tid; p < used; p += 256) {   // pass 3: rank inside the cell by index, final record
-        const int t = tmp_t[p];
-        const plp_keypoint k = kps[t];
-        int cx, cy;
-        cell_of(k, t, cx, cy);
-        const int cell = cx * P.grid_rows + cy, s0 = start[cell], s1 = start[cell + 1];
-        int rank = 0;
-        for (int j = s0; j < s1; ++j) rank += (int)tmp_t[j] < t;
-        StagedTarget r;
-        r.x = k.x; r.y = k.y; r.packed = ((uint32_t)k.octave & 0xffu) | ((uint32_t)cx << 8) | ((uint32_t)cy << 16); r.t = (uint32_t)t;
-        st[s0 + rank] = r;
-        if (t_xr) sxr[s0 + rank] = t_xr[t];
+    for (int p0 = tid; p0 < used; p0 += 4 * 256) {   // pass 3: rank inside the cell by index, final record (four targets per trip, their gathers together)
+        int tt[4]; float kx[4], ky[4], xr[4] = {0.f, 0.f, 0.f, 0.f}; int ko[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            tt[u] = tmp_t[min(p0 + 256 * u, used - 1)];
+            kx[u] = kps[tt[u]].x; ky[u] = kps[tt[u]].y; ko[u] = kps[tt[u]].octave;
+            if (t_xr) xr[u] = t_xr[tt[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (p0 + 256 * u >= used) continue;
+            const int t = tt[u];
+            int cx, cy;
+            cell_xy(kx[u], ky[u], false, cx, cy);
+            const int cell = cx * P.grid_rows + cy, s0 = start[cell], s1 = start[cell + 1];
+            int rank = 0;
+            for (int j = s0; j < s1; ++j) rank += (int)tmp_t[j] < t;
+            StagedTarget r;
+            r.x = kx[u]; r.y = ky[u]; r.packed = ((uint32_t)ko[u] & 0xffu) | ((uint32_t)cx << 8) | ((uint32_t)cy << 16); r.t = (uint32_t)t;
+            st[s0 + rank] = r;
+            if (t_xr) sxr[s0 + rank] = xr[u];
+        }
     }
     for (int i = tid; i <= ncell; i += 256) P.cell_start[(size_t)b * kCellStride + i] = start[min(i, 4096)];
 }
@@ -573,12 +597,20 @@ __global__ PLP_TOPK_CELLS_BOUNDS void k_match_topk_cells(MatchProblem P, int qpb
     {
         const uint16_t* gcs = P.cell_start + (size_t)b * kCellStride;
         const int used = min((int)gcs[ncell], nb);
-        for (int i = tid; i < used; i += 256) {
-            const uint4 r = g_sorted[i];
-            sxy[i] = make_float2(__uint_as_float(r.x), __uint_as_float(r.y));
-            sto[i] = (r.w & 0xffffu) | ((r.z & 0xffu) << 16);
+        for (int i0 = tid; i0 < used; i0 += 4 * 256) {   // four records per thread and trip, loaded together: one memory round trip per 1024 targets, not four
+            uint4 r[4]; float xr[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i = min(i0 + 256 * u, used - 1); r[u] = g_sorted[i]; if (has_xr) xr[u] = g_sorted_xr[i]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + 256 * u;
+                if (i < used) {
+                    sxy[i] = make_float2(__uint_as_float(r[u].x), __uint_as_float(r[u].y));
+                    sto[i] = (r[u].w & 0xffffu) | ((r[u].z & 0xffu) << 16);
+                    if (has_xr) sxr[i] = xr[u];
+                }
+            }
         }
-        if (has_xr) for (int i = tid; i < used; i += 256) sxr[i] = g_sorted_xr[i];
         const uint32_t* g32 = reinterpret_cast<const uint32_t*>(gcs);
         for (int i = tid; i < (ncell + 2) / 2; i += 256) reinterpret_cast<uint32_t*>(cs)[i] = g32[i];
     }

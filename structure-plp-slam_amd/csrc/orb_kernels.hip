@@ -53,15 +53,22 @@ __global__ __launch_bounds__(256) void k_resize_linear(const uint8_t* __restrict
     if (staged) {
         const bool wide = (((uintptr_t)src | (uintptr_t)src_pitch) & 15) == 0;
         const int c = lane & 7, r0 = lane >> 3;      // <= 6 chunks of 16 bytes per row, 8 rows per trip
-        if (c < nchunks)
-            for (int r = r0; r < nrows; r += 8) {
-                const int x = xs + 16 * c;
-                const uint8_t* g = src + (size_t)(ys + r) * src_pitch + x;
-                uint8_t* t = tile + r * kRsPitch + 16 * c;
-                if (wide && x + 16 <= src_pitch) *reinterpret_cast<uint4*>(t) = *reinterpret_cast<const uint4*>(g);
-                else
+        if (c < nchunks) {
+            const int x = xs + 16 * c;
+            if (wide && x + 16 <= src_pitch) {       // all of a lane's (up to six) loads are issued before the first is stored: one memory round trip, not six
+                constexpr int NT = (kRsRows + 7) / 8;
+                uint4 v[NT];
+#pragma unroll
+                for (int q = 0; q < NT; ++q) v[q] = *reinterpret_cast<const uint4*>(src + (size_t)(ys + min(r0 + 8 * q, nrows - 1)) * src_pitch + x);   // (clamped row: no branch between the loads)
+#pragma unroll
+                for (int q = 0; q < NT; ++q) { const int r = r0 + 8 * q; if (r < nrows) *reinterpret_cast<uint4*>(tile + r * kRsPitch + 16 * c) = v[q]; }
+            } else
+                for (int r = r0; r < nrows; r += 8) {
+                    const uint8_t* g = src + (size_t)(ys + r) * src_pitch + x;
+                    uint8_t* t = tile + r * kRsPitch + 16 * c;
                     for (int k = 0; k < 16; ++k) t[k] = x + k < sw ? g[k] : (uint8_t)0;
-            }
+                }
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();   // the strip belongs to this wave alone: its own LDS writes are all it waits for
     }
@@ -83,11 +90,20 @@ __global__ __launch_bounds__(256) void k_resize_linear(const uint8_t* __restrict
 #pragma unroll
             for (int i = 0; i < 4; ++i) h[i] = S[x0[i]] * wa0[i] + S[x1[i]] * wa1[i];
         };
+        // the rows' table entries are loaded together, packed two to a register (they were four loads and a wait per row)
+        uint32_t tyy[ROWS], tbb[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int dy = min(dy0 + r, dh - 1);
+            tyy[r] = (uint32_t)(uint16_t)yofs0[dy] | ((uint32_t)(uint16_t)yofs1[dy] << 16);
+            tbb[r] = (uint32_t)(uint16_t)b0[dy] | ((uint32_t)(uint16_t)b1[dy] << 16);
+        }
+#pragma unroll
         for (int r = 0; r < ROWS; ++r) {
             const int dy = dy0 + r;
             if (dy >= dh) break;
-            const int y0 = yofs0[dy], y1 = yofs1[dy];   // one value per 16 lanes
-            const int wb0 = b0[dy], wb1 = b1[dy];
+            const int y0 = (int)(tyy[r] & 0xffffu), y1 = (int)(tyy[r] >> 16);   // one value per 16 lanes
+            const int wb0 = (int)(int16_t)(tbb[r] & 0xffffu), wb1 = (int)(int16_t)(tbb[r] >> 16);
             int h0[4], h1[4];
             if (y0 == cached_row) {
 #pragma unroll
@@ -191,6 +207,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         const int sh = a0 & 3;
         const int ndw = (w + 2 + 3) >> 2;            // tile columns 0 .. w + 1
         const uint8_t* row0 = img + (size_t)cd.min_y * pitch + (a0 - sh);
+        // (the loop stays a load -> LDS store per trip: issuing a thread's five dword pairs together was measured and is SLOWER here, 2.31 -> 2.40 ms --
+        //  the kernel sits at its register limit and the staging is a small part of it; profiles/r04_tile_pipelining.md)
         for (int i = tid; i < ndw * h; i += 256) {
             const int r = i / ndw, c = i - r * ndw;
             const uint32_t* g = reinterpret_cast<const uint32_t*>(row0 + (size_t)r * pitch + 4 * c);
