@@ -311,6 +311,7 @@ def main():
             d2h_bytes.append(nbytes + h_off[buf].numel() * 8 + sum(t.numel() * t.element_size() for t in h_small[buf]))
 
         pending = []
+        pack_done = [None]
 
         # The next step's upload is enqueued before the host waits for this step's offsets (PLP_BENCH_PREFETCH=0: at the start of its own step).
         # This pass drives seven streams: on the runtime's default of four hardware queues an 11 ms copy queued early sits in front of another
@@ -343,6 +344,9 @@ def main():
                 for s_ in sBs:
                     s_.wait_event(down_done[buf])
             d_frames = stage[sb]
+            if pack_done[0] is not None:
+                ts.sC.wait_event(pack_done[0])                              # m1..m4 / n1..n4 are ONE set of buffers: this step's matchers must not overwrite them
+                                                                             # before the previous step's pack kernels and count copies have read them
             step()
             d_frames = frames_default
             sD.wait_event(ts.done_match[buf])
@@ -355,6 +359,7 @@ def main():
                 for h, t in zip(h_small[buf], small(buf)):
                     h.copy_(t, non_blocking=True)
                 ev_off[buf] = torch.cuda.Event(); ev_off[buf].record(sD)
+                pack_done[0] = ev_off[buf]
             stage_free[sb] = list(ts.extract_events)
             if prefetch and not last:
                 upload(n + 1)                                                # before the host blocks below: the next step's frames travel while this step computes
@@ -402,6 +407,9 @@ def main():
         assert np.array_equal(h_pk[lb][0][:int(o[1]) * 28].numpy().reshape(-1, 28), k_first), "packed key points differ from the padded array"
         d_last = desc2[lb][HALO + B - 1].cpu().numpy()[:int(o[B] - o[B - 1])]
         assert np.array_equal(h_pk[lb][1][int(o[B - 1]) * 32:int(o[B]) * 32].numpy().reshape(-1, 32), d_last), "packed descriptors differ from the padded array"
+        # ... and one match array (the buffers every step shares: the pass's last step wrote m1, nothing has overwritten it since)
+        m_first = m1[0].cpu().numpy()[:int(o[1])]
+        assert np.array_equal(h_pk[lb][2][:int(o[1]) * 4].numpy().view(np.int32), m_first), "packed matches differ from the padded array"
         del h_frames, stage, h_pk, d_pk
         # single-frame latency, 256 calls each, the host-pointer entry points on one frame at a time
         lat = {}

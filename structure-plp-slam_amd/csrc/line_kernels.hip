@@ -346,6 +346,11 @@ struct Rect { double x1, y1, x2, y2, width; };
 __device__ __forceinline__ bool is_used(const GrowCtx& g, int p) { return (g.used[p >> 5] >> (p & 31)) & 1u; }
 __device__ __forceinline__ void set_used(const GrowCtx& g, int p) { atomicOr(&g.used[p >> 5], 1u << (p & 31)); }   // fire-and-forget ds_or
 __device__ __forceinline__ int tent_owner(const GrowCtx& g, int p) { return (int)((g.tent[p >> 3] >> ((unsigned)(p & 7) * 4u)) & 15u); }
+// The three updates below change a nibble with a check or an atomicAnd followed by a separate atomicOr: two waves claiming one pixel at the same moment can
+// leave the OR of their ids (a phantom owner: another helper, a finished region, main) or wipe the other's claim.  That is tolerated, not overlooked: a claim
+// is ADVISORY (policy) -- the main wave validates every speculative region against the committed map C, and every index derived from an
+// owner id stays in range for all 16 values -- so a wrong nibble can only cause a spurious give-up or a wasted attempt.  tests/test_spec_grow_model.py
+// (test_protocol_is_exact_whatever_the_claim_nibbles_say) scrambles the model's claims at random and requires the sequential result all the same.
 __device__ __forceinline__ void tent_release(const GrowCtx& g, int p, int id) {   // give the pixel back if it still carries `id`
     const unsigned sh = (unsigned)(p & 7) * 4u;
     if (((g.tent[p >> 3] >> sh) & 15u) == (unsigned)id) atomicAnd(&g.tent[p >> 3], ~(15u << sh));

@@ -100,7 +100,7 @@ def sequential(img, order):
     return out, used
 
 
-def concurrent(img, order, n_helpers, rng, policy=0):
+def concurrent(img, order, n_helpers, rng, policy=0, claim_noise=0.0):
     C, T = set(), {}                     # T: pixel -> helper that marked it last (the tentative-owner nibbles of the device)
     cur_pos = [0] * n_helpers            # seed position of each helper's latest attempt
     n_groups = (len(order) + GROUP - 1) // GROUP
@@ -112,6 +112,17 @@ def concurrent(img, order, n_helpers, rng, policy=0):
 
     def tick():
         yield
+
+    def scramble(q):
+        # The device updates a 4-bit claim with an atomicAnd followed by an atomicOr (line_kernels.hip set_used_t / tent_retag / tent_release): two waves
+        # claiming one pixel at once can leave the OR of their ids -- a PHANTOM owner (another helper, a finished region, main) -- or wipe the other's
+        # claim.  Claims are advisory: whatever they say, main validates every speculative region against the committed map.  claim_noise makes the
+        # model do the same damage at random: the result must not change.
+        if claim_noise and rng.random() < claim_noise:
+            if rng.random() < 0.3:
+                T.pop(q, None)
+            else:
+                T[q] = (rng.choice(["main"] + list(range(n_helpers))), rng.choice(["growing", "pending"]))
 
     def helper(hid):
         pending = []        # groups whose T marks this helper still has to clear (after main is through with them)
@@ -150,6 +161,7 @@ def concurrent(img, order, n_helpers, rng, policy=0):
 
                 def mark(q, own=own, marked=marked):
                     own.add(q); T[q] = (hid, "growing"); marked.append(q)       # a later seed's claim is simply overwritten
+                    scramble(q)
 
                 def unmark(q, own=own):
                     own.discard(q)
@@ -210,6 +222,7 @@ def concurrent(img, order, n_helpers, rng, policy=0):
 
                     def m_mark(q, own=own):
                         own.add(q); T[q] = ("main", "growing")      # the helpers see what main is growing; main itself ignores every claim
+                        scramble(q)
 
                     def m_unmark(q, own=own):
                         own.discard(q)
@@ -267,3 +280,16 @@ def test_speculative_protocol_equals_the_sequential_scan(seed):
             assert got == want, (seed, n_helpers, policy)
             assert used == want_used
     assert st["used_spec"] > 0          # the helpers did contribute
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_protocol_is_exact_whatever_the_claim_nibbles_say(seed):
+    """the claim map is written with two non-atomic steps on the device: phantom owners and lost claims may only waste speculation"""
+    img, order = toy_image(seed)
+    want, want_used = sequential(img, order)
+    for n_helpers in (3, 7):
+        for policy in (0, 1):
+            for noise in (0.05, 0.5):
+                rng = random.Random(77 * seed + 10 * n_helpers + policy)
+                got, used, st = concurrent(img, order, n_helpers, rng, policy, claim_noise=noise)
+                assert got == want and used == want_used, (seed, n_helpers, policy, noise)
