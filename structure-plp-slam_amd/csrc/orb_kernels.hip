@@ -30,7 +30,7 @@ namespace plp {
 // ------------------------------------------------------------------------------------------
 constexpr int kRsRows = 44, kRsPitch = 96;   // staged source rectangle of one strip (scale factors >= 1.1 fit; larger ones fall back to global reads)
 
-__global__ __launch_bounds__(256) void k_resize_linear(const uint8_t* __restrict__ src_base, size_t src_frame_stride,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_resize_linear(const uint8_t* __restrict__ src_base, size_t src_frame_stride,
                                                        int src_pitch, int sw, uint8_t* __restrict__ dst_base,
                                                        size_t dst_frame_stride, int dst_pitch, int dw, int dh,
                                                        const int16_t* __restrict__ xofs0, const int16_t* __restrict__ xofs1,
