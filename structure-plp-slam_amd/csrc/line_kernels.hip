@@ -1575,6 +1575,10 @@ __constant__ int c_comb[32][2] = {{0, 1}, {0, 2}, {0, 3}, {0, 4}, {0, 5}, {0, 6}
 
 // grid = (2, B), block = 256: one wave per line, 8 lines of a frame in flight (more waves thrash L1/L2: every wave
 // keeps 63 image rows live).
+#ifndef PLP_LBD_U
+#define PLP_LBD_U 8
+#endif
+constexpr int kLbdU = PLP_LBD_U;   // band steps whose gathers are in flight together (per lane = band row)
 __global__ __launch_bounds__(256) void k_lbd(LinePlanes P, LbdWeightsDev W) {
     __shared__ float s_row[4][63][8];   // per row: pgdL, ngdL, pgdL2, ngdL2, pgdO, ngdO, pgdO2, ngdO2 (after the global weight)
     __shared__ float s_des[4][72], s_des2[4][72], s_norm[4][4];
@@ -1601,10 +1605,10 @@ __global__ __launch_bounds__(256) void k_lbd(LinePlanes P, LbdWeightsDev W) {
         float pgdL = 0, ngdL = 0, pgdO = 0, ngdO = 0;
         // the gathers do not depend on the running sums: addresses of 8 steps first, 16 loads in flight, then the
         // strictly ordered accumulation
-        for (int w0 = 0; w0 < lengthOfLSP; w0 += 8) {
-            int off[8];
+        for (int w0 = 0; w0 < lengthOfLSP; w0 += kLbdU) {
+            int off[kLbdU];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < kLbdU; ++u) {
                 short t = (short)roundf(sCorX);
                 const short xCor = (t < 0) ? 0 : (t > imageWidth) ? imageWidth : t;
                 t = (short)roundf(sCorY);
@@ -1613,11 +1617,11 @@ __global__ __launch_bounds__(256) void k_lbd(LinePlanes P, LbdWeightsDev W) {
                 sCorX = __fadd_rn(sCorX, dL0);
                 sCorY = __fadd_rn(sCorY, dL1);
             }
-            short2 vxy[8];
+            short2 vxy[kLbdU];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) vxy[u] = dxyImg[off[u]];
+            for (int u = 0; u < kLbdU; ++u) vxy[u] = dxyImg[off[u]];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < kLbdU; ++u) {
                 if (w0 + u < lengthOfLSP) {
                     const float fx = (float)vxy[u].x, fy = (float)vxy[u].y;
                     const float gDL = __fadd_rn(__fmul_rn(fx, dL0), __fmul_rn(fy, dL1));

@@ -25,6 +25,9 @@ public:
         // the camera only parameterised the identity remap of line_extractor.cc:40-86,103 (elided)
         const char* e = std::getenv("PLP_DEVICE");
         check(plp_line_create(e ? std::atoi(e) : 0, &ctx_));
+        // the library's default is the reference's seed order (std::sort as libstdc++ runs it); PLP_SEED_ORDER=stable selects the cheaper one
+        const char* so = std::getenv("PLP_SEED_ORDER");
+        if (so && std::string(so) == "stable") check(plp_line_set_seed_order(ctx_, PLP_SEED_ORDER_STABLE));
         _scale_factors.assign(1, 1.0f); _inv_scale_factors.assign(1, 1.0f);
         _level_sigma_sq.assign(1, 1.0f); _inv_level_sigma_sq.assign(1, 1.0f);
     }

@@ -1,4 +1,7 @@
-"""What definition D1 costs the caller.  OpenCV's LSD orders its seeds with std::sort on the gradient bin alone -- an
+"""What the choice of LSD's seed order costs the caller (DESIGN.md section 5, D1 -- closed in round 4: the library's default is now the std::sort
+order measured here as "unstable", replayed on the device; the stable order is the opt-in PLP_SEED_ORDER_STABLE mode; tests/test_gpu_seed_sort.py
+requires 0 differing key lines between the library's default mode and std::sort on exactly these frames).  Original text:
+What definition D1 costs the caller.  OpenCV's LSD orders its seeds with std::sort on the gradient bin alone -- an
 UNSTABLE sort, so the order inside a bin is whatever the C++ library's algorithm leaves (reached via LSDDetector_custom.cpp:244-257).  The
 repository defines the order inside a bin as row-major (oracle and HIP path agree on it); `stable_order=False` makes the oracle call
 std::sort as the reference does, i.e. reproduces a reference built with THIS libstdc++.  This test measures, on the fixture frames and the

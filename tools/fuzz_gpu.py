@@ -169,8 +169,10 @@ def main():
         h, w = int(rng.integers(200, 600)), int(rng.integers(240, 900))
         img = rand_image(rng, h, w)
         lt.set_grow_waves((0, 1, 3, 5)[n % 4])          # several waves per frame (automatic / 3 / 5) and one wave per frame: same results
+        stable = n % 5 == 4                            # the reference's seed order (std::sort, the default) four times in five, the stable order once
+        lt.set_seed_order(plp.SEED_ORDER_STABLE if stable else plp.SEED_ORDER_LIBSTDCXX)
         kl, lbd, fn = lt.extract_LSD_LBD(img)
-        o = O.LineOracle(img)
+        o = O.LineOracle(img, stable_order=stable)
         ok = len(kl) == len(o.keylsd) and np.array_equal(lbd, o.lbd) and np.array_equal(kl, o.keylsd) and np.array_equal(fn, o.linefn)
         if not ok:
             bad += 1; print("LINE MISMATCH", h, w, len(kl), len(o.keylsd))
