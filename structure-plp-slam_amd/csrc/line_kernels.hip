@@ -480,8 +480,21 @@ __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed
                 }
                 __builtin_amdgcn_wave_barrier();
             }
-        } else if (cand) cand = !is_used(g, np);
+        }
+#ifdef PLP_GROW_GATHER_FIRST
+        // experiment (profiles/r04_lsd_grow.md): the record gather is issued for every in-image neighbour BEFORE the USED test, whose LDS round trip then
+        // runs beside it instead of in front of it; records of used / undefined pixels are fetched for nothing (undefined ones hold no record: discarded)
+        else {
+            LsdPix px{};
+            if (cand) px = g.pix[np];
+            if (cand) cand = !is_used(g, np);
+            if (cand) { deg = px.deg; ncs = px.cs; }
+        }
+        if (MW && cand) { const LsdPix px = g.pix[np]; deg = px.deg; ncs = px.cs; }
+#else
+        else if (cand) cand = !is_used(g, np);
         if (cand) { const LsdPix px = g.pix[np]; deg = px.deg; ncs = px.cs; }   // 16 bytes per live neighbour
+#endif
         // ---- acceptances in order.  Accepted lanes are strictly increasing, so the set of accepted lanes (a bit mask)
         // already is the order: the list append and the USED bits are written by the accepted lanes themselves after
         // the loop, in parallel (the loop used to hand every acceptance to lane 0: two more broadcasts and a
