@@ -83,6 +83,16 @@ class tracker_step:
         self.sA.wait_stream(self.cur)
         for s in self.sBs:
             s.wait_stream(self.cur)
+        # The line streams only meet the rest of the step at the matchers (which wait for them) and at the reuse of a feature set NBUF steps later:
+        # a stream that starts late STAYS late.  PLP_BENCH_LINE_PHASE_MS delays line stream i by i x that many ms once, before the first step, so
+        # that one sub-block's front (blur, gradient, seed sort: throughput kernels) runs beside the other's region growing (latency-bound) instead
+        # of beside its front (profiles/r04_line_phase.md).
+        shift_ms = float(os.environ.get("PLP_BENCH_LINE_PHASE_MS", "0"))
+        if shift_ms > 0 and not serial:
+            for i, s in enumerate(self.sBs):
+                if i:
+                    with torch.cuda.stream(s):
+                        torch.cuda._sleep(int(i * shift_ms * 1e-3 * 2.1e9))
 
     def match_stage(self, buf=0, st=None, before_lines=None):
         """the tracker's four matcher calls for every frame of the step held in feature set `buf`, on stream st"""
