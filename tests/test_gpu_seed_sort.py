@@ -20,7 +20,7 @@ def _want(e, depth):
 
 
 @pytest.mark.parametrize("variant", [0, 1])
-@pytest.mark.parametrize("n", [17, 33, 64, 65, 66, 129, 1000, 4095, 4096, 4097, 4098, 9000, 24575, 24576, 24577, 24578, 30000, 76241, 115753, 229401])
+@pytest.mark.parametrize("n", [17, 18, 33, 48, 49, 64, 65, 66, 127, 128, 129, 130, 256, 257, 512, 513, 1000, 4095, 4096, 4097, 4098, 9000, 24575, 24576, 24577, 24578, 30000, 76241, 115753, 229401])
 def test_kernel_introsort_loop_equals_libstdcxx_at_the_size_thresholds(n, variant):
     """every boundary between the kernel's regimes (lane / wave / workgroup in LDS / workgroup in global memory), on eight key distributions, in both
     configurations the library launches (variant 0: 4 waves and a 4096-entry window, large batches; 1: 16 waves and 24576 entries, small ones)"""
