@@ -126,7 +126,8 @@ def main():
     ts = rs.tracker_step(plp, B, K, args.rows, args.cols, device_index=local_rank, orb_only=args.orb_only,
                          n_line=int(os.environ.get("PLP_BENCH_LINE_SPLIT", "2")), nbuf=int(os.environ.get("PLP_BENCH_NBUF", "2")), serial=serial,
                          shift=(SHIFT_X, 0.0), parts=os.environ.get("PLP_BENCH_PARTS", "orb,lines,match"),   # PLP_BENCH_PARTS: diagnostic, time a subset of the step
-                         seed_order=plp.SEED_ORDER_STABLE if args.seed_order == "stable" else plp.SEED_ORDER_LIBSTDCXX)
+                         seed_order=plp.SEED_ORDER_STABLE if args.seed_order == "stable" else plp.SEED_ORDER_LIBSTDCXX,
+                         line_depth=int(os.environ.get("PLP_BENCH_LINE_DEPTH", "1")))
     cap, lcap, NBUF = ts.cap, ts.lcap, ts.NBUF
     kps2, desc2, cnt2, kl2, lbd2, fn2, lcnt2 = ts.kps2, ts.desc2, ts.cnt2, ts.kl2, ts.lbd2, ts.fn2, ts.lcnt2
     d_kps, d_desc, d_cnt = kps2[0][HALO:], desc2[0][HALO:], cnt2[0][HALO:]
@@ -156,6 +157,12 @@ def main():
         last_buf = step()
     barrier()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("PLP_BENCH_SS_CHECK"):     # diagnostic builds (-DPLP_SS_CHECK) only: partner positions the seed sort found outside their segment
+        import ctypes
+        chk = (ctypes.c_uint32 * 136)()
+        torch.cuda.synchronize(dev)
+        if getattr(plp.lib(), "plp_debug_seed_sort_check")(chk, 136) == 0:
+            print("seed sort check:", chk[0], [[hex(v) for v in chk[8 + 8 * k: 16 + 8 * k]] for k in range(min(chk[0], 16))], file=sys.stderr)
     ts.last_batch_status()
     # ---- parity of the timed step itself: N frames of the LAST timed step (features + the four matcher results) against the CPU oracle.
     # After the timed region; the oracle is the checker here, never part of what is measured (tests/bench_step_check.py).

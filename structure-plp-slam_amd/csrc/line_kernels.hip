@@ -800,6 +800,9 @@ __device__ void centroid_sums(const GrowCtx& g, int nreg, double cen[3]) {
 #endif
 __global__ __launch_bounds__(256, PLP_GROW_MIN_WAVES) void k_lsd_grow(LinePlanes P, LsdParams lp, int B, int wpb, int ring) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_bits[];
+#ifdef PLP_GROW_PRIO
+    __builtin_amdgcn_s_setprio(PLP_GROW_PRIO);
+#endif
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int b = blockIdx.x * wpb + wv;
     if (b >= B) return;

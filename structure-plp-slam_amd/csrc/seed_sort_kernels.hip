@@ -23,13 +23,23 @@
 
 namespace plp {
 
+#ifdef PLP_SS_CHECK
+__device__ unsigned int g_ss_check[8 + 8 * 16];   // diagnostic build only: [0] = partner positions found outside their segment, then 16 records
+#endif
+
 // Two configurations of one body (seed_sort_impl.inc).  Batches: 4 waves per workgroup and a 4096-entry window (35 KB of LDS) -- alone that is the
 // slower kernel (6.0 against 5.0 ms per 2048 frames) but four such workgroups share a CU with each other and with the other streams' kernels, and
 // the STEP is what counts: 27.6 ms against 32.7 ms with 16 waves and 144 KB (profiles/r04_seed_sort.md).  Small batches (the single-frame call of
 // data/frame.cc:1146-1163): 16 waves and a 24576-entry window, the shortest time per frame.
 #define SS_NS ss_thr
-#define SS_WAVES 4
-#define SS_T 4096
+#ifndef PLP_SS_THR_WAVES
+#define PLP_SS_THR_WAVES 4
+#endif
+#ifndef PLP_SS_THR_T
+#define PLP_SS_THR_T 4096
+#endif
+#define SS_WAVES PLP_SS_THR_WAVES
+#define SS_T PLP_SS_THR_T
 #ifndef PLP_SS_THR_MINW
 #define PLP_SS_THR_MINW 4   /* at most 128 VGPRs: four workgroups of four waves per CU (5.06 against 6.06 ms alone, 27.1 against 27.7 ms in the step) */
 #endif
@@ -160,3 +170,12 @@ void launch_seed_sort_debug(hipStream_t st, uint32_t* ent, int n, int depth, uin
 }
 
 }  // namespace plp
+
+#ifdef PLP_SS_CHECK
+extern "C" int plp_debug_seed_sort_check(unsigned int* out, int n) {
+    unsigned int h[8 + 8 * 16];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(plp::g_ss_check), sizeof(h)) != hipSuccess) return -1;
+    for (int i = 0; i < n && i < (int)(sizeof(h) / sizeof(h[0])); ++i) out[i] = h[i];
+    return 0;
+}
+#endif

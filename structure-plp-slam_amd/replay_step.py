@@ -27,7 +27,8 @@ LCAP = 512  # key lines kept per frame (a 640x480 frame yields ~50 after the >= 
 
 
 class tracker_step:
-    def __init__(self, plp, B, K, rows, cols, device_index=0, orb_only=False, n_line=2, nbuf=2, serial=False, shift=(-3.0, 0.0), parts="orb,lines,match", line_grow_waves=0, seed_order=None):
+    def __init__(self, plp, B, K, rows, cols, device_index=0, orb_only=False, n_line=2, nbuf=2, serial=False, shift=(-3.0, 0.0), parts="orb,lines,match", line_grow_waves=0, seed_order=None,
+                 line_depth=1):
         import torch
         self.torch = torch
         self.plp, self.B, self.K, self.rows, self.cols = plp, B, K, rows, cols
@@ -36,7 +37,10 @@ class tracker_step:
         self.orb_only, self.shift, self.parts = orb_only, shift, parts
         self.cap, self.lcap = 2 * K + 64, LCAP
         cap, lcap = self.cap, self.lcap
-        self.NBUF = NBUF = max(2, nbuf)
+        # line_depth d > 1 (experiment): d sets of line contexts and streams, step n uses set n % d -- the line chains (seed sort -> region growing ->
+        # LBD: one long dependent chain per sub-block) of d consecutive steps are in flight together.  Needs a feature set more than steps in flight.
+        self.line_depth = line_depth = max(1, line_depth)
+        self.NBUF = NBUF = max(2, nbuf, line_depth + 1 if line_depth > 1 else 2)
         full = lambda shape, dt, zero=False: (torch.zeros if zero else torch.empty)((HALO + B,) + shape, dtype=dt, device=dev)
         # NBUF sets of outputs: the matchers of step n read set n % NBUF while the extractors of the next steps fill the others
         self.kps2 = [full((cap, 28), torch.uint8) for _ in range(NBUF)]
@@ -55,7 +59,7 @@ class tracker_step:
         while B % n_line:
             n_line -= 1
         self.n_line = n_line
-        self.lts = [] if orb_only else [plp.LineFeatureTracker(device=device_index) for _ in range(n_line)]
+        self.lts = [] if orb_only else [plp.LineFeatureTracker(device=device_index) for _ in range(n_line * line_depth)]
         for lt in self.lts:
             lt.set_grow_waves(line_grow_waves)      # 0 = automatic (several waves per frame only for batches of at most 256 frames)
             if seed_order is not None:
@@ -73,7 +77,7 @@ class tracker_step:
         # however few frames it gets): line_prio < 0 gives them the higher stream priority, so their kernels are dispatched first.
         line_prio = int(os.environ.get("PLP_BENCH_LINE_PRIO", "0"))
         self.sA = torch.cuda.Stream(dev)
-        self.sBs = [self.sA if serial else torch.cuda.Stream(dev, priority=line_prio) for _ in range(n_line)]
+        self.sBs = [self.sA if serial else torch.cuda.Stream(dev, priority=line_prio) for _ in range(n_line * line_depth)]
         self.sC = self.sA if serial else torch.cuda.Stream(dev)
         self.pq = self.replay.point_queries(plp, B, cap, dev)
         self.lq = None if orb_only else self.replay.line_queries(plp, B, lcap, dev, landmarks=True)
@@ -140,7 +144,8 @@ class tracker_step:
         line_ready = []
         if not self.orb_only:
             bs = B // self.n_line
-            for i, (lti, sbi) in enumerate(zip(self.lts, self.sBs)):
+            g0 = (n % self.line_depth) * self.n_line
+            for i, (lti, sbi) in enumerate(zip(self.lts[g0:g0 + self.n_line], self.sBs[g0:g0 + self.n_line])):
                 sl = slice(i * bs, (i + 1) * bs)
                 if done is not None:
                     sbi.wait_event(done)     # the line matchers of step n - NBUF have read this set
