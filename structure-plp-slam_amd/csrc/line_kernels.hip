@@ -669,15 +669,19 @@ __device__ void region2rect(const GrowCtx& g, int nreg, double reg_angle, double
 // coordinates come from LDS, every lane keeps its (up to four) points and their weights in registers, so the centroid
 // sums, the inertia sums and the extents need ONE round of gathers instead of three passes over the HBM copy of the
 // list.  Same additions in the same order as centroid_sums() + region2rect().
+#ifndef PLP_RING_PTS
+#define PLP_RING_PTS 4
+#endif
+constexpr int kRingPts = PLP_RING_PTS;   // points per lane the fit from the ring keeps in registers: regions up to 64 * kRingPts points take it
 __device__ void rect_from_ring(const GrowCtx& g, int nreg, double reg_angle, double prec, Rect& rec) {
     const int lane = g.lane;
     // per lane up to four points, kept small across the two sequential passes (this function is the kernel's register peak, and what
     // two of these waves leave of a SIMD's registers decides how many waves of the neighbouring kernels fit): coordinates stay packed as
     // in the list
-    uint32_t pc[4];
-    double w[4];
+    uint32_t pc[kRingPts];
+    double w[kRingPts];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < kRingPts; ++u) {
         const int j = lane + 64 * u;
         pc[u] = 0; w[u] = 0;
         if (64 * u >= nreg) continue;   // uniform: most fitted regions have fewer than 64 points
@@ -703,7 +707,7 @@ __device__ void rect_from_ring(const GrowCtx& g, int nreg, double reg_angle, dou
             if ((lane >> 5) == (c & 1) && lane + 64 * u < nreg) {
                 double* o = sc + 3 * (lane & 31);
 #pragma unroll
-                for (int uu = 0; uu < 4; ++uu)
+                for (int uu = 0; uu < kRingPts; ++uu)
                     if (uu == u) { o[0] = addend(uu, 0); o[1] = addend(uu, 1); o[2] = addend(uu, 2); }
             }
             __builtin_amdgcn_wave_barrier();
@@ -754,7 +758,7 @@ __device__ void rect_from_ring(const GrowCtx& g, int nreg, double reg_angle, dou
     sincos(theta, &dy, &dx);
     double l_min = 0, l_max = 0, w_min = 0, w_max = 0;
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < kRingPts; ++u)
         if (lane + 64 * u < nreg) {
             const double rdx = (double)PX(u) - x, rdy = (double)PY(u) - y;
             const double l = rdx * dx + rdy * dy, ww = -rdx * dy + rdy * dx;
@@ -798,7 +802,12 @@ __device__ void centroid_sums(const GrowCtx& g, int nreg, double cen[3]) {
 #ifndef PLP_GROW_MIN_WAVES      // experiment knob: waves per SIMD the register allocation must allow (4 = at most 128 VGPRs)
 #define PLP_GROW_MIN_WAVES 1
 #endif
-__global__ __launch_bounds__(256, PLP_GROW_MIN_WAVES) void k_lsd_grow(LinePlanes P, LsdParams lp, int B, int wpb, int ring) {
+#ifdef PLP_GROW_NUM_VGPR      // experiment knob: an exact register budget (between the occupancy steps of __launch_bounds__)
+#define PLP_GROW_VGPR_ATTR __attribute__((amdgpu_num_vgpr(PLP_GROW_NUM_VGPR)))
+#else
+#define PLP_GROW_VGPR_ATTR
+#endif
+__global__ __launch_bounds__(256, PLP_GROW_MIN_WAVES) PLP_GROW_VGPR_ATTR void k_lsd_grow(LinePlanes P, LsdParams lp, int B, int wpb, int ring) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_bits[];
 #ifdef PLP_GROW_PRIO
     __builtin_amdgcn_s_setprio(PLP_GROW_PRIO);
@@ -860,7 +869,7 @@ __global__ __launch_bounds__(256, PLP_GROW_MIN_WAVES) void k_lsd_grow(LinePlanes
             if (nreg < lp.min_reg_size) continue;
             Rect rec;
             t0 = tick();
-            const int ring_cap = g.ring_mask + 1 >= 256 ? 256 : 0;   // the fit from the ring needs the whole 256-word ring as scratch
+            const int ring_cap = g.ring_mask + 1 >= 256 ? 64 * kRingPts : 0;   // the fit from the ring needs the whole 256-word ring as scratch
             if (nreg <= ring_cap) rect_from_ring(g, nreg, reg_angle, lp.prec, rec);
             else {
                 region_list_fence();
@@ -1039,7 +1048,7 @@ __device__ bool mw_process_seed(const GrowCtx& g, const LsdParams& lp, int seed,
     r.n1 = r.nfinal = nreg;
     if (nreg < lp.min_reg_size) return true;
     Rect rec;
-    const int ring_cap = g.ring_mask + 1 >= 256 ? 256 : 0;
+    const int ring_cap = g.ring_mask + 1 >= 256 ? 64 * kRingPts : 0;
     if (nreg <= ring_cap) rect_from_ring(g, nreg, reg_angle, lp.prec, rec);
     else {
         region_list_fence();
