@@ -1818,6 +1818,8 @@ void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp,
     // the k-th launch; the later stages then chew on the previous launch's segments
     static const int skip_after = [] { const char* e = getenv("PLP_LSD_SKIP_GROW"); return e ? atoi(e) : -1; }();
     static int n_launch = 0;
+    // diagnostic only (how much the LDS the growers HOLD costs their neighbours): PLP_LSD_LDS_PAD = bytes per wave requested on top, never touched
+    static const size_t lds_pad = [] { const char* e = getenv("PLP_LSD_LDS_PAD"); return (size_t)(e ? std::max(0, atoi(e)) : 0); }();
     // Few frames (plp_line_extract brings one): a workgroup of several waves per frame (k_lsd_grow_mw: one main wave + helpers that
     // speculate ahead); many frames: one wave per frame, the chip is full of independent scans anyway.
     static const int mw_max_b = [] { const char* e = getenv("PLP_LSD_MW_MAX_B"); return std::min(e ? atoi(e) : 256, kLsdMwMaxFrames); }();   // 256 = one workgroup per CU
@@ -1841,7 +1843,7 @@ void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp,
         if (L.waves >= 2) {
             hipLaunchKernelGGL(k_lsd_grow_mw, dim3(B), dim3(64 * L.waves), mw_bytes, st, P, lp, L);
         } else
-            hipLaunchKernelGGL(k_lsd_grow, dim3((B + wpb - 1) / wpb), dim3(64 * wpb), per_wave * wpb, st, P, lp, B, wpb, ring);
+            hipLaunchKernelGGL(k_lsd_grow, dim3((B + wpb - 1) / wpb), dim3(64 * wpb), per_wave * wpb + lds_pad * wpb, st, P, lp, B, wpb, ring);
     }
     if (grow_fork) { (void)hipEventRecord(side->join, side->stream); st = st_main; (void)hipStreamWaitEvent(st, side->join, 0); }
     mark(4);
