@@ -37,6 +37,8 @@ for p in (str(ROOT), str(ROOT / "tests")):
 # A hardware queue per stream (the runtime's default is four; the PCIe-inclusive pass drives seven streams, the resident step four: the resident
 # number does not move with this setting, profiles/r03_scheduling_experiments.md).  Read by the HIP runtime when it initialises: set before torch.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# multi-process runs (one rank per GPU over RCCL): the host driver supports dmabuf IPC only; exported on the GPU boxes already, kept here for any other launcher
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import numpy as np
 import torch
 
