@@ -797,6 +797,75 @@ __device__ void centroid_sums(const GrowCtx& g, int nreg, double cen[3]) {
     }
 }
 
+// One pass of reduce_region_radius (lsd.cpp): the points farther than sqrt(radSq) from the seed leave the list by SWAP-WITH-LAST, in list order --
+//     for (i = 0; i < m; ++i) if (far(reg[i])) { used = NOTUSED; reg[i] = reg[m - 1]; --m; --i; }
+// The order it leaves decides the f64 sums of the next rectangle fit, so it is replayed exactly, but not one point after the other (one lane, a
+// dependent global load per point: ~340 cycles each, 5 % of the kernel): the loop is a two-pointer walk in which every far position below the final
+// length m_f = #kept receives a kept point from beyond m_f -- the k-th such position from the LEFT the k-th such point from the RIGHT (points pulled in
+// that are far themselves are dropped on arrival, which is why only kept ones count).  Ranks by ballots and running counts over 64-point chunks; the
+// pairs meet in the frontier ring (idle here): up to ring/2 moves, else the sequential form.  Returns the new length.
+__device__ int reduce_radius_pass(const GrowCtx& g, int nreg, double xc, double yc, double radSq) {
+    const int lane = g.lane, cap = (g.ring_mask + 1) >> 1;
+    auto far_of = [&](uint32_t c) -> bool {
+        const double ddx = (double)(int)(c & 0xffff) - xc, ddy = (double)(int)(c >> 16) - yc;
+        return ddx * ddx + ddy * ddy > radSq;
+    };
+    // pass 1: un-mark the far points, count the kept ones
+    int m_f = 0;
+    for (int base = 0; base < nreg; base += 64) {
+        const int j = base + lane;
+        bool keep = false;
+        if (j < nreg) {
+            const uint32_t c = __hip_atomic_load(&g.reg[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            keep = !far_of(c);
+            if (!keep) { const int p = (int)(c >> 16) * g.sw + (int)(c & 0xffff); atomicAnd(&g.used[p >> 5], ~(1u << (p & 31))); }
+        }
+        m_f += __popcll(__ballot(keep));
+    }
+    if (m_f == nreg) return nreg;
+    // pass 2: far positions below m_f (destinations, by rank from the left) and kept points at or beyond m_f (sources, by rank from the left; the
+    // pairing wants them from the right: their number equals the number of destinations, so rank r from the left is rank n_mv - 1 - r from the right)
+    uint32_t* dst = g.ring; uint32_t* src = g.ring + cap;
+    int n_dst = 0, n_src = 0;
+    bool fits = true;
+    __builtin_amdgcn_wave_barrier();
+    for (int base = 0; base < nreg; base += 64) {
+        const int j = base + lane;
+        uint32_t c = 0;
+        bool is_dst = false, is_src = false;
+        if (j < nreg) {
+            c = __hip_atomic_load(&g.reg[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            const bool far = far_of(c);
+            is_dst = far && j < m_f; is_src = !far && j >= m_f;
+        }
+        const unsigned long long md = __ballot(is_dst), ms = __ballot(is_src);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (n_dst + __popcll(md) > cap || n_src + __popcll(ms) > cap) { fits = false; break; }
+        if (is_dst) dst[n_dst + __popcll(md & below)] = (uint32_t)j;
+        if (is_src) src[n_src + __popcll(ms & below)] = c;
+        n_dst += __popcll(md); n_src += __popcll(ms);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (fits) {   // n_dst == n_src
+        for (int k = lane; k < n_dst; k += 64)
+            __hip_atomic_store(&g.reg[dst[k]], src[n_dst - 1 - k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __builtin_amdgcn_wave_barrier();
+        return m_f;
+    }
+    int m = nreg;   // more moves than the ring holds: the sequential form (the points are un-marked already; doing it again changes nothing)
+    if (lane == 0) {
+        for (int i = 0; i < m; ++i) {
+            const uint32_t c = __hip_atomic_load(&g.reg[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            if (far_of(c)) {
+                const uint32_t lastv = __hip_atomic_load(&g.reg[m - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                __hip_atomic_store(&g.reg[i], lastv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                --m; --i;
+            }
+        }
+    }
+    return __shfl(m, 0);
+}
+
 // grid = (ceil(B / wpb)), block = 64 * wpb: wave w of a block handles frame wpb*blockIdx.x + w (wpb = waves whose
 // USED bitmap + frontier ring fit 64 KB of LDS together, at most 4).
 #ifndef PLP_GROW_MIN_WAVES      // experiment knob: waves per SIMD the register allocation must allow (4 = at most 128 VGPRs)
@@ -835,6 +904,12 @@ __global__ __launch_bounds__(256, PLP_GROW_MIN_WAVES) PLP_GROW_VGPR_ATTR void k_
     float4* raw = P.raw + (size_t)b * kLineCap;
     int n_lines = 0;
     long long t_grow = 0, t_rect = 0, t_refine = 0, n_seed = 0, n_pix = 0;
+#ifdef PLP_GROW_PROF_REFINE   // diagnostic build: what the refinement is made of (costs 14 registers: not in the shipped kernel)
+    long long t_regrow = 0, t_reduce_lane = 0, n_refined = 0, n_reduce_iter = 0, n_reduce_pts = 0, n_fitted = 0;
+#define PLP_PR(x) x
+#else
+#define PLP_PR(x)
+#endif
     int n_exact_tests = 0;
     // phase clocks only for the frame that reports them (every s_memtime is a scalar-memory round trip the wave waits for)
     const bool prof_on = P.prof != nullptr && b == 0;
@@ -881,7 +956,9 @@ __global__ __launch_bounds__(256, PLP_GROW_MIN_WAVES) PLP_GROW_VGPR_ATTR void k_
             bool keep = true;
             if (lp.refine > 0) {
                 double density = rect_density(nreg, rec);
+                PLP_PR(++n_fitted;)
                 if (density < lp.density_th) {
+                    PLP_PR(++n_refined;)
                     // ---- refine: tighter angle tolerance from the points near the seed
                     region_list_fence();
                     const uint32_t c0 = g.reg[0];
@@ -916,7 +993,9 @@ __global__ __launch_bounds__(256, PLP_GROW_MIN_WAVES) PLP_GROW_VGPR_ATTR void k_
                     // guard band of the angle test for this tolerance (disabled = every test takes the exact path)
                     float cp = 2.f, cf = -2.f;
                     if (tau >= kLsdBandMinPrec && tau < kLsdBandMaxPrec) { cp = (float)cos(tau - kLsdAngleBand); cf = (float)cos(tau + kLsdAngleBand); }
+                    PLP_PR(const long long tr0 = tick();)
                     nreg = region_grow<false>(g, (int)(c0 >> 16) * g.sw + (int)(c0 & 0xffff), false, 0.f, nullptr, tau, cp, cf, reg_angle);
+                    PLP_PR(t_regrow += tick() - tr0;)
                     region_list_fence();
                     if (nreg < 2) keep = false;
                     else {
@@ -933,24 +1012,11 @@ __global__ __launch_bounds__(256, PLP_GROW_MIN_WAVES) PLP_GROW_VGPR_ATTR void k_
                             double radSq = r1 > r2 ? r1 : r2;
                             while (density < lp.density_th) {
                                 radSq *= 0.75 * 0.75;
-                                if (lane == 0) {   // swap-with-last removal is order dependent: one lane, region order
-                                    int m = nreg;
-                                    for (int i = 0; i < m; ++i) {
-                                        const uint32_t c = __hip_atomic_load(&g.reg[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                                        const int px = (int)(c & 0xffff), py = (int)(c >> 16);
-                                        const double ddx = (double)px - xc, ddy = (double)py - yc;
-                                        if (ddx * ddx + ddy * ddy > radSq) {
-                                            g.used[(py * g.sw + px) >> 5] &= ~(1u << ((py * g.sw + px) & 31));
-                                            const uint32_t lastv = __hip_atomic_load(&g.reg[m - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                                            __hip_atomic_store(&g.reg[i], lastv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                                            --m; --i;
-                                        }
-                                    }
-                                    nreg = m;
-                                }
-                                nreg = __shfl(nreg, 0);
+                                PLP_PR(++n_reduce_iter; n_reduce_pts += nreg; const long long tl0 = tick();)
+                                nreg = reduce_radius_pass(g, nreg, xc, yc, radSq);
                                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
                                 __builtin_amdgcn_wave_barrier();
+                                PLP_PR(t_reduce_lane += tick() - tl0;)
                                 if (nreg < 2) { keep = false; break; }
                                 centroid_sums(g, nreg, cen);
                                 region2rect(g, nreg, reg_angle, lp.prec, cen, rec);
@@ -974,6 +1040,7 @@ __global__ __launch_bounds__(256, PLP_GROW_MIN_WAVES) PLP_GROW_VGPR_ATTR void k_
     if (lane == 0) { int32_t* gs = P.grow_stats + (size_t)b * 4; gs[0] = (int32_t)n_seed; gs[1] = (int32_t)n_pix; gs[2] = n_exact_tests; gs[3] = 0; }
     if (lane == 0 && prof_on) {   // diagnostics of frame 0: cycles per phase
         P.prof[0] = clock64() - t_begin; P.prof[1] = t_grow; P.prof[2] = t_rect; P.prof[3] = t_refine; P.prof[4] = n_seed; P.prof[5] = n_pix;
+        PLP_PR(P.prof[6] = t_regrow; P.prof[7] = t_reduce_lane; P.prof[8] = n_refined; P.prof[9] = n_reduce_iter; P.prof[10] = n_reduce_pts; P.prof[11] = n_fitted;)
     }
 }
 
