@@ -804,8 +804,10 @@ __device__ void centroid_sums(const GrowCtx& g, int nreg, double cen[3]) {
 // length m_f = #kept receives a kept point from beyond m_f -- the k-th such position from the LEFT the k-th such point from the RIGHT (points pulled in
 // that are far themselves are dropped on arrival, which is why only kept ones count).  Ranks by ballots and running counts over 64-point chunks; the
 // pairs meet in the frontier ring (idle here): up to ring/2 moves, else the sequential form.  Returns the new length.
-__device__ int reduce_radius_pass(const GrowCtx& g, int nreg, double xc, double yc, double radSq) {
-    const int lane = g.lane, cap = (g.ring_mask + 1) >> 1;
+// MW (k_lsd_grow_mw): the far points stay in the list BEHIND the live part (its second list must remain a permutation of what was accepted: the claims
+// are released from it); their order there is free, so the pairs are swapped.
+template <bool MW> __device__ int reduce_radius_pass(const GrowCtx& g, int nreg, double xc, double yc, double radSq) {
+    const int lane = g.lane, cap = (g.ring_mask + 1) >> (MW ? 2 : 1);
     auto far_of = [&](uint32_t c) -> bool {
         const double ddx = (double)(int)(c & 0xffff) - xc, ddy = (double)(int)(c >> 16) - yc;
         return ddx * ddx + ddy * ddy > radSq;
@@ -818,14 +820,17 @@ __device__ int reduce_radius_pass(const GrowCtx& g, int nreg, double xc, double 
         if (j < nreg) {
             const uint32_t c = __hip_atomic_load(&g.reg[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             keep = !far_of(c);
-            if (!keep) { const int p = (int)(c >> 16) * g.sw + (int)(c & 0xffff); atomicAnd(&g.used[p >> 5], ~(1u << (p & 31))); }
+            if (!keep) {
+                const int p = (int)(c >> 16) * g.sw + (int)(c & 0xffff);
+                if (MW) mw_unmark(g, p); else atomicAnd(&g.used[p >> 5], ~(1u << (p & 31)));
+            }
         }
         m_f += __popcll(__ballot(keep));
     }
     if (m_f == nreg) return nreg;
     // pass 2: far positions below m_f (destinations, by rank from the left) and kept points at or beyond m_f (sources, by rank from the left; the
     // pairing wants them from the right: their number equals the number of destinations, so rank r from the left is rank n_mv - 1 - r from the right)
-    uint32_t* dst = g.ring; uint32_t* src = g.ring + cap;
+    uint32_t* dst = g.ring; uint32_t* src = g.ring + cap; uint32_t* dval = g.ring + 2 * cap; uint32_t* spos = g.ring + 3 * cap;   // the last two: MW only
     int n_dst = 0, n_src = 0;
     bool fits = true;
     __builtin_amdgcn_wave_barrier();
@@ -841,24 +846,27 @@ __device__ int reduce_radius_pass(const GrowCtx& g, int nreg, double xc, double 
         const unsigned long long md = __ballot(is_dst), ms = __ballot(is_src);
         const unsigned long long below = (1ull << lane) - 1ull;
         if (n_dst + __popcll(md) > cap || n_src + __popcll(ms) > cap) { fits = false; break; }
-        if (is_dst) dst[n_dst + __popcll(md & below)] = (uint32_t)j;
-        if (is_src) src[n_src + __popcll(ms & below)] = c;
+        if (is_dst) { const int k = n_dst + __popcll(md & below); dst[k] = (uint32_t)j; if (MW) dval[k] = c; }
+        if (is_src) { const int k = n_src + __popcll(ms & below); src[k] = c; if (MW) spos[k] = (uint32_t)j; }
         n_dst += __popcll(md); n_src += __popcll(ms);
     }
     __builtin_amdgcn_wave_barrier();
     if (fits) {   // n_dst == n_src
-        for (int k = lane; k < n_dst; k += 64)
+        for (int k = lane; k < n_dst; k += 64) {
             __hip_atomic_store(&g.reg[dst[k]], src[n_dst - 1 - k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            if (MW) __hip_atomic_store(&g.reg[spos[n_dst - 1 - k]], dval[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
         __builtin_amdgcn_wave_barrier();
         return m_f;
     }
-    int m = nreg;   // more moves than the ring holds: the sequential form (the points are un-marked already; doing it again changes nothing)
+    int m = nreg;   // more moves than the ring holds: the sequential form (the points are un-marked already)
     if (lane == 0) {
         for (int i = 0; i < m; ++i) {
             const uint32_t c = __hip_atomic_load(&g.reg[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             if (far_of(c)) {
                 const uint32_t lastv = __hip_atomic_load(&g.reg[m - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 __hip_atomic_store(&g.reg[i], lastv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                if (MW) __hip_atomic_store(&g.reg[m - 1], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 --m; --i;
             }
         }
@@ -1013,7 +1021,7 @@ __global__ __launch_bounds__(256, PLP_GROW_MIN_WAVES) PLP_GROW_VGPR_ATTR void k_
                             while (density < lp.density_th) {
                                 radSq *= 0.75 * 0.75;
                                 PLP_PR(++n_reduce_iter; n_reduce_pts += nreg; const long long tl0 = tick();)
-                                nreg = reduce_radius_pass(g, nreg, xc, yc, radSq);
+                                nreg = reduce_radius_pass<false>(g, nreg, xc, yc, radSq);
                                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
                                 __builtin_amdgcn_wave_barrier();
                                 PLP_PR(t_reduce_lane += tick() - tl0;)
@@ -1180,23 +1188,7 @@ __device__ bool mw_process_seed(const GrowCtx& g, const LsdParams& lp, int seed,
                     double radSq = r1 > r2 ? r1 : r2;
                     while (density < lp.density_th) {
                         radSq *= 0.75 * 0.75;
-                        if (lane == 0) {   // swap-with-last removal is order dependent: one lane, region order
-                            int m = nreg;
-                            for (int i = 0; i < m; ++i) {
-                                const uint32_t c = __hip_atomic_load(&g2.reg[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                                const int px = (int)(c & 0xffff), py = (int)(c >> 16);
-                                const double ddx = (double)px - xc, ddy = (double)py - yc;
-                                if (ddx * ddx + ddy * ddy > radSq) {
-                                    mw_unmark(g2, py * g.sw + px);
-                                    const uint32_t lastv = __hip_atomic_load(&g2.reg[m - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                                    __hip_atomic_store(&g2.reg[i], lastv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                                    __hip_atomic_store(&g2.reg[m - 1], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   // kept behind the live part: list 2 stays a permutation
-                                    --m; --i;
-                                }
-                            }
-                            nreg = m;
-                        }
-                        nreg = __shfl(nreg, 0);
+                        nreg = reduce_radius_pass<true>(g2, nreg, xc, yc, radSq);
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
                         __builtin_amdgcn_wave_barrier();
                         if (nreg < 2) { keep = false; break; }
