@@ -156,3 +156,62 @@ def test_seed_sort_model_may_leave_the_undefined_pixels_alone():
         fin = got[np.argsort(-key(got), kind="stable")]
         ref = O.std_sort_entries(e)
         assert np.array_equal(fin[key(fin) >= skip], ref[key(ref) >= skip]), (trial, n, skip)
+
+
+def test_reduce_region_radius_as_a_rank_pairing_equals_the_swap_with_last_loop():
+    """lsd.cpp reduce_region_radius removes the far points of a region by swap-with-last in list order; the kernels (csrc/line_kernels.hip
+    reduce_radius_pass) replay it as a pairing by rank: every far position below the final length receives a kept point from beyond it, the k-th
+    such position from the left the k-th such point from the right.  Integer model of the kernel's three passes (64-point chunks, ballots as bit
+    masks, running counts, the ring's capacity with the sequential fallback) against the loop itself; MW: the far points are swapped behind the
+    live part, where they must remain a permutation of what was removed."""
+    r = np.random.default_rng(31)
+
+    def sequential(reg, far):
+        reg = list(reg); m = len(reg); i = 0
+        while i < m:
+            if far[reg[i]]:
+                reg[i], reg[m - 1] = reg[m - 1], reg[i]      # (the one-wave kernel only needs reg[i] = reg[m - 1]; the swap is the MW form)
+                m -= 1
+                continue
+            i += 1
+        return reg[:m], reg[m:]
+
+    def kernel_model(reg, far, cap):
+        n = len(reg); reg = list(reg)
+        m_f = 0
+        for base in range(0, n, 64):                                   # pass 1: ballot of kept lanes per chunk
+            m_f += sum(1 for j in range(base, min(base + 64, n)) if not far[reg[j]])
+        if m_f == n:
+            return reg, [], True
+        dst, dval, src, spos = [], [], [], []
+        fits = True
+        for base in range(0, n, 64):                                   # pass 2: ranks by ballots + running counts
+            lanes = range(base, min(base + 64, n))
+            md = [j for j in lanes if far[reg[j]] and j < m_f]
+            ms = [j for j in lanes if (not far[reg[j]]) and j >= m_f]
+            if len(dst) + len(md) > cap or len(src) + len(ms) > cap:
+                fits = False; break
+            dst += md; dval += [reg[j] for j in md]; src += [reg[j] for j in ms]; spos += ms
+        if not fits:
+            a, b = sequential(reg, far)
+            return a, b, False
+        assert len(dst) == len(src)
+        out = list(reg)
+        for k in range(len(dst)):                                      # pass 3
+            out[dst[k]] = src[len(dst) - 1 - k]
+            out[spos[len(dst) - 1 - k]] = dval[k]
+        return out[:m_f], out[m_f:], True
+
+    n_fallback = 0
+    for trial in range(3000):
+        n = int(r.integers(1, 40)) if trial % 3 else int(r.integers(40, 700))
+        reg = list(r.permutation(n))
+        p = float(r.random()) ** (1 + trial % 3)
+        far = {x: bool(r.random() < p) for x in reg}
+        want_live, want_tail = sequential(reg, far)
+        for cap in (128, 64, 16):
+            live, tail, fitted = kernel_model(reg, far, cap)
+            n_fallback += not fitted
+            assert live == want_live, (trial, n, cap)
+            assert sorted(tail) == sorted(want_tail), (trial, n, cap)
+    assert n_fallback > 0        # the fallback was exercised as well
