@@ -672,8 +672,18 @@ __device__ void region2rect(const GrowCtx& g, int nreg, double reg_angle, double
 #ifndef PLP_RING_PTS
 #define PLP_RING_PTS 4
 #endif
+// NOT YET RUN ON A GPU (written at the end of round 4, after the GPU budget): the ~55 rectangle fits per frame that follow a shrink step of reduce_region_radius take
+// the general path (centroid_sums + region2rect: nine broadcasts and adds per point, ~1.1 M of the kernel's 23 M cycles per frame) although the shrunk list is short;
+// with PLP_GROW_REFIT_FROM_LIST=1 they take the fit that keeps the points in registers, reading the coordinates from the reordered list.  Same additions in the same
+// order by construction (rect_from_ring == centroid_sums + region2rect is what the first fits already rely on) -- to be switched on once the line tests have seen it.
+// (With it on k_lsd_grow compiles to 155 VGPRs, one allocation granule above the shipped 151: what that costs beside the other kernels has to be measured too.)
+#ifndef PLP_GROW_REFIT_FROM_LIST
+#define PLP_GROW_REFIT_FROM_LIST 0
+#endif
 constexpr int kRingPts = PLP_RING_PTS;   // points per lane the fit from the ring keeps in registers: regions up to 64 * kRingPts points take it
-__device__ void rect_from_ring(const GrowCtx& g, int nreg, double reg_angle, double prec, Rect& rec) {
+// FROM_LIST: the coordinates come from the HBM copy of the list instead of the ring (after reduce_region_radius has reordered the list; the ring still
+// serves as scratch) -- opt-in, see PLP_GROW_REFIT_FROM_LIST below.
+template <bool FROM_LIST = false> __device__ void rect_from_ring(const GrowCtx& g, int nreg, double reg_angle, double prec, Rect& rec) {
     const int lane = g.lane;
     // per lane up to four points, kept small across the two sequential passes (this function is the kernel's register peak, and what
     // two of these waves leave of a SIMD's registers decides how many waves of the neighbouring kernels fit): coordinates stay packed as
@@ -686,7 +696,7 @@ __device__ void rect_from_ring(const GrowCtx& g, int nreg, double reg_angle, dou
         pc[u] = 0; w[u] = 0;
         if (64 * u >= nreg) continue;   // uniform: most fitted regions have fewer than 64 points
         if (j < nreg) {
-            pc[u] = g.ring[j & g.ring_mask];
+            pc[u] = FROM_LIST ? __hip_atomic_load(&g.reg[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) : g.ring[j & g.ring_mask];
             w[u] = pix_mod(g.pix[(int)(pc[u] >> 16) * g.sw + (int)(pc[u] & 0xffff)]);
         }
     }
@@ -1026,8 +1036,14 @@ __global__ __launch_bounds__(256, PLP_GROW_MIN_WAVES) PLP_GROW_VGPR_ATTR void k_
                                 __builtin_amdgcn_wave_barrier();
                                 PLP_PR(t_reduce_lane += tick() - tl0;)
                                 if (nreg < 2) { keep = false; break; }
-                                centroid_sums(g, nreg, cen);
-                                region2rect(g, nreg, reg_angle, lp.prec, cen, rec);
+#if PLP_GROW_REFIT_FROM_LIST
+                                if (nreg <= ring_cap) rect_from_ring<true>(g, nreg, reg_angle, lp.prec, rec);
+                                else
+#endif
+                                {
+                                    centroid_sums(g, nreg, cen);
+                                    region2rect(g, nreg, reg_angle, lp.prec, cen, rec);
+                                }
                                 density = rect_density(nreg, rec);
                             }
                         }
@@ -1192,8 +1208,14 @@ __device__ bool mw_process_seed(const GrowCtx& g, const LsdParams& lp, int seed,
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
                         __builtin_amdgcn_wave_barrier();
                         if (nreg < 2) { keep = false; break; }
-                        centroid_sums(g2, nreg, cen);
-                        region2rect(g2, nreg, reg_angle, lp.prec, cen, rec);
+#if PLP_GROW_REFIT_FROM_LIST
+                        if (nreg <= ring_cap) rect_from_ring<true>(g2, nreg, reg_angle, lp.prec, rec);
+                        else
+#endif
+                        {
+                            centroid_sums(g2, nreg, cen);
+                            region2rect(g2, nreg, reg_angle, lp.prec, cen, rec);
+                        }
                         density = rect_density(nreg, rec);
                     }
                     r.nfinal = nreg;
