@@ -159,29 +159,36 @@ def main():
         last_buf = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if os.environ.get("PLP_BENCH_SS_CHECK"):     # diagnostic builds (-DPLP_SS_CHECK) only: partner positions the seed sort found outside their segment
-        import ctypes
-        chk = (ctypes.c_uint32 * 136)()
-        torch.cuda.synchronize(dev)
-        if getattr(plp.lib(), "plp_debug_seed_sort_check")(chk, 136) == 0:
-            print("seed sort check:", chk[0], [[hex(v) for v in chk[8 + 8 * k: 16 + 8 * k]] for k in range(min(chk[0], 16))], file=sys.stderr)
     ts.last_batch_status()
     # ---- parity of the timed step itself: N frames of the LAST timed step (features + the four matcher results) against the CPU oracle.
     # After the timed region; the oracle is the checker here, never part of what is measured (tests/bench_step_check.py).
-    verified = None
-    if args.verify > 0 and rank == 0 and world == 1 and uniq >= 3:
+    # At N > 1 EVERY rank checks its own block (at most 8 frames each: the oracle runs on the host cores all ranks share) -- frames 0 and 1, whose
+    # predecessors came over the halo exchange, among them -- and the halo rows themselves against the predecessor rank's last two frames, which it
+    # regenerates from that rank's seed; the mismatch counts are all-reduced, so one bad rank fails the line.
+    verified = verified_halo = None
+    if args.verify > 0 and uniq >= 3:
         import bench_step_check as BC
-        n_ver = min(args.verify, B)
-        ids = np.unique(np.concatenate([[0, 1], np.linspace(0, B - 1, n_ver).astype(np.int64)]))[:max(n_ver, 2)]   # frames 0 and 1 read the circular halo
+        n_ver = min(args.verify, B) if world == 1 else min(args.verify, B, 8)
+        ids = np.unique(np.concatenate([[0, 1], np.linspace(0, B - 1, n_ver).astype(np.int64)]))[:max(n_ver, 2)]   # frames 0 and 1 read the halo
         h = BC.fetch(ts, last_buf)
         g6 = BC.O.grid6(ts.grid)
+        stable = args.seed_order == "stable"
         bad = []
         for b in ids:
-            bad += BC.check_frame(h, int(b), K, g6, ts.shift, sf, frames_np[int(b) % uniq], args.orb_only, stable_order=args.seed_order == "stable")
+            bad += BC.check_frame(h, int(b), K, g6, ts.shift, sf, frames_np[int(b) % uniq], args.orb_only, stable_order=stable)
+        prev = (rank - 1) % world
+        prev_np = frames_np if prev == rank else synth.replay(1234 + prev, uniq, args.rows, args.cols)
+        bad += BC.check_halo(h, K, [prev_np[(B - HALO + j) % uniq] for j in range(HALO)], args.orb_only, stable_order=stable)
+        counts = [len(bad), len(ids), HALO]
+        if dist is not None:
+            t = torch.tensor(counts, dtype=torch.int64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            counts = [int(v) for v in t.tolist()]
         if bad:
-            print(json.dumps({"error": "bench.py --verify: the timed step differs from the oracle", "mismatches": bad[:8]}), file=sys.stderr)
+            print(json.dumps({"error": "bench.py --verify: the timed step differs from the oracle", "rank": rank, "mismatches": bad[:8]}), file=sys.stderr)
+        if counts[0]:
             sys.exit(3)
-        verified = int(len(ids))
+        verified, verified_halo = counts[1], counts[2]
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

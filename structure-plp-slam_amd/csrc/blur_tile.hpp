@@ -121,9 +121,9 @@ __device__ __forceinline__ void blur_tile_compute(BlurTileLds<R>& S, const int* 
     emit(r0, c4, rows);
 }
 
-// ---- the same tile in three pieces, for PERSISTENT workgroups that walk a list of tiles: the global loads of tile n + 1 are
-// issued into registers right after tile n's first barrier and wait there through its two compute phases, so that the memory latency runs beside
-// the arithmetic of the workgroup's own tile instead of being hidden only by other workgroups; no workgroup launch per tile.
+// ---- the tile in three pieces: issue every load of the tile into registers (blur_prefetch), store them to LDS (blur_stage_prefetched), compute
+// (blur_tile_compute).  Written for persistent workgroups that prefetch tile n + 1 during tile n (measured slower, the kernel is
+// in profiles/r05_removed_experiment_knobs.patch); what it showed and what stays is that ALL of a tile's loads must be in flight before the first wait.
 struct BlurJob { const uint8_t* src; uint8_t* dst; int src_pitch, dst_pitch, w, h, tx0, ty0; };   // wave-uniform
 
 template <int R> struct BlurPrefetch {

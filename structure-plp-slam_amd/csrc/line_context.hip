@@ -20,7 +20,8 @@ struct plp_line {
     hipStream_t stream = nullptr;
     int rows = 0, cols = 0, capB = 0;
     int grow_waves = 0;   // plp_line_set_grow_waves
-    int seed_order = PLP_SEED_ORDER_LIBSTDCXX;   // plp_line_set_seed_order; the reference's order unless the device refuses the sort's LDS (plp_line_create)
+    int seed_order = PLP_SEED_ORDER_LIBSTDCXX;   // plp_line_set_seed_order.  The reference's order is the default on every device; one that refuses the sort's LDS
+                                                 // (seed_sort_ok false) gets an error from extract until the caller selects PLP_SEED_ORDER_STABLE -- never a silent change of results
     bool grow_on_side = false;                 // PLP_GROW_CUS: region growing on the CU-masked side stream
     bool mw_ok = false, seed_sort_ok = false;  // this device accepted the large dynamic-LDS limits of k_lsd_grow_mw / k_lsd_seed_sort
     int mw_capB = 0, seed_capB = 0;            // frames the lazily allocated buffers of those two paths hold
@@ -177,6 +178,8 @@ plp_status ensure(plp_line* c, int B) {
 plp_status run(plp_line* c, const uint8_t* d_imgs, int B, int rows, int cols, size_t step, size_t frame_stride, plp_keyline* d_kl,
                uint8_t* d_lbd, double* d_fn, int cap, int32_t* d_counts, hipStream_t st) {
     PLP_HIP(hipSetDevice(c->device));
+    if (c->seed_order == PLP_SEED_ORDER_LIBSTDCXX && !c->seed_sort_ok)   // (the context exists, so that the caller CAN select the other order)
+        return set_error(PLP_ERR_UNSUPPORTED, "this device refused the dynamic LDS size of the exact seed sort (144 KB per workgroup): select PLP_SEED_ORDER_STABLE with plp_line_set_seed_order");
     PLP_TRY(build(c, rows, cols));
     PLP_TRY(ensure(c, B));
     if (((uintptr_t)d_imgs % 4 == 0) && (step % 4 == 0) && (frame_stride % 4 == 0)) {
@@ -223,7 +226,6 @@ plp_status plp_line_create(int device, plp_line** out) {
     c->mw_ok = grow_mw_configure() == hipSuccess;
     c->seed_sort_ok = seed_sort_configure() == hipSuccess;
     (void)hipGetLastError();
-    if (!c->seed_sort_ok) { delete c; return set_error(PLP_ERR_UNSUPPORTED, "this device refused the dynamic LDS size of the exact seed sort (144 KB per workgroup)"); }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return set_error(PLP_ERR_HIP, "hipStreamCreate failed"); }
     // Experiment (profiles/r04_grow_cu_mask.md): PLP_GROW_CUS=n runs region growing on a stream of its own that may only use n of the CUs
     // (hipExtStreamCreateWithCUMask; the mask's bits go round the XCDs, so the first n bits are n / 8 CUs of each), the rest of the chip stays free
@@ -348,6 +350,8 @@ plp_status plp_line_set_seed_order(plp_line* c, int32_t order) {
     if (order == PLP_SEED_ORDER_LIBSTDCXX && !c->seed_sort_ok) return set_error(PLP_ERR_UNSUPPORTED, "this device refused the LDS size of the exact seed sort");
     std::lock_guard<std::mutex> lk(c->mu);
     c->seed_order = order;
+    // the exact order's buffers (the seed array and the sort's scratch: 476 KB per frame of a 640 x 480 batch) go back when the caller leaves that order
+    if (order == PLP_SEED_ORDER_STABLE && c->seed_capB > 0) { (void)hipSetDevice(c->device); c->seed_ent.release(); c->seed_ws.release(); c->seed_capB = 0; }
     return PLP_OK;
 }
 

@@ -411,8 +411,14 @@ __device__ __forceinline__ void mw_unmark(const GrowCtx& g, int p) {
 // (profiles/r03_lsd_grow_mw.md): yielding to every earlier claim, and assuming every earlier claim used.
 template <bool MW>
 __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed_deg, const float2* seed_cs, double prec, float c_pass,
-                           float c_fail, double& reg_angle, int* n_exact_tests = nullptr) {
+                           float c_fail, double& reg_angle, int* n_exact_tests = nullptr, long long* racc = nullptr) {
     const int lane = g.lane;
+#ifdef PLP_GROW_PROF_ROUND   // diagnostic build: cycles of a round by phase (frame 0 only; every stamp drains the wave's memory counters first and costs ~540 cycles itself)
+    long long rp_t = racc ? clock64() : 0;
+#define PLP_RSTAMP(k) do { if (racc) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const long long t_ = clock64(); racc[k] += t_ - rp_t; rp_t = t_; } } while (0)
+#else
+#define PLP_RSTAMP(k)
+#endif
     int nreg = 1;
     const int sx = seed % g.sw, sy = seed / g.sw;
     reg_angle = (double)(have_deg ? seed_deg : g.pix[seed].deg) * (3.14159265358979323846 / 180);
@@ -435,6 +441,7 @@ __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed
     const bool banded = c_pass <= 1.f;
     const int s_cpass = __builtin_amdgcn_readfirstlane(__float_as_int(c_pass)), s_cfail = __builtin_amdgcn_readfirstlane(__float_as_int(c_fail));
     const int ddx = k9 % 3 - 1, ddy = k9 / 3 - 1;
+    const int npix_m1 = g.sw * g.sh - 1;
     bool gave_up = false;
     const int list_cap = MW ? __builtin_amdgcn_readfirstlane(g.reg_cap) : 0;   // wave-uniform, and said so (the block below keeps nreg in a scalar register)
     for (int i = 0; i < nreg && !(MW && gave_up);) {
@@ -452,6 +459,7 @@ __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed
         }
         cand = cand && nx >= 0 && ny >= 0 && nx < g.sw && ny < g.sh;
         np = ny * g.sw + nx;
+        PLP_RSTAMP(0);   // the batch's points are here (ring read)
         bool foreign = false;   // claimed by the growing region of an earlier seed (or of the main wave)
         if (MW) {
             bool assume = false;
@@ -481,20 +489,18 @@ __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed
                 __builtin_amdgcn_wave_barrier();
             }
         }
-#ifdef PLP_GROW_GATHER_FIRST
-        // experiment (profiles/r04_lsd_grow.md): the record gather is issued for every in-image neighbour BEFORE the USED test, whose LDS round trip then
-        // runs beside it instead of in front of it; records of used / undefined pixels are fetched for nothing (undefined ones hold no record: discarded)
-        else {
-            LsdPix px{};
-            if (cand) px = g.pix[np];
-            if (cand) cand = !is_used(g, np);
-            if (cand) { deg = px.deg; ncs = px.cs; }
+        else {   // the USED word of every lane's pixel, read unconditionally from a clamped index: no predicated block (three instructions and a branch) around one LDS read
+            const int pc = min(max(np, 0), npix_m1);
+            uint32_t uw = g.used[pc >> 5];
+            asm volatile("" : "+v"(uw));   // (keeps the read where it is: the optimiser otherwise sinks it into a block predicated on `cand`)
+            cand = cand & !((uw >> (pc & 31)) & 1u);
         }
-        if (MW && cand) { const LsdPix px = g.pix[np]; deg = px.deg; ncs = px.cs; }
-#else
-        else if (cand) cand = !is_used(g, np);
-        if (cand) { const LsdPix px = g.pix[np]; deg = px.deg; ncs = px.cs; }   // 16 bytes per live neighbour
-#endif
+        PLP_RSTAMP(1);   // USED test
+        if (cand) {   // 16 bytes per live neighbour; a 32-bit byte offset from the frame's (scalar) base: one shift instead of three 64-bit additions per round
+            const LsdPix px = *reinterpret_cast<const LsdPix*>(reinterpret_cast<const char*>(g.pix) + ((uint32_t)np << 4));
+            deg = px.deg; ncs = px.cs;
+        }
+        PLP_RSTAMP(2);   // record gather
         // ---- acceptances in order.  Accepted lanes are strictly increasing, so the set of accepted lanes (a bit mask)
         // already is the order: the list append and the USED bits are written by the accepted lanes themselves after
         // the loop, in parallel (the loop used to hand every acceptance to lane 0: two more broadcasts and a
@@ -579,7 +585,9 @@ __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed
             if (U & before) {
                 if (n_exact_tests) ++*n_exact_tests;
                 if (!theta_valid) { reg_angle = (double)fast_atan2_deg_l(sumdy, sumdx) * (3.14159265358979323846 / 180); theta_valid = true; }
-                bal = __builtin_amdgcn_ballot_w64(aligned_to((double)deg * (3.14159265358979323846 / 180), reg_angle, prec)) & elig;
+                float deg_here = deg;   // (opaque to the optimiser: the f64 conversion of every lane's angle is work for the dozen band cases of a frame, not for every round)
+                asm volatile("" : "+v"(deg_here));
+                bal = __builtin_amdgcn_ballot_w64(aligned_to((double)deg_here * (3.14159265358979323846 / 180), reg_angle, prec)) & elig;
             }
             if (!bal) break;
             const int k = __builtin_ctzll(bal);
@@ -596,6 +604,7 @@ __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed
         if (MW) {   // give up before anything of this round is written or marked
             if (gave_up || nreg > list_cap || (acc & __builtin_amdgcn_ballot_w64(foreign))) { gave_up = true; nreg = n_before; acc = 0; }
         }
+        PLP_RSTAMP(3);   // acceptance loop
         if ((acc >> lane) & 1ull) {
             const int pos = n_before + __popcll(acc & ((1ull << lane) - 1ull));
             const uint32_t c = (uint32_t)nx | ((uint32_t)ny << 16);
@@ -604,6 +613,8 @@ __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed
             __hip_atomic_store(&g.reg[pos], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // HBM copy of the list
         }
         __builtin_amdgcn_wave_barrier();   // LDS operations of one wave complete in order: the next round's reads see these writes
+        PLP_RSTAMP(4);   // appends, marks
+        if (racc) { racc[5] += 1; racc[6] += __popcll(acc); }
         i += nb;
     }
     if (MW && gave_up) return -1 - nreg;
@@ -669,20 +680,13 @@ __device__ void region2rect(const GrowCtx& g, int nreg, double reg_angle, double
 // coordinates come from LDS, every lane keeps its (up to four) points and their weights in registers, so the centroid
 // sums, the inertia sums and the extents need ONE round of gathers instead of three passes over the HBM copy of the
 // list.  Same additions in the same order as centroid_sums() + region2rect().
-#ifndef PLP_RING_PTS
-#define PLP_RING_PTS 4
-#endif
-// NOT YET RUN ON A GPU (written at the end of round 4, after the GPU budget): the ~55 rectangle fits per frame that follow a shrink step of reduce_region_radius take
-// the general path (centroid_sums + region2rect: nine broadcasts and adds per point, ~1.1 M of the kernel's 23 M cycles per frame) although the shrunk list is short;
-// with PLP_GROW_REFIT_FROM_LIST=1 they take the fit that keeps the points in registers, reading the coordinates from the reordered list.  Same additions in the same
-// order by construction (rect_from_ring == centroid_sums + region2rect is what the first fits already rely on) -- to be switched on once the line tests have seen it.
-// (With it on k_lsd_grow compiles to 155 VGPRs, one allocation granule above the shipped 151: what that costs beside the other kernels has to be measured too.)
-#ifndef PLP_GROW_REFIT_FROM_LIST
-#define PLP_GROW_REFIT_FROM_LIST 0
-#endif
-constexpr int kRingPts = PLP_RING_PTS;   // points per lane the fit from the ring keeps in registers: regions up to 64 * kRingPts points take it
+// The ~55 rectangle fits per frame that follow a shrink step of reduce_region_radius also take the fit that keeps the points in registers, reading
+// the coordinates from the reordered list (FROM_LIST): the general path (centroid_sums + region2rect) costs nine broadcasts and adds per point.  Same
+// additions in the same order by construction (rect_from_ring == centroid_sums + region2rect is what the first fits already rely on).  Round 5:
+// k_lsd_grow 12.05 -> 11.75 ms per 2048 frames (155 VGPRs against 151: still three waves per SIMD), line tests + fuzz bit-exact.
+constexpr int kRingPts = 4;   // points per lane the fit from the ring keeps in registers: regions up to 64 * kRingPts points take it
 // FROM_LIST: the coordinates come from the HBM copy of the list instead of the ring (after reduce_region_radius has reordered the list; the ring still
-// serves as scratch) -- opt-in, see PLP_GROW_REFIT_FROM_LIST below.
+// serves as scratch).
 template <bool FROM_LIST = false> __device__ void rect_from_ring(const GrowCtx& g, int nreg, double reg_angle, double prec, Rect& rec) {
     const int lane = g.lane;
     // per lane up to four points, kept small across the two sequential passes (this function is the kernel's register peak, and what
@@ -886,20 +890,11 @@ template <bool MW> __device__ int reduce_radius_pass(const GrowCtx& g, int nreg,
 
 // grid = (ceil(B / wpb)), block = 64 * wpb: wave w of a block handles frame wpb*blockIdx.x + w (wpb = waves whose
 // USED bitmap + frontier ring fit 64 KB of LDS together, at most 4).
-#ifndef PLP_GROW_MIN_WAVES      // experiment knob: waves per SIMD the register allocation must allow (4 = at most 128 VGPRs)
-#define PLP_GROW_MIN_WAVES 1
-#endif
-#ifdef PLP_GROW_NUM_VGPR      // experiment knob: an exact register budget (between the occupancy steps of __launch_bounds__)
-#define PLP_GROW_VGPR_ATTR __attribute__((amdgpu_num_vgpr(PLP_GROW_NUM_VGPR)))
-#else
-#define PLP_GROW_VGPR_ATTR
-#endif
-__global__ __launch_bounds__(256, PLP_GROW_MIN_WAVES) PLP_GROW_VGPR_ATTR void k_lsd_grow(LinePlanes P, LsdParams lp, int B, int wpb, int ring) {
+__global__ __launch_bounds__(256) void k_lsd_grow(LinePlanes P, LsdParams lp, int B, int wpb, int ring) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_bits[];
-#ifdef PLP_GROW_PRIO
-    __builtin_amdgcn_s_setprio(PLP_GROW_PRIO);
-#endif
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // the wave's index is wave-uniform, and said so: every per-frame pointer below then lives in scalar registers (global addresses become an SGPR base + a
+    // 32-bit lane offset instead of 64-bit vector arithmetic)
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int b = blockIdx.x * wpb + wv;
     if (b >= B) return;
     const int n = P.sw * P.sh, nwords = (n + 31) / 32, nv = (P.sw - 1) * (P.sh - 1);
@@ -929,7 +924,12 @@ __global__ __launch_bounds__(256, PLP_GROW_MIN_WAVES) PLP_GROW_VGPR_ATTR void k_
 #define PLP_PR(x)
 #endif
     int n_exact_tests = 0;
-    // phase clocks only for the frame that reports them (every s_memtime is a scalar-memory round trip the wave waits for)
+    long long racc_v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#ifdef PLP_GROW_PROF_ROUND   // (tools/build_variant.sh rprof -DPLP_GROW_PROF_ROUND; python tools/grow_profile.py 2048: 'more' = cycles of {ring read, USED test, gather, acceptance loop, appends}, rounds)
+    long long* const racc = (P.prof != nullptr && b == 0) ? racc_v : nullptr;
+#else
+    long long* const racc = nullptr;
+#endif (every s_memtime is a scalar-memory round trip the wave waits for)
     const bool prof_on = P.prof != nullptr && b == 0;
     auto tick = [&]() -> long long { return prof_on ? clock64() : 0ll; };
     const long long t_begin = tick();
@@ -957,7 +957,7 @@ __global__ __launch_bounds__(256, PLP_GROW_MIN_WAVES) PLP_GROW_VGPR_ATTR void k_
             double reg_angle, cen[3];
             long long t0 = tick();
             const float2 seed_cs = make_float2(bcast_f(s_cs.x, t), bcast_f(s_cs.y, t));
-            int nreg = region_grow<false>(g, seed, true, bcast_f(s_deg, t), &seed_cs, lp.prec, lp.c_pass, lp.c_fail, reg_angle, &n_exact_tests);
+            int nreg = region_grow<false>(g, seed, true, bcast_f(s_deg, t), &seed_cs, lp.prec, lp.c_pass, lp.c_fail, reg_angle, &n_exact_tests, racc);
             t_grow += tick() - t0; ++n_seed; n_pix += nreg;
             if (nreg < lp.min_reg_size) continue;
             Rect rec;
@@ -1012,7 +1012,7 @@ __global__ __launch_bounds__(256, PLP_GROW_MIN_WAVES) PLP_GROW_VGPR_ATTR void k_
                     float cp = 2.f, cf = -2.f;
                     if (tau >= kLsdBandMinPrec && tau < kLsdBandMaxPrec) { cp = (float)cos(tau - kLsdAngleBand); cf = (float)cos(tau + kLsdAngleBand); }
                     PLP_PR(const long long tr0 = tick();)
-                    nreg = region_grow<false>(g, (int)(c0 >> 16) * g.sw + (int)(c0 & 0xffff), false, 0.f, nullptr, tau, cp, cf, reg_angle);
+                    nreg = region_grow<false>(g, (int)(c0 >> 16) * g.sw + (int)(c0 & 0xffff), false, 0.f, nullptr, tau, cp, cf, reg_angle, nullptr, racc);
                     PLP_PR(t_regrow += tick() - tr0;)
                     region_list_fence();
                     if (nreg < 2) keep = false;
@@ -1036,10 +1036,8 @@ __global__ __launch_bounds__(256, PLP_GROW_MIN_WAVES) PLP_GROW_VGPR_ATTR void k_
                                 __builtin_amdgcn_wave_barrier();
                                 PLP_PR(t_reduce_lane += tick() - tl0;)
                                 if (nreg < 2) { keep = false; break; }
-#if PLP_GROW_REFIT_FROM_LIST
                                 if (nreg <= ring_cap) rect_from_ring<true>(g, nreg, reg_angle, lp.prec, rec);
                                 else
-#endif
                                 {
                                     centroid_sums(g, nreg, cen);
                                     region2rect(g, nreg, reg_angle, lp.prec, cen, rec);
@@ -1064,6 +1062,10 @@ __global__ __launch_bounds__(256, PLP_GROW_MIN_WAVES) PLP_GROW_VGPR_ATTR void k_
     if (lane == 0) { int32_t* gs = P.grow_stats + (size_t)b * 4; gs[0] = (int32_t)n_seed; gs[1] = (int32_t)n_pix; gs[2] = n_exact_tests; gs[3] = 0; }
     if (lane == 0 && prof_on) {   // diagnostics of frame 0: cycles per phase
         P.prof[0] = clock64() - t_begin; P.prof[1] = t_grow; P.prof[2] = t_rect; P.prof[3] = t_refine; P.prof[4] = n_seed; P.prof[5] = n_pix;
+#ifdef PLP_GROW_PROF_ROUND
+        for (int k = 0; k < 6; ++k) P.prof[6 + k] = racc_v[k];
+        P.prof[5] = racc_v[6];   // acceptances (instead of pixels)
+#endif
         PLP_PR(P.prof[6] = t_regrow; P.prof[7] = t_reduce_lane; P.prof[8] = n_refined; P.prof[9] = n_reduce_iter; P.prof[10] = n_reduce_pts; P.prof[11] = n_fitted;)
     }
 }
@@ -1208,14 +1210,8 @@ __device__ bool mw_process_seed(const GrowCtx& g, const LsdParams& lp, int seed,
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
                         __builtin_amdgcn_wave_barrier();
                         if (nreg < 2) { keep = false; break; }
-#if PLP_GROW_REFIT_FROM_LIST
-                        if (nreg <= ring_cap) rect_from_ring<true>(g2, nreg, reg_angle, lp.prec, rec);
-                        else
-#endif
-                        {
-                            centroid_sums(g2, nreg, cen);
-                            region2rect(g2, nreg, reg_angle, lp.prec, cen, rec);
-                        }
+                        centroid_sums(g2, nreg, cen);   // (the fit from the reordered list that k_lsd_grow takes here costs this kernel ten registers: 182)
+                        region2rect(g2, nreg, reg_angle, lp.prec, cen, rec);
                         density = rect_density(nreg, rec);
                     }
                     r.nfinal = nreg;
@@ -1688,7 +1684,7 @@ constexpr int kLbdU = PLP_LBD_U;   // band steps whose gathers are in flight tog
 __global__ __launch_bounds__(256) void k_lbd(LinePlanes P, LbdWeightsDev W) {
     __shared__ float s_row[4][63][8];   // per row: pgdL, ngdL, pgdL2, ngdL2, pgdO, ngdO, pgdO2, ngdO2 (after the global weight)
     __shared__ float s_des[4][72], s_des2[4][72], s_norm[4][4];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), b = blockIdx.y;   // (wave-uniform, and said so: the line's record and addresses are scalar)
     const int n_lines = P.n_all[b];
     for (int li = blockIdx.x * 4 + wv; li < n_lines; li += gridDim.x * 4) {   // a few resident waves walk the frame's lines
     const plp_keyline kl = P.all_kl[(size_t)b * kLineCap + li];
@@ -1899,8 +1895,6 @@ void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp,
     // the k-th launch; the later stages then chew on the previous launch's segments
     static const int skip_after = [] { const char* e = getenv("PLP_LSD_SKIP_GROW"); return e ? atoi(e) : -1; }();
     static int n_launch = 0;
-    // diagnostic only (how much the LDS the growers HOLD costs their neighbours): PLP_LSD_LDS_PAD = bytes per wave requested on top, never touched
-    static const size_t lds_pad = [] { const char* e = getenv("PLP_LSD_LDS_PAD"); return (size_t)(e ? std::max(0, atoi(e)) : 0); }();
     // Few frames (plp_line_extract brings one): a workgroup of several waves per frame (k_lsd_grow_mw: one main wave + helpers that
     // speculate ahead); many frames: one wave per frame, the chip is full of independent scans anyway.
     static const int mw_max_b = [] { const char* e = getenv("PLP_LSD_MW_MAX_B"); return std::min(e ? atoi(e) : 256, kLsdMwMaxFrames); }();   // 256 = one workgroup per CU
@@ -1924,7 +1918,7 @@ void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp,
         if (L.waves >= 2) {
             hipLaunchKernelGGL(k_lsd_grow_mw, dim3(B), dim3(64 * L.waves), mw_bytes, st, P, lp, L);
         } else
-            hipLaunchKernelGGL(k_lsd_grow, dim3((B + wpb - 1) / wpb), dim3(64 * wpb), per_wave * wpb + lds_pad * wpb, st, P, lp, B, wpb, ring);
+            hipLaunchKernelGGL(k_lsd_grow, dim3((B + wpb - 1) / wpb), dim3(64 * wpb), per_wave * wpb, st, P, lp, B, wpb, ring);
     }
     if (grow_fork) { (void)hipEventRecord(side->join, side->stream); st = st_main; (void)hipStreamWaitEvent(st, side->join, 0); }
     mark(4);

@@ -339,7 +339,7 @@ template <int FAM>
 __global__ __launch_bounds__(256) void k_match_topk(MatchProblem P) {
     const int lane = threadIdx.x & 63, b = blockIdx.y;
     const int m = P.q_counts ? min(P.q_counts[b], P.m_cap) : P.m_cap;
-    for (int q = blockIdx.x * 4 + (threadIdx.x >> 6); q < m; q += gridDim.x * 4) match_topk_query<FAM>(P, b, q, lane);
+    for (int q = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); q < m; q += gridDim.x * 4) match_topk_query<FAM>(P, b, q, lane);   // the wave's query index: scalar
 }
 
 // The same search with ONE LANE per query (each lane scans all targets and keeps its 8 best keys): for small target sets -- the key
@@ -721,7 +721,7 @@ __global__ PLP_TOPK_CELLS_BOUNDS void k_match_topk_cells(MatchProblem P, int qpb
 // grid = (ceil(m_cap / kQueriesPerBlock), B), block = 256, dynamic LDS = n_cap * 32 bytes.
 __global__ __launch_bounds__(256) void k_match_topk_lds(MatchProblem P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), b = blockIdx.y;
     const int m = P.q_counts ? min(P.q_counts[b], P.m_cap) : P.m_cap;
     const int q_begin = blockIdx.x * kQueriesPerBlock;
     if (q_begin >= m) return;
@@ -781,7 +781,7 @@ __device__ __forceinline__ void match_resolve_body(const MatchProblem& P) {
     extern __shared__ int32_t lds[];
     __shared__ int s_changed, s_num, s_hist[32], s_valid_bin[32], s_full_n, s_claim_tmp[256], s_sort_ws[48];
     __shared__ unsigned s_sort_idx[32];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), b = blockIdx.x;
     const int m = P.q_counts ? min(P.q_counts[b], P.m_cap) : P.m_cap;
     const int n = P.t_counts ? min(P.t_counts[b], P.n_cap) : P.n_cap;
     int32_t* owner_final = lds;                 // smallest claimant among the chunks already finished
@@ -1026,7 +1026,7 @@ __global__ __launch_bounds__(256) void k_hamming_matrix(const uint8_t* __restric
         st[r * 9 + w] = t0 + r < nt ? reinterpret_cast<const uint32_t*>(td)[(size_t)(t0 + r) * 8 + w] : 0u;
     }
     __syncthreads();
-    const int tx = tid & 63, ty = tid >> 6;   // thread: target tx, queries ty, ty+4, ...
+    const int tx = tid & 63, ty = __builtin_amdgcn_readfirstlane(tid >> 6);   // thread: target tx, queries ty, ty+4, ... (ty is the wave's index: scalar)
     uint32_t tv[8];
 #pragma unroll
     for (int w = 0; w < 8; ++w) tv[w] = st[tx * 9 + w];
@@ -1043,7 +1043,7 @@ __global__ __launch_bounds__(256) void k_hamming_matrix(const uint8_t* __restric
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_match_fuse(MatchProblem P) {
     const int lane = threadIdx.x & 63, b = blockIdx.y;
-    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int q = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int m = P.q_counts ? min(P.q_counts[b], P.m_cap) : P.m_cap;
     if (q >= m) return;
     int32_t* out = P.out_query_best + (size_t)b * P.m_cap + q;
@@ -1230,7 +1230,7 @@ void launch_hamming_matrix(hipStream_t st, const uint8_t* q, int nq, const uint8
 __global__ __launch_bounds__(256) void k_lbd_match_1nn(const uint8_t* __restrict__ q, const int32_t* __restrict__ q_counts, int nq_cap,
                                                        const uint8_t* __restrict__ t, const int32_t* __restrict__ t_counts, int nt_cap,
                                                        MihRanks R, int32_t* __restrict__ out_idx, int32_t* __restrict__ out_dist) {
-    const int lane = threadIdx.x & 63, b = blockIdx.y, qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, b = blockIdx.y, qi = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nq = q_counts ? min(q_counts[b], nq_cap) : nq_cap, nt = t_counts ? min(t_counts[b], nt_cap) : nt_cap;
     if (qi >= nq) return;
     const uint8_t* Q = q + ((size_t)b * nq_cap + qi) * 32;

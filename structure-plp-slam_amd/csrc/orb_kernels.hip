@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
                                                        const int16_t* __restrict__ b0, const int16_t* __restrict__ b1) {
     constexpr int ROWS = 8;
     __shared__ __attribute__((aligned(16))) uint8_t tiles[4 * kRsRows * kRsPitch];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: strip bounds and row tables in scalar registers
     const int strip_x0 = blockIdx.x * 64, strip_y0 = (blockIdx.y * 4 + wv) * 32;
     if (strip_y0 >= dh) return;   // the whole wave (no workgroup barrier below)
     uint8_t* tile = tiles + wv * (kRsRows * kRsPitch);
@@ -424,72 +424,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                  L.w, L.h, (t % tiles_x) * kBlurTW, (t / tiles_x) * kBlurTH, taps.k);
 }
 
-// The same blur with the level table in the KERNEL ARGUMENTS (PLP_BLUR7_TAB=1; profiles/r04_tile_pipelining.md): finding a workgroup's level walks
-// lv[] in global memory -- up to eight dependent scalar loads before the first pixel load can be issued -- and then loads the level's record; here the
-// per-level fields are kernel arguments (one batch of scalar loads at the start) and the level comes from a chain of compares on registers.
-struct BlurLevelTab { int n; int cum[kMaxLevels], w[kMaxLevels], h[kMaxLevels], pitch[kMaxLevels]; unsigned off[kMaxLevels]; };
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_blur7t(OrbPlanes pl, uint8_t* __restrict__ blur_base, size_t blur_frame_stride,
-                                               BlurLevelTab T, BlurTaps taps) {
-    __shared__ BlurTileLds<3> S;
-    unsigned ut, uf;
-    xcd_frame_major(ut, uf);
-    const int tt = (int)ut, frame = (int)uf;
-    int level = 0, cum = 0, w = T.w[0], h = T.h[0], pitch = T.pitch[0];
-    unsigned off = T.off[0];
-#pragma unroll
-    for (int l = 1; l < kMaxLevels; ++l)
-        if (l < T.n && tt >= T.cum[l]) { level = l; cum = T.cum[l]; w = T.w[l]; h = T.h[l]; pitch = T.pitch[l]; off = T.off[l]; }
-    const int t = tt - cum, tiles_x = (w + kBlurTW - 1) / kBlurTW;
-    const uint8_t* src = level == 0 ? pl.l0 + (size_t)frame * pl.l0_frame_stride : pl.pyr + (size_t)frame * pl.pyr_frame_stride + off;
-    blur_tile<3>(S, src, level == 0 ? pl.l0_pitch : pitch, blur_base + (size_t)frame * blur_frame_stride + off, pitch, w, h, (t % tiles_x) * kBlurTW,
-                 (t / tiles_x) * kBlurTH, taps.k);
-}
-
-// The same blur by PERSISTENT workgroups (PLP_BLUR7_PERSIST=1; profiles/r04_tile_pipelining.md): workgroup g of G walks the tiles g, g + G, ... of the
-// XCD-major tile order, prefetching the next tile's pixels into registers while it computes the current one (blur_tile.hpp).
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_blur7p(OrbPlanes pl, uint8_t* __restrict__ blur_base, size_t blur_frame_stride,
-                                               const LevelDev* __restrict__ lv, int n_levels, BlurTaps taps, int tiles_per_frame, int B) {
-    __shared__ BlurTileLds<3> S;
-    const unsigned total = (unsigned)tiles_per_frame * (unsigned)B, G = gridDim.x, g = blockIdx.x;
-    // XCD k (workgroups with g % 8 == k) takes the k-th eighth of the frame-major tile list, as xcd_frame_major does for the one-tile kernel
-    const unsigned per_xcd = (total + 7u) / 8u, xcd = g & 7u, lane_g = g >> 3, stride = G >> 3;
-    auto job_of = [&](unsigned j, BlurJob& J) -> bool {
-        const unsigned logical = xcd * per_xcd + j;
-        if (j >= per_xcd || logical >= total) return false;
-        const int frame = (int)(logical / (unsigned)tiles_per_frame);
-        int t = (int)(logical - (unsigned)frame * (unsigned)tiles_per_frame), level = 0;
-        while (level + 1 < n_levels && t >= lv[level].blur_tiles) { t -= lv[level].blur_tiles; ++level; }
-        const LevelDev L = lv[level];
-        const int tiles_x = (L.w + kBlurTW - 1) / kBlurTW;
-        J.src = pl.level_ptr(frame, level, L); J.src_pitch = pl.level_pitch(level, L);
-        J.dst = blur_base + (size_t)frame * blur_frame_stride + L.off; J.dst_pitch = L.pitch;
-        J.w = L.w; J.h = L.h; J.tx0 = (t % tiles_x) * kBlurTW; J.ty0 = (t / tiles_x) * kBlurTH;
-        return true;
-    };
-    BlurJob J, Jn;
-    BlurPrefetch<3> F;
-    unsigned j = lane_g;
-    bool have = job_of(j, J);
-    if (have) blur_prefetch<3>(F, J);
-    while (have) {
-        blur_stage_prefetched<3>(S, F, J);
-        __syncthreads();
-        j += stride;
-        const bool have_n = job_of(j, Jn);
-        if (have_n) blur_prefetch<3>(F, Jn);                     // in flight through the two compute phases below
-        blur_tile_compute<3>(S, taps.k, [&](int r0, int c4, const uint32_t (&rows)[kBlurRS]) {
-            const int x = J.tx0 + c4;
-            if (x >= J.w) return;
-#pragma unroll
-            for (int rr = 0; rr < kBlurRS; ++rr) {
-                const int y = J.ty0 + r0 + rr;
-                if (y < J.h) *reinterpret_cast<uint32_t*>(J.dst + (size_t)y * J.dst_pitch + x) = rows[rr];
-            }
-        });
-        J = Jn; have = have_n;
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // K5+K7  orientation + rBRIEF + KeyPoint assembly, 16 lanes per selected key point (4 key points per wave64).
 // The first version spent a whole wave on one key point: 4.2 M waves of ~300 instructions each, three dependent memory
@@ -719,17 +653,8 @@ void launch_fast(hipStream_t st, const OrbPlanes& pl, const CellDesc* d_cells, i
 
 void launch_blur(hipStream_t st, const OrbPlanes& pl, uint8_t* blur, size_t blur_frame_stride, const LevelDev* d_lv,
                  int n_levels, int total_tiles, int B, const BlurTaps& taps, const LevelDev* h_lv) {
-    static const int blur_tab = [] { const char* e = getenv("PLP_BLUR7_TAB"); return e ? atoi(e) : 0; }();
-    if (blur_tab && h_lv) {
-        BlurLevelTab T{};
-        T.n = n_levels;
-        for (int l = 0, cum = 0; l < n_levels; ++l) { T.cum[l] = cum; cum += h_lv[l].blur_tiles; T.w[l] = h_lv[l].w; T.h[l] = h_lv[l].h; T.pitch[l] = h_lv[l].pitch; T.off[l] = (unsigned)h_lv[l].off; }
-        hipLaunchKernelGGL(k_blur7t, dim3(total_tiles, B), dim3(256), 0, st, pl, blur, blur_frame_stride, T, taps);
-        return;
-    }
-    static const int blur_persist = [] { const char* e = getenv("PLP_BLUR7_PERSIST"); return e ? atoi(e) : 0; }();   // experiment: n = workgroups per CU of the persistent form
-    if (blur_persist > 0 && (size_t)total_tiles * B >= 4096) hipLaunchKernelGGL(k_blur7p, dim3(256 * blur_persist), dim3(256), 0, st, pl, blur, blur_frame_stride, d_lv, n_levels, taps, total_tiles, B);
-    else hipLaunchKernelGGL(k_blur7, dim3(total_tiles, B), dim3(256), 0, st, pl, blur, blur_frame_stride, d_lv, n_levels, taps);
+    (void)h_lv;
+    hipLaunchKernelGGL(k_blur7, dim3(total_tiles, B), dim3(256), 0, st, pl, blur, blur_frame_stride, d_lv, n_levels, taps);
 }
 
 void launch_orient_rbrief(hipStream_t st, const OrbPlanes& pl, const uint8_t* blur, size_t blur_frame_stride,
@@ -749,7 +674,7 @@ void launch_orient_rbrief(hipStream_t st, const OrbPlanes& pl, const uint8_t* bl
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_stereo_match(OrbPlanes pl_l, OrbPlanes pl_r, const LevelDev* __restrict__ lv, StereoArgs A) {
     const int lane = threadIdx.x & 63, b = blockIdx.y;
-    const int il = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int il = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nl = A.cnt_l ? min(A.cnt_l[b], A.cap) : A.cap, nr = A.cnt_r ? min(A.cnt_r[b], A.cap) : A.cap;
     if (il >= A.cap) return;
     float* xr_out = A.x_right + (size_t)b * A.cap;

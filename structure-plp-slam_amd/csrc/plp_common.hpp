@@ -41,6 +41,7 @@ struct DevBuf {
         if (e == hipSuccess) bytes = n; else p = nullptr;
         return e;
     }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }   // (hipFree waits for the device's outstanding work)
     hipError_t upload(const void* src, size_t n, hipStream_t st) {
         hipError_t e = reserve(n);
         if (e != hipSuccess) return e;

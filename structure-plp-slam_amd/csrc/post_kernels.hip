@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void k_post_extract(PostArgs A) {
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_landmark_descriptor(const uint8_t* __restrict__ descs, const int32_t* __restrict__ offsets, int L,
                                                              int32_t* __restrict__ best_idx) {
-    const int lane = threadIdx.x & 63, l = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, l = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (l >= L) return;
     const int o0 = offsets[l], n = offsets[l + 1] - o0;
     if (n <= 0) { if (lane == 0) best_idx[l] = -1; return; }

@@ -23,10 +23,6 @@
 
 namespace plp {
 
-#ifdef PLP_SS_CHECK
-__device__ unsigned int g_ss_check[8 + 8 * 16];   // diagnostic build only: [0] = partner positions found outside their segment, then 16 records
-#endif
-
 // Two configurations of one body (seed_sort_impl.inc).  Batches: 4 waves per workgroup and a 4096-entry window (35 KB of LDS) -- alone that is the
 // slower kernel (6.0 against 5.0 ms per 2048 frames) but four such workgroups share a CU with each other and with the other streams' kernels, and
 // the STEP is what counts: 27.6 ms against 32.7 ms with 16 waves and 144 KB (profiles/r04_seed_sort.md).  Small batches (the single-frame call of
@@ -170,12 +166,3 @@ void launch_seed_sort_debug(hipStream_t st, uint32_t* ent, int n, int depth, uin
 }
 
 }  // namespace plp
-
-#ifdef PLP_SS_CHECK
-extern "C" int plp_debug_seed_sort_check(unsigned int* out, int n) {
-    unsigned int h[8 + 8 * 16];
-    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(plp::g_ss_check), sizeof(h)) != hipSuccess) return -1;
-    for (int i = 0; i < n && i < (int)(sizeof(h) / sizeof(h[0])); ++i) out[i] = h[i];
-    return 0;
-}
-#endif

@@ -101,6 +101,25 @@ def check_frame(h, b, K, g6, shift, sf, frame=None, orb_only=False, stable_order
     return bad
 
 
+def check_halo(h, K, tail_frames, orb_only=False, stable_order=False):
+    """The halo rows 0..HALO-1 of the feature arrays (what exchange_halo_into received) against the oracle's extraction of the frames they must hold:
+    tail_frames = the LAST `HALO` frames of the predecessor rank's block (the own block's at world size 1: the exchange is circular).  This is the part
+    of a sharded step that check_frame cannot see -- it takes the halo rows as given.  Returns a list of mismatch descriptions."""
+    bad = []
+    for j, frame in enumerate(tail_frames):
+        c = int(h["cnt"][j])
+        ok, od = O.OrbOracle(K).extract(frame)
+        if len(ok) != c or not np.array_equal(ok, h["kps"][j][:c]) or not np.array_equal(od, h["desc"][j][:c]):
+            bad.append(f"halo row {j}: key points / descriptors are not the predecessor's frame ({len(ok)} vs {c})")
+        if orb_only:
+            continue
+        l = int(h["lcnt"][j])
+        ora = O.LineOracle(frame, stable_order=stable_order)
+        if len(ora.keylsd) != l or not np.array_equal(ora.keylsd, h["kl"][j][:l]) or not np.array_equal(ora.lbd, h["lbd"][j][:l]):
+            bad.append(f"halo row {j}: key lines / LBD are not the predecessor's frame ({len(ora.keylsd)} vs {l})")
+    return bad
+
+
 def verify(ts, buf, frame_ids, frames_np=None, sf=None):
     """check the frames `frame_ids` of the step that filled feature set `buf` of tracker_step `ts` (the device must be idle);
     frames_np: [B, rows, cols] pixels of the block (None = matchers only).  Returns (n_verified, list of mismatches)."""

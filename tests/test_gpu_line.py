@@ -26,7 +26,7 @@ def compare(img, grow_waves=(0, 1, 3)):
     the device) and the stable one (definition D1)."""
     for order, stable in ((plp.SEED_ORDER_LIBSTDCXX, False), (plp.SEED_ORDER_STABLE, True)):
         ora = O.LineOracle(img, stable_order=stable)
-        for w in (grow_waves if stable else grow_waves[:2]):
+        for w in grow_waves:   # every waves-per-frame setting in BOTH seed orders (ADVICE r04)
             kl = compare_one(img, ora, w, order)
     return kl
 

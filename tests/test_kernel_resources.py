@@ -49,7 +49,7 @@ def test_every_kernel_was_seen_and_none_uses_scratch():
 def test_footprints_the_design_argues_with():
     # beside two growers per SIMD (2 x 147 -> 2 x 152 allotted of 512 VGPRs): 208 registers left
     (grow,) = find("k_lsd_growENS")
-    assert grow["VGPRs"] <= 152, grow
+    assert grow["VGPRs"] <= 120, grow             # 151 until round 5: the wave's frame index is declared wave-uniform, so every per-frame pointer is scalar (113)
     (mw,) = find("k_lsd_grow_mw")
     assert mw["VGPRs"] <= 176, mw                 # eight waves of a workgroup on four SIMDs: 2 x 176 <= 512
     # kernels that run at few waves per SIMD even alone: their footprint is their speed.  Beside two growers per SIMD a kernel of
