@@ -477,7 +477,9 @@ def main():
         # LSD seed order of the headline number (the reference's: std::sort as libstdc++ implements it) and the same steps in the other order
         "seed_order": args.seed_order, "other_seed_order": other,
         # frames of the LAST TIMED step whose features and four matcher results were recomputed by the CPU oracle and found identical
-        "verified_frames": verified,
+        # (at N > 1: summed over the ranks, every rank checks its own block; `verified_halo_rows` = the rows that came over the halo exchange, checked against
+        # the oracle's extraction of the predecessor rank's last two frames)
+        "verified_frames": verified, "verified_halo_rows": verified_halo,
     }
     out.update(extras)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # the CPU baseline is reported at N = 1 only

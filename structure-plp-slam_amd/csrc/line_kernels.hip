@@ -606,11 +606,12 @@ __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed
         }
         PLP_RSTAMP(3);   // acceptance loop
         if ((acc >> lane) & 1ull) {
-            const int pos = n_before + __popcll(acc & ((1ull << lane) - 1ull));
+            const int pos = n_before + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(acc >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)acc, 0u));   // accepted lanes below this one
             const uint32_t c = (uint32_t)nx | ((uint32_t)ny << 16);
             g.ring[pos & g.ring_mask] = c;
             set_used_t<MW>(g, np);
-            __hip_atomic_store(&g.reg[pos], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // HBM copy of the list
+            // HBM copy of the list (a 32-bit byte offset from the list's base, which is scalar in k_lsd_grow)
+            __hip_atomic_store(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(g.reg) + ((uint32_t)pos << 2)), c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         __builtin_amdgcn_wave_barrier();   // LDS operations of one wave complete in order: the next round's reads see these writes
         PLP_RSTAMP(4);   // appends, marks
@@ -924,12 +925,13 @@ __global__ __launch_bounds__(256) void k_lsd_grow(LinePlanes P, LsdParams lp, in
 #define PLP_PR(x)
 #endif
     int n_exact_tests = 0;
-    long long racc_v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #ifdef PLP_GROW_PROF_ROUND   // (tools/build_variant.sh rprof -DPLP_GROW_PROF_ROUND; python tools/grow_profile.py 2048: 'more' = cycles of {ring read, USED test, gather, acceptance loop, appends}, rounds)
+    long long racc_v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long* const racc = (P.prof != nullptr && b == 0) ? racc_v : nullptr;
 #else
     long long* const racc = nullptr;
-#endif (every s_memtime is a scalar-memory round trip the wave waits for)
+#endif
+    // phase clocks only for the frame that reports them (every s_memtime is a scalar-memory round trip the wave waits for)
     const bool prof_on = P.prof != nullptr && b == 0;
     auto tick = [&]() -> long long { return prof_on ? clock64() : 0ll; };
     const long long t_begin = tick();

@@ -10,6 +10,9 @@ band comes before it, in which case the reference's test decides all eligible la
 Rendering 2 (hand-scheduled block): the same with fused multiply-adds, taken only while NO eligible lane is inside the band;
 otherwise one decision by rendering 1, then back.
 
+Rendering 3 (round 5, settle_block): the whole round settled together from the start sum and verified lane by lane against each lane's own sum; kept only
+when every check holds, otherwise the loop (rendering 2 with rendering 1) runs unchanged.
+
 This is a model of the control logic (the device code itself is checked on the GPU by tests/test_gpu_line.py); it shows that
 both renderings are the reference's scan for any placement of band pixels and duplicates.
 """
@@ -96,7 +99,37 @@ def run_round(cand, pix, ang, cs, s, prec, band, hand_scheduled):
         accept(k)
 
 
-def random_round(rng, prec, band):
+def settle_block(cand, pix, cs, s, prec, band):
+    """The round settled together (round 5, region_grow's first block): A = the candidates that pass with certainty against the START sum, one per pixel; a chain over A
+    in lane order gives every lane the sum after the accepted lanes below it (same f32 additions, same order); every lane whose pixel nobody took is tested against ITS
+    sum and must decide as A says, none inside the band.  -> (accepted lanes, sum) or None (nothing kept: the loop runs as if the block did not exist)."""
+    c_pass, c_fail = f32(np.cos(prec - band)), f32(np.cos(prec + band))
+    live = [l for l in range(63) if cand[l]]
+    cos0 = {l: cos_fma(cs[l], s) for l in live}
+    if any(not cos0[l] >= c_pass and not cos0[l] < c_fail for l in live):
+        return None
+    p = [l for l in live if cos0[l] >= c_pass]
+    acc, shadow, lane_sum = [], set(), {l: s for l in range(63)}
+    while p:
+        k = p[0]
+        acc.append(k)
+        s = (f32(s[0] + cs[k][0]), f32(s[1] + cs[k][1]))
+        for l in range(k + 1, 63):
+            lane_sum[l] = s
+        same = {l for l in range(63) if pix[l] == pix[k]}
+        shadow |= same
+        p = [l for l in p if l not in same]
+    checked = [l for l in live if l not in shadow] + acc
+    for l in checked:
+        c = cos_fma(cs[l], lane_sum[l])
+        if not c >= c_pass and not c < c_fail:
+            return None
+        if (c >= c_pass) != (l in acc):
+            return None
+    return acc, s
+
+
+def random_round(rng, prec, band, p_near=0.35):
     # seven region points close together on a grid: their 3x3 neighbourhoods overlap (the same pixel in several lanes)
     base = np.array([50, 50]) + rng.integers(-1, 2, (7, 2)).cumsum(0)
     pix, cand = [], []
@@ -112,7 +145,7 @@ def random_round(rng, prec, band):
     per_pixel = {}
     for q in set(pix):
         kind = rng.uniform()
-        off = rng.uniform(-0.8 * prec, 0.8 * prec) if kind < 0.4 else rng.choice([-1, 1]) * (prec + rng.uniform(-3 * band, 3 * band)) if kind < 0.75 \
+        off = rng.uniform(-0.8 * prec, 0.8 * prec) if kind < 0.4 else rng.choice([-1, 1]) * (prec + rng.uniform(-3 * band, 3 * band)) if kind < 0.4 + p_near \
             else rng.uniform(prec * 1.2, np.pi)
         deg = F(np.degrees((t0 + off) % (2 * np.pi)))
         per_pixel[q] = float(deg) * (np.pi / 180)
@@ -126,14 +159,22 @@ def test_both_renderings_of_a_round_are_the_reference_scan(prec):
     band, lo, hi = constants_from_source()
     assert lo <= prec < hi
     rng = np.random.default_rng(int(prec * 1000))
-    multi, band_rounds = 0, 0
-    for _ in range(400):
-        cand, pix, ang, cs, s = random_round(rng, prec, band)
+    multi, band_rounds, settled, settled_multi = 0, 0, 0, 0
+    for it in range(800):
+        # the first 400 rounds are adversarial (a third of the pixels within three bands of the tolerance: the block rarely keeps its result there),
+        # the second 400 look like an image (few pixels near the tolerance)
+        cand, pix, ang, cs, s = random_round(rng, prec, band, 0.35 if it < 400 else 0.01)
         want = reference_round(cand, pix, ang, cs, s, prec)
         for hand in (False, True):
             got = run_round(cand, pix, ang, cs, s, prec, band, hand)
             assert got[0] == want[0] and got[1] == want[1], (hand, got, want)
+        st = settle_block(cand, pix, cs, s, prec, band)      # whenever the block keeps its result, it is the reference's
+        if st is not None:
+            assert st[0] == want[0] and st[1] == want[1], (st, want)
+            settled += 1
+            settled_multi += len(want[0]) >= 2
         multi += len(want[0]) >= 3
         c_pass, c_fail = f32(np.cos(prec - band)), f32(np.cos(prec + band))
         band_rounds += any(cand[l] and not cos_sep(cs[l], s) >= c_pass and not cos_sep(cs[l], s) < c_fail for l in range(63))
     assert multi > 50 and band_rounds > 20   # rounds with several acceptances and rounds with band pixels both occur
+    assert settled > 150 and settled_multi > 60   # and the block does settle rounds, several acceptances among them
