@@ -135,8 +135,8 @@ plp_status build_geometry_impl(plp_orb* c, int rows, int cols) {
         while ((1 << nb) < n_init) ++nb;
         L.sort_lo = 2 * (kQtDepth - d_eff);
         L.sort_hi = 2 * kQtDepth + nb;
-        if (L.n_cells > 2048 || L.sel_cap > 2048 || n_init > 32)
-            return set_error(PLP_ERR_UNSUPPORTED, "frame/keypoint budget exceeds the quadtree kernel limits (quota per level <= 1022)");
+        if (L.n_cells > 2048 || 3 * L.quota + 8 > kQtMaxNodesLds || n_init > 32)
+            return set_error(PLP_ERR_UNSUPPORTED, "frame/keypoint budget exceeds the quadtree kernel limits (quota per level <= 1960, 2048 cells per level, 32 initial nodes)");
     }
     PLP_HIP(c->d_lv.upload(c->h_lv.data(), sizeof(LevelDev) * nl, c->stream));
     PLP_HIP(c->d_cells.upload(c->geo.cells.data(), sizeof(CellDesc) * c->geo.cells.size(), c->stream));

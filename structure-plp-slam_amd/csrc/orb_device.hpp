@@ -8,6 +8,11 @@
 
 namespace plp {
 
+// k_quadtree keeps 26 bytes of node state per list entry (+ 8 KB of radix counters / key cache) in LDS and a level's lists never hold more than
+// 3 * quota + 8 nodes: 5 888 nodes is what a CU's 160 KB hold, i.e. a per-level quota of up to 1 960 key points (K = 6 000 at 8 levels, K = 2 000 at
+// 2 levels; until round 5 the bound was 2 048 nodes).  Beyond that plp_orb_create refuses (the reference's quota of a single level at K = 2 000 does).
+constexpr int kQtMaxNodesLds = 5888;
+
 // Per-level constants as seen by the kernels (array of n_levels in HBM + a host copy).
 struct LevelDev {
     int w, h, pitch;        // level size, row pitch in the pyramid / blur planes

@@ -17,7 +17,7 @@
 
 namespace plp {
 
-constexpr int kQtMaxNodes = 2048;            // hard upper bound of the node arrays (quota up to ~680 per level)
+constexpr int kQtMaxNodes = kQtMaxNodesLds;   // hard upper bound of the node arrays: what 160 KB of LDS hold (orb_device.hpp; 3 * quota + 8 nodes: quota up to 1960 per level)
 constexpr int kQtSegLds = 256;               // radix counters for up to 256 wave-sized segments live in LDS (n <= 16384) ...
 constexpr int kQtKeyCache = 2048;            // ... and share it with the sorted-key cache; larger levels use the HBM scratch
 

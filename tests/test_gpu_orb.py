@@ -97,6 +97,21 @@ def test_parameter_variants(golden_dir):
     compare_full(img, 300, ini_fast_thr=40, min_fast_thr=15)
 
 
+def test_large_per_level_quotas(golden_dir):
+    """feature/orb_params.cc:40-54 accepts any max_num_keypts / num_levels.  Until round 5 a per-level quota above ~680-1022 was refused (the quadtree kernel's node
+    arrays); now it takes what 160 KB of LDS hold: quota <= 1960.  K = 2000 on two levels (quota 1091 + 909) and K = 6000 on eight (1304 on level 0) against the oracle,
+    on a corner-dense frame so that the quotas are actually filled; a quota beyond the bound is still refused loudly, never computed wrongly."""
+    rng = np.random.default_rng(5)
+    dense = rng.integers(0, 256, (480, 640), dtype=np.uint8)
+    k2, _ = compare_full(dense, 2000, num_levels=2)
+    assert len(k2) >= 1900
+    k6, _ = compare_full(dense, 6000)
+    assert len(k6) >= 5000
+    compare_full(np.asarray(Image.open(golden_dir / "equirect2_crop_640x480.png")), 6000)
+    with pytest.raises(Exception, match="limits"):
+        plp.orb_extractor(2000, num_levels=1).extract(dense)      # one level would need a quota of 2000
+
+
 def test_setters_reinitialize(golden_dir):
     img = np.asarray(Image.open(golden_dir / "equirect1_crop_640x480.png"))
     ex = plp.orb_extractor(1000)

@@ -152,7 +152,7 @@ def main():
         try:
             ex = plp.orb_extractor(K, sfac, nl, ini, mn)
             got = ex.extract(img, mask)
-        except Exception as e:   # documented kernel limits (quota per level <= 1022, ...): refused loudly, never wrong
+        except Exception as e:   # documented kernel limits (quota per level <= 1960, ...): refused loudly, never wrong
             if "limits" not in str(e) and "too small" not in str(e) and "overflow" not in str(e):
                 raise
             skipped = locals().get("skipped", 0) + 1
