@@ -1,3 +1,8 @@
+// Diagnostic (CPU only, test infrastructure: it includes the oracle's LSD restatement): region growing of replay frames in the ROUND STRUCTURE of k_lsd_grow
+// (7 region points x 3 x 3 neighbours per round) -- rounds, queue lengths, acceptances per round, region sizes, how often the next batch is known a round early
+// (VERDICT r04 item 1b), how often the set accepted under the start angle equals the sequential result (bulk acceptance), lone seeds.  profiles/r05_lsd_grow.md quotes it.
+//   python -c "import importlib,sys; sys.path.insert(0,'.'); importlib.import_module('structure-plp-slam_amd.synth').replay(1234, 8).tofile('/tmp/frames.bin')"
+//   g++ -O2 -std=c++17 -Ioracle -o /tmp/grow_round_stats tools/experiments/grow_round_stats.cpp && /tmp/grow_round_stats /tmp/frames.bin
 #define private public
 #include "lsd_restated.hpp"
 #undef private
@@ -15,6 +20,8 @@ struct Stats {
     long first_rounds = 0, first_round_noacc = 0;
     long dup_cand = 0;
     long rounds_small_S = 0;
+    long bulk_ok[16] = {0}, bulk_bad[16] = {0};
+    long seeds_static_lone = 0, seeds_lone_dynamic = 0, seeds_total = 0, seeds_static_nonlone_but_single = 0;
 };
 static Stats st;
 // batched simulation of region_grow: identical result to the sequential one (the kernel's round structure)
@@ -45,6 +52,11 @@ void grow_sim(Lsd& L, int sx, int sy, std::vector<Lsd::RegionPoint>& reg, double
                 if (std::find(seen.begin(), seen.end(), p) != seen.end()) ++st.dup_cand; else seen.push_back(p);
             }
         }
+        // speculation: the candidates aligned with the angle at the START of the round (one per pixel)
+        std::vector<int> spec;
+        for (int p : seen) if (L.is_aligned(p % w, p / w, reg_angle, prec)) spec.push_back(p);
+        std::sort(spec.begin(), spec.end());
+        const size_t n_start = reg.size();
         int a = 0;
         for (size_t s = 0; s < nb; ++s) {
             const int px = reg[i + s].x, py = reg[i + s].y;
@@ -63,6 +75,13 @@ void grow_sim(Lsd& L, int sx, int sy, std::vector<Lsd::RegionPoint>& reg, double
                     }
                 }
         }
+        {
+            std::vector<int> got;
+            for (size_t k = n_start; k < reg.size(); ++k) got.push_back(reg[k].y * w + reg[k].x);
+            std::sort(got.begin(), got.end());
+            const int m = std::min<int>(15, (int)std::max(got.size(), spec.size()));
+            if (got == spec) st.bulk_ok[m]++; else st.bulk_bad[m]++;
+        }
         st.acc += a; st.acc_hist[std::min(63, a)]++;
         if (i == 0) { ++st.first_rounds; if (a == 0) ++st.first_round_noacc; }
         prev_known = n0;
@@ -72,10 +91,10 @@ void grow_sim(Lsd& L, int sx, int sy, std::vector<Lsd::RegionPoint>& reg, double
     int cls = reg.size() <= 1 ? 1 : reg.size() <= 2 ? 2 : reg.size() <= 4 ? 4 : reg.size() <= 8 ? 8 : reg.size() <= 16 ? 16 : reg.size() <= 32 ? 32 : reg.size() <= 64 ? 64 : reg.size() <= 128 ? 128 : reg.size() <= 256 ? 256 : 100000;
     st.reg_rounds[cls] += my_rounds; st.reg_count[cls]++; st.reg_pix[cls] += reg.size();
 }
-int main() {
+int main(int argc, char** argv) {
     const int H = 480, W = 640, NF = 8;
     std::vector<uint8_t> buf((size_t)H * W * NF);
-    FILE* f = fopen("/tmp/gs/frames.bin", "rb"); if (fread(buf.data(), 1, buf.size(), f) != buf.size()) return 1; fclose(f);
+    FILE* f = fopen(argc > 1 ? argv[1] : "/tmp/frames.bin", "rb"); if (!f) { printf("usage: grow_round_stats frames.bin (8 frames of 480 x 640 bytes)\n"); return 2; } if (fread(buf.data(), 1, buf.size(), f) != buf.size()) return 1; fclose(f);
     long total_lines = 0;
     for (int fr = 0; fr < NF; ++fr) {
         Image img(H, W); std::copy(buf.begin() + (size_t)fr * H * W, buf.begin() + (size_t)(fr + 1) * H * W, img.data.begin());
@@ -93,6 +112,16 @@ int main() {
         for (const auto& op : L.ordered_) {
             if (L.used_[(size_t)op.y * L.w_ + op.x] == 0 && L.angles_[(size_t)op.y * L.w_ + op.x] != Lsd::NOTDEF) {
                 double reg_angle;
+                {   // static alignment of the 8 neighbours with the seed's own angle (defined pixels only)
+                    int n_al = 0, n_al_unused = 0;
+                    const double a0 = L.angles_[(size_t)op.y * L.w_ + op.x];
+                    for (int yy = op.y - 1; yy <= op.y + 1; ++yy) for (int xx = op.x - 1; xx <= op.x + 1; ++xx) {
+                        if ((xx == op.x && yy == op.y) || xx < 0 || yy < 0 || xx >= L.w_ || yy >= L.h_) continue;
+                        if (L.is_aligned(xx, yy, a0, prec)) { ++n_al; if (L.used_[(size_t)yy * L.w_ + xx] != 1) ++n_al_unused; }
+                    }
+                    ++st.seeds_total;
+                    if (n_al == 0) ++st.seeds_static_lone; else if (n_al_unused == 0) ++st.seeds_lone_dynamic;
+                }
                 grow_sim(L, op.x, op.y, reg, reg_angle, prec);
                 if (reg.size() < min_reg_size) continue;
                 Lsd::Rect rec;
@@ -107,6 +136,10 @@ int main() {
     printf("first rounds %.0f of which no acceptance %.0f; prefetchable rounds (full batch known a round earlier) %.0f partial %.0f\n", st.first_rounds / 8.0, st.first_round_noacc / 8.0, st.rounds_prefetchable / 8.0, st.rounds_partial / 8.0);
     printf("queue length at round start: "); for (int q = 1; q < 64; ++q) if (st.rounds_by_q[q]) printf("%d:%.0f ", q, st.rounds_by_q[q] / 8.0); printf("\n");
     printf("acceptances per round: "); for (int q = 0; q < 64; ++q) if (st.acc_hist[q]) printf("%d:%.0f ", q, st.acc_hist[q] / 8.0); printf("\n");
+    printf("speculation (set accepted under the start angle == sequential set), by max(set sizes): ");
+    for (int m = 0; m < 16; ++m) if (st.bulk_ok[m] + st.bulk_bad[m]) printf("%d: %.0f ok %.0f bad | ", m, st.bulk_ok[m] / 8.0, st.bulk_bad[m] / 8.0);
+    printf("\n");
+    printf("seeds grown %.0f: no neighbour aligned with the seed's own angle (static) %.0f, aligned neighbours all USED at its turn %.0f\n", st.seeds_total / 8.0, st.seeds_static_lone / 8.0, st.seeds_lone_dynamic / 8.0);
     for (auto& kv : st.reg_count) printf("regions <= %d px: %.0f regions, %.0f px, %.0f rounds\n", kv.first, kv.second / 8.0, st.reg_pix[kv.first] / 8.0, st.reg_rounds[kv.first] / 8.0);
     return 0;
 }
