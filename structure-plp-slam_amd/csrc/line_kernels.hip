@@ -511,7 +511,7 @@ __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed
         // unit only evaluates the two compares of the guard-banded test
         unsigned long long candmask = __builtin_amdgcn_ballot_w64(cand), gt = ~0ull;
         while (true) {
-            // ---- the certain decisions, hand-scheduled: 28 instructions per acceptance where the compiler's rendering of the
+            // ---- the certain decisions, hand-scheduled: 26 instructions per acceptance where the compiler's rendering of the
             // same loop took 40 (a "continue" flag kept as a lane mask, wait states for packed f32 results, the test for "band
             // pixel before the first certain one").  The block decides lanes only while NO eligible lane is inside the guard
             // band; otherwise (`careful`) one decision is taken by the C++ below and the block is entered again.  Its test uses
@@ -523,9 +523,9 @@ __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed
             // resumes.  EXEC is all ones here: every branch around this point is wave-uniform.
             int careful = 1;
             if (banded) {
-                const int n0 = nreg;
+                const unsigned long long acc0 = acc;
                 float ta, tb;
-                unsigned long long t_elig, t_p, t_f, t_bit;
+                unsigned long long t_elig, t_p, t_f;
                 int t_k, t_ap, t_rx, t_ry;
                 asm volatile(
                     "Lgrow_top_%=:\n\t"
@@ -548,13 +548,11 @@ __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed
                     "v_readlane_b32 %[ap], %[np], %[k]\n\t"
                     "v_readlane_b32 %[rx], %[cx], %[k]\n\t"
                     "v_readlane_b32 %[ry], %[cy], %[k]\n\t"
-                    "s_lshl_b64 %[bit], 1, %[k]\n\t"
+                    "s_bitset1_b64 %[acc], %[k]\n\t"
                     "v_cmp_eq_u32 vcc, %[ap], %[np]\n\t"
-                    "s_or_b64 %[acc], %[acc], %[bit]\n\t"
-                    "s_add_i32 %[nreg], %[nreg], 1\n\t"
+                    "s_lshl_b64 %[gt], -2, %[k]\n\t"
                     "v_add_f32 %[sx], %[rx], %[sx]\n\t"
                     "v_add_f32 %[sy], %[ry], %[sy]\n\t"
-                    "s_lshl_b64 %[gt], -2, %[k]\n\t"
                     "s_andn2_b64 %[cand], %[cand], vcc\n\t"
                     "s_branch Lgrow_top_%=\n"
                     "Lgrow_band_%=:\n\t"
@@ -564,12 +562,12 @@ __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed
                     "s_mov_b32 %[careful], 0\n"
                     "Lgrow_end_%=:\n\t"
                     "s_nop 4"
-                    : [sx] "+v"(sumdx), [sy] "+v"(sumdy), [cand] "+s"(candmask), [gt] "+s"(gt), [acc] "+s"(acc), [nreg] "+s"(nreg),
+                    : [sx] "+v"(sumdx), [sy] "+v"(sumdy), [cand] "+s"(candmask), [gt] "+s"(gt), [acc] "+s"(acc),
                       [careful] "=&s"(careful), [a] "=&v"(ta), [b] "=&v"(tb), [elig] "=&s"(t_elig), [p] "=&s"(t_p), [f] "=&s"(t_f),
-                      [bit] "=&s"(t_bit), [k] "=&s"(t_k), [ap] "=&s"(t_ap), [rx] "=&s"(t_rx), [ry] "=&s"(t_ry)
+                      [k] "=&s"(t_k), [ap] "=&s"(t_ap), [rx] "=&s"(t_rx), [ry] "=&s"(t_ry)
                     : [cx] "v"(ncs.x), [cy] "v"(ncs.y), [np] "v"(np), [cp] "s"(s_cpass), [cf] "s"(s_cfail)
                     : "vcc", "scc");
-                if (nreg != n0) theta_valid = false;
+                if (acc != acc0) theta_valid = false;
             }
             if (!careful) break;
             // ---- one decision the careful way (an eligible pixel is inside the band, or the tolerance has no band)
@@ -594,13 +592,13 @@ __device__ int region_grow(const GrowCtx& g, int seed, bool have_deg, float seed
             const float ccos = bcast_f(ncs.x, k), csin = bcast_f(ncs.y, k);
             const int ap = bcast_i(np, k);
             acc |= 1ull << k;
-            ++nreg;
             sumdx = __fadd_rn(sumdx, ccos);
             sumdy = __fadd_rn(sumdy, csin);
             theta_valid = false;
             gt = ~((2ull << k) - 1ull);                                       // lanes above k
             candmask &= ~__builtin_amdgcn_ballot_w64(np == ap);              // the same pixel seen from a later point of the batch
         }
+        nreg = n_before + __popcll(acc);   // (the block keeps the accepted SET; the count follows from it: one scalar instruction per acceptance less)
         if (MW) {   // give up before anything of this round is written or marked
             if (gave_up || nreg > list_cap || (acc & __builtin_amdgcn_ballot_w64(foreign))) { gave_up = true; nreg = n_before; acc = 0; }
         }
