@@ -83,3 +83,17 @@ def test_checker_accepts_the_oracle_chain_and_sees_a_corrupted_match():
     h["m"][1][2, int(np.argmax(h["m"][1][2] >= 0))] += 1
     h["n"][3][1] += 1
     assert len(BC.check_frame(h, 2, K, g6, SHIFT, sf)) == 1 and len(BC.check_frame(h, 1, K, g6, SHIFT, sf)) == 1
+
+
+def test_halo_checker_accepts_the_predecessors_tail_and_sees_a_wrong_or_stale_row():
+    """check_halo (bench.py --verify at N > 1): the halo rows 0..HALO-1 must be the oracle's extraction of the predecessor rank's last two frames.  The fabricated
+    step is circular (rows 0..1 = the block's own tail), so its own last two frames are the right answer, any other frames are not, and a damaged row is seen."""
+    frames = synth.replay(12, 3, 480, 640)
+    h = fabricate(frames)
+    assert BC.check_halo(h, K, frames[-HALO:]) == []
+    assert len(BC.check_halo(h, K, frames[:HALO])) >= 2                      # the rows of some other frames: both feature kinds of at least one row differ
+    h["desc"][1, 3, 0] ^= 1
+    bad = BC.check_halo(h, K, frames[-HALO:])
+    assert len(bad) == 1 and "halo row 1" in bad[0]
+    h["lcnt"][0] -= 1
+    assert len(BC.check_halo(h, K, frames[-HALO:])) == 2
