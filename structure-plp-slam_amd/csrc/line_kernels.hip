@@ -682,7 +682,7 @@ __device__ void region2rect(const GrowCtx& g, int nreg, double reg_angle, double
 // The ~55 rectangle fits per frame that follow a shrink step of reduce_region_radius also take the fit that keeps the points in registers, reading
 // the coordinates from the reordered list (FROM_LIST): the general path (centroid_sums + region2rect) costs nine broadcasts and adds per point.  Same
 // additions in the same order by construction (rect_from_ring == centroid_sums + region2rect is what the first fits already rely on).  Round 5:
-// k_lsd_grow 12.05 -> 11.75 ms per 2048 frames (155 VGPRs against 151: still three waves per SIMD), line tests + fuzz bit-exact.
+// k_lsd_grow 12.05 -> 11.75 ms per 2048 frames for four registers more, line tests + fuzz bit-exact.
 constexpr int kRingPts = 4;   // points per lane the fit from the ring keeps in registers: regions up to 64 * kRingPts points take it
 // FROM_LIST: the coordinates come from the HBM copy of the list instead of the ring (after reduce_region_radius has reordered the list; the ring still
 // serves as scratch).
