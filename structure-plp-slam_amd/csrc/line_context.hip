@@ -276,7 +276,7 @@ plp_status plp_line_last_batch_status(plp_line* c) {
     if (s[0] & 1) return set_error(PLP_ERR_CAPACITY, "a frame produced more lines than `cap`; output truncated");
     if (s[0] & 4) return set_error(PLP_ERR_OVERFLOW, "more LSD segments than the per-frame capacity");
     if (s[0] & 16) return set_error(PLP_ERR_HIP, "region growing with several waves per frame timed out in a wait (protocol error, please report the frame)");
-    if (s[0] & 32) return set_error(PLP_ERR_OVERFLOW, "the exact seed sort ran out of queue space (please report the frame)");
+    if (s[0] & 32) return set_error(PLP_ERR_OVERFLOW, "the exact seed sort stopped short: a queue of its LDS ran out of space, or a partner position lay outside its segment and the swap was skipped (the seed order of this batch is not guaranteed; please report the frame)");
     return PLP_OK;
 }
 
@@ -319,7 +319,7 @@ plp_status plp_line_extract(plp_line* c, const uint8_t* img, int32_t rows, int32
     PLP_HIP(hipMemcpy(s, c->status.p, 16, hipMemcpyDeviceToHost));
     if (s[0] & 4) return set_error(PLP_ERR_OVERFLOW, "more LSD segments than the per-frame capacity");
     if (s[0] & 16) return set_error(PLP_ERR_HIP, "region growing with several waves per frame timed out in a wait (protocol error, please report the frame)");
-    if (s[0] & 32) return set_error(PLP_ERR_OVERFLOW, "the exact seed sort ran out of queue space (please report the frame)");
+    if (s[0] & 32) return set_error(PLP_ERR_OVERFLOW, "the exact seed sort stopped short: a queue of its LDS ran out of space, or a partner position lay outside its segment and the swap was skipped (the seed order of this batch is not guaranteed; please report the frame)");
     return PLP_OK;
 }
 
@@ -483,7 +483,7 @@ plp_status plp_seed_introsort_debug(int32_t device, uint32_t* entries, int64_t n
         PLP_HIP(hipMemcpy(h.data(), dbg.p, h.size() * 4, hipMemcpyDeviceToHost));
         if (FILE* f = fopen(getenv("PLP_SEED_SORT_DBG_FILE"), "wb")) { fwrite(h.data(), 4, h.size(), f); fclose(f); }
     }
-    if (s & 32) return set_error(PLP_ERR_OVERFLOW, "the exact seed sort ran out of queue space");
+    if (s & 32) return set_error(PLP_ERR_OVERFLOW, "the exact seed sort stopped short (queue space, or a partner position outside its segment)");
     return PLP_OK;
 }
 
