@@ -181,6 +181,36 @@ template <int R> __device__ __forceinline__ void blur_stage_prefetched(BlurTileL
 }
 
 
+// Staging of a tile whose 144-byte rows lie inside the image in x (tx0 >= 8 and tx0 + 136 <= w: three tile columns in five of a 640-wide level): every dword
+// is a whole aligned dword of the source, so there are no range checks and no byte-wise patches, the (row, dword) of a thread's q-th load follows from its first by
+// additions (256 = 7 x 36 + 4) instead of a division per load, rows are reflected only where the tile touches the top or bottom border (wave-uniform), and the
+// address is a 32-bit offset from the plane's base.  Half of the blur kernels' vector instructions were this bookkeeping (k_blur7: ~230 of 460 per wave); the
+// bytes that reach LDS are the same.
+template <int R>
+__device__ __forceinline__ void blur_stage_inside_x(BlurTileLds<R>& S, const uint8_t* __restrict__ src, int src_pitch, int h, int tx0, int ty0) {
+    constexpr int IW = BlurTileLds<R>::IW, IH = BlurTileLds<R>::IH, DW = IW / 4, N = IH * DW, NPRE = (N + 255) / 256;
+    constexpr int QR = 256 / DW, QD = 256 % DW;
+    static_assert((NPRE - 1) * QD + DW - 1 < 2 * DW, "a thread's dword index wraps at most once per step");
+    const int tid = threadIdx.x;
+    const int r0 = tid / DW, d0 = tid - r0 * DW;
+    const bool rows_inside = ty0 >= R && ty0 + kBlurTH + R <= h;
+    const int xb = tx0 - kBlurPad;
+    uint32_t v[NPRE]; int lo[NPRE];
+#pragma unroll
+    for (int q = 0; q < NPRE; ++q) {
+        int d = d0 + QD * q, r = r0 + QR * q;
+        if (d >= DW) { d -= DW; ++r; }
+        int y = ty0 + r - R;
+        if (!rows_inside) y = blur_reflect101(y, h);
+        lo[q] = __mul24(r, IW) + 4 * d;
+        const bool live = (q + 1) * 256 <= N || tid + 256 * q < N;
+        v[q] = live ? *reinterpret_cast<const uint32_t*>(src + (uint32_t)(__mul24(y, src_pitch) + xb + 4 * d)) : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < NPRE; ++q)
+        if ((q + 1) * 256 <= N || tid + 256 * q < N) *reinterpret_cast<uint32_t*>(&S.in[lo[q]]) = v[q];
+}
+
 // Core: stage, horizontal pass, vertical pass; every thread ends with the blurred bytes of its 4 columns x 4 rows (one dword per
 // row, tile-local rows r0..r0+3, columns c4..c4+3) and hands them to emit(r0, c4, rows).  The tile origin may lie outside the image
 // (tx0 a multiple of 4, possibly negative): the blur is then evaluated on the REFLECT_101 extension of the source, which for a
@@ -193,7 +223,8 @@ __device__ __forceinline__ void blur_tile_core(BlurTileLds<R>& S, const uint8_t*
     // ---- stage input rows [ty0-R, ty0+TH+R) x columns [tx0-PAD, tx0+TW+PAD): every thread ISSUES all its loads (6 whole dwords inside the image, and
     // on border tiles 2 dwords assembled byte-wise around x = 0 / x = w), then stores them to LDS.  Until round 4 this was a loop of load -> wait ->
     // LDS store: six serialized memory round trips per tile, which is what every kernel built on this tile was waiting for (profiles/r04_tile_pipelining.md).
-    {
+    if (tx0 >= kBlurPad && tx0 + kBlurTW + kBlurPad <= w) blur_stage_inside_x<R>(S, src, src_pitch, h, tx0, ty0);   // (wave-uniform)
+    else {
         const BlurJob J{src, nullptr, src_pitch, 0, w, h, tx0, ty0};
         BlurPrefetch<R> F;
         blur_prefetch<R>(F, J);
