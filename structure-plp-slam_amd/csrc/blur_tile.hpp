@@ -131,15 +131,31 @@ template <int R> struct BlurPrefetch {
     static constexpr int NPRE = (IH * DW + 255) / 256, NPATCH = (IH * 8 + 255) / 256;
     uint32_t pre[NPRE], patch[NPATCH];
 };
-// issue the loads of a tile (whole dwords inside the image; the dwords that straddle the image border assembled byte-wise, border tiles only)
+// (row, dword) of a thread's q-th staging slot: slot i = tid + 256 q of the IH x DW dwords, by additions from the thread's first (256 = QR x DW + QD) instead of a
+// division per slot
+template <int R> struct BlurSlot {
+    static constexpr int DW = BlurTileLds<R>::IW / 4, QR = 256 / DW, QD = 256 % DW;
+    static_assert((BlurPrefetch<R>::NPRE - 1) * QD + DW - 1 < 2 * DW, "a thread's dword index wraps at most once per step");
+    int r0, d0;
+    __device__ __forceinline__ BlurSlot() { const int tid = threadIdx.x; r0 = tid / DW; d0 = tid - r0 * DW; }
+    __device__ __forceinline__ void at(int q, int& r, int& d) const { d = d0 + QD * q; r = r0 + QR * q; if (d >= DW) { d -= DW; ++r; } }
+};
+// issue the loads of a tile (whole dwords inside the image; the dwords that straddle the image border assembled byte-wise, border tiles only).  Rows are
+// reflected only where the tile touches the top or bottom border (wave-uniform); addresses are 32-bit offsets from the plane's base.
 template <int R> __device__ __forceinline__ void blur_prefetch(BlurPrefetch<R>& F, const BlurJob& J) {
     constexpr int IW = BlurTileLds<R>::IW, IH = BlurTileLds<R>::IH, DW = IW / 4;
     const int tid = threadIdx.x;
+    const BlurSlot<R> slot;
+    const bool rows_inside = J.ty0 >= R && J.ty0 + kBlurTH + R <= J.h;
 #pragma unroll
     for (int q = 0; q < BlurPrefetch<R>::NPRE; ++q) {
-        const int i = tid + 256 * q, r = i / DW, d = i - r * DW, x = J.tx0 - kBlurPad + 4 * d;
+        int r, d;
+        slot.at(q, r, d);
+        const int x = J.tx0 - kBlurPad + 4 * d;
+        int y = J.ty0 + r - R;
+        if (!rows_inside) y = blur_reflect101(y, J.h);
         F.pre[q] = 0u;
-        if (i < IH * DW && x >= 0 && x + 3 < J.w) F.pre[q] = *reinterpret_cast<const uint32_t*>(J.src + (size_t)blur_reflect101(J.ty0 + r - R, J.h) * J.src_pitch + x);
+        if (tid + 256 * q < IH * DW && x >= 0 && x + 3 < J.w) F.pre[q] = *reinterpret_cast<const uint32_t*>(J.src + (uint32_t)(__mul24(y, J.src_pitch) + x));
     }
     const int dr0 = (J.w - 3 - (J.tx0 - kBlurPad) + 3) >> 2;
     if (J.tx0 <= 0 || dr0 < DW) {
@@ -163,10 +179,13 @@ template <int R> __device__ __forceinline__ void blur_prefetch(BlurPrefetch<R>& 
 template <int R> __device__ __forceinline__ void blur_stage_prefetched(BlurTileLds<R>& S, const BlurPrefetch<R>& F, const BlurJob& J) {
     constexpr int IW = BlurTileLds<R>::IW, IH = BlurTileLds<R>::IH, DW = IW / 4;
     const int tid = threadIdx.x;
+    const BlurSlot<R> slot;
 #pragma unroll
     for (int q = 0; q < BlurPrefetch<R>::NPRE; ++q) {
-        const int i = tid + 256 * q, r = i / DW, d = i - r * DW, x = J.tx0 - kBlurPad + 4 * d;
-        if (i < IH * DW && x >= 0 && x + 3 < J.w) *reinterpret_cast<uint32_t*>(&S.in[r * IW + 4 * d]) = F.pre[q];
+        int r, d;
+        slot.at(q, r, d);
+        const int x = J.tx0 - kBlurPad + 4 * d;
+        if (tid + 256 * q < IH * DW && x >= 0 && x + 3 < J.w) *reinterpret_cast<uint32_t*>(&S.in[__mul24(r, IW) + 4 * d]) = F.pre[q];
     }
     const int dr0 = (J.w - 3 - (J.tx0 - kBlurPad) + 3) >> 2;
     if (J.tx0 <= 0 || dr0 < DW) {
@@ -183,23 +202,21 @@ template <int R> __device__ __forceinline__ void blur_stage_prefetched(BlurTileL
 
 // Staging of a tile whose 144-byte rows lie inside the image in x (tx0 >= 8 and tx0 + 136 <= w: three tile columns in five of a 640-wide level): every dword
 // is a whole aligned dword of the source, so there are no range checks and no byte-wise patches, the (row, dword) of a thread's q-th load follows from its first by
-// additions (256 = 7 x 36 + 4) instead of a division per load, rows are reflected only where the tile touches the top or bottom border (wave-uniform), and the
+// additions (BlurSlot) instead of a division per load, rows are reflected only where the tile touches the top or bottom border (wave-uniform), and the
 // address is a 32-bit offset from the plane's base.  Half of the blur kernels' vector instructions were this bookkeeping (k_blur7: ~230 of 460 per wave); the
 // bytes that reach LDS are the same.
 template <int R>
 __device__ __forceinline__ void blur_stage_inside_x(BlurTileLds<R>& S, const uint8_t* __restrict__ src, int src_pitch, int h, int tx0, int ty0) {
-    constexpr int IW = BlurTileLds<R>::IW, IH = BlurTileLds<R>::IH, DW = IW / 4, N = IH * DW, NPRE = (N + 255) / 256;
-    constexpr int QR = 256 / DW, QD = 256 % DW;
-    static_assert((NPRE - 1) * QD + DW - 1 < 2 * DW, "a thread's dword index wraps at most once per step");
+    constexpr int IW = BlurTileLds<R>::IW, IH = BlurTileLds<R>::IH, DW = IW / 4, N = IH * DW, NPRE = BlurPrefetch<R>::NPRE;
     const int tid = threadIdx.x;
-    const int r0 = tid / DW, d0 = tid - r0 * DW;
+    const BlurSlot<R> slot;
     const bool rows_inside = ty0 >= R && ty0 + kBlurTH + R <= h;
     const int xb = tx0 - kBlurPad;
     uint32_t v[NPRE]; int lo[NPRE];
 #pragma unroll
     for (int q = 0; q < NPRE; ++q) {
-        int d = d0 + QD * q, r = r0 + QR * q;
-        if (d >= DW) { d -= DW; ++r; }
+        int r, d;
+        slot.at(q, r, d);
         int y = ty0 + r - R;
         if (!rows_inside) y = blur_reflect101(y, h);
         lo[q] = __mul24(r, IW) + 4 * d;

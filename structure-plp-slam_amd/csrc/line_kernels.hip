@@ -1283,7 +1283,7 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
     };
     // state of the group this wave works on (main: `mine` holds 64 seeds = four groups, `sub` is the one it is in; helpers: lanes 0..kMwGroup-1)
     constexpr int kSubs = 64 / kMwGroup;
-    constexpr unsigned long long kGroupMask = kMwGroup == 64 ? ~0ull : ((1ull << kMwGroup) - 1ull);
+    constexpr unsigned long long kGroupMask = kMwGroup == 64 ? ~0ull : ((1ull << (kMwGroup & 63)) - 1ull);
     int grp = -1, own = 0, kbuf = 0, hoff = 0, nent = 0, n_lines = 0, ld = -1, sub = kSubs - 1;
     int n_self = 0, n_spec_ok = 0, n_spec_bad = 0;           // main: regions it grew itself, results it took / had to reject
     long long c_wait = 0, c_self = 0, c_commit = 0, c_pub = 0, c_grp = 0;   // main: cycles waiting for helpers / growing regions itself / taking results / publishing its own / group set-up
