@@ -209,9 +209,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         const uint8_t* row0 = img + (size_t)cd.min_y * pitch + (a0 - sh);
         // (the loop stays a load -> LDS store per trip: issuing a thread's five dword pairs together was measured and is SLOWER here, 2.31 -> 2.40 ms --
         //  the kernel sits at its register limit and the staging is a small part of it; profiles/r04_tile_pipelining.md)
-        for (int i = tid; i < ndw * h; i += 256) {
-            const int r = i / ndw, c = i - r * ndw;
-            const uint32_t* g = reinterpret_cast<const uint32_t*>(row0 + (size_t)r * pitch + 4 * c);
+        // (row, dword) of a thread's next slot by additions: a division by the runtime row length per trip was a fifth of this kernel's vector instructions
+        const int qr = 256 / ndw, qd = 256 - qr * ndw;   // wave-uniform
+        int r = tid / ndw, c = tid - r * ndw;
+        for (int i = tid; i < ndw * h; i += 256, c += qd, r += qr) {
+            if (c >= ndw) { c -= ndw; ++r; }
+            const uint32_t* g = reinterpret_cast<const uint32_t*>(row0 + (ptrdiff_t)(__mul24(r, pitch) + 4 * c));
             const uint32_t lo = g[0];
             const uint32_t v = sh ? __builtin_amdgcn_alignbyte(g[1], lo, (uint32_t)sh) : lo;
             *reinterpret_cast<uint32_t*>(&tile[r * kTileW + 4 * c]) = v;
