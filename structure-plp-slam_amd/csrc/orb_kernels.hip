@@ -28,6 +28,9 @@ namespace plp {
 // for one pixel per row); strips of 64 columns x 32 rows per wave leave 12 %.
 // grid = (ceil(dw / 64), ceil(dh / 128), B), block = 256: the four waves of a workgroup take four vertically adjacent strips.
 // ------------------------------------------------------------------------------------------
+// table entry i of a wave-uniform int16 table: the byte offset is formed in 32 bits, so the load is "scalar base + lane offset" (an index widened first costs
+// a 64-bit shift and a 64-bit add per load: 48 loads per lane in k_resize_linear)
+__device__ __forceinline__ int rs_tab(const int16_t* __restrict__ t, int i) { return *reinterpret_cast<const int16_t*>(reinterpret_cast<const char*>(t) + ((uint32_t)i << 1)); }
 constexpr int kRsRows = 44, kRsPitch = 96;   // staged source rectangle of one strip (scale factors >= 1.1 fit; larger ones fall back to global reads)
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_resize_linear(const uint8_t* __restrict__ src_base, size_t src_frame_stride,
@@ -59,7 +62,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
                 constexpr int NT = (kRsRows + 7) / 8;
                 uint4 v[NT];
 #pragma unroll
-                for (int q = 0; q < NT; ++q) v[q] = *reinterpret_cast<const uint4*>(src + (size_t)(ys + min(r0 + 8 * q, nrows - 1)) * src_pitch + x);   // (clamped row: no branch between the loads)
+                for (int q = 0; q < NT; ++q) v[q] = *reinterpret_cast<const uint4*>(src + (uint32_t)(__mul24(ys + min(r0 + 8 * q, nrows - 1), src_pitch) + x));   // (clamped row: no branch between the loads)
 #pragma unroll
                 for (int q = 0; q < NT; ++q) { const int r = r0 + 8 * q; if (r < nrows) *reinterpret_cast<uint4*>(tile + r * kRsPitch + 16 * c) = v[q]; }
             } else
@@ -79,7 +82,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int dx = min(dx0 + i, dw - 1);
-        x0[i] = xofs0[dx]; x1[i] = xofs1[dx]; wa0[i] = a0[dx]; wa1[i] = a1[dx];
+        x0[i] = rs_tab(xofs0, dx); x1[i] = rs_tab(xofs1, dx); wa0[i] = rs_tab(a0, dx); wa1[i] = rs_tab(a1, dx);
     }
     if (staged) {
 #pragma unroll
@@ -95,8 +98,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
             const int dy = min(dy0 + r, dh - 1);
-            tyy[r] = (uint32_t)(uint16_t)yofs0[dy] | ((uint32_t)(uint16_t)yofs1[dy] << 16);
-            tbb[r] = (uint32_t)(uint16_t)b0[dy] | ((uint32_t)(uint16_t)b1[dy] << 16);
+            tyy[r] = (uint32_t)(uint16_t)rs_tab(yofs0, dy) | ((uint32_t)(uint16_t)rs_tab(yofs1, dy) << 16);
+            tbb[r] = (uint32_t)(uint16_t)rs_tab(b0, dy) | ((uint32_t)(uint16_t)rs_tab(b1, dy) << 16);
         }
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
             }
             cached_row = y1;
             // rows are padded to a 64-byte pitch, so the 4-byte store never leaves the row
-            *reinterpret_cast<uint32_t*>(dst + (size_t)dy * dst_pitch + dx0) = packed;
+            *reinterpret_cast<uint32_t*>(dst + (uint32_t)(__mul24(dy, dst_pitch) + dx0)) = packed;
         }
         return;
     }
