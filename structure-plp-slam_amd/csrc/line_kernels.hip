@@ -34,6 +34,10 @@
 
 namespace plp {
 
+// the two divisions of a tile kernel's workgroup index by launch constants, as multipliers (xcd_map.hpp plp_div_magic)
+struct TileDiv { uint32_t gx_magic, tiles_x_magic; };
+static inline TileDiv tile_div(int tiles, int tiles_x, int B) { return TileDiv{plp_div_magic((uint32_t)tiles, (uint64_t)tiles * B), plp_div_magic((uint32_t)tiles_x, (uint64_t)tiles)}; }
+
 __device__ __forceinline__ int reflect101_l(int p, int len) {
     if (len == 1) return 0;
     while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p;
@@ -66,13 +70,14 @@ __device__ __forceinline__ float fast_atan2_deg_l(float y, float x) {   // cv::f
 // (2R+1)-tap fixed-point Gaussian of one plane per frame (blur_tile.hpp); 128 x 64 output tile per workgroup.
 template <int R>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_blur_plane(const uint8_t* __restrict__ src, size_t src_fs, int src_pitch,
-                                                    uint8_t* __restrict__ dst, size_t dst_fs, int dst_pitch, int w, int h, BlurTapsN taps) {
+                                                    uint8_t* __restrict__ dst, size_t dst_fs, int dst_pitch, int w, int h, BlurTapsN taps, TileDiv td) {
     __shared__ BlurTileLds<R> S;
     const int tiles_x = (w + kBlurTW - 1) / kBlurTW;
     unsigned t, f;
-    xcd_frame_major(t, f);
+    xcd_frame_major(t, f, td.gx_magic);
+    const int trow = (int)plp_div(t, (unsigned)tiles_x, td.tiles_x_magic);
     blur_tile<R>(S, src + (size_t)f * src_fs, src_pitch, dst + (size_t)f * dst_fs, dst_pitch, w, h,
-                 ((int)t % tiles_x) * kBlurTW, ((int)t / tiles_x) * kBlurTH, taps.k);
+                 ((int)t - trow * tiles_x) * kBlurTW, trow * kBlurTH, taps.k);
 }
 
 // ------------------------------------------------------------------------------------------ x0.5 INTER_LINEAR_EXACT
@@ -110,12 +115,13 @@ __global__ __launch_bounds__(256) void k_resize_exact(const uint8_t* __restrict_
 // its own 2x2 blocks, so the blurred plane never goes to HBM.  The host checks the tables (line_context.hip) and falls back to
 // k_blur_plane<5> + k_resize_exact otherwise.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_blur_half(const uint8_t* __restrict__ src, size_t src_fs, int src_pitch,
-                                                                                           uint8_t* __restrict__ dst, size_t dst_fs, int dst_pitch, int w, int h, BlurTapsN taps) {
+                                                                                           uint8_t* __restrict__ dst, size_t dst_fs, int dst_pitch, int w, int h, BlurTapsN taps, TileDiv td) {
     __shared__ BlurTileLds<5> S;
     const int tiles_x = (w + kBlurTW - 1) / kBlurTW;
     unsigned t, f;
-    xcd_frame_major(t, f);
-    const int tx0 = ((int)t % tiles_x) * kBlurTW, ty0 = ((int)t / tiles_x) * kBlurTH;
+    xcd_frame_major(t, f, td.gx_magic);
+    const int trow = (int)plp_div(t, (unsigned)tiles_x, td.tiles_x_magic);
+    const int tx0 = ((int)t - trow * tiles_x) * kBlurTW, ty0 = trow * kBlurTH;
     uint8_t* d = dst + (size_t)f * dst_fs;
     blur_tile_core<5>(S, src + (size_t)f * src_fs, src_pitch, w, h, tx0, ty0, taps.k, [&](int r0, int c4, const uint32_t (&rows)[kBlurRS]) {
         const int x = tx0 + c4;
@@ -1629,13 +1635,14 @@ constexpr int kSobelTW = 120, kSobelTH = 30;
 // 77 KB two region-growing workgroups leave on a CU.
 static_assert(sizeof(BlurTileLds<2>::in) >= kBlurTH * (kBlurTW / 4) * 4, "the blurred tile must fit the input rows it replaces");
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_blur_sobel(const uint8_t* __restrict__ src, size_t src_fs, int src_pitch,
-                                                                                            short2* __restrict__ dxy, int w, int h, BlurTapsN taps) {
+                                                                                            short2* __restrict__ dxy, int w, int h, BlurTapsN taps, TileDiv td) {
     __shared__ __attribute__((aligned(16))) BlurTileLds<2> Sb;
     uint32_t* const bt = reinterpret_cast<uint32_t*>(Sb.in);
     const int tiles_x = (w + kSobelTW - 1) / kSobelTW;
     unsigned t, f;
-    xcd_frame_major(t, f);
-    const int bx0 = ((int)t % tiles_x) * kSobelTW - 4, by0 = ((int)t / tiles_x) * kSobelTH - 1;
+    xcd_frame_major(t, f, td.gx_magic);
+    const int trow = (int)plp_div(t, (unsigned)tiles_x, td.tiles_x_magic);
+    const int bx0 = ((int)t - trow * tiles_x) * kSobelTW - 4, by0 = trow * kSobelTH - 1;
     blur_tile_core<2>(Sb, src + (size_t)f * src_fs, src_pitch, w, h, bx0, by0, taps.k, [&](int r0, int c4, const uint32_t (&rows)[kBlurRS]) {
 #pragma unroll
         for (int rr = 0; rr < kBlurRS; ++rr) bt[(r0 + rr) * (kBlurTW / 4) + c4 / 4] = rows[rr];
@@ -1860,19 +1867,20 @@ void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp,
     const size_t plane_fs = (size_t)P.pitch * P.H, splane_fs = (size_t)P.spitch * P.sh;
     const int tiles = ((P.W + 127) / 128) * ((P.H + kBlurTH - 1) / kBlurTH);
     const int sobel_tiles = ((P.W + kSobelTW - 1) / kSobelTW) * ((P.H + kSobelTH - 1) / kSobelTH);
+    const TileDiv blur_td = tile_div(tiles, (P.W + 127) / 128, B), sobel_td = tile_div(sobel_tiles, (P.W + kSobelTW - 1) / kSobelTW, B);
     mark(0);
     if (fork) {
         (void)hipEventRecord(side->fork, st);
         (void)hipStreamWaitEvent(st2, side->fork, 0);
-        hipLaunchKernelGGL(k_blur_sobel, dim3(sobel_tiles, B), dim3(256), 0, st2, P.img, P.img_frame_stride, P.img_pitch, P.dxy, P.W, P.H, t5);
+        hipLaunchKernelGGL(k_blur_sobel, dim3(sobel_tiles, B), dim3(256), 0, st2, P.img, P.img_frame_stride, P.img_pitch, P.dxy, P.W, P.H, t5, sobel_td);
         (void)hipEventRecord(side->join, st2);
     }
-    if (sobel_first) hipLaunchKernelGGL(k_blur_sobel, dim3(sobel_tiles, B), dim3(256), 0, st, P.img, P.img_frame_stride, P.img_pitch, P.dxy, P.W, P.H, t5);
+    if (sobel_first) hipLaunchKernelGGL(k_blur_sobel, dim3(sobel_tiles, B), dim3(256), 0, st, P.img, P.img_frame_stride, P.img_pitch, P.dxy, P.W, P.H, t5, sobel_td);
     if (P.half_exact)
-        hipLaunchKernelGGL(k_blur_half, dim3(tiles, B), dim3(256), 0, st, P.img, P.img_frame_stride, P.img_pitch, P.scaled, splane_fs, P.spitch, P.W, P.H, t11);
+        hipLaunchKernelGGL(k_blur_half, dim3(tiles, B), dim3(256), 0, st, P.img, P.img_frame_stride, P.img_pitch, P.scaled, splane_fs, P.spitch, P.W, P.H, t11, blur_td);
     else {
         hipLaunchKernelGGL(k_blur_plane<5>, dim3(tiles, B), dim3(256), 0, st, P.img, P.img_frame_stride, P.img_pitch, P.blur11, plane_fs,
-                           P.pitch, P.W, P.H, t11);
+                           P.pitch, P.W, P.H, t11, blur_td);
         hipLaunchKernelGGL(k_resize_exact, dim3((P.sw + 255) / 256, (P.sh + 3) / 4, B), dim3(64, 4), 0, st, P.blur11, plane_fs, P.pitch,
                            P.scaled, splane_fs, P.spitch, P.sw, P.sh, rt);
     }
@@ -1926,7 +1934,7 @@ void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp,
     mark(5);
     if (fork) (void)hipStreamWaitEvent(st, side->join, 0);
     else if (!sobel_first) {
-        hipLaunchKernelGGL(k_blur_sobel, dim3(sobel_tiles, B), dim3(256), 0, st, P.img, P.img_frame_stride, P.img_pitch, P.dxy, P.W, P.H, t5);
+        hipLaunchKernelGGL(k_blur_sobel, dim3(sobel_tiles, B), dim3(256), 0, st, P.img, P.img_frame_stride, P.img_pitch, P.dxy, P.W, P.H, t5, sobel_td);
     }
     mark(6);
     // few resident waves per frame: their 63-row working sets have to stay in L1 / L2.  Workgroups of four waves per frame, kernel alone / step: 1: 1.41 ms /

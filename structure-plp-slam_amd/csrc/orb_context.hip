@@ -12,6 +12,7 @@
 
 #include "blur_tile.hpp"
 #include "orb_device.hpp"
+#include "xcd_map.hpp"
 #include "plp_common.hpp"
 #include "quadtree_model.hpp"
 
@@ -115,6 +116,7 @@ plp_status build_geometry_impl(plp_orb* c, int rows, int cols) {
         LevelDev& L = c->h_lv[l];
         L.w = G.w; L.h = G.h; L.pitch = G.pitch; L.off = G.off;
         L.blur_tiles = ((G.w + 127) / 128) * ((G.h + plp::kBlurTH - 1) / plp::kBlurTH);
+        L.blur_tiles_x_magic = plp::plp_div_magic((uint32_t)((G.w + 127) / 128), (uint64_t)L.blur_tiles);
         c->total_blur_tiles += L.blur_tiles;
         L.scale = c->st.sf[l];
         L.sel_base = G.sel_base; L.sel_cap = G.sel_cap;

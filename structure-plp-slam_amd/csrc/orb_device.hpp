@@ -17,6 +17,7 @@ constexpr int kQtMaxNodesLds = 5888;
 struct LevelDev {
     int w, h, pitch;        // level size, row pitch in the pyramid / blur planes
     int blur_tiles;         // number of 128x64 blur tiles of this level
+    uint32_t blur_tiles_x_magic;   // plp_div_magic of the level's tile columns (xcd_map.hpp): a tile index -> (column, row) without a vector division
     size_t off;             // byte offset of the level inside one frame's plane set
     float scale;            // scale_factors_[level]
     int sel_base, sel_cap;  // slot range of this level in the per-frame selected list

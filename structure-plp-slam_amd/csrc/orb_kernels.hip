@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                                                     const LevelDev* __restrict__ lv, int ini_thr, int min_thr,
                                                     const uint8_t* __restrict__ mask, size_t mask_step,
                                                     size_t mask_frame_stride, uint32_t* __restrict__ cell_cand,
-                                                    int32_t* __restrict__ cell_count, int n_cells) {
+                                                    int32_t* __restrict__ cell_count, int n_cells, uint32_t gx_magic) {
     __shared__ __attribute__((aligned(16))) uint8_t tile[70 * kTileW];
     __shared__ __attribute__((aligned(16))) uint8_t score[66 * kScoreW];   // score map of the tested interior, +1 zero ring
     __shared__ unsigned long long keepbits[64];                            // NMS survivors, one bit per tested position
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     __shared__ int q_count, q2_count, n_ini, wave_tot[4], run_base;
 
     unsigned ucell, uframe;
-    xcd_frame_major(ucell, uframe);   // neighbouring cell ROIs overlap by 6 pixels and share cache lines
+    xcd_frame_major(ucell, uframe, gx_magic);   // neighbouring cell ROIs overlap by 6 pixels and share cache lines
     const int tid = threadIdx.x, frame = (int)uframe, cell = (int)ucell;
     const CellDesc cd = cells[cell];
     const LevelDev L = lv[cd.level];
@@ -416,18 +416,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 // grid = (tiles of all levels, B), block = 256.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_blur7(OrbPlanes pl, uint8_t* __restrict__ blur_base, size_t blur_frame_stride,
-                                               const LevelDev* __restrict__ lv, int n_levels, BlurTaps taps) {
+                                               const LevelDev* __restrict__ lv, int n_levels, BlurTaps taps, uint32_t gx_magic) {
     __shared__ BlurTileLds<3> S;
     unsigned ut, uf;
-    xcd_frame_major(ut, uf);   // all tiles of a frame share halo rows: one L2 per frame
+    xcd_frame_major(ut, uf, gx_magic);   // all tiles of a frame share halo rows: one L2 per frame
     int t = (int)ut;
     const int frame = (int)uf;
     int level = 0;
     while (level + 1 < n_levels && t >= lv[level].blur_tiles) { t -= lv[level].blur_tiles; ++level; }
     const LevelDev L = lv[level];
     const int tiles_x = (L.w + kBlurTW - 1) / kBlurTW;
+    const int trow = (int)plp_div((unsigned)t, (unsigned)tiles_x, L.blur_tiles_x_magic);
     blur_tile<3>(S, pl.level_ptr(frame, level, L), pl.level_pitch(level, L), blur_base + (size_t)frame * blur_frame_stride + L.off, L.pitch,
-                 L.w, L.h, (t % tiles_x) * kBlurTW, (t / tiles_x) * kBlurTH, taps.k);
+                 L.w, L.h, (t - trow * tiles_x) * kBlurTW, trow * kBlurTH, taps.k);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -654,13 +655,13 @@ void launch_fast(hipStream_t st, const OrbPlanes& pl, const CellDesc* d_cells, i
                  int ini_thr, int min_thr, const uint8_t* d_mask, size_t mask_step, size_t mask_frame_stride,
                  uint32_t* cell_cand, int32_t* cell_count) {
     hipLaunchKernelGGL(k_fast_cells, dim3(n_cells, B), dim3(256), 0, st, pl, d_cells, d_lv, ini_thr, min_thr, d_mask, mask_step,
-                       mask_frame_stride, cell_cand, cell_count, n_cells);
+                       mask_frame_stride, cell_cand, cell_count, n_cells, plp_div_magic((uint32_t)n_cells, (uint64_t)n_cells * B));
 }
 
 void launch_blur(hipStream_t st, const OrbPlanes& pl, uint8_t* blur, size_t blur_frame_stride, const LevelDev* d_lv,
                  int n_levels, int total_tiles, int B, const BlurTaps& taps, const LevelDev* h_lv) {
     (void)h_lv;
-    hipLaunchKernelGGL(k_blur7, dim3(total_tiles, B), dim3(256), 0, st, pl, blur, blur_frame_stride, d_lv, n_levels, taps);
+    hipLaunchKernelGGL(k_blur7, dim3(total_tiles, B), dim3(256), 0, st, pl, blur, blur_frame_stride, d_lv, n_levels, taps, plp_div_magic((uint32_t)total_tiles, (uint64_t)total_tiles * B));
 }
 
 void launch_orient_rbrief(hipStream_t st, const OrbPlanes& pl, const uint8_t* blur, size_t blur_frame_stride,
