@@ -509,12 +509,12 @@ __global__ __launch_bounds__(256) void k_orient_rbrief(OrbPlanes pl, const uint8
                                                        const int32_t* __restrict__ sel_count,           // [B][kMaxLevels]
                                                        int total_sel_cap, UMax um, plp_keypoint* __restrict__ out_kps,
                                                        uint8_t* __restrict__ out_desc, int cap, int32_t* __restrict__ out_counts,
-                                                       int32_t* __restrict__ status) {
+                                                       int32_t* __restrict__ status, uint32_t gx_magic) {
     __shared__ uint32_t s_w0[16][8], s_w1[16][8];   // per |v|: byte weights 1 / (u + 15) inside the disc, 0 outside
     __shared__ uint32_t s_pat[256];                 // the 256 test pairs (ax, ay, bx, by as int8)
     __shared__ __attribute__((aligned(16))) uint8_t s_patch[16 * 37 * 48];   // per key point: the disc of the level, then the patch of the blurred level
     unsigned ublk, uframe;
-    xcd_frame_major(ublk, uframe);   // a frame's patches (two planes, ~2.6 MB) stay in one L2
+    xcd_frame_major(ublk, uframe, gx_magic);   // a frame's patches (two planes, ~2.6 MB) stay in one L2
     const int tid = threadIdx.x, sub = tid & 15, frame = (int)uframe;
     // Key point slots are dealt DENSELY: group d of 16 lanes takes the d-th selected key point of the frame (levels in order), which is also its
     // output row.  The selection array is laid out by level CAPACITY (2032 slots for ~1000 key points at K = 1000): dealt by slot, half of
@@ -669,7 +669,8 @@ void launch_orient_rbrief(hipStream_t st, const OrbPlanes& pl, const uint8_t* bl
                           int total_sel_cap, const UMax& um, plp_keypoint* kps, uint8_t* desc, int cap, int32_t* counts,
                           int32_t* status, int B) {
     hipLaunchKernelGGL(k_orient_rbrief, dim3((total_sel_cap + 15) / 16, B), dim3(256), 0, st, pl, blur, blur_frame_stride, d_lv,
-                       n_levels, sel, sel_count, total_sel_cap, um, kps, desc, cap, counts, status);
+                       n_levels, sel, sel_count, total_sel_cap, um, kps, desc, cap, counts, status,
+                       plp_div_magic((uint32_t)((total_sel_cap + 15) / 16), (uint64_t)((total_sel_cap + 15) / 16) * B));
 }
 
 // ------------------------------------------------------------------------------------------
