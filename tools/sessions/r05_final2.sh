@@ -1,4 +1,4 @@
-# GPU session r05/final2: the closing measurements again on the final tree (after the late changes: acceptance block, blur-tile and FAST staging, pyramid offsets) -- full GPU suite, round profile
+# GPU session r05/final2: the closing measurements again on the final tree (after the late changes: acceptance block, blur-tile and FAST staging, pyramid offsets, launch-constant divisions as multipliers) -- full GPU suite, round profile
 export TMPDIR=/tmp
 O=gpurun_out/r05z; mkdir -p $O
 (timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tail -3) > $O/pytest2.log; cat $O/pytest2.log
