@@ -50,8 +50,8 @@ def test_footprints_the_design_argues_with():
     # beside two growers per SIMD (2 x 147 -> 2 x 152 allotted of 512 VGPRs): 208 registers left
     (grow,) = find("k_lsd_growENS")
     assert grow["VGPRs"] <= 120, grow             # 151 until round 5: the wave's frame index is declared wave-uniform, so every per-frame pointer is scalar (113)
-    # the exact seed sort: every build of it that held more than 128 vector registers page-faulted beside other kernels (profiles/r05_seed_sort.md; cause not
-    # identified), every build at or below never did -- the property is pinned (85 since the scan pass stages its counts through LDS)
+    # the exact seed sort: the builds of it that page-faulted beside other kernels (profiles/r05_seed_sort.md; cause not identified) all carried the scan pass's per-thread
+    # register arrays and 150+ spilled SGPRs; staged through LDS the kernel holds 85 registers -- a footprint of the old kind must not come back unnoticed
     for k in find("k_lsd_seed_sort"):
         assert k["VGPRs"] <= 128, k
     (mw,) = find("k_lsd_grow_mw")
