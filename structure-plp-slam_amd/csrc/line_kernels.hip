@@ -1108,13 +1108,23 @@ constexpr int kMwAssumed = 192;      // assumed-used pixels per attempt (a pixel
 struct MwResult { int n1, n2, nfinal, na; bool second, keep; float4 line; };
 struct alignas(16) MwEntry { int pos, n1, n2, nfinal; uint32_t flags, off; int na; uint32_t pad1; float4 line; uint32_t inl[kMwInline]; };   // flags: 1 keep, 2 final list = second
 static_assert(sizeof(MwEntry) == 80, "MwEntry layout");
-struct MwLayout { int waves, ring, nw_al, n_groups_cap, lookahead, policy; };   // LDS (words): C | T (4 bits per pixel) | waves x (O | ring | assumed) | control | owner bytes | entries
+struct MwLayout { int waves, ring, nw_al, n_groups_cap, lookahead, policy, prof; };   // LDS (words): C | T (4 bits per pixel) | waves x (O | ring | assumed) | control | owner bytes | entries
 
 // control words are read by all lanes from one address: the value is wave-uniform, and said so (readfirstlane) -- the hand-scheduled
 // block of region_grow wants its loop state in scalar registers, which the compiler only grants to values it can prove uniform
 __device__ __forceinline__ int lds_ld(const int* p) { return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)); }
 __device__ __forceinline__ void lds_st(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ uint32_t heap_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// (the lists in HBM go from one wave of the workgroup to another: WORKGROUP scope -- the waves share the CU's vector cache.  Until round 5 the
+// loads, the stores and the release fence of the hand-over had agent scope: cache-bypassing loads and a write-back of the L2 (buffer_wbl2) per
+// finished region, for readers that do not exist)
+#ifdef PLP_MW_AGENT_SCOPE      // diagnostic build only (tools/build_variant.sh): the scope of rounds 3 / 4
+#define PLP_MW_SCOPE __HIP_MEMORY_SCOPE_AGENT
+#define PLP_MW_SCOPE_NAME "agent"
+#else
+#define PLP_MW_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
+#define PLP_MW_SCOPE_NAME "workgroup"
+#endif
+__device__ __forceinline__ uint32_t heap_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, PLP_MW_SCOPE); }
 __device__ __forceinline__ int pix_of(uint32_t c, int sw) { return (int)(c >> 16) * sw + (int)(c & 0xffff); }
 
 // give back the claim nibbles of list[0..n) that still carry `id` (another wave may have taken a pixel over)
@@ -1280,6 +1290,10 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
     float4* raw = P.raw + (size_t)b * kLineCap;
     auto committed = [&](int p) -> bool { return (C[p >> 5] >> (p & 31)) & 1u; };
     // a spin that lasts longer than any legitimate wait (tens of milliseconds) is a protocol error: every wave leaves, the batch reports it
+    // the main wave's own clocks (plp_line_set_profiling; tools/experiments/latency_profile.py): a clock read is a scalar-memory operation the wave waits
+    // for, and five of them around every seed the main wave deals with were taken whether anybody asked or not -- now only when profiling is on
+    const bool prof_on = L.prof != 0;
+    auto now = [&]() -> long long { return prof_on ? (long long)clock64() : 0ll; };
     long long wd_t0 = 0;
     auto spin = [&]() -> bool {
         __builtin_amdgcn_s_sleep(2);
@@ -1293,7 +1307,7 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
     int grp = -1, own = 0, kbuf = 0, hoff = 0, nent = 0, n_lines = 0, ld = -1, sub = kSubs - 1;
     int n_self = 0, n_spec_ok = 0, n_spec_bad = 0;           // main: regions it grew itself, results it took / had to reject
     long long c_wait = 0, c_self = 0, c_commit = 0, c_pub = 0, c_grp = 0;   // main: cycles waiting for helpers / growing regions itself / taking results / publishing its own / group set-up
-    const long long c_begin = (long long)clock64();
+    const long long c_begin = now();
     uint32_t mine = 0, mine_next = 0; float s_deg = 0.f; float2 s_cs = make_float2(0.f, 0.f);
     unsigned long long todo = 0;      // helpers: the group's seeds still to look at; main: those of its 64-seed load
     unsigned long long bits = 0;      // main: those of the current group
@@ -1315,8 +1329,7 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
         int t = -1;
         wd_t0 = 0;
         if (is_main) {
-            for (;;) {
-                if (lds_ld(wd_abort)) break;
+            for (;;) {   // (the watchdog's flag is looked at where a wave waits: spin())
                 if (!bits) {   // on to the next group that still has a seed to look at
                     if (++sub >= kSubs) {
                         if (++ld * 64 >= n_ord) break;
@@ -1327,7 +1340,7 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
                     }
                     bits = (todo >> (kMwGroup * sub)) & kGroupMask;
                     if (!bits) continue;
-                    const long long cg0 = (long long)clock64();
+                    const long long cg0 = now();
                     grp = ld * kSubs + sub;
                     lds_st(main_group, grp);
                     // whose group is it?  unclaimed (nobody's fetch-and-add has reached it): take it (and every skipped one before it); else wait
@@ -1352,7 +1365,7 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
                     wd_t0 = 0;
                     have_cs = false;   // main grows few seeds itself: their angles are fetched when that happens
                     if (own > 1) refresh((own - 2) / kMwBufs, own - 2);
-                    c_grp += (long long)clock64() - cg0;
+                    c_grp += now() - cg0;
                     continue;
                 }
                 const int tt = __ffsll((long long)bits) - 1;
@@ -1363,7 +1376,7 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
                     const int hk = own - 2, hh = hk / kMwBufs;
                     if (prog <= tt) {   // until the helper has dealt with position tt
                         bool alive = true;
-                        const long long cw0 = (long long)clock64();
+                        const long long cw0 = now();
                         for (;;) {
                             refresh(hh, hk);
                             if (prog > tt) break;
@@ -1371,10 +1384,10 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
                         }
                         if (!alive) break;
                         wd_t0 = 0;
-                        c_wait += (long long)clock64() - cw0;
+                        c_wait += now() - cw0;
                     }
                     const unsigned long long hit = __ballot(pos_vec == tt);
-                    const long long cc0 = (long long)clock64();
+                    const long long cc0 = now();
                     if (hit) {
                         const int ei = __ffsll((long long)hit) - 1;
                         const MwEntry* e = eb + ei;
@@ -1412,11 +1425,11 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
                                 todo &= __ballot(!committed((int)mine));
                                 bits &= (todo >> (kMwGroup * sub)) & kGroupMask;
                             }
-                            c_commit += (long long)clock64() - cc0;
+                            c_commit += now() - cc0;
                             continue;
                         }
                         ++n_spec_bad;
-                        c_commit += (long long)clock64() - cc0;
+                        c_commit += now() - cc0;
                     }
                 }
                 t = kMwGroup * sub + tt;
@@ -1495,7 +1508,7 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
             lds_st(&cur_pos[h], g.my_pos);
         }
         MwResult r;
-        const long long cs0 = (long long)clock64();
+        const long long cs0 = now();
         float seed_deg; float2 seed_cs;
         if (have_cs) { seed_deg = bcast_f(s_deg, t); seed_cs = make_float2(bcast_f(s_cs.x, t), bcast_f(s_cs.y, t)); }
         else {
@@ -1506,17 +1519,17 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
         }
         const bool ok = mw_process_seed(g, lp, seed, seed_deg, seed_cs, r);
         region_list_fence();
-        if (is_main) { c_self += (long long)clock64() - cs0; ++n_self; }
+        if (is_main) { c_self += now() - cs0; ++n_self; }
         else if (lane == 0) { atomicAdd(&hcount[0], 1); if (!ok) atomicAdd(&hcount[1], 1); }
         const int acc_n = r.n1 + r.n2;
         if (is_main) {
-            const long long cp0 = (long long)clock64();
+            const long long cp0 = now();
             const int fb = r.second ? r.n1 : 0;
             for (int j = lane; j < r.nfinal; j += 64) { const int p = pix_of(heap_ld(g.reg + fb + j), g.sw); atomicOr(&C[p >> 5], 1u << (p & 31)); }
             mw_forget(g, g.reg, acc_n, kMwMainId);
             todo &= __ballot(!committed((int)mine));
             bits &= (todo >> (kMwGroup * sub)) & kGroupMask;
-            c_pub += (long long)clock64() - cp0;
+            c_pub += now() - cp0;
             if (r.keep) {
                 if (n_lines < kLineCap) { if (lane == 0) raw[n_lines] = r.line; }
                 else if (lane == 0) atomicOr(P.status, 4);
@@ -1529,7 +1542,7 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
                 // the region is finished: its pixels change from "helper h is growing this" to "a finished region of helper h" -- the next
                 // attempts of this helper treat them like anybody else's finished region (assumed used, and checked at their turn)
                 for (int j = lane; j < r.nfinal; j += 64) tent_retag(g, pix_of(heap_ld(g.reg + (r.second ? r.n1 : 0) + j), g.sw), wv, wv + kMwPending);
-                for (int j = lane; j < r.na; j += 64) __hip_atomic_store(g.reg + acc_n + j, g.assumed[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the assumed-used pixels follow the two lists
+                for (int j = lane; j < r.na; j += 64) __hip_atomic_store(g.reg + acc_n + j, g.assumed[j], __ATOMIC_RELAXED, PLP_MW_SCOPE);   // the assumed-used pixels follow the two lists
                 MwEntry* e = entries + (size_t)(h * kMwBufs + kbuf) * kMwEntries + nent;
                 if (lane == 0) {
                     e->pos = t; e->n1 = r.n1; e->n2 = r.n2; e->nfinal = r.nfinal; e->flags = (r.keep ? 1u : 0u) | (r.second ? 2u : 0u); e->off = (uint32_t)hoff;
@@ -1539,7 +1552,7 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
                     if (lane < acc_n) e->inl[lane] = heap_ld(g.reg + lane);
                     else if (lane < tot) e->inl[lane] = g.assumed[lane - acc_n];
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the lists in HBM are complete before the entry is announced
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, PLP_MW_SCOPE_NAME);   // the lists in HBM are complete before the entry is announced
                 __builtin_amdgcn_wave_barrier();
                 ++nent; hoff += (tot + 1) & ~1;
                 if (lds_ld(&pend_hi[h]) < 0) lds_st(&pend_lo[h], g.my_pos);
@@ -1561,8 +1574,8 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
         if (lane == 0) {
             P.n_raw[b] = min(n_lines, kLineCap);
             int32_t* gs = P.grow_stats + (size_t)b * 4; gs[0] = n_self; gs[1] = n_spec_ok; gs[2] = n_spec_bad; gs[3] = W;
-            if (P.prof && b == 0) {   // diagnostics of frame 0: cycles {total, waiting for helpers, growing itself}, helper attempts | give-ups << 32, regions grown by main, results taken
-                P.prof[0] = (long long)clock64() - c_begin; P.prof[1] = c_wait; P.prof[2] = c_self;
+            if (P.prof && b == 0 && prof_on) {   // diagnostics of frame 0: cycles {total, waiting for helpers, growing itself}, helper attempts | give-ups << 32, regions grown by main, results taken
+                P.prof[0] = now() - c_begin; P.prof[1] = c_wait; P.prof[2] = c_self;
                 P.prof[3] = (long long)hcount[0] | ((long long)hcount[1] << 32); P.prof[4] = n_self; P.prof[5] = (long long)n_spec_ok | ((long long)n_spec_bad << 32);
                 P.prof[6] = c_commit; P.prof[7] = c_pub; P.prof[8] = c_grp; P.prof[9] = P.prof[10] = P.prof[11] = 0;
             }
@@ -1916,7 +1929,7 @@ void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp,
         for (int w = want_waves; w >= 2; --w) {
             const size_t bytes = (size_t)5 * nw_al * 4 + (size_t)w * (nw_al + 256 + kMwAssumed + 2) * 4 + (8 + (4 + 2 * kMwBufs) * kMwMaxWaves) * 4 + ((groups_cap + 15) & ~15) + 16 +
                                  (size_t)(w - 1) * kMwBufs * kMwEntries * sizeof(MwEntry);
-            if (bytes <= 160 * 1024) { L.waves = w; L.ring = 256; L.nw_al = nw_al; L.n_groups_cap = groups_cap; L.lookahead = kMwBufs * (w - 1); L.policy = mw_policy; mw_bytes = bytes; break; }
+            if (bytes <= 160 * 1024) { L.waves = w; L.ring = 256; L.nw_al = nw_al; L.n_groups_cap = groups_cap; L.lookahead = kMwBufs * (w - 1); L.policy = mw_policy; L.prof = ev ? 1 : 0; mw_bytes = bytes; break; }
         }
     }
     hipStream_t st_main = st;

@@ -7,7 +7,8 @@ Why that rule is exact: C only grows, and a helper that read C(x) = 0 where the 
 if it then ACCEPTS x (a pixel that is tested and rejected leaves no trace) -- so "no accepted pixel is committed at my turn" is precisely the
 condition under which the sequential algorithm grows the same region from the same seed; and a helper that skipped x as used is right iff
 x is used at its turn.  What a helper does about other waves' claims (a region growing from an EARLIER seed or by the main wave: the helper
-gives up when it is about to accept such a pixel; from a LATER seed: overridden; a finished region that waits for its turn: judged the same
+gives up when it is about to accept such a pixel -- or, with `park` > 0, first WAITS (bounded) for that claim to change and looks at the
+pixel again: park / resume, round 5; from a LATER seed: overridden; a finished region that waits for its turn: judged the same
 way (policy 0) or assumed used (policy 1)) only changes how much speculation is wasted: the two checks above alone decide what is committed.
 
 The model runs the protocol on toy images with a toy order-dependent region_grow (running mean angle, refinement that un-marks and regrows with
@@ -36,37 +37,43 @@ class Abort(Exception):
     pass
 
 
-def grow(img, seed, tol, is_used, mark, poison=None, tick=None):
-    """toy region_grow: breadth first over the list, running mean `angle`, acceptance depends on the order of acceptances"""
+def grow(img, seed, tol, is_used, mark, poison=None, tick=None, park=None):
+    """toy region_grow: breadth first over the list, running mean `angle`, acceptance depends on the order of acceptances.
+    park(q): generator, True when the claim that stood in the way of q has changed (the pixel is then looked at AGAIN, from the used test on:
+    the device repeats the whole round of seven points, nothing of which had been written), False when the wait ran out (give up)"""
     W, H, ang = img
     reg, s = [seed], float(ang[seed])
     mark(seed)
     i = 0
     while i < len(reg):
         for q in neighbours(reg[i], W, H):
-            if tick:
-                yield from tick()
-            if is_used(q):
-                continue
-            if abs(ang[q] - s / len(reg)) <= tol:
-                if poison and poison(q):
-                    raise Abort()
-                reg.append(q); s += float(ang[q]); mark(q)
+            while True:
+                if tick:
+                    yield from tick()
+                if is_used(q):
+                    break
+                if abs(ang[q] - s / len(reg)) <= tol:
+                    if poison and poison(q):
+                        if park and (yield from park(q)):
+                            continue
+                        raise Abort()
+                    reg.append(q); s += float(ang[q]); mark(q)
+                break
         i += 1
     return reg
 
 
-def process_seed(img, seed, is_used, mark, unmark, poison=None, tick=None):
+def process_seed(img, seed, is_used, mark, unmark, poison=None, tick=None, park=None):
     """grow -> (maybe) refine: un-mark everything, regrow tighter -> (maybe) reduce: drop far pixels.  Returns (final list, every pixel ever
     accepted, line or None)"""
     W, H, ang = img
-    first = yield from grow(img, seed, 0.30, is_used, mark, poison, tick)
+    first = yield from grow(img, seed, 0.30, is_used, mark, poison, tick, park)
     ever = list(first)
     final = first
     if len(first) >= 3 and (np.ptp(ang[first]) > 0.35):          # "density too low": refine
         for q in first:
             unmark(q)
-        final = yield from grow(img, seed, 0.12, is_used, mark, poison, tick)
+        final = yield from grow(img, seed, 0.12, is_used, mark, poison, tick, park)
         ever += final
         if len(final) > 4 and np.ptp(ang[final]) > 0.15:         # reduce_region_radius: keep the points near the seed
             sx, sy = seed % W, seed // W
@@ -100,14 +107,14 @@ def sequential(img, order):
     return out, used
 
 
-def concurrent(img, order, n_helpers, rng, policy=0, claim_noise=0.0):
+def concurrent(img, order, n_helpers, rng, policy=0, claim_noise=0.0, park=0, park_spins=40):
     C, T = set(), {}                     # T: pixel -> helper that marked it last (the tentative-owner nibbles of the device)
     cur_pos = [0] * n_helpers            # seed position of each helper's latest attempt
     n_groups = (len(order) + GROUP - 1) // GROUP
     owner = [None] * n_groups          # None / "main" / helper id
     progress = [0] * n_groups          # positions of the group the owner has dealt with (published after the entry, if any)
     entries = [[] for _ in range(n_groups)]
-    state = {"main_group": 0, "next_group": 0, "done": False, "wasted": 0, "used_spec": 0}
+    state = {"main_group": 0, "next_group": 0, "done": False, "wasted": 0, "used_spec": 0, "parked": 0, "resumed": 0}
     out = []
 
     def tick():
@@ -182,10 +189,26 @@ def concurrent(img, order, n_helpers, rng, policy=0, claim_noise=0.0):
                     if o is None or o == (hid, "growing") or (policy == 1 and o[1] == "pending"):
                         return False
                     return o[0] == "main" or (o[0] != hid and cur_pos[o[0]] < my_pos)       # policy 0: a finished region's claim is judged like a growing one's
+                parks = [park]
+
+                def park_on(q, parks=parks):
+                    # the claim in the way is a GROWING region's (a finished one that waits for its turn may wait long: no park); the wait ends when the
+                    # claim on q has changed or q is committed, and it is bounded (a claim can be stale or a phantom: claim_noise) -- then: give up
+                    o = T.get(q)
+                    if parks[0] <= 0 or o is None or o[1] != "growing":
+                        return False
+                    parks[0] -= 1
+                    state["parked"] += 1
+                    for _ in range(park_spins):
+                        yield
+                        if T.get(q) != o or q in C:
+                            state["resumed"] += 1
+                            return True
+                    return False
                 try:
                     if len(marked) > 10_000:
                         raise Abort()
-                    final, ever, line = yield from process_seed(img, seed, is_used, mark, unmark, poison=poison, tick=tick)
+                    final, ever, line = yield from process_seed(img, seed, is_used, mark, unmark, poison=poison, tick=tick, park=park_on if park else None)
                     for q in final:                                 # finished: "helper is growing this" -> "a finished region that waits for its turn"
                         if T.get(q) == (hid, "growing"):
                             T[q] = (hid, "pending")
@@ -293,3 +316,33 @@ def test_protocol_is_exact_whatever_the_claim_nibbles_say(seed):
                 rng = random.Random(77 * seed + 10 * n_helpers + policy)
                 got, used, st = concurrent(img, order, n_helpers, rng, policy, claim_noise=noise)
                 assert got == want and used == want_used, (seed, n_helpers, policy, noise)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_park_and_resume_equals_the_sequential_scan(seed):
+    """region_grow<MW> with g.park > 0 (PLP_LSD_MW_PARK): a helper that is about to accept a pixel of an earlier seed's GROWING region waits for that
+    claim to change and looks again, instead of leaving the seed to main.  Only the amount of useful speculation may change -- and the waits end: a
+    helper only ever waits for a strictly earlier position, main never waits inside a region, every wait is bounded."""
+    img, order = toy_image(seed)
+    want, want_used = sequential(img, order)
+    resumed = 0
+    for n_helpers in (1, 3, 7):
+        for policy in (0, 1):
+            for park, spins in ((1, 40), (4, 200), (4, 3)):      # (4, 3): the wait mostly runs out -> the old give-up
+                rng = random.Random(4000 * seed + 10 * n_helpers + policy + 100 * park + spins)
+                got, used, st = concurrent(img, order, n_helpers, rng, policy, park=park, park_spins=spins)
+                assert got == want, (seed, n_helpers, policy, park, spins)
+                assert used == want_used
+                resumed += st["resumed"]
+    assert resumed > 0          # the waits did end with a second look somewhere
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_park_and_resume_with_scrambled_claims(seed):
+    img, order = toy_image(seed)
+    want, want_used = sequential(img, order)
+    for n_helpers in (3, 7):
+        for noise in (0.05, 0.5):
+            rng = random.Random(91 * seed + n_helpers)
+            got, used, st = concurrent(img, order, n_helpers, rng, 0, claim_noise=noise, park=3, park_spins=60)
+            assert got == want and used == want_used, (seed, n_helpers, noise)
