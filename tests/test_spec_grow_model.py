@@ -8,7 +8,7 @@ if it then ACCEPTS x (a pixel that is tested and rejected leaves no trace) -- so
 condition under which the sequential algorithm grows the same region from the same seed; and a helper that skipped x as used is right iff
 x is used at its turn.  What a helper does about other waves' claims (a region growing from an EARLIER seed or by the main wave: the helper
 gives up when it is about to accept such a pixel -- or, with `park` > 0, first WAITS (bounded) for that claim to change and looks at the
-pixel again: park / resume, round 5; from a LATER seed: overridden; a finished region that waits for its turn: judged the same
+pixel again: park / resume, built and measured in round 5, not shipped; from a LATER seed: overridden; a finished region that waits for its turn: judged the same
 way (policy 0) or assumed used (policy 1)) only changes how much speculation is wasted: the two checks above alone decide what is committed.
 
 The model runs the protocol on toy images with a toy order-dependent region_grow (running mean angle, refinement that un-marks and regrows with
@@ -320,8 +320,9 @@ def test_protocol_is_exact_whatever_the_claim_nibbles_say(seed):
 
 @pytest.mark.parametrize("seed", range(12))
 def test_park_and_resume_equals_the_sequential_scan(seed):
-    """region_grow<MW> with g.park > 0 (PLP_LSD_MW_PARK): a helper that is about to accept a pixel of an earlier seed's GROWING region waits for that
-    claim to change and looks again, instead of leaving the seed to main.  Only the amount of useful speculation may change -- and the waits end: a
+    """region_grow<MW> with parking (round 5's experimental kernel, profiles/r05_latency_path_series.patch -- measured exact and 3 % slower, not shipped:
+    profiles/r05_latency_path.md): a helper that is about to accept a pixel of an earlier seed's GROWING region waits for that claim to change and looks
+    again, instead of leaving the seed to main.  Only the amount of useful speculation may change -- and the waits end: a
     helper only ever waits for a strictly earlier position, main never waits inside a region, every wait is bounded."""
     img, order = toy_image(seed)
     want, want_used = sequential(img, order)
