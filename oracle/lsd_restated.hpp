@@ -18,8 +18,14 @@
 
 namespace oracle {
 
+#ifdef ORACLE_D2_LIBM_FLOAT
+// the reference's literal calls (cosf / sinf of this machine's glibc): liboracle_d2.so, built only to MEASURE definition D2 (tests/test_d2_libm_float.py)
+inline float f_cos(float x) { return cosf(x); }
+inline float f_sin(float x) { return sinf(x); }
+#else
 inline float f_cos(float x) { return (float)std::cos((double)x); }   // (D2)
 inline float f_sin(float x) { return (float)std::sin((double)x); }
+#endif
 
 // cv::resize(src, dst, Size(), 0.5, 0.5, INTER_LINEAR_EXACT) for u8 (bit-exact 8.8 coefficients)
 inline Image resize_linear_exact_u8(const Image& src, double fx, double fy) {

@@ -6,6 +6,7 @@
 #include <thread>
 
 #include "orb_oracle.hpp"
+#include "lsd_restated.hpp"
 
 using namespace oracle;
 
@@ -119,7 +120,7 @@ int oracle_fast9_16(const uint8_t* base, int step, int w, int h, int threshold, 
 }
 float oracle_fast_atan2(float y, float x) { return fast_atan2f_deg(y, x); }
 // D2: cosf / sinf of the line sources, defined as the rounded f64 libm results (lsd_restated.hpp f_cos / f_sin)
-void oracle_f_cos_sin(const float* a, long n, float* c, float* s) { for (long i = 0; i < n; ++i) { c[i] = (float)std::cos((double)a[i]); s[i] = (float)std::sin((double)a[i]); } }
+void oracle_f_cos_sin(const float* a, long n, float* c, float* s) { for (long i = 0; i < n; ++i) { c[i] = oracle::f_cos(a[i]); s[i] = oracle::f_sin(a[i]); } }
 float oracle_trig_cos(float v) { return trig::cos(v); }
 float oracle_trig_sin(float v) { return trig::sin(v); }
 void oracle_scale_tables(unsigned n, float sf, float* a, float* b, float* c, float* d) {

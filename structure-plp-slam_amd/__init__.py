@@ -79,6 +79,7 @@ _API = [
     ("plp_line_set_grow_waves", C.c_int, [_VP, _I32]),
     ("plp_line_set_seed_order", C.c_int, [_VP, _I32]),
     ("plp_line_get_seed_order", C.c_int, [_VP, _VP]),
+    ("plp_line_trim", C.c_int, [_VP]),
     ("plp_model_seed_introsort_host", _I32, [_VP, C.c_int64, _I32, C.c_uint32]),
     ("plp_seed_introsort_debug", C.c_int, [_I32, _VP, C.c_int64, _I32, C.c_uint32, _I32]),
     ("plp_line_get_stage_times", C.c_int, [_VP, _VP, _VP]),
@@ -369,6 +370,10 @@ class LineFeatureTracker:
     def set_seed_order(self, order):
         """SEED_ORDER_LIBSTDCXX: the seed order of a reference built with GCC's library, SEED_ORDER_STABLE: row-major inside a bin (plp_line_set_seed_order)"""
         _check(lib().plp_line_set_seed_order(self._h, int(order)))
+
+    def trim(self):
+        """give back the device memory the current settings do not need (plp_line_trim: the exact order's buffers under SEED_ORDER_STABLE, the several-waves heap)"""
+        _check(lib().plp_line_trim(self._h))
 
     def set_grow_waves(self, waves):
         """0 = automatic, 1 = one wave per frame in LSD region growing, 2..8 = that many waves per frame (plp_line_set_grow_waves)"""

@@ -35,6 +35,7 @@ struct plp_line {
     DevBuf aligned;                             // aligned copy of odd-pitch device frames
     int s_cap = 0;
     int last_B = 0;
+    bool last_profiled = false;   // the last batch ran with profiling on: only then does `prof` hold that batch's counters
     hipStream_t last_stream = nullptr;
     bool profiling = false;
     hipEvent_t ev[9] = {};
@@ -205,7 +206,7 @@ plp_status run(plp_line* c, const uint8_t* d_imgs, int B, int rows, int cols, si
         float tot = 0; PLP_HIP(hipEventElapsedTime(&tot, c->ev[0], c->ev[8])); c->stage_ms[8] += tot;
         ++c->stage_batches;
     }
-    c->last_B = B; c->last_stream = st;
+    c->last_B = B; c->last_stream = st; c->last_profiled = c->profiling;
     return PLP_OK;
 }
 
@@ -328,6 +329,8 @@ plp_status plp_line_debug_grow_profile(plp_line* c, int64_t* out12) {
     if (!c || !out6) return set_error(PLP_ERR_INVALID_ARG, "NULL argument");
     std::lock_guard<std::mutex> lk(c->mu);
     if (!c->last_B) return set_error(PLP_ERR_INVALID_ARG, "no batch yet");
+    // the growers write their clocks only when profiling is on, and the buffer is cleared only then: without it the bytes are stale or uninitialised
+    if (!c->last_profiled) return set_error(PLP_ERR_INVALID_ARG, "the last batch ran with profiling off: call plp_line_set_profiling(ctx, 1) before the batch");
     PLP_HIP(hipSetDevice(c->device));
     PLP_HIP(hipStreamSynchronize(c->last_stream));
     long long v[12] = {0};
@@ -350,8 +353,24 @@ plp_status plp_line_set_seed_order(plp_line* c, int32_t order) {
     if (order == PLP_SEED_ORDER_LIBSTDCXX && !c->seed_sort_ok) return set_error(PLP_ERR_UNSUPPORTED, "this device refused the LDS size of the exact seed sort");
     std::lock_guard<std::mutex> lk(c->mu);
     c->seed_order = order;
-    // the exact order's buffers (the seed array and the sort's scratch: 476 KB per frame of a 640 x 480 batch) go back when the caller leaves that order
-    if (order == PLP_SEED_ORDER_STABLE && c->seed_capB > 0) { (void)hipSetDevice(c->device); c->seed_ent.release(); c->seed_ws.release(); c->seed_capB = 0; }
+    //  the exact order's buffers -- the seed array and the sort's scratch: 476 KB per frame of a 640 x 480 batch, INTEGRATION.md -- are NOT freed here any
+    // more: hipFree drains the whole device (every stream of every other context of an overlapped step) and a caller that alternates the two orders paid that
+    // and a re-allocation of ~0.5 GB per switch.  A caller that leaves the exact order for good gives the memory back with plp_line_trim().
+    return PLP_OK;
+}
+
+// Give back what the current settings do not need: the exact seed order's buffers while the stable order is selected, the several-waves grower's heap.
+// hipFree waits for the device: call it where a pause is acceptable.  The caller's current device is restored.
+plp_status plp_line_trim(plp_line* c) {
+    if (!c) return set_error(PLP_ERR_INVALID_ARG, "ctx is NULL");
+    std::lock_guard<std::mutex> lk(c->mu);
+    int prev = -1;
+    PLP_HIP(hipGetDevice(&prev));
+    PLP_HIP(hipSetDevice(c->device));
+    if (c->last_B) (void)hipStreamSynchronize(c->last_stream);
+    if (c->seed_order == PLP_SEED_ORDER_STABLE && c->seed_capB > 0) { c->seed_ent.release(); c->seed_ws.release(); c->seed_capB = 0; }
+    c->mw_heap.release(); c->mw_capB = 0;
+    if (prev >= 0 && prev != c->device) PLP_HIP(hipSetDevice(prev));
     return PLP_OK;
 }
 

@@ -1117,6 +1117,8 @@ __device__ __forceinline__ void lds_st(int* p, int v) { __hip_atomic_store(p, v,
 // (the lists in HBM go from one wave of the workgroup to another: WORKGROUP scope -- the waves share the CU's vector cache.  Until round 5 the
 // loads, the stores and the release fence of the hand-over had agent scope: cache-bypassing loads and a write-back of the L2 (buffer_wbl2) per
 // finished region, for readers that do not exist)
+// REQUIREMENT: workgroup scope is enough only while the waves of a workgroup share one CU's vector L1 -- not in threadgroup-split mode.  The build pins
+// -mno-tgsplit (csrc/Makefile; checked by tests/test_kernel_resources.py); a tgsplit build must define PLP_MW_AGENT_SCOPE.
 #ifdef PLP_MW_AGENT_SCOPE      // diagnostic build only (tools/build_variant.sh): the scope of rounds 3 / 4
 #define PLP_MW_SCOPE __HIP_MEMORY_SCOPE_AGENT
 #define PLP_MW_SCOPE_NAME "agent"

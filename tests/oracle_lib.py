@@ -63,6 +63,42 @@ class reference:
         return False
 
 
+class _VariantProxy:
+    """another build of the SAME oracle sources (e.g. liboracle_d2.so): same entry points, the argtypes / restype of the default build"""
+
+    def __init__(self, other, orc):
+        self._other, self._orc = other, orc
+
+    def __getattr__(self, name):
+        if not name.startswith("oracle_"):
+            raise AttributeError(name)
+        fn, src = getattr(self._other, name), getattr(self._orc, name)
+        if src.argtypes is not None:
+            fn.argtypes = src.argtypes
+        fn.restype = src.restype
+        return fn
+
+
+class variant:
+    """context manager: inside it the wrappers of this module call the oracle build `so_name` (a file beside liboracle.so)"""
+
+    def __init__(self, so_name):
+        self.path = ORACLE_DIR / so_name
+
+    def __enter__(self):
+        global _backend
+        orc = _load()
+        if not self.path.exists():
+            build()
+        _backend = _VariantProxy(C.CDLL(str(self.path)), orc)
+        return self
+
+    def __exit__(self, *exc):
+        global _backend
+        _backend = None
+        return False
+
+
 def lib():
     return _backend if _backend is not None else _load()
 

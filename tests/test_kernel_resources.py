@@ -78,3 +78,42 @@ def test_footprints_the_design_argues_with():
     # the per-family instantiations of the generic matcher kernels exist (line, group, point)
     for name in ("k_match_topk_lanesILi", "k_match_topkILi", "k_match_resolve_genericILi"):
         assert len(find(name)) == 3, name
+
+
+# Scalar registers spilled into VGPR lanes (a v_writelane / v_readlane pair each time one is used), per kernel.  VERDICT r05: the chain-bound kernels -- one instruction
+# per ~15 cycles -- pay for every one of them on their critical path, and every build of the seed sort that ever faulted beside other kernels carried 150+ of them
+# (profiles/r05_seed_sort.md), so the number is RECORDED per kernel and held: a kernel not listed may spill at most kSpillDefault, a listed one at most its figure.
+# Lower a cap when a kernel's spills go down; raising one needs a reason in the line's comment.
+kSpillDefault = 20
+SPILL_CAPS = {
+    "k_lsd_growENS": 72,                 # round 5: 72 (the loop state of region_grow + rectangle fit + refinement live across the round loop)
+    "k_lsd_grow_mw": 175,                # round 5: 175 -- the latency path's kernel; soaked beside other kernels by tests/test_gpu_concurrent_single_frame.py
+    "k_match_resolve_sorted": 69,
+    "k_match_resolve_genericILi1": 51,
+    "k_match_resolve_genericILi2": 44,
+    "k_match_resolve_genericILi3": 64,
+    "k_quadtree": 39,
+}
+
+
+def spill_table():
+    return {k: v.get("SGPRs Spill", 0) for k, v in K.items()}
+
+
+@needs_build
+def test_spilled_scalar_registers_are_recorded_and_capped():
+    over = {}
+    for name, n in spill_table().items():
+        cap = next((c for sub, c in SPILL_CAPS.items() if sub in name), kSpillDefault)
+        if n > cap:
+            over[name] = (n, cap)
+    assert not over, f"spilled SGPRs above the recorded cap (kernel: (now, cap)): {over}"
+    for sub in SPILL_CAPS:               # every listed kernel still exists under that name
+        find(sub)
+
+
+def test_the_build_pins_the_cache_mode_the_workgroup_scope_hand_overs_need():
+    """k_lsd_grow_mw's region lists and the seed sort's global partitions go from wave to wave through HBM at workgroup scope: valid only without threadgroup split"""
+    mk = open(os.path.join(BUILD, "..", "Makefile")).read()
+    flags = next(l for l in mk.splitlines() if l.startswith("FLAGS"))
+    assert "-mno-tgsplit" in flags and "-mtgsplit" not in flags.replace("-mno-tgsplit", ""), flags

@@ -8,7 +8,7 @@ mkdir -p build_exp/obj_$name
 cd structure-plp-slam_amd/csrc
 pids=()
 for f in *.hip; do
-  ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-unused-function -Wno-unused-result $extra -c -o ../../build_exp/obj_$name/${f%.hip}.o $f ) &
+  ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -mno-tgsplit -ffp-contract=off -Wall -Wno-unused-function -Wno-unused-result $extra -c -o ../../build_exp/obj_$name/${f%.hip}.o $f ) &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p || { echo "build_variant: a compile failed"; exit 1; }; done

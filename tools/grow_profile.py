@@ -20,6 +20,7 @@ def main():
     frames = torch.from_numpy(synth.replay(1234, uniq)).cuda().repeat((B + uniq - 1) // uniq, 1, 1)[:B].contiguous()
     cap = 512
     lt = plp.LineFeatureTracker()
+    lt.set_profiling(True)     # the growers write their clocks only then (plp_line_debug_grow_profile refuses otherwise)
     kl = torch.zeros((B, cap, 68), dtype=torch.uint8, device="cuda"); lbd = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
     fn = torch.zeros((B, cap, 3), dtype=torch.float64, device="cuda"); cnt = torch.zeros(B, dtype=torch.int32, device="cuda")
     for _ in range(2):
