@@ -485,13 +485,15 @@ plp_status plp_seed_introsort_debug(int32_t device, uint32_t* entries, int64_t n
     PLP_HIP(seed_sort_configure());
     if (depth_limit < 0) { int lg = 0; while ((2ll << lg) <= n) ++lg; depth_limit = 2 * lg; }
     DevBuf ent, ws, st;
-    PLP_HIP(ent.reserve((size_t)std::max<int64_t>(n, 1) * 4)); PLP_HIP(ws.reserve(seed_sort_ws_entries((size_t)n) * 4)); PLP_HIP(st.reserve(16));
-    PLP_HIP(hipMemcpy(ent.p, entries, (size_t)n * 4, hipMemcpyHostToDevice));
+    // PLP_SEED_SORT_DBG_COPIES=N (diagnostic): N workgroups sort N copies at once, workgroup 0's result and clocks are returned -- the phase split with the chip full
+    const int copies = std::max(1, std::min(4096, getenv("PLP_SEED_SORT_DBG_COPIES") ? atoi(getenv("PLP_SEED_SORT_DBG_COPIES")) : 1));
+    PLP_HIP(ent.reserve((size_t)std::max<int64_t>(n, 1) * 4 * copies)); PLP_HIP(ws.reserve(seed_sort_ws_entries((size_t)n) * 4 * copies)); PLP_HIP(st.reserve(16));
+    for (int k = 0; k < copies; ++k) PLP_HIP(hipMemcpy((uint32_t*)ent.p + (size_t)k * n, entries, (size_t)n * 4, hipMemcpyHostToDevice));
     PLP_HIP(hipMemset(st.p, 0, 16));
     DevBuf dbg;
     const char* dflag = getenv("PLP_SEED_SORT_DBG");
     if (dflag) { PLP_HIP(dbg.reserve(4 * (2 + 6 * 4000 + 48))); PLP_HIP(hipMemset(dbg.p, 0, 4 * (2 + 6 * 4000 + 48))); int f = atoi(dflag); PLP_HIP(hipMemcpy(dbg.p, &f, 4, hipMemcpyHostToDevice)); }
-    launch_seed_sort_debug(nullptr, (uint32_t*)ent.p, (int)n, depth_limit, skip_key, (uint32_t*)ws.p, (int32_t*)st.p, dflag ? (int*)dbg.p : nullptr, variant);
+    launch_seed_sort_debug(nullptr, (uint32_t*)ent.p, (int)n, depth_limit, skip_key, (uint32_t*)ws.p, (int32_t*)st.p, dflag ? (int*)dbg.p : nullptr, variant, copies);
     PLP_HIP(hipGetLastError());
     PLP_HIP(hipDeviceSynchronize());
     int32_t s = 0;

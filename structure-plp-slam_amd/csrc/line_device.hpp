@@ -93,7 +93,7 @@ struct SeedSortBufs { uint32_t* ent; uint32_t* ws; size_t ws_stride; };
 size_t seed_sort_ws_entries(size_t nv);
 hipError_t seed_sort_configure();   // raises the kernels' dynamic LDS limit on the CURRENT device
 void launch_seed_order_exact(hipStream_t st, const LinePlanes& P, const LsdParams& lp, int B, uint32_t* ent, uint32_t* ws, size_t ws_stride);
-void launch_seed_sort_debug(hipStream_t st, uint32_t* ent, int n, int depth, uint32_t skip_key, uint32_t* ws, int32_t* status, int* dbg, int variant);
+void launch_seed_sort_debug(hipStream_t st, uint32_t* ent, int n, int depth, uint32_t skip_key, uint32_t* ws, int32_t* status, int* dbg, int variant, int copies = 1);
 hipError_t grow_mw_configure();      // the same for k_lsd_grow_mw (line_kernels.hip)
 
 // ev: NULL or 9 events recorded around the 8 stages {blur11+resize, gradient+bins, seed order, region grow, key lines,

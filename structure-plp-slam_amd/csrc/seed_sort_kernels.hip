@@ -160,9 +160,10 @@ hipError_t seed_sort_configure() {
     return hipSuccess;
 }
 // variant 0: the configuration of large batches, 1: of small ones
-void launch_seed_sort_debug(hipStream_t st, uint32_t* ent, int n, int depth, uint32_t skip_key, uint32_t* ws, int32_t* status, int* dbg, int variant) {
-    if (variant) hipLaunchKernelGGL(ss_lat::k_seed_sort_debug, dim3(1), dim3(ss_lat::kSsThreads), ss_lat::lds_bytes((size_t)n), st, ent, n, depth, skip_key, ws, status, dbg);
-    else hipLaunchKernelGGL(ss_thr::k_seed_sort_debug, dim3(1), dim3(ss_thr::kSsThreads), ss_thr::lds_bytes((size_t)n), st, ent, n, depth, skip_key, ws, status, dbg);
+void launch_seed_sort_debug(hipStream_t st, uint32_t* ent, int n, int depth, uint32_t skip_key, uint32_t* ws, int32_t* status, int* dbg, int variant, int copies) {
+    const size_t ws_stride = seed_sort_ws_entries((size_t)n);
+    if (variant) hipLaunchKernelGGL(ss_lat::k_seed_sort_debug, dim3(copies), dim3(ss_lat::kSsThreads), ss_lat::lds_bytes((size_t)n), st, ent, n, depth, skip_key, ws, ws_stride, status, dbg);
+    else hipLaunchKernelGGL(ss_thr::k_seed_sort_debug, dim3(copies), dim3(ss_thr::kSsThreads), ss_thr::lds_bytes((size_t)n), st, ent, n, depth, skip_key, ws, ws_stride, status, dbg);
 }
 
 }  // namespace plp

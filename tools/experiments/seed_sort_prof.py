@@ -6,7 +6,7 @@ from plp import plp, synth
 from PIL import Image
 os.environ["PLP_SEED_SORT_DBG"] = "0"; os.environ["PLP_SEED_SORT_DBG_FILE"] = "/tmp/ss_log.bin"
 frames = [np.asarray(Image.open("tests/golden/equirect2_640x480.png")), synth.replay(1234, 1, 480, 640)[0]]
-names = ["G_partitions", "win_load", "wg_levels", "wave_tasks", "lanes", "store", "n_windows", "n_G", "task_busy_sum", "task_max", "L_A", "L_S", "L_X", "L_B", "L_C", "L_n", "G_A", "G_S", "G_X", "G_B", "G_C", "G_n", "", ""]
+names = ["G_partitions", "win_load", "wg_levels", "wave_tasks", "lanes", "store", "n_windows", "n_G", "task_busy_sum", "task_max", "reg_cycles", "reg_calls", "reg_parts", "sub_cycles(incl reg)", "sub_calls", "sub_parts", "G_A", "G_S", "G_X", "G_B", "G_C", "G_n", "", ""]
 for f in frames:
     s = O.LineOracle(f, False).scaled.astype(np.int64)
     DA, BC = s[1:, 1:] - s[:-1, :-1], s[:-1, 1:] - s[1:, :-1]
