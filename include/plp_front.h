@@ -233,8 +233,11 @@ int32_t plp_model_index_sort_host(const int32_t* sizes, int32_t n, int32_t depth
  * No GPU needed.  Returns 0, or -1 for a bad argument. */
 int32_t plp_model_seed_introsort_host(uint32_t* entries, int64_t n, int32_t depth_limit, uint32_t skip_key);
 /* Test entry: the KERNEL's introsort loop on caller-made entries (host pointer, in place), one workgroup, chosen recursion budget and skip key.
- * variant 0: the kernel configuration of large batches (4 waves, 4096-entry LDS window), 1: of batches up to 256 frames (16 waves, 24576 entries). */
-plp_status plp_seed_introsort_debug(int32_t device, uint32_t* entries, int64_t n, int32_t depth_limit, uint32_t skip_key, int32_t variant);
+ * variant 0: the kernel configuration of large batches (4 waves, 4096-entry LDS window), 1: of batches up to 256 frames (16 waves, 24576 entries).
+ * n_live (may be NULL): the length of the array's LIVE part.  With a skip key the kernel stops storing into the right part of a global-memory partition
+ * whose pivot key lies below it once that part is the end of the live array (only keys below the skip key live there, nothing reads them again): entries
+ * [0, n_live) equal the host model's, entries behind are unspecified (stale copies).  Without a skip key n_live = n. */
+plp_status plp_seed_introsort_debug(int32_t device, uint32_t* entries, int64_t n, int32_t depth_limit, uint32_t skip_key, int32_t variant, int32_t* n_live);
 /* Host model of the LSD gradient kernel's (float)cos((double)a), (float)sin((double)a) fast path (csrc/sincos_ziv.hpp): proven[i] = 0 marks the
  * arguments for which the kernel falls back to the general f64 routine.  Returns the number of proven arguments.  No GPU needed. */
 int32_t plp_model_sincos_host(const float* a, int64_t n, float* c, float* s, uint8_t* proven);

@@ -81,7 +81,7 @@ _API = [
     ("plp_line_get_seed_order", C.c_int, [_VP, _VP]),
     ("plp_line_trim", C.c_int, [_VP]),
     ("plp_model_seed_introsort_host", _I32, [_VP, C.c_int64, _I32, C.c_uint32]),
-    ("plp_seed_introsort_debug", C.c_int, [_I32, _VP, C.c_int64, _I32, C.c_uint32, _I32]),
+    ("plp_seed_introsort_debug", C.c_int, [_I32, _VP, C.c_int64, _I32, C.c_uint32, _I32, _VP]),
     ("plp_line_get_stage_times", C.c_int, [_VP, _VP, _VP]),
     ("plp_line_debug_read", C.c_int, [_VP, C.c_int, _I32, _VP, _SZ, _VP]),
     ("plp_line_scaled_size", C.c_int, [_VP, _VP, _VP]),
@@ -171,12 +171,13 @@ def model_seed_introsort(entries, depth_limit=-1, skip_key=0):
     return e
 
 
-def seed_introsort_debug(entries, depth_limit=-1, skip_key=0, variant=0, device=0):
+def seed_introsort_debug(entries, depth_limit=-1, skip_key=0, variant=0, device=0, return_live=False):
     """The KERNEL's introsort loop on caller-made entries (one workgroup), with a chosen recursion budget and skip key; variant 0 / 1: the kernel
-    configuration of large / small batches"""
+    configuration of large / small batches.  return_live: also the length of the live part (entries behind it are unspecified: plp_front.h)"""
     e = np.ascontiguousarray(entries, np.uint32).copy()
-    _check(lib().plp_seed_introsort_debug(int(device), _p(e), e.size, int(depth_limit), int(skip_key), int(variant)))
-    return e
+    nl = C.c_int32(e.size)
+    _check(lib().plp_seed_introsort_debug(int(device), _p(e), e.size, int(depth_limit), int(skip_key), int(variant), C.byref(nl)))
+    return (e, nl.value) if return_live else e
 
 
 def model_index_sort(sizes, depth_limit=-1):

@@ -477,7 +477,7 @@ int32_t plp_model_seed_introsort_host(uint32_t* entries, int64_t n, int32_t dept
 
 // The kernel's introsort loop on caller-made entries (host pointers; one workgroup), with a chosen recursion budget: the tests' way to
 // reach every branch (global partitions, LDS window, wave tasks, lanes, heap sort) on arbitrary key distributions.
-plp_status plp_seed_introsort_debug(int32_t device, uint32_t* entries, int64_t n, int32_t depth_limit, uint32_t skip_key, int32_t variant) {
+plp_status plp_seed_introsort_debug(int32_t device, uint32_t* entries, int64_t n, int32_t depth_limit, uint32_t skip_key, int32_t variant, int32_t* n_live) {
     if (!entries || n < 0 || n > (int64_t)kLsdMaxScaledPixels) return set_error(PLP_ERR_INVALID_ARG, "bad entries");
     int nd = 0;
     if (hipGetDeviceCount(&nd) != hipSuccess || nd == 0) return set_error(PLP_ERR_NO_DEVICE, "no HIP device visible");
@@ -499,6 +499,7 @@ plp_status plp_seed_introsort_debug(int32_t device, uint32_t* entries, int64_t n
     int32_t s = 0;
     PLP_HIP(hipMemcpy(&s, st.p, 4, hipMemcpyDeviceToHost));
     PLP_HIP(hipMemcpy(entries, ent.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (n_live) { uint32_t nl = (uint32_t)n; if (n > 16) PLP_HIP(hipMemcpy(&nl, ws.p, 4, hipMemcpyDeviceToHost)); *n_live = (int32_t)nl; }
     if (dflag && getenv("PLP_SEED_SORT_DBG_FILE")) {
         std::vector<int> h(2 + 6 * 4000 + 48);
         PLP_HIP(hipMemcpy(h.data(), dbg.p, h.size() * 4, hipMemcpyDeviceToHost));

@@ -57,19 +57,22 @@ namespace plp {
 
 constexpr int kSsLatMaxFrames = 256;   // batches up to this many frames take the 16-wave configuration (one workgroup per CU)
 
-size_t seed_sort_ws_entries(size_t nv) { return ((nv / 2 + 64 + 1) & ~(size_t)1) + 2 * 2 * ((nv + 63) / 64 + 1); }   // u32 units per frame
+size_t seed_sort_ws_entries(size_t nv) { return 2 + 2 * ((nv / 2 + 64 + 1) & ~(size_t)1) + 2 * 2 * ((nv + 63) / 64 + 1); }   // u32 units per frame: n_live, two rank-indexed entry lists, chunk masks
 
 // The final insertion sort = a stable counting sort by bin of the DEFINED entries, in array order (k_lsd_order's steps 2-4 on the
 // permuted array instead of the row-major pixel sequence).
-__global__ __launch_bounds__(256) void k_lsd_order_entries(LinePlanes P, const uint32_t* __restrict__ ent_all) {
+__global__ __launch_bounds__(256) void k_lsd_order_entries(LinePlanes P, const uint32_t* __restrict__ ent_all, const uint32_t* __restrict__ ws_all, size_t ws_stride) {
     __shared__ uint32_t cnt[4][1024];
     __shared__ uint32_t s_wsum[4];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
-    const int nv = (P.sw - 1) * (P.sh - 1);
+    const int nv_all = (P.sw - 1) * (P.sh - 1);
+    // the sort's live length: behind it lie right parts of partitions whose pivot bin was below the bin of the smallest defined magnitude -- undefined pixels
+    // and stale copies of entries that moved to the left (seed_sort_impl.inc wg_partition): not part of the array any more
+    const int nv = min(nv_all, (int)__builtin_amdgcn_readfirstlane((int)ws_all[(size_t)b * ws_stride]));
     for (int i = tid; i < 4096; i += 256) (&cnt[0][0])[i] = 0;
     __syncthreads();
-    const uint32_t* ent = ent_all + (size_t)b * nv;
-    uint32_t* order = P.order + (size_t)b * nv;
+    const uint32_t* ent = ent_all + (size_t)b * nv_all;
+    uint32_t* order = P.order + (size_t)b * nv_all;
     const int ngroups = (nv + 63) / 64, gper = (ngroups + 3) / 4, g0 = q * gper, g1 = min(ngroups, g0 + gper);
     uint32_t* comp = P.reg + (size_t)b * P.reg_frame_stride + (size_t)g0 * 64;
     int ncomp = 0;
@@ -147,7 +150,7 @@ void launch_seed_order_exact(hipStream_t st, const LinePlanes& P, const LsdParam
     const size_t nv = (size_t)(P.sw - 1) * (P.sh - 1);
     if (B <= kSsLatMaxFrames) hipLaunchKernelGGL(ss_lat::k_lsd_seed_sort, dim3(B), dim3(ss_lat::kSsThreads), ss_lat::lds_bytes(nv), st, P, lp, (n + 255) / 256, ent, ws, ws_stride);
     else hipLaunchKernelGGL(ss_thr::k_lsd_seed_sort, dim3(B), dim3(ss_thr::kSsThreads), ss_thr::lds_bytes(nv), st, P, lp, (n + 255) / 256, ent, ws, ws_stride);
-    hipLaunchKernelGGL(k_lsd_order_entries, dim3(B), dim3(256), 0, st, P, (const uint32_t*)ent);
+    hipLaunchKernelGGL(k_lsd_order_entries, dim3(B), dim3(256), 0, st, P, (const uint32_t*)ent, (const uint32_t*)ws, ws_stride);
 }
 hipError_t seed_sort_configure() {
     const void* fns[4] = {reinterpret_cast<const void*>(ss_thr::k_lsd_seed_sort), reinterpret_cast<const void*>(ss_thr::k_seed_sort_debug),

@@ -47,15 +47,22 @@ def test_kernel_leaves_parts_below_the_skip_key_alone_exactly_as_the_model_does(
     identical arrays, and the order of the entries at or above the key is std::sort's"""
     r = np.random.default_rng(9)
     key = lambda a: (a >> np.uint32(20)).astype(np.int64)
+    n_dead_total = 0
     for trial in range(64):
         n = [300, 5000, 24577, 40000, 76241, 100000][trial % 6] + trial
         e = _seed_entries(r, n, [1, 7, 0, 2, 3, 6, 4, 5][trial % 8])
         skip = int(r.integers(1, 60)) if trial % 2 else int(r.integers(1, 1024))
-        got = plp.seed_introsort_debug(e, -1, skip, variant=(trial // 2) % 2)
-        assert np.array_equal(got, plp.model_seed_introsort(e, -1, skip)), (trial, n, skip)
-        fin = got[np.argsort(-key(got), kind="stable")]
+        got, n_live = plp.seed_introsort_debug(e, -1, skip, variant=(trial // 2) % 2, return_live=True)
+        want = plp.model_seed_introsort(e, -1, skip)
+        # round 6: behind n_live lie right parts of global-memory partitions whose pivot key was below the skip key -- the kernel no longer stores into them (nothing
+        # reads them again): the live part must be the model's, and the model's entries behind it must all be below the skip key
+        assert 0 < n_live <= n and np.array_equal(got[:n_live], want[:n_live]), (trial, n, skip, n_live)
+        assert np.all(key(want[n_live:]) < skip), (trial, n, skip, n_live)
+        fin = got[:n_live][np.argsort(-key(got[:n_live]), kind="stable")]
         ref = O.std_sort_entries(e)
         assert np.array_equal(fin[key(fin) >= skip], ref[key(ref) >= skip]), (trial, n, skip)
+        n_dead_total += n - n_live
+    assert n_dead_total > 0, "no trial exercised the dead-suffix rule"
 
 
 def test_exact_seed_order_leaves_no_key_line_different_from_std_sort(golden_dir):

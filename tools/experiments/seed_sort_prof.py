@@ -17,8 +17,9 @@ for f in frames:
     skip = int(bins[(norm > rho).ravel()].min())
     w = plp.model_seed_introsort(e, -1, skip)
     for rep in range(3):
-        t0 = time.perf_counter(); g = plp.seed_introsort_debug(e, -1, skip); dt = time.perf_counter() - t0
-    assert np.array_equal(g, w)
+        t0 = time.perf_counter(); g, nl = plp.seed_introsort_debug(e, -1, skip, return_live=True); dt = time.perf_counter() - t0
+    assert np.array_equal(g[:nl], w[:nl]), 'live part differs from the model'
+    print('n_live', nl, 'of', e.size)
     print('skip key', skip)
     log = np.fromfile("/tmp/ss_log.bin", np.int32)
     t = log[2 + 6 * 4000:].view(np.int64)
