@@ -277,7 +277,12 @@ plp_status plp_line_last_batch_status(plp_line* c) {
     if (s[0] & 1) return set_error(PLP_ERR_CAPACITY, "a frame produced more lines than `cap`; output truncated");
     if (s[0] & 4) return set_error(PLP_ERR_OVERFLOW, "more LSD segments than the per-frame capacity");
     if (s[0] & 16) return set_error(PLP_ERR_HIP, "region growing with several waves per frame timed out in a wait (protocol error, please report the frame)");
-    if (s[0] & 32) return set_error(PLP_ERR_OVERFLOW, "the exact seed sort stopped short: a queue of its LDS ran out of space, or a partner position lay outside its segment and the swap was skipped (the seed order of this batch is not guaranteed; please report the frame)");
+    if (s[0] & 32) {
+        static thread_local char msg[320];
+        snprintf(msg, sizeof msg, "the exact seed sort stopped short in frame %d of the batch (reason %d: 1 = a partition's swap count / cut failed its check [m = %d], 2-3, 6-8 = a list or stack of its LDS ran out of space, "
+                 "4-5 = a wave waited beyond the limit): the seed order of this batch is not guaranteed; please report the frame", s[2], s[1], s[3]);
+        return set_error(PLP_ERR_OVERFLOW, msg);
+    }
     return PLP_OK;
 }
 
@@ -320,7 +325,12 @@ plp_status plp_line_extract(plp_line* c, const uint8_t* img, int32_t rows, int32
     PLP_HIP(hipMemcpy(s, c->status.p, 16, hipMemcpyDeviceToHost));
     if (s[0] & 4) return set_error(PLP_ERR_OVERFLOW, "more LSD segments than the per-frame capacity");
     if (s[0] & 16) return set_error(PLP_ERR_HIP, "region growing with several waves per frame timed out in a wait (protocol error, please report the frame)");
-    if (s[0] & 32) return set_error(PLP_ERR_OVERFLOW, "the exact seed sort stopped short: a queue of its LDS ran out of space, or a partner position lay outside its segment and the swap was skipped (the seed order of this batch is not guaranteed; please report the frame)");
+    if (s[0] & 32) {
+        static thread_local char msg[320];
+        snprintf(msg, sizeof msg, "the exact seed sort stopped short in frame %d of the batch (reason %d: 1 = a partition's swap count / cut failed its check [m = %d], 2-3, 6-8 = a list or stack of its LDS ran out of space, "
+                 "4-5 = a wave waited beyond the limit): the seed order of this batch is not guaranteed; please report the frame", s[2], s[1], s[3]);
+        return set_error(PLP_ERR_OVERFLOW, msg);
+    }
     return PLP_OK;
 }
 

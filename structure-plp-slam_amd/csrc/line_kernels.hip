@@ -1263,7 +1263,11 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
     int* cur_pos = hcount + 4;                                                                      // [helpers]: seed position of each helper's latest attempt
     int* pend_lo = cur_pos + kMwMaxWaves; int* pend_hi = pend_lo + kMwMaxWaves;                      // [helpers]: lowest / highest seed position among its finished, waiting regions
     uint8_t* owner = reinterpret_cast<uint8_t*>(pend_hi + kMwMaxWaves);                          // [n_groups_cap]: 0 unpublished, 1 main, 2 + (h * kMwBufs + k)
-    MwEntry* entries = reinterpret_cast<MwEntry*>((reinterpret_cast<uintptr_t>(owner + ((L.n_groups_cap + 15) & ~15)) + 15) & ~(uintptr_t)15);   // [helpers][kMwBufs][kMwEntries]
+    // [helpers][kMwBufs][kMwEntries], 16-byte aligned.  The rounding is done on the OFFSET from the (16-byte aligned) LDS base, not on the address as an integer: a pointer
+    // made from an integer has no address space the compiler knows, and the hand-over records were reached through FLAT instructions until round 6 -- the one way of
+    // reaching LDS that a seed-sort build failed with inside the overlapped step while the same layout through DS instructions never did (profiles/r06_seed_sort.md)
+    unsigned char* const mw_base = reinterpret_cast<unsigned char*>(s_mw);
+    MwEntry* entries = reinterpret_cast<MwEntry*>(mw_base + (((size_t)((owner + ((L.n_groups_cap + 15) & ~15)) - mw_base) + 15) & ~(size_t)15));
     const int n_ord = P.n_order[b];
     const int n_groups = (n_ord + kMwGroup - 1) / kMwGroup;   // ownership units: kMwGroup consecutive seeds
     {   // C = NOTDEF mask (an undefined pixel is never a seed and never aligned), no pixel held by anybody

@@ -615,9 +615,13 @@ __global__ PLP_TOPK_CELLS_BOUNDS void k_match_topk_cells(MatchProblem P, int qpb
         for (int i = tid; i < (ncell + 2) / 2; i += 256) reinterpret_cast<uint32_t*>(cs)[i] = g32[i];
     }
     __syncthreads();
-    auto t_xy = [&](int i) -> float2 { if (i < nb) return sxy[i]; const uint4 r = g_sorted[i]; return make_float2(__uint_as_float(r.x), __uint_as_float(r.y)); };
-    auto t_to = [&](int i) -> uint32_t { if (i < nb) return sto[i]; const uint4 r = g_sorted[i]; return (r.w & 0xffffu) | ((r.z & 0xffu) << 16); };   // index | octave << 16
-    auto t_xr = [&](int i) -> float { return i < nb ? sxr[i] : g_sorted_xr[i]; };
+    // (the staged copies are read through pointers that SAY they are LDS: written as `i < nb ? sxy[i] : ...` the compiler selected between the two POINTERS and
+    // loaded through a FLAT instruction -- round 6 keeps FLAT away from LDS in every kernel, profiles/r06_seed_sort.md)
+    typedef const __attribute__((address_space(3))) uint32_t* lds_u32; typedef const __attribute__((address_space(3))) float* lds_f32;
+    const lds_f32 sxy_l = (lds_f32)sxy; const lds_u32 sto_l = (lds_u32)sto; const lds_f32 sxr_l = (lds_f32)sxr;
+    auto t_xy = [&](int i) -> float2 { if (i < nb) return make_float2(sxy_l[2 * i], sxy_l[2 * i + 1]); const uint4 r = g_sorted[i]; return make_float2(__uint_as_float(r.x), __uint_as_float(r.y)); };
+    auto t_to = [&](int i) -> uint32_t { if (i < nb) return sto_l[i]; const uint4 r = g_sorted[i]; return (r.w & 0xffffu) | ((r.z & 0xffu) << 16); };   // index | octave << 16
+    auto t_xr = [&](int i) -> float { return i < nb ? sxr_l[i] : g_sorted_xr[i]; };
     const uint8_t* q_valid = P.q_valid ? P.q_valid + (size_t)b * P.m_cap : nullptr;
     const int q_end = min(m, q_begin + qpb);
     for (int q = q_begin + tid; q < q_end; q += 256) {

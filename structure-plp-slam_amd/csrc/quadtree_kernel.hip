@@ -170,10 +170,12 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelDev* __restrict__ l
 
     // ---- 2. LSD radix sort (4 bits per pass) of candidate indices by key bits [sort_lo, sort_hi)
     const int nseg = (n + 63) >> 6;
-    uint16_t* CNT = nseg <= kQtSegLds ? S.cnt : cnt_hbm;   // flat pointer
     uint32_t* src = idxA;
     uint32_t* dst = idxB;
     bool first = true;
+    // The radix counters live in LDS, or -- levels with more than 32768 candidates -- in HBM.  ONE instantiation per place (round 6): a pointer chosen at run time made
+    // every access a FLAT instruction, and FLAT is the one way of reaching LDS that a seed-sort build failed with beside other kernels (profiles/r06_seed_sort.md).
+    auto radix_passes = [&](auto* CNT) {
     for (int shift = L.sort_lo; shift < L.sort_hi; shift += 4) {
         for (int seg = wv; seg < nseg; seg += 4) {
             const int i = seg * 64 + lane;
@@ -209,6 +211,8 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelDev* __restrict__ l
         uint32_t* t = src; src = dst; dst = t;
         first = false;
     }
+    };
+    if (nseg <= kQtSegLds) radix_passes(S.cnt); else radix_passes(cnt_hbm);
     // src now holds candidate indices in key order (identity if no pass ran); dst <- sorted keys
     for (int i = tid; i < n; i += 256) {
         const uint32_t id = first ? (uint32_t)i : src[i];
@@ -219,7 +223,9 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelDev* __restrict__ l
     }
     __syncthreads();
     const uint32_t* sidx = src;
-    const uint32_t* K = n <= kQtKeyCache ? S.big : dst;   // flat pointer: LDS cache or HBM scratch
+    // The sorted keys are read from their LDS copy when it exists, from the HBM scratch otherwise.  The rest of the kernel is written once and inlined once per
+    // place (round 6): `K = n <= kQtKeyCache ? S.big : dst` made every key read a FLAT instruction -- see radix_passes above.
+    auto divide_and_select = [&](const uint32_t* K) {
 
     // ---- 3a. initial nodes = runs of equal initial-node index
     int cur = 0;
@@ -398,6 +404,8 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelDev* __restrict__ l
         out_sel[i] = (int32_t)best_pk;
     }
     if (tid == 0) *out_cnt = m_out;
+    };
+    if (n <= kQtKeyCache) divide_and_select(S.big); else divide_and_select(dst);
 }
 
 size_t quadtree_scratch_bytes_per_frame(const LevelDev* h_lv, int n_levels) {
