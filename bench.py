@@ -78,6 +78,27 @@ def algorithmic_bytes(rows, cols, n_levels, mean_kp, mean_cand, mean_lines, mean
     }
 
 
+def step_profile_fields(bytes_per_frame, B, dominant):
+    """in-step launch time of the dominant kernel and the register-time bound of the step, from profiles/step_profile.json (committed; same command, same batch)"""
+    out = {"in_step_launch_ms": None, "in_step_frac": None, "occupancy_bound": None, "step_profile_source": None}
+    try:
+        sp = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "step_profile.json")))
+    except (OSError, ValueError):
+        return out
+    if sp.get("batch") != B or sp.get("dominant", "").split("::")[-1] != {"lsd_grow": "k_lsd_grow"}.get(dominant, dominant):
+        return out
+    ins = {int(k): v for k, v in sp.get("in_step_launches", {}).items() if not v.get("isolated")}
+    if ins:
+        frames, v = max(ins.items(), key=lambda kv: kv[1]["launches"])
+        out["in_step_launch_ms"] = {"frames_per_launch": frames, "mean_ms": v["mean_ms"], "launches_in_the_trace": v["launches"]}
+        out["in_step_frac"] = round(bytes_per_frame * frames / (v["mean_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)
+    ob = sp.get("occupancy_bound")
+    if ob:
+        out["occupancy_bound"] = {k: ob[k] for k in ("register_cycles", "ideal_ms", "ms_per_step_of_that_run", "packing", "shares") if k in ob}
+    out["step_profile_source"] = sp.get("source")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,7 +150,8 @@ def main():
                          n_line=int(os.environ.get("PLP_BENCH_LINE_SPLIT", "2")), nbuf=int(os.environ.get("PLP_BENCH_NBUF", "2")), serial=serial,
                          shift=(SHIFT_X, 0.0), parts=os.environ.get("PLP_BENCH_PARTS", "orb,lines,match"),   # PLP_BENCH_PARTS: diagnostic, time a subset of the step
                          seed_order=plp.SEED_ORDER_STABLE if args.seed_order == "stable" else plp.SEED_ORDER_LIBSTDCXX,
-                         line_depth=int(os.environ.get("PLP_BENCH_LINE_DEPTH", "1")))
+                         line_depth=int(os.environ.get("PLP_BENCH_LINE_DEPTH", "1")),
+                         halo_mode=os.environ.get("PLP_BENCH_HALO", "ring"))      # PLP_BENCH_HALO=allgather: the step's one exchange as an all-gather (the collective north_star names)
     cap, lcap, NBUF = ts.cap, ts.lcap, ts.NBUF
     kps2, desc2, cnt2, kl2, lbd2, fn2, lcnt2 = ts.kps2, ts.desc2, ts.cnt2, ts.kl2, ts.lbd2, ts.fn2, ts.lcnt2
     d_kps, d_desc, d_cnt = kps2[0][HALO:], desc2[0][HALO:], cnt2[0][HALO:]
@@ -254,7 +276,30 @@ def main():
     mean_cand = float(sum(len(ex.debug_read(ex.DBG_CANDIDATES, l, 0)) for l in range(nl)))
     per_frame = algorithmic_bytes(args.rows, args.cols, nl, mean_kp, mean_cand, mean_lines, mean_len, mean_raw)
     n_match_q = 3 * mean_kp + 3 * mean_lines            # last-frame + 2 x landmark queries, points and lines
-    per_frame["match_4x"] = n_match_q * 32 + n_match_q * 15 * (32 + 28)   # 32*M + 60*C, ~15 candidates per query
+    # 32 M + 60 C bytes, C = candidates whose descriptor distance is computed.  C is COUNTED here (it was assumed to be 15): for eight
+    # frames of the step, every query of the two point matchers against the key points of its target frame -- inside the query's square window (margin x the scale
+    # factor of its level, data/common.cc get_keypoints_in_cell) and inside the matcher's level range -- on the host from the step's own arrays.
+    cand_per_query = None
+    if not args.orb_only:
+        hk = kps2[last_buf][:HALO + 8].cpu().numpy().view(plp.KP_DTYPE).reshape(HALO + 8, cap)
+        hc = cnt2[last_buf][:HALO + 8].cpu().numpy()
+        sf_np = np.asarray(sf, np.float32)
+        tot_c = tot_q = 0
+        for b in range(8):
+            t = hk[HALO + b][:hc[HALO + b]]
+            tx, ty, tl = t["x"].astype(np.float64), t["y"].astype(np.float64), t["octave"].astype(np.int64)
+            for back, margin, lo, hi in ((1, 20.0, -1, 1), (1, 10.0, -1, 0), (2, 10.0, -1, 0)):     # last-frame matcher (levels l-1 .. l+1); landmarks of frames b-1, b-2 (l-1 .. l)
+                q = hk[HALO + b - back][:hc[HALO + b - back]]
+                qx, qy, ql = q["x"].astype(np.float64) + back * SHIFT_X, q["y"].astype(np.float64), q["octave"].astype(np.int64)
+                r = margin * sf_np[ql].astype(np.float64)
+                for i0 in range(0, len(q), 256):
+                    sl = slice(i0, i0 + 256)
+                    inside = (np.abs(tx[None, :] - qx[sl, None]) < r[sl, None]) & (np.abs(ty[None, :] - qy[sl, None]) < r[sl, None])
+                    inside &= (tl[None, :] >= ql[sl, None] + lo) & (tl[None, :] <= ql[sl, None] + hi)
+                    tot_c += int(inside.sum())
+                tot_q += len(q)
+        cand_per_query = tot_c / max(tot_q, 1)
+    per_frame["match_4x"] = n_match_q * 32 + n_match_q * (cand_per_query if cand_per_query is not None else 15) * (32 + 28)
     kern = {k: v for k, v in stage_ms.items() if k in per_frame and v > 0}
     dominant = max(kern, key=kern.get)
     launches = {"pyramid": 7, "lsd_blur11_resize": 2, "lsd_gradient_bins": 2, "lbd_blur5_sobel": 2, "match_4x": 8}.get(dominant, 1)
@@ -280,6 +325,12 @@ def main():
                 # whole path: algorithmic bytes of one frame through all stages x frames/s / peak
                 "path_bytes_per_frame": int(sum(per_frame.values())), "path_frac": round(sum(per_frame.values()) * fps / world / 1e9 / HBM_PEAK_GBS, 6),
                 "launch_ms": round(kern[dominant] / launches, 4), "bytes_per_launch": int(dom_bytes / launches),
+                # The figures above describe an ISOLATED, synchronous pass.  Inside the overlapped step the dominant kernel runs per line sub-block beside the other
+                # streams' kernels: its launch duration there and the fraction that follows come from the committed kernel trace of this command (profiles/step_profile.json,
+                # tools/step_profile.py); `occupancy_bound` = the step against the resource round 4 found binding (register-time: waves x cycles x VGPRs of all its kernels
+                # against 1024 SIMDs x 512 registers x 2.4 GHz).  Quoted from the committed profile, not measured by this run (as `traffic`).
+                **step_profile_fields(per_frame[dominant], B, dominant),
+                "match_candidates_per_query_counted": None if cand_per_query is None else round(cand_per_query, 2),
                 "stage_ms_per_batch": {k: round(v, 4) for k, v in stage_ms.items()},
                 "stage_GBps": {k: round(per_frame[k] * B / (kern[k] * 1e-3) / 1e9, 1) for k in kern}}
 
@@ -472,7 +523,11 @@ def main():
                    "frames_per_rank_per_step": B, "keypoints_mean": round(mean_kp, 1), "lines_mean": round(mean_lines, 1),
                    "matches_mean": [round(float(n1.float().mean().item()), 1), round(float(n2.float().mean().item()), 1)] + ([] if args.orb_only else [round(float(n3.float().mean().item()), 1), round(float(n4.float().mean().item()), 1)]),
                    "match_rescans_rounds": (match_dbg if not args.orb_only else None),
-                   "sharding": "contiguous frame blocks per rank; one packed RCCL send/recv per rank (ring) of the 2-frame feature halo for the matchers"},
+                   "sharding": f"contiguous frame blocks per rank; ONE exchange per step and rank of the 2-frame feature halo the matchers read -- key points, descriptors, key lines, LBD "
+                               f"rows and both count arrays packed into one record per frame ({ts.halo.record_bytes} bytes), moved by "
+                               + ("one send to the successor + one receive from the predecessor (ring)" if ts.halo_mode == "ring" else "one all_gather_into_tensor of the packed tails")
+                               + (" over RCCL" if world > 1 and not os.environ.get("PLP_BENCH_SHARE_GPU") else (" over gloo (diagnostic: all ranks on one GPU)" if world > 1 else "; a single rank copies its own tail")),
+                   "halo_mode": ts.halo_mode, "halo_bytes_per_rank_per_step": ts.halo.bytes_per_step},
         "roofline": roofline,
         # LSD seed order of the headline number (the reference's: std::sort as libstdc++ implements it) and the same steps in the other order
         "seed_order": args.seed_order, "other_seed_order": other,

@@ -71,6 +71,63 @@ def exchange_halo_into(buffers, halo=2, group=None, mode="ring"):
         t[:halo].copy_(tail)
 
 
+class halo_exchanger:
+    """The ONE packed exchange of a step: the two-frame tails of ALL feature arrays of the step -- key points, descriptors, key lines, LBD rows
+    and both count arrays -- travel as one record per frame in one collective, through buffers that are allocated once (exchange_halo builds its record with
+    torch.cat: an allocation inside the timed step).  mode "ring": one send to the successor and one receive from the predecessor (xGMI is point-to-point: only the
+    bytes that are needed cross a link); "allgather": one all_gather_into_tensor of the packed tails, the collective north_star names.  A single rank copies its
+    own tail (the replay is circular).  Stream order is the caller's, as for exchange_halo_into."""
+
+    def __init__(self, buffers, halo=2, mode="ring", group=None):
+        assert mode in ("ring", "allgather"), mode
+        self.halo, self.mode, self.group = halo, mode, group
+        self.sizes = [int(t[0].numel() * t.element_size()) for t in buffers]          # bytes per frame of every array
+        self.record_bytes = sum(self.sizes)
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.bytes_per_step = halo * self.record_bytes if self.world > 1 else 0
+        if self.world > 1:
+            dev = buffers[0].device
+            self.rank = dist.get_rank(group)
+            self.bounce = dev.type == "cuda" and dist.get_backend(group) == "gloo"      # gloo moves host tensors only (diagnostic runs on one GPU)
+            self.send = torch.empty((halo, self.record_bytes), dtype=torch.uint8, device=dev)
+            self.recv = torch.empty((halo, self.record_bytes), dtype=torch.uint8, device=dev)
+            xdev = "cpu" if self.bounce else dev
+            if self.bounce:
+                self.h_send, self.h_recv = torch.empty_like(self.send, device="cpu"), torch.empty_like(self.recv, device="cpu")
+            if mode == "allgather":
+                self.gathered = torch.empty((self.world * halo, self.record_bytes), dtype=torch.uint8, device=xdev)
+
+    def __call__(self, buffers):
+        """buffers laid out [halo + B, ...]: rows halo.. are this rank's block, rows 0..halo-1 receive the predecessor's tail"""
+        halo = self.halo
+        if self.world == 1:
+            for t in buffers:
+                t[:halo].copy_(t[-halo:].clone() if t.shape[0] < 2 * halo else t[-halo:])
+            return
+        rows = lambda t, sl: t[sl].contiguous().view(torch.uint8).reshape(halo, -1)    # (a slice of whole frames of a contiguous array: no copy)
+        off = 0
+        for t, nb in zip(buffers, self.sizes):
+            self.send[:, off:off + nb].copy_(rows(t, slice(t.shape[0] - halo, t.shape[0])))
+            off += nb
+        src, dst = self.send, self.recv
+        if self.bounce:
+            self.h_send.copy_(self.send); src, dst = self.h_send, self.h_recv
+        if self.mode == "allgather":
+            dist.all_gather_into_tensor(self.gathered, src, group=self.group)
+            prev = (self.rank - 1) % self.world
+            dst = self.gathered[prev * halo:(prev + 1) * halo]
+        else:
+            ops = [dist.P2POp(dist.isend, src, (self.rank + 1) % self.world, self.group), dist.P2POp(dist.irecv, dst, (self.rank - 1) % self.world, self.group)]
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        if self.bounce or self.mode == "allgather":
+            self.recv.copy_(dst)
+        off = 0
+        for t, nb in zip(buffers, self.sizes):
+            rows(t, slice(0, halo)).copy_(self.recv[:, off:off + nb])
+            off += nb
+
+
 class point_queries:
     """Device-side builder of the tracker's per-frame queries in a replay (plp_replay_point_queries_device): outputs are allocated
     once and rewritten every step."""

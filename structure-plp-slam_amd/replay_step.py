@@ -6,7 +6,7 @@ matcher calls), for all frames of the batch at once:
 
   stream A        ORB extract                                           plp_orb_extract_batch_device
   streams B1..Bn  LSD + LBD extract, the batch cut into n sub-blocks    plp_line_extract_batch_device
-  stream C        halo exchange of the two-frame feature tails (replay.exchange_halo_into), then for every frame b
+  stream C        ONE packed halo exchange of the two-frame tails of all feature arrays (replay.halo_exchanger), then for every frame b
                     m1  match_current_and_last_frames       frame b-1's key points moved by the pan -> frame b   margin 20, ratio 0.9, orientation check
                     m2  match_frame_and_landmarks           key points of frames b-2, b-1 as ~2K local landmarks  margin 10, ratio 0.8
                     m3  match_current_and_last_frames_line  frame b-1's key lines moved by the pan -> frame b    margin 20
@@ -28,7 +28,7 @@ LCAP = 512  # key lines kept per frame (a 640x480 frame yields ~50 after the >= 
 
 class tracker_step:
     def __init__(self, plp, B, K, rows, cols, device_index=0, orb_only=False, n_line=2, nbuf=2, serial=False, shift=(-3.0, 0.0), parts="orb,lines,match", line_grow_waves=0, seed_order=None,
-                 line_depth=1):
+                 line_depth=1, halo_mode="ring"):
         import torch
         self.torch = torch
         self.plp, self.B, self.K, self.rows, self.cols = plp, B, K, rows, cols
@@ -81,6 +81,9 @@ class tracker_step:
         self.sC = self.sA if serial else torch.cuda.Stream(dev)
         self.pq = self.replay.point_queries(plp, B, cap, dev)
         self.lq = None if orb_only else self.replay.line_queries(plp, B, lcap, dev, landmarks=True)
+        # ONE exchange per step: the tails of every feature array the matchers read, packed into one record per frame (replay.halo_exchanger)
+        self.halo_mode = halo_mode
+        self.halo = self.replay.halo_exchanger(self._halo_arrays(0), halo=HALO, mode=halo_mode)
         self.done_match = [None] * NBUF
         self.extract_events = []
         self.step_no = 0
@@ -98,13 +101,21 @@ class tracker_step:
                     with torch.cuda.stream(s):
                         torch.cuda._sleep(int(i * shift_ms * 1e-3 * 2.1e9))
 
+    def _halo_arrays(self, buf):
+        pts = [self.kps2[buf], self.desc2[buf], self.cnt2[buf]]
+        return pts if self.orb_only else pts + [self.kl2[buf], self.lbd2[buf], self.lcnt2[buf]]
+
     def match_stage(self, buf=0, st=None, before_lines=None):
         """the tracker's four matcher calls for every frame of the step held in feature set `buf`, on stream st"""
         plp, replay, B, cap, lcap = self.plp, self.replay, self.B, self.cap, self.lcap
         st = st or self.sA
         kps, desc, cnt = self.kps2[buf], self.desc2[buf], self.cnt2[buf]
-        # the two frames preceding this rank's block come from the previous rank: one packed exchange into rows 0..HALO-1
-        replay.exchange_halo_into([kps, desc, cnt], halo=HALO)
+        # The two frames preceding this rank's block come from the previous rank: ONE packed exchange per step into rows 0..HALO-1 of all six arrays (round 6; until
+        # then the points went first and the lines in a second exchange once their streams were done).  It needs every extractor of the step, so the matchers start
+        # when the line streams are done too -- they run on a stream of their own beside the NEXT step's extractors, which is where the time goes either way.
+        if before_lines is not None:
+            before_lines()
+        self.halo(self._halo_arrays(buf))
         self.pq.build(kps, cnt, HALO, self.shift, st)       # reprojections / levels / angles / validity of the queries: one launch
         pq = self.pq
         t = dict(t_kps=kps[HALO:], t_desc=desc[HALO:], t_counts=cnt[HALO:])
@@ -117,10 +128,7 @@ class tracker_step:
         self.mt_lm.match_device(plp.MODE_LANDMARKS, cap, 2 * cap, {**t, **q2}, self.m2, self.n2, margin=10.0, scale_factors=self.sf, grid=self.grid, B=B, stream=st)
         if self.orb_only:
             return
-        if before_lines is not None:
-            before_lines()          # the point matchers only needed the ORB stream; the line matchers wait for the line streams here
         kl, lbd, lcnt = self.kl2[buf], self.lbd2[buf], self.lcnt2[buf]
-        replay.exchange_halo_into([kl, lbd, lcnt], halo=HALO)
         lq = self.lq
         lq.build(kl, lcnt, HALO, self.shift, st, feat_kps=kps, feat_kp_counts=cnt)   # key lines of the previous frames, both end points moved by the pan
         tl = dict(t_kl=kl[HALO:], t_desc=lbd[HALO:], t_counts=lcnt[HALO:])

@@ -15,9 +15,10 @@ pytestmark = pytest.mark.gpu
 ROOT = pathlib.Path(__file__).resolve().parents[1]
 
 
-def test_two_rank_bench_line_is_verified_on_every_rank():
+@pytest.mark.parametrize("halo", ["ring", "allgather"])     # the step's one exchange as a neighbour shift (default) and as the all-gather north_star names (PLP_BENCH_HALO)
+def test_two_rank_bench_line_is_verified_on_every_rank(halo):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    env = dict(os.environ, PLP_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, PLP_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1", PLP_BENCH_HALO=halo)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
            str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "128", "--no-cpu-baseline", "--no-extras", "--verify", "8"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
@@ -28,3 +29,4 @@ def test_two_rank_bench_line_is_verified_on_every_rank():
     assert j["verified_frames"] == 16, j["verified_frames"]          # 8 per rank
     assert j["verified_halo_rows"] == 4, j["verified_halo_rows"]      # 2 per rank
     assert j["value"] > 0
+    assert j["config"]["halo_mode"] == halo and j["config"]["halo_bytes_per_rank_per_step"] > 2 * (2064 * 60 + 512 * 100)     # one record per frame: points AND lines

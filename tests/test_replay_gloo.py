@@ -28,6 +28,14 @@ def _worker(rank, world, port, n_frames, q):
     ak, ad, ac = replay.exchange_halo([kps, desc, cnt], halo=2, mode="allgather")      # the two transports agree
     assert torch.equal(hk, ak) and torch.equal(hd, ad) and torch.equal(hc, ac)
     assert hk.dtype == kps.dtype and hd.dtype == desc.dtype and hc.dtype == cnt.dtype and hk.shape == (2, 5, 7)
+    # the step's form (replay.halo_exchanger: persistent buffers, ONE exchange for all arrays) fills rows 0..1 of [halo + B, ...] arrays with the same tails, both modes
+    for mode in ("ring", "allgather"):
+        bufs = [torch.cat([torch.zeros_like(t[:2]), t], 0) for t in (kps, desc, cnt)]
+        ex = replay.halo_exchanger(bufs, halo=2, mode=mode)
+        assert ex.record_bytes == 5 * 7 * 4 + 5 * 32 + 4 and ex.bytes_per_step == 2 * ex.record_bytes
+        ex(bufs)
+        assert torch.equal(bufs[0][:2], hk) and torch.equal(bufs[1][:2], hd) and torch.equal(bufs[2][:2], hc), mode
+        assert torch.equal(bufs[0][2:], kps) and torch.equal(bufs[2][2:], cnt)
     full = replay.with_halo(cnt, hc)
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)          # the max-over-ranks timing reduction of bench.py
@@ -60,5 +68,8 @@ def test_single_rank_halo_is_circular():
     cnt = torch.arange(5)
     (h,) = replay.exchange_halo([cnt], halo=2)
     assert h.tolist() == [3, 4]
+    buf = torch.cat([torch.zeros(2, dtype=cnt.dtype), cnt])
+    replay.halo_exchanger([buf], halo=2)([buf])
+    assert buf.tolist() == [3, 4, 0, 1, 2, 3, 4]
     assert replay.frame_block(0, 1, 7) == (0, 7)
     assert [replay.frame_block(r, 3, 10) for r in range(3)] == [(0, 4), (4, 7), (7, 10)]

@@ -24,6 +24,8 @@ struct Stats {
     long seeds_static_lone = 0, seeds_lone_dynamic = 0, seeds_total = 0, seeds_static_nonlone_but_single = 0;
 };
 static Stats st;
+static int g_slots = 7;                          // region points per round (7 in k_lsd_grow; 3 when two frames share a wave: 27 of a half-wave's 32 lanes)
+static std::vector<std::vector<int>> g_round_acc;   // per frame: acceptances of every round, in order (for the two-frames-per-wave projection)
 // batched simulation of region_grow: identical result to the sequential one (the kernel's round structure)
 void grow_sim(Lsd& L, int sx, int sy, std::vector<Lsd::RegionPoint>& reg, double& reg_angle, double prec) {
     const int w = L.w_, h = L.h_;
@@ -36,7 +38,7 @@ void grow_sim(Lsd& L, int sx, int sy, std::vector<Lsd::RegionPoint>& reg, double
     size_t prev_known = 1;   // nreg before the previous round
     for (size_t i = 0; i < reg.size();) {
         const size_t n0 = reg.size();
-        const size_t nb = std::min<size_t>(7, n0 - i);
+        const size_t nb = std::min<size_t>((size_t)g_slots, n0 - i);
         ++st.rounds; ++my_rounds;
         st.rounds_by_q[std::min<size_t>(63, n0 - i)]++;
         if (i > 0) { if (i + nb <= prev_known) ++st.rounds_prefetchable; else if (i < prev_known) ++st.rounds_partial; }
@@ -83,6 +85,7 @@ void grow_sim(Lsd& L, int sx, int sy, std::vector<Lsd::RegionPoint>& reg, double
             if (got == spec) st.bulk_ok[m]++; else st.bulk_bad[m]++;
         }
         st.acc += a; st.acc_hist[std::min(63, a)]++;
+        if (!g_round_acc.empty()) g_round_acc.back().push_back(a);
         if (i == 0) { ++st.first_rounds; if (a == 0) ++st.first_round_noacc; }
         prev_known = n0;
         i += nb;
@@ -93,10 +96,12 @@ void grow_sim(Lsd& L, int sx, int sy, std::vector<Lsd::RegionPoint>& reg, double
 }
 int main(int argc, char** argv) {
     const int H = 480, W = 640, NF = 8;
+    if (argc > 2) g_slots = atoi(argv[2]);
     std::vector<uint8_t> buf((size_t)H * W * NF);
     FILE* f = fopen(argc > 1 ? argv[1] : "/tmp/frames.bin", "rb"); if (!f) { printf("usage: grow_round_stats frames.bin (8 frames of 480 x 640 bytes)\n"); return 2; } if (fread(buf.data(), 1, buf.size(), f) != buf.size()) return 1; fclose(f);
     long total_lines = 0;
     for (int fr = 0; fr < NF; ++fr) {
+        g_round_acc.emplace_back();
         Image img(H, W); std::copy(buf.begin() + (size_t)fr * H * W, buf.begin() + (size_t)(fr + 1) * H * W, img.data.begin());
         LsdOptions o; Lsd L(o, false);
         const double prec = M_PI * o.ang_th / 180, p = o.ang_th / 180, rho = o.quant / std::sin(prec);
@@ -140,6 +145,21 @@ int main(int argc, char** argv) {
     for (int m = 0; m < 16; ++m) if (st.bulk_ok[m] + st.bulk_bad[m]) printf("%d: %.0f ok %.0f bad | ", m, st.bulk_ok[m] / 8.0, st.bulk_bad[m] / 8.0);
     printf("\n");
     printf("seeds grown %.0f: no neighbour aligned with the seed's own angle (static) %.0f, aligned neighbours all USED at its turn %.0f\n", st.seeds_total / 8.0, st.seeds_static_lone / 8.0, st.seeds_lone_dynamic / 8.0);
+    {   // Projection of "two frames per wave" (VERDICT r05 item 4a).  Cost model from the kernel's own clocks (profiles/r05_lsd_grow.md, cycles per round: ring read 340,
+        // USED test 320, record gather 390, appends 230 = 1280 fixed; acceptance loop 730 at 2.35 acceptances = 100 + 268 per acceptance).  A PAIR of frames in one
+        // instruction stream, lanes 0..31 / 32..63, three points x nine lanes each, rounds in lockstep: the fixed phases once per round of the pair (+10 % for the half-wave
+        // bookkeeping), the acceptance loop as two interleaved chains: 1.3 x 268 per iteration, max(a_A, a_B) iterations.
+        double one = 0, pair = 0; long r_one = 0, r_pair = 0;
+        for (auto& f : g_round_acc) { for (int a : f) one += 1280 + 100 + 268.0 * a; r_one += (long)f.size(); }
+        for (size_t k = 0; k + 1 < g_round_acc.size(); k += 2) {
+            const auto &A = g_round_acc[k], &B = g_round_acc[k + 1];
+            const size_t n = std::max(A.size(), B.size());
+            for (size_t i = 0; i < n; ++i) { const int a = i < A.size() ? A[i] : 0, b = i < B.size() ? B[i] : 0; pair += 1280 * 1.10 + 100 + 268.0 * 1.3 * std::max(a, b); }
+            r_pair += (long)n;
+        }
+        printf("slots %d: rounds per frame %.0f; modelled round cycles per frame, one frame per wave: %.2f M; as pairs in lockstep: %ld rounds per pair, %.2f M cycles per PAIR = %.2f M per frame\n",
+               g_slots, r_one / 8.0, one / 8.0 / 1e6, r_pair / 4, pair / 4.0 / 1e6, pair / 8.0 / 1e6);
+    }
     for (auto& kv : st.reg_count) printf("regions <= %d px: %.0f regions, %.0f px, %.0f rounds\n", kv.first, kv.second / 8.0, st.reg_pix[kv.first] / 8.0, st.reg_rounds[kv.first] / 8.0);
     return 0;
 }

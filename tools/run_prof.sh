@@ -19,6 +19,7 @@ cd $R
 python tools/rocpd_summary.py $O/kt/kt_results.db "$T (bench.py --steps 3 --warmup 1)" > $O/${T}_full_kernel_stats.md
 python tools/pmc_traffic.py $O/pmc_fetch/f_results.db $O/pmc_write/w_results.db --batch 2048 --md $O/${T}_pmc_traffic.md --json $O/pmc_traffic.json --source profiles/${T}_pmc_traffic.md
 python tools/sq_table.py $O/sq/sq_results.db > $O/${T}_sq_counters.md
+python tools/step_profile.py $O/kt/kt_results.db $O/sq/sq_results.db --bench $O/bench.json --out $O/step_profile.json --source profiles/${T}_full_kernel_stats.md,profiles/${T}_sq_counters.md > $O/step_profile.log 2>&1; tail -30 $O/step_profile.log
 cp $O/bench.json $O/${T}_bench.json
 rm -rf $O/kt $O/pmc_fetch $O/pmc_write $O/sq
 ls -la $O

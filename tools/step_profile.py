@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Digest of a round profile for bench.py's `roofline` object: what the dominant kernel takes INSIDE the overlapped step, and the step against the
+one resource the round-4 model found binding -- register-time.
+
+    python tools/step_profile.py <kernel-trace results.db> <SQ-counter results.db> --bench <bench.json of the same tree> --out profiles/step_profile.json --source profiles/<tag>_*.md
+
+in_step: durations of `plp::k_lsd_grow` from the kernel trace of `bench.py --steps 3 --warmup 1`, split by launch size (the step launches it per line sub-block of
+1024 frames, two in flight; the isolated stage passes of the same run launch it once over 2048 frames).
+occupancy_bound: sum over the step's kernels of waves x cycles per wave x allocated VGPRs (SQ_WAVES, SQ_WAVE_CYCLES of the counter pass, one launch = the whole batch;
+VGPRs from the build's resource remarks, rounded up to the allocation granule of 8) x launches per step = register-cycles per step; the chip offers
+1024 SIMDs x 512 VGPRs x 2.4e9 cycles/s; ideal_ms = the step if the register file were packed perfectly, packing = ideal_ms / measured ms per step."""
+import argparse, glob, json, os, re, sqlite3
+from collections import defaultdict
+
+LAUNCHES_PER_STEP = {"plp::k_resize_linear": 7}          # every other kernel: 1 (the counter pass runs the line path unsplit); the matcher kernels: 2 (below)
+CHIP = 1024 * 512 * 2.4e9
+
+
+def short(name):
+    return re.sub(r"\(.*", "", name).replace("void ", "").strip()
+
+
+def vgprs():
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "structure-plp-slam_amd", "csrc", "build")
+    out = {}
+    for path in glob.glob(os.path.join(here, "*.remarks")):
+        name = None
+        for line in open(path, errors="replace"):
+            m = re.search(r"Function Name: (\S+)", line)
+            if m:
+                name = m.group(1); continue
+            m = re.search(r"\sVGPRs: (\d+)", line)
+            if m and name:
+                out[name] = int(m.group(1))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("kt_db"); ap.add_argument("sq_db"); ap.add_argument("--bench", required=True); ap.add_argument("--out", required=True); ap.add_argument("--source", default=None)
+    ap.add_argument("--dominant", default="plp::k_lsd_grow")
+    a = ap.parse_args()
+    bench = json.load(open(a.bench))
+    B = bench["config"]["frames_per_rank_per_step"]
+    # ---- in-step launches of the dominant kernel, by launch size
+    cur = sqlite3.connect(a.kt_db).cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+    size_col = next((c for c in ("grid_size", "grid_size_x", "grid_x", "grid") if c in cols), None)
+    name_col = "name" if "name" in cols else "kernel_name"
+    s_col, e_col = ("start", "end") if "start" in cols else ("start_timestamp", "end_timestamp")
+    rows = list(cur.execute(f"select {name_col}, {s_col}, {e_col}" + (f", {size_col}" if size_col else "") + " from kernels"))
+    by_size = defaultdict(list)
+    for r in rows:
+        if short(r[0]) == a.dominant:
+            by_size[int(r[3]) if size_col else 0].append((r[2] - r[1]) / 1e6)
+    in_step = {}
+    if by_size:
+        sizes = sorted(by_size)
+        full = sizes[-1]                                   # the isolated passes launch the whole batch
+        for sz in sizes:
+            frames = B * sz // full if full else B
+            in_step[str(frames)] = {"launches": len(by_size[sz]), "mean_ms": round(sum(by_size[sz]) / len(by_size[sz]), 4), "isolated": sz == full and len(sizes) > 1}
+    # ---- register-time of a step
+    V = vgprs()
+    def vg(kernel):
+        base = kernel.split("<")[0].split("::")[-1]
+        cands = [v for k, v in V.items() if base in k and ("ss_thr" in k) == ("ss_thr" in kernel) and ("ss_lat" in k) == ("ss_lat" in kernel) and "debug" not in k]
+        return (max(cands) + 7) // 8 * 8 if cands else None
+    cur = sqlite3.connect(a.sq_db).cursor()
+    acc = defaultdict(lambda: defaultdict(float)); cnt = defaultdict(int)
+    for name, cn, val in cur.execute("select kernel_name, counter_name, value from counters_collection"):
+        s = short(name)
+        acc[s][cn] += val
+        if cn == "SQ_WAVES":
+            cnt[s] += 1
+    per_kernel, total = {}, 0.0
+    for s, c in acc.items():
+        if not s.startswith("plp::") or s.endswith("k_lsd_order") or not cnt[s]:
+            continue
+        waves = c["SQ_WAVES"] / cnt[s]
+        cyc_per_wave = 4 * c["SQ_WAVE_CYCLES"] / max(c["SQ_WAVES"], 1)
+        v = vg(s)
+        if v is None:
+            continue
+        launches = LAUNCHES_PER_STEP.get(s, 2 if "k_match_" in s else 1)
+        rc = waves * cyc_per_wave * v * launches
+        per_kernel[s] = {"waves": round(waves), "cycles_per_wave": round(cyc_per_wave), "vgprs": v, "launches_per_step": launches, "register_cycles": rc}
+        total += rc
+    ms = bench["ms_per_step"]
+    ideal = total / CHIP * 1e3
+    out = {"batch": B, "source": a.source, "dominant": a.dominant, "in_step_launches": in_step,
+           "occupancy_bound": {"register_cycles": total, "ideal_ms": round(ideal, 3), "ms_per_step_of_that_run": ms, "packing": round(ideal / ms, 4),
+                               "shares": {k: round(v["register_cycles"] / total, 4) for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1]["register_cycles"])[:8]}},
+           "per_kernel": per_kernel}
+    json.dump(out, open(a.out, "w"), indent=1)
+    print(json.dumps({k: out[k] for k in ("in_step_launches", "occupancy_bound")}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
