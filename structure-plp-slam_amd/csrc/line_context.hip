@@ -38,6 +38,7 @@ struct plp_line {
     bool last_profiled = false;   // the last batch ran with profiling on: only then does `prof` hold that batch's counters
     hipStream_t last_stream = nullptr;
     bool profiling = false;
+    bool grow_big_ok = false;
     hipEvent_t ev[9] = {};
     LineSideStream side{};                      // blur5 + Sobel beside the LSD chain
     double stage_ms[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // 8 stages + total
@@ -86,8 +87,8 @@ plp_status build(plp_line* c, int rows, int cols) {
     P.sw = (int)std::nearbyint(cols * 0.5); P.sh = (int)std::nearbyint(rows * 0.5);   // cvRound(ssize * scale)
     // idx / sw as mulhi(idx, ceil(2^32 / sw)): exact while idx * sw < 2^32, i.e. (idx < sw * sh <= kLsdMaxScaledPixels < 2^19) for sw <= 8192; 0 = divide
     P.sw_magic = (P.sw >= 2 && P.sw <= 8192) ? (uint32_t)(((1ull << 32) + (uint64_t)P.sw - 1) / (uint64_t)P.sw) : 0u;
-    if (P.sw >= 65536 || P.sh >= 65536 || (size_t)P.sw * P.sh > kLsdMaxScaledPixels)
-        return set_error(PLP_ERR_UNSUPPORTED, "frame too large for the LSD region-growing kernel (the half-resolution image must not exceed 516,065 pixels)");
+    if (P.sw >= 65536 || P.sh >= 65536 || (size_t)P.sw * P.sh > kLsdMaxScaledPixels || (!c->grow_big_ok && (size_t)P.sw * P.sh > 516065))
+        return set_error(PLP_ERR_UNSUPPORTED, "frame too large for the LSD region-growing kernel (the half-resolution image must not exceed 524,257 pixels: a 1920 x 1080 frame is the largest common one)");
     P.pitch = (cols + 63) / 64 * 64; P.spitch = (P.sw + 63) / 64 * 64;
     // LSD constants (line_extractor.cc:113-122, lsd.cpp flsd)
     LsdParams& lp = c->lp;
@@ -225,6 +226,7 @@ plp_status plp_line_create(int device, plp_line** out) {
     c->device = device;
     // dynamic-LDS limits are per function AND per device: raised here, for this context's device, not once per process
     c->mw_ok = grow_mw_configure() == hipSuccess;
+    c->grow_big_ok = grow_configure() == hipSuccess;     // frames whose USED bitmap needs more than 64 KB of LDS (half-resolution image above 516,065 pixels)
     c->seed_sort_ok = seed_sort_configure() == hipSuccess;
     (void)hipGetLastError();
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return set_error(PLP_ERR_HIP, "hipStreamCreate failed"); }

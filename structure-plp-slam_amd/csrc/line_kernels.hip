@@ -1917,7 +1917,7 @@ void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp,
     // one-wave workgroups had spread unevenly (13.2 -> 14.2 ms); profiles/r03_lsd_grow.md section 2
     static const int wpb_env = [] { const char* e = getenv("PLP_LSD_WPB"); return e ? atoi(e) : 4; }();
     const size_t per_wave = (size_t)((((n + 31) / 32 + 1) & ~1) + ring) * 4;
-    const int wpb = (int)std::max<size_t>(1, std::min<size_t>(std::min(4, std::max(1, wpb_env)), 65536 / per_wave));
+    const int wpb = (int)std::max<size_t>(1, std::min<size_t>(std::min(4, std::max(1, wpb_env)), 65536 / per_wave));   // (one wave of the largest admitted frame: kLsdGrowLdsBytes, above 64 KB)
     // diagnostic only (what the rest of a step costs without region growing): PLP_LSD_SKIP_GROW=k leaves the kernel out after
     // the k-th launch; the later stages then chew on the previous launch's segments
     static const int skip_after = [] { const char* e = getenv("PLP_LSD_SKIP_GROW"); return e ? atoi(e) : -1; }();
@@ -1969,6 +1969,9 @@ void launch_line_front(hipStream_t st, const LinePlanes& P, const LsdParams& lp,
 
 // The several-waves-per-frame kernel takes up to 160 KB of dynamic LDS: the limit belongs to the function ON THE CURRENT DEVICE, so every context
 // raises it for its own device when it is created (plp_line_create); a context whose device refuses runs one wave per frame.
+hipError_t grow_configure() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_lsd_grow), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLsdGrowLdsBytes);
+}
 hipError_t grow_mw_configure() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(k_lsd_grow_mw), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
 }

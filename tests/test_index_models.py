@@ -60,7 +60,7 @@ def test_peers_from_bit_ballots_equal_the_per_value_ballot():
 
 
 def test_magic_division_by_the_scaled_width_is_exact_for_every_admitted_frame():
-    n_max = 516_065                         # kLsdMaxScaledPixels (csrc/line_device.hpp)
+    n_max = 524_257                         # kLsdMaxScaledPixels (csrc/line_device.hpp)
     for sw in list(range(2, 2050)) + [4095, 4096, 8191, 8192]:
         magic = ((1 << 32) + sw - 1) // sw
         assert magic < (1 << 32)
