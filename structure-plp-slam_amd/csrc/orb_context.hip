@@ -111,6 +111,7 @@ plp_status build_geometry_impl(plp_orb* c, int rows, int cols) {
     c->h_lv.assign(nl, LevelDev{});
     c->total_blur_tiles = 0;
     size_t qt_off = 0;
+    int max_cells = 0;
     for (int l = 0; l < nl; ++l) {
         const LevelGeom& G = c->geo.lv[l];
         LevelDev& L = c->h_lv[l];
@@ -137,9 +138,12 @@ plp_status build_geometry_impl(plp_orb* c, int rows, int cols) {
         while ((1 << nb) < n_init) ++nb;
         L.sort_lo = 2 * (kQtDepth - d_eff);
         L.sort_hi = 2 * kQtDepth + nb;
-        if (L.n_cells > 2048 || 3 * L.quota + 8 > kQtMaxNodesLds || n_init > 32)
-            return set_error(PLP_ERR_UNSUPPORTED, "frame/keypoint budget exceeds the quadtree kernel limits (quota per level <= 1960, 2048 cells per level, 32 initial nodes)");
+        if (L.n_cells > 2048 || 3 * L.quota + 8 > kQtMaxNodesLdsSmallBlock || n_init > 32)
+            return set_error(PLP_ERR_UNSUPPORTED, "frame/keypoint budget exceeds the quadtree kernel limits (quota per level <= 2010, 2048 cells per level, 32 initial nodes)");
+        max_cells = std::max(max_cells, L.n_cells);
     }
+    if (3 * c->max_quota + 8 > kQtMaxNodesLds && max_cells > 1024)   // a quota above 1960 halves the kernel's cell-prefix block (quadtree_kernel.hip kQtBlkWordsSmall)
+        return set_error(PLP_ERR_UNSUPPORTED, "frame/keypoint budget exceeds the quadtree kernel limits (a quota above 1960 per level needs levels of at most 1024 cells)");
     PLP_HIP(c->d_lv.upload(c->h_lv.data(), sizeof(LevelDev) * nl, c->stream));
     PLP_HIP(c->d_cells.upload(c->geo.cells.data(), sizeof(CellDesc) * c->geo.cells.size(), c->stream));
     // resize tables: 8 int16 arrays back to back

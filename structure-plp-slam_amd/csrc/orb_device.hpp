@@ -12,6 +12,9 @@ namespace plp {
 // 3 * quota + 8 nodes: 5 888 nodes is what a CU's 160 KB hold, i.e. a per-level quota of up to 1 960 key points (K = 6 000 at 8 levels, K = 2 000 at
 // 2 levels; until round 5 the bound was 2 048 nodes).  Beyond that plp_orb_create refuses (the reference's quota of a single level at K = 2 000 does).
 constexpr int kQtMaxNodesLds = 5888;
+// ... with the kernel's radix / key block halved (4 KB instead of 8: levels of at most 1024 cells, fewer candidates sorted with LDS counters) 6 040 nodes fit: a quota of
+// up to 2 010, i.e. ONE level at K = 2 000 -- what the reference's orb_params accept and round 5 still refused (feature/orb_params.cc:40-54).
+constexpr int kQtMaxNodesLdsSmallBlock = 6040;
 
 // Per-level constants as seen by the kernels (array of n_levels in HBM + a host copy).
 struct LevelDev {

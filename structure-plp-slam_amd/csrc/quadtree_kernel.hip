@@ -18,8 +18,10 @@
 namespace plp {
 
 constexpr int kQtMaxNodes = kQtMaxNodesLds;   // hard upper bound of the node arrays: what 160 KB of LDS hold (orb_device.hpp; 3 * quota + 8 nodes: quota up to 1960 per level)
-constexpr int kQtSegLds = 256;               // radix counters for up to 256 wave-sized segments live in LDS (n <= 16384) ...
-constexpr int kQtKeyCache = 2048;            // ... and share it with the sorted-key cache; larger levels use the HBM scratch
+// One block of LDS serves as the cell prefix (n_cells words), then the radix counters [16 digits][segments] (u16) of levels of up to blk_words / 8 wave-sized
+// segments, then the sorted-key cache (blk_words keys); larger levels use the HBM scratch.  blk_words = 2048 (8 KB: 256 segments = 16384 candidates in LDS) -- or 1024
+// for a per-level quota above 1960 (round 6: the 4 KB that buys fit the node arrays of one level at K = 2000, the reference's single-level configuration).
+constexpr int kQtBlkWords = 2048, kQtBlkWordsSmall = 1024;
 
 // LDS of one workgroup, carved from dynamic shared memory: the node arrays are sized by the largest per-level quota
 // (a list never holds more than 3 * quota + 3 nodes), so that 2-3 workgroups fit a CU for the usual K = 1000..2000
@@ -42,13 +44,13 @@ struct QtShared {
     int* misc;
     int max_nodes;
 };
-__host__ __device__ inline size_t qt_lds_bytes(int max_nodes) {
-    return 8192 + (size_t)max_nodes * (4 * 2 + 4 * 1 + 3 * 2 + 4 + 2 * 2) + 16 + 32;
+__host__ __device__ inline size_t qt_lds_bytes(int max_nodes, int blk_words) {
+    return 4 * (size_t)blk_words + (size_t)max_nodes * (4 * 2 + 4 * 1 + 3 * 2 + 4 + 2 * 2) + 16 + 32;
 }
-__device__ __forceinline__ QtShared qt_carve(uint8_t* base, int mn) {
+__device__ __forceinline__ QtShared qt_carve(uint8_t* base, int mn, int blk_words) {
     QtShared S;
     S.cnt = reinterpret_cast<uint16_t*>(base); S.big = reinterpret_cast<uint32_t*>(base);
-    uint8_t* p = base + 8192;
+    uint8_t* p = base + 4 * (size_t)blk_words;
     S.pk = reinterpret_cast<uint32_t*>(p); p += 4 * (size_t)mn;
     S.partial = reinterpret_cast<uint32_t*>(p); p += 16;
     S.misc = reinterpret_cast<int*>(p); p += 32;
@@ -132,9 +134,10 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelDev* __restrict__ l
                                                   const uint32_t* __restrict__ cell_cand, const int32_t* __restrict__ cell_count,
                                                   int32_t* __restrict__ sel, int32_t* __restrict__ sel_count, int total_sel_cap,
                                                   uint8_t* __restrict__ scratch, size_t scratch_frame_stride,
-                                                  int32_t* __restrict__ status, int max_nodes) {
+                                                  int32_t* __restrict__ status, int max_nodes, int blk_words) {
     extern __shared__ __attribute__((aligned(16))) uint8_t qt_smem[];
-    const QtShared S = qt_carve(qt_smem, max_nodes);
+    const QtShared S = qt_carve(qt_smem, max_nodes, blk_words);
+    const int kQtSegLds = blk_words >> 3, kQtKeyCache = blk_words;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int level = blockIdx.x, frame = blockIdx.y;
     const LevelDev L = lv[level];
@@ -419,11 +422,13 @@ void launch_quadtree(hipStream_t st, const LevelDev* d_lv, int n_levels, int n_c
                      size_t qt_scratch_frame_stride, int32_t* status, int B, int max_quota) {
     // node arrays for 3 * quota + 8 entries (the bound of the lists, see QtShared), rounded to 8: at K = 1000 (quota 217) 25.5 KB, so that THREE
     // workgroups fit the 77 KB two region-growing workgroups leave on a CU (rounded to a power of two it was 34.9 KB: two)
-    const int mn = std::min(kQtMaxNodes, std::max(256, (3 * max_quota + 8 + 7) / 8 * 8));
+    const int want = std::max(256, (3 * max_quota + 8 + 7) / 8 * 8);
+    const bool small_blk = want > kQtMaxNodes;                    // a quota above 1960 (plp_orb_create has checked that it fits with the smaller block and that no level has more cells than it holds)
+    const int mn = std::min(small_blk ? kQtMaxNodesLdsSmallBlock : kQtMaxNodes, want), blk = small_blk ? kQtBlkWordsSmall : kQtBlkWords;
     static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)qt_lds_bytes(kQtMaxNodes)); attr_set = true; }
-    hipLaunchKernelGGL(k_quadtree, dim3(n_levels, B), dim3(256), qt_lds_bytes(mn), st, d_lv, n_cells_total, cell_cand, cell_count, sel,
-                       sel_count, total_sel_cap, reinterpret_cast<uint8_t*>(qt_scratch), qt_scratch_frame_stride, status, mn);
+    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    hipLaunchKernelGGL(k_quadtree, dim3(n_levels, B), dim3(256), qt_lds_bytes(mn, blk), st, d_lv, n_cells_total, cell_cand, cell_count, sel,
+                       sel_count, total_sel_cap, reinterpret_cast<uint8_t*>(qt_scratch), qt_scratch_frame_stride, status, mn, blk);
 }
 
 }  // namespace plp
