@@ -127,12 +127,11 @@ def isa_files():
 
 @pytest.mark.skipif(not isa_files(), reason="csrc/build/*.s absent: run __graft_entry__.build() (make keeps the device ISA of every translation unit)")
 def test_no_kernel_reaches_memory_through_flat_instructions():
-    """Round 6 (profiles/r06_seed_sort.md): a build of the seed sort whose chunk masks lay in LDS behind a pointer chosen at run time -- FLAT loads and
-    stores -- reported damaged partitions or faulted in 13 of 13 runs inside the overlapped step and in none alone; the same layout through DS instructions (one
-    instantiation per address space) passed 6 of 6.  No missing wait (draining vmcnt and lgkmcnt before every barrier changes nothing), no standalone reproducer
-    (tools/experiments/flat_lds_race.hip).  Until then three kernels had such pointers (k_quadtree's radix counters and sorted keys -- the kernel of round 2's never-explained
-    rare fault --, k_lsd_grow_mw's hand-over records, k_match_topk_cells' staged targets).  The library now holds NO flat memory instruction at all, and this test keeps it so:
-    every pointer's address space is known where it is dereferenced."""
+    """Round 6 (profiles/r06_seed_sort.md section 4): a build of the seed sort that reached its chunk masks through a pointer chosen at run time -- FLAT
+    loads and stores -- failed 17 of 17 times beside a second dispatch of the kernel and never alone.  Ten one-macro variants narrowed it to the ADDRESS FORM of the accesses to the
+    masks' copy in HBM (64-bit address in vector registers: fails, with FLAT or GLOBAL instructions alike; scalar base + vector offset: never fails), not to LDS, not to FLAT as
+    such, not to a missing wait; the mechanism is not identified.  A pointer whose address space the compiler does not know forces the failing form, so the library holds NO flat
+    memory instruction (three kernels had them: k_quadtree, k_lsd_grow_mw, k_match_topk_cells) and this test keeps it so."""
     bad = {}
     for path in isa_files():
         kernel = None
