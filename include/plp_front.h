@@ -204,7 +204,7 @@ plp_status plp_line_set_grow_waves(plp_line* ctx, int32_t waves);
 typedef enum plp_seed_order { PLP_SEED_ORDER_STABLE = 0, PLP_SEED_ORDER_LIBSTDCXX = 1 } plp_seed_order;
 plp_status plp_line_set_seed_order(plp_line* ctx, int32_t order);
 plp_status plp_line_get_seed_order(const plp_line* ctx, int32_t* order);
-/* Gives back device memory the current settings do not need: the exact seed order's buffers (476 KB per frame of the largest 640 x 480 batch seen) while
+/* Gives back device memory the current settings do not need: the exact seed order's buffers (630 KB per frame of the largest 640 x 480 batch seen) while
  * PLP_SEED_ORDER_STABLE is selected, and the several-waves grower's region lists.  plp_line_set_seed_order itself frees nothing (a caller may alternate the two
  * orders per batch at no cost).  Waits for the device (hipFree): call it where a pause is acceptable.  The caller's current device is left as it was. */
 plp_status plp_line_trim(plp_line* ctx);
