@@ -1,7 +1,7 @@
 """bench.py at N = 2 on ONE GPU (PLP_BENCH_SHARE_GPU=1: both ranks on cuda:0 over gloo), launched the way the driver launches it: the line must carry
 `verified_frames` and `verified_halo_rows` -- every rank re-derives frames of its own block (frames 0 and 1, whose predecessors arrived over the halo exchange,
 among them) and its halo rows (against the predecessor RANK's last two frames, regenerated from that rank's seed) with the CPU oracle after the timed region.
-With backend nccl (one GPU per rank) exactly this code runs on an 8-GPU node (tools/sessions/scale8.sh)."""
+With backend nccl (one GPU per rank) exactly this code runs on an 8-GPU node (tools/scale8.sh)."""
 import json
 import os
 import pathlib
