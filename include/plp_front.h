@@ -524,7 +524,7 @@ plp_status plp_color_vote_device(plp_matcher* ctx, const uint8_t* d_mask, int32_
  *   bow_word / bow_value / n_bow   the BowVector (std::map<WordId, WordValue>) in key order, normalised;
  *   fv_node / fv_feat / n_fv       the FeatureVector (std::map<NodeId, std::vector<unsigned>>) flattened in key order,
  *                                  the features of a node in increasing index.
- * Limits: cap <= 4096.  One transform in flight per vocabulary handle.  Device pointers, asynchronous. */
+ * Limits: cap <= 8192 (4096 until round 6: the per-frame maps are sorted in LDS, 16 bytes per descriptor).  One transform in flight per vocabulary handle.  Device pointers, asynchronous. */
 typedef struct plp_bow_vocab plp_bow_vocab;
 typedef struct plp_bow_tree {
     int32_t n_nodes;               /* >= 2 */

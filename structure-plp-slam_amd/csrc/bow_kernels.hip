@@ -269,7 +269,7 @@ static plp_status bow_transform_locked(plp_bow_vocab* v, const uint8_t* d_desc, 
     if (!v || !d_desc || !d_bow_word || !d_bow_value || !d_n_bow || !d_fv_node || !d_fv_feat || !d_n_fv)
         return set_error(PLP_ERR_INVALID_ARG, "NULL argument");
     if (cap <= 0 || B <= 0 || levelsup < 0) return set_error(PLP_ERR_INVALID_ARG, "cap, B must be positive, levelsup >= 0");
-    if (cap > 4096) return set_error(PLP_ERR_UNSUPPORTED, "more than 4096 descriptors per frame");
+    if (cap > 8192) return set_error(PLP_ERR_UNSUPPORTED, "more than 8192 descriptors per frame");   // (the per-frame maps are sorted in LDS: 16 bytes per descriptor, 128 KB of a CU's 160)
     PLP_HIP(hipSetDevice(v->device));
     const size_t tot = (size_t)B * cap;
     if (!d_word_id) { PLP_HIP(v->word.reserve(tot * 4)); d_word_id = (uint32_t*)v->word.p; }
@@ -281,7 +281,7 @@ static plp_status bow_transform_locked(plp_bow_vocab* v, const uint8_t* d_desc, 
     int N = 256;
     while (N < cap) N <<= 1;
     const size_t lds = (size_t)N * 16;
-    if (lds > 48 * 1024) PLP_HIP(hipFuncSetAttribute((const void*)k_bow_assemble, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 16));
+    if (lds > 48 * 1024) PLP_HIP(hipFuncSetAttribute((const void*)k_bow_assemble, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 16));
     hipLaunchKernelGGL(k_bow_assemble, dim3(B), dim3(256), lds, st, d_word_id, d_node_id, (const double*)v->weight.p, d_counts, cap, N, v->accumulate,
                        v->norm, d_bow_word, d_bow_value, d_n_bow, d_fv_node, d_fv_feat, d_n_fv);
     PLP_HIP(hipGetLastError());
@@ -303,7 +303,7 @@ plp_status plp_bow_transform_host(plp_bow_vocab* v, const uint8_t* desc, int32_t
         return set_error(PLP_ERR_INVALID_ARG, "NULL argument");
     *n_bow = 0; *n_fv = 0;
     if (n == 0) return PLP_OK;
-    if (n > 4096) return set_error(PLP_ERR_UNSUPPORTED, "more than 4096 descriptors per frame");
+    if (n > 8192) return set_error(PLP_ERR_UNSUPPORTED, "more than 8192 descriptors per frame");
     uint8_t* slab;
     const size_t cap = (size_t)n;
     // desc | word | node | bow_word | bow_value | fv_node | fv_feat | n_bow, n_fv

