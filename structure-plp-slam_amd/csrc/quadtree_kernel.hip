@@ -66,6 +66,42 @@ __device__ __forceinline__ QtShared qt_carve(uint8_t* base, int mn, int blk_word
 // in-place exclusive scan of a[0..M) by the whole workgroup; returns the total.  Per-thread chunk sums are scanned
 // inside each wave with shuffles; only the four wave totals cross a barrier (the kernel runs ~50 of these scans per
 // level, and a 16-barrier Hillis-Steele over 256 partials had made barriers its main cost).
+// An array that lives in LDS or in HBM, decided per level (wave-uniform): every access is a DS or a GLOBAL instruction behind a scalar branch -- never a FLAT one (a
+// pointer chosen at run time, `n <= cap ? lds : hbm`, had made every access FLAT: round 6) -- and the code around it exists once (inlining the radix
+// passes and the division once per place cost 0.1 ms per step: 83 spilled SGPRs, twice the code; `tools/sessions/r06/run38.sh`).
+template <typename T> struct DualArr {
+    __attribute__((address_space(3))) T* l; T* g; bool in_lds;
+    __device__ __forceinline__ T operator[](int i) const { T v; if (in_lds) v = l[i]; else v = g[i]; return v; }
+    __device__ __forceinline__ void set(int i, T v) const { if (in_lds) l[i] = v; else g[i] = v; }
+};
+template <typename T> __device__ __forceinline__ DualArr<T> dual_arr(T* lds_ptr, T* hbm_ptr, bool in_lds) {
+    return DualArr<T>{(__attribute__((address_space(3))) T*)lds_ptr, hbm_ptr, in_lds};
+}
+struct PtrArr32 { uint32_t* p; __device__ __forceinline__ uint32_t operator[](int i) const { return p[i]; } __device__ __forceinline__ void set(int i, uint32_t v) const { p[i] = v; } };
+
+template <typename T, class Arr>
+__device__ uint32_t block_scan_excl_arr(const Arr& a, int M, uint32_t* partial) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int chunk = (M + 255) >> 8;
+    const int lo = min(tid * chunk, M), hi = min(lo + chunk, M);
+    uint32_t sum = 0;
+    for (int i = lo; i < hi; ++i) sum += a[i];
+    uint32_t inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(inc, off);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) partial[wv] = inc;
+    __syncthreads();
+    const uint32_t w0 = partial[0], w1 = partial[1], w2 = partial[2], w3 = partial[3];
+    const uint32_t base = (wv > 0 ? w0 : 0) + (wv > 1 ? w1 : 0) + (wv > 2 ? w2 : 0);
+    uint32_t run = base + inc - sum;
+    for (int i = lo; i < hi; ++i) { const uint32_t v = a[i]; a.set(i, (T)run); run += v; }
+    __syncthreads();
+    return w0 + w1 + w2 + w3;
+}
+
 template <typename T>
 __device__ uint32_t block_scan_excl(T* a, int M, uint32_t* partial) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -108,7 +144,7 @@ __device__ __forceinline__ uint32_t dev_qt_key(int x, int y, const LevelDev& L) 
 }
 
 // split node [s,e) at `depth`: boundaries of digit values 1,2,3; returns number of non-empty children
-__device__ __forceinline__ int dev_split(const uint32_t* K, int s, int e, int depth, int& o1, int& o2, int& o3) {
+template <class KeyArr> __device__ __forceinline__ int dev_split(const KeyArr& K, int s, int e, int depth, int& o1, int& o2, int& o3) {
     if (depth >= kQtDepth) { o1 = o2 = o3 = e; return 1; }
     const int sh = 2 * (kQtDepth - 1 - depth);
     if (e - s == 1) {
@@ -176,9 +212,8 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelDev* __restrict__ l
     uint32_t* src = idxA;
     uint32_t* dst = idxB;
     bool first = true;
-    // The radix counters live in LDS, or -- levels with more than 32768 candidates -- in HBM.  ONE instantiation per place (round 6): a pointer chosen at run time made
-    // every access a FLAT instruction, and FLAT is the one way of reaching LDS that a seed-sort build failed with beside other kernels (profiles/r06_seed_sort.md).
-    auto radix_passes = [&](auto* CNT) {
+    // The radix counters live in LDS, or -- levels with more than blk_words / 8 segments -- in HBM: a DualArr (DS or GLOBAL instructions behind a scalar branch)
+    const DualArr<uint16_t> CNT = dual_arr(S.cnt, cnt_hbm, nseg <= kQtSegLds);
     for (int shift = L.sort_lo; shift < L.sort_hi; shift += 4) {
         for (int seg = wv; seg < nseg; seg += 4) {
             const int i = seg * 64 + lane;
@@ -190,10 +225,10 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelDev* __restrict__ l
                 const unsigned long long bal = __ballot(d == v);
                 if ((unsigned)lane == v) mine = (uint32_t)__popcll(bal);
             }
-            if (lane < 16) CNT[lane * nseg + seg] = (uint16_t)mine;
+            if (lane < 16) CNT.set(lane * nseg + seg, (uint16_t)mine);
         }
         __syncthreads();
-        block_scan_excl(CNT, 16 * nseg, S.partial);
+        block_scan_excl_arr<uint16_t>(CNT, 16 * nseg, S.partial);
         for (int seg = wv; seg < nseg; seg += 4) {
             const int i = seg * 64 + lane;
             unsigned d = 16;
@@ -214,8 +249,6 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelDev* __restrict__ l
         uint32_t* t = src; src = dst; dst = t;
         first = false;
     }
-    };
-    if (nseg <= kQtSegLds) radix_passes(S.cnt); else radix_passes(cnt_hbm);
     // src now holds candidate indices in key order (identity if no pass ran); dst <- sorted keys
     for (int i = tid; i < n; i += 256) {
         const uint32_t id = first ? (uint32_t)i : src[i];
@@ -226,9 +259,8 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelDev* __restrict__ l
     }
     __syncthreads();
     const uint32_t* sidx = src;
-    // The sorted keys are read from their LDS copy when it exists, from the HBM scratch otherwise.  The rest of the kernel is written once and inlined once per
-    // place (round 6): `K = n <= kQtKeyCache ? S.big : dst` made every key read a FLAT instruction -- see radix_passes above.
-    auto divide_and_select = [&](const uint32_t* K) {
+    // The sorted keys are read from their LDS copy when it exists, from the HBM scratch otherwise: a DualArr again
+    const DualArr<uint32_t> K = dual_arr(S.big, dst, n <= kQtKeyCache);
 
     // ---- 3a. initial nodes = runs of equal initial-node index
     int cur = 0;
@@ -407,8 +439,6 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelDev* __restrict__ l
         out_sel[i] = (int32_t)best_pk;
     }
     if (tid == 0) *out_cnt = m_out;
-    };
-    if (n <= kQtKeyCache) divide_and_select(S.big); else divide_and_select(dst);
 }
 
 size_t quadtree_scratch_bytes_per_frame(const LevelDev* h_lv, int n_levels) {

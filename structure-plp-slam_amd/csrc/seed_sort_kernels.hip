@@ -40,20 +40,27 @@ namespace plp {
 #define PLP_SS_THR_MINW 4   /* at most 128 VGPRs: four workgroups of four waves per CU (5.06 against 6.06 ms alone, 27.1 against 27.7 ms in the step) */
 #endif
 #define SS_MINW PLP_SS_THR_MINW
+#ifndef PLP_SS_THR_TASK
+#define PLP_SS_THR_TASK 4096
+#endif
+#define SS_TASK PLP_SS_THR_TASK
 #include "seed_sort_impl.inc"
 #undef SS_NS
 #undef SS_WAVES
 #undef SS_T
 #undef SS_MINW
+#undef SS_TASK
 #define SS_NS ss_lat
 #define SS_WAVES 16
 #define SS_T 24576
 #define SS_MINW 1
+#define SS_TASK 4096
 #include "seed_sort_impl.inc"
 #undef SS_NS
 #undef SS_WAVES
 #undef SS_T
 #undef SS_MINW
+#undef SS_TASK
 
 constexpr int kSsLatMaxFrames = 256;   // batches up to this many frames take the 16-wave configuration (one workgroup per CU)
 

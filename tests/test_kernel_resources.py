@@ -92,7 +92,7 @@ SPILL_CAPS = {
     "k_match_resolve_genericILi1": 51,
     "k_match_resolve_genericILi2": 44,
     "k_match_resolve_genericILi3": 64,
-    "k_quadtree": 84,                    # 39 until round 6 (83 now: + the run-time size of the radix / key block, for quotas above 1960): the radix passes and the division are now inlined once per address space of their key / counter arrays (no FLAT access to LDS); 1.01 ms per 2048 frames as before
+    "k_quadtree": 48,                    # 39 in round 5, 44 now: the radix counters and sorted keys are reached through dual-address-space accessors (DS / GLOBAL behind a scalar branch: no FLAT access); two inlined copies of the code had cost 83
     "k_lsd_seed_sort": 32,               # round 6: 29 (8 in round 5): wave_sub_sort / wave_reg_sort keep their stacks, chunk masks and prefix sums in scalar registers by design
     "k_seed_sort_debug": 48,             # the test entry of the same body, with the phase clocks
 }
