@@ -75,6 +75,23 @@ def test_full_hd_frame():
     compare(synth.canvas(2025, 1080, 1920), grow_waves=(0,))
 
 
+def test_trim_gives_the_exact_orders_buffers_back_and_the_context_keeps_working():
+    """plp_line_set_seed_order frees nothing (hipFree drains the device); plp_line_trim does, and the next call in the exact order allocates again"""
+    img = synth.canvas(4242, 480, 640)
+    exact, stable = O.LineOracle(img, stable_order=False), O.LineOracle(img, stable_order=True)
+    lt = plp.LineFeatureTracker()
+    for order, ora in ((plp.SEED_ORDER_LIBSTDCXX, exact), (plp.SEED_ORDER_STABLE, stable), (plp.SEED_ORDER_LIBSTDCXX, exact)):
+        lt.set_seed_order(order)
+        if order == plp.SEED_ORDER_STABLE:
+            lt.trim()
+        for _ in range(2):
+            kl, lbd, fn = lt.extract_LSD_LBD(img)
+            assert np.array_equal(kl, ora.keylsd) and np.array_equal(lbd, ora.lbd) and np.array_equal(fn, ora.linefn)
+    lt.trim()      # in the exact order: only the several-waves heap goes; the next call brings it back
+    kl, lbd, fn = lt.extract_LSD_LBD(img)
+    assert np.array_equal(kl, exact.keylsd) and np.array_equal(lbd, exact.lbd)
+
+
 def test_degenerate_images():
     compare(np.full((480, 640), 90, np.uint8))      # no gradient at all: no line, no descriptor
     img = np.zeros((480, 640), np.uint8); img[:, 320:] = 200
