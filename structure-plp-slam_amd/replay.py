@@ -80,6 +80,7 @@ class halo_exchanger:
 
     def __init__(self, buffers, halo=2, mode="ring", group=None):
         assert mode in ("ring", "allgather"), mode
+        assert all(t.is_contiguous() for t in buffers), "the head rows are written through a view: the arrays must be contiguous"
         self.halo, self.mode, self.group = halo, mode, group
         self.sizes = [int(t[0].numel() * t.element_size()) for t in buffers]          # bytes per frame of every array
         self.record_bytes = sum(self.sizes)
