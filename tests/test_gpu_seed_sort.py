@@ -109,6 +109,36 @@ def test_exact_seed_order_in_a_large_batch_takes_the_other_kernel_configuration_
             assert cnt[b] == len(ora.keylsd) and np.array_equal(kl[b, :cnt[b]], ora.keylsd) and np.array_equal(lbd[b, :cnt[b]], ora.lbd), (f, b)
 
 
+@pytest.mark.parametrize("shape", [(480, 752), (376, 1241), (240, 320)])     # EuRoC, KITTI (its first partitions' chunk masks do not fit LDS: the HBM form), a quarter frame (one window after one partition)
+def test_large_batches_of_other_geometries_in_the_exact_order(shape):
+    """the 4-wave configuration (batches above 256 frames) at the other BASELINE geometries: 264 frames (12 distinct) against the oracle's std::sort order"""
+    import torch
+    uniq = synth.replay(5 + shape[0], 12, shape[0], shape[1])
+    dev = torch.device("cuda:0")
+    d = torch.from_numpy(uniq).to(dev).repeat(22, 1, 1).contiguous()
+    B, cap = d.shape[0], 512
+    assert B > 256
+    d_kl = torch.zeros((B, cap, 68), dtype=torch.uint8, device=dev); d_lbd = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_fn = torch.zeros((B, cap, 3), dtype=torch.float64, device=dev); d_cnt = torch.zeros(B, dtype=torch.int32, device=dev)
+    lt = plp.LineFeatureTracker()
+    lt.extract_batch(d, d_kl, d_lbd, d_fn, d_cnt)
+    torch.cuda.synchronize()
+    lt.last_batch_status()
+    cnt = d_cnt.cpu().numpy()
+    kl = d_kl.cpu().numpy().view(plp.KL_DTYPE).reshape(B, cap)
+    lbd = d_lbd.cpu().numpy()
+    for f in range(12):
+        ora = O.LineOracle(uniq[f], stable_order=False)
+        for b in (f, f + 12 * 9, f + 12 * 21):
+            assert cnt[b] == len(ora.keylsd) and np.array_equal(kl[b, :cnt[b]], ora.keylsd) and np.array_equal(lbd[b, :cnt[b]], ora.lbd), (shape, f, b)
+        want_order = np.asarray(ora.order)
+        s_ = ora.scaled.astype(np.int64)
+        DA = s_[1:, 1:] - s_[:-1, :-1]; BC = s_[:-1, 1:] - s_[1:, :-1]
+        dmask = np.zeros(ora.scaled.shape, bool)
+        dmask[:-1, :-1] = ~(np.sqrt(((DA + BC) ** 2 + (DA - BC) ** 2) / 4.0) <= 2.0 / np.sin(np.pi * 22.5 / 180))
+        assert np.array_equal(lt.debug_read(lt.DBG_ORDER, f + 12 * 9), want_order[dmask.ravel()[want_order]]), (shape, f)
+
+
 def test_exact_seed_order_in_a_batch_and_against_the_single_frame_path():
     import torch
     frames = synth.replay(77, 6)
