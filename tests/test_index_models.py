@@ -215,3 +215,68 @@ def test_reduce_region_radius_as_a_rank_pairing_equals_the_swap_with_last_loop()
             assert live == want_live, (trial, n, cap)
             assert sorted(tail) == sorted(want_tail), (trial, n, cap)
     assert n_fallback > 0        # the fallback was exercised as well
+
+
+# ---- the dead-suffix rule of the exact seed sort's global partitions (csrc/seed_sort_impl.inc wg_partition, round 6) -----------------------------------------
+def _introsort_tree(keys, skip, min_part=17):
+    """std::__introsort_loop on `keys` (descending comparator, libstdc++'s median-of-three and unguarded Hoare partition, written out sequentially), visiting the right part
+    first as the kernel's stack does and leaving alone every right part whose pivot lies below `skip`.  Yields (first, last, pivot_key, cut) per partition."""
+    v = list(keys)
+    stack = [(0, len(v))]
+    while stack:
+        first, last = stack.pop()
+        if last - first < min_part:
+            continue
+        a, mid, c = first + 1, first + (last - first) // 2, last - 1
+        ka, kb, kc = v[a], v[mid], v[c]
+        # __move_median_to_first with comp(x, y) = x > y
+        if ka > kb:
+            m3 = mid if kb > kc else (c if ka > kc else a)
+        else:
+            m3 = a if ka > kc else (c if kb > kc else mid)
+        v[first], v[m3] = v[m3], v[first]
+        pk = v[first]
+        lo, hi = first + 1, last
+        while True:
+            while v[lo] > pk:
+                lo += 1
+            hi -= 1
+            while pk > v[hi]:
+                hi -= 1
+            if not lo < hi:
+                break
+            v[lo], v[hi] = v[hi], v[lo]
+            lo += 1
+        yield first, last, pk, lo
+        stack.append((first, lo))
+        if pk >= skip:
+            stack.append((lo, last))
+
+
+def test_a_partition_whose_pivot_lies_below_the_skip_key_always_ends_the_live_array():
+    """The kernel stops storing into the right part of such a partition and shrinks the array's live length to the cut -- which is only right if that partition's segment
+    reaches the END of the live array whenever its pivot lies below the skip key (everything to its right is dead already).  The kernel checks it at run time; here it is
+    checked on 600 random arrays in the shapes of a frame's seed array (a heavy low end of keys below the skip key) and in adversarial ones."""
+    r = np.random.default_rng(42)
+    n_dead_parts = 0
+    for trial in range(600):
+        n = int(r.integers(40, 3000))
+        kind = trial % 4
+        if kind == 0:
+            keys = np.where(r.random(n) < 0.75, r.integers(0, 77, n), r.integers(77, 1024, n))       # a frame: three quarters undefined pixels
+        elif kind == 1:
+            keys = r.integers(0, 1024, n)
+        elif kind == 2:
+            keys = r.integers(60, 95, n)                                                               # everything around the skip key
+        else:
+            keys = np.sort(r.integers(0, 200, n))[::-1] if trial % 8 == 3 else np.sort(r.integers(0, 200, n))
+        skip = 77 if kind != 3 else int(r.integers(1, 200))
+        n_live = n
+        for first, last, pk, cut in _introsort_tree(keys.tolist(), skip):
+            if pk < skip:
+                assert last == n_live, (trial, first, last, n_live, pk, skip)
+                n_live = cut
+                n_dead_parts += 1
+            else:
+                assert last <= n_live, (trial, first, last, n_live)                                   # a live segment never reaches into the dead part
+    assert n_dead_parts > 300
