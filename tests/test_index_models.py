@@ -280,3 +280,152 @@ def test_a_partition_whose_pivot_lies_below_the_skip_key_always_ends_the_live_ar
             else:
                 assert last <= n_live, (trial, first, last, n_live)                                   # a live segment never reaches into the dead part
     assert n_dead_parts > 300
+
+
+# ---- the register-resident sort of segments of at most 64 entries (csrc/seed_sort_impl.inc wave_reg_sort, round 6), lane by lane -----------------------------
+def _uniform_final_pos(x, f, l):
+    """csrc/seed_sort_model.hpp uniform_final_pos"""
+    while l - f > 16:
+        p0, npos, mid = f + 1, l - f - 1, f + (l - f) // 2
+        m, cut = npos >> 1, f + 1 + (npos >> 1)
+        if x == f:
+            x = mid
+        elif x == mid:
+            x = f
+        if x >= p0 and (x - p0 < m or l - 1 - x < m):
+            x = p0 + l - 1 - x
+        if x < cut:
+            l = cut
+        else:
+            f = cut
+    return x
+
+
+def _uniform_levels(n):
+    lv = 0
+    while n > 16:
+        n = 1 + (n - 1) // 2
+        lv += 1
+    return lv
+
+
+def _reg_sort_lanes(keys, depth, skip):
+    """wave_reg_sort emulated on 64 lanes: lane i holds entry i (here (key, original index)); a partition = two ballots, ranks by counting bits below / above, m by the
+    maximum over the lanes, the swaps as two pushes (ds_permute: the stoppers of rank r send their lane number to lane r; lane 63 takes what the others send), one pull of the
+    partner's lane from the lane of one's rank and one pull of the partner's entry (ds_bpermute)."""
+    n0 = len(keys)
+    e = [(k, i) for i, k in enumerate(keys)] + [(0, -1)] * (64 - n0)
+    lo, hi, stack = 0, n0, []
+    below = lambda m, lane: bin(m & ((1 << lane) - 1)).count("1")
+    above = lambda m, lane: bin(m >> (lane + 1)).count("1")
+    while True:
+        while hi - lo > 16:
+            assert depth > 0
+            p0, npos, mid = lo + 1, hi - lo - 1, lo + (hi - lo) // 2
+            e0, ka, kb, kc = e[lo], e[p0][0], e[mid][0], e[hi - 1][0]
+            if ka > kb:
+                m3 = mid if kb > kc else (hi - 1 if ka > kc else p0)
+            else:
+                m3 = p0 if ka > kc else (hi - 1 if kb > kc else mid)
+            em = e[m3]; pk = em[0]
+            es = [em if l == lo else (e0 if l == m3 else e[l]) for l in range(64)]
+            mL = sum(1 << l for l in range(p0, hi) if es[l][0] <= pk)
+            mR = sum(1 << l for l in range(p0, hi) if es[l][0] >= pk)
+            totL, totR = bin(mL).count("1"), bin(mR).count("1")
+            if totL == npos and totR == npos and _uniform_levels(hi - lo) <= depth:
+                if pk >= skip:
+                    new = list(e)
+                    for l in range(lo, hi):
+                        new[_uniform_final_pos(l, lo, hi)] = e[l]
+                    e = new
+                break
+            m = max(min(below(mL, l), totR - below(mR, l)) for l in range(64))
+            if m == 0:
+                cut = (mL & -mL).bit_length() - 1
+            else:
+                cut = next(l for l in range(64) if (mR >> l) & 1 and above(mR, l) == m - 1)
+                if m < totL:
+                    cut = min(cut, next(l for l in range(64) if (mL >> l) & 1 and below(mL, l) == m))
+            isL = [bool((mL >> l) & 1) and below(mL, l) < m for l in range(64)]
+            isR = [bool((mR >> l) & 1) and above(mR, l) < m for l in range(64)]
+            assert not any(a and b for a, b in zip(isL, isR)) and m <= 32
+            Lp, Rp = [0] * 64, [0] * 64
+            for l in range(64):      # ds_permute: lane l sends its number to lane (rank or 63); a lane nobody sends to reads 0
+                Lp[below(mL, l) if isL[l] else 63] = l
+                Rp[above(mR, l) if isR[l] else 63] = l
+            new = list(es)
+            for l in range(64):      # ds_bpermute twice: the partner's lane from the lane of my rank, then the partner's entry
+                if isL[l]:
+                    new[l] = es[Rp[below(mL, l)]]
+                elif isR[l]:
+                    new[l] = es[Lp[above(mR, l)]]
+            e = new
+            depth -= 1
+            nl, nr = cut - lo, (hi - cut if pk >= skip else 0)
+            goL, goR = nl > 16, nr > 16
+            if goL and goR:
+                if nl >= nr:
+                    stack.append((lo, cut, depth)); lo = cut
+                else:
+                    stack.append((cut, hi, depth)); hi = cut
+                assert len(stack) <= 4
+            elif goL:
+                hi = cut
+            elif goR:
+                lo = cut
+            else:
+                break
+        if not stack:
+            break
+        lo, hi, depth = stack.pop()
+    return e[:n0]
+
+
+def _introsort_final(keys, skip):
+    """the array a sequential std::__introsort_loop leaves (the generator above, run to its end), as (key, original index) pairs"""
+    v = [(k, i) for i, k in enumerate(keys)]
+    stack = [(0, len(v))]
+    while stack:
+        first, last = stack.pop()
+        if last - first <= 16:
+            continue
+        a, mid, c = first + 1, first + (last - first) // 2, last - 1
+        ka, kb, kc = v[a][0], v[mid][0], v[c][0]
+        if ka > kb:
+            m3 = mid if kb > kc else (c if ka > kc else a)
+        else:
+            m3 = a if ka > kc else (c if kb > kc else mid)
+        v[first], v[m3] = v[m3], v[first]
+        pk = v[first][0]
+        lo, hi = first + 1, last
+        while True:
+            while v[lo][0] > pk:
+                lo += 1
+            hi -= 1
+            while pk > v[hi][0]:
+                hi -= 1
+            if not lo < hi:
+                break
+            v[lo], v[hi] = v[hi], v[lo]
+            lo += 1
+        stack.append((first, lo))
+        if pk >= skip:
+            stack.append((lo, last))
+    return v
+
+
+def test_register_resident_sort_of_small_segments_equals_the_sequential_introsort_loop():
+    """2 000 random segments of 17 .. 64 entries in five key shapes (few values, all equal, a frame's low-heavy bins, uniform, sorted): the lane-level emulation of the kernel's
+    register sort must leave exactly the array libstdc++'s loop leaves, with and without a skip key (equal-key segments below it are left alone: those entries are compared as sets)"""
+    r = np.random.default_rng(7)
+    for trial in range(2000):
+        n = int(r.integers(17, 65))
+        kind = trial % 5
+        keys = (r.integers(0, 4, n) if kind == 0 else np.full(n, int(r.integers(0, 1024))) if kind == 1 else
+                np.where(r.random(n) < 0.6, r.integers(70, 80, n), r.integers(80, 1024, n)) if kind == 2 else r.integers(0, 1024, n) if kind == 3 else np.sort(r.integers(0, 50, n))).tolist()
+        skip = 0 if trial % 3 else 77
+        got, want = _reg_sort_lanes(keys, 12, skip), _introsort_final(keys, skip)
+        if skip == 0:
+            assert got == want, (trial, n, kind)
+        else:   # parts the loop leaves alone are left alone by both, but an all-equal segment below the skip key is not even permuted by the kernel: compare what is at or above the key
+            assert sorted(got) == sorted(want) and [x for x in got if x[0] >= skip] == [x for x in want if x[0] >= skip], (trial, n, kind)
