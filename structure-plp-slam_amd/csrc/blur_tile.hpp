@@ -14,6 +14,7 @@
 //               on unpacked values; the four output bytes are cut out with v_perm_b32 (the sums cannot exceed 255 << 16)
 #pragma once
 #include <hip/hip_runtime.h>
+#include "plp_barrier.hpp"
 #include <stdint.h>
 
 namespace plp {
@@ -91,7 +92,7 @@ __device__ __forceinline__ void blur_tile_compute(BlurTileLds<R>& S, const int* 
         v.x = a[0][0] | (a[1][0] << 16); v.y = a[0][1] | (a[1][1] << 16); v.z = a[0][2] | (a[1][2] << 16); v.w = a[0][3] | (a[1][3] << 16);
         *reinterpret_cast<uint4*>(&S.hs2[p * kBlurTW + c4]) = v;
     }
-    __syncthreads();
+    wg_barrier();
     // ---- vertical: 4 columns x 4 rows per thread
     const int cg = tid & 31, strip = tid >> 5;
     const int c4 = cg * 4, r0 = strip * kBlurRS;
@@ -247,7 +248,7 @@ __device__ __forceinline__ void blur_tile_core(BlurTileLds<R>& S, const uint8_t*
         blur_prefetch<R>(F, J);
         blur_stage_prefetched<R>(S, F, J);
     }
-    __syncthreads();
+    wg_barrier();
     blur_tile_compute<R>(S, taps, emit);
 }
 

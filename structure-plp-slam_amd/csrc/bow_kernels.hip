@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "plp_common.hpp"
+#include "plp_barrier.hpp"
 
 namespace plp {
 
@@ -86,7 +87,7 @@ __device__ void bitonic_sort_u64(unsigned long long* s, int N) {
                 const unsigned long long a = s[i], c = s[l];
                 if ((a > c) == ((i & k) == 0)) { s[i] = c; s[l] = a; }
             }
-            __syncthreads();
+            wg_barrier();
         }
 }
 
@@ -100,11 +101,11 @@ __device__ int block_scan256(int v, int* s_part, int* total) {
         if (lane >= d) inc += u;
     }
     if (lane == 63) s_part[wave] = inc;
-    __syncthreads();
+    wg_barrier();
     int base = 0;
     for (int w = 0; w < wave; ++w) base += s_part[w];
     *total = s_part[0] + s_part[1] + s_part[2] + s_part[3];
-    __syncthreads();
+    wg_barrier();
     return base + inc - v;
 }
 
@@ -132,11 +133,11 @@ __global__ __launch_bounds__(256) void k_bow_assemble(const uint32_t* __restrict
             keys[i] = k;
         }
         if (tid == 0) s_m = 0;
-        __syncthreads();
+        wg_barrier();
         bitonic_sort_u64(keys, N);
         for (int j = tid; j < N; j += 256)
             if (keys[j] != kNone && (j + 1 == N || keys[j + 1] == kNone)) s_m = j + 1;
-        __syncthreads();
+        wg_barrier();
         const int m = s_m;
         if (pass == 1) {
             for (int j = tid; j < m; j += 256) { fv_node[base + j] = (uint32_t)(keys[j] >> 32); fv_feat[base + j] = (uint32_t)keys[j]; }
@@ -161,11 +162,11 @@ __global__ __launch_bounds__(256) void k_bow_assemble(const uint32_t* __restrict
             bow_word[base + pos] = w_id;
             ++pos;
         }
-        __syncthreads();
+        wg_barrier();
         if (accumulate && norm == 0 && nu > 0) {
             const double nd = (double)nu;
             for (int p = tid; p < nu; p += 256) vals[p] /= nd;
-            __syncthreads();
+            wg_barrier();
         }
         if (norm != 0) {
             if (tid == 0) {
@@ -174,15 +175,15 @@ __global__ __launch_bounds__(256) void k_bow_assemble(const uint32_t* __restrict
                 else { for (int p = 0; p < nu; ++p) s += vals[p] * vals[p]; s = sqrt(s); }
                 s_norm = s;
             }
-            __syncthreads();
+            wg_barrier();
             const double s = s_norm;
             if (s > 0.0)
                 for (int p = tid; p < nu; p += 256) vals[p] /= s;
-            __syncthreads();
+            wg_barrier();
         }
         for (int p = tid; p < nu; p += 256) bow_value[base + p] = vals[p];
         if (tid == 0) n_bow[b] = nu;
-        __syncthreads();
+        wg_barrier();
     }
 }
 

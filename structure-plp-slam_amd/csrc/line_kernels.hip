@@ -23,6 +23,7 @@
 #include <cstdlib>
 
 #include "blur_tile.hpp"
+#include "plp_barrier.hpp"
 #include "line_device.hpp"
 #include "plp_common.hpp"
 #include "sincos_ziv.hpp"
@@ -179,12 +180,12 @@ __global__ __launch_bounds__(256) void k_lsd_gradient(LinePlanes P, LsdParams lp
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
     if (lane == 0) { s_max[wv] = mx; s_cnt[wv] = (uint32_t)__popcll(defm); }
-    __syncthreads();
+    wg_barrier();
     const uint32_t c0 = s_cnt[0], c1 = s_cnt[1], c2 = s_cnt[2], c3 = s_cnt[3];
     const int base = (wv > 0 ? (int)c0 : 0) + (wv > 1 ? (int)c1 : 0) + (wv > 2 ? (int)c2 : 0);
     if (g2_def) s_list[base + rank] = packed;
     if (tid == 0) P.blockmax[(size_t)b * gridDim.x + blockIdx.x] = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
-    __syncthreads();
+    wg_barrier();
     const int total = (int)(c0 + c1 + c2 + c3);
     if (tid < total) {
         const uint32_t e = s_list[tid];
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(256) void k_lsd_order(LinePlanes P, LsdParams lp, i
     for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
     if (lane == 0) s_red[q] = mx;
     for (int i = tid; i < 4096; i += 256) (&cnt[0][0])[i] = 0;
-    __syncthreads();
+    wg_barrier();
     mx = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
     const double max_grad = sqrt((double)mx / 4.0);
     const double bin_coef = (max_grad > 0) ? (double)(lp.n_bins - 1) / max_grad : 0;
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(256) void k_lsd_order(LinePlanes P, LsdParams lp, i
             ncomp += __popcll(defm);
         }
     }
-    __syncthreads();
+    wg_barrier();
     {   // thread t owns bins 1023-4t .. 1020-4t (descending)
         const int v0 = 1023 - 4 * tid;
         uint32_t c[4][4], tot = 0;
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(256) void k_lsd_order(LinePlanes P, LsdParams lp, i
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc, o); if (lane >= o) inc += t; }
         if (lane == 63) s_wsum[q] = inc;
-        __syncthreads();
+        wg_barrier();
         uint32_t run = inc - tot;
         for (int k = 0; k < q; ++k) run += s_wsum[k];
 #pragma unroll
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(256) void k_lsd_order(LinePlanes P, LsdParams lp, i
             for (int k = 0; k < 4; ++k) { cnt[k][v0 - j] = run; run += c[j][k]; }
         if (tid == 255) P.n_order[b] = (int32_t)run;
     }
-    __syncthreads();
+    wg_barrier();
     for (int ib = 0; ib < ncomp; ib += 256) {   // four groups of entries loaded together, ranked one after the other
     uint32_t e4[4];
 #pragma unroll
@@ -1282,7 +1283,7 @@ __global__ __launch_bounds__(64 * kMwMaxWaves) void k_lsd_grow_mw(LinePlanes P, 
             ctrl[i] = (pi >= buf_group && pi < buf_n) ? -1 : (pi >= pend_lo && pi < pend_hi) ? 0x7fffffff : (pi >= pend_hi) ? -1 : 0;
         }
     }
-    __syncthreads();
+    wg_barrier();
     const bool is_main = wv == 0;
     const int h = wv - 1;
     GrowCtx g;
@@ -1666,7 +1667,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 #pragma unroll
         for (int rr = 0; rr < kBlurRS; ++rr) bt[(r0 + rr) * (kBlurTW / 4) + c4 / 4] = rows[rr];
     });
-    __syncthreads();
+    wg_barrier();
     short2* out_frame = dxy + (size_t)f * dxy_frame_entries(w, h);
     const int tiles8 = (w + 7) / 8;
     for (int i = threadIdx.x; i < (kSobelTW / 4) * (kSobelTH / 2); i += 256) {

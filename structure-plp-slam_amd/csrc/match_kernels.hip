@@ -27,6 +27,7 @@
 #include <cstdlib>
 
 #include "libstdcxx_sort.hpp"
+#include "plp_barrier.hpp"
 #include "match_device.hpp"
 #include "plp_common.hpp"
 #include "xcd_map.hpp"
@@ -458,7 +459,7 @@ __global__ __launch_bounds__(256) void k_match_prep(MatchProblem P) {
     float* sxr = P.sorted_xr + (size_t)b * P.n_cap;
     auto cnt_inc = [&](int c) -> int { return (int)((atomicAdd(&cnt2[c >> 1], 1u << (16 * (c & 1))) >> (16 * (c & 1))) & 0xffffu); };   // the count before
     for (int i = tid; i < 2048; i += 256) cnt2[i] = 0;
-    __syncthreads();
+    wg_barrier();
     // (passes 1 and 2 take four targets per thread and trip and load them together: a trip per target had been a memory round trip per target)
     auto cell_xy = [&](float x, float y, bool occ, int& cx, int& cy) -> bool {
         cx = floor_d((double)__fsub_rn(x, P.grid_min_x) * P.inv_cell_w);
@@ -475,7 +476,7 @@ __global__ __launch_bounds__(256) void k_match_prep(MatchProblem P) {
             if (t0 + 256 * u < n && cell_xy(kx[u], ky[u], oc[u], cx, cy)) cnt_inc(cx * P.grid_rows + cy);
         }
     }
-    __syncthreads();
+    wg_barrier();
     {   // exclusive scan over the cells: 16 cells per thread, a shuffle scan inside the wave, four wave totals through LDS
         const int lane = tid & 63, wv = tid >> 6;
         int c16[16], sum = 0;
@@ -485,15 +486,15 @@ __global__ __launch_bounds__(256) void k_match_prep(MatchProblem P) {
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(inc, o); if (lane >= o) inc += up; }
         if (lane == 63) part[wv] = inc;
-        __syncthreads();
+        wg_barrier();
         int base = inc - sum;
         for (int k = 0; k < wv; ++k) base += part[k];
 #pragma unroll
         for (int i = 0; i < 16; ++i) { start[tid * 16 + i] = (uint16_t)base; base += c16[i]; }
         if (tid == 255) { start[4096] = (uint16_t)base; start[4097] = (uint16_t)base; }
-        __syncthreads();
+        wg_barrier();
         for (int i = tid; i < 2048; i += 256) cnt2[i] = 0;
-        __syncthreads();
+        wg_barrier();
     }
     for (int t0 = tid; t0 < n; t0 += 4 * 256) {   // pass 2: unordered placement inside the cell
         float kx[4], ky[4]; bool oc[4];
@@ -508,7 +509,7 @@ __global__ __launch_bounds__(256) void k_match_prep(MatchProblem P) {
             tmp_t[start[cell] + cnt_inc(cell)] = (uint16_t)t;
         }
     }
-    __syncthreads();
+    wg_barrier();
     const int used = start[4096];
     for (int p0 = tid; p0 < used; p0 += 4 * 256) {   // pass 3: rank inside the cell by index, final record (four targets per trip, their gathers together)
         int tt[4]; float kx[4], ky[4], xr[4] = {0.f, 0.f, 0.f, 0.f}; int ko[4];
@@ -614,7 +615,7 @@ __global__ PLP_TOPK_CELLS_BOUNDS void k_match_topk_cells(MatchProblem P, int qpb
         const uint32_t* g32 = reinterpret_cast<const uint32_t*>(gcs);
         for (int i = tid; i < (ncell + 2) / 2; i += 256) reinterpret_cast<uint32_t*>(cs)[i] = g32[i];
     }
-    __syncthreads();
+    wg_barrier();
     // (the staged copies are read through pointers that SAY they are LDS: written as `i < nb ? sxy[i] : ...` the compiler selected between the two POINTERS and
     // loaded through a FLAT instruction -- round 6 keeps FLAT away from LDS in every kernel, profiles/r06_seed_sort.md)
     typedef const __attribute__((address_space(3))) uint32_t* lds_u32; typedef const __attribute__((address_space(3))) float* lds_f32;
@@ -736,7 +737,7 @@ __global__ __launch_bounds__(256) void k_match_topk_lds(MatchProblem P) {
         const uint4* src = reinterpret_cast<const uint4*>(t_desc);
         for (int i = tid; i < 2 * n; i += 256) sdesc[i] = src[i];
     }
-    __syncthreads();
+    wg_barrier();
     const uint8_t* q_valid = P.q_valid ? P.q_valid + (size_t)b * P.m_cap : nullptr;
     for (int q = q_begin + wv; q < min(m, q_begin + kQueriesPerBlock); q += 4) {
         uint32_t* klist = P.klist + ((size_t)b * P.m_cap + q) * kMatchK;
@@ -803,7 +804,7 @@ __device__ __forceinline__ void match_resolve_body(const MatchProblem& P) {
 
     for (int t = tid; t < n; t += 256) { owner_final[t] = 0x7fffffff; out[t] = -1; }
     for (int q = tid; q < m; q += 256) claim[q] = -1;
-    __syncthreads();
+    wg_barrier();
 
     int32_t* full_list = P.full_list + (size_t)b * P.m_cap;   // queries whose truncated best-K list ran dry
     const int need = (is_last_frame_mode(mode) || mode == PLP_MATCH_MODE_TRIANGULATION) ? 1 : 2;   // the last-frame matcher has no second-best test
@@ -845,7 +846,7 @@ __device__ __forceinline__ void match_resolve_body(const MatchProblem& P) {
           for (int inner = 0; inner <= 256; ++inner) {
             if (tid == 0) { s_full_n = 0; s_changed = 0; }
             for (int t = tid; t < n; t += 256) owner_next[t] = 0x7fffffff;
-            __syncthreads();
+            wg_barrier();
             int new_claim = -1;
             bool decided = false;
             if (q < m) {
@@ -881,7 +882,7 @@ __device__ __forceinline__ void match_resolve_body(const MatchProblem& P) {
                     else { decided = true; if (found > 0 && accept<FAM>(P, best, best_lvl, second, second_lvl)) new_claim = best_t; }
                 }
             }
-            __syncthreads();
+            wg_barrier();
             // rare: exact two-best over the query's whole window with the occupancy filter, one wave per query
             const int nf = s_full_n;
             if (tid == 0 && P.dbg && nf) atomicAdd(&P.dbg[0], nf);
@@ -937,16 +938,16 @@ __device__ __forceinline__ void match_resolve_body(const MatchProblem& P) {
                     s_claim_tmp[fq - chunk_start] = nc;
                 }
             }
-            __syncthreads();
+            wg_barrier();
             if (q < m) {
                 if (!decided) new_claim = s_claim_tmp[tid];
                 if (my_claim != new_claim) { my_claim = new_claim; s_changed = 1; }
                 if (new_claim >= 0 && (blocks_always || has_obs[q])) atomicMin(&owner_next[new_claim], q);
             }
-            __syncthreads();
+            wg_barrier();
             { int32_t* t = owner_prev; owner_prev = owner_next; owner_next = t; }
             const int changed = s_changed;
-            __syncthreads();
+            wg_barrier();
             if (!changed) break;
           }
           if (tid == 0 && P.dbg) atomicAdd(&P.dbg[1], 1);
@@ -955,14 +956,14 @@ __device__ __forceinline__ void match_resolve_body(const MatchProblem& P) {
               claim[q] = my_claim;
               if (my_claim >= 0 && (blocks_always || has_obs[q])) atomicMin(&owner_final[my_claim], q);
           }
-          __syncthreads();
+          wg_barrier();
         }
     }
 
     // ---- results: last writer per key point, number of accepted queries, delta-angle histogram check
     if (tid == 0) s_num = 0;
     for (int i = tid; i < 32; i += 256) { s_hist[i] = 0; s_valid_bin[i] = 0; }
-    __syncthreads();
+    wg_barrier();
     const bool angle_check = P.check_orientation && (mode == PLP_MATCH_MODE_LAST_FRAME || mode == PLP_MATCH_MODE_BRUTE_FORCE || is_group_mode(mode));
     const float* q_angle = P.q_angle ? P.q_angle + (size_t)b * P.m_cap : nullptr;
     const float* t_angle = P.t_angle ? P.t_angle + (size_t)b * P.n_cap : nullptr;
@@ -985,13 +986,13 @@ __device__ __forceinline__ void match_resolve_body(const MatchProblem& P) {
         if (angle_check) atomicAdd(&s_hist[min(bin_of(q, t), 31)], 1);
     }
     if (my) atomicAdd(&s_num, my);
-    __syncthreads();
+    wg_barrier();
     if (angle_check) {
         if (tid == 0) {   // the first 3 of the 30 bins as the reference's std::sort by size orders them (angle_checker.h:165-176), ties included
             libstdcxx::index_sort_by_size(s_hist, 30, s_sort_idx, s_sort_ws);
             for (int r = 0; r < 3; ++r) s_valid_bin[s_sort_idx[r]] = 1;
         }
-        __syncthreads();
+        wg_barrier();
         int bad = 0;
         for (int q = tid; q < m; q += 256) {
             const int t = claim[q];
@@ -999,7 +1000,7 @@ __device__ __forceinline__ void match_resolve_body(const MatchProblem& P) {
             if (!s_valid_bin[min(bin_of(q, t), 31)]) { out[t] = (P.flags & PLP_MATCH_FLAG_MARK_INVALIDATED) ? -2 : -1; ++bad; }
         }
         if (bad) atomicSub(&s_num, bad);
-        __syncthreads();
+        wg_barrier();
     }
     if (tid == 0) P.out_num[b] = s_num;
 }
@@ -1029,7 +1030,7 @@ __global__ __launch_bounds__(256) void k_hamming_matrix(const uint8_t* __restric
         sq[r * 9 + w] = q0 + r < nq ? reinterpret_cast<const uint32_t*>(qd)[(size_t)(q0 + r) * 8 + w] : 0u;
         st[r * 9 + w] = t0 + r < nt ? reinterpret_cast<const uint32_t*>(td)[(size_t)(t0 + r) * 8 + w] : 0u;
     }
-    __syncthreads();
+    wg_barrier();
     const int tx = tid & 63, ty = __builtin_amdgcn_readfirstlane(tid >> 6);   // thread: target tx, queries ty, ty+4, ... (ty is the wave's index: scalar)
     uint32_t tv[8];
 #pragma unroll

@@ -11,6 +11,7 @@
 #include <stdint.h>
 
 #include "blur_tile.hpp"
+#include "plp_barrier.hpp"
 #include "orb_device.hpp"
 #include "plp_common.hpp"
 #include "xcd_map.hpp"
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         for (int i = tid; i < 66 * kScoreW / 4; i += 256) reinterpret_cast<uint32_t*>(score)[i] = 0;
         if (tid < 64) { keepbits[tid] = 0ull; bits1[tid] = 0ull; bits2[tid] = 0ull; }
         if (tid == 0) { q_count = 0; q2_count = 0; n_ini = 0; run_base = 0; }
-        __syncthreads();
+        wg_barrier();
         // pass 1: every arc of 9 contains two neighbouring compass pixels (0, 4, 8, 12): five dword reads serve four
         // positions and reject most of them
         for (int i = tid; i < 1024; i += 256) {   // 64 rows x 16 groups of 4 positions
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 }
             }
         }
-        __syncthreads();
+        wg_barrier();
         // pass 2: 16-bit brighter / darker masks of the survivors -> "has an arc of 9" -> second queue
         const int nq1 = q_count;
         const bool dense1 = nq1 <= kFastQ1;
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 if (slot < kFastQ2) queue2[slot] = (uint16_t)i;
             }
         }
-        __syncthreads();
+        wg_barrier();
         // pass 3: exact score of the corners (dense over the queue: no lane idles on non-corners)
         const int nq = q2_count;
         const bool dense2 = nq <= kFastQ2;
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             const int sc = max(bright, -dark) - 1;
             score[(ty + 1) * kScoreW + tx + 1] = (uint8_t)(sc >= thr ? sc : 0);
         }
-        __syncthreads();
+        wg_barrier();
         // pass 4: 3x3 strict NMS, only around the corners
         int my_ini = 0;
         for (int j = tid; j < (dense2 ? nq : 4096); j += 256) {
@@ -353,9 +354,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             if (ok) { atomicOr(&keepbits[ty], 1ull << tx); ++my_ini; }
         }
         if (my_ini) atomicAdd(&n_ini, my_ini);
-        __syncthreads();
+        wg_barrier();
         const int found = n_ini;
-        __syncthreads();
+        wg_barrier();
         if (found > 0 || min_thr >= ini_thr) break;
     }
 
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     int cnt = 0;
     for (int ty = 16 * wv; ty < 16 * wv + 16; ++ty) cnt += __popcll(row_mask(ty));
     if (lane == 0) wave_tot[wv] = cnt;
-    __syncthreads();
+    wg_barrier();
     int off = 0;
     for (int k = 0; k < wv; ++k) off += wave_tot[k];
     for (int ty = 16 * wv; ty < 16 * wv + 16; ++ty) {
@@ -406,7 +407,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         off += __popcll(m);
     }
     if (tid == 0) run_base = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
-    __syncthreads();
+    wg_barrier();
     if (tid == 0) cell_count[out_slot] = run_base;
 }
 
@@ -537,7 +538,7 @@ __global__ __launch_bounds__(256) void k_orient_rbrief(OrbPlanes pl, const uint8
         s_w0[av][j] = w0; s_w1[av][j] = w1;
     }
     s_pat[tid] = reinterpret_cast<const uint32_t*>(c_pattern)[tid];
-    __syncthreads();
+    wg_barrier();
     const int out_idx = (int)ublk * 16 + (tid >> 4);
     if (out_idx >= total || out_idx >= cap) return;   // the 16 lanes of a key point leave together
     int level = 0, i = out_idx;
@@ -768,9 +769,9 @@ __global__ __launch_bounds__(256) void k_stereo_median(StereoArgs A) {
     float* xr_out = A.x_right + (size_t)b * A.cap;
     float* dp_out = A.depth + (size_t)b * A.cap;
     hist[tid] = 0;
-    __syncthreads();
+    wg_barrier();
     for (int i = tid; i < nl; i += 256) { const int c = corr[i]; if (c >= 0) atomicAdd(&hist[min(c >> 8, 255)], 1); }
-    __syncthreads();
+    wg_barrier();
     if (tid == 0) {
         int total = 0;
         for (int i = 0; i < 256; ++i) total += hist[i];
@@ -778,20 +779,20 @@ __global__ __launch_bounds__(256) void k_stereo_median(StereoArgs A) {
         if (total) { while (k >= hist[hb]) { k -= hist[hb]; ++hb; } }
         s_sel[0] = total; s_sel[1] = hb; s_sel[2] = k;
     }
-    __syncthreads();
+    wg_barrier();
     const int total = s_sel[0], hb = s_sel[1], k = s_sel[2];
     if (total == 0) return;
-    __syncthreads();
+    wg_barrier();
     hist[tid] = 0;
-    __syncthreads();
+    wg_barrier();
     for (int i = tid; i < nl; i += 256) { const int c = corr[i]; if (c >= 0 && min(c >> 8, 255) == hb) atomicAdd(&hist[c & 255], 1); }
-    __syncthreads();
+    wg_barrier();
     if (tid == 0) {
         int kk = k, lb = 0;
         while (kk >= hist[lb]) { kk -= hist[lb]; ++lb; }
         s_sel[1] = (hb << 8) | lb;
     }
-    __syncthreads();
+    wg_barrier();
     const float median = (float)s_sel[1];
     const float thr = (float)(2.0 * (double)median);
     for (int i = tid; i < nl; i += 256) { const int c = corr[i]; if (c >= 0 && thr < (float)c) { xr_out[i] = -1.0f; dp_out[i] = -1.0f; } }

@@ -12,6 +12,7 @@
 #include <algorithm>
 
 #include "orb_device.hpp"
+#include "plp_barrier.hpp"
 #include "plp_common.hpp"
 #include "quadtree_model.hpp"
 
@@ -93,12 +94,12 @@ __device__ uint32_t block_scan_excl_arr(const Arr& a, int M, uint32_t* partial) 
         if (lane >= off) inc += t;
     }
     if (lane == 63) partial[wv] = inc;
-    __syncthreads();
+    wg_barrier();
     const uint32_t w0 = partial[0], w1 = partial[1], w2 = partial[2], w3 = partial[3];
     const uint32_t base = (wv > 0 ? w0 : 0) + (wv > 1 ? w1 : 0) + (wv > 2 ? w2 : 0);
     uint32_t run = base + inc - sum;
     for (int i = lo; i < hi; ++i) { const uint32_t v = a[i]; a.set(i, (T)run); run += v; }
-    __syncthreads();
+    wg_barrier();
     return w0 + w1 + w2 + w3;
 }
 
@@ -116,12 +117,12 @@ __device__ uint32_t block_scan_excl(T* a, int M, uint32_t* partial) {
         if (lane >= off) inc += t;
     }
     if (lane == 63) partial[wv] = inc;
-    __syncthreads();
+    wg_barrier();
     const uint32_t w0 = partial[0], w1 = partial[1], w2 = partial[2], w3 = partial[3];
     const uint32_t base = (wv > 0 ? w0 : 0) + (wv > 1 ? w1 : 0) + (wv > 2 ? w2 : 0);
     uint32_t run = base + inc - sum;
     for (int i = lo; i < hi; ++i) { const uint32_t v = a[i]; a[i] = (T)run; run += v; }
-    __syncthreads();
+    wg_barrier();
     return w0 + w1 + w2 + w3;
 }
 
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelDev* __restrict__ l
     // ---- 1. gather candidates in reference order + keys
     const int32_t* cc = cell_count + (size_t)frame * n_cells_total + L.cell_base;
     for (int c = tid; c < L.n_cells; c += 256) S.big[c] = (uint32_t)cc[c];
-    __syncthreads();
+    wg_barrier();
     int n = (int)block_scan_excl(S.big, L.n_cells, S.partial);
     if (n > L.qt_cap) { if (tid == 0) atomicOr(status, 2); n = L.qt_cap; }
     for (int c = wv; c < L.n_cells; c += 4) {
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelDev* __restrict__ l
             }
         }
     }
-    __syncthreads();
+    wg_barrier();
     if (n == 0) { if (tid == 0) *out_cnt = 0; return; }
 
     // ---- 2. LSD radix sort (4 bits per pass) of candidate indices by key bits [sort_lo, sort_hi)
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelDev* __restrict__ l
             }
             if (lane < 16) CNT.set(lane * nseg + seg, (uint16_t)mine);
         }
-        __syncthreads();
+        wg_barrier();
         block_scan_excl_arr<uint16_t>(CNT, 16 * nseg, S.partial);
         for (int seg = wv; seg < nseg; seg += 4) {
             const int i = seg * 64 + lane;
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelDev* __restrict__ l
             }
             if (i < n) dst[(uint32_t)CNT[d * nseg + seg] + (uint32_t)__popcll(mybal & ((1ull << lane) - 1ull))] = id;
         }
-        __syncthreads();
+        wg_barrier();
         uint32_t* t = src; src = dst; dst = t;
         first = false;
     }
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelDev* __restrict__ l
         dst[i] = k;
         if (n <= kQtKeyCache) S.big[i] = k;
     }
-    __syncthreads();
+    wg_barrier();
     const uint32_t* sidx = src;
     // The sorted keys are read from their LDS copy when it exists, from the HBM scratch otherwise: a DualArr again
     const DualArr<uint32_t> K = dual_arr(S.big, dst, n <= kQtKeyCache);
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelDev* __restrict__ l
         }
         S.misc[0] = m;
     }
-    __syncthreads();
+    wg_barrier();
     int m = S.misc[0];
     bool filled = false, failed = false;
 
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelDev* __restrict__ l
     while (true) {
         const int prev = m;
         if (tid == 0) S.misc[1] = 0;   // pool size (children with more than one point)
-        __syncthreads();
+        wg_barrier();
         for (int i = tid; i < m; i += 256) {
             if (S.nleaf(cur)[i]) { S.pk[i] = 1u << 16; continue; }
             int o1, o2, o3;
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelDev* __restrict__ l
             const int big = (o1 - s > 1) + (o2 - o1 > 1) + (o3 - o2 > 1) + (e - o3 > 1);
             if (big) atomicAdd(&S.misc[1], big);
         }
-        __syncthreads();
+        wg_barrier();
         const uint32_t tot = block_scan_excl(S.pk, m, S.partial);
         const int T = (int)(tot & 0xffff), kept = (int)(tot >> 16);
         const int m_new = T + kept;
@@ -319,12 +320,12 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelDev* __restrict__ l
                     ++q;
                 }
         }
-        __syncthreads();
+        wg_barrier();
         cur = nxt; m = m_new;
         const int pool = S.misc[1];
         if (N <= m || m == prev) { filled = true; break; }
         if (N < m + pool) break;
-        __syncthreads();
+        wg_barrier();
     }
 
     // ---- 3c. phase 2: split the fullest entries first until the quota is reached
@@ -332,11 +333,11 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelDev* __restrict__ l
         const int prev = m;
         // pool = entries with more than one point, in list order (ordered compaction)
         for (int i = tid; i < m; i += 256) S.pk[i] = (uint32_t)(S.ne(cur)[i] - S.ns(cur)[i] > 1);
-        __syncthreads();
+        wg_barrier();
         const int p = (int)block_scan_excl(S.pk, m, S.partial);
         for (int i = tid; i < m; i += 256)
             if (S.ne(cur)[i] - S.ns(cur)[i] > 1) S.pool_pos[S.pk[i]] = (uint16_t)i;
-        __syncthreads();
+        wg_barrier();
         if (p == 0) break;   // nothing left to split
         // order: count descending, then list position ascending (== creation descending)
         for (int a = tid; a < p; a += 256) {
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelDev* __restrict__ l
             }
             S.pool_sorted[rank] = (uint16_t)ia;
         }
-        __syncthreads();
+        wg_barrier();
         // split in sorted order; inclusive gain prefix decides where the quota is met
         for (int j = tid; j < p; j += 256) {
             const int i = S.pool_sorted[j];
@@ -360,7 +361,7 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelDev* __restrict__ l
             S.pk[j] = (uint32_t)k;
         }
         if (tid == 0) S.misc[2] = p;   // r+1 = number of pool entries actually split
-        __syncthreads();
+        wg_barrier();
         block_scan_excl(S.pk, p, S.partial);   // exclusive prefix of k over sorted order
         for (int j = tid; j < p; j += 256) {
             const int i = S.pool_sorted[j];
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelDev* __restrict__ l
             const int size_after = m + (int)S.pk[j] + k - (j + 1);   // m + sum_{t<=j} (k_t - 1)
             if (N <= size_after) atomicMin(&S.misc[2], j + 1);
         }
-        __syncthreads();
+        wg_barrier();
         const int nsplit = S.misc[2];
         // total children created by the first nsplit entries
         int T;
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelDev* __restrict__ l
         if (m_new > S.max_nodes) { failed = true; break; }
         const int nxt = cur ^ 1;
         // erased flags + survivors' new positions
-        __syncthreads();
+        wg_barrier();
         for (int j = tid; j < nsplit; j += 256) {
             const int i = S.pool_sorted[j];
             int q = (int)S.pk[j];
@@ -402,16 +403,16 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelDev* __restrict__ l
                 }
             S.nleaf(cur)[i] |= 2;   // mark erased
         }
-        __syncthreads();
+        wg_barrier();
         for (int i = tid; i < m; i += 256) S.pk[i] = (S.nleaf(cur)[i] & 2) ? 0u : 1u;
-        __syncthreads();
+        wg_barrier();
         block_scan_excl(S.pk, m, S.partial);
         for (int i = tid; i < m; i += 256)
             if (!(S.nleaf(cur)[i] & 2)) {
                 const int pos = T + (int)S.pk[i];
                 S.ns(nxt)[pos] = S.ns(cur)[i]; S.ne(nxt)[pos] = S.ne(cur)[i]; S.nd(nxt)[pos] = S.nd(cur)[i]; S.nleaf(nxt)[pos] = S.nleaf(cur)[i];
             }
-        __syncthreads();
+        wg_barrier();
         cur = nxt; m = m_new;
         if (N <= m || m == prev) break;
     }

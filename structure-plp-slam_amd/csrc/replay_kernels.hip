@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include "plp_common.hpp"
+#include "plp_barrier.hpp"
 
 namespace plp {
 
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(1024) void k_pack_offsets(const int32_t* __restrict
     __shared__ long long s_carry;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) s_carry = 0;
-    __syncthreads();
+    wg_barrier();
     for (int base = 0; base < B; base += 1024) {
         const int i = base + tid;
         const long long v = i < B ? (long long)min(max(counts[i], 0), cap) : 0;
@@ -90,13 +91,13 @@ __global__ __launch_bounds__(1024) void k_pack_offsets(const int32_t* __restrict
             if (lane >= o) inc += up;
         }
         if (lane == 63) s_wave[wv] = inc;
-        __syncthreads();
+        wg_barrier();
         long long before = s_carry;
         for (int k = 0; k < wv; ++k) before += s_wave[k];
         if (i < B) offsets[i] = before + inc - v;
-        __syncthreads();
+        wg_barrier();
         if (tid == 1023) s_carry = before + inc;
-        __syncthreads();
+        wg_barrier();
     }
     if (tid == 0) offsets[B] = s_carry;
 }

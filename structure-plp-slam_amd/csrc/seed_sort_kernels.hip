@@ -19,6 +19,7 @@
 #include <type_traits>
 
 #include "line_device.hpp"
+#include "plp_barrier.hpp"
 #include "seed_sort_model.hpp"
 
 namespace plp {
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(256) void k_lsd_order_entries(LinePlanes P, const u
     // and stale copies of entries that moved to the left (seed_sort_impl.inc wg_partition): not part of the array any more
     const int nv = min(nv_all, (int)__builtin_amdgcn_readfirstlane((int)ws_all[(size_t)b * ws_stride]));
     for (int i = tid; i < 4096; i += 256) (&cnt[0][0])[i] = 0;
-    __syncthreads();
+    wg_barrier();
     const uint32_t* ent = ent_all + (size_t)b * nv_all;
     uint32_t* order = P.order + (size_t)b * nv_all;
     const int ngroups = (nv + 63) / 64, gper = (ngroups + 3) / 4, g0 = q * gper, g1 = min(ngroups, g0 + gper);
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256) void k_lsd_order_entries(LinePlanes P, const u
             ncomp += __popcll(defm);
         }
     }
-    __syncthreads();
+    wg_barrier();
     {   // thread t owns bins 1023-4t .. 1020-4t (descending)
         const int v0 = 1023 - 4 * tid;
         uint32_t c[4][4], tot = 0;
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256) void k_lsd_order_entries(LinePlanes P, const u
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc, o); if (lane >= o) inc += t; }
         if (lane == 63) s_wsum[q] = inc;
-        __syncthreads();
+        wg_barrier();
         uint32_t run = inc - tot;
         for (int k = 0; k < q; ++k) run += s_wsum[k];
 #pragma unroll
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(256) void k_lsd_order_entries(LinePlanes P, const u
             for (int k = 0; k < 4; ++k) { cnt[k][v0 - j] = run; run += c[j][k]; }
         if (tid == 255) P.n_order[b] = (int32_t)run;
     }
-    __syncthreads();
+    wg_barrier();
     for (int ib = 0; ib < ncomp; ib += 256) {
         uint32_t e4[4];
 #pragma unroll

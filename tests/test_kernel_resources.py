@@ -127,11 +127,10 @@ def isa_files():
 
 @pytest.mark.skipif(not isa_files(), reason="csrc/build/*.s absent: run __graft_entry__.build() (make keeps the device ISA of every translation unit)")
 def test_no_kernel_reaches_memory_through_flat_instructions():
-    """Round 6 (profiles/r06_seed_sort.md section 4): a build of the seed sort that reached its chunk masks through a pointer chosen at run time -- FLAT
-    loads and stores -- failed 17 of 17 times beside a second dispatch of the kernel and never alone.  Ten one-macro variants narrowed it to the ADDRESS FORM of the accesses to the
-    masks' copy in HBM (64-bit address in vector registers: fails, with FLAT or GLOBAL instructions alike; scalar base + vector offset: never fails), not to LDS, not to FLAT as
-    such, not to a missing wait; the mechanism is not identified.  A pointer whose address space the compiler does not know forces the failing form, so the library holds NO flat
-    memory instruction (three kernels had them: k_quadtree, k_lsd_grow_mw, k_match_topk_cells) and this test keeps it so."""
+    """A pointer whose address space the compiler does not know (`fits ? lds : hbm`, a pointer made from an integer) is reached through FLAT loads and stores: an aperture check
+    per access, both wait counters held, no scalar-base addressing.  Three kernels had them until round 6 (k_quadtree, k_lsd_grow_mw, k_match_topk_cells); each is now specialised
+    per address space (DS instructions for LDS, scalar-base GLOBAL instructions for HBM) and this test keeps the library free of them.  (Round 6 first read the seed sort's failure
+    beside a second dispatch as a property of FLAT / vector-address accesses; it was a barrier that had lost its wait -- see the next test.)"""
     bad = {}
     for path in isa_files():
         kernel = None
@@ -142,3 +141,64 @@ def test_no_kernel_reaches_memory_through_flat_instructions():
             elif re.match(r"^\s+flat_(load|store|atomic)", line):
                 bad[kernel] = bad.get(kernel, 0) + 1
     assert not bad, f"FLAT memory instructions (kernel: count): {bad}"
+
+
+def _barrier_check():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("isa_barrier_check", os.path.join(os.path.dirname(__file__), "..", "tools", "isa_barrier_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_the_barrier_check_sees_a_wait_that_is_missing_on_the_back_edge_only(tmp_path):
+    """the shape the compiler produced (profiles/r06_seed_sort.md section 4): nothing pending on the way in, an LDS write pending on the loop's back edge, no wait at the header"""
+    chk = _barrier_check()
+    text = """_Zkernel:
+\ts_load_dword s0, s[4:5], 0x0
+\ts_branch .LBB0_2
+.LBB0_1:
+\tds_write_b32 v2, v3 offset:64
+.LBB0_2:
+{wait}\ts_barrier
+\tds_read_b32 v3, v2 offset:64
+\ts_waitcnt lgkmcnt(0)
+\tv_readfirstlane_b32 s2, v3
+\ts_cmp_eq_u32 s2, 0
+\ts_cbranch_scc0 .LBB0_1
+\ts_endpgm
+.Lfunc_end0:
+"""
+    for wait, want in (("", 1), ("\ts_waitcnt lgkmcnt(0)\n", 0), ("\ts_waitcnt vmcnt(0)\n", 1), ("\ts_waitcnt vmcnt(0) lgkmcnt(0)\n", 0)):
+        f = tmp_path / "k.s"
+        f.write_text(text.format(wait=wait))
+        (name, body), = list(chk.kernels(str(f)))
+        assert name == "_Zkernel" and len(chk.check(body)) == want, (wait, chk.check(body))
+
+
+@pytest.mark.skipif(not isa_files(), reason="csrc/build/*.s absent: run __graft_entry__.build() (make keeps the device ISA of every translation unit)")
+def test_every_barrier_is_reached_with_the_waves_lds_writes_drained():
+    """THE CAUSE of the failure of rounds 4 - 6 (profiles/r06_seed_sort.md section 4): the `s_waitcnt lgkmcnt(0)` of __syncthreads()'s release fence is a soft wait, and the
+    compiler deleted it at the barrier that heads the seed sort's loop over global partitions in some builds (nothing pending on the path from the entry; wave 0's pushes to
+    the segment stack pending on the back edge).  The other waves then read the stack early -- beside a second dispatch, whose LDS traffic stretches the window, every time.
+    The library's barriers carry a hard wait (csrc/plp_barrier.hpp); this test proves on the kept ISA, by data-flow over the basic blocks of every kernel, that no s_barrier can
+    be reached while an LDS write of the arriving wave may still be in flight."""
+    chk = _barrier_check()
+    bad, seen = {}, 0
+    for path in isa_files():
+        for name, body in chk.kernels(path):
+            if any(re.match(r"^\s+s_barrier", l) for _, l in body):
+                seen += 1
+                lines = chk.check(body)
+                if lines:
+                    bad[name] = lines
+    assert seen >= 20, seen
+    assert not bad, f"barriers reached with LDS writes in flight (kernel: lines of csrc/build/*.s): {bad}"
+    # ... and the sources do not go back to the soft form
+    src = os.path.join(BUILD, "..")
+    for path in glob.glob(os.path.join(src, "*.hip")) + glob.glob(os.path.join(src, "*.inc")) + glob.glob(os.path.join(src, "*.hpp")):
+        if os.path.basename(path) == "plp_barrier.hpp":
+            continue
+        for no, line in enumerate(open(path), 1):
+            code = line.split("//")[0]
+            assert "__syncthreads()" not in code, f"{os.path.basename(path)}:{no}: use wg_barrier() (csrc/plp_barrier.hpp)"
