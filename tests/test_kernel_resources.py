@@ -202,3 +202,23 @@ def test_every_barrier_is_reached_with_the_waves_lds_writes_drained():
         for no, line in enumerate(open(path), 1):
             code = line.split("//")[0]
             assert "__syncthreads()" not in code, f"{os.path.basename(path)}:{no}: use wg_barrier() (csrc/plp_barrier.hpp)"
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="no hipcc")
+def test_the_25_line_reproducer_of_the_deleted_wait_and_its_cure(tmp_path):
+    """tools/experiments/soft_wait_loop_header.hip: with __syncthreads() this compiler leaves the loop header's s_barrier without its LDS wait (on the hardware: half of all thread
+    results wrong, tools/sessions/r06/run56.sh); with the hard wait of csrc/plp_barrier.hpp the barrier is reached clean (0 wrong).  The cure is asserted; the defect is reported
+    (a compiler that no longer shows it makes this test say so, not fail)."""
+    import subprocess
+    chk = _barrier_check()
+    src = os.path.join(os.path.dirname(__file__), "..", "tools", "experiments", "soft_wait_loop_header.hip")
+    found = {}
+    for name, flag in (("soft", []), ("hard", ["-DHARD_WAIT"])):
+        out = tmp_path / f"{name}.s"
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-mno-tgsplit", "-DWITH_MAIN", "--cuda-device-only", "-S", "-o", str(out), src] + flag,
+                       check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        (kname, body), = [kb for kb in chk.kernels(str(out)) if kb[0].startswith("_Z1k")]
+        found[name] = chk.check(body)
+    assert found["hard"] == [], found
+    if not found["soft"]:
+        pytest.skip("this compiler keeps the wait of __syncthreads() at the loop header: the defect of ROCm 7.2 is not present")
