@@ -94,7 +94,7 @@ def step_profile_fields(bytes_per_frame, B, dominant):
         out["in_step_frac"] = round(bytes_per_frame * frames / (v["mean_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)
     ob = sp.get("occupancy_bound")
     if ob:
-        out["occupancy_bound"] = {k: ob[k] for k in ("register_cycles", "ideal_ms", "ms_per_step_of_that_run", "packing", "shares") if k in ob}
+        out["occupancy_bound"] = {k: ob[k] for k in ("register_cycles", "ideal_ms", "ms_per_step_of_that_run", "packing", "shares", "lds") if k in ob}
     out["step_profile_source"] = sp.get("source")
     return out
 

@@ -7,13 +7,18 @@ one resource the round-4 model found binding -- register-time.
 in_step: durations of `plp::k_lsd_grow` from the kernel trace of `bench.py --steps 3 --warmup 1`, split by launch size (the step launches it per line sub-block of
 1024 frames, two in flight; the isolated stage passes of the same run launch it once over 2048 frames).
 occupancy_bound: sum over the step's kernels of waves x cycles per wave x allocated VGPRs (SQ_WAVES, SQ_WAVE_CYCLES of the counter pass, one launch = the whole batch;
-VGPRs from the build's resource remarks, rounded up to the allocation granule of 8) x launches per step = register-cycles per step; the chip offers
-1024 SIMDs x 512 VGPRs x 2.4e9 cycles/s; ideal_ms = the step if the register file were packed perfectly, packing = ideal_ms / measured ms per step."""
-import argparse, glob, json, os, re, sqlite3
+VGPRs from the dispatch records of the counter pass -- arch + accumulation registers as allocated; the build's resource remarks where a database lacks them -- rounded up
+to the allocation granule of 8) x launches per step = register-cycles per step; the chip offers 1024 SIMDs x 512 VGPRs x 2.4e9 cycles/s; ideal_ms = the step if the register
+file were packed perfectly, packing = ideal_ms / measured ms per step.  occupancy_bound.lds: the same sum with the LDS a wave's workgroup holds (lds_block_size / waves per
+workgroup) against 256 CUs x 160 KB: the second resource a resident wave occupies while it waits.
+(Until the end of round 6 the remarks were matched by SUBSTRING and the maximum taken: k_lsd_grow was booked with k_lsd_grow_mw's 170 registers instead of its own 111,
+which put the ideal at 17.6 ms and the packing at 0.77; with each kernel's own allocation: 15.1 ms, 0.67.)"""
+import argparse, glob, json, os, re, sqlite3, sys
 from collections import defaultdict
 
 LAUNCHES_PER_STEP = {"plp::k_resize_linear": 7}          # every other kernel: 1 (the counter pass runs the line path unsplit); the matcher kernels: 2 (below)
 CHIP = 1024 * 512 * 2.4e9
+CHIP_LDS = 256 * 160 * 1024 * 2.4e9   # bytes of LDS x cycles per second
 
 
 def short(name):
@@ -63,35 +68,61 @@ def main():
     # ---- register-time of a step
     V = vgprs()
     def vg(kernel):
+        # the kernel's own entry of the resource remarks, by its MANGLED name: <length><identifier> (+ IL<type><value>E for a template argument).  (Until the end of round 6 this
+        # matched substrings and took the maximum: k_lsd_grow got k_lsd_grow_mw's 170 registers instead of its 111, the matchers' <1> variants the largest instantiation's.)
         base = kernel.split("<")[0].split("::")[-1]
-        cands = [v for k, v in V.items() if base in k and ("ss_thr" in k) == ("ss_thr" in kernel) and ("ss_lat" in k) == ("ss_lat" in kernel) and "debug" not in k]
-        return (max(cands) + 7) // 8 * 8 if cands else None
+        key = f"{len(base)}{base}"
+        targ = re.search(r"<(\d+)>", kernel)
+        pat = re.compile(r"(?<!\d)" + key + (r"IL[a-z]" + targ.group(1) + "E" if targ else r"E"))
+        cands = [v for k, v in V.items() if pat.search(k) and ("ss_thr" in k) == ("ss_thr" in kernel) and ("ss_lat" in k) == ("ss_lat" in kernel) and "debug" not in k]
+        assert len(cands) <= 1, (kernel, cands)
+        return (cands[0] + 7) // 8 * 8 if cands else None
     cur = sqlite3.connect(a.sq_db).cursor()
-    acc = defaultdict(lambda: defaultdict(float)); cnt = defaultdict(int)
-    for name, cn, val in cur.execute("select kernel_name, counter_name, value from counters_collection"):
+    acc = defaultdict(lambda: defaultdict(float)); cnt = defaultdict(int); disp = {}
+    ccols = [r[1] for r in cur.execute("pragma table_info(counters_collection)")]
+    has_disp = all(c in ccols for c in ("workgroup_size", "lds_block_size", "vgpr_count", "accum_vgpr_count"))
+    q = "select kernel_name, counter_name, value" + (", workgroup_size, lds_block_size, vgpr_count, accum_vgpr_count" if has_disp else "") + " from counters_collection"
+    for row in cur.execute(q):
+        name, cn, val = row[:3]
         s = short(name)
         acc[s][cn] += val
         if cn == "SQ_WAVES":
             cnt[s] += 1
-    per_kernel, total = {}, 0.0
+        if has_disp:   # what the dispatch itself was given: registers per lane (arch + accumulation, allocated), LDS per workgroup
+            disp[s] = {"wg": row[3], "lds": row[4], "vgprs": row[5] + row[6]}
+    per_kernel, total, total_lds = {}, 0.0, 0.0
     for s, c in acc.items():
         if not s.startswith("plp::") or s.endswith("k_lsd_order") or not cnt[s]:
             continue
         waves = c["SQ_WAVES"] / cnt[s]
         cyc_per_wave = 4 * c["SQ_WAVE_CYCLES"] / max(c["SQ_WAVES"], 1)
         v = vg(s)
+        if s in disp:
+            dv = (disp[s]["vgprs"] + 7) // 8 * 8
+            if v is not None and dv != v:
+                print(f"note: {s}: {v} VGPRs by the build's remarks, {dv} by the dispatch record (used)", file=sys.stderr)
+            v = dv
         if v is None:
             continue
         launches = LAUNCHES_PER_STEP.get(s, 2 if "k_match_" in s else 1)
         rc = waves * cyc_per_wave * v * launches
         per_kernel[s] = {"waves": round(waves), "cycles_per_wave": round(cyc_per_wave), "vgprs": v, "launches_per_step": launches, "register_cycles": rc}
         total += rc
+        if s in disp:
+            lds_per_wave = disp[s]["lds"] / max(1, (disp[s]["wg"] + 63) // 64)
+            lc = waves * cyc_per_wave * lds_per_wave * launches
+            per_kernel[s].update({"lds_bytes_per_workgroup": disp[s]["lds"], "waves_per_workgroup": (disp[s]["wg"] + 63) // 64, "lds_byte_cycles": lc})
+            total_lds += lc
     ms = bench["ms_per_step"]
     ideal = total / CHIP * 1e3
     out = {"batch": B, "source": a.source, "dominant": a.dominant, "in_step_launches": in_step,
            "occupancy_bound": {"register_cycles": total, "ideal_ms": round(ideal, 3), "ms_per_step_of_that_run": ms, "packing": round(ideal / ms, 4),
                                "shares": {k: round(v["register_cycles"] / total, 4) for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1]["register_cycles"])[:8]}},
            "per_kernel": per_kernel}
+    if total_lds:   # the same sum for the other resource a resident wave holds while it waits: LDS (256 CUs x 160 KB)
+        ideal_lds = total_lds / CHIP_LDS * 1e3
+        out["occupancy_bound"]["lds"] = {"lds_byte_cycles": total_lds, "ideal_ms": round(ideal_lds, 3), "packing": round(ideal_lds / ms, 4),
+                                         "shares": {k: round(v.get("lds_byte_cycles", 0.0) / total_lds, 4) for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1].get("lds_byte_cycles", 0.0))[:6]}}
     json.dump(out, open(a.out, "w"), indent=1)
     print(json.dumps({k: out[k] for k in ("in_step_launches", "occupancy_bound")}, indent=1))
 
