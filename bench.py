@@ -327,8 +327,8 @@ def main():
                 "launch_ms": round(kern[dominant] / launches, 4), "bytes_per_launch": int(dom_bytes / launches),
                 # The figures above describe an ISOLATED, synchronous pass.  Inside the overlapped step the dominant kernel runs per line sub-block beside the other
                 # streams' kernels: its launch duration there and the fraction that follows come from the committed kernel trace of this command (profiles/step_profile.json,
-                # tools/step_profile.py); `occupancy_bound` = the step against the resource round 4 found binding (register-time: waves x cycles x VGPRs of all its kernels
-                # against 1024 SIMDs x 512 registers x 2.4 GHz).  Quoted from the committed profile, not measured by this run (as `traffic`).
+                # tools/step_profile.py); `occupancy_bound` = the step against the two resources a resident wave holds while it waits -- registers (waves x cycles x VGPRs of all
+                # its kernels against 1024 SIMDs x 512 registers x 2.4 GHz) and, under `lds`, LDS bytes against 256 CUs x 160 KB.  Quoted from the committed profile, not measured by this run (as `traffic`).
                 **step_profile_fields(per_frame[dominant], B, dominant),
                 "match_candidates_per_query_counted": None if cand_per_query is None else round(cand_per_query, 2),
                 "stage_ms_per_batch": {k: round(v, 4) for k, v in stage_ms.items()},

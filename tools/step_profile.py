@@ -40,7 +40,48 @@ def vgprs():
     return out
 
 
+def bounds(per_kernel, ms):
+    """register-time and LDS-time of a step against what the chip offers"""
+    total = sum(v["register_cycles"] for v in per_kernel.values())
+    total_lds = sum(v.get("lds_byte_cycles", 0.0) for v in per_kernel.values())
+    ideal = total / CHIP * 1e3
+    ob = {"register_cycles": total, "ideal_ms": round(ideal, 3), "ms_per_step_of_that_run": ms, "packing": round(ideal / ms, 4),
+          "shares": {k: round(v["register_cycles"] / total, 4) for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1]["register_cycles"])[:8]}}
+    if total_lds:   # the same sum for the other resource a resident wave holds while it waits: LDS (256 CUs x 160 KB)
+        ideal_lds = total_lds / CHIP_LDS * 1e3
+        ob["lds"] = {"lds_byte_cycles": total_lds, "ideal_ms": round(ideal_lds, 3), "packing": round(ideal_lds / ms, 4),
+                     "shares": {k: round(v.get("lds_byte_cycles", 0.0) / total_lds, 4) for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1].get("lds_byte_cycles", 0.0))[:6]}}
+    return ob
+
+
+def recompute(path):
+    """--recompute <step_profile.json>: the bounds of a stored table again, with the registers the CURRENT build's remarks give each kernel"""
+    d = json.load(open(path)); V = vgprs()
+    for k, rec in d["per_kernel"].items():
+        v = vg_of(V, k)
+        if v is not None:
+            rec["vgprs"] = v
+        rec["register_cycles"] = rec["waves"] * rec["cycles_per_wave"] * rec["vgprs"] * rec["launches_per_step"]
+    d["occupancy_bound"] = bounds(d["per_kernel"], d["occupancy_bound"]["ms_per_step_of_that_run"])
+    json.dump(d, open(path, "w"), indent=1)
+    print(json.dumps(d["occupancy_bound"], indent=1))
+
+
+def vg_of(V, kernel):
+    # the kernel's own entry of the resource remarks, by its MANGLED name: <length><identifier> (+ IL<type><value>E for a template argument).  (Until the end of round 6 this
+    # matched substrings and took the maximum: k_lsd_grow got k_lsd_grow_mw's 170 registers instead of its 111, the matchers' <1> variants the largest instantiation's.)
+    base = kernel.split("<")[0].split("::")[-1]
+    key = f"{len(base)}{base}"
+    targ = re.search(r"<(\d+)>", kernel)
+    pat = re.compile(r"(?<!\d)" + key + (r"IL[a-z]" + targ.group(1) + "E" if targ else r"E"))
+    cands = [v for k, v in V.items() if pat.search(k) and ("ss_thr" in k) == ("ss_thr" in kernel) and ("ss_lat" in k) == ("ss_lat" in kernel) and "debug" not in k]
+    assert len(cands) <= 1, (kernel, cands)
+    return (cands[0] + 7) // 8 * 8 if cands else None
+
+
 def main():
+    if len(sys.argv) == 3 and sys.argv[1] == "--recompute":
+        return recompute(sys.argv[2])
     ap = argparse.ArgumentParser()
     ap.add_argument("kt_db"); ap.add_argument("sq_db"); ap.add_argument("--bench", required=True); ap.add_argument("--out", required=True); ap.add_argument("--source", default=None)
     ap.add_argument("--dominant", default="plp::k_lsd_grow")
@@ -67,16 +108,7 @@ def main():
             in_step[str(frames)] = {"launches": len(by_size[sz]), "mean_ms": round(sum(by_size[sz]) / len(by_size[sz]), 4), "isolated": sz == full and len(sizes) > 1}
     # ---- register-time of a step
     V = vgprs()
-    def vg(kernel):
-        # the kernel's own entry of the resource remarks, by its MANGLED name: <length><identifier> (+ IL<type><value>E for a template argument).  (Until the end of round 6 this
-        # matched substrings and took the maximum: k_lsd_grow got k_lsd_grow_mw's 170 registers instead of its 111, the matchers' <1> variants the largest instantiation's.)
-        base = kernel.split("<")[0].split("::")[-1]
-        key = f"{len(base)}{base}"
-        targ = re.search(r"<(\d+)>", kernel)
-        pat = re.compile(r"(?<!\d)" + key + (r"IL[a-z]" + targ.group(1) + "E" if targ else r"E"))
-        cands = [v for k, v in V.items() if pat.search(k) and ("ss_thr" in k) == ("ss_thr" in kernel) and ("ss_lat" in k) == ("ss_lat" in kernel) and "debug" not in k]
-        assert len(cands) <= 1, (kernel, cands)
-        return (cands[0] + 7) // 8 * 8 if cands else None
+    vg = lambda kernel: vg_of(V, kernel)
     cur = sqlite3.connect(a.sq_db).cursor()
     acc = defaultdict(lambda: defaultdict(float)); cnt = defaultdict(int); disp = {}
     ccols = [r[1] for r in cur.execute("pragma table_info(counters_collection)")]
@@ -90,39 +122,26 @@ def main():
             cnt[s] += 1
         if has_disp:   # what the dispatch itself was given: registers per lane (arch + accumulation, allocated), LDS per workgroup
             disp[s] = {"wg": row[3], "lds": row[4], "vgprs": row[5] + row[6]}
-    per_kernel, total, total_lds = {}, 0.0, 0.0
+    per_kernel = {}
     for s, c in acc.items():
         if not s.startswith("plp::") or s.endswith("k_lsd_order") or not cnt[s]:
             continue
         waves = c["SQ_WAVES"] / cnt[s]
         cyc_per_wave = 4 * c["SQ_WAVE_CYCLES"] / max(c["SQ_WAVES"], 1)
         v = vg(s)
-        if s in disp:
-            dv = (disp[s]["vgprs"] + 7) // 8 * 8
-            if v is not None and dv != v:
-                print(f"note: {s}: {v} VGPRs by the build's remarks, {dv} by the dispatch record (used)", file=sys.stderr)
-            v = dv
+        # (the dispatch records' vgpr_count is NOT used: on this target it comes back as about half of what the kernel descriptor allots -- 56 for k_lsd_grow's 111 -- except
+        # where it does not (k_match_prep: 56 for 55); the build's resource remarks are the compiler's own statement of the allocation)
         if v is None:
             continue
         launches = LAUNCHES_PER_STEP.get(s, 2 if "k_match_" in s else 1)
         rc = waves * cyc_per_wave * v * launches
         per_kernel[s] = {"waves": round(waves), "cycles_per_wave": round(cyc_per_wave), "vgprs": v, "launches_per_step": launches, "register_cycles": rc}
-        total += rc
         if s in disp:
             lds_per_wave = disp[s]["lds"] / max(1, (disp[s]["wg"] + 63) // 64)
             lc = waves * cyc_per_wave * lds_per_wave * launches
             per_kernel[s].update({"lds_bytes_per_workgroup": disp[s]["lds"], "waves_per_workgroup": (disp[s]["wg"] + 63) // 64, "lds_byte_cycles": lc})
-            total_lds += lc
-    ms = bench["ms_per_step"]
-    ideal = total / CHIP * 1e3
-    out = {"batch": B, "source": a.source, "dominant": a.dominant, "in_step_launches": in_step,
-           "occupancy_bound": {"register_cycles": total, "ideal_ms": round(ideal, 3), "ms_per_step_of_that_run": ms, "packing": round(ideal / ms, 4),
-                               "shares": {k: round(v["register_cycles"] / total, 4) for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1]["register_cycles"])[:8]}},
-           "per_kernel": per_kernel}
-    if total_lds:   # the same sum for the other resource a resident wave holds while it waits: LDS (256 CUs x 160 KB)
-        ideal_lds = total_lds / CHIP_LDS * 1e3
-        out["occupancy_bound"]["lds"] = {"lds_byte_cycles": total_lds, "ideal_ms": round(ideal_lds, 3), "packing": round(ideal_lds / ms, 4),
-                                         "shares": {k: round(v.get("lds_byte_cycles", 0.0) / total_lds, 4) for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1].get("lds_byte_cycles", 0.0))[:6]}}
+    out = {"batch": B, "source": a.source, "dominant": a.dominant, "in_step_launches": in_step, "per_kernel": per_kernel}
+    out["occupancy_bound"] = bounds(per_kernel, bench["ms_per_step"])
     json.dump(out, open(a.out, "w"), indent=1)
     print(json.dumps({k: out[k] for k in ("in_step_launches", "occupancy_bound")}, indent=1))
 
