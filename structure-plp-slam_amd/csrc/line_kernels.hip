@@ -898,9 +898,6 @@ template <bool MW> __device__ int reduce_radius_pass(const GrowCtx& g, int nreg,
 // USED bitmap + frontier ring fit 64 KB of LDS together, at most 4).
 __global__ __launch_bounds__(256) void k_lsd_grow(LinePlanes P, LsdParams lp, int B, int wpb, int ring) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_bits[];
-#ifdef PLP_GROW_PRIO
-    __builtin_amdgcn_s_setprio(PLP_GROW_PRIO);
-#endif
     // the wave's index is wave-uniform, and said so: every per-frame pointer below then lives in scalar registers (global addresses become an SGPR base + a
     // 32-bit lane offset instead of 64-bit vector arithmetic)
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
