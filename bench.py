@@ -106,6 +106,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=2048, help="frames per rank per step (region growing is one wave per frame: 2048 frames put two of them on every SIMD; larger batches give the same throughput)")
     ap.add_argument("--keypoints", type=int, default=1000, help="Feature.max_num_keypoints (TUM RGB-D YAML: 1000)")
+    ap.add_argument("--distinct", type=int, default=64, help="distinct frames of the synthetic pan that fill the batch (repeated): 64 is what every round measured; "
+                    "--distinct 2048 makes every frame of a 2048-frame step its own (the pan crosses its 2 561-pixel canvas 2.4 times)")
     ap.add_argument("--rows", type=int, default=480)
     ap.add_argument("--cols", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -138,7 +140,7 @@ def main():
     synth = importlib.import_module("structure-plp-slam_amd.synth")
 
     B, K = args.batch, args.keypoints
-    uniq = min(B, 64)   # 64 distinct frames of the pan, repeated to fill the batch (host-side generation is slow)
+    uniq = max(3, min(B, args.distinct))   # distinct frames of the pan, repeated to fill the batch (64 by default: every round's figure is on that workload)
     frames_np = synth.replay(1234 + rank, uniq, args.rows, args.cols)
     d_frames = torch.from_numpy(frames_np).to(dev)
     if uniq < B:
@@ -520,7 +522,7 @@ def main():
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": f"TUM-RGBD-shaped replay {args.cols}x{args.rows} (BASELINE configs[1]): {what}; K={K}, 8 levels, 1.2; "
                                "BoW matchers not included",
-                   "frames_per_rank_per_step": B, "keypoints_mean": round(mean_kp, 1), "lines_mean": round(mean_lines, 1),
+                   "frames_per_rank_per_step": B, "distinct_frames": uniq, "keypoints_mean": round(mean_kp, 1), "lines_mean": round(mean_lines, 1),
                    "matches_mean": [round(float(n1.float().mean().item()), 1), round(float(n2.float().mean().item()), 1)] + ([] if args.orb_only else [round(float(n3.float().mean().item()), 1), round(float(n4.float().mean().item()), 1)]),
                    "match_rescans_rounds": (match_dbg if not args.orb_only else None),
                    "sharding": f"contiguous frame blocks per rank; ONE exchange per step and rank of the 2-frame feature halo the matchers read -- key points, descriptors, key lines, LBD "
