@@ -74,22 +74,34 @@ cv::Mat desc_rows(const uint8_t* d, int n) {
 cv::Mat desc_row(const uint8_t* d) { cv::Mat m(1, 32, CV_8UC1); std::memcpy(m.data, d, 32); return m; }
 Vec3_t coded(size_t j, int k) { return Vec3_t((double)(4 * j + k), 0.0, 1.0); }
 
+// A caller's scale-factor array holds one entry per level it uses (at least Levels::have of them); the reference's vectors are made one entry longer (Levels::n) so that
+// no `.at(level + 1)` of the reference can throw.  The extra entry is EXTENDED geometrically, not read from behind the caller's array (found by AddressSanitizer in round 6:
+// tools/oracle_sanitized_tests.sh -- four bytes behind an eight-entry array were read, and never used).
+struct Levels { int n, have; };
+void assign_scale_factors(std::vector<float>& v, const float* sf, Levels L) {
+    v.assign(sf, sf + L.have);
+    while ((int)v.size() < L.n) v.push_back(v.size() >= 2 ? v.back() * (v[1] / v[0]) : v.back());
+}
+void assign_scale_factors(std::vector<float>& v, const float* sf, int n) { v.assign(sf, sf + n); }
+inline int count_of(int n) { return n; }
+inline int count_of(Levels L) { return L.n; }
 // key points of a frame / key frame
-template <class F> void fill_points(F& f, camera::base* cam, const cv::KeyPoint* kps, const uint8_t* desc, const float* x_right, int n, const float* sf, int n_sf) {
+template <class F, class NL> void fill_points(F& f, camera::base* cam, const cv::KeyPoint* kps, const uint8_t* desc, const float* x_right, int n, const float* sf, NL n_sf_) {
+    const int n_sf = count_of(n_sf_);
     f.camera_ = cam; f.num_keypts_ = (unsigned)n;
     f.keypts_.assign(kps, kps + n); f.undist_keypts_ = f.keypts_;
     f.descriptors_ = desc_rows(desc, n);
     f.stereo_x_right_.assign(n, -1.f);
     if (x_right) f.stereo_x_right_.assign(x_right, x_right + n);
-    f.scale_factors_.assign(sf, sf + n_sf);
+    assign_scale_factors(f.scale_factors_, sf, n_sf_);
     f.num_scale_levels_ = (unsigned)n_sf;
     f.assign_grid();
 }
-template <class F> void fill_lines(F& f, camera::base* cam, const KeyLine* kl, const uint8_t* lbd, int n, const float* sf_lsd, int n_sf) {
+template <class F, class NL> void fill_lines(F& f, camera::base* cam, const KeyLine* kl, const uint8_t* lbd, int n, const float* sf_lsd, NL n_sf_) {
     f.camera_ = cam; f._num_keylines = (unsigned)n;
     f._keylsd.assign(kl, kl + n);
     f._lbd_descr = desc_rows(lbd, n);
-    f._scale_factors_lsd.assign(sf_lsd, sf_lsd + n_sf);
+    assign_scale_factors(f._scale_factors_lsd, sf_lsd, n_sf_);
     f._stereo_x_right_cooresponding_to_keylines.assign(n, std::make_pair(-1.f, -1.f));
 }
 // a frame slot that already holds a landmark WITH observations blocks (occupied = 1)
@@ -107,10 +119,10 @@ void occupy_lines(data::frame& f, Pool& P, const uint8_t* occupied, int n) {
     f._landmarks_line.assign(n, nullptr); f._outlier_flags_line.assign(n, false);
     for (int i = 0; i < n; ++i) if (occupied && occupied[i]) { auto* b = P.line(); b->num_obs_ = 1; b->id_ = -2; f._landmarks_line[i] = b; }
 }
-int n_levels_of(const int* lvl, const unsigned* ulvl, int m, int at_least) {
-    int mx = at_least;
-    for (int i = 0; i < m; ++i) mx = std::max(mx, (lvl ? lvl[i] : (int)ulvl[i]) + 2);
-    return mx;
+Levels n_levels_of(const int* lvl, const unsigned* ulvl, int m, int at_least) {
+    int top = -1;
+    for (int i = 0; i < m; ++i) top = std::max(top, lvl ? lvl[i] : (int)ulvl[i]);
+    return Levels{std::max(at_least, top + 2), std::max(at_least, top + 1)};
 }
 
 }  // namespace
@@ -356,9 +368,9 @@ void ref_project_best(const double* grid6, const cv::KeyPoint* kps, const uint8_
     cam.resize(m);
     Pool P;
     data::keyframe kf;
-    const int nl = n_levels_of(nullptr, pred_level, m, 8);
+    const Levels nl = n_levels_of(nullptr, pred_level, m, 8);
     fill_points(kf, &cam, kps, desc, nullptr, n, scale_factors, nl);
-    kf.inv_level_sigma_sq_.assign(std::max(nl, 64), 0.f);
+    kf.inv_level_sigma_sq_.assign(std::max(nl.n, 64), 0.f);
     kf.landmarks_.assign(n, nullptr);
     for (int i = 0; i < n; ++i) { auto* s = P.lm(); s->id_ = i; s->num_obs_ = 1000000; kf.landmarks_[i] = s; }
     std::vector<data::landmark*> lms;
@@ -566,9 +578,9 @@ void ref_fuse_search(const double* grid6, const cv::KeyPoint* kps, const uint8_t
     cam.resize(m);
     Pool P;
     data::keyframe kf;
-    const int nl = n_levels_of(nullptr, pred_level, m, 8);
+    const Levels nl = n_levels_of(nullptr, pred_level, m, 8);
     fill_points(kf, &cam, kps, desc, x_right, n, scale_factors, nl);
-    kf.inv_level_sigma_sq_.assign(inv_level_sigma_sq, inv_level_sigma_sq + nl);
+    kf.inv_level_sigma_sq_.assign(inv_level_sigma_sq, inv_level_sigma_sq + nl.have); kf.inv_level_sigma_sq_.resize(nl.n, kf.inv_level_sigma_sq_.back());
     kf.landmarks_.assign(n, nullptr);
     for (int i = 0; i < n; ++i) { auto* s = P.lm(); s->id_ = i; s->num_obs_ = 1000000; kf.landmarks_[i] = s; }   // sentinel: best_idx is read from lm->replace(sentinel)
     std::vector<data::landmark*> lms;
@@ -589,9 +601,9 @@ void ref_fuse_search_line(const KeyLine* kl, const uint8_t* lbd, int n, const fl
     cam.resize(m);
     Pool P;
     data::keyframe kf;
-    const int nl = n_levels_of(nullptr, pred_level, m, 2);
+    const Levels nl = n_levels_of(nullptr, pred_level, m, 2);
     fill_lines(kf, &cam, kl, lbd, n, scale_factors_lsd, nl);
-    kf._inv_level_sigma_sq_lsd.assign(inv_level_sigma_sq_lsd, inv_level_sigma_sq_lsd + nl);
+    kf._inv_level_sigma_sq_lsd.assign(inv_level_sigma_sq_lsd, inv_level_sigma_sq_lsd + nl.have); kf._inv_level_sigma_sq_lsd.resize(nl.n, kf._inv_level_sigma_sq_lsd.back());
     kf.landmarks_line_.assign(n, nullptr);
     for (int i = 0; i < n; ++i) { auto* s = P.line(); s->id_ = i; s->num_obs_ = 1000000; kf.landmarks_line_[i] = s; }
     std::vector<data::Line*> lms;

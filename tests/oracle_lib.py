@@ -106,7 +106,8 @@ def lib():
 def _load():
     global _lib
     if _lib is None:
-        so = ORACLE_DIR / "liboracle.so"
+        # PLP_ORACLE_SO: another build of the same sources in the default's place for a whole run (tools/oracle_sanitized_tests.sh: the AddressSanitizer / UBSan build)
+        so = ORACLE_DIR / os.environ.get("PLP_ORACLE_SO", "liboracle.so")
         if not so.exists():
             build()
         L = C.CDLL(str(so))
