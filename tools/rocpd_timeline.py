@@ -23,6 +23,28 @@ t0, t1 = fc[step], fc[step + 1]
 win = [r for r in rows if r[2] > t0 and r[1] < t1]
 queues = sorted({r[3] for r in win})
 print(f"# step {step}: {(t1 - t0) / 1e6:.2f} ms between two k_fast_cells launches; {len(win)} dispatches on {len(queues)} queues (columns: table `kernels` = {cols})\n")
+# per queue: how much of the step some kernel of that queue was executing (union of its dispatches' intervals), and the sum of their durations
+print("| queue | busy (ms) | busy / step | sum of kernel durations (ms) | kernels |")
+print("|---|---:|---:|---:|---|")
+for qi, q in enumerate(queues):
+    iv = sorted((max(s, t0), min(e, t1)) for n, s, e, qq in win if qq == q)
+    busy, cur_s, cur_e = 0.0, None, None
+    for a, b in iv:
+        if cur_e is None or a > cur_e:
+            if cur_e is not None:
+                busy += cur_e - cur_s
+            cur_s, cur_e = a, b
+        else:
+            cur_e = max(cur_e, b)
+    if cur_e is not None:
+        busy += cur_e - cur_s
+    names = {}
+    for n, s, e, qq in win:
+        if qq == q:
+            names[short(n)] = names.get(short(n), 0.0) + (min(e, t1) - max(s, t0)) / 1e6
+    top = ", ".join(f"{k} {v:.2f}" for k, v in sorted(names.items(), key=lambda kv: -kv[1])[:6])
+    print(f"| {qi} | {busy / 1e6:.2f} | {busy / (t1 - t0):.2f} | {sum(names.values()):.2f} | {top} |")
+print()
 print("| start (ms) | dur (ms) | queue | kernel |")
 print("|---:|---:|---|---|")
 for n, s, e, q in win:
