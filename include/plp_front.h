@@ -296,7 +296,9 @@ typedef struct plp_match_grid {     /* camera::base grid (camera/base.h:91) used
 
 typedef struct plp_match_args {
     int32_t mode;                   /* plp_match_mode */
-    int32_t B, n_cap, m_cap;
+    int32_t B, n_cap, m_cap;        /* B > 0; n_cap = 0 (a frame without key points / key lines) or m_cap = 0 (no landmarks / queries) is a valid call: nothing can match --
+                                     * the reference's loops do not run -- every out_match slot becomes -1, every out_num 0 (fuse modes: out_query_best -1); input pointers
+                                     * of the empty side may be NULL */
     /* targets (current frame): data::frame::undist_keypts_, descriptors_, stereo_x_right_, and
      * "landmarks_[idx] && landmarks_[idx]->has_observation()" as a byte flag */
     const plp_keypoint* t_kps;      /* B x n_cap (ignored in brute-force mode) */

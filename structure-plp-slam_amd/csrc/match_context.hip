@@ -23,9 +23,20 @@ struct plp_matcher {
 
 namespace {
 
+// An EMPTY side -- a frame without key points / key lines (n_cap = 0) or an empty set of landmarks / queries (m_cap = 0): nothing can match, the reference's loops do not
+// run (projection.cc, robust.cc, fuse.cc: every matcher starts from `unsigned int num_matches = 0` and iterates over the landmarks).  The result is defined without a
+// kernel: every out_match slot -1, every out_num 0 (fuse modes: every out_query_best -1).  Returns 1 when the call is such a call and well-formed, 0 otherwise.
+int empty_side(const plp_match_args* a) {
+    if (!a || a->B <= 0 || a->n_cap < 0 || a->m_cap < 0 || (a->n_cap > 0 && a->m_cap > 0)) return 0;
+    if (a->mode < PLP_MATCH_MODE_LANDMARKS || a->mode > PLP_MATCH_MODE_TRIANGULATION) return 0;
+    const bool fuse = a->mode == PLP_MATCH_MODE_FUSE || a->mode == PLP_MATCH_MODE_FUSE_LINE;
+    if (fuse ? (a->m_cap > 0 && !a->out_query_best) : (!a->out_num || (a->n_cap > 0 && !a->out_match))) return 0;
+    return 1;
+}
+
 plp_status check_args(const plp_match_args* a) {
     if (!a) return set_error(PLP_ERR_INVALID_ARG, "args is NULL");
-    if (a->B <= 0 || a->n_cap <= 0 || a->m_cap <= 0) return set_error(PLP_ERR_INVALID_ARG, "B, n_cap, m_cap must be positive");
+    if (a->B <= 0 || a->n_cap <= 0 || a->m_cap <= 0) return set_error(PLP_ERR_INVALID_ARG, "B must be positive, n_cap and m_cap non-negative (with the outputs an empty side needs)");
     if (a->n_cap > 8192) return set_error(PLP_ERR_UNSUPPORTED, "more than 8192 key points per frame");
     if (!a->t_desc || !a->q_desc) return set_error(PLP_ERR_INVALID_ARG, "descriptor arrays are required");
     if (a->mode != PLP_MATCH_MODE_FUSE && a->mode != PLP_MATCH_MODE_FUSE_LINE && (!a->out_match || !a->out_num)) return set_error(PLP_ERR_INVALID_ARG, "output arrays are required");
@@ -126,6 +137,18 @@ void plp_matcher_destroy(plp_matcher* c) {
 
 plp_status plp_match_device(plp_matcher* c, const plp_match_args* a, void* hip_stream) {
     if (!c) return set_error(PLP_ERR_INVALID_ARG, "ctx is NULL");
+    if (empty_side(a)) {
+        std::lock_guard<std::mutex> lk(c->mu);
+        PLP_HIP(hipSetDevice(c->device));
+        hipStream_t st = (hipStream_t)hip_stream;
+        if (a->mode == PLP_MATCH_MODE_FUSE || a->mode == PLP_MATCH_MODE_FUSE_LINE) {
+            if (a->m_cap > 0) PLP_HIP(hipMemsetAsync(a->out_query_best, 0xFF, (size_t)a->B * a->m_cap * 4, st));
+            return PLP_OK;
+        }
+        if (a->n_cap > 0) PLP_HIP(hipMemsetAsync(a->out_match, 0xFF, (size_t)a->B * a->n_cap * 4, st));
+        PLP_HIP(hipMemsetAsync(a->out_num, 0, (size_t)a->B * 4, st));
+        return PLP_OK;
+    }
     PLP_TRY(check_args(a));
     std::lock_guard<std::mutex> lk(c->mu);
     return run_device(c, a, (hipStream_t)hip_stream);
@@ -133,6 +156,12 @@ plp_status plp_match_device(plp_matcher* c, const plp_match_args* a, void* hip_s
 
 plp_status plp_match_host(plp_matcher* c, const plp_match_args* a) {
     if (!c) return set_error(PLP_ERR_INVALID_ARG, "ctx is NULL");
+    if (empty_side(a)) {
+        if (a->mode == PLP_MATCH_MODE_FUSE || a->mode == PLP_MATCH_MODE_FUSE_LINE) { std::fill_n(a->out_query_best, (size_t)a->B * a->m_cap, -1); return PLP_OK; }
+        std::fill_n(a->out_match, (size_t)a->B * a->n_cap, -1);
+        std::fill_n(a->out_num, (size_t)a->B, 0);
+        return PLP_OK;
+    }
     PLP_TRY(check_args(a));
     if (a->q_desc_stride != 0 && a->q_desc_stride != a->m_cap) return set_error(PLP_ERR_UNSUPPORTED, "q_desc_stride is a device-path option (overlapping query windows of a batched replay)");
     std::lock_guard<std::mutex> lk(c->mu);
