@@ -253,7 +253,7 @@ class orb_extractor:
 
     # ---- extract (orb_extractor.cc:73-160): host image in, key points + descriptors out
     def extract(self, in_image, in_image_mask=None):
-        img = np.ascontiguousarray(in_image, np.uint8)
+        img = _rows_u8(in_image)
         cap = 2 * self.get_max_num_keypoints() + 64
         kps = np.zeros(cap, KP_DTYPE)
         desc = np.zeros((cap, 32), np.uint8)
@@ -261,7 +261,7 @@ class orb_extractor:
         if img.size == 0:
             _check(lib().plp_orb_extract(self._h, None, 0, 0, 0, None, 0, _p(kps), _p(desc), cap, C.byref(n)))
             return kps[:0], desc[:0]
-        mask = None if in_image_mask is None else np.ascontiguousarray(in_image_mask, np.uint8)
+        mask = None if in_image_mask is None else _rows_u8(in_image_mask)
         _check(lib().plp_orb_extract(self._h, _p(img), img.shape[0], img.shape[1], img.strides[0],
                                      _p(mask) if mask is not None else None,
                                      mask.strides[0] if mask is not None else 0, _p(kps), _p(desc), cap, C.byref(n)))
@@ -360,7 +360,7 @@ class LineFeatureTracker:
 
     def extract_LSD_LBD(self, img):
         """returns (frame_keylsd, frame_lbd_descr, keyline_functions) like line_extractor.cc:88-160"""
-        img = np.ascontiguousarray(img, np.uint8)
+        img = _rows_u8(img)
         kl = np.zeros(LINE_CAP, KL_DTYPE)
         lbd = np.zeros((LINE_CAP, 32), np.uint8)
         fn = np.zeros((LINE_CAP, 3), np.float64)
@@ -466,6 +466,15 @@ class match_args_c(C.Structure):
 
 MODE_LANDMARKS, MODE_LAST_FRAME, MODE_BRUTE_FORCE, MODE_LANDMARKS_LINE, MODE_LAST_FRAME_LINE, MODE_BOW, MODE_FUSE, MODE_FUSE_LINE, MODE_TRIANGULATION = 0, 1, 2, 3, 4, 5, 6, 7, 8
 FLAG_NO_CHI2, FLAG_SIGNED_LEVEL, FLAG_UNSIGNED_LEVEL, FLAG_MARK_INVALIDATED = 1, 2, 4, 8
+
+
+def _rows_u8(a):
+    """a 2-D uint8 image as the C ABI takes it: unit stride inside a row, any row step >= the row length -- a view into a larger image (cv::Mat ROI, a cropped numpy
+    slice) is passed AS IT IS, with its step; anything else is copied to a contiguous array first"""
+    a = np.asarray(a)
+    if a.dtype == np.uint8 and a.ndim == 2 and a.size and a.strides[1] == 1 and a.strides[0] >= a.shape[1]:
+        return a
+    return np.ascontiguousarray(a, np.uint8)
 
 
 def make_grid(cols_px, rows_px, grid_cols=64, grid_rows=48, min_x=0.0, min_y=0.0):

@@ -1,0 +1,45 @@
+"""Host images whose row step is larger than their width (a cv::Mat ROI, a cropped view): the C ABI takes (pointer, rows, cols, step) like cv::Mat, and the Python mirror hands a
+view over as it is.  Results must equal those of a contiguous copy -- and the bytes around the view must never be read into the result (the surroundings are noise)."""
+import importlib
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+plp = importlib.import_module("structure-plp-slam_amd")
+synth = importlib.import_module("structure-plp-slam_amd.synth")
+
+
+def embedded(img, rng, top, left, right):
+    """`img` inside a larger array of noise, returned as a VIEW (row step = width + left + right)"""
+    h, w = img.shape
+    big = rng.integers(0, 256, (h + top + 3, w + left + right), dtype=np.uint8)
+    big[top:top + h, left:left + w] = img
+    view = big[top:top + h, left:left + w]
+    assert view.strides == (w + left + right, 1) and not view.flags["C_CONTIGUOUS"]
+    return view
+
+
+@pytest.mark.parametrize("shape, pad", [((480, 640), (5, 7, 9)), ((376, 1241), (1, 3, 0)), ((240, 320), (2, 64, 1)), ((481, 641), (4, 1, 258))])
+def test_orb_and_lines_on_a_view_with_a_row_step(shape, pad):
+    rng = np.random.default_rng(shape[1])
+    img = synth.replay(77 + shape[0], 1, shape[0], shape[1])[0]
+    view = embedded(img, rng, *pad)
+    ex = plp.orb_extractor(1000)
+    kps_c, desc_c = ex.extract(img)
+    kps_v, desc_v = ex.extract(view)
+    assert len(kps_c) > 300 and np.array_equal(kps_c, kps_v) and np.array_equal(desc_c, desc_v)
+    ok, od = O.OrbOracle(1000).extract(img)
+    assert np.array_equal(kps_v, ok) and np.array_equal(desc_v, od)
+    # a mask with its own step
+    mask = np.zeros(shape, np.uint8); mask[shape[0] // 4: 3 * shape[0] // 4, shape[1] // 5: 4 * shape[1] // 5] = 255
+    mview = embedded(mask, rng, pad[2] % 5, pad[0], pad[1])
+    km_c, dm_c = ex.extract(img, mask)
+    km_v, dm_v = ex.extract(view, mview)
+    assert len(km_c) > 50 and np.array_equal(km_c, km_v) and np.array_equal(dm_c, dm_v)
+    lt = plp.LineFeatureTracker()
+    kl_c, lbd_c, fn_c = lt.extract_LSD_LBD(img)
+    kl_v, lbd_v, fn_v = lt.extract_LSD_LBD(view)
+    assert len(kl_c) > 5 and np.array_equal(kl_c, kl_v) and np.array_equal(lbd_c, lbd_v) and np.array_equal(fn_c, fn_v)
