@@ -572,7 +572,8 @@ class matcher:
         n = len(k)
         und = np.zeros(max(n, 1), KP_DTYPE); bear = np.zeros((max(n, 1), 3), np.float64)
         xr = np.zeros(max(n, 1), np.float32); dep = np.zeros(max(n, 1), np.float32)
-        d = np.ascontiguousarray(depth, np.float32) if depth is not None else None
+        d = None if depth is None else (depth if (isinstance(depth, np.ndarray) and depth.dtype == np.float32 and depth.ndim == 2 and depth.size and depth.strides[1] == 4
+                                                and depth.strides[0] >= 4 * depth.shape[1]) else np.ascontiguousarray(depth, np.float32))   # (a view with a row step goes as it is)
         kl = np.ascontiguousarray(keylines, KL_DTYPE) if keylines is not None else None
         nl = len(kl) if kl is not None else 0
         kd = np.ascontiguousarray(kl_depths, np.float32).copy() if kl is not None else None

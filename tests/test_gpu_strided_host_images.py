@@ -43,3 +43,23 @@ def test_orb_and_lines_on_a_view_with_a_row_step(shape, pad):
     kl_c, lbd_c, fn_c = lt.extract_LSD_LBD(img)
     kl_v, lbd_v, fn_v = lt.extract_LSD_LBD(view)
     assert len(kl_c) > 5 and np.array_equal(kl_c, kl_v) and np.array_equal(lbd_c, lbd_v) and np.array_equal(fn_c, fn_v)
+
+
+def test_post_extract_reads_a_depth_view_with_its_row_step():
+    from test_gpu_post_extract import CAMS, cam_struct
+    rng = np.random.default_rng(11)
+    img = synth.replay(3, 1, 480, 640)[0]
+    kps, _ = O.OrbOracle(800).extract(img)
+    depth = rng.uniform(0.3, 8.0, (480, 640)).astype(np.float32)
+    depth[rng.uniform(size=depth.shape) < 0.2] = 0.0
+    big = rng.uniform(-5, 50, (480 + 6, 640 + 37)).astype(np.float32)
+    big[4:484, 21:661] = depth
+    view = big[4:484, 21:661]
+    assert view.strides == (4 * 677, 4)
+    kl = np.zeros(20, O.KL_DTYPE)
+    kl["startPointX"] = rng.uniform(0, 639, 20); kl["startPointY"] = rng.uniform(0, 479, 20); kl["endPointX"] = rng.uniform(0, 639, 20); kl["endPointY"] = rng.uniform(0, 479, 20)
+    pre = np.full((20, 2), -1, np.float32)
+    want = O.post_extract(CAMS["fr1"], kps, depth, kl, pre, pre)
+    got = plp.matcher().post_extract(cam_struct(CAMS["fr1"]), kps, view, kl, pre, pre)
+    for key in want:
+        assert np.array_equal(got[key], want[key]), key
