@@ -171,3 +171,12 @@ def test_extract_equals_committed_reference_vectors(golden_dir):
         assert len(kps) == len(want_k) and np.array_equal(kps, want_k) and np.array_equal(desc, want_d), (name, K)
         n += 1
     assert n == 6
+
+
+@pytest.mark.parametrize("h, w, K", [(1080, 1920, 2000), (2160, 3840, 5000), (480, 4000, 2000), (3000, 600, 1500)])
+def test_large_and_elongated_frames(h, w, K):
+    """full HD, 4K, a panorama strip and a tall strip (the reference takes any size: orb_extractor.cc:73-160): key points and descriptors equal the oracle's"""
+    img = synth.canvas(5 + h, h, w)
+    kps, desc = plp.orb_extractor(K).extract(img)
+    ok, od = O.OrbOracle(K).extract(img)
+    assert len(kps) == len(ok) and len(kps) > K // 2 and np.array_equal(kps, ok) and np.array_equal(desc, od)
