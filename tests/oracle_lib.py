@@ -214,7 +214,7 @@ class OrbOracle:
 
     def extract(self, img, mask=None):
         img = np.ascontiguousarray(img, np.uint8)
-        cap = max(self.max_num_keypts * 2, 16)
+        cap = 2 * self.max_num_keypts + 64      # (a level yields at least the four nodes of its first split, whatever its quota: K = 2 returns 32 key points)
         kps = np.zeros(cap, KP_DTYPE)
         desc = np.zeros((cap, 32), np.uint8)
         if mask is not None:

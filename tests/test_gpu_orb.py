@@ -180,3 +180,17 @@ def test_large_and_elongated_frames(h, w, K):
     kps, desc = plp.orb_extractor(K).extract(img)
     ok, od = O.OrbOracle(K).extract(img)
     assert len(kps) == len(ok) and len(kps) > K // 2 and np.array_equal(kps, ok) and np.array_equal(desc, od)
+
+
+@pytest.mark.parametrize("kw", [dict(max_num_keypts=1), dict(max_num_keypts=2), dict(max_num_keypts=7), dict(max_num_keypts=9), dict(max_num_keypts=50),
+                                dict(max_num_keypts=1000, num_levels=1), dict(max_num_keypts=1000, num_levels=2, scale_factor=2.0), dict(max_num_keypts=1500, num_levels=12, scale_factor=1.1),
+                                dict(max_num_keypts=1000, num_levels=16, scale_factor=1.05), dict(max_num_keypts=1000, ini_fast_thr=5, min_fast_thr=3),
+                                dict(max_num_keypts=1000, ini_fast_thr=100, min_fast_thr=60), dict(max_num_keypts=1000, ini_fast_thr=7, min_fast_thr=7)])
+def test_parameter_corners(kw):
+    """budgets so small that levels get a quota of 0 or 1 (a level still yields the nodes of its first split: K = 2 returns 32 key points, as in the reference), one level,
+    sixteen levels, scale factors 1.05 .. 2.0, thresholds 3 .. 100"""
+    img = synth.replay(99, 1, 480, 640)[0]
+    kps, desc = plp.orb_extractor(**kw).extract(img)
+    okw = dict(kw)
+    ok, od = O.OrbOracle(okw.pop("max_num_keypts"), **okw).extract(img)
+    assert len(kps) == len(ok) and len(kps) >= 16 and np.array_equal(kps, ok) and np.array_equal(desc, od)
