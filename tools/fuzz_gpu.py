@@ -26,6 +26,15 @@ def rand_image(rng, h, w):
     return fr
 
 
+def strided_view(rng, img):
+    """the image inside a larger array of noise, as a view with a row step (cv::Mat ROI)"""
+    h, w = img.shape
+    top, left, right = int(rng.integers(0, 6)), int(rng.integers(0, 70)), int(rng.integers(1, 300))
+    big = rng.integers(0, 256, (h + top + 2, w + left + right), dtype=np.uint8)
+    big[top:top + h, left:left + w] = img
+    return big[top:top + h, left:left + w]
+
+
 def aux_families(rng, seconds):
     import ctypes as C
     import torch
@@ -149,9 +158,10 @@ def main():
         if rng.uniform() < 0.25:
             mask = np.full((h, w), 255, np.uint8); x0 = int(rng.integers(0, w - 20)); mask[:, x0:x0 + int(rng.integers(10, w // 2))] = 0
             if os.environ.get("PLP_FUZZ_NOMASK"): mask = None   # bisection aid: same random sequence, no image masks
+        img_in, mask_in = (strided_view(rng, img), None if mask is None else strided_view(rng, mask)) if n % 5 == 3 else (img, mask)   # one case in five: views with a row step
         try:
             ex = plp.orb_extractor(K, sfac, nl, ini, mn)
-            got = ex.extract(img, mask)
+            got = ex.extract(img_in, mask_in)
         except Exception as e:   # documented kernel limits (quota per level <= 1960, ...): refused loudly, never wrong
             if "limits" not in str(e) and "too small" not in str(e) and "overflow" not in str(e):
                 raise
@@ -171,7 +181,7 @@ def main():
         lt.set_grow_waves((0, 1, 3, 5)[n % 4])          # several waves per frame (automatic / 3 / 5) and one wave per frame: same results
         stable = n % 5 == 4                            # the reference's seed order (std::sort, the default) four times in five, the stable order once
         lt.set_seed_order(plp.SEED_ORDER_STABLE if stable else plp.SEED_ORDER_LIBSTDCXX)
-        kl, lbd, fn = lt.extract_LSD_LBD(img)
+        kl, lbd, fn = lt.extract_LSD_LBD(strided_view(rng, img) if n % 5 == 2 else img)
         o = O.LineOracle(img, stable_order=stable)
         ok = len(kl) == len(o.keylsd) and np.array_equal(lbd, o.lbd) and np.array_equal(kl, o.keylsd) and np.array_equal(fn, o.linefn)
         if not ok:
@@ -185,6 +195,9 @@ def main():
     while time.time() - t0 < share("match"):
         nt, m = int(rng.integers(1, 2500)), int(rng.integers(1, 3000))
         t, q = MC.random_problem(rng, nt, m, n_words=int(rng.choice([0, 0, 3, 20])), stereo=bool(rng.integers(0, 2)))
+        if n % 25 == 24:   # an empty side (no key points / no landmarks): defined result, no kernel
+            if rng.integers(0, 2): nt = 0; t = {k: v[:0] for k, v in t.items()}
+            else: m = 0; q = {k: v[:0] for k, v in q.items()}
         margin, ratio = float(rng.uniform(2, 40)), float(rng.choice([0.6, 0.75, 0.9]))
         # the LDS-size hint never changes a result: none / far too small / a little too small / generous, at random
         t = {**t, "t_count_hint": int(rng.choice([0, max(1, nt // 4), max(1, nt - 1), nt + 100]))}
